@@ -1,0 +1,102 @@
+"""ctypes binding of include/cnm_engine.h (the C ABI of libcnm_engine.so).
+
+There is deliberately no fallback: if the library is missing the import of any
+operator fails loudly -- this package never computes on the CPU and never routes
+through oracle/.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcnm_engine.so")
+
+c_fp = C.c_void_p          # device pointers travel as integers
+c_i, c_f, c_d, c_ll, c_sz = C.c_int, C.c_float, C.c_double, C.c_longlong, C.c_size_t
+
+
+class LayerInfo(C.Structure):
+    _fields_ = [("conv_key", C.c_char_p), ("bn_key", C.c_char_p), ("Cin", c_i), ("Cout", c_i),
+                ("ksize", c_i), ("stride", c_i), ("rot", c_i), ("is_head", c_i)]
+
+
+class LayerWeights(C.Structure):
+    _fields_ = [("w", c_fp), ("b", c_fp)]
+
+
+# name -> (restype, argtypes); mirrors include/cnm_engine.h declaration by declaration
+PROTOTYPES = {
+    "cnm_abi_version": (c_i, []),
+    "cnm_status_string": (C.c_char_p, [c_i]),
+    "cnm_homography_terms_f32": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_fp]),
+    "cnm_idepth_range_host": (c_i, [c_d, C.POINTER(c_d), C.POINTER(c_d)]),
+    "cnm_planesweep_volume_nchw_f32": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_d, c_d, c_fp]),
+    "cnm_planesweep_cat_c4_f32": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_d, c_d, c_fp]),
+    "cnm_packed_conv_floats": (c_sz, [c_i, c_i, c_i]),
+    "cnm_pack_conv_bn_f32": (c_i, [c_fp] * 6 + [c_f, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
+    "cnm_conv2d_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    "cnm_conv2d_cat2_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp,
+                                     c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    "cnm_upsample2x_c4_f32": (c_i, [c_fp, c_i, c_i, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    "cnm_pack_head_f32": (c_i, [c_fp, c_i, c_fp, c_fp]),
+    "cnm_head_sigmoid_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_fp, c_f, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    "cnm_refine_assemble_c4_f32": (c_i, [c_fp, c_fp, c_ll, c_fp, c_i, c_i, c_fp, c_i, c_i, c_fp, c_i, c_i, c_i, c_i, c_fp]),
+    "cnm_nchw_to_c4_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    "cnm_c4_to_nchw_f32": (c_i, [c_fp, c_i, c_i, c_fp, c_i, c_i, c_i, c_i, c_fp]),
+    "cnm_net_num_layers": (c_i, [c_i]),
+    "cnm_net_layer": (c_i, [c_i, c_i, C.POINTER(LayerInfo)]),
+    "cnm_depthnet_workspace_floats": (c_sz, [c_i, c_i, c_i, c_i]),
+    "cnm_depthnet_forward_f32": (c_i, [C.POINTER(LayerWeights), c_f, c_i, c_fp, c_fp, c_fp, c_fp,
+                                       c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_sz, c_i, c_i, c_i, c_i, c_fp]),
+    "cnm_refinenet_workspace_floats": (c_sz, [c_i, c_i, c_i]),
+    "cnm_refinenet_forward_f32": (c_i, [C.POINTER(LayerWeights), c_f, c_fp, c_fp, c_ll, c_fp, c_i, c_i, c_fp, c_i, c_i,
+                                        c_fp, c_fp, c_fp, c_fp, c_sz, c_i, c_i, c_i, c_fp]),
+    "cnm_depth2normal_f32": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    "cnm_intrinsics_inverse_f32": (c_i, [c_fp, c_ll, c_fp, c_i, c_fp]),
+    "cnm_inverse_warp_f32": (c_i, [c_fp] * 6 + [c_i, c_i, c_i, c_i, c_fp]),
+}
+
+NET_DEPTH, NET_REFINE = 0, 1
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """dlopen the engine (after torch, so that both share ONE libamdhip64.so.7)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EngineError(
+            "libcnm_engine.so not found at %s -- build it with `python -m cnmnet_amd.build` "
+            "(there is no CPU fallback in this package)" % LIB_PATH)
+    import torch  # noqa: F401  (loads torch's HIP runtime first; same SONAME as the one we link)
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.restype, fn.argtypes = res, args
+    if lib.cnm_abi_version() != 1:
+        raise EngineError("libcnm_engine.so ABI version %d, expected 1" % lib.cnm_abi_version())
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != 0:
+        raise EngineError("cnm_engine: %s (status %d)" % (load().cnm_status_string(status).decode(), status))
+
+
+def net_layers(net):
+    lib = load()
+    out = []
+    for i in range(lib.cnm_net_num_layers(net)):
+        info = LayerInfo()
+        check(lib.cnm_net_layer(net, i, C.byref(info)))
+        out.append(dict(conv_key=info.conv_key.decode(), bn_key=info.bn_key.decode() if info.bn_key else None,
+                        Cin=info.Cin, Cout=info.Cout, ksize=info.ksize, stride=info.stride, rot=info.rot,
+                        is_head=bool(info.is_head)))
+    return out

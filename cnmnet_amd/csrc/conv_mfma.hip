@@ -1,0 +1,278 @@
+// K2: Conv2d(+folded BatchNorm)(+ReLU) as an fp32 MFMA implicit GEMM on c4 activations.
+//
+// Replaces the nn.Conv2d -> nn.BatchNorm2d -> nn.ReLU chains built by
+// down_conv_layer / conv_layer / up_conv_layer (reference depthnet/depthNet_model.py:19-112)
+// in eval mode.  GEMM view:  D[cout][pixel] = sum_k Wp[cout][k] * X[k][pixel],
+//   k = (ky*ks + kx) * 4*Gin + c,  X[k][pixel] = in[img][c/4][oy*s+ky-p][ox*s+kx-p][c%4] (0 outside).
+// MFMA: v_mfma_f32_32x32x2_f32, A operand = weights (rows = cout), B operand = pixels, so
+// every lane ends up holding 4 consecutive output channels (= one c4 group) of one pixel and
+// consecutive lanes hold consecutive pixels: the epilogue is a coalesced float4 store.
+// Numerics: exact fp32 FMA chains (the MFMA is bitwise an fmaf chain), no reduced precision.
+//
+// Tiling (64-lane wavefronts): block = 4 waves (2x2), block tile TC couts x TP pixels x 16 k,
+// wave tile (TC/2)x(TP/2) built from 32x32 MFMA tiles; LDS double buffered, rows padded to
+// 20 floats so the ds_read_b128 fragment reads are bank-conflict free; global->register
+// prefetch of k-step t+1 overlaps the 32..128 MFMAs of k-step t.
+#include "cnm_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvArgs {
+    const float* in; float* out; const float* w; const float* bias;
+    const float* in2;            // optional second source: channel groups [Gsplit, Gin) (torch.cat without the copy)
+    int Gin2_tot, gin2_0, Gsplit;
+    int N, H, W, Ho, Wo;
+    int Gin_tot, gin0, Gin;
+    int Gout_tot, gout0, Cout;
+    int ks, stride, pad;
+    int nk;          // Kpad / 16
+    int M;           // N*Ho*Wo
+    int relu;
+};
+
+template <int TC, int TP>
+__global__ __launch_bounds__(256) void conv_mfma_f32_kernel(const ConvArgs a) {
+    constexpr int NT = 256, WP = 2;
+    constexpr int CI = TC / 64, PI = TP / 64;          // 32x32 MFMA tiles per wave
+    constexpr int LDK = 20;                            // 16 k + 4 pad floats per LDS row
+    constexpr int A_LOADS = TC * 4 / NT, B_LOADS = TP * 4 / NT;
+    __shared__ __attribute__((aligned(16))) float smem[2 * (TC + TP) * LDK];
+    float* As = smem;                                  // [2][TC][LDK]
+    float* Bs = smem + 2 * TC * LDK;                   // [2][TP][LDK]
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wc = wave / WP, wp = wave % WP;
+    const int tilesC = a.Cout / TC;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int c0 = (tile % tilesC) * TC, m0 = (tile / tilesC) * TP;
+    const int HW = a.H * a.W, HoWo = a.Ho * a.Wo;
+
+    // ---- pixel (B operand) loader state: one output pixel per thread, B_LOADS k-quads
+    const int prow = t % TP;
+    const int m = m0 + prow;
+    const bool mvalid = m < a.M;
+    int iy0, ix0;
+    const float* in_img;
+    const float* in2_img;
+    {
+        const int mm = mvalid ? m : 0;
+        const int img = mm / HoWo, rem = mm - img * HoWo;
+        const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+        iy0 = oy * a.stride - a.pad; ix0 = ox * a.stride - a.pad;
+        in_img = a.in + ((size_t)img * a.Gin_tot + a.gin0) * (size_t)HW * 4;
+        in2_img = a.in2 ? a.in2 + ((long long)img * a.Gin2_tot + a.gin2_0 - a.Gsplit) * (long long)HW * 4 : in_img;
+    }
+    int bg[B_LOADS], bky[B_LOADS], bkx[B_LOADS];
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) {
+        const int kq = t / TP + i * (NT / TP);         // wave-uniform k-quad index within the k-step
+        const int tap = kq / a.Gin;
+        bg[i] = kq - tap * a.Gin; bky[i] = tap / a.ks; bkx[i] = tap - bky[i] * a.ks;
+    }
+    const float* wtile = a.w + (size_t)c0 * 16;        // [nk][Cout][16]
+
+    float4 ra[A_LOADS], rb[B_LOADS];
+    auto load_global = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i)
+            ra[i] = *reinterpret_cast<const float4*>(wtile + (size_t)kt * a.Cout * 16 + (size_t)(t + i * NT) * 4);
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) {
+            const int iy = iy0 + bky[i], ix = ix0 + bkx[i];
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (mvalid && bky[i] < a.ks && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                v = *reinterpret_cast<const float4*>((bg[i] < a.Gsplit ? in_img : in2_img) +
+                                                     ((size_t)bg[i] * HW + (size_t)iy * a.W + ix) * 4);
+            rb[i] = v;
+            bg[i] += 4;                                // advance 16 floats of flat k
+            while (bg[i] >= a.Gin) { bg[i] -= a.Gin; if (++bkx[i] == a.ks) { bkx[i] = 0; ++bky[i]; } }
+        }
+    };
+    auto store_lds = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) {
+            const int f = t + i * NT;
+            *reinterpret_cast<float4*>(As + ((size_t)buf * TC + (f >> 2)) * LDK + (f & 3) * 4) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) {
+            const int q = t / TP + i * (NT / TP);
+            *reinterpret_cast<float4*>(Bs + ((size_t)buf * TP + prow) * LDK + q * 4) = rb[i];
+        }
+    };
+
+    f32x16 acc[CI][PI];
+#pragma unroll
+    for (int i = 0; i < CI; ++i)
+#pragma unroll
+        for (int j = 0; j < PI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_global(0);
+    store_lds(0);
+    __syncthreads();
+
+    const int frow = lane & 31, fk = (lane >> 5) * 4;
+    for (int kt = 0; kt < a.nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < a.nk) load_global(kt + 1);
+        const float* Ab = As + ((size_t)buf * TC + wc * (CI * 32) + frow) * LDK + fk;
+        const float* Bb = Bs + ((size_t)buf * TP + wp * (PI * 32) + frow) * LDK + fk;
+#pragma unroll
+        for (int kg = 0; kg < 2; ++kg) {
+            float4 af[CI], bf[PI];
+#pragma unroll
+            for (int i = 0; i < CI; ++i) af[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDK + kg * 8);
+#pragma unroll
+            for (int j = 0; j < PI; ++j) bf[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDK + kg * 8);
+#pragma unroll
+            for (int i = 0; i < CI; ++i)
+#pragma unroll
+                for (int j = 0; j < PI; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        if (kt + 1 < a.nk) store_lds(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: acc row = cout (r&3)+8*(r>>2)+4*(lane>>5), col = pixel lane&31
+#pragma unroll
+    for (int j = 0; j < PI; ++j) {
+        const int mm = m0 + (wp * PI + j) * 32 + (lane & 31);
+        if (mm >= a.M) continue;
+        const int img = mm / HoWo, pix = mm - img * HoWo;
+#pragma unroll
+        for (int i = 0; i < CI; ++i) {
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int c = c0 + (wc * CI + i) * 32 + 8 * qd + 4 * (lane >> 5);
+                const float4 b = *reinterpret_cast<const float4*>(a.bias + c);
+                float4 v = make_float4(acc[i][j][4 * qd + 0] + b.x, acc[i][j][4 * qd + 1] + b.y,
+                                       acc[i][j][4 * qd + 2] + b.z, acc[i][j][4 * qd + 3] + b.w);
+                if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                *reinterpret_cast<float4*>(a.out + c4_offset(img, a.Gout_tot, a.gout0 + (c >> 2), HoWo, pix)) = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ weight packing
+__global__ void pack_conv_kernel(const float* __restrict__ w, const float* __restrict__ gamma,
+                                 const float* __restrict__ var, float eps, int Cout, int Cin, int ks, int rot,
+                                 int Kpad, float* __restrict__ wp) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)Kpad * Cout) return;
+    const int kk = (int)(idx & 15);
+    const int co = (int)((idx >> 4) % Cout);
+    const int kstep = (int)((idx >> 4) / Cout);
+    const int k = kstep * 16 + kk;
+    const int Cp = 4 * ((Cin + 3) / 4);
+    const int tap = k / Cp, cp = k - tap * Cp;
+    float v = 0.f;
+    if (tap < ks * ks && cp < Cin) {
+        const int ci = (cp + rot) % Cin;
+        double s = 1.0;
+        if (gamma) s = (double)gamma[co] / sqrt((double)var[co] + (double)eps);
+        v = (float)((double)w[((size_t)co * Cin + ci) * ks * ks + tap] * s);
+    }
+    wp[idx] = v;
+}
+
+__global__ void pack_bias_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                 const float* __restrict__ mean, const float* __restrict__ var,
+                                 const float* __restrict__ bias, float eps, int Cout, float* __restrict__ bp) {
+    const int co = blockIdx.x * blockDim.x + threadIdx.x;
+    if (co >= Cout) return;
+    double b = bias ? (double)bias[co] : 0.0;
+    if (gamma) {
+        const double s = (double)gamma[co] / sqrt((double)var[co] + (double)eps);
+        b = (double)beta[co] + (b - (double)mean[co]) * s;
+    }
+    bp[co] = (float)b;
+}
+
+static inline int conv_kpad(int Cin, int ks) { return ((ks * ks * 4 * ((Cin + 3) / 4) + 15) / 16) * 16; }
+
+extern "C" size_t cnm_packed_conv_floats(int Cout, int Cin, int ksize) {
+    if (Cout <= 0 || Cin <= 0 || ksize <= 0) return 0;
+    return (size_t)conv_kpad(Cin, ksize) * (size_t)Cout;
+}
+
+extern "C" int cnm_pack_conv_bn_f32(const float* w_oihw, const float* bn_gamma, const float* bn_beta,
+                                    const float* bn_mean, const float* bn_var, const float* bias, float eps,
+                                    int Cout, int Cin, int ksize, int rot,
+                                    float* w_packed, float* b_packed, void* stream) {
+    CNM_REQUIRE(w_oihw && w_packed && b_packed, CNM_ERR_BAD_ARG);
+    CNM_REQUIRE(Cout > 0 && Cin > 0 && ksize > 0 && (ksize & 1) && rot >= 0 && rot < Cin, CNM_ERR_BAD_ARG);
+    const bool bn = bn_gamma || bn_beta || bn_mean || bn_var;
+    CNM_REQUIRE(!bn || (bn_gamma && bn_beta && bn_mean && bn_var), CNM_ERR_BAD_ARG);
+    const int Kpad = conv_kpad(Cin, ksize);
+    const long long total = (long long)Kpad * Cout;
+    pack_conv_kernel<<<(unsigned)cnm_ceil_div_ll(total, 256), 256, 0, cnm_stream(stream)>>>(
+        w_oihw, bn_gamma, bn_var, eps, Cout, Cin, ksize, rot, Kpad, w_packed);
+    pack_bias_kernel<<<cnm_ceil_div(Cout, 256), 256, 0, cnm_stream(stream)>>>(
+        bn_gamma, bn_beta, bn_mean, bn_var, bias, eps, Cout, b_packed);
+    CNM_LAUNCH_CHECK();
+    return CNM_OK;
+}
+
+template <int TC, int TP>
+static void launch_conv(const ConvArgs& a, hipStream_t s) {
+    const int nblocks = (a.Cout / TC) * cnm_ceil_div(a.M, TP);
+    conv_mfma_f32_kernel<TC, TP><<<nblocks, 256, 0, s>>>(a);
+}
+
+static int conv_dispatch(const float* in, int Gin_total, int gin0, int Gin,
+                         const float* in2, int Gin2_total, int gin2_0, int Gsplit,
+                         float* out, int Gout_total, int gout0, int Cout,
+                         const float* w_packed, const float* b_packed,
+                         int N, int H, int W, int ksize, int stride, int relu, void* stream) {
+    CNM_REQUIRE(in && out && w_packed && b_packed, CNM_ERR_BAD_ARG);
+    CNM_REQUIRE(N > 0 && H > 0 && W > 0 && Gin > 0 && Gsplit > 0 && Gsplit <= Gin, CNM_ERR_BAD_ARG);
+    CNM_REQUIRE(gin0 >= 0 && gin0 + Gsplit <= Gin_total, CNM_ERR_BAD_ARG);
+    CNM_REQUIRE(Gsplit == Gin || (in2 && gin2_0 >= 0 && gin2_0 + (Gin - Gsplit) <= Gin2_total), CNM_ERR_BAD_ARG);
+    CNM_REQUIRE(Cout > 0 && Cout % 64 == 0 && gout0 >= 0 && gout0 + Cout / 4 <= Gout_total, CNM_ERR_BAD_ARG);
+    CNM_REQUIRE((ksize == 3 || ksize == 5 || ksize == 7) && (stride == 1 || stride == 2), CNM_ERR_BAD_ARG);
+    ConvArgs a;
+    a.in = in; a.out = out; a.w = w_packed; a.bias = b_packed;
+    a.in2 = (Gsplit < Gin) ? in2 : nullptr; a.Gin2_tot = Gin2_total; a.gin2_0 = gin2_0; a.Gsplit = Gsplit;
+    a.N = N; a.H = H; a.W = W;
+    a.ks = ksize; a.stride = stride; a.pad = (ksize - 1) / 2;
+    a.Ho = (H + 2 * a.pad - ksize) / stride + 1; a.Wo = (W + 2 * a.pad - ksize) / stride + 1;
+    a.Gin_tot = Gin_total; a.gin0 = gin0; a.Gin = Gin;
+    a.Gout_tot = Gout_total; a.gout0 = gout0; a.Cout = Cout;
+    a.nk = ((ksize * ksize * 4 * Gin + 15) / 16);
+    a.M = N * a.Ho * a.Wo; a.relu = relu;
+    hipStream_t s = cnm_stream(stream);
+    // Tile choice: largest tile that still gives every CU (256) a couple of workgroups.
+    const long long t128 = (long long)(Cout / 128) * cnm_ceil_div(a.M, 128);
+    const long long t64x128 = (long long)(Cout / 64) * cnm_ceil_div(a.M, 128);
+    if (Cout % 128 == 0 && t128 >= 512) launch_conv<128, 128>(a, s);
+    else if (t64x128 >= 512) launch_conv<64, 128>(a, s);
+    else launch_conv<64, 64>(a, s);
+    CNM_LAUNCH_CHECK();
+    return CNM_OK;
+}
+
+extern "C" int cnm_conv2d_c4_f32(const float* in, int Gin_total, int gin0, int Gin,
+                                 float* out, int Gout_total, int gout0, int Cout,
+                                 const float* w_packed, const float* b_packed,
+                                 int N, int H, int W, int ksize, int stride, int relu, void* stream) {
+    return conv_dispatch(in, Gin_total, gin0, Gin, nullptr, 0, 0, Gin, out, Gout_total, gout0, Cout,
+                         w_packed, b_packed, N, H, W, ksize, stride, relu, stream);
+}
+
+extern "C" int cnm_conv2d_cat2_c4_f32(const float* in_a, int Ga_total, int ga0, int Ga,
+                                      const float* in_b, int Gb_total, int gb0, int Gb,
+                                      float* out, int Gout_total, int gout0, int Cout,
+                                      const float* w_packed, const float* b_packed,
+                                      int N, int H, int W, int ksize, int stride, int relu, void* stream) {
+    CNM_REQUIRE(Ga > 0 && Gb > 0, CNM_ERR_BAD_ARG);
+    return conv_dispatch(in_a, Ga_total, ga0, Ga + Gb, in_b, Gb_total, gb0, Ga, out, Gout_total, gout0, Cout,
+                         w_packed, b_packed, N, H, W, ksize, stride, relu, stream);
+}

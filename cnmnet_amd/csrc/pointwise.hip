@@ -1,0 +1,215 @@
+// K3-K5 and boundary layout kernels (all HBM-bound, one float4 per lane, coalesced).
+//   upsample2x   : nn.Upsample(scale_factor=2, bilinear, align_corners=False)  depthNet_model.py:94,105
+//   head         : depth_layer conv3x3 C->1 + bias + sigmoid, * idepth_scale    :82-84,246,251,256,261,351,365
+//                  + F.upsample(disp, 2) nearest written into the consumer's concat slot (:247,252,257)
+//   refine input : cat(id1, id2, |id1-id2|, iconv01+iconv02)                    :332-333
+//   nchw <-> c4  : module-boundary converters
+#include "cnm_common.h"
+
+// ------------------------------------------------------------------ bilinear x2 (c4)
+// src = (dst+0.5)/2 - 0.5 clamped at 0; i0 = floor, i1 = min(i0+1, n-1), lambda = src - i0
+// (torch upsample_bilinear2d, align_corners=False).
+__global__ __launch_bounds__(256) void upsample2x_c4_kernel(const float* __restrict__ in, int Gin_tot, int gin0,
+                                                            float* __restrict__ out, int Gout_tot, int gout0,
+                                                            int N, int G, int H, int W) {
+    const int Wo = 2 * W, Ho = 2 * H;
+    const long long total = (long long)N * G * Ho * Wo;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int ox = (int)(idx % Wo);
+        long long r = idx / Wo;
+        const int oy = (int)(r % Ho); r /= Ho;
+        const int g = (int)(r % G), n = (int)(r / G);
+        const float sy = fmaxf((oy + 0.5f) * 0.5f - 0.5f, 0.f), sx = fmaxf((ox + 0.5f) * 0.5f - 0.5f, 0.f);
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+        const float ly = sy - y0, lx = sx - x0, hy = 1.f - ly, hx = 1.f - lx;
+        const float4* base = reinterpret_cast<const float4*>(in + c4_offset(n, Gin_tot, gin0 + g, H * W, 0));
+        const float4 p00 = base[y0 * W + x0], p01 = base[y0 * W + x1], p10 = base[y1 * W + x0], p11 = base[y1 * W + x1];
+        float4 v;
+        v.x = hy * (hx * p00.x + lx * p01.x) + ly * (hx * p10.x + lx * p11.x);
+        v.y = hy * (hx * p00.y + lx * p01.y) + ly * (hx * p10.y + lx * p11.y);
+        v.z = hy * (hx * p00.z + lx * p01.z) + ly * (hx * p10.z + lx * p11.z);
+        v.w = hy * (hx * p00.w + lx * p01.w) + ly * (hx * p10.w + lx * p11.w);
+        *reinterpret_cast<float4*>(out + c4_offset(n, Gout_tot, gout0 + g, Ho * Wo, oy * Wo + ox)) = v;
+    }
+}
+
+extern "C" int cnm_upsample2x_c4_f32(const float* in, int Gin_total, int gin0,
+                                     float* out, int Gout_total, int gout0,
+                                     int N, int G, int H, int W, void* stream) {
+    CNM_REQUIRE(in && out && N > 0 && G > 0 && H > 0 && W > 0, CNM_ERR_BAD_ARG);
+    CNM_REQUIRE(gin0 >= 0 && gin0 + G <= Gin_total && gout0 >= 0 && gout0 + G <= Gout_total, CNM_ERR_BAD_ARG);
+    const long long total = (long long)N * G * 4 * H * W;
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    upsample2x_c4_kernel<<<blocks, 256, 0, cnm_stream(stream)>>>(in, Gin_total, gin0, out, Gout_total, gout0, N, G, H, W);
+    CNM_LAUNCH_CHECK();
+    return CNM_OK;
+}
+
+// ------------------------------------------------------------------ disparity head
+__global__ void pack_head_kernel(const float* __restrict__ w, int C, float* __restrict__ wh) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // wh[tap][c] <- w[0][c][tap]
+    if (i >= 9 * C) return;
+    const int tap = i / C, c = i - tap * C;
+    wh[i] = w[c * 9 + tap];
+}
+
+extern "C" int cnm_pack_head_f32(const float* w_oihw, int C, float* w_head, void* stream) {
+    CNM_REQUIRE(w_oihw && w_head && C > 0 && C % 4 == 0, CNM_ERR_BAD_ARG);
+    pack_head_kernel<<<cnm_ceil_div(9 * C, 256), 256, 0, cnm_stream(stream)>>>(w_oihw, C, w_head);
+    CNM_LAUNCH_CHECK();
+    return CNM_OK;
+}
+
+// One lane per output pixel; consecutive lanes = consecutive x, so every float4 tap load
+// is coalesced across the wave; the 9*C weights are wave-uniform (scalar loads).
+__global__ __launch_bounds__(256) void head_sigmoid_c4_kernel(const float* __restrict__ in, int Gin_tot, int gin0, int G,
+                                                              const float* __restrict__ wh, const float* __restrict__ bias,
+                                                              float scale, float* __restrict__ disp,
+                                                              float* __restrict__ up_out, int up_Gtot, int up_g,
+                                                              int N, int H, int W) {
+    const int HW = H * W;
+    const long long total = (long long)N * HW;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int n = (int)(idx / HW), pix = (int)(idx - (long long)n * HW);
+    const int y = pix / W, x = pix - y * W;
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    for (int g = 0; g < G; ++g) {
+        const float4* base = reinterpret_cast<const float4*>(in + c4_offset(n, Gin_tot, gin0 + g, HW, 0));
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = y + ky - 1;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = x + kx - 1;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = base[iy * W + ix];
+                const float4 w = *reinterpret_cast<const float4*>(wh + (size_t)(ky * 3 + kx) * (G * 4) + g * 4);
+                acc0 = fmaf(v.x, w.x, acc0); acc1 = fmaf(v.y, w.y, acc1);
+                acc2 = fmaf(v.z, w.z, acc2); acc3 = fmaf(v.w, w.w, acc3);
+            }
+        }
+    }
+    const float s = (acc0 + acc1) + (acc2 + acc3) + bias[0];
+    const float d = scale / (1.f + expf(-s));
+    disp[idx] = d;
+    if (up_out) {
+        const int Wo = 2 * W;
+        float* o = up_out + c4_offset(n, up_Gtot, up_g, 4 * HW, (2 * y) * Wo + 2 * x);
+        const float4 v = make_float4(d, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(o) = v; *reinterpret_cast<float4*>(o + 4) = v;
+        *reinterpret_cast<float4*>(o + (size_t)Wo * 4) = v; *reinterpret_cast<float4*>(o + (size_t)Wo * 4 + 4) = v;
+    }
+}
+
+extern "C" int cnm_head_sigmoid_c4_f32(const float* in, int Gin_total, int gin0, int C,
+                                       const float* w_head, const float* bias, float scale,
+                                       float* disp, float* up_out, int up_Gtotal, int up_g,
+                                       int N, int H, int W, void* stream) {
+    CNM_REQUIRE(in && w_head && bias && disp && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, CNM_ERR_BAD_ARG);
+    CNM_REQUIRE(gin0 >= 0 && gin0 + C / 4 <= Gin_total, CNM_ERR_BAD_ARG);
+    CNM_REQUIRE(!up_out || (up_g >= 0 && up_g < up_Gtotal), CNM_ERR_BAD_ARG);
+    const long long total = (long long)N * H * W;
+    head_sigmoid_c4_kernel<<<(unsigned)cnm_ceil_div_ll(total, 256), 256, 0, cnm_stream(stream)>>>(
+        in, Gin_total, gin0, C / 4, w_head, bias, scale, disp, up_out, up_Gtotal, up_g, N, H, W);
+    CNM_LAUNCH_CHECK();
+    return CNM_OK;
+}
+
+// ------------------------------------------------------------------ refine input assembly
+__global__ __launch_bounds__(256) void refine_assemble_c4_kernel(const float* __restrict__ id1, const float* __restrict__ id2, long long ids,
+                                                                 const float* __restrict__ f1, int G1t, int g1,
+                                                                 const float* __restrict__ f2, int G2t, int g2,
+                                                                 float* __restrict__ x, int N, int G, int HW) {
+    const long long total = (long long)N * (G + 1) * HW;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int pix = (int)(idx % HW);
+        const long long r = idx / HW;
+        const int g = (int)(r % (G + 1)), n = (int)(r / (G + 1));
+        float4 v;
+        if (g < G) {
+            const float4 a = *reinterpret_cast<const float4*>(f1 + c4_offset(n, G1t, g1 + g, HW, pix));
+            const float4 b = *reinterpret_cast<const float4*>(f2 + c4_offset(n, G2t, g2 + g, HW, pix));
+            v = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+        } else {
+            const float a = id1[(size_t)n * ids + pix], b = id2[(size_t)n * ids + pix];
+            v = make_float4(a, b, fabsf(a - b), 0.f);
+        }
+        *reinterpret_cast<float4*>(x + c4_offset(n, G + 1, g, HW, pix)) = v;
+    }
+}
+
+extern "C" int cnm_refine_assemble_c4_f32(const float* idepth01, const float* idepth02, long long idepth_stride,
+                                          const float* f1, int G1_total, int g1,
+                                          const float* f2, int G2_total, int g2,
+                                          float* x, int N, int C, int H, int W, void* stream) {
+    CNM_REQUIRE(idepth01 && idepth02 && f1 && f2 && x && N > 0 && C > 0 && C % 4 == 0 && H > 0 && W > 0, CNM_ERR_BAD_ARG);
+    CNM_REQUIRE(g1 >= 0 && g1 + C / 4 <= G1_total && g2 >= 0 && g2 + C / 4 <= G2_total, CNM_ERR_BAD_ARG);
+    CNM_REQUIRE(idepth_stride >= (long long)H * W, CNM_ERR_BAD_ARG);
+    const long long total = (long long)N * (C / 4 + 1) * H * W;
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    refine_assemble_c4_kernel<<<blocks, 256, 0, cnm_stream(stream)>>>(idepth01, idepth02, idepth_stride, f1, G1_total, g1, f2, G2_total, g2,
+                                                                     x, N, C / 4, H * W);
+    CNM_LAUNCH_CHECK();
+    return CNM_OK;
+}
+
+// ------------------------------------------------------------------ layout converters
+__global__ __launch_bounds__(256) void nchw_to_c4_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                         int Gt, int g0, int N, int C, int HW) {
+    const int G = (C + 3) / 4;
+    const long long total = (long long)N * G * HW;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int pix = (int)(idx % HW);
+        const long long r = idx / HW;
+        const int g = (int)(r % G), n = (int)(r / G);
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = 4 * g + j;
+            v[j] = c < C ? src[((size_t)n * C + c) * HW + pix] : 0.f;
+        }
+        *reinterpret_cast<float4*>(dst + c4_offset(n, Gt, g0 + g, HW, pix)) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void c4_to_nchw_kernel(const float* __restrict__ src, int Gt, int g0,
+                                                         float* __restrict__ dst, int N, int C, int HW) {
+    const int G = (C + 3) / 4;
+    const long long total = (long long)N * G * HW;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int pix = (int)(idx % HW);
+        const long long r = idx / HW;
+        const int g = (int)(r % G), n = (int)(r / G);
+        const float4 v = *reinterpret_cast<const float4*>(src + c4_offset(n, Gt, g0 + g, HW, pix));
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = 4 * g + j;
+            if (c < C) dst[((size_t)n * C + c) * HW + pix] = vv[j];
+        }
+    }
+}
+
+extern "C" int cnm_nchw_to_c4_f32(const float* nchw, float* c4, int G_total, int g0, int N, int C, int H, int W, void* stream) {
+    CNM_REQUIRE(nchw && c4 && N > 0 && C > 0 && H > 0 && W > 0 && g0 >= 0 && g0 + (C + 3) / 4 <= G_total, CNM_ERR_BAD_ARG);
+    const long long total = (long long)N * ((C + 3) / 4) * H * W;
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    nchw_to_c4_kernel<<<blocks, 256, 0, cnm_stream(stream)>>>(nchw, c4, G_total, g0, N, C, H * W);
+    CNM_LAUNCH_CHECK();
+    return CNM_OK;
+}
+
+extern "C" int cnm_c4_to_nchw_f32(const float* c4, int G_total, int g0, float* nchw, int N, int C, int H, int W, void* stream) {
+    CNM_REQUIRE(nchw && c4 && N > 0 && C > 0 && H > 0 && W > 0 && g0 >= 0 && g0 + (C + 3) / 4 <= G_total, CNM_ERR_BAD_ARG);
+    const long long total = (long long)N * ((C + 3) / 4) * H * W;
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    c4_to_nchw_kernel<<<blocks, 256, 0, cnm_stream(stream)>>>(c4, G_total, g0, nchw, N, C, H * W);
+    CNM_LAUNCH_CHECK();
+    return CNM_OK;
+}

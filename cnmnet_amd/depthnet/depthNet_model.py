@@ -1,0 +1,235 @@
+"""depthNet / DepthRefineNet with the reference's interface, executed by the HIP engine.
+
+Interface parity (reference depthnet/depthNet_model.py):
+  depthNet(idepth_scale=3).forward(left_image, right_image, left_cam, right_cam)
+      -> ([disp1, disp2, disp3, disp4], iconv1)                                   (:127, :226-263)
+  DepthRefineNet(base_channels_num=32, idepth_scale=2).forward(
+      idepth01, idepth02, iconv01, iconv02, ReturnVolume=False)
+      -> (disp_refined, prob_map[, iconv1_depth])                                 (:273, :331-370)
+state_dict keys and shapes are identical to the reference's (nn.Sequential indices
+.0/.1/.3/.4 in down blocks, .1/.2 in up blocks, .0 in heads), so its checkpoints load.
+
+The torch modules below only CONTAIN parameters.  forward() folds eval-mode BatchNorm
+into packed weights on the device (cached until a parameter changes) and makes ONE call
+into the C ABI (cnm_depthnet_forward_f32 / cnm_refinenet_forward_f32).  There is no CPU
+or eager-torch fallback.
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from .. import _lib, ops
+
+
+class _Slot(nn.Identity):
+    """Parameter-free placeholder keeping nn.Sequential indices aligned with the reference
+    (ReLU / Upsample / Sigmoid positions); the engine fuses or runs those ops itself."""
+
+
+def _seq(*mods):
+    return nn.Sequential(*mods)
+
+
+def _cbr(cin, cout, k, stride=1):
+    return [nn.Conv2d(cin, cout, k, stride=stride, padding=(k - 1) // 2, bias=False), nn.BatchNorm2d(cout), _Slot()]
+
+
+def _down(cin, cout, k):
+    return _seq(*(_cbr(cin, cout, k, 1) + _cbr(cout, cout, k, 2)))
+
+
+def _same(cin, cout, k):
+    return _seq(*_cbr(cin, cout, k))
+
+
+def _up(cin, cout, k):
+    return _seq(_Slot(), *_cbr(cin, cout, k))
+
+
+def _head(cin):
+    return _seq(nn.Conv2d(cin, 1, 3, padding=1), _Slot())
+
+
+def _init_like_reference(module):
+    """Kaiming-normal fan_out convs, BN (1,0), zero head bias (reference :165-182)."""
+    for m in module.modules():
+        if isinstance(m, nn.Conv2d):
+            nn.init.kaiming_normal_(m.weight, mode="fan_out")
+            if m.bias is not None:
+                nn.init.zeros_(m.bias)
+        elif isinstance(m, nn.BatchNorm2d):
+            nn.init.ones_(m.weight)
+            nn.init.zeros_(m.bias)
+
+
+class _EngineNet(nn.Module):
+    _NET = None
+
+    def _engine_init(self):
+        self._layers = None        # engine layer table (resolved lazily: needs the library)
+        self._packed = None        # [(w, b)] device tensors, one per engine layer
+        self._packed_key = None
+        self._weights_arr = None
+        self._ws = {}
+
+    # -- parameter lookup by the engine's state_dict-style keys ("conv1.0", "upconv3_depth.2")
+    def _sub(self, key):
+        name, idx = key.split(".")
+        return getattr(self, name)[int(idx)]
+
+    def _param_key(self):
+        ts = list(self.parameters()) + list(self.buffers())
+        return (str(ts[0].device), tuple(t._version for t in ts), tuple(t.data_ptr() for t in ts[:4]))
+
+    def _first_cin(self):
+        return None
+
+    def _ensure_packed(self):
+        key = self._param_key()
+        if self._packed is not None and key == self._packed_key:
+            return
+        if self._layers is None:
+            self._layers = _lib.net_layers(self._NET)
+        packed = []
+        for i, L in enumerate(self._layers):
+            conv = self._sub(L["conv_key"])
+            w = conv.weight.detach()
+            if L["is_head"]:
+                packed.append((ops.pack_head(w), conv.bias.detach().contiguous()))
+            else:
+                bn = self._sub(L["bn_key"])
+                packed.append(ops.pack_conv(w, (bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var),
+                                            rot=L["rot"], eps=bn.eps))
+        arr = (_lib.LayerWeights * len(packed))()
+        for i, (w, b) in enumerate(packed):
+            arr[i].w, arr[i].b = w.data_ptr(), b.data_ptr()
+        self._packed, self._weights_arr, self._packed_key = packed, arr, key
+
+    def _workspace(self, device, nfloats):
+        ws = self._ws.get(str(device))
+        if ws is None or ws.numel() < nfloats:
+            self._ws = {str(device): torch.empty(nfloats, device=device, dtype=torch.float32)}
+            ws = self._ws[str(device)]
+        return ws
+
+    def _require_eval_on_gpu(self, *tensors):
+        if self.training:
+            raise NotImplementedError(
+                "%s: only eval-mode (running-stat BatchNorm) forward is built in this round; "
+                "call .eval() -- there is no eager fallback" % type(self).__name__)
+        ops._dev(*tensors)
+        p = next(self.parameters())
+        if not p.is_cuda or p.device != tensors[0].device:
+            raise _lib.EngineError("module parameters are on %s but inputs are on %s" % (p.device, tensors[0].device))
+
+
+class depthNet(_EngineNet):
+    """Plane-sweep cost volume + hourglass regression (reference depthNet_model.py:124-263).
+
+    ``planes`` (default 64, what the reference hard-codes at :194,:199,:208 and in conv1's 67
+    input channels) is exposed for the 32/96-plane configurations; state_dict compatibility
+    with reference checkpoints holds at planes=64."""
+    _NET = _lib.NET_DEPTH
+
+    def __init__(self, idepth_scale=3, planes=64):
+        super().__init__()
+        if planes % 4 or not (4 <= planes <= 128):
+            raise ValueError("planes must be a multiple of 4 in [4,128]")
+        self.idepth_scale, self.planes = idepth_scale, planes
+        self.conv1 = _down(3 + planes, 128, 7)
+        self.conv2 = _down(128, 256, 5)
+        self.conv3 = _down(256, 512, 3)
+        self.conv4 = _down(512, 512, 3)
+        self.conv5 = _down(512, 512, 3)
+        self.upconv5, self.iconv5 = _up(512, 512, 3), _same(1024, 512, 3)
+        self.upconv4, self.iconv4, self.disp4 = _up(512, 512, 3), _same(1024, 512, 3), _head(512)
+        self.upconv3, self.iconv3, self.disp3 = _up(512, 256, 3), _same(513, 256, 3), _head(256)
+        self.upconv2, self.iconv2, self.disp2 = _up(256, 128, 3), _same(257, 128, 3), _head(128)
+        self.upconv1, self.iconv1, self.disp1 = _up(128, 64, 3), _same(65, 64, 3), _head(64)
+        _init_like_reference(self)
+        self._engine_init()
+
+    def forward_pairs(self, ref, src, ref_cam, src_cam):
+        """ref [B,3,H,W], src [B,S,3,H,W], ref_cam [B,2,4,4], src_cam [B,S,2,4,4]
+        -> ([disp1..4] each [B*S,1,h,w], iconv1 as c4 [B*S,16,H,W,4]); pair p = b*S + s.
+        One engine call for all pairs; the reference replicates the ref image instead
+        (eval.py:635-657)."""
+        ops.idepth_range(self.idepth_scale)
+        self._require_eval_on_gpu(ref, src, ref_cam, src_cam)
+        B, S, _, H, W = src.shape
+        if H % 32 or W % 32:
+            raise ValueError("image height and width must be multiples of 32 (got %dx%d)" % (H, W))
+        self._ensure_packed()
+        lib, P, dev = _lib.load(), B * S, ref.device
+        ref, src, ref_cam, src_cam = (t.contiguous() for t in (ref, src, ref_cam, src_cam))
+        disp = [torch.empty(P, 1, H >> i, W >> i, device=dev, dtype=torch.float32) for i in range(4)]
+        feat = torch.empty(P, 16, H, W, 4, device=dev, dtype=torch.float32)
+        n = lib.cnm_depthnet_workspace_floats(P, H, W, self.planes)
+        ws = self._workspace(dev, n)
+        with torch.cuda.device(dev):
+            _lib.check(lib.cnm_depthnet_forward_f32(
+                self._weights_arr, float(self.idepth_scale), self.planes,
+                ref.data_ptr(), src.data_ptr(), ref_cam.data_ptr(), src_cam.data_ptr(),
+                disp[0].data_ptr(), disp[1].data_ptr(), disp[2].data_ptr(), disp[3].data_ptr(), feat.data_ptr(),
+                ws.data_ptr(), ws.numel(), B, S, H, W, torch.cuda.current_stream().cuda_stream))
+        return disp, feat
+
+    def forward(self, left_image, right_image, left_cam, right_cam):
+        disp, feat_c4 = self.forward_pairs(left_image, right_image.unsqueeze(1), left_cam, right_cam.unsqueeze(1))
+        iconv1 = ops.c4_to_nchw(feat_c4, 64)
+        iconv1._cnm_c4 = feat_c4           # lets DepthRefineNet skip the NCHW->c4 round trip
+        return disp, iconv1
+
+
+class DepthRefineNet(_EngineNet):
+    """Occlusion-aware two-view fusion (reference depthNet_model.py:268-370)."""
+    _NET = _lib.NET_REFINE
+
+    def __init__(self, base_channels_num=32, idepth_scale=2):
+        super().__init__()
+        self.base_channels_num, self.idepth_scale = base_channels_num, idepth_scale
+        self.conv1, self.conv2, self.conv3 = _down(67, 128, 3), _down(128, 256, 3), _down(256, 512, 3)
+        for tag in ("depth", "prob"):
+            setattr(self, "upconv3_" + tag, _up(512, 256, 3))
+            setattr(self, "iconv3_" + tag, _same(512, 256, 3))
+            setattr(self, "upconv2_" + tag, _up(256, 128, 3))
+            setattr(self, "iconv2_" + tag, _same(256, 128, 3))
+            setattr(self, "upconv1_" + tag, _up(128, 64, 3))
+            setattr(self, "iconv1_" + tag, _same(64, 64, 3))
+            setattr(self, "disp_refine" if tag == "depth" else "prob", _head(64))
+        _init_like_reference(self)
+        self._engine_init()
+
+    def forward_c4(self, idepth01, idepth02, idepth_stride, f1, G1_total, g1, f2, G2_total, g2, N, H, W, return_volume=False):
+        """Raw-view entry used by the frame pipeline (no layout conversion)."""
+        self._ensure_packed()
+        lib, dev = _lib.load(), idepth01.device
+        disp = torch.empty(N, 1, H, W, device=dev, dtype=torch.float32)
+        prob = torch.empty_like(disp)
+        vol = torch.empty(N, 16, H, W, 4, device=dev, dtype=torch.float32) if return_volume else None
+        ws = self._workspace(dev, lib.cnm_refinenet_workspace_floats(N, H, W))
+        with torch.cuda.device(dev):
+            _lib.check(lib.cnm_refinenet_forward_f32(
+                self._weights_arr, float(self.idepth_scale), idepth01.data_ptr(), idepth02.data_ptr(), idepth_stride,
+                f1.data_ptr(), G1_total, g1, f2.data_ptr(), G2_total, g2,
+                disp.data_ptr(), prob.data_ptr(), vol.data_ptr() if vol is not None else 0,
+                ws.data_ptr(), ws.numel(), N, H, W, torch.cuda.current_stream().cuda_stream))
+        return disp, prob, vol
+
+    def forward(self, idepth01, idepth02, iconv01, iconv02, ReturnVolume=False):
+        self._require_eval_on_gpu(idepth01, idepth02, iconv01, iconv02)
+        N, _, H, W = idepth01.shape
+        if H % 8 or W % 8:
+            raise ValueError("image height and width must be multiples of 8 (got %dx%d)" % (H, W))
+        f1 = getattr(iconv01, "_cnm_c4", None)
+        f2 = getattr(iconv02, "_cnm_c4", None)
+        f1 = f1 if f1 is not None else ops.nchw_to_c4(iconv01)
+        f2 = f2 if f2 is not None else ops.nchw_to_c4(iconv02)
+        disp, prob, vol = self.forward_c4(idepth01.contiguous(), idepth02.contiguous(), H * W,
+                                          f1, 16, 0, f2, 16, 0, N, H, W, ReturnVolume)
+        if not ReturnVolume:
+            return disp, prob
+        iconv1_depth = ops.c4_to_nchw(vol, 64)
+        iconv1_depth._cnm_c4 = vol
+        return disp, prob, iconv1_depth

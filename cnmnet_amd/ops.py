@@ -1,0 +1,199 @@
+"""Operator-level Python API over the C ABI: torch tensors in, torch tensors out.
+
+torch is used for device memory and streams only; every computation is a call into
+libcnm_engine.so on the tensor's device and the current torch stream.  CPU tensors
+are rejected (there is no CPU path in this package -- the CPU restatement lives in
+oracle/ and is test infrastructure).
+"""
+import torch
+
+from . import _lib
+
+IDEPTH_RANGE = {2.0: (0.02, 2.0), 3.0: (0.1, 3.0)}   # reference depthnet/depthNet_model.py:186-191
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.EngineError("cnmnet_amd operators run on the GPU only; got a %s tensor" % t.device)
+        if t.dtype != torch.float32:
+            raise _lib.EngineError("cnmnet_amd operators take float32 tensors; got %s" % t.dtype)
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def idepth_range(idepth_scale):
+    try:
+        return IDEPTH_RANGE[float(idepth_scale)]
+    except KeyError:
+        raise ValueError("idepth_scale must be 2.0 or 3.0 (got %r); the reference leaves the sweep range "
+                         "undefined otherwise (depthNet_model.py:186-191)" % (idepth_scale,))
+
+
+def homography_terms(ref_cam, src_cam):
+    """ref_cam [B,2,4,4], src_cam [B,S,2,4,4] -> hmkt [B*S,12]   (depth_util.py:24-56)"""
+    _dev(ref_cam, src_cam)
+    ref_cam, src_cam = _c(ref_cam), _c(src_cam)
+    B, S = src_cam.shape[0], src_cam.shape[1]
+    out = torch.empty(B * S, 12, device=ref_cam.device, dtype=torch.float32)
+    with torch.cuda.device(ref_cam.device):
+        _lib.check(_lib.load().cnm_homography_terms_f32(_p(ref_cam), _p(src_cam), _p(out), B, S, _stream()))
+    return out
+
+
+def plane_sweep_volume(left, right, left_cam, right_cam, idepth_scale=3.0, planes=64):
+    """Drop-in for depthNet.getVolume fed by process_camera_parameters
+    (depthNet_model.py:185-224): left/right [B,3,H,W], cams [B,2,4,4] -> [B,planes,H,W]."""
+    _dev(left, right, left_cam, right_cam)
+    lo, hi = idepth_range(idepth_scale)
+    left, right = _c(left), _c(right)
+    B, _, H, W = left.shape
+    hmkt = homography_terms(left_cam, right_cam.unsqueeze(1))
+    vol = torch.empty(B, planes, H, W, device=left.device, dtype=torch.float32)
+    with torch.cuda.device(left.device):
+        _lib.check(_lib.load().cnm_planesweep_volume_nchw_f32(_p(left), _p(right), _p(hmkt), _p(vol),
+                                                              B, 1, H, W, planes, lo, hi, _stream()))
+    return vol
+
+
+def plane_sweep_cat_c4(ref, src, hmkt, idepth_scale=3.0, planes=64):
+    """ref [B,3,H,W], src [B,S,3,H,W], hmkt [B*S,12] -> c4 conv input [B*S, planes/4+1, H, W, 4]."""
+    _dev(ref, src, hmkt)
+    lo, hi = idepth_range(idepth_scale)
+    ref, src = _c(ref), _c(src)
+    B, S, _, H, W = src.shape
+    x = torch.empty(B * S, planes // 4 + 1, H, W, 4, device=ref.device, dtype=torch.float32)
+    with torch.cuda.device(ref.device):
+        _lib.check(_lib.load().cnm_planesweep_cat_c4_f32(_p(ref), _p(src), _p(hmkt), _p(x), B, S, H, W, planes, lo, hi, _stream()))
+    return x
+
+
+def nchw_to_c4(x):
+    _dev(x)
+    x = _c(x)
+    N, Cc, H, W = x.shape
+    G = (Cc + 3) // 4
+    out = torch.empty(N, G, H, W, 4, device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().cnm_nchw_to_c4_f32(_p(x), _p(out), G, 0, N, Cc, H, W, _stream()))
+    return out
+
+
+def c4_to_nchw(x, channels=None):
+    _dev(x)
+    N, G, H, W, _ = x.shape
+    Cc = channels or 4 * G
+    out = torch.empty(N, Cc, H, W, device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().cnm_c4_to_nchw_f32(_p(_c(x)), G, 0, _p(out), N, Cc, H, W, _stream()))
+    return out
+
+
+def pack_conv(weight, bn=None, bias=None, rot=0, eps=1e-5):
+    """weight [Cout,Cin,k,k]; bn = (gamma, beta, mean, var) or None -> (w_packed, b_packed)."""
+    _dev(weight, bias, *(bn or ()))
+    lib = _lib.load()
+    Cout, Cin, k, _ = weight.shape
+    wp = torch.empty(lib.cnm_packed_conv_floats(Cout, Cin, k), device=weight.device, dtype=torch.float32)
+    bp = torch.empty(Cout, device=weight.device, dtype=torch.float32)
+    g, b, m, v = [_c(t) for t in bn] if bn else (None, None, None, None)
+    with torch.cuda.device(weight.device):
+        _lib.check(lib.cnm_pack_conv_bn_f32(_p(_c(weight)), _p(g), _p(b), _p(m), _p(v), _p(bias), eps,
+                                            Cout, Cin, k, rot, _p(wp), _p(bp), _stream()))
+    return wp, bp
+
+
+def pack_head(weight):
+    _dev(weight)
+    Cc = weight.shape[1]
+    wh = torch.empty(9 * Cc, device=weight.device, dtype=torch.float32)
+    with torch.cuda.device(weight.device):
+        _lib.check(_lib.load().cnm_pack_head_f32(_p(_c(weight)), Cc, _p(wh), _stream()))
+    return wh
+
+
+def conv2d_c4(x, w_packed, b_packed, Cout, ksize, stride=1, relu=True, x2=None):
+    """x [N,G,H,W,4] (optionally concatenated with x2 along channels) -> [N,Cout/4,Ho,Wo,4]."""
+    _dev(x, w_packed, b_packed, x2)
+    N, G, H, W, _ = x.shape
+    pad = (ksize - 1) // 2
+    Ho, Wo = (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1
+    out = torch.empty(N, Cout // 4, Ho, Wo, 4, device=x.device, dtype=torch.float32)
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        if x2 is None:
+            _lib.check(lib.cnm_conv2d_c4_f32(_p(x), G, 0, G, _p(out), Cout // 4, 0, Cout, _p(w_packed), _p(b_packed),
+                                             N, H, W, ksize, stride, int(relu), _stream()))
+        else:
+            G2 = x2.shape[1]
+            _lib.check(lib.cnm_conv2d_cat2_c4_f32(_p(x), G, 0, G, _p(x2), G2, 0, G2, _p(out), Cout // 4, 0, Cout,
+                                                  _p(w_packed), _p(b_packed), N, H, W, ksize, stride, int(relu), _stream()))
+    return out
+
+
+def upsample2x_c4(x):
+    _dev(x)
+    N, G, H, W, _ = x.shape
+    out = torch.empty(N, G, 2 * H, 2 * W, 4, device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().cnm_upsample2x_c4_f32(_p(x), G, 0, _p(out), G, 0, N, G, H, W, _stream()))
+    return out
+
+
+def head_sigmoid_c4(x, w_head, bias, scale, up_out=None, up_group=0):
+    _dev(x, w_head, bias, up_out)
+    N, G, H, W, _ = x.shape
+    disp = torch.empty(N, 1, H, W, device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().cnm_head_sigmoid_c4_f32(_p(x), G, 0, 4 * G, _p(w_head), _p(bias), float(scale), _p(disp),
+                                                       _p(up_out), up_out.shape[1] if up_out is not None else 0, up_group,
+                                                       N, H, W, _stream()))
+    return disp
+
+
+def depth2normal(depth, intrinsic_inv, k_size=9, input_is_idepth=False):
+    """depth [B,H,W], K^-1 [B,3,3] -> (normal [B,3,H,W], points [B,3,H,W])   (depth_util.py:149-203)"""
+    _dev(depth, intrinsic_inv)
+    depth, intrinsic_inv = _c(depth), _c(intrinsic_inv)
+    B, H, W = depth.shape
+    normal = torch.empty(B, 3, H, W, device=depth.device, dtype=torch.float32)
+    points = torch.empty_like(normal)
+    with torch.cuda.device(depth.device):
+        _lib.check(_lib.load().cnm_depth2normal_f32(_p(depth), _p(intrinsic_inv), _p(normal), _p(points),
+                                                    B, H, W, k_size, int(input_is_idepth), _stream()))
+    return normal, points
+
+
+def intrinsics_inverse(cam):
+    """cam [B,2,4,4] (any batch stride) -> K^-1 [B,3,3]   (train.py:201-202, eval.py:271)"""
+    _dev(cam)
+    if cam.stride()[-3:] != (16, 4, 1):
+        cam = cam.contiguous()
+    B = cam.shape[0]
+    out = torch.empty(B, 3, 3, device=cam.device, dtype=torch.float32)
+    with torch.cuda.device(cam.device):
+        _lib.check(_lib.load().cnm_intrinsics_inverse_f32(_p(cam), cam.stride(0) if B > 1 else 32, _p(out), B, _stream()))
+    return out
+
+
+def inverse_warp(feat, depth, pose, intrinsics, intrinsics_inv):
+    _dev(feat, depth, pose, intrinsics, intrinsics_inv)
+    feat, depth, pose, intrinsics, intrinsics_inv = map(_c, (feat, depth, pose, intrinsics, intrinsics_inv))
+    B, Cc, H, W = feat.shape
+    out = torch.empty_like(feat)
+    with torch.cuda.device(feat.device):
+        _lib.check(_lib.load().cnm_inverse_warp_f32(_p(feat), _p(depth), _p(pose), _p(intrinsics), _p(intrinsics_inv),
+                                                    _p(out), B, Cc, H, W, _stream()))
+    return out

@@ -1,0 +1,39 @@
+"""One 'frame' of the headline metric as a single GPU pipeline.
+
+frame = 1 reference view + S source views (reference eval.py:440-455 for S=2, :635-663 for
+S=4, :885-929 for S=6): depthNet over the S (ref,src) pairs, DepthRefineNet on the two
+sides, depth = 1/idepth, Depth2normal.  Everything stays in the engine's c4 layout between
+the nets: the pair axis of the depthNet output [B*S,16,H,W,4] is re-read as [B, S*16, H, W, 4]
+so the two refine inputs are plain channel-group views -- no copies, no layout conversion.
+"""
+import torch
+
+from . import ops
+
+
+class FramePipeline(torch.nn.Module):
+    def __init__(self, depth_net, refine_net, k_size=9, normals=True):
+        super().__init__()
+        self.depth_net, self.refine_net, self.k_size, self.normals = depth_net, refine_net, k_size, normals
+
+    @torch.no_grad()
+    def forward(self, images, cams):
+        """images [B,1+S,3,H,W] (index 0 = reference), cams [B,1+S,2,4,4]
+        -> dict(disp, prob, disp_pairs[, normal, points])."""
+        B, V, _, H, W = images.shape
+        S = V - 1
+        if S != 2:
+            raise NotImplementedError("S=%d sources: the averaged 4/6-source fusion (eval.py:659-663, :920-929) "
+                                      "is not built yet; use S=2" % S)
+        ref, src = images[:, 0], images[:, 1:]
+        disp_pairs, feat = self.depth_net.forward_pairs(ref, src, cams[:, 0], cams[:, 1:])
+        d1 = disp_pairs[0]                                   # [B*S,1,H,W], pair p = b*S + s
+        HW = H * W
+        flat = d1.view(-1)
+        id1, id2 = flat, flat[HW:]                           # side s of image b starts at (b*S+s)*HW
+        disp, prob, _ = self.refine_net.forward_c4(id1, id2, S * HW, feat, S * 16, 0, feat, S * 16, 16, B, H, W)
+        out = {"disp": disp, "prob": prob, "disp_pairs": disp_pairs, "disp_a": d1[0::S], "disp_b": d1[1::S]}
+        if self.normals:
+            k_inv = ops.intrinsics_inverse(cams[:, 0])
+            out["normal"], out["points"] = ops.depth2normal(disp.view(B, H, W), k_inv, self.k_size, input_is_idepth=True)
+        return out

@@ -1,0 +1,200 @@
+/*
+ * cnm_engine.h -- C ABI of the MI355X (gfx950) CNMNet depth engine.
+ *
+ * Drop-in boundary for ONE hot path of xxlong0/CNMNet: plane-sweep warp + L1 cost
+ * volume, the encoder/decoder inverse-depth regression, the two-view fusion net,
+ * depth->normal and the depth-based inverse warp.  The reference has no FFI of its
+ * own (it is pure Python on torch ops); each entry point below names the reference
+ * function (file:line under the reference checkout) whose arithmetic it replaces.
+ * The Python shim in cnmnet_amd/ binds these with ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is
+ *     enqueued on it, nothing synchronises, nothing allocates;
+ *   - the caller owns every buffer, including workspaces (sizes via *_floats());
+ *   - return value: CNM_OK (0) or a negative cnm_status; never throws;
+ *   - re-entrant: no process-global mutable state (contrast the reference's module
+ *     global pixel_coords, depthnet/inverse_warp.py:5).
+ *
+ * Activation layout inside the engine ("c4"): [N][G][H][W][4] floats, channel
+ * c = 4*g + j, G = ceil(C/4), padded channels are zero.  A c4 view is described by
+ * (base pointer, G_total = groups per image in the underlying buffer, g0 = first
+ * group of the view), which lets producers write straight into channel slices of a
+ * consumer's concatenated input (torch.cat at depthNet_model.py:233,242,245,250,255,260
+ * is never materialised as a copy).
+ */
+#ifndef CNM_ENGINE_H
+#define CNM_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CNM_ABI_VERSION 1
+
+typedef enum cnm_status {
+    CNM_OK = 0,
+    CNM_ERR_BAD_ARG = -1,       /* null pointer, non-positive size, unsupported parameter */
+    CNM_ERR_BAD_SHAPE = -2,     /* H/W not a multiple of 32 for the nets (reference: torch.cat fails) */
+    CNM_ERR_BAD_SCALE = -3,     /* idepth_scale not 2.0 or 3.0 (reference: UnboundLocalError, depthNet_model.py:186-191) */
+    CNM_ERR_LAUNCH = -4,        /* hipGetLastError() != hipSuccess after a launch */
+    CNM_ERR_WORKSPACE = -5      /* workspace smaller than *_workspace_floats() */
+} cnm_status;
+
+int cnm_abi_version(void);
+const char* cnm_status_string(int status);
+
+/* ---------------------------------------------------------------- geometry prep
+ * Replaces get_pixel_coordinates + process_camera_parameters
+ * (depthnet/depth_util.py:13-56): per (ref,src) pair the 3x3 homography factor
+ * Hm = K_r R K_l^-1 and KT = K_r T, 12 floats; the [B,3,H*W] KRKiUV tensor of
+ * depth_util.py:43 is never materialised.
+ * ref_cam [B,2,4,4], src_cam [B,S,2,4,4] -> hmkt [B*S,12] (row-major Hm, then KT). */
+int cnm_homography_terms_f32(const float* ref_cam, const float* src_cam, float* hmkt,
+                             int B, int S, void* stream);
+
+/* Inverse-depth sweep range for a given idepth_scale (depthNet_model.py:186-191).
+ * Host-side helper, returns CNM_ERR_BAD_SCALE for anything but 2.0 / 3.0. */
+int cnm_idepth_range_host(double idepth_scale, double* idepth_min, double* idepth_max);
+
+/* ---------------------------------------------------------------- plane sweep (K1)
+ * Replaces depthNet.getVolume (depthnet/depthNet_model.py:185-224):
+ *   cost[p,d,y,x] = sum_c | bilinear_zero(src[p,c], u'-0.5, v'-0.5) - ref[b,c,y,x] |
+ *   (u',v') = (t0,t1)/(t2+1e-6),  t = Hm (x,y,1)^T z_d + KT,
+ *   z_d = 1/(idepth_min + d (idepth_max-idepth_min)/(D-1)),  p = b*S + s.
+ * ref [B,3,H,W], src [B,S,3,H,W] (NCHW fp32), hmkt [B*S,12].
+ * _nchw : volume [B*S,D,H,W]            -- the drop-in for getVolume's return value.
+ * _c4   : x [B*S][G][H][W][4], G = D/4+1 -- groups 0..D/4-1 = cost planes, last group =
+ *         (ref r,g,b,0): the concatenated conv1 input of depthNet_model.py:233 with the
+ *         three image channels rotated to the end.  D must be a multiple of 4. */
+int cnm_planesweep_volume_nchw_f32(const float* ref, const float* src, const float* hmkt, float* volume,
+                                   int B, int S, int H, int W, int D,
+                                   double idepth_min, double idepth_max, void* stream);
+int cnm_planesweep_cat_c4_f32(const float* ref, const float* src, const float* hmkt, float* x,
+                              int B, int S, int H, int W, int D,
+                              double idepth_min, double idepth_max, void* stream);
+
+/* ---------------------------------------------------------------- conv stack (K2-K5)
+ * Weight packing.  Folds eval-mode BatchNorm (depthNet_model.py:19-79, eps/affine per
+ * torch defaults) into the convolution and re-tiles OIHW weights for the MFMA kernel:
+ *   w_packed [Kpad/16][Cout][16], k = (ky*ks+kx)*4*Gin + cpacked, cpacked = (ci+Cin-rot)%Cin
+ *   b_packed [Cout] = beta - mean*gamma/sqrt(var+eps)   (or `bias`, or 0).
+ * bn_* may be NULL (no BN); bias may be NULL.  Gin = ceil(Cin/4).
+ * cnm_packed_conv_floats gives the size of w_packed. */
+size_t cnm_packed_conv_floats(int Cout, int Cin, int ksize);
+int cnm_pack_conv_bn_f32(const float* w_oihw, const float* bn_gamma, const float* bn_beta,
+                         const float* bn_mean, const float* bn_var, const float* bias, float eps,
+                         int Cout, int Cin, int ksize, int rot,
+                         float* w_packed, float* b_packed, void* stream);
+
+/* Conv2d(k, stride, pad=(k-1)/2, bias folded) + optional ReLU on c4 views, fp32 MFMA
+ * implicit GEMM (v_mfma_f32_32x32x2_f32).  Cout % 64 == 0.  in: N x (Gin groups) x H x W. */
+int cnm_conv2d_c4_f32(const float* in, int Gin_total, int gin0, int Gin,
+                      float* out, int Gout_total, int gout0, int Cout,
+                      const float* w_packed, const float* b_packed,
+                      int N, int H, int W, int ksize, int stride, int relu, void* stream);
+
+/* Same, reading torch.cat((a, b), 1) without materialising it: channel groups [0,Ga) come
+ * from view a, [Ga,Ga+Gb) from view b (used where one skip tensor feeds two decoders,
+ * depthNet_model.py:343,346 and :357,360). */
+int cnm_conv2d_cat2_c4_f32(const float* in_a, int Ga_total, int ga0, int Ga,
+                           const float* in_b, int Gb_total, int gb0, int Gb,
+                           float* out, int Gout_total, int gout0, int Cout,
+                           const float* w_packed, const float* b_packed,
+                           int N, int H, int W, int ksize, int stride, int relu, void* stream);
+
+/* nn.Upsample(scale_factor=2, mode='bilinear') with align_corners=False
+ * (depthNet_model.py:94,105) on a c4 view: [N,G,H,W,4] -> [N,G,2H,2W,4]. */
+int cnm_upsample2x_c4_f32(const float* in, int Gin_total, int gin0,
+                          float* out, int Gout_total, int gout0,
+                          int N, int G, int H, int W, void* stream);
+
+/* depth_layer + scale (depthNet_model.py:82-84,246,251,256,261,351,365):
+ *   disp[n,y,x] = scale * sigmoid(conv3x3(in)[n,y,x] + bias);  w_head [9][C] (tap-major).
+ * If up_out != NULL also writes F.upsample(disp, 2) (nearest, :247,252,257) as the c4
+ * group `up_g` of the [N,up_Gtotal,2H,2W,4] buffer: (value,0,0,0). */
+int cnm_pack_head_f32(const float* w_oihw, int C, float* w_head, void* stream);
+int cnm_head_sigmoid_c4_f32(const float* in, int Gin_total, int gin0, int C,
+                            const float* w_head, const float* bias, float scale,
+                            float* disp, float* up_out, int up_Gtotal, int up_g,
+                            int N, int H, int W, void* stream);
+
+/* DepthRefineNet input assembly (depthNet_model.py:332-333), channels rotated so the
+ * 64 feature channels come first: x = [iconv01+iconv02 (C), id1, id2, |id1-id2|, 0].
+ * idepth0x: image n starts at idepth0x + n*idepth_stride floats (H*W when contiguous;
+ * 2*H*W when the two sides are interleaved pairs of one depthnet call). */
+int cnm_refine_assemble_c4_f32(const float* idepth01, const float* idepth02, long long idepth_stride,
+                               const float* f1, int G1_total, int g1,
+                               const float* f2, int G2_total, int g2,
+                               float* x, int N, int C, int H, int W, void* stream);
+
+/* Layout converters at the module boundary (NCHW torch tensors <-> c4 views). */
+int cnm_nchw_to_c4_f32(const float* nchw, float* c4, int G_total, int g0, int N, int C, int H, int W, void* stream);
+int cnm_c4_to_nchw_f32(const float* c4, int G_total, int g0, float* nchw, int N, int C, int H, int W, void* stream);
+
+/* ---------------------------------------------------------------- whole networks
+ * Layer tables: the engine's own description of the two nets (names follow the
+ * reference's state_dict prefixes, e.g. "conv1.0"/"conv1.1" = conv / its BN). */
+typedef struct cnm_layer_info {
+    const char* conv_key;   /* state_dict prefix of the Conv2d, e.g. "upconv5.1" */
+    const char* bn_key;     /* state_dict prefix of its BatchNorm2d, NULL for heads */
+    int Cin, Cout, ksize, stride;
+    int rot;                /* input-channel rotation used when packing (0 or 3) */
+    int is_head;            /* 1: depth_layer (Cout=1, bias, sigmoid) */
+} cnm_layer_info;
+
+#define CNM_NET_DEPTH 0
+#define CNM_NET_REFINE 1
+int cnm_net_num_layers(int net);
+int cnm_net_layer(int net, int index, cnm_layer_info* info);   /* D=64 table */
+
+typedef struct cnm_layer_weights { const float* w; const float* b; } cnm_layer_weights;
+
+/* depthNet.forward (depthNet_model.py:226-263) for P = B*S (ref,src) pairs.
+ * weights[i] = packed tensors of layer i of the CNM_NET_DEPTH table (conv1.0 packed with
+ * Cin = 3+D).  Outputs: disp1..4 [P,1,H/2^i,W/2^i], iconv1 as c4 [P,16,H,W,4].
+ * ws: workspace of cnm_depthnet_workspace_floats(P,H,W,D) floats. */
+size_t cnm_depthnet_workspace_floats(int P, int H, int W, int D);
+int cnm_depthnet_forward_f32(const cnm_layer_weights* weights, float idepth_scale, int D,
+                             const float* ref, const float* src, const float* ref_cam, const float* src_cam,
+                             float* disp1, float* disp2, float* disp3, float* disp4, float* iconv1_c4,
+                             float* ws, size_t ws_floats, int B, int S, int H, int W, void* stream);
+
+/* DepthRefineNet.forward (depthNet_model.py:331-370).  iconv01/02 are c4 views
+ * (base, G_total, g0) with 64 channels.  Outputs disp_refined, prob_map [N,1,H,W];
+ * iconv1_depth_c4 [N,16,H,W,4] may be NULL (ReturnVolume=False). */
+size_t cnm_refinenet_workspace_floats(int N, int H, int W);
+int cnm_refinenet_forward_f32(const cnm_layer_weights* weights, float idepth_scale,
+                              const float* idepth01, const float* idepth02, long long idepth_stride,
+                              const float* iconv01, int G1_total, int g1,
+                              const float* iconv02, int G2_total, int g2,
+                              float* disp_refined, float* prob_map, float* iconv1_depth_c4,
+                              float* ws, size_t ws_floats, int N, int H, int W, void* stream);
+
+/* ---------------------------------------------------------------- depth -> normal (K6)
+ * Replaces Depth2normal.forward without the plane branch (depth_util.py:149-203):
+ * depth [B,H,W], K_inv [B,3,3] -> normal [B,3,H,W], points [B,3,H,W]. k odd, 1..15.
+ * input_is_idepth != 0: `depth` holds inverse depth and z = 1/idepth is taken on load
+ * (the reference's call sites do this in torch first: eval.py:452, train.py:185-186). */
+int cnm_depth2normal_f32(const float* depth, const float* K_inv, float* normal, float* points,
+                         int B, int H, int W, int ksize, int input_is_idepth, void* stream);
+
+/* K^-1 of the intrinsics stored in a camera tensor (cam[:,1,:3,:3].inverse(), train.py:201-202,
+ * eval.py:271): cam [B,2,4,4] with cam_stride floats between images -> K_inv [B,3,3]. */
+int cnm_intrinsics_inverse_f32(const float* cam, long long cam_stride, float* K_inv, int B, void* stream);
+
+/* ---------------------------------------------------------------- inverse warp (K7)
+ * Replaces inverse_warp / pixel2cam / cam2pixel (depthnet/inverse_warp.py:27-118),
+ * padding_mode='zeros'.  feat [B,C,H,W], depth [B,H,W], pose [B,3,4], K,K_inv [B,3,3]. */
+int cnm_inverse_warp_f32(const float* feat, const float* depth, const float* pose,
+                         const float* K, const float* K_inv, float* out,
+                         int B, int C, int H, int W, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CNM_ENGINE_H */

@@ -156,7 +156,7 @@ class DepthRefineNetCPU(nn.Module):
             setattr(self, "iconv2_" + tag, _same(256, 128, 3))
             setattr(self, "upconv1_" + tag, _up(128, 64, 3))
             setattr(self, "iconv1_" + tag, _same(64, 64, 3))
-        self.disp_refine, self.prob = _head(64), _head(64)
+            setattr(self, "disp_refine" if tag == "depth" else "prob", _head(64))   # :296, :308
         _init(self)
 
     def _decode(self, tag, c1, c2, c3):
