@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Headline benchmark: frames/s of the CNMNet depth hot path on MI355X.
+
+A "frame" (BASELINE.json) = 1 reference + 2 source views at 256x192 with 64 depth planes =
+2 x depthNet.forward + 1 x DepthRefineNet.forward + Depth2normal(k=9)
+(reference eval.py:440-455).  A "step" = one pass of that pipeline over one batch of 8
+frames per GPU (BASELINE config[1]: "1 ref + 2 src, 256x192, 64 planes, batch=8"), inputs
+resident in HBM.  N GPUs = N independent shards (weak scaling, no data-path collective).
+
+    python bench.py [--gpus N --steps K --warmup W]          # N>1: launched by torch.distributed.run
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline           dominant kernel (fp32-MFMA implicit-GEMM conv): achieved TFLOP/s vs 157.3 dense fp32 MFMA
+  roofline_planesweep  fused warp + cost-volume kernel: algorithmic GB/s vs 8 TB/s HBM
+  cpu_baseline       the oracle's reference-arrangement torch-CPU graph on this box's host cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np   # noqa: E402
+import torch         # noqa: E402
+
+H, W, PLANES, SRC, KSIZE = 192, 256, 64, 2, 9
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_32x32x2_f32)
+DEPTH_LEVEL = [0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 4, 4, 3, 3, 2, 2, 1, 1, 0, 0]      # input resolution level per conv layer
+REFINE_LEVEL = [0, 0, 1, 1, 2, 2, 2, 2, 1, 1, 0, 0, 2, 2, 1, 1, 0, 0]
+
+
+def load_weights(module, seed):
+    from cnmnet_amd import synthetic as syn
+    shapes = {k: tuple(v.shape) for k, v in module.state_dict().items()}
+    w = syn.state_dict_like(shapes, seed=seed, randomize_bn=False)
+    module.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in w.items()})
+    return module.eval()
+
+
+def event_ms(fn, iters, warm=2):
+    """Average duration of fn() measured with HIP events on the current (= launch) stream."""
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def conv_tile(cout, m):
+    """Mirror of the tile heuristic in cnmnet_amd/csrc/conv_mfma.hip (conv_dispatch)."""
+    if cout % 128 == 0 and (cout // 128) * -(-m // 128) >= 512:
+        return "conv_mfma_f32_kernel<128,128>"
+    if (cout // 64) * -(-m // 128) >= 512:
+        return "conv_mfma_f32_kernel<64,128>"
+    return "conv_mfma_f32_kernel<64,64>"
+
+
+def kernel_rooflines(dev, frames):
+    """Per-kernel HIP-event timing of the dominant kernels at exactly the shapes of the timed
+    region: every conv layer of both nets (grouped by kernel instance) and the plane sweep."""
+    from cnmnet_amd import _lib, ops, synthetic as syn
+    per_kernel = {}
+    for net, n_img, levels in ((_lib.NET_DEPTH, frames * SRC, DEPTH_LEVEL), (_lib.NET_REFINE, frames, REFINE_LEVEL)):
+        layers = [L for L in _lib.net_layers(net) if not L["is_head"]]
+        for L, lv in zip(layers, levels):
+            cin = 3 + PLANES if (net == _lib.NET_DEPTH and L["conv_key"] == "conv1.0") else L["Cin"]
+            h, w = H >> lv, W >> lv
+            x = torch.randn(n_img, (cin + 3) // 4, h, w, 4, device=dev)
+            wp, bp = ops.pack_conv(torch.randn(L["Cout"], cin, L["ksize"], L["ksize"], device=dev) * 0.02)
+            ms = event_ms(lambda: ops.conv2d_c4(x, wp, bp, L["Cout"], L["ksize"], L["stride"], True), iters=3, warm=1)
+            ho, wo = h // L["stride"], w // L["stride"]
+            flop = 2.0 * L["Cout"] * cin * L["ksize"] ** 2 * ho * wo * n_img
+            k = per_kernel.setdefault(conv_tile(L["Cout"], n_img * ho * wo), [0.0, 0.0, 0])
+            k[0] += flop; k[1] += ms; k[2] += 1
+            del x, wp, bp
+    name, (flop, ms, launches) = max(per_kernel.items(), key=lambda kv: kv[1][1])
+    conv = {"kernel": name, "bound": "mfma", "achieved": flop / ms / 1e9, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+            "frac": flop / ms / 1e9 / MFMA_F32_PEAK_TF, "traffic": None, "launches_per_step": launches,
+            "avg_launch_ms": ms / launches,
+            "all_conv": {"achieved": sum(v[0] for v in per_kernel.values()) / sum(v[1] for v in per_kernel.values()) / 1e9,
+                         "ms_per_step": sum(v[1] for v in per_kernel.values())}}
+    img, cams = syn.frames(frames, SRC, H, W, seed=99)
+    img, cams = torch.from_numpy(img).to(dev), torch.from_numpy(cams).to(dev)
+    ref, src = img[:, 0].contiguous(), img[:, 1:].contiguous()
+    hmkt = ops.homography_terms(cams[:, 0], cams[:, 1:])
+    ms = event_ms(lambda: ops.plane_sweep_cat_c4(ref, src, hmkt, 3.0, PLANES), iters=50, warm=5)
+    # algorithmic bytes per launch (cat-emit variant): per pair read ref 3HW*4 + read src 3HW*4
+    # + write (D+3)HW*4; ref counted once per frame because one launch covers both sources of a frame
+    pairs = frames * SRC
+    byts = frames * 3 * H * W * 4 + pairs * 3 * H * W * 4 + pairs * (PLANES + 3) * H * W * 4
+    sweep = {"kernel": "planesweep_kernel<1>", "bound": "hbm", "achieved": byts / ms / 1e6, "peak": HBM_PEAK_GBS,
+             "unit": "GB/s", "frac": byts / ms / 1e6 / HBM_PEAK_GBS, "traffic": None,
+             "algorithmic_bytes_per_launch": byts, "avg_launch_ms": ms}
+    return conv, sweep
+
+
+def host_cpu_quota():
+    """CPUs this process may actually use: min(affinity, cgroup v2 cpu.max quota)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(budget_s=20.0):
+    """The oracle's torch-CPU reference-arrangement graph (bit-identical to the imported reference,
+    tests/test_oracle_vs_reference.py) timed on this box's host cores: kind = "port".  Thread count:
+    the faster of {cgroup CPU quota, half of it} (oversubscribing the quota is several times slower)."""
+    from cnmnet_amd import synthetic as syn
+    from oracle import ref_arrangement as ra
+    quota = host_cpu_quota()
+    dn, rn = load_weights(ra.DepthNetCPU(3.0, PLANES), 1), load_weights(ra.DepthRefineNetCPU(32, 3.0), 2)
+    img, cams = syn.frames(1, SRC, H, W, seed=1234)
+    T = torch.from_numpy
+    args = (T(img[:, 0]), T(img[:, 1]), T(img[:, 2]), T(cams[:, 0]), T(cams[:, 1]), T(cams[:, 2]))
+
+    def one():
+        t = time.perf_counter(); ra.frame_forward(dn, rn, *args, k_size=KSIZE); return time.perf_counter() - t
+
+    best = None
+    for threads in sorted({quota, max(1, quota // 2)}):
+        torch.set_num_threads(threads)
+        one()                                            # warm-up (allocator, oneDNN primitives)
+        dt = one()
+        if best is None or dt < best[1]:
+            best = (threads, dt)
+    threads, dt = best
+    torch.set_num_threads(threads)
+    n = int(max(2, min(20, budget_s / max(dt, 1e-3))))
+    dt = sum(one() for _ in range(n)) / n
+    return {"value": 1.0 / dt, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": "%d frames (1 ref + 2 src, 256x192, 64 planes, batch 1) after warm-up; torch %s CPU ops in the "
+                      "reference's arrangement, %d threads (host CPU quota %d of %d logical CPUs)"
+                      % (n, torch.__version__, threads, quota, os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames-per-gpu", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
+        a.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the engine has no CPU path)"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from cnmnet_amd import synthetic as syn
+    from cnmnet_amd.depthnet import depthNet, DepthRefineNet
+    from cnmnet_amd.pipeline import FramePipeline
+    pipe = FramePipeline(load_weights(depthNet(3.0, PLANES), 1).to(dev), load_weights(DepthRefineNet(32, 3.0), 2).to(dev),
+                         k_size=KSIZE, normals=True)
+    B = a.frames_per_gpu
+    img, cams = syn.frames(B, SRC, H, W, seed=1234 + rank)       # each rank its own shard of frames
+    img, cams = torch.from_numpy(img).to(dev), torch.from_numpy(cams).to(dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        out = pipe(img, cams)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = pipe(img, cams)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    assert bool(torch.isfinite(out["disp"]).all()) and bool(torch.isfinite(out["normal"]).all())
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    line = None
+    if rank == 0:
+        frames = world * B * a.steps
+        line = {"metric": "frames/sec (ref+2src, 256x192, 64 planes)", "value": frames / elapsed, "unit": "frames/s",
+                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "CNMNet eval frame: 2x depthNet + DepthRefineNet + Depth2normal(k=9), 1 ref + 2 src, "
+                                       "256x192, 64 planes, batch=%d frames per GPU (BASELINE configs[1])" % B,
+                           "frames_per_gpu": B, "sharding": "independent frame shards per GPU, no collective"}}
+        if not a.no_roofline:
+            line["roofline"], line["roofline_planesweep"] = kernel_rooflines(dev, B)
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+            line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if line is not None:
+        print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()

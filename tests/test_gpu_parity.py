@@ -105,8 +105,10 @@ def test_planesweep_full_size_identity_known_answer(dev, ops):
     srcf = src.reshape(B * S, 3, H, W)
     box = F.avg_pool2d(F.pad(srcf, (1, 0, 1, 0)), 2, stride=1)
     want = (box - ref.repeat_interleave(S, 0)).abs().sum(1, keepdim=True)
-    assert float((vol - want).abs().max()) < 2e-4
-    assert float((vol - vol[:, :1]).abs().max()) < 2e-4            # all planes agree
+    # u' = x z/(z + 1e-6) (depthNet_model.py:211-212): the 1e-6 shifts the sample by x*1e-6/z px,
+    # 2.5e-5 px on the far plane (z = 10) and 7.7e-4 px on the near one (z = 1/3)
+    assert float((vol[:, :1] - want).abs().max()) < 5e-4
+    assert float((vol - want).abs().max()) < 1e-2
 
 
 # ------------------------------------------------------------------ conv stack pieces
@@ -217,7 +219,7 @@ def test_error_behaviour(dev):
     with pytest.raises(NotImplementedError):
         net.train()(x[:, :, :32], x[:, :, :32], cam, cam)
     with pytest.raises(AssertionError, match="wrong size for pose"):
-        inverse_warp(x, x[:, 0], torch.zeros(1, 6, device=dev), cam[:, 1, :3, :3], cam[:, 1, :3, :3])
+        inverse_warp(x, x[:, 0], torch.zeros(1, 4, 4, device=dev), cam[:, 1, :3, :3], cam[:, 1, :3, :3])
 
 
 # ------------------------------------------------------------------ K6 / K7
