@@ -91,7 +91,8 @@ def kernel_rooflines(dev, frames):
     img, cams = torch.from_numpy(img).to(dev), torch.from_numpy(cams).to(dev)
     ref, src = img[:, 0].contiguous(), img[:, 1:].contiguous()
     hmkt = ops.homography_terms(cams[:, 0], cams[:, 1:])
-    ms = event_ms(lambda: ops.plane_sweep_cat_c4(ref, src, hmkt, 3.0, PLANES), iters=50, warm=5)
+    ws = torch.empty(_lib.load().cnm_planesweep_workspace_floats(frames, SRC, H, W), device=dev)
+    ms = event_ms(lambda: ops.plane_sweep_cat_c4(ref, src, hmkt, 3.0, PLANES, ws=ws), iters=50, warm=5)
     # algorithmic bytes per launch (cat-emit variant): per pair read ref 3HW*4 + read src 3HW*4
     # + write (D+3)HW*4; ref counted once per frame because one launch covers both sources of a frame
     pairs = frames * SRC

@@ -29,8 +29,9 @@ PROTOTYPES = {
     "cnm_status_string": (C.c_char_p, [c_i]),
     "cnm_homography_terms_f32": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_fp]),
     "cnm_idepth_range_host": (c_i, [c_d, C.POINTER(c_d), C.POINTER(c_d)]),
-    "cnm_planesweep_volume_nchw_f32": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_d, c_d, c_fp]),
-    "cnm_planesweep_cat_c4_f32": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_d, c_d, c_fp]),
+    "cnm_planesweep_workspace_floats": (c_sz, [c_i, c_i, c_i, c_i]),
+    "cnm_planesweep_volume_nchw_f32": (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_sz, c_i, c_i, c_i, c_i, c_i, c_d, c_d, c_fp]),
+    "cnm_planesweep_cat_c4_f32": (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_sz, c_i, c_i, c_i, c_i, c_i, c_d, c_d, c_fp]),
     "cnm_packed_conv_floats": (c_sz, [c_i, c_i, c_i]),
     "cnm_pack_conv_bn_f32": (c_i, [c_fp] * 6 + [c_f, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
     "cnm_conv2d_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),

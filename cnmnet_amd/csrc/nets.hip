@@ -74,13 +74,14 @@ struct Carver {
 };
 
 struct DepthBufs {
-    float *hmkt, *X0, *A1, *CAT2, *A2, *CAT3, *A3, *CAT4, *A4, *CAT5, *A5, *C5, *U5, *I5, *U4, *I4, *U3, *I3, *U2, *I2, *U1, *CAT1;
+    float *hmkt, *TEX, *X0, *A1, *CAT2, *A2, *CAT3, *A3, *CAT4, *A4, *CAT5, *A5, *C5, *U5, *I5, *U4, *I4, *U3, *I3, *U2, *I2, *U1, *CAT1;
 };
 
 static size_t carve_depth(float* ws, int P, int H, int W, int D, DepthBufs* b) {
     Carver c{ws, 0};
     const size_t q = (size_t)P * H * W * 4;     // floats of one channel group at full resolution
     b->hmkt = c.take((size_t)P * 12);
+    b->TEX = c.take((size_t)P * (H + 4) * (W + 4) * 4);
     b->X0 = c.take(q * (D / 4 + 1));
     b->A1 = c.take(q * 32);        b->U1 = c.take(q * 32);       b->CAT1 = c.take(q * 17);
     b->CAT2 = c.take(q / 4 * 65);  b->A2 = c.take(q / 4 * 64);   b->U2 = c.take(q / 4 * 64);   b->I2 = c.take(q / 4 * 32);
@@ -119,7 +120,7 @@ extern "C" int cnm_depthnet_forward_f32(const cnm_layer_weights* wt, float idept
     CNM_TRY(cnm_conv2d_c4_f32(in, Gt, g0, Gin, out, Gto, go0, Cout, wt[L].w, wt[L].b, P, HH, WW, kDepthLayers[L].ksize, kDepthLayers[L].stride, 1, s))
     // geometry + cost volume                                                   depthNet_model.py:228-233
     CNM_TRY(cnm_homography_terms_f32(ref_cam, src_cam, b.hmkt, B, S, s));
-    CNM_TRY(cnm_planesweep_cat_c4_f32(ref, src, b.hmkt, b.X0, B, S, H, W, D, idmin, idmax, s));
+    CNM_TRY(cnm_planesweep_cat_c4_f32(ref, src, b.hmkt, b.X0, b.TEX, (size_t)P * (H + 4) * (W + 4) * 4, B, S, H, W, D, idmin, idmax, s));
     // encoder                                                                  :235-239
     CONV(D_CONV1_0, b.X0, G0, 0, G0, b.A1, 32, 0, 128, H, W);
     CONV(D_CONV1_3, b.A1, 32, 0, 32, b.CAT2, 65, 32, 128, H, W);           // conv1 -> skip slot of iconv2

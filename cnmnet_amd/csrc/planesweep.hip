@@ -6,29 +6,50 @@
 // K1 replaces depthNet.getVolume (reference depthnet/depthNet_model.py:185-224), i.e.
 //    64 x ~12 ATen launches per pair, with ONE launch over all pairs, planes and pixels.
 //
-// K1 mapping (gfx950, 64-lane waves): workgroup = 4 waves = 64x4 pixel tile, one lane per
-// reference pixel, all D planes walked by that lane; the (u,v,1) homography product and the
-// reference RGB stay in registers for the whole sweep.  Planes are taken in groups of 8:
-// for a group the workgroup computes the bounding box of the tile's footprint in the source
-// image (projective map => extremes at the 4 tile corners x 2 end planes), stages that box
-// into LDS as interleaved (r,g,b,0) float4 texels with a 2-texel zero border where it leaves
-// the image, and every bilinear tap becomes one ds_read_b128 -- no per-corner bounds tests.
-// Double-buffered staging => one barrier per group.  If a footprint does not fit (extreme
-// geometry, points behind the source camera) the group falls back to bounds-checked global
-// gathers with identical arithmetic.  Output leaves the registers as coalesced stores:
-// float4 (4 planes of one pixel) in the c4 layout, or one float per plane for NCHW.
+// K1 = two launches on the caller's stream:
+//  (a) texture pre-pass: every source image is re-laid once as an interleaved (r,g,b,0) float4
+//      texture with a 2-texel zero border, [(H+4) x (W+4)] per pair (1.4 MB/pair of extra traffic
+//      against 14.3 MB/pair of algorithmic traffic; it stays in L2 / Infinity Cache).
+//  (b) sweep (gfx950, 64-lane waves): workgroup = 4 waves = SWEEP_TW x SWEEP_TH pixel tile, one
+//      lane per reference pixel, all D planes walked by that lane; the (u,v,1) homography product
+//      and the reference RGB stay in registers for the whole sweep.  Planes are taken in groups of
+//      SWEEP_PG: for a group the workgroup computes the bounding box of the tile's footprint in the
+//      source image (projective map => extremes at the 4 tile corners x 2 end planes) and copies
+//      that box of texels straight into LDS with global_load_lds_dwordx4 (LDS-DMA: no VGPRs, no
+//      ds_write, no bounds tests thanks to the zero border).  Every bilinear tap is then one
+//      ds_read_b128 and the interpolation runs on packed fp32 pairs.  The box of group g+1 is in
+//      flight while group g is computed (double buffer, one barrier per group).  If a footprint
+//      does not fit the LDS box (extreme geometry, points behind the source camera) the group falls
+//      back to bounds-checked global gathers with the same arithmetic.  Output leaves the registers
+//      as coalesced stores: float4 (4 planes of one pixel) in the c4 layout, one float per plane
+//      for NCHW.
 // HBM-bound by design: algorithmic bytes per pair = 3HW*4 (ref) + 3HW*4 (src) + D*HW*4 (volume)
 // (+ 4HW*4 for the ref group when emitting the concatenated conv input).
 #include "cnm_common.h"
 
 #define CNM_MAX_PLANES 128
-#define SWEEP_TW 64
-#define SWEEP_TH 4
-#define SWEEP_PG 8            // planes per staging group
-#define SWEEP_CAP 1024        // texels per LDS staging buffer (16 KB)
+#ifndef SWEEP_TW
+#define SWEEP_TW 64           // tile width  (pixels, lanes along x)
+#endif
+#ifndef SWEEP_TH
+#define SWEEP_TH 8            // tile height (SWEEP_TW * SWEEP_TH = 256 or 512 threads)
+#endif
+#ifndef SWEEP_PG
+#define SWEEP_PG 16           // planes per staging group (multiple of 4)
+#endif
+#ifndef SWEEP_CAP
+#define SWEEP_CAP 1664        // texels per LDS staging buffer (26 KB; two buffers)
+#endif
+#ifndef SWEEP_BATCH
+#define SWEEP_BATCH 2         // planes per software-pipeline stage
+#endif
+#ifndef SWEEP_DEFER
+#define SWEEP_DEFER 0         // 1: issue the stores of group g after the barrier of group g+1
+#endif
+#define SWEEP_NT (SWEEP_TW * SWEEP_TH)   // threads per workgroup (256 or 512)
 
 struct SweepArgs {
-    const float* ref; const float* src; const float* hmkt; float* out;
+    const float* ref; const float* src; const float* hmkt; float* out; const float4* tex;
     int B, S, H, W, D;
     float z[CNM_MAX_PLANES];
 };
@@ -105,29 +126,160 @@ __device__ static inline float fast_div(float n, float d) {       // v_rcp_f32 +
     return n * r;
 }
 
-template <int LAYOUT>   // 0: volume [P,D,H,W]   1: c4 [P,D/4+1,H,W,4]
-__global__ __launch_bounds__(256) void planesweep_kernel(const SweepArgs a) {
-    __shared__ float4 tex[2][SWEEP_CAP];
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// (a) texture pre-pass: src [P,3,H,W] planar -> tex [P][H+4][W+4] float4 (r,g,b,0), zero border of 2
+__global__ __launch_bounds__(256) void sweep_texture_kernel(const float* __restrict__ src, float4* __restrict__ tex,
+                                                            int P, int H, int W) {
+    const int TWp = W + 4, THp = H + 4;
+    const long long total = (long long)P * THp * TWp;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int tx = (int)(idx % TWp);
+        const long long r = idx / TWp;
+        const int ty = (int)(r % THp), p = (int)(r / THp);
+        const int x = tx - 2, y = ty - 2;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H) {
+            const float* s = src + (size_t)p * 3 * H * W + (size_t)y * W + x;
+            v.x = s[0]; v.y = s[(size_t)H * W]; v.z = s[2 * (size_t)H * W];
+        }
+        tex[idx] = v;
+    }
+}
+
+// Staged sampling is split in three so that the sweep loop can software-pipeline it across planes:
+//   sweep_coords : homography, perspective divide, floor/fraction, clamped LDS offset of tap (0,0)
+//   4 x ds_read_b128 issued by the caller one batch of planes ahead
+//   sweep_blend  : bilinear blend on packed fp32 pairs, |.-ref| summed over channels
+// Out-of-image texels are zeros in the staged box, coordinates are clamped into it: no bounds tests.
+// The .w lane of every texel is exactly zero; it is carried through the packed math (adds 0) so the
+// taps stay single 128-bit reads.
+struct SweepTap { int off; f32x2 w1; };      // off: texel index of tap (0,0) in the LDS box
+
+__device__ __forceinline__ SweepTap sweep_coords(f32x2 r0f, f32x2 rmaxf, float rwf, f32x2 a01, float a2,
+                                                 f32x2 k01, float k2, float z) {
+    const float den = fmaf(a2, z, k2) + 1e-6f;                               // depthNet_model.py:210-212
+    float r = __builtin_amdgcn_rcpf(den);
+    r = fmaf(fmaf(-den, r, 1.0f), r, r);                                     // one Newton step: ~0.5 ulp reciprocal
+    const f32x2 zz = {z, z}, rr2 = {r, r}, half = {0.5f, 0.5f};
+    const f32x2 i = (a01 * zz + k01) * rr2 - half;                           // :213 + grid_sample unnormalise
+    const f32x2 fl = {floorf(i.x), floorf(i.y)};
+    const f32x2 rel = fl - r0f;
+    const float xf = __builtin_amdgcn_fmed3f(rel.x, 0.f, rmaxf.x), yf = __builtin_amdgcn_fmed3f(rel.y, 0.f, rmaxf.y);
+    SweepTap t;
+#ifdef SWEEP_ABL_NOCOORD
+    t.off = (int)(z * 3.f); t.w1 = a01 * (f32x2){z, z};
+    return t;
+#endif
+    t.off = (int)fmaf(yf, rwf, xf);                                          // exact: integers < 2^24
+    t.w1 = i - fl;
+    return t;
+}
+
+__device__ __forceinline__ float sweep_blend(const float4 p00, const float4 p01, const float4 p10, const float4 p11,
+                                             f32x2 w1, f32x2 ref_rg, f32x2 ref_b0) {
+    const f32x2 one = {1.f, 1.f};
+    const f32x2 w0 = one - w1;
+    const f32x2 wx = {w0.x, w1.x};
+    const f32x2 wt = wx * (f32x2){w0.y, w0.y}, wb = wx * (f32x2){w1.y, w1.y};   // (w00,w01), (w10,w11)
+    const f32x2 w00 = {wt.x, wt.x}, w01 = {wt.y, wt.y}, w10 = {wb.x, wb.x}, w11 = {wb.y, wb.y};
+    f32x2 lo = w00 * (f32x2){p00.x, p00.y} - ref_rg;                         // warped - ref folded into the FMA chain
+    f32x2 hi = w00 * (f32x2){p00.z, p00.w} - ref_b0;
+    lo = w01 * (f32x2){p01.x, p01.y} + lo; hi = w01 * (f32x2){p01.z, p01.w} + hi;
+    lo = w10 * (f32x2){p10.x, p10.y} + lo; hi = w10 * (f32x2){p10.z, p10.w} + hi;
+    lo = w11 * (f32x2){p11.x, p11.y} + lo; hi = w11 * (f32x2){p11.z, p11.w} + hi;
+    return (__builtin_fabsf(lo.x) + __builtin_fabsf(lo.y)) + __builtin_fabsf(hi.x + hi.y);   // :222-223 (hi.y == 0 exactly)
+}
+
+// Same arithmetic, texels gathered from the planar source with per-corner bounds tests
+// (grid_sample zeros padding).  Used when a footprint does not fit the LDS box.
+__device__ __forceinline__ float sweep_sample_global(const float* __restrict__ srcp, int H, int W, int HW,
+                                                     f32x2 a01, float a2, f32x2 k01, float k2, float z,
+                                                     f32x2 ref_rg, f32x2 ref_b0) {
+    const float den = fmaf(a2, z, k2) + 1e-6f;
+    float r = __builtin_amdgcn_rcpf(den);
+    r = fmaf(fmaf(-den, r, 1.0f), r, r);
+    const f32x2 zz = {z, z}, rr2 = {r, r}, half = {0.5f, 0.5f}, one = {1.f, 1.f};
+    const f32x2 t = a01 * zz + k01;
+    const f32x2 i = t * rr2 - half;
+    const f32x2 fl = {floorf(i.x), floorf(i.y)};
+    const f32x2 w1 = i - fl, w0 = one - w1;
+    float4 p00, p01, p10, p11;
+    p00 = p01 = p10 = p11 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (fabsf(i.x) < 1e7f && fabsf(i.y) < 1e7f) {                            // false for NaN/inf as well
+        const int xi = (int)fl.x, yi = (int)fl.y;
+        const bool x0in = (unsigned)xi < (unsigned)W, x1in = (unsigned)(xi + 1) < (unsigned)W;
+        const bool y0in = (unsigned)yi < (unsigned)H, y1in = (unsigned)(yi + 1) < (unsigned)H;
+        const float* s = srcp + (ptrdiff_t)yi * W + xi;
+        if (y0in && x0in) { p00.x = s[0]; p00.y = s[HW]; p00.z = s[2 * HW]; }
+        if (y0in && x1in) { p01.x = s[1]; p01.y = s[HW + 1]; p01.z = s[2 * HW + 1]; }
+        if (y1in && x0in) { p10.x = s[W]; p10.y = s[HW + W]; p10.z = s[2 * HW + W]; }
+        if (y1in && x1in) { p11.x = s[W + 1]; p11.y = s[HW + W + 1]; p11.z = s[2 * HW + W + 1]; }
+    }
+    const f32x2 wy0 = {w0.y, w0.y}, wy1 = {w1.y, w1.y};
+    const f32x2 wx = {w0.x, w1.x};
+    const f32x2 wt = wx * wy0, wb = wx * wy1;
+    const f32x2 w00 = {wt.x, wt.x}, w01 = {wt.y, wt.y}, w10 = {wb.x, wb.x}, w11 = {wb.y, wb.y};
+    f32x2 lo = w00 * (f32x2){p00.x, p00.y} - ref_rg;
+    f32x2 hi = w00 * (f32x2){p00.z, p00.w} - ref_b0;
+    lo = w01 * (f32x2){p01.x, p01.y} + lo; hi = w01 * (f32x2){p01.z, p01.w} + hi;
+    lo = w10 * (f32x2){p10.x, p10.y} + lo; hi = w10 * (f32x2){p10.z, p10.w} + hi;
+    lo = w11 * (f32x2){p11.x, p11.y} + lo; hi = w11 * (f32x2){p11.z, p11.w} + hi;
+    return (__builtin_fabsf(lo.x) + __builtin_fabsf(lo.y)) + __builtin_fabsf(hi.x + hi.y);
+}
+
+struct SweepBox { int rx0, ry0, rw, rh; bool staged; };
+#ifdef SWEEP_STATS
+__device__ unsigned int sweep_stats[2];     // debug builds only: groups served from LDS / by the global fallback
+#endif
+#ifdef SWEEP_TRACE
+__device__ long long sweep_trace[4096][40];  // debug builds only: s_memtime stamps of wave 0 per workgroup
+#define TRACE(slot) do { if (threadIdx.x == 0 && tr_blk < 4096 && (slot) < 40) sweep_trace[tr_blk][slot] = clock64(); } while (0)
+#else
+#define TRACE(slot) do {} while (0)
+#endif
+
+template <int LAYOUT>   // 0: volume [P,D,H,W]   1: c4 [P,D/4+1,H,W,4]
+__global__ __launch_bounds__(SWEEP_NT) void planesweep_kernel(const SweepArgs a) {
+    static_assert((SWEEP_NT == 256 || SWEEP_NT == 512) && (SWEEP_TW & (SWEEP_TW - 1)) == 0 && SWEEP_TW <= 64 &&
+                  SWEEP_PG % 4 == 0 && SWEEP_PG % SWEEP_BATCH == 0 && CNM_MAX_PLANES % SWEEP_PG == 0, "tile");
+    // one LDS object (a second __shared__ array makes hipcc drain the LDS-DMA queue early): two texel
+    // boxes, the per-group footprint boxes and the plane depths.  The depths arrive in the kernel
+    // argument segment, which is host-visible memory: reading them group by group costs a PCIe-class
+    // round trip per group, so they are copied to LDS once.
+    __shared__ float4 smem[2 * SWEEP_CAP + (CNM_MAX_PLANES / 4) * 2 + CNM_MAX_PLANES / 4];
+    float4 (*tex)[SWEEP_CAP] = reinterpret_cast<float4 (*)[SWEEP_CAP]>(smem);
+    int (*boxes)[8] = reinterpret_cast<int (*)[8]>(smem + 2 * SWEEP_CAP);
+    float* zsh = reinterpret_cast<float*>(smem + 2 * SWEEP_CAP + (CNM_MAX_PLANES / 4) * 2);
+    if (threadIdx.x < CNM_MAX_PLANES) zsh[threadIdx.x] = a.z[threadIdx.x];
+
+#ifdef SWEEP_TRACE
+    const int tr_blk = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+#endif
+    TRACE(0);
+    const int lane = threadIdx.x & 63;
+    const int wbase = __builtin_amdgcn_readfirstlane(threadIdx.x & ~63);
     const int tx0 = blockIdx.x * SWEEP_TW, ty0 = blockIdx.y * SWEEP_TH;
-    const int x = tx0 + lane, y = ty0 + wave;
+    const int x = tx0 + (threadIdx.x & (SWEEP_TW - 1)), y = ty0 + threadIdx.x / SWEEP_TW;
     const int p = blockIdx.z, b = p / a.S;
-    const int H = a.H, W = a.W, HW = H * W, D = a.D;
+    const int H = a.H, W = a.W, HW = H * W, D = a.D, TWp = W + 4;
     const bool pvalid = x < W && y < H;
 
     const float* hk = a.hmkt + (size_t)p * 12;
     const float h00 = hk[0], h01 = hk[1], h02 = hk[2], h10 = hk[3], h11 = hk[4], h12 = hk[5];
-    const float h20 = hk[6], h21 = hk[7], h22 = hk[8], k0 = hk[9], k1 = hk[10], k2 = hk[11];
+    const float h20 = hk[6], h21 = hk[7], h22 = hk[8], k2 = hk[11];
+    const f32x2 k01 = {hk[9], hk[10]};
     const float fx_ = (float)x, fy_ = (float)y;
-    const float a0 = fmaf(h00, fx_, fmaf(h01, fy_, h02));
-    const float a1 = fmaf(h10, fx_, fmaf(h11, fy_, h12));
+    const f32x2 a01 = {fmaf(h00, fx_, fmaf(h01, fy_, h02)), fmaf(h10, fx_, fmaf(h11, fy_, h12))};
     const float a2 = fmaf(h20, fx_, fmaf(h21, fy_, h22));
 
     const float* refp = a.ref + (size_t)b * 3 * HW + (size_t)y * W + x;
     float rr = 0.f, rg = 0.f, rb = 0.f;
     if (pvalid) { rr = refp[0]; rg = refp[HW]; rb = refp[2 * HW]; }
+    const f32x2 ref_rg = {rr, rg}, ref_b0 = {rb, 0.f};
     const float* srcp = a.src + (size_t)p * 3 * HW;
+    const float4* texp = a.tex + (size_t)p * (H + 4) * TWp;
 
     // tile corners for the footprint box: lanes 0..7 = 4 corners x {first,last plane of group}
     const int cxi = (lane & 1) ? min(tx0 + SWEEP_TW - 1, W - 1) : tx0;
@@ -137,106 +289,186 @@ __global__ __launch_bounds__(256) void planesweep_kernel(const SweepArgs a) {
     const float ca1 = fmaf(h10, cxf, fmaf(h11, cyf, h12));
     const float ca2 = fmaf(h20, cxf, fmaf(h21, cyf, h22));
 
-    float cost4[4];
+    // ---- footprint boxes of all plane groups, once per workgroup: lane (8g + c) of wave 0 projects tile
+    // corner (c&3) on the first (c<4) / last (c>=4) plane of group g; an 8-lane min/max gives the box,
+    // which is parked in LDS and read back wave-uniformly when the group is processed.
     const int ngroups = (D + SWEEP_PG - 1) / SWEEP_PG;
-    for (int g = 0; g < ngroups; ++g) {
-        const int d0 = g * SWEEP_PG, d1 = min(d0 + SWEEP_PG, D) - 1;
-        // ---- footprint box (computed redundantly by every wave: identical, no exchange needed)
-        float umin, umax, vmin, vmax; int okc;
-        {
+    for (int gbase = 0; gbase < ngroups; gbase += 8) {        // wave 0 only; 8 groups per pass
+        if (threadIdx.x < 64) {
+            const int g = min(gbase + (lane >> 3), ngroups - 1);
+            const int d0 = g * SWEEP_PG, d1 = min(d0 + SWEEP_PG, D) - 1;
             const float zc = a.z[(lane & 4) ? d1 : d0];
             const float den = fmaf(ca2, zc, k2) + 1e-6f;
-            const float u = fast_div(fmaf(ca0, zc, k0), den), v = fast_div(fmaf(ca1, zc, k1), den);
-            okc = (den > 1e-4f) && (fabsf(u) < 1e6f) && (fabsf(v) < 1e6f);
-            umin = umax = u; vmin = vmax = v;
+            const float u = fast_div(fmaf(ca0, zc, k01.x), den), v = fast_div(fmaf(ca1, zc, k01.y), den);
+            int okc = (den > 1e-4f) && (fabsf(u) < 1e6f) && (fabsf(v) < 1e6f);
+            float umin = u, umax = u, vmin = v, vmax = v;
 #pragma unroll
             for (int m = 1; m < 8; m <<= 1) {
                 umin = fminf(umin, __shfl_xor(umin, m, 8)); umax = fmaxf(umax, __shfl_xor(umax, m, 8));
                 vmin = fminf(vmin, __shfl_xor(vmin, m, 8)); vmax = fmaxf(vmax, __shfl_xor(vmax, m, 8));
                 okc &= __shfl_xor(okc, m, 8);
             }
-            umin = __shfl(umin, 0); umax = __shfl(umax, 0); vmin = __shfl(vmin, 0); vmax = __shfl(vmax, 0);
-            okc = __shfl(okc, 0);
-        }
-        // sample corners x0 = floor(u-0.5) .. x0+1, with one texel of safety margin either side
-        int rx0 = (int)fminf(fmaxf(floorf(umin - 0.5f) - 1.f, -2.f), (float)W);
-        int rx1 = (int)fminf(fmaxf(floorf(umax - 0.5f) + 2.f, (float)(rx0 + 1)), (float)(W + 1));
-        int ry0 = (int)fminf(fmaxf(floorf(vmin - 0.5f) - 1.f, -2.f), (float)H);
-        int ry1 = (int)fminf(fmaxf(floorf(vmax - 0.5f) + 2.f, (float)(ry0 + 1)), (float)(H + 1));
-        rx0 = __builtin_amdgcn_readfirstlane(rx0); rx1 = __builtin_amdgcn_readfirstlane(rx1);
-        ry0 = __builtin_amdgcn_readfirstlane(ry0); ry1 = __builtin_amdgcn_readfirstlane(ry1);
-        const int rw = rx1 - rx0 + 1, rh = ry1 - ry0 + 1;
-        const bool staged = __builtin_amdgcn_readfirstlane(okc) && (rw * rh <= SWEEP_CAP);
-        float4* tb = tex[g & 1];
-
-        if (staged) {
-            for (int r = wave; r < rh; r += 4) {
-                const int iy = ry0 + r;
-                const bool rowin = (unsigned)iy < (unsigned)H;
-                for (int c = lane; c < rw; c += 64) {
-                    const int ix = rx0 + c;
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (rowin && (unsigned)ix < (unsigned)W) {
-                        const float* s = srcp + (size_t)iy * W + ix;
-                        v.x = s[0]; v.y = s[HW]; v.z = s[2 * HW];
-                    }
-                    tb[r * rw + c] = v;
-                }
-            }
-        }
-        __syncthreads();   // unconditional: also orders buffer reuse when a group was not staged
-
-#pragma unroll
-        for (int j = 0; j < SWEEP_PG; ++j) {
-            const int dd = d0 + j;
-            if (dd > d1) break;
-            const float z = a.z[dd];
-            const float den = fmaf(a2, z, k2) + 1e-6f;                      // depthNet_model.py:210-212
-            const float ix = fast_div(fmaf(a0, z, k0), den) - 0.5f;         // :213 + grid_sample unnormalise
-            const float iy = fast_div(fmaf(a1, z, k1), den) - 0.5f;
-            const float flx = floorf(ix), fly = floorf(iy);
-            const float wx1 = ix - flx, wy1 = iy - fly, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
-            float4 p00, p01, p10, p11;
-            if (staged) {
-                const int xi = (int)fminf(fmaxf(flx, (float)rx0), (float)(rx1 - 1)) - rx0;
-                const int yi = (int)fminf(fmaxf(fly, (float)ry0), (float)(ry1 - 1)) - ry0;
-                const float4* q = tb + yi * rw + xi;
-                p00 = q[0]; p01 = q[1]; p10 = q[rw]; p11 = q[rw + 1];
-            } else {
-                p00 = p01 = p10 = p11 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (fabsf(ix) < 1e7f && fabsf(iy) < 1e7f) {                  // false for NaN/inf as well
-                    const int xi = (int)flx, yi = (int)fly;
-                    const bool x0in = (unsigned)xi < (unsigned)W, x1in = (unsigned)(xi + 1) < (unsigned)W;
-                    const bool y0in = (unsigned)yi < (unsigned)H, y1in = (unsigned)(yi + 1) < (unsigned)H;
-                    const float* s = srcp + (ptrdiff_t)yi * W + xi;
-                    if (y0in && x0in) { p00.x = s[0]; p00.y = s[HW]; p00.z = s[2 * HW]; }
-                    if (y0in && x1in) { p01.x = s[1]; p01.y = s[HW + 1]; p01.z = s[2 * HW + 1]; }
-                    if (y1in && x0in) { p10.x = s[W]; p10.y = s[HW + W]; p10.z = s[2 * HW + W]; }
-                    if (y1in && x1in) { p11.x = s[W + 1]; p11.y = s[HW + W + 1]; p11.z = s[2 * HW + W + 1]; }
-                }
-            }
-            const float w00 = wx0 * wy0, w01 = wx1 * wy0, w10 = wx0 * wy1, w11 = wx1 * wy1;
-            const float wr = fmaf(w11, p11.x, fmaf(w10, p10.x, fmaf(w01, p01.x, w00 * p00.x)));
-            const float wg = fmaf(w11, p11.y, fmaf(w10, p10.y, fmaf(w01, p01.y, w00 * p00.y)));
-            const float wb = fmaf(w11, p11.z, fmaf(w10, p10.z, fmaf(w01, p01.z, w00 * p00.z)));
-            const float cost = fabsf(wr - rr) + fabsf(wg - rg) + fabsf(wb - rb);   // :222-223
-            if (LAYOUT == 0) {
-                if (pvalid) a.out[((size_t)p * D + dd) * HW + (size_t)y * W + x] = cost;
-            } else {
-                cost4[j & 3] = cost;
-                if ((j & 3) == 3 && pvalid)
-                    *reinterpret_cast<float4*>(a.out + c4_offset(p, D / 4 + 1, dd >> 2, HW, y * W + x)) =
-                        make_float4(cost4[0], cost4[1], cost4[2], cost4[3]);
+            // sample corners x0 = floor(u-0.5) .. x0+1, one texel of safety margin either side,
+            // clipped to the texture's zero border [-2, W+1] x [-2, H+1]
+            const int rx0 = (int)fminf(fmaxf(floorf(umin - 0.5f) - 1.f, -2.f), (float)W);
+            const int rx1 = (int)fminf(fmaxf(floorf(umax - 0.5f) + 2.f, (float)(rx0 + 1)), (float)(W + 1));
+            const int ry0 = (int)fminf(fmaxf(floorf(vmin - 0.5f) - 1.f, -2.f), (float)H);
+            const int ry1 = (int)fminf(fmaxf(floorf(vmax - 0.5f) + 2.f, (float)(ry0 + 1)), (float)(H + 1));
+            if ((lane & 7) == 0 && gbase + (lane >> 3) < ngroups) {
+                int* bx = boxes[g];
+                bx[0] = rx0; bx[1] = ry0; bx[2] = rx1 - rx0 + 1; bx[3] = ry1 - ry0 + 1;
+                bx[4] = okc && ((rx1 - rx0 + 1) * (ry1 - ry0 + 1) <= SWEEP_CAP);
             }
         }
     }
+    __syncthreads();
+    auto box_of = [&](int g) {
+        SweepBox bx;
+#ifdef SWEEP_ABL_CONSTBOX
+        bx.rx0 = tx0; bx.ry0 = ty0; bx.rw = 80; bx.rh = 10; bx.staged = true; return bx;
+#endif
+        bx.rx0 = __builtin_amdgcn_readfirstlane(boxes[g][0]); bx.ry0 = __builtin_amdgcn_readfirstlane(boxes[g][1]);
+        bx.rw = __builtin_amdgcn_readfirstlane(boxes[g][2]); bx.rh = __builtin_amdgcn_readfirstlane(boxes[g][3]);
+        bx.staged = __builtin_amdgcn_readfirstlane(boxes[g][4]) != 0;
+        return bx;
+    };
+    // LDS-DMA copy of a box: texel i = r*rw + c of the box lands at tb[i]; lane l of a wave owns i = chunk + l
+    auto stage = [&](const SweepBox& bx, float4* tb) {
+        const int n = bx.rw * bx.rh;
+        const float inv_rw = 1.0f / (float)bx.rw;
+        const float4* base = texp + (size_t)(bx.ry0 + 2) * TWp + (bx.rx0 + 2);
+        for (int i0 = wbase; i0 < n; i0 += SWEEP_NT) {
+            const int i = i0 + lane;
+            if (i < n) {
+                const int r = (int)(((float)i + 0.5f) * inv_rw), c = i - r * bx.rw;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + r * TWp + c),
+                                                 (__attribute__((address_space(3))) void*)(tb + i0), 16, 0, 0);
+            }
+        }
+    };
+
+    // Stores of group g are issued AFTER the barrier of group g+1: the barrier's vmcnt(0) (needed for the
+    // LDS-DMA) then only ever waits for stores that had a whole compute phase to drain.
+    float pend[SWEEP_PG];
+    auto emit = [&](int d0) {
+#ifdef SWEEP_ABL_NOSTORE
+#pragma unroll
+        for (int j = 0; j < SWEEP_PG; ++j) asm volatile("" :: "v"(pend[j]));
+        if (a.D >= 0) return;
+#endif
+        if (!pvalid) return;
+        if (LAYOUT == 0) {
+#pragma unroll
+            for (int j = 0; j < SWEEP_PG; ++j)
+                if (d0 + j < D) a.out[((size_t)p * D + d0 + j) * HW + (size_t)y * W + x] = pend[j];
+        } else {
+#pragma unroll
+            for (int q = 0; q < SWEEP_PG / 4; ++q)
+                if (d0 + 4 * q < D)
+                    *reinterpret_cast<float4*>(a.out + c4_offset(p, D / 4 + 1, (d0 >> 2) + q, HW, y * W + x)) =
+                        make_float4(pend[4 * q], pend[4 * q + 1], pend[4 * q + 2], pend[4 * q + 3]);
+        }
+    };
+    TRACE(1);
+    SweepBox cur = box_of(0);
+    if (cur.staged) stage(cur, tex[0]);
+    TRACE(2);
+    for (int g = 0; g < ngroups; ++g) {
+        const int d0 = g * SWEEP_PG;
+        SweepBox nxt = cur;
+#ifndef SWEEP_ABL_NOBOX
+        if (g + 1 < ngroups) nxt = box_of(g + 1);
+#endif
+        TRACE(3 + 4 * g);
+#ifndef SWEEP_ABL_NOGROUPSYNC
+        __syncthreads();   // box g has landed (vmcnt(0) + barrier); every wave is done reading the other buffer
+#endif
+        TRACE(4 + 4 * g);
+        if (SWEEP_DEFER && g > 0) emit(d0 - SWEEP_PG);
+#ifndef SWEEP_ABL_NODMA
+        if (g + 1 < ngroups && nxt.staged) stage(nxt, tex[(g + 1) & 1]);
+#endif
+        TRACE(5 + 4 * g);
+        const float4* tb = tex[g & 1];
+
+#ifdef SWEEP_STATS
+        if (threadIdx.x == 0) atomicAdd(&sweep_stats[cur.staged ? 0 : 1], 1u);
+#endif
+        float zs[SWEEP_PG];
+#pragma unroll
+        for (int j = 0; j < SWEEP_PG; ++j) zs[j] = zsh[d0 + j];             // LDS broadcast reads, d0+j < CNM_MAX_PLANES
+        float cost[SWEEP_PG];
+        if (cur.staged) {
+            const f32x2 r0f = {(float)cur.rx0, (float)cur.ry0}, rmaxf = {(float)(cur.rw - 2), (float)(cur.rh - 2)};
+            const float rwf = (float)cur.rw;
+            const int rw = cur.rw;
+            // software pipeline over batches of SWEEP_BATCH planes: the taps of batch k+1 are in flight
+            // while batch k is blended
+            constexpr int NB = SWEEP_PG / SWEEP_BATCH, BT = SWEEP_BATCH;
+            SweepTap tap[2][BT];
+            float4 tx[2][BT][4];
+#pragma unroll
+            for (int u = 0; u < BT; ++u) tap[0][u] = sweep_coords(r0f, rmaxf, rwf, a01, a2, k01, k2, zs[u]);
+#pragma unroll
+            for (int u = 0; u < BT; ++u) {
+                const float4* q = tb + tap[0][u].off;
+                tx[0][u][0] = q[0]; tx[0][u][1] = q[1]; tx[0][u][2] = q[rw]; tx[0][u][3] = q[rw + 1];
+            }
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const int c = k & 1, n = c ^ 1;
+                if (k + 1 < NB) {
+#pragma unroll
+                    for (int u = 0; u < BT; ++u) tap[n][u] = sweep_coords(r0f, rmaxf, rwf, a01, a2, k01, k2, zs[BT * (k + 1) + u]);
+#pragma unroll
+                    for (int u = 0; u < BT; ++u) {
+                        const float4* q = tb + tap[n][u].off;
+                        tx[n][u][0] = q[0]; tx[n][u][1] = q[1]; tx[n][u][2] = q[rw]; tx[n][u][3] = q[rw + 1];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < BT; ++u)
+#if defined(SWEEP_ABL_NOTAPS)
+                    cost[BT * k + u] = tap[c][u].w1.x + (float)tap[c][u].off;
+#elif defined(SWEEP_ABL_NOBLEND)
+                    cost[BT * k + u] = tap[c][u].w1.x + tx[c][u][0].x + tx[c][u][1].x + tx[c][u][2].x + tx[c][u][3].x;
+#else
+                    cost[BT * k + u] = sweep_blend(tx[c][u][0], tx[c][u][1], tx[c][u][2], tx[c][u][3], tap[c][u].w1, ref_rg, ref_b0);
+#endif
+            }
+        } else {
+#pragma unroll 1
+            for (int j = 0; j < SWEEP_PG; ++j) {
+                float zj = zs[0];
+#pragma unroll
+                for (int jj = 1; jj < SWEEP_PG; ++jj) if (jj == j) zj = zs[jj];
+                const float c = sweep_sample_global(srcp, H, W, HW, a01, a2, k01, k2, zj, ref_rg, ref_b0);
+#pragma unroll
+                for (int jj = 0; jj < SWEEP_PG; ++jj) if (jj == j) cost[jj] = c;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < SWEEP_PG; ++j) pend[j] = cost[j];
+        if (!SWEEP_DEFER) emit(d0);
+        TRACE(6 + 4 * g);
+        cur = nxt;
+    }
+    if (SWEEP_DEFER) emit((ngroups - 1) * SWEEP_PG);
+    TRACE(39);
     if (LAYOUT == 1 && pvalid)
         *reinterpret_cast<float4*>(a.out + c4_offset(p, D / 4 + 1, D / 4, HW, y * W + x)) = make_float4(rr, rg, rb, 0.f);
 }
 
+extern "C" size_t cnm_planesweep_workspace_floats(int B, int S, int H, int W) {
+    if (B <= 0 || S <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)B * S * (H + 4) * (W + 4) * 4;
+}
+
 static int sweep_launch(int layout, const float* ref, const float* src, const float* hmkt, float* out,
-                        int B, int S, int H, int W, int D, double idepth_min, double idepth_max, void* stream) {
-    CNM_REQUIRE(ref && src && hmkt && out, CNM_ERR_BAD_ARG);
+                        float* ws, size_t ws_floats, int B, int S, int H, int W, int D,
+                        double idepth_min, double idepth_max, void* stream) {
+    CNM_REQUIRE(ref && src && hmkt && out && ws, CNM_ERR_BAD_ARG);
+    CNM_REQUIRE(((uintptr_t)ws & 15) == 0, CNM_ERR_BAD_ARG);
     CNM_REQUIRE(B > 0 && S > 0 && H > 0 && W > 0 && D >= 2 && D <= CNM_MAX_PLANES, CNM_ERR_BAD_ARG);
     CNM_REQUIRE(layout == 0 || D % 4 == 0, CNM_ERR_BAD_ARG);
     CNM_REQUIRE((long long)B * S <= 65535, CNM_ERR_BAD_ARG);
@@ -246,21 +478,28 @@ static int sweep_launch(int layout, const float* ref, const float* src, const fl
     const double step = (idepth_max - idepth_min) / (D - 1.0);              // depthNet_model.py:194
     for (int d = 0; d < CNM_MAX_PLANES; ++d)
         a.z[d] = d < D ? (float)(1.0 / (idepth_min + d * step)) : 0.f;      // :209 (python double -> fp32)
+    CNM_REQUIRE(ws_floats >= cnm_planesweep_workspace_floats(B, S, H, W), CNM_ERR_WORKSPACE);
+    a.tex = reinterpret_cast<const float4*>(ws);
+    {
+        const long long total = (long long)B * S * (H + 4) * (W + 4);
+        const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+        sweep_texture_kernel<<<blocks, 256, 0, cnm_stream(stream)>>>(src, reinterpret_cast<float4*>(ws), B * S, H, W);
+    }
     dim3 grid(cnm_ceil_div(W, SWEEP_TW), cnm_ceil_div(H, SWEEP_TH), B * S);
-    if (layout == 0) planesweep_kernel<0><<<grid, 256, 0, cnm_stream(stream)>>>(a);
-    else planesweep_kernel<1><<<grid, 256, 0, cnm_stream(stream)>>>(a);
+    if (layout == 0) planesweep_kernel<0><<<grid, SWEEP_NT, 0, cnm_stream(stream)>>>(a);
+    else planesweep_kernel<1><<<grid, SWEEP_NT, 0, cnm_stream(stream)>>>(a);
     CNM_LAUNCH_CHECK();
     return CNM_OK;
 }
 
 extern "C" int cnm_planesweep_volume_nchw_f32(const float* ref, const float* src, const float* hmkt, float* volume,
-                                              int B, int S, int H, int W, int D,
+                                              float* ws, size_t ws_floats, int B, int S, int H, int W, int D,
                                               double idepth_min, double idepth_max, void* stream) {
-    return sweep_launch(0, ref, src, hmkt, volume, B, S, H, W, D, idepth_min, idepth_max, stream);
+    return sweep_launch(0, ref, src, hmkt, volume, ws, ws_floats, B, S, H, W, D, idepth_min, idepth_max, stream);
 }
 
 extern "C" int cnm_planesweep_cat_c4_f32(const float* ref, const float* src, const float* hmkt, float* x,
-                                         int B, int S, int H, int W, int D,
+                                         float* ws, size_t ws_floats, int B, int S, int H, int W, int D,
                                          double idepth_min, double idepth_max, void* stream) {
-    return sweep_launch(1, ref, src, hmkt, x, B, S, H, W, D, idepth_min, idepth_max, stream);
+    return sweep_launch(1, ref, src, hmkt, x, ws, ws_floats, B, S, H, W, D, idepth_min, idepth_max, stream);
 }

@@ -62,21 +62,27 @@ def plane_sweep_volume(left, right, left_cam, right_cam, idepth_scale=3.0, plane
     B, _, H, W = left.shape
     hmkt = homography_terms(left_cam, right_cam.unsqueeze(1))
     vol = torch.empty(B, planes, H, W, device=left.device, dtype=torch.float32)
+    lib = _lib.load()
+    ws = torch.empty(lib.cnm_planesweep_workspace_floats(B, 1, H, W), device=left.device, dtype=torch.float32)
     with torch.cuda.device(left.device):
-        _lib.check(_lib.load().cnm_planesweep_volume_nchw_f32(_p(left), _p(right), _p(hmkt), _p(vol),
-                                                              B, 1, H, W, planes, lo, hi, _stream()))
+        _lib.check(lib.cnm_planesweep_volume_nchw_f32(_p(left), _p(right), _p(hmkt), _p(vol), _p(ws), ws.numel(),
+                                                      B, 1, H, W, planes, lo, hi, _stream()))
     return vol
 
 
-def plane_sweep_cat_c4(ref, src, hmkt, idepth_scale=3.0, planes=64):
+def plane_sweep_cat_c4(ref, src, hmkt, idepth_scale=3.0, planes=64, ws=None):
     """ref [B,3,H,W], src [B,S,3,H,W], hmkt [B*S,12] -> c4 conv input [B*S, planes/4+1, H, W, 4]."""
     _dev(ref, src, hmkt)
     lo, hi = idepth_range(idepth_scale)
     ref, src = _c(ref), _c(src)
     B, S, _, H, W = src.shape
     x = torch.empty(B * S, planes // 4 + 1, H, W, 4, device=ref.device, dtype=torch.float32)
+    lib = _lib.load()
+    if ws is None:
+        ws = torch.empty(lib.cnm_planesweep_workspace_floats(B, S, H, W), device=ref.device, dtype=torch.float32)
     with torch.cuda.device(ref.device):
-        _lib.check(_lib.load().cnm_planesweep_cat_c4_f32(_p(ref), _p(src), _p(hmkt), _p(x), B, S, H, W, planes, lo, hi, _stream()))
+        _lib.check(lib.cnm_planesweep_cat_c4_f32(_p(ref), _p(src), _p(hmkt), _p(x), _p(ws), ws.numel(),
+                                                 B, S, H, W, planes, lo, hi, _stream()))
     return x
 
 

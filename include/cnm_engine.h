@@ -70,12 +70,15 @@ int cnm_idepth_range_host(double idepth_scale, double* idepth_min, double* idept
  * _nchw : volume [B*S,D,H,W]            -- the drop-in for getVolume's return value.
  * _c4   : x [B*S][G][H][W][4], G = D/4+1 -- groups 0..D/4-1 = cost planes, last group =
  *         (ref r,g,b,0): the concatenated conv1 input of depthNet_model.py:233 with the
- *         three image channels rotated to the end.  D must be a multiple of 4. */
+ *         three image channels rotated to the end.  D must be a multiple of 4.
+ * ws: 16-byte aligned scratch of cnm_planesweep_workspace_floats(B,S,H,W) floats (the sources
+ *     re-laid as zero-bordered RGBA textures by a pre-pass on the same stream). */
+size_t cnm_planesweep_workspace_floats(int B, int S, int H, int W);
 int cnm_planesweep_volume_nchw_f32(const float* ref, const float* src, const float* hmkt, float* volume,
-                                   int B, int S, int H, int W, int D,
+                                   float* ws, size_t ws_floats, int B, int S, int H, int W, int D,
                                    double idepth_min, double idepth_max, void* stream);
 int cnm_planesweep_cat_c4_f32(const float* ref, const float* src, const float* hmkt, float* x,
-                              int B, int S, int H, int W, int D,
+                              float* ws, size_t ws_floats, int B, int S, int H, int W, int D,
                               double idepth_min, double idepth_max, void* stream);
 
 /* ---------------------------------------------------------------- conv stack (K2-K5)
