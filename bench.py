@@ -194,10 +194,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     assert bool(torch.isfinite(out["disp"]).all()) and bool(torch.isfinite(out["normal"]).all())
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    from cnmnet_amd import sharding
+    elapsed = sharding.job_elapsed(elapsed, dist, dev)            # max over ranks
 
     line = None
     if rank == 0:

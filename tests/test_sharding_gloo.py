@@ -1,0 +1,57 @@
+"""CPU, world_size-2 gloo: the N>1 path of bench.py is host logic only (independent frame shards,
+barrier, max-over-ranks timing) -- exercised here without a GPU."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from cnmnet_amd import sharding
+
+
+def test_shard_range_partitions_exactly():
+    for total in (0, 1, 7, 8, 9, 64):
+        for world in (1, 2, 3, 8):
+            spans = [sharding.shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [e - s for s, e in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        sharding.shard_range(8, 2, 2)
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = sharding.shard_range(9, rank, world)
+        local = 1.0 + rank                      # rank 1 is the slow one
+        dist.barrier()
+        elapsed = sharding.job_elapsed(local, dist)
+        thr = sharding.job_throughput(hi - lo, local, dist)
+        out.put((rank, lo, hi, elapsed, thr))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_max_time_and_sum_units():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get() for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [(r[1], r[2]) for r in res] == [(0, 5), (5, 9)]
+    assert all(abs(r[3] - 2.0) < 1e-12 for r in res)            # max over ranks
+    assert all(abs(r[4] - 9 / 2.0) < 1e-12 for r in res)        # all units / slowest rank
+
+
+def test_single_process_is_identity():
+    assert sharding.job_elapsed(0.25) == 0.25 and sharding.job_throughput(8, 0.5) == 16.0
