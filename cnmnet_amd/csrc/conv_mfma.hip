@@ -17,25 +17,52 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef CONV_BK
+#define CONV_BK 16            // k-depth of one LDS tile (16 or 32)
+#endif
+#ifndef CONV_MINW
+#define CONV_MINW 1           // __launch_bounds__ min waves per SIMD (register cap)
+#endif
+#ifndef CONV_SETPRIO
+#define CONV_SETPRIO 0
+#endif
+#ifndef CONV_PIN
+#define CONV_PIN 0            // 1: pin load -> MFMA -> LDS-store order inside a k-step (measured slower)
+#endif
+
 struct ConvArgs {
     const float* in; float* out; const float* w; const float* bias;
     const float* in2;            // optional second source: channel groups [Gsplit, Gin) (torch.cat without the copy)
+    unsigned in_bytes, in2_bytes; // extents for the buffer descriptors (< 4 GB each)
     int Gin2_tot, gin2_0, Gsplit;
     int N, H, W, Ho, Wo;
     int Gin_tot, gin0, Gin;
     int Gout_tot, gout0, Cout;
     int ks, stride, pad;
-    int nk;          // Kpad / 16
+    int nk;          // Kpad / CONV_BK
     int M;           // N*Ho*Wo
     int relu;
 };
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// 16-byte load through a buffer descriptor: an out-of-range byte offset (we pass 0xFFFFFFFF for the
+// zero-padding taps and the tile's pixel tail) returns zeros in hardware -- the im2col gather needs
+// no branches and no selects, so the whole k-step stays one basic block the scheduler can interleave
+// with the MFMAs.
+__device__ __forceinline__ float4 buffer_load_f4(const float* base, unsigned bytes, unsigned voff, unsigned soff) {
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes, 0x00020000);
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
 template <int TC, int TP>
-__global__ __launch_bounds__(256) void conv_mfma_f32_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, CONV_MINW) void conv_mfma_f32_kernel(const ConvArgs a) {
     constexpr int NT = 256, WP = 2;
     constexpr int CI = TC / 64, PI = TP / 64;          // 32x32 MFMA tiles per wave
-    constexpr int LDK = 20;                            // 16 k + 4 pad floats per LDS row
-    constexpr int A_LOADS = TC * 4 / NT, B_LOADS = TP * 4 / NT;
+    constexpr int BK = CONV_BK, KQ = BK / 4;           // k-quads (float4) per LDS row
+    constexpr int LDK = BK + 4;                        // +4 pad floats per LDS row: conflict-free ds_read_b128
+    constexpr int A_LOADS = TC * KQ / NT, B_LOADS = TP * KQ / NT, QSTEP = NT / TP;
     __shared__ __attribute__((aligned(16))) float smem[2 * (TC + TP) * LDK];
     float* As = smem;                                  // [2][TC][LDK]
     float* Bs = smem + 2 * TC * LDK;                   // [2][TP][LDK]
@@ -47,59 +74,62 @@ __global__ __launch_bounds__(256) void conv_mfma_f32_kernel(const ConvArgs a) {
     const int c0 = (tile % tilesC) * TC, m0 = (tile / tilesC) * TP;
     const int HW = a.H * a.W, HoWo = a.Ho * a.Wo;
 
-    // ---- pixel (B operand) loader state: one output pixel per thread, B_LOADS k-quads
+    // ---- pixel (B operand) loader state: one output pixel per thread
     const int prow = t % TP;
     const int m = m0 + prow;
     const bool mvalid = m < a.M;
     int iy0, ix0;
-    const float* in_img;
-    const float* in2_img;
+    unsigned vb1, vb2;                                  // byte offset of tap (0,0), group 0 in source 1 / 2 (mod 2^32)
     {
         const int mm = mvalid ? m : 0;
         const int img = mm / HoWo, rem = mm - img * HoWo;
         const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
         iy0 = oy * a.stride - a.pad; ix0 = ox * a.stride - a.pad;
-        in_img = a.in + ((size_t)img * a.Gin_tot + a.gin0) * (size_t)HW * 4;
-        in2_img = a.in2 ? a.in2 + ((long long)img * a.Gin2_tot + a.gin2_0 - a.Gsplit) * (long long)HW * 4 : in_img;
+        const unsigned pix0 = (unsigned)(iy0 * a.W + ix0);
+        vb1 = ((unsigned)(img * a.Gin_tot + a.gin0) * (unsigned)HW + pix0) * 16u;
+        vb2 = ((unsigned)(img * a.Gin2_tot + a.gin2_0) * (unsigned)HW + pix0) * 16u;
     }
+    // (tap, channel-group) of the k-quads this wave loads is wave-uniform: SGPR state, SALU updates
+    const int wq = __builtin_amdgcn_readfirstlane(t / TP);
     int bg[B_LOADS], bky[B_LOADS], bkx[B_LOADS];
 #pragma unroll
     for (int i = 0; i < B_LOADS; ++i) {
-        const int kq = t / TP + i * (NT / TP);         // wave-uniform k-quad index within the k-step
+        const int kq = wq + i * QSTEP;                 // k-quad index within the k-step
         const int tap = kq / a.Gin;
         bg[i] = kq - tap * a.Gin; bky[i] = tap / a.ks; bkx[i] = tap - bky[i] * a.ks;
     }
-    const float* wtile = a.w + (size_t)c0 * 16;        // [nk][Cout][16]
+    const float* wtile = a.w + (size_t)c0 * BK;        // [nk][Cout][BK]
+    const unsigned HW16 = (unsigned)HW * 16u;
 
     float4 ra[A_LOADS], rb[B_LOADS];
-    auto load_global = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < A_LOADS; ++i)
-            ra[i] = *reinterpret_cast<const float4*>(wtile + (size_t)kt * a.Cout * 16 + (size_t)(t + i * NT) * 4);
-#pragma unroll
-        for (int i = 0; i < B_LOADS; ++i) {
-            const int iy = iy0 + bky[i], ix = ix0 + bkx[i];
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (mvalid && bky[i] < a.ks && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
-                v = *reinterpret_cast<const float4*>((bg[i] < a.Gsplit ? in_img : in2_img) +
-                                                     ((size_t)bg[i] * HW + (size_t)iy * a.W + ix) * 4);
-            rb[i] = v;
-            bg[i] += 4;                                // advance 16 floats of flat k
-            while (bg[i] >= a.Gin) { bg[i] -= a.Gin; if (++bkx[i] == a.ks) { bkx[i] = 0; ++bky[i]; } }
-        }
-    };
-    auto store_lds = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < A_LOADS; ++i) {
-            const int f = t + i * NT;
-            *reinterpret_cast<float4*>(As + ((size_t)buf * TC + (f >> 2)) * LDK + (f & 3) * 4) = ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < B_LOADS; ++i) {
-            const int q = t / TP + i * (NT / TP);
-            *reinterpret_cast<float4*>(Bs + ((size_t)buf * TP + prow) * LDK + q * 4) = rb[i];
-        }
-    };
+#define CONV_LOAD_GLOBAL(KT)                                                                                       \
+    do {                                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i)                                                        \
+            ra[i] = *reinterpret_cast<const float4*>(wtile + (size_t)(KT) * a.Cout * BK + (size_t)(t + i * NT) * 4); \
+        _Pragma("unroll") for (int i = 0; i < B_LOADS; ++i) {                                                      \
+            const int iy = iy0 + bky[i], ix = ix0 + bkx[i];                                                        \
+            const bool ok = mvalid && bky[i] < a.ks && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W; \
+            const bool s1 = bg[i] < a.Gsplit;                                            /* wave-uniform */         \
+            const unsigned tapoff = (unsigned)(bky[i] * a.W + bkx[i]) * 16u;                                        \
+            const unsigned voff = ok ? (s1 ? vb1 : vb2) + tapoff : 0xFFFFFFFFu;                                     \
+            rb[i] = buffer_load_f4(s1 ? a.in : a.in2, s1 ? a.in_bytes : a.in2_bytes, voff,                          \
+                                   (unsigned)(s1 ? bg[i] : bg[i] - a.Gsplit) * HW16);                              \
+            bg[i] += KQ;                                                 /* advance BK floats of flat k */           \
+            const bool wrap = bg[i] >= a.Gin;                            /* Gin >= KQ: at most one wrap */           \
+            bg[i] -= wrap ? a.Gin : 0; bkx[i] += wrap ? 1 : 0;                                                      \
+            const bool wrapx = bkx[i] == a.ks;                                                                      \
+            bkx[i] = wrapx ? 0 : bkx[i]; bky[i] += wrapx ? 1 : 0;                                                   \
+        }                                                                                                          \
+    } while (0)
+#define CONV_STORE_LDS(BUF)                                                                                        \
+    do {                                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i) {                                                      \
+            const int f = t + i * NT;                                                                              \
+            *reinterpret_cast<float4*>(As + ((size_t)(BUF) * TC + f / KQ) * LDK + (f % KQ) * 4) = ra[i];           \
+        }                                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < B_LOADS; ++i)                                                        \
+            *reinterpret_cast<float4*>(Bs + ((size_t)(BUF) * TP + prow) * LDK + (wq + i * QSTEP) * 4) = rb[i];     \
+    } while (0)
 
     f32x16 acc[CI][PI];
 #pragma unroll
@@ -109,36 +139,47 @@ __global__ __launch_bounds__(256) void conv_mfma_f32_kernel(const ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    load_global(0);
-    store_lds(0);
-    __syncthreads();
-
     const int frow = lane & 31, fk = (lane >> 5) * 4;
-    for (int kt = 0; kt < a.nk; ++kt) {
+#define CONV_COMPUTE(BUF)                                                                                          \
+    do {                                                                                                           \
+        const float* Ab = As + ((size_t)(BUF) * TC + wc * (CI * 32) + frow) * LDK + fk;                            \
+        const float* Bb = Bs + ((size_t)(BUF) * TP + wp * (PI * 32) + frow) * LDK + fk;                            \
+        if (CONV_SETPRIO) __builtin_amdgcn_s_setprio(1);                                                           \
+        _Pragma("unroll") for (int kg = 0; kg < BK / 8; ++kg) {                                                    \
+            float4 af[CI], bf[PI];                                                                                 \
+            _Pragma("unroll") for (int i = 0; i < CI; ++i) af[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDK + kg * 8); \
+            _Pragma("unroll") for (int j = 0; j < PI; ++j) bf[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDK + kg * 8); \
+            _Pragma("unroll") for (int i = 0; i < CI; ++i)                                                         \
+                _Pragma("unroll") for (int j = 0; j < PI; ++j) {                                                   \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);        \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);        \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);        \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);        \
+                }                                                                                                  \
+        }                                                                                                          \
+        if (CONV_SETPRIO) __builtin_amdgcn_s_setprio(0);                                                           \
+    } while (0)
+
+    CONV_LOAD_GLOBAL(0);
+    CONV_STORE_LDS(0);
+    __syncthreads();
+    for (int kt = 0; kt + 1 < a.nk; ++kt) {            // steady state: one basic block per k-step
         const int buf = kt & 1;
-        if (kt + 1 < a.nk) load_global(kt + 1);
-        const float* Ab = As + ((size_t)buf * TC + wc * (CI * 32) + frow) * LDK + fk;
-        const float* Bb = Bs + ((size_t)buf * TP + wp * (PI * 32) + frow) * LDK + fk;
-#pragma unroll
-        for (int kg = 0; kg < 2; ++kg) {
-            float4 af[CI], bf[PI];
-#pragma unroll
-            for (int i = 0; i < CI; ++i) af[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDK + kg * 8);
-#pragma unroll
-            for (int j = 0; j < PI; ++j) bf[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDK + kg * 8);
-#pragma unroll
-            for (int i = 0; i < CI; ++i)
-#pragma unroll
-                for (int j = 0; j < PI; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-                }
-        }
-        if (kt + 1 < a.nk) store_lds(buf ^ 1);
+        CONV_LOAD_GLOBAL(kt + 1);                      // issue first: a whole k-step of MFMAs hides the latency
+#if CONV_PIN
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        CONV_COMPUTE(buf);
+#if CONV_PIN
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        CONV_STORE_LDS(buf ^ 1);
         __syncthreads();
     }
+    CONV_COMPUTE((a.nk - 1) & 1);
+#undef CONV_LOAD_GLOBAL
+#undef CONV_STORE_LDS
+#undef CONV_COMPUTE
 
     // ---- epilogue: acc row = cout (r&3)+8*(r>>2)+4*(lane>>5), col = pixel lane&31
 #pragma unroll
@@ -167,10 +208,10 @@ __global__ void pack_conv_kernel(const float* __restrict__ w, const float* __res
                                  int Kpad, float* __restrict__ wp) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)Kpad * Cout) return;
-    const int kk = (int)(idx & 15);
-    const int co = (int)((idx >> 4) % Cout);
-    const int kstep = (int)((idx >> 4) / Cout);
-    const int k = kstep * 16 + kk;
+    const int kk = (int)(idx % CONV_BK);
+    const int co = (int)((idx / CONV_BK) % Cout);
+    const int kstep = (int)((idx / CONV_BK) / Cout);
+    const int k = kstep * CONV_BK + kk;
     const int Cp = 4 * ((Cin + 3) / 4);
     const int tap = k / Cp, cp = k - tap * Cp;
     float v = 0.f;
@@ -196,7 +237,7 @@ __global__ void pack_bias_kernel(const float* __restrict__ gamma, const float* _
     bp[co] = (float)b;
 }
 
-static inline int conv_kpad(int Cin, int ks) { return ((ks * ks * 4 * ((Cin + 3) / 4) + 15) / 16) * 16; }
+static inline int conv_kpad(int Cin, int ks) { return ((ks * ks * 4 * ((Cin + 3) / 4) + CONV_BK - 1) / CONV_BK) * CONV_BK; }
 
 extern "C" size_t cnm_packed_conv_floats(int Cout, int Cin, int ksize) {
     if (Cout <= 0 || Cin <= 0 || ksize <= 0) return 0;
@@ -240,19 +281,31 @@ static int conv_dispatch(const float* in, int Gin_total, int gin0, int Gin,
     CNM_REQUIRE((ksize == 3 || ksize == 5 || ksize == 7) && (stride == 1 || stride == 2), CNM_ERR_BAD_ARG);
     ConvArgs a;
     a.in = in; a.out = out; a.w = w_packed; a.bias = b_packed;
-    a.in2 = (Gsplit < Gin) ? in2 : nullptr; a.Gin2_tot = Gin2_total; a.gin2_0 = gin2_0; a.Gsplit = Gsplit;
+    const bool two = Gsplit < Gin;
+    const unsigned long long b1 = (unsigned long long)N * Gin_total * H * W * 16ull;
+    const unsigned long long b2 = two ? (unsigned long long)N * Gin2_total * H * W * 16ull : b1;
+    CNM_REQUIRE(b1 < 0xFFFFFFFFull && b2 < 0xFFFFFFFFull, CNM_ERR_BAD_ARG);   // 32-bit buffer offsets
+    CNM_REQUIRE(Gin >= CONV_BK / 4, CNM_ERR_BAD_ARG);                          // loader: one tap wrap per k-step
+    a.in2 = two ? in2 : in; a.Gin2_tot = two ? Gin2_total : Gin_total; a.gin2_0 = two ? gin2_0 : gin0; a.Gsplit = Gsplit;
+    a.in_bytes = (unsigned)b1; a.in2_bytes = (unsigned)b2;
     a.N = N; a.H = H; a.W = W;
     a.ks = ksize; a.stride = stride; a.pad = (ksize - 1) / 2;
     a.Ho = (H + 2 * a.pad - ksize) / stride + 1; a.Wo = (W + 2 * a.pad - ksize) / stride + 1;
     a.Gin_tot = Gin_total; a.gin0 = gin0; a.Gin = Gin;
     a.Gout_tot = Gout_total; a.gout0 = gout0; a.Cout = Cout;
-    a.nk = ((ksize * ksize * 4 * Gin + 15) / 16);
+    a.nk = ((ksize * ksize * 4 * Gin + CONV_BK - 1) / CONV_BK);
     a.M = N * a.Ho * a.Wo; a.relu = relu;
     hipStream_t s = cnm_stream(stream);
     // Tile choice: largest tile that still gives every CU (256) a couple of workgroups.
     const long long t128 = (long long)(Cout / 128) * cnm_ceil_div(a.M, 128);
     const long long t64x128 = (long long)(Cout / 64) * cnm_ceil_div(a.M, 128);
+#ifdef CONV_TRY_256
+    if (Cout % 128 == 0 && t128 >= 1024) { launch_conv<128, 256>(a, s); CNM_LAUNCH_CHECK(); return CNM_OK; }
+#endif
     if (Cout % 128 == 0 && t128 >= 512) launch_conv<128, 128>(a, s);
+#ifdef CONV_TRY_64x256
+    else if (Cout == 64 && t64x128 >= 2048) launch_conv<64, 256>(a, s);
+#endif
     else if (t64x128 >= 512) launch_conv<64, 128>(a, s);
     else launch_conv<64, 64>(a, s);
     CNM_LAUNCH_CHECK();
