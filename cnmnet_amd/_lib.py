@@ -41,6 +41,7 @@ PROTOTYPES = {
     "cnm_pack_head_f32": (c_i, [c_fp, c_i, c_fp, c_fp]),
     "cnm_head_sigmoid_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_fp, c_f, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "cnm_refine_assemble_c4_f32": (c_i, [c_fp, c_fp, c_ll, c_fp, c_i, c_i, c_fp, c_i, c_i, c_fp, c_i, c_i, c_i, c_i, c_fp]),
+    "cnm_refine_assemble_multi_c4_f32": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "cnm_nchw_to_c4_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "cnm_c4_to_nchw_f32": (c_i, [c_fp, c_i, c_i, c_fp, c_i, c_i, c_i, c_i, c_fp]),
     "cnm_net_num_layers": (c_i, [c_i]),
@@ -51,6 +52,8 @@ PROTOTYPES = {
     "cnm_refinenet_workspace_floats": (c_sz, [c_i, c_i, c_i]),
     "cnm_refinenet_forward_f32": (c_i, [C.POINTER(LayerWeights), c_f, c_fp, c_fp, c_ll, c_fp, c_i, c_i, c_fp, c_i, c_i,
                                         c_fp, c_fp, c_fp, c_fp, c_sz, c_i, c_i, c_i, c_fp]),
+    "cnm_refinenet_forward_multi_f32": (c_i, [C.POINTER(LayerWeights), c_f, c_fp, c_fp, c_i, c_fp, c_fp, c_fp,
+                                              c_fp, c_sz, c_i, c_i, c_i, c_fp]),
     "cnm_depth2normal_f32": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "cnm_intrinsics_inverse_f32": (c_i, [c_fp, c_ll, c_fp, c_i, c_fp]),
     "cnm_inverse_warp_f32": (c_i, [c_fp] * 6 + [c_i, c_i, c_i, c_i, c_fp]),

@@ -175,24 +175,13 @@ extern "C" size_t cnm_refinenet_workspace_floats(int N, int H, int W) {
     return carve_refine(nullptr, N, H, W, &b);
 }
 
-extern "C" int cnm_refinenet_forward_f32(const cnm_layer_weights* wt, float idepth_scale,
-                                         const float* idepth01, const float* idepth02, long long idepth_stride,
-                                         const float* iconv01, int G1_total, int g1,
-                                         const float* iconv02, int G2_total, int g2,
-                                         float* disp_refined, float* prob_map, float* iconv1_depth_c4,
-                                         float* ws, size_t ws_floats, int N, int H, int W, void* stream) {
-    CNM_REQUIRE(wt && idepth01 && idepth02 && iconv01 && iconv02 && disp_refined && prob_map && ws && N > 0, CNM_ERR_BAD_ARG);
-    CNM_REQUIRE(H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0, CNM_ERR_BAD_SHAPE);
-    for (int i = 0; i < R_NUM; ++i) CNM_REQUIRE(wt[i].w && wt[i].b, CNM_ERR_BAD_ARG);
-    RefineBufs b;
-    CNM_REQUIRE(carve_refine(ws, N, H, W, &b) <= ws_floats, CNM_ERR_WORKSPACE);
+static int refinenet_body(const cnm_layer_weights* wt, float idepth_scale, const RefineBufs& b,
+                          float* disp_refined, float* prob_map, float* iconv1_depth_c4, int N, int H, int W, void* s) {
     const int H1 = H / 2, W1 = W / 2, H2 = H / 4, W2 = W / 4, H3 = H / 8, W3 = W / 8;
-    void* s = stream;
 #define CONV(L, in, Gt, g0, Gin, out, Gto, go0, Cout, HH, WW) \
     CNM_TRY(cnm_conv2d_c4_f32(in, Gt, g0, Gin, out, Gto, go0, Cout, wt[L].w, wt[L].b, N, HH, WW, 3, kRefineLayers[L].stride, 1, s))
 #define CONV2(L, ina, Ga, inb, Gb, out, Gto, Cout, HH, WW) \
     CNM_TRY(cnm_conv2d_cat2_c4_f32(ina, Ga, 0, Ga, inb, Gb, 0, Gb, out, Gto, 0, Cout, wt[L].w, wt[L].b, N, HH, WW, 3, 1, 1, s))
-    CNM_TRY(cnm_refine_assemble_c4_f32(idepth01, idepth02, idepth_stride, iconv01, G1_total, g1, iconv02, G2_total, g2, b.X, N, 64, H, W, s));  // :332-333
     CONV(R_CONV1_0, b.X, 17, 0, 17, b.A1, 32, 0, 128, H, W);
     CONV(R_CONV1_3, b.A1, 32, 0, 32, b.C1, 32, 0, 128, H, W);
     CONV(R_CONV2_0, b.C1, 32, 0, 32, b.A2, 64, 0, 256, H1, W1);
@@ -218,4 +207,32 @@ extern "C" int cnm_refinenet_forward_f32(const cnm_layer_weights* wt, float idep
 #undef CONV
 #undef CONV2
     return CNM_OK;
+}
+
+extern "C" int cnm_refinenet_forward_f32(const cnm_layer_weights* wt, float idepth_scale,
+                                         const float* idepth01, const float* idepth02, long long idepth_stride,
+                                         const float* iconv01, int G1_total, int g1,
+                                         const float* iconv02, int G2_total, int g2,
+                                         float* disp_refined, float* prob_map, float* iconv1_depth_c4,
+                                         float* ws, size_t ws_floats, int N, int H, int W, void* stream) {
+    CNM_REQUIRE(wt && idepth01 && idepth02 && iconv01 && iconv02 && disp_refined && prob_map && ws && N > 0, CNM_ERR_BAD_ARG);
+    CNM_REQUIRE(H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0, CNM_ERR_BAD_SHAPE);
+    for (int i = 0; i < R_NUM; ++i) CNM_REQUIRE(wt[i].w && wt[i].b, CNM_ERR_BAD_ARG);
+    RefineBufs b;
+    CNM_REQUIRE(carve_refine(ws, N, H, W, &b) <= ws_floats, CNM_ERR_WORKSPACE);
+    CNM_TRY(cnm_refine_assemble_c4_f32(idepth01, idepth02, idepth_stride, iconv01, G1_total, g1, iconv02, G2_total, g2, b.X, N, 64, H, W, stream));  // :332-333
+    return refinenet_body(wt, idepth_scale, b, disp_refined, prob_map, iconv1_depth_c4, N, H, W, stream);
+}
+
+extern "C" int cnm_refinenet_forward_multi_f32(const cnm_layer_weights* wt, float idepth_scale,
+                                               const float* idepth_pairs, const float* iconv_pairs_c4, int S,
+                                               float* disp_refined, float* prob_map, float* iconv1_depth_c4,
+                                               float* ws, size_t ws_floats, int B, int H, int W, void* stream) {
+    CNM_REQUIRE(wt && idepth_pairs && iconv_pairs_c4 && disp_refined && prob_map && ws && B > 0 && S >= 2 && S % 2 == 0, CNM_ERR_BAD_ARG);
+    CNM_REQUIRE(H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0, CNM_ERR_BAD_SHAPE);
+    for (int i = 0; i < R_NUM; ++i) CNM_REQUIRE(wt[i].w && wt[i].b, CNM_ERR_BAD_ARG);
+    RefineBufs b;
+    CNM_REQUIRE(carve_refine(ws, B, H, W, &b) <= ws_floats, CNM_ERR_WORKSPACE);
+    CNM_TRY(cnm_refine_assemble_multi_c4_f32(idepth_pairs, iconv_pairs_c4, b.X, B, S, 64, H, W, stream));
+    return refinenet_body(wt, idepth_scale, b, disp_refined, prob_map, iconv1_depth_c4, B, H, W, stream);
 }

@@ -157,6 +157,49 @@ extern "C" int cnm_refine_assemble_c4_f32(const float* idepth01, const float* id
     return CNM_OK;
 }
 
+// Multi-source variant (reference eval.py:656-663 for S=4, :917-929 for S=6): the S pairs of frame b
+// (p = b*S + s) are averaged into the two refine sides -- even sources -> side 1, odd -> side 2 --
+// as (a + c) * 0.5 resp. (a + c + e) / 3, then assembled as above.  S = 2 reduces to the plain case.
+__global__ __launch_bounds__(256) void refine_assemble_multi_c4_kernel(const float* __restrict__ idp, const float* __restrict__ f,
+                                                                       float* __restrict__ x, int B, int S, int G, int HW) {
+    const long long total = (long long)B * (G + 1) * HW;
+    const int h = S / 2;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int pix = (int)(idx % HW);
+        const long long r = idx / HW;
+        const int g = (int)(r % (G + 1)), b = (int)(r / (G + 1));
+        float4 v;
+        if (g < G) {
+            float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+            for (int k = 0; k < h; ++k) {
+                const float4 a = *reinterpret_cast<const float4*>(f + c4_offset(b * S + 2 * k, G, g, HW, pix));
+                const float4 c = *reinterpret_cast<const float4*>(f + c4_offset(b * S + 2 * k + 1, G, g, HW, pix));
+                s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w; s2.x += c.x; s2.y += c.y; s2.z += c.z; s2.w += c.w;
+            }
+            if (h == 2) { s1.x *= 0.5f; s1.y *= 0.5f; s1.z *= 0.5f; s1.w *= 0.5f; s2.x *= 0.5f; s2.y *= 0.5f; s2.z *= 0.5f; s2.w *= 0.5f; }
+            else if (h > 2) { const float d = (float)h; s1.x /= d; s1.y /= d; s1.z /= d; s1.w /= d; s2.x /= d; s2.y /= d; s2.z /= d; s2.w /= d; }
+            v = make_float4(s1.x + s2.x, s1.y + s2.y, s1.z + s2.z, s1.w + s2.w);
+        } else {
+            float a = 0.f, c = 0.f;
+            for (int k = 0; k < h; ++k) { a += idp[(size_t)(b * S + 2 * k) * HW + pix]; c += idp[(size_t)(b * S + 2 * k + 1) * HW + pix]; }
+            if (h == 2) { a *= 0.5f; c *= 0.5f; } else if (h > 2) { a /= (float)h; c /= (float)h; }
+            v = make_float4(a, c, fabsf(a - c), 0.f);
+        }
+        *reinterpret_cast<float4*>(x + c4_offset(b, G + 1, g, HW, pix)) = v;
+    }
+}
+
+extern "C" int cnm_refine_assemble_multi_c4_f32(const float* idepth_pairs, const float* feat_pairs_c4, float* x,
+                                                int B, int S, int C, int H, int W, void* stream) {
+    CNM_REQUIRE(idepth_pairs && feat_pairs_c4 && x && B > 0 && S >= 2 && S % 2 == 0 && C > 0 && C % 4 == 0 && H > 0 && W > 0, CNM_ERR_BAD_ARG);
+    const long long total = (long long)B * (C / 4 + 1) * H * W;
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    refine_assemble_multi_c4_kernel<<<blocks, 256, 0, cnm_stream(stream)>>>(idepth_pairs, feat_pairs_c4, x, B, S, C / 4, H * W);
+    CNM_LAUNCH_CHECK();
+    return CNM_OK;
+}
+
 // ------------------------------------------------------------------ layout converters
 __global__ __launch_bounds__(256) void nchw_to_c4_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                          int Gt, int g0, int N, int C, int HW) {

@@ -6,3 +6,4 @@ intended drop-in."""
 from .depthNet_model import depthNet, DepthRefineNet          # noqa: F401
 from .depth_util import Depth2normal, process_camera_parameters, get_pixel_coordinates  # noqa: F401
 from .inverse_warp import inverse_warp, pixel2cam              # noqa: F401
+from .losses import IdepthLoss, IdepthLoss_234, IdepthwithProbLoss, surface_normal_loss  # noqa: F401

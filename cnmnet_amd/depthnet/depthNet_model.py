@@ -217,6 +217,26 @@ class DepthRefineNet(_EngineNet):
                 ws.data_ptr(), ws.numel(), N, H, W, torch.cuda.current_stream().cuda_stream))
         return disp, prob, vol
 
+    def forward_multi(self, idepth_pairs, feat_pairs_c4, S, return_volume=False):
+        """S (even) sources per frame from ONE depthNet.forward_pairs call: disp1 [B*S,1,H,W] and
+        iconv1 c4 [B*S,16,H,W,4]; even sources average into side 1, odd into side 2
+        (reference eval.py:656-663 for S=4, :917-929 for S=6; S=2 is the plain two-view case)."""
+        self._require_eval_on_gpu(idepth_pairs, feat_pairs_c4)
+        self._ensure_packed()
+        P, _, H, W = idepth_pairs.shape
+        B = P // S
+        lib, dev = _lib.load(), idepth_pairs.device
+        disp = torch.empty(B, 1, H, W, device=dev, dtype=torch.float32)
+        prob = torch.empty_like(disp)
+        vol = torch.empty(B, 16, H, W, 4, device=dev, dtype=torch.float32) if return_volume else None
+        ws = self._workspace(dev, lib.cnm_refinenet_workspace_floats(B, H, W))
+        with torch.cuda.device(dev):
+            _lib.check(lib.cnm_refinenet_forward_multi_f32(
+                self._weights_arr, float(self.idepth_scale), idepth_pairs.contiguous().data_ptr(), feat_pairs_c4.data_ptr(), S,
+                disp.data_ptr(), prob.data_ptr(), vol.data_ptr() if vol is not None else 0,
+                ws.data_ptr(), ws.numel(), B, H, W, torch.cuda.current_stream().cuda_stream))
+        return disp, prob, vol
+
     def forward(self, idepth01, idepth02, iconv01, iconv02, ReturnVolume=False):
         self._require_eval_on_gpu(idepth01, idepth02, iconv01, iconv02)
         N, _, H, W = idepth01.shape

@@ -22,16 +22,18 @@ class FramePipeline(torch.nn.Module):
         -> dict(disp, prob, disp_pairs[, normal, points])."""
         B, V, _, H, W = images.shape
         S = V - 1
-        if S != 2:
-            raise NotImplementedError("S=%d sources: the averaged 4/6-source fusion (eval.py:659-663, :920-929) "
-                                      "is not built yet; use S=2" % S)
+        if S < 2 or S % 2:
+            raise ValueError("a frame needs an even number (2, 4, 6) of source views, got %d" % S)
         ref, src = images[:, 0], images[:, 1:]
         disp_pairs, feat = self.depth_net.forward_pairs(ref, src, cams[:, 0], cams[:, 1:])
         d1 = disp_pairs[0]                                   # [B*S,1,H,W], pair p = b*S + s
         HW = H * W
-        flat = d1.view(-1)
-        id1, id2 = flat, flat[HW:]                           # side s of image b starts at (b*S+s)*HW
-        disp, prob, _ = self.refine_net.forward_c4(id1, id2, S * HW, feat, S * 16, 0, feat, S * 16, 16, B, H, W)
+        if S == 2:
+            flat = d1.view(-1)
+            id1, id2 = flat, flat[HW:]                       # side s of image b starts at (b*S+s)*HW
+            disp, prob, _ = self.refine_net.forward_c4(id1, id2, S * HW, feat, S * 16, 0, feat, S * 16, 16, B, H, W)
+        else:                                                # 4 / 6 sources: averaged sides (eval.py:656-663, :917-929)
+            disp, prob, _ = self.refine_net.forward_multi(d1, feat, S)
         out = {"disp": disp, "prob": prob, "disp_pairs": disp_pairs, "disp_a": d1[0::S], "disp_b": d1[1::S]}
         if self.normals:
             k_inv = ops.intrinsics_inverse(cams[:, 0])

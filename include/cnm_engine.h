@@ -135,6 +135,12 @@ int cnm_refine_assemble_c4_f32(const float* idepth01, const float* idepth02, lon
                                const float* f2, int G2_total, int g2,
                                float* x, int N, int C, int H, int W, void* stream);
 
+/* Multi-source variant (eval.py:656-663 for S=4, :917-929 for S=6): idepth_pairs [B*S,H,W] and
+ * feat_pairs_c4 [B*S,C/4,H,W,4] are one depthnet call's outputs, pair p = b*S + s; even sources are
+ * averaged into side 1, odd into side 2 ((a+c)*0.5, (a+c+e)/3.), then assembled as above. S even. */
+int cnm_refine_assemble_multi_c4_f32(const float* idepth_pairs, const float* feat_pairs_c4, float* x,
+                                     int B, int S, int C, int H, int W, void* stream);
+
 /* Layout converters at the module boundary (NCHW torch tensors <-> c4 views). */
 int cnm_nchw_to_c4_f32(const float* nchw, float* c4, int G_total, int g0, int N, int C, int H, int W, void* stream);
 int cnm_c4_to_nchw_f32(const float* c4, int G_total, int g0, float* nchw, int N, int C, int H, int W, void* stream);
@@ -177,6 +183,13 @@ int cnm_refinenet_forward_f32(const cnm_layer_weights* weights, float idepth_sca
                               const float* iconv02, int G2_total, int g2,
                               float* disp_refined, float* prob_map, float* iconv1_depth_c4,
                               float* ws, size_t ws_floats, int N, int H, int W, void* stream);
+
+/* Same for a frame with S (even) sources processed by ONE depthnet call (eval.py:635-663, :885-929):
+ * idepth_pairs = disp1 [B*S,1,H,W], iconv_pairs_c4 = iconv1 [B*S,16,H,W,4]; workspace as for N = B. */
+int cnm_refinenet_forward_multi_f32(const cnm_layer_weights* weights, float idepth_scale,
+                                    const float* idepth_pairs, const float* iconv_pairs_c4, int S,
+                                    float* disp_refined, float* prob_map, float* iconv1_depth_c4,
+                                    float* ws, size_t ws_floats, int B, int H, int W, void* stream);
 
 /* ---------------------------------------------------------------- depth -> normal (K6)
  * Replaces Depth2normal.forward without the plane branch (depth_util.py:149-203):

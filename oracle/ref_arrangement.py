@@ -239,3 +239,22 @@ def frame_forward(depth_net, refine_net, ref, src1, src2, ref_cam, cam1, cam2, k
         K_inv = ref_cam[:, 1, :3, :3].inverse()
         out["normal"], out["points"] = depth_to_normal(depth, K_inv, k_size)        # eval.py:455
     return out
+
+
+@torch.no_grad()
+def frame_forward_multi(depth_net, refine_net, images, cams):
+    """S = 4 / 6 sources: ref replicated, sources stacked on the batch axis, ONE depth_net call,
+    even/odd outputs averaged into the two refine sides (eval.py:635-663 for S=4, :885-929 for S=6).
+    images [1+S,3,H,W], cams [1+S,2,4,4] for ONE frame."""
+    S = images.shape[0] - 1
+    outs, feat = depth_net(images[0:1].repeat(S, 1, 1, 1), images[1:], cams[0:1].repeat(S, 1, 1, 1), cams[1:])
+    d = outs[0]
+    if S == 4:
+        a, b = (d[0:1] + d[2:3]) * 0.5, (d[1:2] + d[3:4]) * 0.5
+        fa, fb = (feat[0:1] + feat[2:3]) * 0.5, (feat[1:2] + feat[3:4]) * 0.5
+    elif S == 6:
+        a, b = (d[0:1] + d[2:3] + d[4:5]) / 3., (d[1:2] + d[3:4] + d[5:6]) / 3.
+        fa, fb = (feat[0:1] + feat[2:3] + feat[4:5]) / 3., (feat[1:2] + feat[3:4] + feat[5:6]) / 3.
+    else:
+        raise ValueError(S)
+    return refine_net(idepth01=a, idepth02=b, iconv01=fa, iconv02=fb)

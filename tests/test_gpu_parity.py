@@ -205,6 +205,21 @@ def test_depthnet_other_plane_counts_vs_oracle(dev, planes, S):
             assert _stats(ops.c4_to_nchw(feat[s::S].contiguous()).cpu().numpy(), f.numpy())[2] < 1e-4 * float(f.abs().max())
 
 
+@pytest.mark.parametrize("S", [4, 6])
+def test_multi_source_frame_vs_oracle(dev, S):
+    """a-8: 4- and 6-source fusion (eval.py:635-663, :885-929) through the frame pipeline."""
+    from cnmnet_amd.depthnet import depthNet, DepthRefineNet
+    from cnmnet_amd.pipeline import FramePipeline
+    img, cams = syn.frames(2, S, 32, 64, seed=90 + S)
+    pipe = FramePipeline(_load(depthNet(3.0), 31).to(dev), _load(DepthRefineNet(32, 3.0), 32).to(dev), normals=False)
+    out = pipe(T(img).to(dev), T(cams).to(dev))
+    cd, cr = _load(ra.DepthNetCPU(3.0), 31), _load(ra.DepthRefineNetCPU(32, 3.0), 32)
+    for b in range(2):
+        disp, prob = ra.frame_forward_multi(cd, cr, T(img[b]), T(cams[b]))
+        assert _stats(out["disp"][b:b + 1].cpu().numpy(), disp.numpy())[2] < 1e-3
+        assert _stats(out["prob"][b:b + 1].cpu().numpy(), prob.numpy())[2] < 1e-3
+
+
 def test_error_behaviour(dev):
     from cnmnet_amd import _lib
     from cnmnet_amd.depthnet import depthNet, inverse_warp
