@@ -46,6 +46,9 @@
 #ifndef SWEEP_DEFER
 #define SWEEP_DEFER 0         // 1: issue the stores of group g after the barrier of group g+1
 #endif
+#ifndef SWEEP_ASM_DMA
+#define SWEEP_ASM_DMA 0       // 1: LDS-DMA from inline asm + counted vmcnt (measured: no gain over the builtin, kept for study)
+#endif
 #define SWEEP_NT (SWEEP_TW * SWEEP_TH)   // threads per workgroup (256 or 512)
 
 struct SweepArgs {
@@ -341,8 +344,20 @@ __global__ __launch_bounds__(SWEEP_NT) void planesweep_kernel(const SweepArgs a)
             const int i = i0 + lane;
             if (i < n) {
                 const int r = (int)(((float)i + 0.5f) * inv_rw), c = i - r * bx.rw;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + r * TWp + c),
+                const float4* gsrc = base + r * TWp + c;
+#if SWEEP_ASM_DMA
+                // hipcc does not see this load: it is waited for with a COUNTED vmcnt before the barrier,
+                // so the output stores issued after it are never drained (guide 5.7: M0 set and used in
+                // one statement, s_nop 0 between the SALU write of M0 and the DMA).
+                const unsigned lds_dst = __builtin_amdgcn_readfirstlane(
+                    (unsigned)(size_t)(__attribute__((address_space(3))) float4*)(tb + i0));
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+#else
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                                  (__attribute__((address_space(3))) void*)(tb + i0), 16, 0, 0);
+#endif
             }
         }
     };
@@ -370,6 +385,8 @@ __global__ __launch_bounds__(SWEEP_NT) void planesweep_kernel(const SweepArgs a)
         }
     };
     TRACE(1);
+    // counted waits need a fixed number of stores per wave and group: full tiles and full groups only
+    const bool counted = __builtin_amdgcn_readfirstlane((tx0 + SWEEP_TW <= W) && (ty0 + SWEEP_TH <= H) && (D % SWEEP_PG == 0) && !SWEEP_DEFER);
     SweepBox cur = box_of(0);
     if (cur.staged) stage(cur, tex[0]);
     TRACE(2);
@@ -381,7 +398,12 @@ __global__ __launch_bounds__(SWEEP_NT) void planesweep_kernel(const SweepArgs a)
 #endif
         TRACE(3 + 4 * g);
 #ifndef SWEEP_ABL_NOGROUPSYNC
-        __syncthreads();   // box g has landed (vmcnt(0) + barrier); every wave is done reading the other buffer
+#if SWEEP_ASM_DMA
+        // DMA(g) was issued before the stores of group g-1: wait for it but not for those stores
+        if (counted && g > 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LAYOUT == 0 ? SWEEP_PG : SWEEP_PG / 4) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        __syncthreads();   // box g has landed; every wave is done reading the other buffer
 #endif
         TRACE(4 + 4 * g);
         if (SWEEP_DEFER && g > 0) emit(d0 - SWEEP_PG);
