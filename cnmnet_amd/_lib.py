@@ -54,6 +54,14 @@ PROTOTYPES = {
                                         c_fp, c_fp, c_fp, c_fp, c_sz, c_i, c_i, c_i, c_fp]),
     "cnm_refinenet_forward_multi_f32": (c_i, [C.POINTER(LayerWeights), c_f, c_fp, c_fp, c_i, c_fp, c_fp, c_fp,
                                               c_fp, c_sz, c_i, c_i, c_i, c_fp]),
+    "cnm_packed_dgrad_floats": (c_sz, [c_i, c_i, c_i]),
+    "cnm_pack_conv_dgrad_f32": (c_i, [c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp]),
+    "cnm_conv2d_dgrad_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    "cnm_conv2d_wgrad_workspace_floats": (c_sz, [c_i, c_i, c_i, c_i, c_i, c_i]),
+    "cnm_conv2d_wgrad_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_sz, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    "cnm_bn_train_forward_c4_f32": (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_f, c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp]),
+    "cnm_bn_train_backward_c4_f32": (c_i, [c_fp] * 6 + [c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp]),
+    "cnm_upsample2x_backward_c4_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp]),
     "cnm_depth2normal_f32": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "cnm_intrinsics_inverse_f32": (c_i, [c_fp, c_ll, c_fp, c_i, c_fp]),
     "cnm_inverse_warp_f32": (c_i, [c_fp] * 6 + [c_i, c_i, c_i, c_i, c_fp]),

@@ -1,0 +1,164 @@
+"""torch.autograd.Functions over the engine's forward/backward operators on c4 activations.
+
+Training path of SURVEY.md section 8 (row a-10; reference train.py:164-310 trains with stock autograd).
+torch supplies the tape, the optimizer and the elementwise glue (concatenation along channel groups,
+sigmoid of the 1-channel heads, losses); every convolution, BatchNorm and resampling -- forward and
+backward -- is a HIP kernel.  The plane sweep is a leaf without gradient.
+"""
+import torch
+
+from . import _lib, ops
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class ConvC4(torch.autograd.Function):
+    """y = conv2d(x, weight, stride, padding=(k-1)//2) on c4 tensors, no bias.
+    x [N,ceil(Cin/4),H,W,4] (channels possibly rotated by `rot`), weight OIHW; Cout % 4 == 0, >= 16."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, rot):
+        x = x.contiguous()
+        Cout, Cin, k, _ = weight.shape
+        wp, _ = ops.pack_conv(weight.detach(), None, None, rot)
+        y = ops.conv2d_c4(x, wp, None, Cout, k, stride, relu=False)
+        ctx.save_for_backward(x, weight)
+        ctx.stride, ctx.rot = stride, rot
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        Cout, Cin, k, _ = weight.shape
+        N, G, H, W, _ = x.shape
+        lib, dev = _lib.load(), x.device
+        dx = dw = None
+        with torch.cuda.device(dev):
+            if ctx.needs_input_grad[0]:
+                wd = torch.empty(lib.cnm_packed_dgrad_floats(Cout, Cin, k), device=dev, dtype=torch.float32)
+                _lib.check(lib.cnm_pack_conv_dgrad_f32(weight.detach().contiguous().data_ptr(), Cout, Cin, k, ctx.rot, wd.data_ptr(), _s()))
+                dx = torch.empty_like(x)
+                _lib.check(lib.cnm_conv2d_dgrad_c4_f32(dy.data_ptr(), dy.shape[1], 0, Cout, dx.data_ptr(), G, 0, Cin,
+                                                       wd.data_ptr(), N, H, W, k, ctx.stride, _s()))
+            if ctx.needs_input_grad[1]:
+                Ho, Wo = dy.shape[2], dy.shape[3]
+                ws = torch.empty(lib.cnm_conv2d_wgrad_workspace_floats(Cout, Cin, k, N, Ho, Wo), device=dev, dtype=torch.float32)
+                dw = torch.empty_like(weight)
+                _lib.check(lib.cnm_conv2d_wgrad_c4_f32(x.data_ptr(), G, 0, Cin, dy.data_ptr(), dy.shape[1], 0, Cout,
+                                                       dw.data_ptr(), ws.data_ptr(), ws.numel(), N, H, W, k, ctx.stride, ctx.rot, _s()))
+        return dx, dw, None, None
+
+
+class BatchNormReLUC4(torch.autograd.Function):
+    """nn.BatchNorm2d in train mode followed (optionally) by ReLU; running stats updated in place."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, relu):
+        x = x.contiguous()
+        N, G, H, W, _ = x.shape
+        C = gamma.numel()
+        lib, dev = _lib.load(), x.device
+        y = torch.empty_like(x)
+        mean = torch.empty(C, device=dev, dtype=torch.float32)
+        invstd = torch.empty_like(mean)
+        ws = torch.empty(8 * G, device=dev, dtype=torch.float64)
+        with torch.cuda.device(dev):
+            _lib.check(lib.cnm_bn_train_forward_c4_f32(
+                x.data_ptr(), gamma.detach().contiguous().data_ptr(), beta.detach().contiguous().data_ptr(),
+                running_mean.data_ptr() if running_mean is not None else 0,
+                running_var.data_ptr() if running_var is not None else 0, float(momentum), float(eps), int(relu),
+                y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(), N, C, H, W, _s()))
+        ctx.save_for_backward(x, y, gamma, mean, invstd)
+        ctx.relu = relu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, mean, invstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        N, G, H, W, _ = x.shape
+        C = gamma.numel()
+        lib, dev = _lib.load(), x.device
+        dx = torch.empty_like(x)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        ws = torch.empty(8 * G, device=dev, dtype=torch.float64)
+        with torch.cuda.device(dev):
+            _lib.check(lib.cnm_bn_train_backward_c4_f32(
+                x.data_ptr(), y.data_ptr(), dy.data_ptr(), gamma.detach().contiguous().data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                int(ctx.relu), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), N, C, H, W, _s()))
+        return dx, dgamma, dbeta, None, None, None, None, None
+
+
+class Upsample2xC4(torch.autograd.Function):
+    """nn.Upsample(scale_factor=2, mode='bilinear', align_corners=False) on c4 tensors."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return ops.upsample2x_c4(x.contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        N, G, Ho, Wo, _ = dy.shape
+        dx = torch.empty(N, G, Ho // 2, Wo // 2, 4, device=dy.device, dtype=torch.float32)
+        with torch.cuda.device(dy.device):
+            _lib.check(_lib.load().cnm_upsample2x_backward_c4_f32(dy.data_ptr(), dx.data_ptr(), N, G, Ho // 2, Wo // 2, _s()))
+        return dx
+
+
+class C4ToNCHW(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, channels):
+        ctx.groups = x.shape[1]
+        return ops.c4_to_nchw(x.contiguous(), channels)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.nchw_to_c4(dy.contiguous()), None
+
+
+class NCHWToC4(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.channels = x.shape[1]
+        return ops.nchw_to_c4(x.contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.c4_to_nchw(dy.contiguous(), ctx.channels)
+
+
+# ---------------------------------------------------------------- building blocks used by the modules in train mode
+def conv_bn_relu(x, conv, bn, rot=0):
+    """Conv2d(bias=False) -> BatchNorm2d(train) -> ReLU, as the reference's layer builders
+    (depthNet_model.py:19-112) in training mode."""
+    y = ConvC4.apply(x, conv.weight, conv.stride[0], rot)
+    out = BatchNormReLUC4.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, True)
+    if bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    return out
+
+
+def head(x, conv, scale):
+    """depth_layer: Conv2d(C,1,3,padding=1) + Sigmoid, times `scale` (depthNet_model.py:82-84,246).
+    The 1-output-channel conv runs through the MFMA kernel padded to 16 output channels (zero rows)."""
+    w = conv.weight
+    w16 = torch.cat((w, w.new_zeros(15, *w.shape[1:])), 0)
+    y = ConvC4.apply(x, w16, 1, 0)                        # [N,4,H,W,4]; channel 0 is the real one
+    return scale * torch.sigmoid(y[:, 0, :, :, 0] + conv.bias).unsqueeze(1)      # [N,1,H,W]
+
+
+def scalar_maps_to_group(*maps):
+    """Up to four [N,1,H,W] maps -> one c4 channel group [N,1,H,W,4] (missing lanes zero)."""
+    m = [t.squeeze(1) for t in maps]
+    while len(m) < 4:
+        m.append(torch.zeros_like(m[0]))
+    return torch.stack(m, -1).unsqueeze(1)
+
+
+def nearest_up2(d):
+    """F.upsample(disp, scale_factor=2) (nearest; depthNet_model.py:247,252,257)."""
+    return d.repeat_interleave(2, 2).repeat_interleave(2, 3)

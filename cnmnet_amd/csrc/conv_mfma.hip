@@ -37,7 +37,8 @@ struct ConvArgs {
     int Gin2_tot, gin2_0, Gsplit;
     int N, H, W, Ho, Wo;
     int Gin_tot, gin0, Gin;
-    int Gout_tot, gout0, Cout;
+    int Gout_tot, gout0, Cout;   // Cout: real output channels (multiple of 4); weights/tiles use Cout_pad
+    int Cout_pad;                // Cout rounded up to 64
     int ks, stride, pad;
     int nk;          // Kpad / CONV_BK
     int M;           // N*Ho*Wo
@@ -56,7 +57,10 @@ __device__ __forceinline__ float4 buffer_load_f4(const float* base, unsigned byt
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
-template <int TC, int TP>
+// TS = 1: ordinary convolution (any stride, via a.stride).  TS = 2: transposed stride-2 gather used by the
+// data gradient of a stride-2 layer: tap (a,b) of output pixel (y,x) reads source pixel ((y+a-pad)/2, (x+b-pad)/2)
+// when both are even and in range (the zero-upsampled view of dy, never materialised).
+template <int TC, int TP, int TS = 1>
 __global__ __launch_bounds__(256, CONV_MINW) void conv_mfma_f32_kernel(const ConvArgs a) {
     constexpr int NT = 256, WP = 2;
     constexpr int CI = TC / 64, PI = TP / 64;          // 32x32 MFMA tiles per wave
@@ -69,7 +73,7 @@ __global__ __launch_bounds__(256, CONV_MINW) void conv_mfma_f32_kernel(const Con
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wc = wave / WP, wp = wave % WP;
-    const int tilesC = a.Cout / TC;
+    const int tilesC = a.Cout_pad / TC;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int c0 = (tile % tilesC) * TC, m0 = (tile / tilesC) * TP;
     const int HW = a.H * a.W, HoWo = a.Ho * a.Wo;
@@ -85,7 +89,7 @@ __global__ __launch_bounds__(256, CONV_MINW) void conv_mfma_f32_kernel(const Con
         const int img = mm / HoWo, rem = mm - img * HoWo;
         const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
         iy0 = oy * a.stride - a.pad; ix0 = ox * a.stride - a.pad;
-        const unsigned pix0 = (unsigned)(iy0 * a.W + ix0);
+        const unsigned pix0 = TS == 1 ? (unsigned)(iy0 * a.W + ix0) : 0u;
         vb1 = ((unsigned)(img * a.Gin_tot + a.gin0) * (unsigned)HW + pix0) * 16u;
         vb2 = ((unsigned)(img * a.Gin2_tot + a.gin2_0) * (unsigned)HW + pix0) * 16u;
     }
@@ -105,12 +109,19 @@ __global__ __launch_bounds__(256, CONV_MINW) void conv_mfma_f32_kernel(const Con
 #define CONV_LOAD_GLOBAL(KT)                                                                                       \
     do {                                                                                                           \
         _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i)                                                        \
-            ra[i] = *reinterpret_cast<const float4*>(wtile + (size_t)(KT) * a.Cout * BK + (size_t)(t + i * NT) * 4); \
+            ra[i] = *reinterpret_cast<const float4*>(wtile + (size_t)(KT) * a.Cout_pad * BK + (size_t)(t + i * NT) * 4); \
         _Pragma("unroll") for (int i = 0; i < B_LOADS; ++i) {                                                      \
             const int iy = iy0 + bky[i], ix = ix0 + bkx[i];                                                        \
-            const bool ok = mvalid && bky[i] < a.ks && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W; \
+            bool ok = mvalid && bky[i] < a.ks;                                                                      \
+            unsigned tapoff;                                                                                       \
+            if (TS == 1) {                                                                                         \
+                ok = ok && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;                           \
+                tapoff = (unsigned)(bky[i] * a.W + bkx[i]) * 16u;                                                  \
+            } else {                                                                                               \
+                ok = ok && !((iy | ix) & 1) && (unsigned)(iy >> 1) < (unsigned)a.H && (unsigned)(ix >> 1) < (unsigned)a.W; \
+                tapoff = (unsigned)((iy >> 1) * a.W + (ix >> 1)) * 16u;                                            \
+            }                                                                                                      \
             const bool s1 = bg[i] < a.Gsplit;                                            /* wave-uniform */         \
-            const unsigned tapoff = (unsigned)(bky[i] * a.W + bkx[i]) * 16u;                                        \
             const unsigned voff = ok ? (s1 ? vb1 : vb2) + tapoff : 0xFFFFFFFFu;                                     \
             rb[i] = buffer_load_f4(s1 ? a.in : a.in2, s1 ? a.in_bytes : a.in2_bytes, voff,                          \
                                    (unsigned)(s1 ? bg[i] : bg[i] - a.Gsplit) * HW16);                              \
@@ -192,7 +203,8 @@ __global__ __launch_bounds__(256, CONV_MINW) void conv_mfma_f32_kernel(const Con
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
                 const int c = c0 + (wc * CI + i) * 32 + 8 * qd + 4 * (lane >> 5);
-                const float4 b = *reinterpret_cast<const float4*>(a.bias + c);
+                if (c >= a.Cout) continue;
+                const float4 b = a.bias ? *reinterpret_cast<const float4*>(a.bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
                 float4 v = make_float4(acc[i][j][4 * qd + 0] + b.x, acc[i][j][4 * qd + 1] + b.y,
                                        acc[i][j][4 * qd + 2] + b.z, acc[i][j][4 * qd + 3] + b.w);
                 if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
@@ -204,18 +216,18 @@ __global__ __launch_bounds__(256, CONV_MINW) void conv_mfma_f32_kernel(const Con
 
 // ------------------------------------------------------------------ weight packing
 __global__ void pack_conv_kernel(const float* __restrict__ w, const float* __restrict__ gamma,
-                                 const float* __restrict__ var, float eps, int Cout, int Cin, int ks, int rot,
+                                 const float* __restrict__ var, float eps, int Cout, int Cout_pad, int Cin, int ks, int rot,
                                  int Kpad, float* __restrict__ wp) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)Kpad * Cout) return;
+    if (idx >= (long long)Kpad * Cout_pad) return;
     const int kk = (int)(idx % CONV_BK);
-    const int co = (int)((idx / CONV_BK) % Cout);
-    const int kstep = (int)((idx / CONV_BK) / Cout);
+    const int co = (int)((idx / CONV_BK) % Cout_pad);
+    const int kstep = (int)((idx / CONV_BK) / Cout_pad);
     const int k = kstep * CONV_BK + kk;
     const int Cp = 4 * ((Cin + 3) / 4);
     const int tap = k / Cp, cp = k - tap * Cp;
     float v = 0.f;
-    if (tap < ks * ks && cp < Cin) {
+    if (tap < ks * ks && cp < Cin && co < Cout) {
         const int ci = (cp + rot) % Cin;
         double s = 1.0;
         if (gamma) s = (double)gamma[co] / sqrt((double)var[co] + (double)eps);
@@ -237,11 +249,12 @@ __global__ void pack_bias_kernel(const float* __restrict__ gamma, const float* _
     bp[co] = (float)b;
 }
 
+static inline int round64(int c) { return (c + 63) / 64 * 64; }
 static inline int conv_kpad(int Cin, int ks) { return ((ks * ks * 4 * ((Cin + 3) / 4) + CONV_BK - 1) / CONV_BK) * CONV_BK; }
 
 extern "C" size_t cnm_packed_conv_floats(int Cout, int Cin, int ksize) {
     if (Cout <= 0 || Cin <= 0 || ksize <= 0) return 0;
-    return (size_t)conv_kpad(Cin, ksize) * (size_t)Cout;
+    return (size_t)conv_kpad(Cin, ksize) * (size_t)round64(Cout);
 }
 
 extern "C" int cnm_pack_conv_bn_f32(const float* w_oihw, const float* bn_gamma, const float* bn_beta,
@@ -253,31 +266,34 @@ extern "C" int cnm_pack_conv_bn_f32(const float* w_oihw, const float* bn_gamma, 
     const bool bn = bn_gamma || bn_beta || bn_mean || bn_var;
     CNM_REQUIRE(!bn || (bn_gamma && bn_beta && bn_mean && bn_var), CNM_ERR_BAD_ARG);
     const int Kpad = conv_kpad(Cin, ksize);
-    const long long total = (long long)Kpad * Cout;
+    const long long total = (long long)Kpad * round64(Cout);
     pack_conv_kernel<<<(unsigned)cnm_ceil_div_ll(total, 256), 256, 0, cnm_stream(stream)>>>(
-        w_oihw, bn_gamma, bn_var, eps, Cout, Cin, ksize, rot, Kpad, w_packed);
+        w_oihw, bn_gamma, bn_var, eps, Cout, round64(Cout), Cin, ksize, rot, Kpad, w_packed);
     pack_bias_kernel<<<cnm_ceil_div(Cout, 256), 256, 0, cnm_stream(stream)>>>(
         bn_gamma, bn_beta, bn_mean, bn_var, bias, eps, Cout, b_packed);
     CNM_LAUNCH_CHECK();
     return CNM_OK;
 }
 
-template <int TC, int TP>
+template <int TC, int TP, int TS = 1>
 static void launch_conv(const ConvArgs& a, hipStream_t s) {
-    const int nblocks = (a.Cout / TC) * cnm_ceil_div(a.M, TP);
-    conv_mfma_f32_kernel<TC, TP><<<nblocks, 256, 0, s>>>(a);
+    const int nblocks = (a.Cout_pad / TC) * cnm_ceil_div(a.M, TP);
+    conv_mfma_f32_kernel<TC, TP, TS><<<nblocks, 256, 0, s>>>(a);
 }
 
+// out_h/out_w > 0 selects the transposed (data-gradient) gather: `in` is then dy [N,.,H,W] and the output is
+// out_h x out_w with tstride in {1,2}; otherwise an ordinary convolution with `stride`.
 static int conv_dispatch(const float* in, int Gin_total, int gin0, int Gin,
                          const float* in2, int Gin2_total, int gin2_0, int Gsplit,
                          float* out, int Gout_total, int gout0, int Cout,
                          const float* w_packed, const float* b_packed,
-                         int N, int H, int W, int ksize, int stride, int relu, void* stream) {
-    CNM_REQUIRE(in && out && w_packed && b_packed, CNM_ERR_BAD_ARG);
+                         int N, int H, int W, int ksize, int stride, int relu, void* stream,
+                         int out_h = 0, int out_w = 0, int tstride = 1) {
+    CNM_REQUIRE(in && out && w_packed, CNM_ERR_BAD_ARG);
     CNM_REQUIRE(N > 0 && H > 0 && W > 0 && Gin > 0 && Gsplit > 0 && Gsplit <= Gin, CNM_ERR_BAD_ARG);
     CNM_REQUIRE(gin0 >= 0 && gin0 + Gsplit <= Gin_total, CNM_ERR_BAD_ARG);
     CNM_REQUIRE(Gsplit == Gin || (in2 && gin2_0 >= 0 && gin2_0 + (Gin - Gsplit) <= Gin2_total), CNM_ERR_BAD_ARG);
-    CNM_REQUIRE(Cout > 0 && Cout % 64 == 0 && gout0 >= 0 && gout0 + Cout / 4 <= Gout_total, CNM_ERR_BAD_ARG);
+    CNM_REQUIRE(Cout > 0 && Cout % 4 == 0 && gout0 >= 0 && gout0 + Cout / 4 <= Gout_total, CNM_ERR_BAD_ARG);
     CNM_REQUIRE((ksize == 3 || ksize == 5 || ksize == 7) && (stride == 1 || stride == 2), CNM_ERR_BAD_ARG);
     ConvArgs a;
     a.in = in; a.out = out; a.w = w_packed; a.bias = b_packed;
@@ -289,25 +305,27 @@ static int conv_dispatch(const float* in, int Gin_total, int gin0, int Gin,
     a.in2 = two ? in2 : in; a.Gin2_tot = two ? Gin2_total : Gin_total; a.gin2_0 = two ? gin2_0 : gin0; a.Gsplit = Gsplit;
     a.in_bytes = (unsigned)b1; a.in2_bytes = (unsigned)b2;
     a.N = N; a.H = H; a.W = W;
-    a.ks = ksize; a.stride = stride; a.pad = (ksize - 1) / 2;
-    a.Ho = (H + 2 * a.pad - ksize) / stride + 1; a.Wo = (W + 2 * a.pad - ksize) / stride + 1;
+    a.ks = ksize; a.pad = (ksize - 1) / 2;
+    const bool transposed = out_h > 0;
+    if (transposed) { a.stride = 1; a.Ho = out_h; a.Wo = out_w; }             // pad' = ks-1-pad = pad for odd ks
+    else { a.stride = stride; a.Ho = (H + 2 * a.pad - ksize) / stride + 1; a.Wo = (W + 2 * a.pad - ksize) / stride + 1; }
     a.Gin_tot = Gin_total; a.gin0 = gin0; a.Gin = Gin;
-    a.Gout_tot = Gout_total; a.gout0 = gout0; a.Cout = Cout;
+    a.Gout_tot = Gout_total; a.gout0 = gout0; a.Cout = Cout; a.Cout_pad = round64(Cout);
     a.nk = ((ksize * ksize * 4 * Gin + CONV_BK - 1) / CONV_BK);
     a.M = N * a.Ho * a.Wo; a.relu = relu;
     hipStream_t s = cnm_stream(stream);
     // Tile choice: largest tile that still gives every CU (256) a couple of workgroups.
-    const long long t128 = (long long)(Cout / 128) * cnm_ceil_div(a.M, 128);
-    const long long t64x128 = (long long)(Cout / 64) * cnm_ceil_div(a.M, 128);
-#ifdef CONV_TRY_256
-    if (Cout % 128 == 0 && t128 >= 1024) { launch_conv<128, 256>(a, s); CNM_LAUNCH_CHECK(); return CNM_OK; }
-#endif
-    if (Cout % 128 == 0 && t128 >= 512) launch_conv<128, 128>(a, s);
-#ifdef CONV_TRY_64x256
-    else if (Cout == 64 && t64x128 >= 2048) launch_conv<64, 256>(a, s);
-#endif
-    else if (t64x128 >= 512) launch_conv<64, 128>(a, s);
-    else launch_conv<64, 64>(a, s);
+    const long long t128 = (long long)(a.Cout_pad / 128) * cnm_ceil_div(a.M, 128);
+    const long long t64x128 = (long long)(a.Cout_pad / 64) * cnm_ceil_div(a.M, 128);
+    if (transposed && tstride == 2) {
+        if (a.Cout_pad % 128 == 0 && t128 >= 512) launch_conv<128, 128, 2>(a, s);
+        else if (t64x128 >= 512) launch_conv<64, 128, 2>(a, s);
+        else launch_conv<64, 64, 2>(a, s);
+    } else {
+        if (a.Cout_pad % 128 == 0 && t128 >= 512) launch_conv<128, 128>(a, s);
+        else if (t64x128 >= 512) launch_conv<64, 128>(a, s);
+        else launch_conv<64, 64>(a, s);
+    }
     CNM_LAUNCH_CHECK();
     return CNM_OK;
 }
@@ -328,4 +346,54 @@ extern "C" int cnm_conv2d_cat2_c4_f32(const float* in_a, int Ga_total, int ga0, 
     CNM_REQUIRE(Ga > 0 && Gb > 0, CNM_ERR_BAD_ARG);
     return conv_dispatch(in_a, Ga_total, ga0, Ga + Gb, in_b, Gb_total, gb0, Ga, out, Gout_total, gout0, Cout,
                          w_packed, b_packed, N, H, W, ksize, stride, relu, stream);
+}
+
+// ------------------------------------------------------------------ data gradient (training)
+// dX = conv_transpose(dY, W): the same implicit GEMM with the roles of Cin/Cout swapped and the taps
+// flipped,  w'[ci][(a,b), co] = w[co][ci][ks-1-a][ks-1-b];  output channels follow the (rotated) channel
+// order of the forward input, so dX has exactly the layout of X.
+__global__ void pack_conv_dgrad_kernel(const float* __restrict__ w, int Cout, int Cin, int Cin_pad, int ks, int rot,
+                                       int Kpad, float* __restrict__ wp) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)Kpad * Cin_pad) return;
+    const int kk = (int)(idx % CONV_BK);
+    const int p = (int)((idx / CONV_BK) % Cin_pad);          // packed input-channel position = output row here
+    const int kstep = (int)((idx / CONV_BK) / Cin_pad);
+    const int k = kstep * CONV_BK + kk;
+    const int Cp = 4 * ((Cout + 3) / 4);
+    const int tap = k / Cp, co = k - tap * Cp;
+    float v = 0.f;
+    if (tap < ks * ks && co < Cout && p < Cin) {
+        const int ci = (p + rot) % Cin;
+        v = w[((size_t)co * Cin + ci) * ks * ks + (ks * ks - 1 - tap)];
+    }
+    wp[idx] = v;
+}
+
+extern "C" size_t cnm_packed_dgrad_floats(int Cout, int Cin, int ksize) {
+    if (Cout <= 0 || Cin <= 0 || ksize <= 0) return 0;
+    return (size_t)conv_kpad(Cout, ksize) * (size_t)round64(4 * ((Cin + 3) / 4));
+}
+
+extern "C" int cnm_pack_conv_dgrad_f32(const float* w_oihw, int Cout, int Cin, int ksize, int rot,
+                                       float* w_packed, void* stream) {
+    CNM_REQUIRE(w_oihw && w_packed && Cout > 0 && Cin > 0 && (ksize & 1) && rot >= 0 && rot < Cin, CNM_ERR_BAD_ARG);
+    const int Kpad = conv_kpad(Cout, ksize), Cin_pad = round64(4 * ((Cin + 3) / 4));
+    const long long total = (long long)Kpad * Cin_pad;
+    pack_conv_dgrad_kernel<<<(unsigned)cnm_ceil_div_ll(total, 256), 256, 0, cnm_stream(stream)>>>(
+        w_oihw, Cout, Cin, Cin_pad, ksize, rot, Kpad, w_packed);
+    CNM_LAUNCH_CHECK();
+    return CNM_OK;
+}
+
+extern "C" int cnm_conv2d_dgrad_c4_f32(const float* dy, int Gy_total, int gy0, int Cout,
+                                       float* dx, int Gx_total, int gx0, int Cin,
+                                       const float* w_packed_dgrad, int N, int H, int W,
+                                       int ksize, int stride, void* stream) {
+    CNM_REQUIRE(Cout > 0 && Cin > 0 && H > 0 && W > 0 && (stride == 1 || stride == 2), CNM_ERR_BAD_ARG);
+    const int pad = (ksize - 1) / 2;
+    const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
+    const int Gy = (Cout + 3) / 4;
+    return conv_dispatch(dy, Gy_total, gy0, Gy, nullptr, 0, 0, Gy, dx, Gx_total, gx0, 4 * ((Cin + 3) / 4),
+                         w_packed_dgrad, nullptr, N, Ho, Wo, ksize, 1, 0, stream, H, W, stride);
 }

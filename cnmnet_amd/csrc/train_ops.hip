@@ -1,0 +1,406 @@
+// Training-path kernels (reference train.py:164-310):
+//   weight gradient of the convolution (fp32 MFMA, split over the pixel reduction),
+//   train-mode BatchNorm2d (+ReLU) forward/backward on c4 activations (batch statistics, torch defaults),
+//   adjoint of the bilinear x2 upsample.
+// The plane sweep needs no backward: images and cameras carry no gradient.
+#include "cnm_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float4 tr_buffer_load_f4(const float* base, unsigned bytes, unsigned voff) {
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes, 0x00020000);
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+// ------------------------------------------------------------------ weight gradient
+// dWp[co][k] = sum_pix dY[co][pix] * Xcol[k][pix],  k = (ky*ks+kx)*4*Gin + cpacked  (the forward's k order).
+// GEMM with the PIXELS as the reduction dimension: tile 128 (co) x 128 (k), 16 pixels per step, split over
+// pixel ranges (grid.z) into partial buffers that a second kernel sums and scatters back to OIHW.
+struct WgradArgs {
+    const float* x; const float* dy; float* partial;
+    unsigned x_bytes, dy_bytes;
+    int N, H, W, Ho, Wo, Gx_tot, gx0, Gin, Gy_tot, gy0, Cout, Cout_pad;
+    int ks, stride, pad, Kflat, Kpad128, M, pix_per_split;
+};
+
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
+    constexpr int LDK = 20;
+    __shared__ __attribute__((aligned(16))) float smem[2 * 256 * LDK];
+    float* As = smem;                 // [2][128 co][LDK pix]
+    float* Bs = smem + 2 * 128 * LDK; // [2][128 k ][LDK pix]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wc = wave >> 1, wp = wave & 1;
+    const int c0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
+    const int HW = a.H * a.W, HoWo = a.Ho * a.Wo;
+    const int r0 = blockIdx.z * a.pix_per_split, r1 = min(r0 + a.pix_per_split, a.M);
+
+    // loader mapping: float4 slot f = t + i*256 (i = 0,1): pixel lane pl = f % 16, quad row q = f / 16 (0..31)
+    const int pl = t & 15;
+    int aq[2], bgc[2], bky[2], bkx[2]; bool bok[2], aok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = (t >> 4) + 16 * i;
+        aq[i] = c0 / 4 + q; aok[i] = (c0 + 4 * q) < a.Cout;
+        const int kq = k0 / 4 + q;                                  // flat k-quad -> (tap, channel group): fixed per thread
+        const int tap = kq / a.Gin;
+        bgc[i] = kq - tap * a.Gin; bky[i] = tap / a.ks; bkx[i] = tap - bky[i] * a.ks;
+        bok[i] = tap < a.ks * a.ks;
+    }
+    // running output-pixel coordinate of this thread's pixel lane
+    int m = r0 + pl, img = m / HoWo, rem = m - img * HoWo, oy = rem / a.Wo, ox = rem - oy * a.Wo;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[2], rb[2];
+    auto load = [&]() {
+        const bool mok = m < r1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const unsigned offa = (mok && aok[i]) ? ((unsigned)((img * a.Gy_tot + a.gy0 + aq[i]) * HoWo + rem)) * 16u : 0xFFFFFFFFu;
+            ra[i] = tr_buffer_load_f4(a.dy, a.dy_bytes, offa);
+            const int iy = oy * a.stride - a.pad + bky[i], ix = ox * a.stride - a.pad + bkx[i];
+            const bool ok = mok && bok[i] && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const unsigned offb = ok ? ((unsigned)((img * a.Gx_tot + a.gx0 + bgc[i]) * HW + iy * a.W + ix)) * 16u : 0xFFFFFFFFu;
+            rb[i] = tr_buffer_load_f4(a.x, a.x_bytes, offb);
+        }
+        m += 16; ox += 16; rem += 16;
+        while (ox >= a.Wo) { ox -= a.Wo; ++oy; }
+        while (oy >= a.Ho) { oy -= a.Ho; ++img; rem -= HoWo; }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = 4 * ((t >> 4) + 16 * i);
+            float* pa = As + ((size_t)buf * 128 + row) * LDK + pl;
+            pa[0] = ra[i].x; pa[LDK] = ra[i].y; pa[2 * LDK] = ra[i].z; pa[3 * LDK] = ra[i].w;
+            float* pb = Bs + ((size_t)buf * 128 + row) * LDK + pl;
+            pb[0] = rb[i].x; pb[LDK] = rb[i].y; pb[2 * LDK] = rb[i].z; pb[3 * LDK] = rb[i].w;
+        }
+    };
+    const int nsteps = (r1 - r0 + 15) / 16;
+    const int frow = lane & 31, fk = (lane >> 5) * 4;
+    if (nsteps > 0) {
+        load(); store(0);
+        __syncthreads();
+        for (int st = 0; st < nsteps; ++st) {
+            const int buf = st & 1;
+            if (st + 1 < nsteps) load();
+            const float* Ab = As + ((size_t)buf * 128 + wc * 64 + frow) * LDK + fk;
+            const float* Bb = Bs + ((size_t)buf * 128 + wp * 64 + frow) * LDK + fk;
+#pragma unroll
+            for (int kg = 0; kg < 2; ++kg) {
+                float4 af[2], bf[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) { af[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDK + kg * 8); bf[i] = *reinterpret_cast<const float4*>(Bb + i * 32 * LDK + kg * 8); }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                    }
+            }
+            if (st + 1 < nsteps) store(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    // partial[split][co][k]: acc row = co, col = k
+    float* P = a.partial + (size_t)blockIdx.z * a.Cout_pad * a.Kpad128;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = k0 + (wp * 2 + j) * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = c0 + (wc * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                P[(size_t)co * a.Kpad128 + k] = acc[i][j][r];
+            }
+        }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int splits, int Cout, int Cout_pad, int Cin, int ks,
+                                    int rot, int Kpad128, float* __restrict__ dw) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)Cout * Cin * ks * ks;
+    if (idx >= total) return;
+    const int tap = (int)(idx % (ks * ks));
+    const int ci = (int)((idx / (ks * ks)) % Cin), co = (int)(idx / ((long long)ks * ks * Cin));
+    const int Cp = 4 * ((Cin + 3) / 4);
+    const int cp = (ci + Cin - rot) % Cin;
+    const int k = tap * Cp + cp;
+    double s = 0.0;
+    for (int z = 0; z < splits; ++z) s += (double)partial[((size_t)z * Cout_pad + co) * Kpad128 + k];
+    dw[idx] = (float)s;
+}
+
+static inline int wg_round(int v, int m) { return (v + m - 1) / m * m; }
+
+static void wgrad_plan(int Cout, int Cin, int ksize, int M, int* Cout_pad, int* Kpad128, int* splits, int* pps) {
+    *Cout_pad = wg_round(Cout, 128);
+    *Kpad128 = wg_round(ksize * ksize * 4 * ((Cin + 3) / 4), 128);
+    const int tiles = (*Cout_pad / 128) * (*Kpad128 / 128);
+    int s = (2048 + tiles - 1) / tiles;                       // aim at ~2048 workgroups
+    const int maxs = (M + 255) / 256;                         // at least 256 pixels per split
+    if (s > maxs) s = maxs;
+    if (s < 1) s = 1;
+    *pps = wg_round((M + s - 1) / s, 16);
+    *splits = (M + *pps - 1) / *pps;
+}
+
+extern "C" size_t cnm_conv2d_wgrad_workspace_floats(int Cout, int Cin, int ksize, int N, int Ho, int Wo) {
+    if (Cout <= 0 || Cin <= 0 || ksize <= 0 || N <= 0 || Ho <= 0 || Wo <= 0) return 0;
+    int cp, kp, sp, pps;
+    wgrad_plan(Cout, Cin, ksize, N * Ho * Wo, &cp, &kp, &sp, &pps);
+    return (size_t)sp * cp * kp;
+}
+
+extern "C" int cnm_conv2d_wgrad_c4_f32(const float* x, int Gx_total, int gx0, int Cin,
+                                       const float* dy, int Gy_total, int gy0, int Cout,
+                                       float* dw_oihw, float* ws, size_t ws_floats,
+                                       int N, int H, int W, int ksize, int stride, int rot, void* stream) {
+    CNM_REQUIRE(x && dy && dw_oihw && ws && N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, CNM_ERR_BAD_ARG);
+    CNM_REQUIRE((ksize == 3 || ksize == 5 || ksize == 7) && (stride == 1 || stride == 2) && rot >= 0 && rot < Cin, CNM_ERR_BAD_ARG);
+    WgradArgs a;
+    a.x = x; a.dy = dy; a.partial = ws;
+    a.N = N; a.H = H; a.W = W; a.ks = ksize; a.stride = stride; a.pad = (ksize - 1) / 2;
+    a.Ho = (H + 2 * a.pad - ksize) / stride + 1; a.Wo = (W + 2 * a.pad - ksize) / stride + 1;
+    a.Gx_tot = Gx_total; a.gx0 = gx0; a.Gin = (Cin + 3) / 4; a.Gy_tot = Gy_total; a.gy0 = gy0; a.Cout = Cout;
+    a.Kflat = ksize * ksize * 4 * a.Gin; a.M = N * a.Ho * a.Wo;
+    int splits;
+    wgrad_plan(Cout, Cin, ksize, a.M, &a.Cout_pad, &a.Kpad128, &splits, &a.pix_per_split);
+    CNM_REQUIRE((size_t)splits * a.Cout_pad * a.Kpad128 <= ws_floats, CNM_ERR_WORKSPACE);
+    const unsigned long long xb = (unsigned long long)N * Gx_total * H * W * 16ull, yb = (unsigned long long)N * Gy_total * a.Ho * a.Wo * 16ull;
+    CNM_REQUIRE(xb < 0xFFFFFFFFull && yb < 0xFFFFFFFFull, CNM_ERR_BAD_ARG);
+    a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)yb;
+    dim3 grid(a.Cout_pad / 128, a.Kpad128 / 128, splits);
+    conv_wgrad_kernel<<<grid, 256, 0, cnm_stream(stream)>>>(a);
+    const long long total = (long long)Cout * Cin * ksize * ksize;
+    wgrad_reduce_kernel<<<(unsigned)cnm_ceil_div_ll(total, 256), 256, 0, cnm_stream(stream)>>>(
+        ws, splits, Cout, a.Cout_pad, Cin, ksize, rot, a.Kpad128, dw_oihw);
+    CNM_LAUNCH_CHECK();
+    return CNM_OK;
+}
+
+// ------------------------------------------------------------------ BatchNorm2d (train mode) + ReLU on c4
+// stats[c] = (sum, sum of squares) in fp64; mean/invstd derived from them (biased variance for the
+// normalisation, unbiased for the running update -- torch.nn.BatchNorm2d defaults).
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int N, int G, int HW, double* __restrict__ stats) {
+    const int g = blockIdx.x;
+    const long long total = (long long)N * HW;
+    double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    for (long long i = (long long)blockIdx.y * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.y * blockDim.x) {
+        const int n = (int)(i / HW), pix = (int)(i - (long long)n * HW);
+        const float4 v = *reinterpret_cast<const float4*>(x + c4_offset(n, G, g, HW, pix));
+        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+        q[0] += (double)v.x * v.x; q[1] += (double)v.y * v.y; q[2] += (double)v.z * v.z; q[3] += (double)v.w * v.w;
+    }
+    __shared__ double red[8][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { s[j] += __shfl_down(s[j], o); q[j] += __shfl_down(q[j], o); }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) for (int j = 0; j < 4; ++j) { red[wave][j] = s[j]; red[wave + 4][j] = q[j]; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int j = threadIdx.x;
+        atomicAdd(&stats[(4 * g + j) * 2 + 0], red[0][j] + red[1][j] + red[2][j] + red[3][j]);
+        atomicAdd(&stats[(4 * g + j) * 2 + 1], red[4][j] + red[5][j] + red[6][j] + red[7][j]);
+    }
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, int C, double count, float eps, float momentum,
+                                   float* __restrict__ mean, float* __restrict__ invstd,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mu = stats[2 * c] / count;
+    double var = stats[2 * c + 1] / count - mu * mu;
+    if (var < 0) var = 0;
+    mean[c] = (float)mu; invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unbiased = count > 1 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, int C, int relu,
+                                                       float* __restrict__ y, int N, int G, int HW) {
+    const long long total = (long long)N * G * HW;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int g = (int)((idx / HW) % G);
+        const float4 v = *reinterpret_cast<const float4*>(x + idx * 4);
+        float in[4] = {v.x, v.y, v.z, v.w}, o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = 4 * g + j;
+            float r = 0.f;
+            if (c < C) { r = (in[j] - mean[c]) * invstd[c] * gamma[c] + beta[c]; if (relu) r = fmaxf(r, 0.f); }
+            o[j] = r;
+        }
+        *reinterpret_cast<float4*>(y + idx * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// backward pass 1: sum_dy[c], sum_dy_xhat[c] (dy masked by the ReLU of the forward output y)
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                            const float* __restrict__ dy, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, int C, int relu,
+                                                            int N, int G, int HW, double* __restrict__ sums) {
+    const int g = blockIdx.x;
+    const long long total = (long long)N * HW;
+    double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    float mu[4], is[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int c = 4 * g + j; mu[j] = c < C ? mean[c] : 0.f; is[j] = c < C ? invstd[c] : 0.f; }
+    for (long long i = (long long)blockIdx.y * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.y * blockDim.x) {
+        const int n = (int)(i / HW), pix = (int)(i - (long long)n * HW);
+        const size_t o = c4_offset(n, G, g, HW, pix);
+        const float4 xv = *reinterpret_cast<const float4*>(x + o), yv = *reinterpret_cast<const float4*>(y + o);
+        const float4 dv = *reinterpret_cast<const float4*>(dy + o);
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ys[4] = {yv.x, yv.y, yv.z, yv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float d = (relu && !(ys[j] > 0.f)) ? 0.f : ds[j];
+            s[j] += d; q[j] += (double)d * ((xs[j] - mu[j]) * is[j]);
+        }
+    }
+    __shared__ double red[8][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { s[j] += __shfl_down(s[j], o); q[j] += __shfl_down(q[j], o); }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) for (int j = 0; j < 4; ++j) { red[wave][j] = s[j]; red[wave + 4][j] = q[j]; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int j = threadIdx.x;
+        atomicAdd(&sums[(4 * g + j) * 2 + 0], red[0][j] + red[1][j] + red[2][j] + red[3][j]);
+        atomicAdd(&sums[(4 * g + j) * 2 + 1], red[4][j] + red[5][j] + red[6][j] + red[7][j]);
+    }
+}
+
+// backward pass 2: dx = gamma*invstd*(dy - sum_dy/m - xhat*sum_dy_xhat/m); dgamma = sum_dy_xhat; dbeta = sum_dy
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                           const float* __restrict__ dy, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                           const double* __restrict__ sums, double count, int C, int relu,
+                                                           float* __restrict__ dx, int N, int G, int HW) {
+    const long long total = (long long)N * G * HW;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int g = (int)((idx / HW) % G);
+        const float4 xv = *reinterpret_cast<const float4*>(x + idx * 4), yv = *reinterpret_cast<const float4*>(y + idx * 4);
+        const float4 dv = *reinterpret_cast<const float4*>(dy + idx * 4);
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ys[4] = {yv.x, yv.y, yv.z, yv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = 4 * g + j;
+            float r = 0.f;
+            if (c < C) {
+                const float d = (relu && !(ys[j] > 0.f)) ? 0.f : ds[j];
+                const float xh = (xs[j] - mean[c]) * invstd[c];
+                const float sd = (float)(sums[2 * c] / count), sq = (float)(sums[2 * c + 1] / count);
+                r = gamma[c] * invstd[c] * (d - sd - xh * sq);
+            }
+            o[j] = r;
+        }
+        *reinterpret_cast<float4*>(dx + idx * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+__global__ void bn_param_grad_kernel(const double* __restrict__ sums, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    dbeta[c] = (float)sums[2 * c]; dgamma[c] = (float)sums[2 * c + 1];
+}
+
+static int bn_grid_y(int N, int HW) { long long t = ((long long)N * HW + 255) / 256; return (int)(t < 64 ? (t < 1 ? 1 : t) : 64); }
+
+extern "C" int cnm_bn_train_forward_c4_f32(const float* x, const float* gamma, const float* beta,
+                                           float* running_mean, float* running_var, float momentum, float eps, int relu,
+                                           float* y, float* save_mean, float* save_invstd, double* stats_ws,
+                                           int N, int C, int H, int W, void* stream) {
+    CNM_REQUIRE(x && gamma && beta && y && save_mean && save_invstd && stats_ws && N > 0 && C > 0 && H > 0 && W > 0, CNM_ERR_BAD_ARG);
+    const int G = (C + 3) / 4, HW = H * W;
+    hipStream_t s = cnm_stream(stream);
+    if (hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * 4 * G, s) != hipSuccess) return CNM_ERR_LAUNCH;
+    bn_stats_kernel<<<dim3(G, bn_grid_y(N, HW)), 256, 0, s>>>(x, N, G, HW, stats_ws);
+    bn_finalize_kernel<<<cnm_ceil_div(C, 256), 256, 0, s>>>(stats_ws, C, (double)N * HW, eps, momentum, save_mean, save_invstd, running_mean, running_var);
+    const long long total = (long long)N * G * HW;
+    bn_apply_kernel<<<(int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384), 256, 0, s>>>(x, save_mean, save_invstd, gamma, beta, C, relu, y, N, G, HW);
+    CNM_LAUNCH_CHECK();
+    return CNM_OK;
+}
+
+extern "C" int cnm_bn_train_backward_c4_f32(const float* x, const float* y, const float* dy, const float* gamma,
+                                            const float* save_mean, const float* save_invstd, int relu,
+                                            float* dx, float* dgamma, float* dbeta, double* sums_ws,
+                                            int N, int C, int H, int W, void* stream) {
+    CNM_REQUIRE(x && y && dy && gamma && save_mean && save_invstd && dx && dgamma && dbeta && sums_ws && N > 0 && C > 0, CNM_ERR_BAD_ARG);
+    const int G = (C + 3) / 4, HW = H * W;
+    hipStream_t s = cnm_stream(stream);
+    if (hipMemsetAsync(sums_ws, 0, sizeof(double) * 2 * 4 * G, s) != hipSuccess) return CNM_ERR_LAUNCH;
+    bn_bwd_reduce_kernel<<<dim3(G, bn_grid_y(N, HW)), 256, 0, s>>>(x, y, dy, save_mean, save_invstd, C, relu, N, G, HW, sums_ws);
+    const long long total = (long long)N * G * HW;
+    bn_bwd_apply_kernel<<<(int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384), 256, 0, s>>>(
+        x, y, dy, save_mean, save_invstd, gamma, sums_ws, (double)N * HW, C, relu, dx, N, G, HW);
+    bn_param_grad_kernel<<<cnm_ceil_div(C, 256), 256, 0, s>>>(sums_ws, C, dgamma, dbeta);
+    CNM_LAUNCH_CHECK();
+    return CNM_OK;
+}
+
+// ------------------------------------------------------------------ adjoint of the bilinear x2 upsample
+__global__ __launch_bounds__(256) void upsample2x_bwd_c4_kernel(const float* __restrict__ dy, float* __restrict__ dx,
+                                                                int N, int G, int H, int W) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    const long long total = (long long)N * G * H * W;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int ix = (int)(idx % W);
+        long long r = idx / W;
+        const int iy = (int)(r % H); r /= H;                    // r = n*G + g
+        const float4* base = reinterpret_cast<const float4*>(dy) + r * (long long)Ho * Wo;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int oy = max(2 * iy - 2, 0); oy <= min(2 * iy + 2, Ho - 1); ++oy) {
+            const float sy = fmaxf((oy + 0.5f) * 0.5f - 0.5f, 0.f);
+            const int y0 = (int)sy, y1 = min(y0 + 1, H - 1);
+            const float ly = sy - y0;
+            const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+            if (wy == 0.f) continue;
+            for (int ox = max(2 * ix - 2, 0); ox <= min(2 * ix + 2, Wo - 1); ++ox) {
+                const float sx = fmaxf((ox + 0.5f) * 0.5f - 0.5f, 0.f);
+                const int x0 = (int)sx, x1 = min(x0 + 1, W - 1);
+                const float lx = sx - x0;
+                const float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+                if (wx == 0.f) continue;
+                const float4 v = base[(size_t)oy * Wo + ox];
+                const float w = wy * wx;
+                acc.x = fmaf(w, v.x, acc.x); acc.y = fmaf(w, v.y, acc.y); acc.z = fmaf(w, v.z, acc.z); acc.w = fmaf(w, v.w, acc.w);
+            }
+        }
+        reinterpret_cast<float4*>(dx)[idx] = acc;
+    }
+}
+
+extern "C" int cnm_upsample2x_backward_c4_f32(const float* dy, float* dx, int N, int G, int H, int W, void* stream) {
+    CNM_REQUIRE(dy && dx && N > 0 && G > 0 && H > 0 && W > 0, CNM_ERR_BAD_ARG);
+    const long long total = (long long)N * G * H * W;
+    upsample2x_bwd_c4_kernel<<<(int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384), 256, 0, cnm_stream(stream)>>>(dy, dx, N, G, H, W);
+    CNM_LAUNCH_CHECK();
+    return CNM_OK;
+}

@@ -20,6 +20,7 @@ import torch
 import torch.nn as nn
 
 from .. import _lib, ops
+from .. import autograd as ag
 
 
 class _Slot(nn.Identity):
@@ -113,15 +114,21 @@ class _EngineNet(nn.Module):
             ws = self._ws[str(device)]
         return ws
 
-    def _require_eval_on_gpu(self, *tensors):
-        if self.training:
-            raise NotImplementedError(
-                "%s: only eval-mode (running-stat BatchNorm) forward is built in this round; "
-                "call .eval() -- there is no eager fallback" % type(self).__name__)
+    def _require_gpu(self, *tensors):
         ops._dev(*tensors)
         p = next(self.parameters())
         if not p.is_cuda or p.device != tensors[0].device:
             raise _lib.EngineError("module parameters are on %s but inputs are on %s" % (p.device, tensors[0].device))
+
+
+def _down_train(x, seq, rot=0):
+    """down_conv_layer in train mode: conv s1 -> BN -> ReLU -> conv s2 -> BN -> ReLU (reference :19-39)."""
+    return ag.conv_bn_relu(ag.conv_bn_relu(x, seq[0], seq[1], rot), seq[3], seq[4])
+
+
+def _up_train(x, seq):
+    """up_conv_layer in train mode: bilinear x2 -> conv -> BN -> ReLU (reference :91-101)."""
+    return ag.conv_bn_relu(ag.Upsample2xC4.apply(x), seq[1], seq[2])
 
 
 class depthNet(_EngineNet):
@@ -156,10 +163,12 @@ class depthNet(_EngineNet):
         One engine call for all pairs; the reference replicates the ref image instead
         (eval.py:635-657)."""
         ops.idepth_range(self.idepth_scale)
-        self._require_eval_on_gpu(ref, src, ref_cam, src_cam)
+        self._require_gpu(ref, src, ref_cam, src_cam)
         B, S, _, H, W = src.shape
         if H % 32 or W % 32:
             raise ValueError("image height and width must be multiples of 32 (got %dx%d)" % (H, W))
+        if self.training:
+            return self._forward_train(ref, src, ref_cam, src_cam)
         self._ensure_packed()
         lib, P, dev = _lib.load(), B * S, ref.device
         ref, src, ref_cam, src_cam = (t.contiguous() for t in (ref, src, ref_cam, src_cam))
@@ -175,9 +184,33 @@ class depthNet(_EngineNet):
                 ws.data_ptr(), ws.numel(), B, S, H, W, torch.cuda.current_stream().cuda_stream))
         return disp, feat
 
+    def _forward_train(self, ref, src, ref_cam, src_cam):
+        """Train mode (batch-statistics BatchNorm, autograd): the same graph as reference :226-263 built
+        from cnmnet_amd.autograd Functions; the cost volume is a constant of the graph."""
+        s = float(self.idepth_scale)
+        with torch.no_grad():
+            hmkt = ops.homography_terms(ref_cam, src_cam)
+            x0 = ops.plane_sweep_cat_c4(ref, src, hmkt, s, self.planes)
+        c1 = _down_train(x0, self.conv1, rot=3)
+        c2 = _down_train(c1, self.conv2); c3 = _down_train(c2, self.conv3)
+        c4 = _down_train(c3, self.conv4); c5 = _down_train(c4, self.conv5)
+        i5 = ag.conv_bn_relu(torch.cat((_up_train(c5, self.upconv5), c4), 1), self.iconv5[0], self.iconv5[1])
+        i4 = ag.conv_bn_relu(torch.cat((_up_train(i5, self.upconv4), c3), 1), self.iconv4[0], self.iconv4[1])
+        d4 = ag.head(i4, self.disp4[0], s)
+        g4 = ag.scalar_maps_to_group(ag.nearest_up2(d4))
+        i3 = ag.conv_bn_relu(torch.cat((_up_train(i4, self.upconv3), c2, g4), 1), self.iconv3[0], self.iconv3[1])
+        d3 = ag.head(i3, self.disp3[0], s)
+        g3 = ag.scalar_maps_to_group(ag.nearest_up2(d3))
+        i2 = ag.conv_bn_relu(torch.cat((_up_train(i3, self.upconv2), c1, g3), 1), self.iconv2[0], self.iconv2[1])
+        d2 = ag.head(i2, self.disp2[0], s)
+        g2 = ag.scalar_maps_to_group(ag.nearest_up2(d2))
+        i1 = ag.conv_bn_relu(torch.cat((_up_train(i2, self.upconv1), g2), 1), self.iconv1[0], self.iconv1[1])
+        d1 = ag.head(i1, self.disp1[0], s)
+        return [d1, d2, d3, d4], i1
+
     def forward(self, left_image, right_image, left_cam, right_cam):
         disp, feat_c4 = self.forward_pairs(left_image, right_image.unsqueeze(1), left_cam, right_cam.unsqueeze(1))
-        iconv1 = ops.c4_to_nchw(feat_c4, 64)
+        iconv1 = ag.C4ToNCHW.apply(feat_c4, 64) if self.training else ops.c4_to_nchw(feat_c4, 64)
         iconv1._cnm_c4 = feat_c4           # lets DepthRefineNet skip the NCHW->c4 round trip
         return disp, iconv1
 
@@ -221,7 +254,7 @@ class DepthRefineNet(_EngineNet):
         """S (even) sources per frame from ONE depthNet.forward_pairs call: disp1 [B*S,1,H,W] and
         iconv1 c4 [B*S,16,H,W,4]; even sources average into side 1, odd into side 2
         (reference eval.py:656-663 for S=4, :917-929 for S=6; S=2 is the plain two-view case)."""
-        self._require_eval_on_gpu(idepth_pairs, feat_pairs_c4)
+        self._require_gpu(idepth_pairs, feat_pairs_c4)
         self._ensure_packed()
         P, _, H, W = idepth_pairs.shape
         B = P // S
@@ -237,13 +270,40 @@ class DepthRefineNet(_EngineNet):
                 ws.data_ptr(), ws.numel(), B, H, W, torch.cuda.current_stream().cuda_stream))
         return disp, prob, vol
 
+    def _forward_train(self, idepth01, idepth02, f1, f2, ReturnVolume):
+        """Train mode: reference :331-370 from cnmnet_amd.autograd Functions (c4 tensors throughout)."""
+        grp = ag.scalar_maps_to_group(idepth01, idepth02, (idepth01 - idepth02).abs())
+        x = torch.cat((f1 + f2, grp), 1)                               # rotated order: 64 features, then the 3 maps
+        c1 = _down_train(x, self.conv1, rot=3); c2 = _down_train(c1, self.conv2); c3 = _down_train(c2, self.conv3)
+        u3 = ag.Upsample2xC4.apply(c3)
+
+        def decode(tag):
+            g = lambda n: getattr(self, n + "_" + tag)
+            uc3 = ag.conv_bn_relu(u3, g("upconv3")[1], g("upconv3")[2])
+            i3 = ag.conv_bn_relu(torch.cat((uc3, c2), 1), g("iconv3")[0], g("iconv3")[1])
+            i2 = ag.conv_bn_relu(torch.cat((_up_train(i3, g("upconv2")), c1), 1), g("iconv2")[0], g("iconv2")[1])
+            return ag.conv_bn_relu(_up_train(i2, g("upconv1")), g("iconv1")[0], g("iconv1")[1])
+
+        feat = decode("depth")
+        disp = ag.head(feat, self.disp_refine[0], float(self.idepth_scale))
+        prob = ag.head(decode("prob"), self.prob[0], 1.0)
+        if not ReturnVolume:
+            return disp, prob
+        vol = ag.C4ToNCHW.apply(feat, 64)
+        vol._cnm_c4 = feat
+        return disp, prob, vol
+
     def forward(self, idepth01, idepth02, iconv01, iconv02, ReturnVolume=False):
-        self._require_eval_on_gpu(idepth01, idepth02, iconv01, iconv02)
+        self._require_gpu(idepth01, idepth02, iconv01, iconv02)
         N, _, H, W = idepth01.shape
         if H % 8 or W % 8:
             raise ValueError("image height and width must be multiples of 8 (got %dx%d)" % (H, W))
         f1 = getattr(iconv01, "_cnm_c4", None)
         f2 = getattr(iconv02, "_cnm_c4", None)
+        if self.training:
+            f1 = f1 if f1 is not None else ag.NCHWToC4.apply(iconv01)
+            f2 = f2 if f2 is not None else ag.NCHWToC4.apply(iconv02)
+            return self._forward_train(idepth01, idepth02, f1, f2, ReturnVolume)
         f1 = f1 if f1 is not None else ops.nchw_to_c4(iconv01)
         f2 = f2 if f2 is not None else ops.nchw_to_c4(iconv02)
         disp, prob, vol = self.forward_c4(idepth01.contiguous(), idepth02.contiguous(), H * W,

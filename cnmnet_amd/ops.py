@@ -113,6 +113,8 @@ def pack_conv(weight, bn=None, bias=None, rot=0, eps=1e-5):
     lib = _lib.load()
     Cout, Cin, k, _ = weight.shape
     wp = torch.empty(lib.cnm_packed_conv_floats(Cout, Cin, k), device=weight.device, dtype=torch.float32)
+    if bias is not None:
+        bias = _c(bias)
     bp = torch.empty(Cout, device=weight.device, dtype=torch.float32)
     g, b, m, v = [_c(t) for t in bn] if bn else (None, None, None, None)
     with torch.cuda.device(weight.device):

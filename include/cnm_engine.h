@@ -191,6 +191,44 @@ int cnm_refinenet_forward_multi_f32(const cnm_layer_weights* weights, float idep
                                     float* disp_refined, float* prob_map, float* iconv1_depth_c4,
                                     float* ws, size_t ws_floats, int B, int H, int W, void* stream);
 
+/* ---------------------------------------------------------------- training path
+ * The reference trains with stock autograd (train.py:164-310).  These are the backward operators of
+ * the conv stack on c4 activations; the Python side wires them into torch.autograd.Functions
+ * (cnmnet_amd/autograd.py).  The plane sweep has no backward.
+ *
+ * Data gradient: dX = conv_transpose(dY, W) as the same MFMA implicit GEMM with flipped taps and
+ * swapped channel roles; stride 2 gathers the zero-upsampled dY without materialising it.
+ * dy [N,ceil(Cout/4),Ho,Wo,4] -> dx [N,ceil(Cin/4),H,W,4] in the forward input's (rotated) channel order. */
+size_t cnm_packed_dgrad_floats(int Cout, int Cin, int ksize);
+int cnm_pack_conv_dgrad_f32(const float* w_oihw, int Cout, int Cin, int ksize, int rot, float* w_packed, void* stream);
+int cnm_conv2d_dgrad_c4_f32(const float* dy, int Gy_total, int gy0, int Cout,
+                            float* dx, int Gx_total, int gx0, int Cin,
+                            const float* w_packed_dgrad, int N, int H, int W, int ksize, int stride, void* stream);
+
+/* Weight gradient: dW[co,ci,ky,kx] = sum_{n,y,x} dY[n,co,y,x] X[n,ci,y*s+ky-p,x*s+kx-p], an MFMA GEMM with
+ * the pixels as the reduction dimension, split into partial sums (ws) and reduced in fp64.
+ * x [N,.,H,W,4] (forward input view), dy [N,.,Ho,Wo,4] -> dw_oihw [Cout,Cin,k,k] (rotation undone). */
+size_t cnm_conv2d_wgrad_workspace_floats(int Cout, int Cin, int ksize, int N, int Ho, int Wo);
+int cnm_conv2d_wgrad_c4_f32(const float* x, int Gx_total, int gx0, int Cin,
+                            const float* dy, int Gy_total, int gy0, int Cout,
+                            float* dw_oihw, float* ws, size_t ws_floats,
+                            int N, int H, int W, int ksize, int stride, int rot, void* stream);
+
+/* nn.BatchNorm2d in train mode (+ optional ReLU) on a contiguous c4 tensor [N,ceil(C/4),H,W,4]: batch
+ * statistics (biased variance to normalise, unbiased for the running update, momentum/eps as torch),
+ * running stats updated in place (may be NULL).  stats_ws: 8*ceil(C/4) doubles. */
+int cnm_bn_train_forward_c4_f32(const float* x, const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, float momentum, float eps, int relu,
+                                float* y, float* save_mean, float* save_invstd, double* stats_ws,
+                                int N, int C, int H, int W, void* stream);
+int cnm_bn_train_backward_c4_f32(const float* x, const float* y, const float* dy, const float* gamma,
+                                 const float* save_mean, const float* save_invstd, int relu,
+                                 float* dx, float* dgamma, float* dbeta, double* sums_ws,
+                                 int N, int C, int H, int W, void* stream);
+
+/* Adjoint of cnm_upsample2x_c4_f32: dy [N,G,2H,2W,4] -> dx [N,G,H,W,4] (contiguous). */
+int cnm_upsample2x_backward_c4_f32(const float* dy, float* dx, int N, int G, int H, int W, void* stream);
+
 /* ---------------------------------------------------------------- depth -> normal (K6)
  * Replaces Depth2normal.forward without the plane branch (depth_util.py:149-203):
  * depth [B,H,W], K_inv [B,3,3] -> normal [B,3,H,W], points [B,3,H,W]. k odd, 1..15.
