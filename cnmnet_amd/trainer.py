@@ -1,0 +1,149 @@
+"""Training step of the reference (`train_wo_normal`, reference train.py:413-656) on the HIP engine,
+data-parallel over one process per GPU.
+
+* The step (`train.py:509-562`): two depthNet forwards (ref+src1, ref+src2; each with its own BatchNorm
+  batch statistics, as in the reference), DepthRefineNet, the loss mix of `train.py:524-556`
+  (the missing `ProbLoss` of `train.py:30,551` is only logged there and excluded from `loss_train`),
+  `optimizer.zero_grad -> backward -> step` with Adam lr 1e-4, weight decay 1e-5 (configs/config.yaml:16-19).
+* Data parallelism: the reference wraps the nets in single-process `nn.DataParallel` (`train.py:464-468`):
+  scatter, replicate every step, gather, loss on GPU 0, reduce-add gradients.  Here every rank owns a
+  batch shard and a full replica; the ONE exchange is the gradient all-reduce (44.67 M fp32 = 178.7 MB),
+  done by `BucketedGradAllReduce`: ~25 MB buckets in reverse registration order, each launched
+  asynchronously from a post-accumulate-grad hook the moment its last gradient is ready, so RCCL (backend
+  "nccl" on ROCm) overlaps with the rest of backward; BatchNorm keeps per-replica statistics exactly like
+  DataParallel.  `exact_masked_means=True` divides every masked loss sum by the GLOBAL mask count
+  (one tiny all-reduce of counts), which reproduces DataParallel's gathered-batch masked means.
+"""
+import torch
+
+from .depthnet.losses import IdepthLoss_234, _valid
+
+
+class BucketedGradAllReduce:
+    """Average gradients across ranks with bucketed, backward-overlapped all-reduces."""
+
+    def __init__(self, params, dist, bucket_bytes=25 * 2**20):
+        self.dist, self.world = dist, dist.get_world_size()
+        self.params = [p for p in params if p.requires_grad]
+        self.buckets, cur, size = [], [], 0
+        for p in reversed(self.params):                    # decoder grads are ready first
+            cur.append(p); size += p.numel() * 4
+            if size >= bucket_bytes:
+                self.buckets.append(cur); cur, size = [], 0
+        if cur:
+            self.buckets.append(cur)
+        self.bucket_of = {id(p): i for i, b in enumerate(self.buckets) for p in b}
+        self.flat = [torch.zeros(sum(p.numel() for p in b), device=b[0].device, dtype=torch.float32) for b in self.buckets]
+        self.pending, self.work = [len(b) for b in self.buckets], [None] * len(self.buckets)
+        self.handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
+
+    def _hook(self, p):
+        i = self.bucket_of[id(p)]
+        self.pending[i] -= 1
+        if self.pending[i] == 0:
+            self._launch(i)
+
+    def _launch(self, i):
+        off = 0
+        for p in self.buckets[i]:
+            n = p.numel()
+            self.flat[i][off:off + n].copy_((p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1))
+            off += n
+        self.work[i] = self.dist.all_reduce(self.flat[i], op=self.dist.ReduceOp.SUM, async_op=True)
+
+    def finish(self):
+        """Call after backward(): waits for all buckets and writes the averaged gradients back."""
+        for i, b in enumerate(self.buckets):
+            if self.work[i] is None:                       # parameters that received no gradient this step
+                self._launch(i)
+            self.work[i].wait()
+            off = 0
+            for p in b:
+                n = p.numel()
+                g = self.flat[i][off:off + n].view_as(p) / self.world
+                if p.grad is None:
+                    p.grad = g.clone()
+                else:
+                    p.grad.copy_(g)
+                off += n
+            self.work[i], self.pending[i] = None, len(b)
+
+    def remove(self):
+        for h in self.handles:
+            h.remove()
+
+
+def _masked_l1(pred, gt, dist=None, weight=None, exact=False):
+    """IdepthLoss / IdepthwithProbLoss (reference losses.py:30-73), optionally normalised by the global
+    mask count so that averaging the per-rank gradients equals the gathered-batch loss."""
+    m = _valid(pred, gt)
+    diff = (pred[m] - gt[m]).abs()
+    if weight is not None:
+        diff = diff * weight[m]
+    if exact and dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        n = torch.tensor([float(diff.numel())], device=pred.device)
+        dist.all_reduce(n)
+        return diff.sum() / (n[0] / dist.get_world_size()).clamp(min=1.0)
+    return diff.mean()
+
+
+class TrainStepWoNormal:
+    """One optimisation step of `train_wo_normal` (reference train.py:509-562)."""
+
+    def __init__(self, depth_net, refine_net, lr=1e-4, weight_decay=1e-5, dist=None, exact_masked_means=False):
+        self.depth_net, self.refine_net, self.dist, self.exact = depth_net, refine_net, dist, exact_masked_means
+        params = list(refine_net.parameters()) + list(depth_net.parameters())              # train.py:87, :446
+        self.optimizer = torch.optim.Adam(params, lr=lr, weight_decay=weight_decay)       # utils/misc.py:31-33
+        self.reducer = None
+        if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+            self.reducer = BucketedGradAllReduce(params, dist)
+        self.l234 = IdepthLoss_234()
+
+    def __call__(self, rgbs, cameras, disparities, depths, warmup_epoch=False):
+        """rgbs [B,3,3,H,W] (ref, src1, src2), cameras [B,3,2,4,4], disparities / depths [B,V,1,H,W]
+        (ground truth of the reference view at index 0).  Returns a dict of detached scalars."""
+        self.depth_net.train(); self.refine_net.train()
+        gt_id, gt_d = disparities[:, 0], depths[:, 0]
+        p01, f01 = self.depth_net(rgbs[:, 0], rgbs[:, 1], cameras[:, 0], cameras[:, 1])     # :509-512
+        p02, f02 = self.depth_net(rgbs[:, 0], rgbs[:, 2], cameras[:, 0], cameras[:, 2])
+        idr, prob = self.refine_net(idepth01=p01[0], idepth02=p02[0], iconv01=f01, iconv02=f02)   # :517-520
+        L = lambda a, b, w=None: _masked_l1(a, b, self.dist, w, self.exact)
+        loss_idepth_1 = (L(p01[0], gt_id) + L(p02[0], gt_id)) * 0.5                          # :522-523
+        loss_idepth_refined = L(idr, gt_id)                                                  # :525
+        loss_idepth_234 = (self.l234(p01, gt_id) + self.l234(p02, gt_id)) * 0.5              # :527-528
+        eps = 1e-8
+        d01, d02, dr = 1.0 / (p01[0] + eps), 1.0 / (p02[0] + eps), 1.0 / (idr + eps)          # :530-534
+        prob_loss_depth = L(idr, gt_id, prob) + L(dr, gt_d, prob)                            # :539-540
+        prob_loss = 5 * prob_loss_depth + (1 - prob.mean())                                  # :541, :545
+        loss_depth_1 = (L(d01, gt_d) + L(d02, gt_d)) * 0.5                                    # :550-551
+        loss_depth_refined = L(dr, gt_d)                                                     # :553
+        if warmup_epoch:                                                                     # :555-559
+            loss = loss_idepth_1 + loss_idepth_234 + loss_idepth_refined
+        else:
+            loss = loss_depth_1 + loss_depth_refined + (loss_idepth_1 + loss_idepth_234 + loss_idepth_refined) + prob_loss
+        self.optimizer.zero_grad(set_to_none=False)                                          # :562-565
+        loss.backward()
+        if self.reducer is not None:
+            self.reducer.finish()
+        self.optimizer.step()
+        return {"loss": float(loss.detach()), "loss_idepth": float(loss_idepth_1.detach()),
+                "loss_idepth_refined": float(loss_idepth_refined.detach()), "loss_depth_refined": float(loss_depth_refined.detach()),
+                "prob_loss": float(prob_loss.detach())}
+
+
+def synthetic_training_sample(B, H, W, seed=0, device="cpu"):
+    """Seeded sample with the keys/shapes `train.py:489-507` reads (3 views): smooth ground-truth depth in
+    [0.6, 4] m for the reference view, disparities = 1/depth, a few invalid (zero) pixels."""
+    import numpy as np
+    from . import synthetic as syn
+    img, cams = syn.frames(B, 2, H, W, seed=seed)
+    rng = np.random.default_rng(seed + 1)
+    ys, xs = np.mgrid[0:H, 0:W].astype(np.float32)
+    depth = np.stack([1.5 + 0.8 * np.sin(xs / (20 + 3 * b)) * np.cos(ys / 17.0) + 0.5 * rng.random() + 0.002 * xs for b in range(B)])
+    depth = np.clip(depth, 0.6, 4.0).astype(np.float32)
+    depth[:, :4, :6] = 0.0                                                  # holes: masked by the losses
+    disp = np.where(depth > 0, 1.0 / np.maximum(depth, 1e-6), 0.0).astype(np.float32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    d = t(depth)[:, None, None].expand(B, 3, 1, H, W).contiguous()
+    i = t(disp)[:, None, None].expand(B, 3, 1, H, W).contiguous()
+    return {"rgbs": t(img), "cameras": t(cams), "depths": d, "disparities": i}

@@ -132,3 +132,31 @@ def test_train_step_both_nets_vs_oracle(dev):
     for k in (("d", "conv1.1.running_mean"), ("d", "conv2.4.running_var"), ("d", "iconv1.1.running_var")):
         np.testing.assert_allclose(bg[k], b64[k], rtol=1e-3, atol=1e-4)
     assert bg[("d", "conv1.1.num_batches_tracked")] == b64[("d", "conv1.1.num_batches_tracked")] == 2
+
+
+def test_trainer_steps_and_first_loss_vs_oracle(dev):
+    """train_wo_normal step (reference train.py:509-562): first-step loss equals the oracle's with the
+    reference's own loss classes; a few Adam steps run and reduce the loss."""
+    from cnmnet_amd.depthnet import depthNet, DepthRefineNet, losses as RL
+    from cnmnet_amd.trainer import TrainStepWoNormal, synthetic_training_sample
+    s = synthetic_training_sample(2, 64, 96, seed=3)
+    # oracle: same graph on CPU (fp32) with the restated losses
+    cd, cr = _load(ra.DepthNetCPU(3.0), 71).train(), _load(ra.DepthRefineNetCPU(32, 3.0), 72).train()
+    p01, f01 = cd(s["rgbs"][:, 0], s["rgbs"][:, 1], s["cameras"][:, 0], s["cameras"][:, 1])
+    p02, f02 = cd(s["rgbs"][:, 0], s["rgbs"][:, 2], s["cameras"][:, 0], s["cameras"][:, 2])
+    idr, prob = cr(idepth01=p01[0], idepth02=p02[0], iconv01=f01, iconv02=f02)
+    gi, gd = s["disparities"][:, 0], s["depths"][:, 0]
+    c1, c234, cp = RL.IdepthLoss(), RL.IdepthLoss_234(), RL.IdepthwithProbLoss()
+    dr = 1.0 / (idr + 1e-8)
+    want = ((c1(1 / (p01[0] + 1e-8), gd) + c1(1 / (p02[0] + 1e-8), gd)) * 0.5 + c1(dr, gd)
+            + (c1(p01[0], gi) + c1(p02[0], gi)) * 0.5 + (c234(p01, gi) + c234(p02, gi)) * 0.5 + c1(idr, gi)
+            + 5 * (cp(idr, gi, prob) + cp(dr, gd, prob)) + 1 - prob.mean())
+    step = TrainStepWoNormal(_load(depthNet(3.0), 71).to(dev), _load(DepthRefineNet(32, 3.0), 72).to(dev), lr=1e-4)
+    sd = {k: v.to(dev) for k, v in s.items()}
+    logs = [step(sd["rgbs"], sd["cameras"], sd["disparities"], sd["depths"]) for _ in range(4)]
+    assert abs(logs[0]["loss"] - float(want)) < 2e-3 * max(1.0, abs(float(want))), (logs[0]["loss"], float(want))
+    assert all(np.isfinite(l["loss"]) for l in logs) and logs[-1]["loss"] < logs[0]["loss"]
+    # back to eval: the packed-weight cache must notice the updated parameters
+    step.depth_net.eval()
+    o, _ = step.depth_net(sd["rgbs"][:, 0], sd["rgbs"][:, 1], sd["cameras"][:, 0], sd["cameras"][:, 1])
+    assert torch.isfinite(o[0]).all()

@@ -55,3 +55,49 @@ def test_two_rank_gloo_max_time_and_sum_units():
 
 def test_single_process_is_identity():
     assert sharding.job_elapsed(0.25) == 0.25 and sharding.job_throughput(8, 0.5) == 16.0
+
+
+def _ddp_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cnmnet_amd.trainer import BucketedGradAllReduce
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4), torch.nn.Linear(4, 1))
+        red = BucketedGradAllReduce(net.parameters(), dist, bucket_bytes=256)       # several buckets
+        x = torch.arange(16, dtype=torch.float32).view(2, 8) * (rank + 1) / 10
+        for _ in range(2):                                                          # two steps: state resets between steps
+            net.zero_grad()
+            (net(x).sum() + net(x * 0.5).sum()).backward()                          # two forwards, one backward
+            red.finish()
+        out.put((rank, len(red.buckets), [p.grad.clone() for p in net.parameters()]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucketed_grad_allreduce_two_ranks_gloo():
+    """The training path's only exchange step: bucketed gradient all-reduce == mean of per-rank grads."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get() for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][1] >= 2
+    for a, b in zip(res[0][2], res[1][2]):
+        assert torch.equal(a, b)                                                    # identical averaged gradients on both ranks
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4), torch.nn.Linear(4, 1))
+    want = None
+    for rank in range(2):
+        net.zero_grad()
+        x = torch.arange(16, dtype=torch.float32).view(2, 8) * (rank + 1) / 10
+        (net(x).sum() + net(x * 0.5).sum()).backward()
+        g = [p.grad.clone() for p in net.parameters()]
+        want = g if want is None else [u + v for u, v in zip(want, g)]
+    for a, w in zip(res[0][2], want):
+        assert torch.allclose(a, w / 2, atol=1e-6)
