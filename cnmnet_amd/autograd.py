@@ -131,6 +131,53 @@ class NCHWToC4(torch.autograd.Function):
         return ops.c4_to_nchw(dy.contiguous(), ctx.channels)
 
 
+class Depth2NormalFn(torch.autograd.Function):
+    """Depth2normal.forward (reference depth_util.py:149-203) with its gradient w.r.t. the depth map."""
+
+    @staticmethod
+    def forward(ctx, depth, intrinsic_inv, k_size, input_is_idepth):
+        depth, intrinsic_inv = depth.contiguous(), intrinsic_inv.contiguous()
+        normal, points = ops.depth2normal(depth, intrinsic_inv, k_size, input_is_idepth)
+        ctx.save_for_backward(depth, intrinsic_inv)
+        ctx.k, ctx.inv = k_size, input_is_idepth
+        return normal, points
+
+    @staticmethod
+    def backward(ctx, gn, gp):
+        depth, kinv = ctx.saved_tensors
+        B, H, W = depth.shape
+        gd = torch.empty_like(depth)
+        ws = torch.empty(9 * B * H * W, device=depth.device, dtype=torch.float32)
+        gn = gn.contiguous() if gn is not None else torch.zeros(B, 3, H, W, device=depth.device)
+        gp_ptr = gp.contiguous() if gp is not None else None
+        with torch.cuda.device(depth.device):
+            _lib.check(_lib.load().cnm_depth2normal_backward_f32(
+                depth.data_ptr(), kinv.data_ptr(), gn.data_ptr(), gp_ptr.data_ptr() if gp_ptr is not None else 0,
+                gd.data_ptr(), ws.data_ptr(), B, H, W, ctx.k, int(ctx.inv), _s()))
+        return gd, None, None, None
+
+
+class InverseWarpFn(torch.autograd.Function):
+    """inverse_warp (reference inverse_warp.py:81-118) with its gradient w.r.t. the target depth."""
+
+    @staticmethod
+    def forward(ctx, feat, depth, pose, K, K_inv):
+        feat, depth, pose, K, K_inv = (t.contiguous() for t in (feat, depth, pose, K, K_inv))
+        ctx.save_for_backward(feat, depth, pose, K, K_inv)
+        return ops.inverse_warp(feat, depth, pose, K, K_inv)
+
+    @staticmethod
+    def backward(ctx, gout):
+        feat, depth, pose, K, K_inv = ctx.saved_tensors
+        B, C, H, W = feat.shape
+        gd = torch.empty_like(depth)
+        with torch.cuda.device(depth.device):
+            _lib.check(_lib.load().cnm_inverse_warp_backward_depth_f32(
+                feat.data_ptr(), depth.data_ptr(), pose.data_ptr(), K.data_ptr(), K_inv.data_ptr(),
+                gout.contiguous().data_ptr(), gd.data_ptr(), B, C, H, W, _s()))
+        return None, gd, None, None, None
+
+
 # ---------------------------------------------------------------- building blocks used by the modules in train mode
 def conv_bn_relu(x, conv, bn, rot=0):
     """Conv2d(bias=False) -> BatchNorm2d(train) -> ReLU, as the reference's layer builders

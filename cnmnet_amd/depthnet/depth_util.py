@@ -32,4 +32,7 @@ class Depth2normal(nn.Module):
         if planes_num is not None:
             raise NotImplementedError("plane-instance regularisation (reference depth_util.py:205-238) is not "
                                       "built yet (SURVEY.md section 8f rank 4); no call site in eval.py uses it")
+        if torch.is_grad_enabled() and depth.requires_grad:
+            from ..autograd import Depth2NormalFn
+            return Depth2NormalFn.apply(depth, intrinsic_inv, self.k_size, False)
         return ops.depth2normal(depth, intrinsic_inv, self.k_size)

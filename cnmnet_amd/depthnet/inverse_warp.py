@@ -28,4 +28,7 @@ def inverse_warp(feat, depth, pose, intrinsics, intrinsics_inv, padding_mode="ze
     assert intrinsics_inv.size() == intrinsics.size()
     if padding_mode != "zeros":
         raise NotImplementedError("only padding_mode='zeros' (the reference's default and only use) is built")
+    if torch.is_grad_enabled() and depth.requires_grad:
+        from ..autograd import InverseWarpFn
+        return InverseWarpFn.apply(feat, depth, pose, intrinsics, intrinsics_inv)
     return ops.inverse_warp(feat, depth, pose, intrinsics, intrinsics_inv)

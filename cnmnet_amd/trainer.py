@@ -146,4 +146,84 @@ def synthetic_training_sample(B, H, W, seed=0, device="cpu"):
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
     d = t(depth)[:, None, None].expand(B, 3, 1, H, W).contiguous()
     i = t(disp)[:, None, None].expand(B, 3, 1, H, W).contiguous()
-    return {"rgbs": t(img), "cameras": t(cams), "depths": d, "disparities": i}
+    # ground-truth normals of the reference view from the ground-truth depth (finite differences of the point cloud)
+    K = syn.intrinsics(H, W)
+    X = (xs - K[0, 2]) / K[0, 0] * depth; Y = (ys - K[1, 2]) / K[1, 1] * depth
+    P = np.stack([X, Y, depth], 1)                                          # [B,3,H,W]
+    du = np.gradient(P, axis=3); dv = np.gradient(P, axis=2)
+    n = np.cross(dv, du, axis=1); n /= (np.linalg.norm(n, axis=1, keepdims=True) + 1e-8)
+    n = t(n.astype(np.float32))[:, None].expand(B, 3, 3, H, W).contiguous()
+    return {"rgbs": t(img), "cameras": t(cams), "depths": d, "disparities": i, "normals": n}
+
+
+def get_warped_depth_loss(depth_refined, gt_depth_src, pose, intrinsic, intrinsic_inv):
+    """Stand-in for the reference's MISSING `fusion_depth.fuse_depth.get_warped_depth_loss`
+    (imported at train.py:34, called at :287-293; not in the repository -- parity unpinned).
+    Definition chosen here: sample the source view's ground-truth depth at the
+    re-projection of the refined reference depth (`inverse_warp`, gradient w.r.t. the refined depth through the
+    sampling position) and take the masked L1 against the refined depth."""
+    from .depthnet.inverse_warp import inverse_warp
+    warped = inverse_warp(gt_depth_src.unsqueeze(1), depth_refined, pose, intrinsic, intrinsic_inv).squeeze(1)
+    m = (warped > 0) & torch.isfinite(warped) & torch.isfinite(depth_refined) & (depth_refined > 0)
+    if not bool(m.any()):
+        return depth_refined.sum() * 0.0
+    return (warped[m] - depth_refined[m]).abs().mean()
+
+
+class TrainStep(TrainStepWoNormal):
+    """One optimisation step of the reference's `train` command (train.py:164-310): the depth / inverse-depth /
+    probability terms of `train_wo_normal` plus surface-normal losses on normals derived from the three predicted
+    depth maps (Depth2normal, k_size 9, gradient through the least-squares fit) and two warped-depth losses.
+    Not restated: the plane-instance inputs the shipped loaders never produce (train.py:147-162) --
+    i.e. the `use_normal_refined_by_planes=False` branch (:226-241) is the one built."""
+
+    def __init__(self, depth_net, refine_net, k_size=9, **kw):
+        super().__init__(depth_net, refine_net, **kw)
+        from .depthnet.depth_util import Depth2normal
+        self.depth2normal = Depth2normal(k_size)
+
+    def __call__(self, rgbs, cameras, disparities, depths, normals):
+        from .depthnet.losses import surface_normal_loss
+        from . import ops
+        self.depth_net.train(); self.refine_net.train()
+        B = rgbs.shape[0]
+        gt_id, gt_d, gt_n = disparities[:, 0], depths[:, 0], normals[:, 0]
+        gt_n_valid = gt_d > 0.1                                                              # :153
+        p01, f01 = self.depth_net(rgbs[:, 0], rgbs[:, 1], cameras[:, 0], cameras[:, 1])     # :164-167
+        p02, f02 = self.depth_net(rgbs[:, 0], rgbs[:, 2], cameras[:, 0], cameras[:, 2])
+        idr, prob = self.refine_net(idepth01=p01[0], idepth02=p02[0], iconv01=f01, iconv02=f02)   # :172-175
+        L = lambda a, b, w=None: _masked_l1(a, b, self.dist, w, self.exact)
+        loss_idepth_1 = (L(p01[0], gt_id) + L(p02[0], gt_id)) * 0.5                          # :177-178
+        loss_idepth_refined = L(idr, gt_id)                                                  # :180
+        d01, d02 = 1.0 / p01[0].squeeze(1), 1.0 / p02[0].squeeze(1)                          # :185-186
+        dr = 1.0 / (idr.squeeze(1) + 1e-5)                                                   # :188
+        prob_loss = 5 * (L(idr, gt_id, prob) + L(dr.unsqueeze(1), gt_d, prob)) + (1 - prob.mean())   # :193-199
+        k_inv = ops.intrinsics_inverse(cameras[:, 0])                                        # :201-202
+        n01, _ = self.depth2normal(d01, k_inv)                                               # :204-207
+        n02, _ = self.depth2normal(d02, k_inv)
+        nr, _ = self.depth2normal(dr, k_inv)
+        loss_depth_1 = (L(d01.unsqueeze(1), gt_d) + L(d02.unsqueeze(1), gt_d)) * 0.5          # :217-218
+        loss_depth_refined = L(dr.unsqueeze(1), gt_d)                                        # :220
+        ln, lnr = 0.0, 0.0
+        for i in range(B):                                                                   # :226-263 per-sample loop
+            a, _ = surface_normal_loss(n01[i:i + 1], gt_n[i:i + 1], gt_n_valid[i:i + 1])
+            b, _ = surface_normal_loss(n02[i:i + 1], gt_n[i:i + 1], gt_n_valid[i:i + 1])
+            c, _ = surface_normal_loss(nr[i:i + 1], gt_n[i:i + 1], gt_n_valid[i:i + 1])
+            ln = ln + (a + b) * 0.5; lnr = lnr + c
+        ln, lnr = ln / B, lnr / B                                                            # :268-269
+        if bool(torch.isnan(ln)) or bool(torch.isnan(lnr)):                                  # :275-280 NaN guard
+            loss = loss_idepth_1 + loss_depth_1 + loss_depth_refined + loss_idepth_refined
+        else:
+            loss = loss_idepth_1 + ln + loss_depth_1 + loss_depth_refined + loss_idepth_refined + lnr + prob_loss
+        K = cameras[:, 0, 1, :3, :3].contiguous()
+        ref_inv = torch.linalg.inv(cameras[:, 0, 0])
+        for v in (1, 2):                                                                     # :284-293, :304
+            pose = (cameras[:, v, 0] @ ref_inv)[:, :3, :].contiguous()
+            loss = loss + get_warped_depth_loss(dr, depths[:, v, 0], pose, K, k_inv)
+        self.optimizer.zero_grad(set_to_none=False)                                          # :307-310
+        loss.backward()
+        if self.reducer is not None:
+            self.reducer.finish()
+        self.optimizer.step()
+        return {"loss": float(loss.detach()), "loss_normal": float(ln.detach()), "loss_normal_refined": float(lnr.detach()),
+                "loss_depth_refined": float(loss_depth_refined.detach()), "prob_loss": float(prob_loss.detach())}

@@ -237,6 +237,13 @@ int cnm_upsample2x_backward_c4_f32(const float* dy, float* dx, int N, int G, int
 int cnm_depth2normal_f32(const float* depth, const float* K_inv, float* normal, float* points,
                          int B, int H, int W, int ksize, int input_is_idepth, void* stream);
 
+/* Backward of cnm_depth2normal_f32 w.r.t. its depth (or inverse-depth) input, as needed by the normal losses of
+ * train.py:204-263: grad_normal [B,3,H,W], grad_points [B,3,H,W] or NULL -> grad_depth [B,H,W].
+ * ws: 9*B*H*W floats.  The validity mask (0 < z < 10) and the det < 1e-5 branch are treated as constants. */
+int cnm_depth2normal_backward_f32(const float* depth, const float* K_inv, const float* grad_normal,
+                                  const float* grad_points, float* grad_depth, float* ws,
+                                  int B, int H, int W, int ksize, int input_is_idepth, void* stream);
+
 /* K^-1 of the intrinsics stored in a camera tensor (cam[:,1,:3,:3].inverse(), train.py:201-202,
  * eval.py:271): cam [B,2,4,4] with cam_stride floats between images -> K_inv [B,3,3]. */
 int cnm_intrinsics_inverse_f32(const float* cam, long long cam_stride, float* K_inv, int B, void* stream);
@@ -247,6 +254,12 @@ int cnm_intrinsics_inverse_f32(const float* cam, long long cam_stride, float* K_
 int cnm_inverse_warp_f32(const float* feat, const float* depth, const float* pose,
                          const float* K, const float* K_inv, float* out,
                          int B, int C, int H, int W, void* stream);
+
+/* Backward of cnm_inverse_warp_f32 w.r.t. the target depth (train.py:284-293 differentiates the sampling
+ * position; the sampled map itself carries no gradient there): grad_out [B,C,H,W] -> grad_depth [B,H,W]. */
+int cnm_inverse_warp_backward_depth_f32(const float* feat, const float* depth, const float* pose,
+                                        const float* K, const float* K_inv, const float* grad_out,
+                                        float* grad_depth, int B, int C, int H, int W, void* stream);
 
 #ifdef __cplusplus
 }

@@ -14,6 +14,13 @@ T = torch.from_numpy
 
 
 @pytest.fixture(scope="module")
+def golden():
+    import os
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    return lambda name: dict(np.load(os.path.join(G, name), allow_pickle=False))
+
+
+@pytest.fixture(scope="module")
 def dev():
     assert torch.cuda.is_available()
     return torch.device("cuda:0")
@@ -160,3 +167,63 @@ def test_trainer_steps_and_first_loss_vs_oracle(dev):
     step.depth_net.eval()
     o, _ = step.depth_net(sd["rgbs"][:, 0], sd["rgbs"][:, 1], sd["cameras"][:, 0], sd["cameras"][:, 1])
     assert torch.isfinite(o[0]).all()
+
+
+@pytest.mark.parametrize("k", [9, 5])
+def test_depth2normal_backward(dev, golden, k):
+    """K6 backward vs torch autograd through the oracle's Unfold formulation in fp64 (same fixture as the
+    forward golden: zero holes, a > 10 m patch, sensor-like noise)."""
+    from cnmnet_amd.depthnet import Depth2normal
+    g = golden("depth2normal_48x64.npz")
+    rng = np.random.default_rng(k)
+    gn = T(rng.standard_normal((2, 3, 48, 64)).astype(np.float32)); gp = T(rng.standard_normal((2, 3, 48, 64)).astype(np.float32))
+    d64 = T(g["depth"]).double().requires_grad_(True)
+    n, p = ra.depth_to_normal(d64, T(g["K_inv"]).double(), k)
+    (n * gn.double()).sum().backward(retain_graph=True)
+    gd_n = d64.grad.clone(); d64.grad = None
+    (p * gp.double()).sum().backward()
+    gd_p = d64.grad.clone()
+    dd = T(g["depth"]).to(dev).requires_grad_(True)
+    nd, pd = Depth2normal(k)(dd, T(g["K_inv"]).to(dev))
+    (nd * gn.to(dev)).sum().backward(retain_graph=True)
+    got_n = dd.grad.clone().cpu().double(); dd.grad = None
+    (pd * gp.to(dev)).sum().backward()
+    got_p = dd.grad.cpu().double()
+    np.testing.assert_allclose(got_p.numpy(), gd_p.numpy(), rtol=1e-5, atol=1e-5)
+    # normals: pixels whose window touches the det<1e-5 branch or the validity edge are excluded by construction of the
+    # fixture (smooth interior); compare in relative L2 and on the bulk
+    err = (got_n - gd_n).abs()
+    scale = float(gd_n.abs().max())
+    assert float(err.max()) < 2e-3 * scale and float(np.linalg.norm((got_n - gd_n).numpy()) / np.linalg.norm(gd_n.numpy())) < 1e-4
+
+
+def test_inverse_warp_backward_depth(dev, golden):
+    from cnmnet_amd.depthnet import inverse_warp
+    g = golden("inverse_warp_32x64.npz")
+    rng = np.random.default_rng(2)
+    go = T(rng.standard_normal((2, 3, 32, 64)).astype(np.float32))
+    d64 = T(g["depth"]).double().requires_grad_(True)
+    w = ra.inverse_warp(T(g["feat"]).double(), d64, T(g["pose"]).double(), T(g["K"]).double(), T(g["K_inv"]).double())
+    (w * go.double()).sum().backward()
+    dd = T(g["depth"]).to(dev).requires_grad_(True)
+    wd = inverse_warp(T(g["feat"]).to(dev), dd, T(g["pose"]).to(dev), T(g["K"]).to(dev), T(g["K_inv"]).to(dev))
+    (wd * go.to(dev)).sum().backward()
+    got, want = dd.grad.cpu().double().numpy(), d64.grad.numpy()
+    err = np.abs(got - want)
+    # pixels whose sample sits within fp32 rounding of a texel boundary pick the neighbouring cell's slope: exclude via quantile
+    assert np.quantile(err, 0.995) < 1e-3 * np.abs(want).max() and np.linalg.norm(got - want) / np.linalg.norm(want) < 2e-2
+
+
+def test_train_with_normals_step(dev):
+    """`train` command step (train.py:164-310): normal losses through Depth2normal's backward and the two
+    warped-depth losses through inverse_warp's; every parameter receives a finite gradient, loss goes down."""
+    from cnmnet_amd.depthnet import depthNet, DepthRefineNet
+    from cnmnet_amd.trainer import TrainStep, synthetic_training_sample
+    s = {k: v.to(dev) for k, v in synthetic_training_sample(2, 64, 96, seed=5).items()}
+    step = TrainStep(_load(depthNet(3.0), 81).to(dev), _load(DepthRefineNet(32, 3.0), 82).to(dev), lr=1e-4)
+    logs = [step(s["rgbs"], s["cameras"], s["disparities"], s["depths"], s["normals"]) for _ in range(4)]
+    assert all(np.isfinite(l["loss"]) and np.isfinite(l["loss_normal"]) for l in logs), logs
+    assert logs[-1]["loss"] < logs[0]["loss"]
+    for net in (step.depth_net, step.refine_net):
+        for k, p in net.named_parameters():
+            assert p.grad is not None and bool(torch.isfinite(p.grad).all()), k
