@@ -155,6 +155,8 @@ def main():
     ap.add_argument("--frames-per-gpu", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--precision", choices=["f32", "f16"], default="f32",
+                    help="f16 = BASELINE config 5 path (fp16 storage + f16 MFMA; tolerance in tests/test_gpu_fp16.py); not the headline")
     a = ap.parse_args()
 
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
@@ -173,7 +175,8 @@ def main():
     from cnmnet_amd import synthetic as syn
     from cnmnet_amd.depthnet import depthNet, DepthRefineNet
     from cnmnet_amd.pipeline import FramePipeline
-    pipe = FramePipeline(load_weights(depthNet(3.0, PLANES), 1).to(dev), load_weights(DepthRefineNet(32, 3.0), 2).to(dev),
+    pipe = FramePipeline(load_weights(depthNet(3.0, PLANES, precision=a.precision), 1).to(dev),
+                         load_weights(DepthRefineNet(32, 3.0, precision=a.precision), 2).to(dev),
                          k_size=KSIZE, normals=True)
     B = a.frames_per_gpu
     img, cams = syn.frames(B, SRC, H, W, seed=1234 + rank)       # each rank its own shard of frames
@@ -202,11 +205,12 @@ def main():
         frames = world * B * a.steps
         line = {"metric": "frames/sec (ref+2src, 256x192, 64 planes)", "value": frames / elapsed, "unit": "frames/s",
                 "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32" if a.precision == "f32" else "f16 storage / f32 accumulate", "data": "synthetic",
                 "config": {"workload": "CNMNet eval frame: 2x depthNet + DepthRefineNet + Depth2normal(k=9), 1 ref + 2 src, "
                                        "256x192, 64 planes, batch=%d frames per GPU (BASELINE configs[1])" % B,
                            "frames_per_gpu": B, "sharding": "independent frame shards per GPU, no collective"}}
-        if not a.no_roofline:
+        if not a.no_roofline and a.precision == "f32":
             line["roofline"], line["roofline_planesweep"] = kernel_rooflines(dev, B)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()

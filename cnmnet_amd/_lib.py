@@ -54,6 +54,22 @@ PROTOTYPES = {
                                         c_fp, c_fp, c_fp, c_fp, c_sz, c_i, c_i, c_i, c_fp]),
     "cnm_refinenet_forward_multi_f32": (c_i, [C.POINTER(LayerWeights), c_f, c_fp, c_fp, c_i, c_fp, c_fp, c_fp,
                                               c_fp, c_sz, c_i, c_i, c_i, c_fp]),
+    "cnm_packed_conv_halfs": (c_sz, [c_i, c_i, c_i]),
+    "cnm_pack_conv_bn_f16": (c_i, [c_fp] * 6 + [c_f, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
+    "cnm_conv2d_c8_f16": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    "cnm_conv2d_cat2_c8_f16": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp,
+                                     c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    "cnm_planesweep_cat_c8_f16": (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_sz, c_i, c_i, c_i, c_i, c_i, c_d, c_d, c_fp]),
+    "cnm_upsample2x_c8_f16": (c_i, [c_fp, c_i, c_i, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    "cnm_head_sigmoid_c8_f16": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_fp, c_f, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    "cnm_refine_assemble_multi_c8_f16": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    "cnm_nchw_to_c8_f16": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    "cnm_c8_to_nchw_f16": (c_i, [c_fp, c_i, c_i, c_fp, c_i, c_i, c_i, c_i, c_fp]),
+    "cnm_depthnet_workspace_floats_f16": (c_sz, [c_i, c_i, c_i, c_i]),
+    "cnm_depthnet_forward_f16": (c_i, [C.POINTER(LayerWeights), c_f, c_i, c_fp, c_fp, c_fp, c_fp,
+                                       c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_sz, c_i, c_i, c_i, c_i, c_fp]),
+    "cnm_refinenet_forward_multi_f16": (c_i, [C.POINTER(LayerWeights), c_f, c_fp, c_fp, c_i, c_fp, c_fp, c_fp,
+                                              c_fp, c_sz, c_i, c_i, c_i, c_fp]),
     "cnm_packed_dgrad_floats": (c_sz, [c_i, c_i, c_i]),
     "cnm_pack_conv_dgrad_f32": (c_i, [c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp]),
     "cnm_conv2d_dgrad_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),

@@ -60,7 +60,14 @@ __device__ __forceinline__ float4 buffer_load_f4(const float* base, unsigned byt
 // TS = 1: ordinary convolution (any stride, via a.stride).  TS = 2: transposed stride-2 gather used by the
 // data gradient of a stride-2 layer: tap (a,b) of output pixel (y,x) reads source pixel ((y+a-pad)/2, (x+b-pad)/2)
 // when both are even and in range (the zero-upsampled view of dy, never materialised).
-template <int TC, int TP, int TS = 1>
+// F16 = true: the same kernel on fp16 data ("c8" activations: 8 channels per 16-byte pixel group, weights packed
+// [nk][Cout][32 halfs]).  Every address, the LDS image and the loader are byte-identical to the fp32 kernel (a k-step
+// is 64 bytes per row either way); only the matrix instruction (v_mfma_f32_32x32x16_f16, fp32 accumulate: the 16-byte
+// fragment a lane reads IS its 8-half operand) and the epilogue (fp32 bias/ReLU, 4 halfs = 8 bytes per lane) differ.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+template <int TC, int TP, int TS = 1, bool F16 = false>
 __global__ __launch_bounds__(256, CONV_MINW) void conv_mfma_f32_kernel(const ConvArgs a) {
     constexpr int NT = 256, WP = 2;
     constexpr int CI = TC / 64, PI = TP / 64;          // 32x32 MFMA tiles per wave
@@ -162,6 +169,11 @@ __global__ __launch_bounds__(256, CONV_MINW) void conv_mfma_f32_kernel(const Con
             _Pragma("unroll") for (int j = 0; j < PI; ++j) bf[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDK + kg * 8); \
             _Pragma("unroll") for (int i = 0; i < CI; ++i)                                                         \
                 _Pragma("unroll") for (int j = 0; j < PI; ++j) {                                                   \
+                    if constexpr (F16) {                                                                           \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(&af[i]), \
+                                                                           *reinterpret_cast<const f16x8*>(&bf[j]), acc[i][j], 0, 0, 0); \
+                        continue;                                                                                  \
+                    }                                                                                              \
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);        \
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);        \
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);        \
@@ -208,6 +220,12 @@ __global__ __launch_bounds__(256, CONV_MINW) void conv_mfma_f32_kernel(const Con
                 float4 v = make_float4(acc[i][j][4 * qd + 0] + b.x, acc[i][j][4 * qd + 1] + b.y,
                                        acc[i][j][4 * qd + 2] + b.z, acc[i][j][4 * qd + 3] + b.w);
                 if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if constexpr (F16) {     // c8: this lane owns channels c..c+3 = half of the 16-byte group c/8
+                    const f16x4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+                    char* o = reinterpret_cast<char*>(a.out + c4_offset(img, a.Gout_tot, a.gout0 + (c >> 3), HoWo, pix)) + (c & 4) * 2;
+                    *reinterpret_cast<f16x4*>(o) = h;
+                    continue;
+                }
                 *reinterpret_cast<float4*>(a.out + c4_offset(img, a.Gout_tot, a.gout0 + (c >> 2), HoWo, pix)) = v;
             }
         }
@@ -275,10 +293,10 @@ extern "C" int cnm_pack_conv_bn_f32(const float* w_oihw, const float* bn_gamma, 
     return CNM_OK;
 }
 
-template <int TC, int TP, int TS = 1>
+template <int TC, int TP, int TS = 1, bool F16 = false>
 static void launch_conv(const ConvArgs& a, hipStream_t s) {
     const int nblocks = (a.Cout_pad / TC) * cnm_ceil_div(a.M, TP);
-    conv_mfma_f32_kernel<TC, TP, TS><<<nblocks, 256, 0, s>>>(a);
+    conv_mfma_f32_kernel<TC, TP, TS, F16><<<nblocks, 256, 0, s>>>(a);
 }
 
 // out_h/out_w > 0 selects the transposed (data-gradient) gather: `in` is then dy [N,.,H,W] and the output is
@@ -288,12 +306,12 @@ static int conv_dispatch(const float* in, int Gin_total, int gin0, int Gin,
                          float* out, int Gout_total, int gout0, int Cout,
                          const float* w_packed, const float* b_packed,
                          int N, int H, int W, int ksize, int stride, int relu, void* stream,
-                         int out_h = 0, int out_w = 0, int tstride = 1) {
+                         int out_h = 0, int out_w = 0, int tstride = 1, bool f16 = false) {
     CNM_REQUIRE(in && out && w_packed, CNM_ERR_BAD_ARG);
     CNM_REQUIRE(N > 0 && H > 0 && W > 0 && Gin > 0 && Gsplit > 0 && Gsplit <= Gin, CNM_ERR_BAD_ARG);
     CNM_REQUIRE(gin0 >= 0 && gin0 + Gsplit <= Gin_total, CNM_ERR_BAD_ARG);
     CNM_REQUIRE(Gsplit == Gin || (in2 && gin2_0 >= 0 && gin2_0 + (Gin - Gsplit) <= Gin2_total), CNM_ERR_BAD_ARG);
-    CNM_REQUIRE(Cout > 0 && Cout % 4 == 0 && gout0 >= 0 && gout0 + Cout / 4 <= Gout_total, CNM_ERR_BAD_ARG);
+    CNM_REQUIRE(Cout > 0 && Cout % (f16 ? 8 : 4) == 0 && gout0 >= 0 && gout0 + Cout / (f16 ? 8 : 4) <= Gout_total, CNM_ERR_BAD_ARG);
     CNM_REQUIRE((ksize == 3 || ksize == 5 || ksize == 7) && (stride == 1 || stride == 2), CNM_ERR_BAD_ARG);
     ConvArgs a;
     a.in = in; a.out = out; a.w = w_packed; a.bias = b_packed;
@@ -317,7 +335,12 @@ static int conv_dispatch(const float* in, int Gin_total, int gin0, int Gin,
     // Tile choice: largest tile that still gives every CU (256) a couple of workgroups.
     const long long t128 = (long long)(a.Cout_pad / 128) * cnm_ceil_div(a.M, 128);
     const long long t64x128 = (long long)(a.Cout_pad / 64) * cnm_ceil_div(a.M, 128);
-    if (transposed && tstride == 2) {
+    if (f16) {
+        CNM_REQUIRE(!transposed, CNM_ERR_BAD_ARG);
+        if (a.Cout_pad % 128 == 0 && t128 >= 512) launch_conv<128, 128, 1, true>(a, s);
+        else if (t64x128 >= 512) launch_conv<64, 128, 1, true>(a, s);
+        else launch_conv<64, 64, 1, true>(a, s);
+    } else if (transposed && tstride == 2) {
         if (a.Cout_pad % 128 == 0 && t128 >= 512) launch_conv<128, 128, 2>(a, s);
         else if (t64x128 >= 512) launch_conv<64, 128, 2>(a, s);
         else launch_conv<64, 64, 2>(a, s);
@@ -396,4 +419,72 @@ extern "C" int cnm_conv2d_dgrad_c4_f32(const float* dy, int Gy_total, int gy0, i
     const int Gy = (Cout + 3) / 4;
     return conv_dispatch(dy, Gy_total, gy0, Gy, nullptr, 0, 0, Gy, dx, Gx_total, gx0, 4 * ((Cin + 3) / 4),
                          w_packed_dgrad, nullptr, N, Ho, Wo, ksize, 1, 0, stream, H, W, stride);
+}
+
+
+// ------------------------------------------------------------------ fp16 path (BASELINE config 5)
+__global__ void pack_conv_f16_kernel(const float* __restrict__ w, const float* __restrict__ gamma,
+                                     const float* __restrict__ var, float eps, int Cout, int Cout_pad, int Cin, int ks, int rot,
+                                     int Kpad, _Float16* __restrict__ wp) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)Kpad * Cout_pad) return;
+    const int kk = (int)(idx % 32);
+    const int co = (int)((idx / 32) % Cout_pad);
+    const int kstep = (int)((idx / 32) / Cout_pad);
+    const int k = kstep * 32 + kk;
+    const int Cp = 8 * ((Cin + 7) / 8);
+    const int tap = k / Cp, cp = k - tap * Cp;
+    float v = 0.f;
+    if (tap < ks * ks && cp < Cin && co < Cout) {
+        const int ci = (cp + rot) % Cin;
+        double s = 1.0;
+        if (gamma) s = (double)gamma[co] / sqrt((double)var[co] + (double)eps);
+        v = (float)((double)w[((size_t)co * Cin + ci) * ks * ks + tap] * s);
+    }
+    wp[idx] = (_Float16)v;
+}
+
+static inline int conv_kpad_f16(int Cin, int ks) { return ((ks * ks * 8 * ((Cin + 7) / 8) + 31) / 32) * 32; }
+
+extern "C" size_t cnm_packed_conv_halfs(int Cout, int Cin, int ksize) {
+    if (Cout <= 0 || Cin <= 0 || ksize <= 0) return 0;
+    return (size_t)conv_kpad_f16(Cin, ksize) * (size_t)round64(Cout);
+}
+
+extern "C" int cnm_pack_conv_bn_f16(const float* w_oihw, const float* bn_gamma, const float* bn_beta,
+                                    const float* bn_mean, const float* bn_var, const float* bias, float eps,
+                                    int Cout, int Cin, int ksize, int rot,
+                                    void* w_packed_f16, float* b_packed, void* stream) {
+    CNM_REQUIRE(w_oihw && w_packed_f16 && b_packed, CNM_ERR_BAD_ARG);
+    CNM_REQUIRE(Cout > 0 && Cin > 0 && ksize > 0 && (ksize & 1) && rot >= 0 && rot < Cin, CNM_ERR_BAD_ARG);
+    const bool bn = bn_gamma || bn_beta || bn_mean || bn_var;
+    CNM_REQUIRE(!bn || (bn_gamma && bn_beta && bn_mean && bn_var), CNM_ERR_BAD_ARG);
+    const int Kpad = conv_kpad_f16(Cin, ksize);
+    const long long total = (long long)Kpad * round64(Cout);
+    pack_conv_f16_kernel<<<(unsigned)cnm_ceil_div_ll(total, 256), 256, 0, cnm_stream(stream)>>>(
+        w_oihw, bn_gamma, bn_var, eps, Cout, round64(Cout), Cin, ksize, rot, Kpad, static_cast<_Float16*>(w_packed_f16));
+    pack_bias_kernel<<<cnm_ceil_div(Cout, 256), 256, 0, cnm_stream(stream)>>>(
+        bn_gamma, bn_beta, bn_mean, bn_var, bias, eps, Cout, b_packed);
+    CNM_LAUNCH_CHECK();
+    return CNM_OK;
+}
+
+extern "C" int cnm_conv2d_c8_f16(const void* in, int Gin_total, int gin0, int Gin,
+                                 void* out, int Gout_total, int gout0, int Cout,
+                                 const void* w_packed_f16, const float* b_packed,
+                                 int N, int H, int W, int ksize, int stride, int relu, void* stream) {
+    return conv_dispatch(static_cast<const float*>(in), Gin_total, gin0, Gin, nullptr, 0, 0, Gin,
+                         static_cast<float*>(out), Gout_total, gout0, Cout, static_cast<const float*>(w_packed_f16), b_packed,
+                         N, H, W, ksize, stride, relu, stream, 0, 0, 1, true);
+}
+
+extern "C" int cnm_conv2d_cat2_c8_f16(const void* in_a, int Ga_total, int ga0, int Ga,
+                                      const void* in_b, int Gb_total, int gb0, int Gb,
+                                      void* out, int Gout_total, int gout0, int Cout,
+                                      const void* w_packed_f16, const float* b_packed,
+                                      int N, int H, int W, int ksize, int stride, int relu, void* stream) {
+    CNM_REQUIRE(Ga > 0 && Gb > 0, CNM_ERR_BAD_ARG);
+    return conv_dispatch(static_cast<const float*>(in_a), Ga_total, ga0, Ga + Gb, static_cast<const float*>(in_b), Gb_total, gb0, Ga,
+                         static_cast<float*>(out), Gout_total, gout0, Cout, static_cast<const float*>(w_packed_f16), b_packed,
+                         N, H, W, ksize, stride, relu, stream, 0, 0, 1, true);
 }

@@ -1,0 +1,186 @@
+// fp16 path (BASELINE config 5): the memory-bound operators on "c8" activations -- [N][G][H][W][8 halfs],
+// channel c = 8g + j, 16 bytes per (pixel, group) exactly like the fp32 c4 layout, so every offset helper is shared.
+// Arithmetic inside each kernel is fp32; only storage is fp16.
+#include "cnm_common.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f16x8 ld8(const float* base, size_t chunk_off) {      // chunk_off in floats (16 B = 4 floats)
+    return *reinterpret_cast<const f16x8*>(base + chunk_off);
+}
+__device__ __forceinline__ void st8(float* base, size_t chunk_off, f16x8 v) {
+    *reinterpret_cast<f16x8*>(base + chunk_off) = v;
+}
+
+// ------------------------------------------------------------------ bilinear x2
+__global__ __launch_bounds__(256) void upsample2x_c8h_kernel(const float* __restrict__ in, int Gin_tot, int gin0,
+                                                             float* __restrict__ out, int Gout_tot, int gout0,
+                                                             int N, int G, int H, int W) {
+    const int Wo = 2 * W, Ho = 2 * H;
+    const long long total = (long long)N * G * Ho * Wo;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int ox = (int)(idx % Wo);
+        long long r = idx / Wo;
+        const int oy = (int)(r % Ho); r /= Ho;
+        const int g = (int)(r % G), n = (int)(r / G);
+        const float sy = fmaxf((oy + 0.5f) * 0.5f - 0.5f, 0.f), sx = fmaxf((ox + 0.5f) * 0.5f - 0.5f, 0.f);
+        const int y0 = (int)sy, x0 = (int)sx, y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+        const float ly = sy - y0, lx = sx - x0, hy = 1.f - ly, hx = 1.f - lx;
+        const size_t b = c4_offset(n, Gin_tot, gin0 + g, H * W, 0);
+        const f16x8 p00 = ld8(in, b + (size_t)(y0 * W + x0) * 4), p01 = ld8(in, b + (size_t)(y0 * W + x1) * 4);
+        const f16x8 p10 = ld8(in, b + (size_t)(y1 * W + x0) * 4), p11 = ld8(in, b + (size_t)(y1 * W + x1) * 4);
+        f16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            v[j] = (_Float16)(hy * (hx * (float)p00[j] + lx * (float)p01[j]) + ly * (hx * (float)p10[j] + lx * (float)p11[j]));
+        st8(out, c4_offset(n, Gout_tot, gout0 + g, Ho * Wo, oy * Wo + ox), v);
+    }
+}
+
+extern "C" int cnm_upsample2x_c8_f16(const void* in, int Gin_total, int gin0, void* out, int Gout_total, int gout0,
+                                     int N, int G, int H, int W, void* stream) {
+    CNM_REQUIRE(in && out && N > 0 && G > 0 && H > 0 && W > 0, CNM_ERR_BAD_ARG);
+    CNM_REQUIRE(gin0 >= 0 && gin0 + G <= Gin_total && gout0 >= 0 && gout0 + G <= Gout_total, CNM_ERR_BAD_ARG);
+    const long long total = (long long)N * G * 4 * H * W;
+    upsample2x_c8h_kernel<<<(int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384), 256, 0, cnm_stream(stream)>>>(
+        static_cast<const float*>(in), Gin_total, gin0, static_cast<float*>(out), Gout_total, gout0, N, G, H, W);
+    CNM_LAUNCH_CHECK();
+    return CNM_OK;
+}
+
+// ------------------------------------------------------------------ disparity head (fp32 weights, fp32 output)
+__global__ __launch_bounds__(256) void head_sigmoid_c8h_kernel(const float* __restrict__ in, int Gin_tot, int gin0, int G,
+                                                               const float* __restrict__ wh, const float* __restrict__ bias,
+                                                               float scale, float* __restrict__ disp,
+                                                               float* __restrict__ up_out, int up_Gtot, int up_g,
+                                                               int N, int H, int W) {
+    const int HW = H * W;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)N * HW) return;
+    const int n = (int)(idx / HW), pix = (int)(idx - (long long)n * HW);
+    const int y = pix / W, x = pix - y * W;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < G; ++g) {
+        const size_t b = c4_offset(n, Gin_tot, gin0 + g, HW, 0);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = y + ky - 1;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = x + kx - 1;
+                if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) continue;
+                const f16x8 v = ld8(in, b + (size_t)(iy * W + ix) * 4);
+                const float* w = wh + (size_t)(ky * 3 + kx) * (G * 8) + g * 8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j & 3] = fmaf((float)v[j], w[j], acc[j & 3]);
+            }
+        }
+    }
+    const float s = (acc[0] + acc[1]) + (acc[2] + acc[3]) + bias[0];
+    const float d = scale / (1.f + expf(-s));
+    disp[idx] = d;
+    if (up_out) {
+        const int Wo = 2 * W;
+        f16x8 v = {(_Float16)d, 0, 0, 0, 0, 0, 0, 0};
+        const size_t o = c4_offset(n, up_Gtot, up_g, 4 * HW, (2 * y) * Wo + 2 * x);
+        st8(up_out, o, v); st8(up_out, o + 4, v); st8(up_out, o + (size_t)Wo * 4, v); st8(up_out, o + (size_t)Wo * 4 + 4, v);
+    }
+}
+
+extern "C" int cnm_head_sigmoid_c8_f16(const void* in, int Gin_total, int gin0, int C,
+                                       const float* w_head, const float* bias, float scale,
+                                       float* disp, void* up_out, int up_Gtotal, int up_g,
+                                       int N, int H, int W, void* stream) {
+    CNM_REQUIRE(in && w_head && bias && disp && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, CNM_ERR_BAD_ARG);
+    CNM_REQUIRE(gin0 >= 0 && gin0 + C / 8 <= Gin_total && (!up_out || (up_g >= 0 && up_g < up_Gtotal)), CNM_ERR_BAD_ARG);
+    const long long total = (long long)N * H * W;
+    head_sigmoid_c8h_kernel<<<(unsigned)cnm_ceil_div_ll(total, 256), 256, 0, cnm_stream(stream)>>>(
+        static_cast<const float*>(in), Gin_total, gin0, C / 8, w_head, bias, scale, disp, static_cast<float*>(up_out), up_Gtotal, up_g, N, H, W);
+    CNM_LAUNCH_CHECK();
+    return CNM_OK;
+}
+
+// ------------------------------------------------------------------ refine input assembly (S sources, S even; S = 2 is the plain case)
+// x = [mean_even(f) + mean_odd(f) (C channels), id_even, id_odd, |id_even - id_odd|, 0 x5]   (depthNet_model.py:332-333, eval.py:656-663)
+__global__ __launch_bounds__(256) void refine_assemble_multi_c8h_kernel(const float* __restrict__ idp, const float* __restrict__ f,
+                                                                        float* __restrict__ x, int B, int S, int G, int HW) {
+    const long long total = (long long)B * (G + 1) * HW;
+    const int h = S / 2;
+    const float inv = h == 1 ? 1.f : (h == 2 ? 0.5f : 1.f / (float)h);
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int pix = (int)(idx % HW);
+        const long long r = idx / HW;
+        const int g = (int)(r % (G + 1)), b = (int)(r / (G + 1));
+        f16x8 v;
+        if (g < G) {
+            float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int k = 0; k < h; ++k) {
+                const f16x8 a = ld8(f, c4_offset(b * S + 2 * k, G, g, HW, pix)), c = ld8(f, c4_offset(b * S + 2 * k + 1, G, g, HW, pix));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { s1[j] += (float)a[j]; s2[j] += (float)c[j]; }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (_Float16)(s1[j] * inv + s2[j] * inv);
+        } else {
+            float a = 0.f, c = 0.f;
+            for (int k = 0; k < h; ++k) { a += idp[(size_t)(b * S + 2 * k) * HW + pix]; c += idp[(size_t)(b * S + 2 * k + 1) * HW + pix]; }
+            a *= inv; c *= inv;
+            v = (f16x8){(_Float16)a, (_Float16)c, (_Float16)fabsf(a - c), 0, 0, 0, 0, 0};
+        }
+        st8(x, c4_offset(b, G + 1, g, HW, pix), v);
+    }
+}
+
+extern "C" int cnm_refine_assemble_multi_c8_f16(const float* idepth_pairs, const void* feat_pairs_c8, void* x,
+                                                int B, int S, int C, int H, int W, void* stream) {
+    CNM_REQUIRE(idepth_pairs && feat_pairs_c8 && x && B > 0 && S >= 2 && S % 2 == 0 && C > 0 && C % 8 == 0 && H > 0 && W > 0, CNM_ERR_BAD_ARG);
+    const long long total = (long long)B * (C / 8 + 1) * H * W;
+    refine_assemble_multi_c8h_kernel<<<(int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384), 256, 0, cnm_stream(stream)>>>(
+        idepth_pairs, static_cast<const float*>(feat_pairs_c8), static_cast<float*>(x), B, S, C / 8, H * W);
+    CNM_LAUNCH_CHECK();
+    return CNM_OK;
+}
+
+// ------------------------------------------------------------------ layout converters NCHW fp32 <-> c8 fp16
+__global__ __launch_bounds__(256) void nchw_to_c8h_kernel(const float* __restrict__ src, float* __restrict__ dst, int Gt, int g0, int N, int C, int HW) {
+    const int G = (C + 7) / 8;
+    const long long total = (long long)N * G * HW;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int pix = (int)(idx % HW);
+        const long long r = idx / HW;
+        const int g = (int)(r % G), n = (int)(r / G);
+        f16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int c = 8 * g + j; v[j] = (_Float16)(c < C ? src[((size_t)n * C + c) * HW + pix] : 0.f); }
+        st8(dst, c4_offset(n, Gt, g0 + g, HW, pix), v);
+    }
+}
+
+__global__ __launch_bounds__(256) void c8h_to_nchw_kernel(const float* __restrict__ src, int Gt, int g0, float* __restrict__ dst, int N, int C, int HW) {
+    const int G = (C + 7) / 8;
+    const long long total = (long long)N * G * HW;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int pix = (int)(idx % HW);
+        const long long r = idx / HW;
+        const int g = (int)(r % G), n = (int)(r / G);
+        const f16x8 v = ld8(src, c4_offset(n, Gt, g0 + g, HW, pix));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int c = 8 * g + j; if (c < C) dst[((size_t)n * C + c) * HW + pix] = (float)v[j]; }
+    }
+}
+
+extern "C" int cnm_nchw_to_c8_f16(const float* nchw, void* c8, int G_total, int g0, int N, int C, int H, int W, void* stream) {
+    CNM_REQUIRE(nchw && c8 && N > 0 && C > 0 && H > 0 && W > 0 && g0 >= 0 && g0 + (C + 7) / 8 <= G_total, CNM_ERR_BAD_ARG);
+    const long long total = (long long)N * ((C + 7) / 8) * H * W;
+    nchw_to_c8h_kernel<<<(int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384), 256, 0, cnm_stream(stream)>>>(nchw, static_cast<float*>(c8), G_total, g0, N, C, H * W);
+    CNM_LAUNCH_CHECK();
+    return CNM_OK;
+}
+
+extern "C" int cnm_c8_to_nchw_f16(const void* c8, int G_total, int g0, float* nchw, int N, int C, int H, int W, void* stream) {
+    CNM_REQUIRE(nchw && c8 && N > 0 && C > 0 && H > 0 && W > 0 && g0 >= 0 && g0 + (C + 7) / 8 <= G_total, CNM_ERR_BAD_ARG);
+    const long long total = (long long)N * ((C + 7) / 8) * H * W;
+    c8h_to_nchw_kernel<<<(int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384), 256, 0, cnm_stream(stream)>>>(static_cast<const float*>(c8), G_total, g0, nchw, N, C, H * W);
+    CNM_LAUNCH_CHECK();
+    return CNM_OK;
+}

@@ -67,6 +67,48 @@ extern "C" int cnm_net_layer(int net, int index, cnm_layer_info* info) {
     return CNM_OK;
 }
 
+// ------------------------------------------------------------------ engines (fp32 c4 / fp16 c8)
+// Both activation layouts use 16 bytes per (pixel, channel group); a policy supplies the group width and the
+// operator entry points, the launch sequences below are shared.
+extern "C" {
+int cnm_conv2d_c8_f16(const void*, int, int, int, void*, int, int, int, const void*, const float*, int, int, int, int, int, int, void*);
+int cnm_conv2d_cat2_c8_f16(const void*, int, int, int, const void*, int, int, int, void*, int, int, int, const void*, const float*, int, int, int, int, int, int, void*);
+int cnm_upsample2x_c8_f16(const void*, int, int, void*, int, int, int, int, int, int, void*);
+int cnm_head_sigmoid_c8_f16(const void*, int, int, int, const float*, const float*, float, float*, void*, int, int, int, int, int, void*);
+int cnm_refine_assemble_multi_c8_f16(const float*, const void*, void*, int, int, int, int, int, void*);
+int cnm_planesweep_cat_c8_f16(const float*, const float*, const float*, void*, float*, size_t, int, int, int, int, int, double, double, void*);
+}
+
+struct EngF32 {
+    static constexpr int GD = 4;
+    static int conv(const float* in, int Gt, int g0, int Gin, float* out, int Gto, int go0, int Cout, const cnm_layer_weights& w, int N, int H, int W, int k, int st, void* s) {
+        return cnm_conv2d_c4_f32(in, Gt, g0, Gin, out, Gto, go0, Cout, w.w, w.b, N, H, W, k, st, 1, s); }
+    static int conv2(const float* a, int Ga, const float* b, int Gb, float* out, int Gto, int Cout, const cnm_layer_weights& w, int N, int H, int W, void* s) {
+        return cnm_conv2d_cat2_c4_f32(a, Ga, 0, Ga, b, Gb, 0, Gb, out, Gto, 0, Cout, w.w, w.b, N, H, W, 3, 1, 1, s); }
+    static int up(const float* in, int G, float* out, int N, int H, int W, void* s) { return cnm_upsample2x_c4_f32(in, G, 0, out, G, 0, N, G, H, W, s); }
+    static int head(const float* in, int G, int C, const cnm_layer_weights& w, float scale, float* disp, float* up, int upG, int upg, int N, int H, int W, void* s) {
+        return cnm_head_sigmoid_c4_f32(in, G, 0, C, w.w, w.b, scale, disp, up, upG, upg, N, H, W, s); }
+    static int assemble_multi(const float* idp, const float* f, float* x, int B, int S, int H, int W, void* s) { return cnm_refine_assemble_multi_c4_f32(idp, f, x, B, S, 64, H, W, s); }
+    static int sweep(const float* ref, const float* src, const float* hmkt, float* x, float* tex, size_t texn, int B, int S, int H, int W, int D, double lo, double hi, void* s) {
+        return cnm_planesweep_cat_c4_f32(ref, src, hmkt, x, tex, texn, B, S, H, W, D, lo, hi, s); }
+};
+
+struct EngF16 {
+    static constexpr int GD = 8;
+    static int conv(const float* in, int Gt, int g0, int Gin, float* out, int Gto, int go0, int Cout, const cnm_layer_weights& w, int N, int H, int W, int k, int st, void* s) {
+        return cnm_conv2d_c8_f16(in, Gt, g0, Gin, out, Gto, go0, Cout, w.w, w.b, N, H, W, k, st, 1, s); }
+    static int conv2(const float* a, int Ga, const float* b, int Gb, float* out, int Gto, int Cout, const cnm_layer_weights& w, int N, int H, int W, void* s) {
+        return cnm_conv2d_cat2_c8_f16(a, Ga, 0, Ga, b, Gb, 0, Gb, out, Gto, 0, Cout, w.w, w.b, N, H, W, 3, 1, 1, s); }
+    static int up(const float* in, int G, float* out, int N, int H, int W, void* s) { return cnm_upsample2x_c8_f16(in, G, 0, out, G, 0, N, G, H, W, s); }
+    static int head(const float* in, int G, int C, const cnm_layer_weights& w, float scale, float* disp, float* up, int upG, int upg, int N, int H, int W, void* s) {
+        return cnm_head_sigmoid_c8_f16(in, G, 0, C, w.w, w.b, scale, disp, up, upG, upg, N, H, W, s); }
+    static int assemble_multi(const float* idp, const float* f, float* x, int B, int S, int H, int W, void* s) { return cnm_refine_assemble_multi_c8_f16(idp, f, x, B, S, 64, H, W, s); }
+    static int sweep(const float* ref, const float* src, const float* hmkt, float* x, float* tex, size_t texn, int B, int S, int H, int W, int D, double lo, double hi, void* s) {
+        return cnm_planesweep_cat_c8_f16(ref, src, hmkt, x, tex, texn, B, S, H, W, D, lo, hi, s); }
+};
+
+#define CNM_TRY(expr) do { int _e = (expr); if (_e != CNM_OK) return _e; } while (0)
+
 // ------------------------------------------------------------------ workspace carving
 struct Carver {
     float* base; size_t used;
@@ -77,135 +119,157 @@ struct DepthBufs {
     float *hmkt, *TEX, *X0, *A1, *CAT2, *A2, *CAT3, *A3, *CAT4, *A4, *CAT5, *A5, *C5, *U5, *I5, *U4, *I4, *U3, *I3, *U2, *I2, *U1, *CAT1;
 };
 
+template <class E>
 static size_t carve_depth(float* ws, int P, int H, int W, int D, DepthBufs* b) {
     Carver c{ws, 0};
-    const size_t q = (size_t)P * H * W * 4;     // floats of one channel group at full resolution
+    const size_t q = (size_t)P * H * W * 4;     // floats (= 16 bytes x pixels) of one channel group at full resolution
+    auto G = [](int C) { return (size_t)((C + E::GD - 1) / E::GD); };
     b->hmkt = c.take((size_t)P * 12);
     b->TEX = c.take((size_t)P * (H + 4) * (W + 4) * 4);
-    b->X0 = c.take(q * (D / 4 + 1));
-    b->A1 = c.take(q * 32);        b->U1 = c.take(q * 32);       b->CAT1 = c.take(q * 17);
-    b->CAT2 = c.take(q / 4 * 65);  b->A2 = c.take(q / 4 * 64);   b->U2 = c.take(q / 4 * 64);   b->I2 = c.take(q / 4 * 32);
-    b->CAT3 = c.take(q / 16 * 129); b->A3 = c.take(q / 16 * 128); b->U3 = c.take(q / 16 * 128); b->I3 = c.take(q / 16 * 64);
-    b->CAT4 = c.take(q / 64 * 256); b->A4 = c.take(q / 64 * 128); b->U4 = c.take(q / 64 * 128); b->I4 = c.take(q / 64 * 128);
-    b->CAT5 = c.take(q / 256 * 256); b->A5 = c.take(q / 256 * 128); b->U5 = c.take(q / 256 * 128); b->I5 = c.take(q / 256 * 128);
-    b->C5 = c.take(q / 1024 * 128);
+    b->X0 = c.take(q * (G(D) + 1));
+    b->A1 = c.take(q * G(128));        b->U1 = c.take(q * G(128));       b->CAT1 = c.take(q * (G(64) + 1));
+    b->CAT2 = c.take(q / 4 * (2 * G(128) + 1));  b->A2 = c.take(q / 4 * G(256));   b->U2 = c.take(q / 4 * G(256));   b->I2 = c.take(q / 4 * G(128));
+    b->CAT3 = c.take(q / 16 * (2 * G(256) + 1)); b->A3 = c.take(q / 16 * G(512)); b->U3 = c.take(q / 16 * G(512)); b->I3 = c.take(q / 16 * G(256));
+    b->CAT4 = c.take(q / 64 * 2 * G(512)); b->A4 = c.take(q / 64 * G(512)); b->U4 = c.take(q / 64 * G(512)); b->I4 = c.take(q / 64 * G(512));
+    b->CAT5 = c.take(q / 256 * 2 * G(512)); b->A5 = c.take(q / 256 * G(512)); b->U5 = c.take(q / 256 * G(512)); b->I5 = c.take(q / 256 * G(512));
+    b->C5 = c.take(q / 1024 * G(512));
     return c.used;
 }
 
 extern "C" size_t cnm_depthnet_workspace_floats(int P, int H, int W, int D) {
     if (P <= 0 || H <= 0 || W <= 0 || D < 4 || (H % 32) || (W % 32) || (D % 4)) return 0;
     DepthBufs b;
-    return carve_depth(nullptr, P, H, W, D, &b);
+    return carve_depth<EngF32>(nullptr, P, H, W, D, &b);
 }
 
-#define CNM_TRY(expr) do { int _e = (expr); if (_e != CNM_OK) return _e; } while (0)
+extern "C" size_t cnm_depthnet_workspace_floats_f16(int P, int H, int W, int D) {
+    if (P <= 0 || H <= 0 || W <= 0 || D < 8 || (H % 32) || (W % 32) || (D % 8)) return 0;
+    DepthBufs b;
+    return carve_depth<EngF16>(nullptr, P, H, W, D, &b);
+}
 
-extern "C" int cnm_depthnet_forward_f32(const cnm_layer_weights* wt, float idepth_scale, int D,
-                                        const float* ref, const float* src, const float* ref_cam, const float* src_cam,
-                                        float* disp1, float* disp2, float* disp3, float* disp4, float* iconv1_c4,
-                                        float* ws, size_t ws_floats, int B, int S, int H, int W, void* stream) {
-    CNM_REQUIRE(wt && ref && src && ref_cam && src_cam && disp1 && disp2 && disp3 && disp4 && iconv1_c4 && ws, CNM_ERR_BAD_ARG);
-    CNM_REQUIRE(B > 0 && S > 0 && D >= 4 && D % 4 == 0 && D <= 128, CNM_ERR_BAD_ARG);
+template <class E>
+static int depthnet_forward(const cnm_layer_weights* wt, float idepth_scale, int D,
+                            const float* ref, const float* src, const float* ref_cam, const float* src_cam,
+                            float* disp1, float* disp2, float* disp3, float* disp4, float* iconv1,
+                            float* ws, size_t ws_floats, int B, int S, int H, int W, void* s) {
+    CNM_REQUIRE(wt && ref && src && ref_cam && src_cam && disp1 && disp2 && disp3 && disp4 && iconv1 && ws, CNM_ERR_BAD_ARG);
+    CNM_REQUIRE(B > 0 && S > 0 && D >= E::GD && D % E::GD == 0 && D <= 128, CNM_ERR_BAD_ARG);
     CNM_REQUIRE(H > 0 && W > 0 && H % 32 == 0 && W % 32 == 0, CNM_ERR_BAD_SHAPE);
     double idmin, idmax;
     CNM_TRY(cnm_idepth_range_host((double)idepth_scale, &idmin, &idmax));
     for (int i = 0; i < D_NUM; ++i) CNM_REQUIRE(wt[i].w && wt[i].b, CNM_ERR_BAD_ARG);
     const int P = B * S;
     DepthBufs b;
-    CNM_REQUIRE(carve_depth(ws, P, H, W, D, &b) <= ws_floats, CNM_ERR_WORKSPACE);
-    const int G0 = D / 4 + 1;
+    CNM_REQUIRE(carve_depth<E>(ws, P, H, W, D, &b) <= ws_floats, CNM_ERR_WORKSPACE);
+    auto G = [](int C) { return (C + E::GD - 1) / E::GD; };
+    const int G0 = G(D) + 1, g64 = G(64), g128 = G(128), g256 = G(256), g512 = G(512);
     const int H1 = H / 2, W1 = W / 2, H2 = H / 4, W2 = W / 4, H3 = H / 8, W3 = W / 8, H4 = H / 16, W4 = W / 16, H5 = H / 32, W5 = W / 32;
-    void* s = stream;
 #define CONV(L, in, Gt, g0, Gin, out, Gto, go0, Cout, HH, WW) \
-    CNM_TRY(cnm_conv2d_c4_f32(in, Gt, g0, Gin, out, Gto, go0, Cout, wt[L].w, wt[L].b, P, HH, WW, kDepthLayers[L].ksize, kDepthLayers[L].stride, 1, s))
+    CNM_TRY(E::conv(in, Gt, g0, Gin, out, Gto, go0, Cout, wt[L], P, HH, WW, kDepthLayers[L].ksize, kDepthLayers[L].stride, s))
     // geometry + cost volume                                                   depthNet_model.py:228-233
     CNM_TRY(cnm_homography_terms_f32(ref_cam, src_cam, b.hmkt, B, S, s));
-    CNM_TRY(cnm_planesweep_cat_c4_f32(ref, src, b.hmkt, b.X0, b.TEX, (size_t)P * (H + 4) * (W + 4) * 4, B, S, H, W, D, idmin, idmax, s));
+    CNM_TRY(E::sweep(ref, src, b.hmkt, b.X0, b.TEX, (size_t)P * (H + 4) * (W + 4) * 4, B, S, H, W, D, idmin, idmax, s));
     // encoder                                                                  :235-239
-    CONV(D_CONV1_0, b.X0, G0, 0, G0, b.A1, 32, 0, 128, H, W);
-    CONV(D_CONV1_3, b.A1, 32, 0, 32, b.CAT2, 65, 32, 128, H, W);           // conv1 -> skip slot of iconv2
-    CONV(D_CONV2_0, b.CAT2, 65, 32, 32, b.A2, 64, 0, 256, H1, W1);
-    CONV(D_CONV2_3, b.A2, 64, 0, 64, b.CAT3, 129, 64, 256, H1, W1);        // conv2 -> skip slot of iconv3
-    CONV(D_CONV3_0, b.CAT3, 129, 64, 64, b.A3, 128, 0, 512, H2, W2);
-    CONV(D_CONV3_3, b.A3, 128, 0, 128, b.CAT4, 256, 128, 512, H2, W2);     // conv3 -> skip slot of iconv4
-    CONV(D_CONV4_0, b.CAT4, 256, 128, 128, b.A4, 128, 0, 512, H3, W3);
-    CONV(D_CONV4_3, b.A4, 128, 0, 128, b.CAT5, 256, 128, 512, H3, W3);     // conv4 -> skip slot of iconv5
-    CONV(D_CONV5_0, b.CAT5, 256, 128, 128, b.A5, 128, 0, 512, H4, W4);
-    CONV(D_CONV5_3, b.A5, 128, 0, 128, b.C5, 128, 0, 512, H4, W4);
+    CONV(D_CONV1_0, b.X0, G0, 0, G0, b.A1, g128, 0, 128, H, W);
+    CONV(D_CONV1_3, b.A1, g128, 0, g128, b.CAT2, 2 * g128 + 1, g128, 128, H, W);              // conv1 -> skip slot of iconv2
+    CONV(D_CONV2_0, b.CAT2, 2 * g128 + 1, g128, g128, b.A2, g256, 0, 256, H1, W1);
+    CONV(D_CONV2_3, b.A2, g256, 0, g256, b.CAT3, 2 * g256 + 1, g256, 256, H1, W1);            // conv2 -> skip slot of iconv3
+    CONV(D_CONV3_0, b.CAT3, 2 * g256 + 1, g256, g256, b.A3, g512, 0, 512, H2, W2);
+    CONV(D_CONV3_3, b.A3, g512, 0, g512, b.CAT4, 2 * g512, g512, 512, H2, W2);                // conv3 -> skip slot of iconv4
+    CONV(D_CONV4_0, b.CAT4, 2 * g512, g512, g512, b.A4, g512, 0, 512, H3, W3);
+    CONV(D_CONV4_3, b.A4, g512, 0, g512, b.CAT5, 2 * g512, g512, 512, H3, W3);                // conv4 -> skip slot of iconv5
+    CONV(D_CONV5_0, b.CAT5, 2 * g512, g512, g512, b.A5, g512, 0, 512, H4, W4);
+    CONV(D_CONV5_3, b.A5, g512, 0, g512, b.C5, g512, 0, 512, H4, W4);
     // decoder                                                                  :241-261
-    CNM_TRY(cnm_upsample2x_c4_f32(b.C5, 128, 0, b.U5, 128, 0, P, 128, H5, W5, s));
-    CONV(D_UPCONV5, b.U5, 128, 0, 128, b.CAT5, 256, 0, 512, H4, W4);
-    CONV(D_ICONV5, b.CAT5, 256, 0, 256, b.I5, 128, 0, 512, H4, W4);
-    CNM_TRY(cnm_upsample2x_c4_f32(b.I5, 128, 0, b.U4, 128, 0, P, 128, H4, W4, s));
-    CONV(D_UPCONV4, b.U4, 128, 0, 128, b.CAT4, 256, 0, 512, H3, W3);
-    CONV(D_ICONV4, b.CAT4, 256, 0, 256, b.I4, 128, 0, 512, H3, W3);
-    CNM_TRY(cnm_head_sigmoid_c4_f32(b.I4, 128, 0, 512, wt[D_DISP4].w, wt[D_DISP4].b, idepth_scale, disp4, b.CAT3, 129, 128, P, H3, W3, s));
-    CNM_TRY(cnm_upsample2x_c4_f32(b.I4, 128, 0, b.U3, 128, 0, P, 128, H3, W3, s));
-    CONV(D_UPCONV3, b.U3, 128, 0, 128, b.CAT3, 129, 0, 256, H2, W2);
-    CONV(D_ICONV3, b.CAT3, 129, 0, 129, b.I3, 64, 0, 256, H2, W2);
-    CNM_TRY(cnm_head_sigmoid_c4_f32(b.I3, 64, 0, 256, wt[D_DISP3].w, wt[D_DISP3].b, idepth_scale, disp3, b.CAT2, 65, 64, P, H2, W2, s));
-    CNM_TRY(cnm_upsample2x_c4_f32(b.I3, 64, 0, b.U2, 64, 0, P, 64, H2, W2, s));
-    CONV(D_UPCONV2, b.U2, 64, 0, 64, b.CAT2, 65, 0, 128, H1, W1);
-    CONV(D_ICONV2, b.CAT2, 65, 0, 65, b.I2, 32, 0, 128, H1, W1);
-    CNM_TRY(cnm_head_sigmoid_c4_f32(b.I2, 32, 0, 128, wt[D_DISP2].w, wt[D_DISP2].b, idepth_scale, disp2, b.CAT1, 17, 16, P, H1, W1, s));
-    CNM_TRY(cnm_upsample2x_c4_f32(b.I2, 32, 0, b.U1, 32, 0, P, 32, H1, W1, s));
-    CONV(D_UPCONV1, b.U1, 32, 0, 32, b.CAT1, 17, 0, 64, H, W);
-    CONV(D_ICONV1, b.CAT1, 17, 0, 17, iconv1_c4, 16, 0, 64, H, W);
-    CNM_TRY(cnm_head_sigmoid_c4_f32(iconv1_c4, 16, 0, 64, wt[D_DISP1].w, wt[D_DISP1].b, idepth_scale, disp1, nullptr, 0, 0, P, H, W, s));
+    CNM_TRY(E::up(b.C5, g512, b.U5, P, H5, W5, s));
+    CONV(D_UPCONV5, b.U5, g512, 0, g512, b.CAT5, 2 * g512, 0, 512, H4, W4);
+    CONV(D_ICONV5, b.CAT5, 2 * g512, 0, 2 * g512, b.I5, g512, 0, 512, H4, W4);
+    CNM_TRY(E::up(b.I5, g512, b.U4, P, H4, W4, s));
+    CONV(D_UPCONV4, b.U4, g512, 0, g512, b.CAT4, 2 * g512, 0, 512, H3, W3);
+    CONV(D_ICONV4, b.CAT4, 2 * g512, 0, 2 * g512, b.I4, g512, 0, 512, H3, W3);
+    CNM_TRY(E::head(b.I4, g512, 512, wt[D_DISP4], idepth_scale, disp4, b.CAT3, 2 * g256 + 1, 2 * g256, P, H3, W3, s));
+    CNM_TRY(E::up(b.I4, g512, b.U3, P, H3, W3, s));
+    CONV(D_UPCONV3, b.U3, g512, 0, g512, b.CAT3, 2 * g256 + 1, 0, 256, H2, W2);
+    CONV(D_ICONV3, b.CAT3, 2 * g256 + 1, 0, 2 * g256 + 1, b.I3, g256, 0, 256, H2, W2);
+    CNM_TRY(E::head(b.I3, g256, 256, wt[D_DISP3], idepth_scale, disp3, b.CAT2, 2 * g128 + 1, 2 * g128, P, H2, W2, s));
+    CNM_TRY(E::up(b.I3, g256, b.U2, P, H2, W2, s));
+    CONV(D_UPCONV2, b.U2, g256, 0, g256, b.CAT2, 2 * g128 + 1, 0, 128, H1, W1);
+    CONV(D_ICONV2, b.CAT2, 2 * g128 + 1, 0, 2 * g128 + 1, b.I2, g128, 0, 128, H1, W1);
+    CNM_TRY(E::head(b.I2, g128, 128, wt[D_DISP2], idepth_scale, disp2, b.CAT1, g64 + 1, g64, P, H1, W1, s));
+    CNM_TRY(E::up(b.I2, g128, b.U1, P, H1, W1, s));
+    CONV(D_UPCONV1, b.U1, g128, 0, g128, b.CAT1, g64 + 1, 0, 64, H, W);
+    CONV(D_ICONV1, b.CAT1, g64 + 1, 0, g64 + 1, iconv1, g64, 0, 64, H, W);
+    CNM_TRY(E::head(iconv1, g64, 64, wt[D_DISP1], idepth_scale, disp1, nullptr, 0, 0, P, H, W, s));
 #undef CONV
     return CNM_OK;
+}
+
+extern "C" int cnm_depthnet_forward_f32(const cnm_layer_weights* wt, float idepth_scale, int D,
+                                        const float* ref, const float* src, const float* ref_cam, const float* src_cam,
+                                        float* disp1, float* disp2, float* disp3, float* disp4, float* iconv1_c4,
+                                        float* ws, size_t ws_floats, int B, int S, int H, int W, void* stream) {
+    return depthnet_forward<EngF32>(wt, idepth_scale, D, ref, src, ref_cam, src_cam, disp1, disp2, disp3, disp4, iconv1_c4, ws, ws_floats, B, S, H, W, stream);
+}
+
+extern "C" int cnm_depthnet_forward_f16(const cnm_layer_weights* wt, float idepth_scale, int D,
+                                        const float* ref, const float* src, const float* ref_cam, const float* src_cam,
+                                        float* disp1, float* disp2, float* disp3, float* disp4, void* iconv1_c8,
+                                        float* ws, size_t ws_floats, int B, int S, int H, int W, void* stream) {
+    return depthnet_forward<EngF16>(wt, idepth_scale, D, ref, src, ref_cam, src_cam, disp1, disp2, disp3, disp4, static_cast<float*>(iconv1_c8), ws, ws_floats, B, S, H, W, stream);
 }
 
 // ------------------------------------------------------------------ refine net
 struct RefineBufs { float *X, *A1, *C1, *A2, *C2, *A3, *C3, *U3, *UC3, *I3, *U2, *UC2, *I2, *U1, *UC1, *I1; };
 
+template <class E>
 static size_t carve_refine(float* ws, int N, int H, int W, RefineBufs* b) {
     Carver c{ws, 0};
     const size_t q = (size_t)N * H * W * 4;
-    b->X = c.take(q * 17); b->A1 = c.take(q * 32); b->U1 = c.take(q * 32); b->UC1 = c.take(q * 16); b->I1 = c.take(q * 16);
-    b->C1 = c.take(q / 4 * 32); b->A2 = c.take(q / 4 * 64); b->U2 = c.take(q / 4 * 64); b->UC2 = c.take(q / 4 * 32); b->I2 = c.take(q / 4 * 32);
-    b->C2 = c.take(q / 16 * 64); b->A3 = c.take(q / 16 * 128); b->U3 = c.take(q / 16 * 128); b->UC3 = c.take(q / 16 * 64); b->I3 = c.take(q / 16 * 64);
-    b->C3 = c.take(q / 64 * 128);
+    auto G = [](int C) { return (size_t)((C + E::GD - 1) / E::GD); };
+    b->X = c.take(q * (G(64) + 1)); b->A1 = c.take(q * G(128)); b->U1 = c.take(q * G(128)); b->UC1 = c.take(q * G(64)); b->I1 = c.take(q * G(64));
+    b->C1 = c.take(q / 4 * G(128)); b->A2 = c.take(q / 4 * G(256)); b->U2 = c.take(q / 4 * G(256)); b->UC2 = c.take(q / 4 * G(128)); b->I2 = c.take(q / 4 * G(128));
+    b->C2 = c.take(q / 16 * G(256)); b->A3 = c.take(q / 16 * G(512)); b->U3 = c.take(q / 16 * G(512)); b->UC3 = c.take(q / 16 * G(256)); b->I3 = c.take(q / 16 * G(256));
+    b->C3 = c.take(q / 64 * G(512));
     return c.used;
 }
 
 extern "C" size_t cnm_refinenet_workspace_floats(int N, int H, int W) {
     if (N <= 0 || H <= 0 || W <= 0 || (H % 8) || (W % 8)) return 0;
     RefineBufs b;
-    return carve_refine(nullptr, N, H, W, &b);
+    return carve_refine<EngF32>(nullptr, N, H, W, &b);
 }
 
+template <class E>
 static int refinenet_body(const cnm_layer_weights* wt, float idepth_scale, const RefineBufs& b,
-                          float* disp_refined, float* prob_map, float* iconv1_depth_c4, int N, int H, int W, void* s) {
+                          float* disp_refined, float* prob_map, float* iconv1_depth, int N, int H, int W, void* s) {
     const int H1 = H / 2, W1 = W / 2, H2 = H / 4, W2 = W / 4, H3 = H / 8, W3 = W / 8;
-#define CONV(L, in, Gt, g0, Gin, out, Gto, go0, Cout, HH, WW) \
-    CNM_TRY(cnm_conv2d_c4_f32(in, Gt, g0, Gin, out, Gto, go0, Cout, wt[L].w, wt[L].b, N, HH, WW, 3, kRefineLayers[L].stride, 1, s))
-#define CONV2(L, ina, Ga, inb, Gb, out, Gto, Cout, HH, WW) \
-    CNM_TRY(cnm_conv2d_cat2_c4_f32(ina, Ga, 0, Ga, inb, Gb, 0, Gb, out, Gto, 0, Cout, wt[L].w, wt[L].b, N, HH, WW, 3, 1, 1, s))
-    CONV(R_CONV1_0, b.X, 17, 0, 17, b.A1, 32, 0, 128, H, W);
-    CONV(R_CONV1_3, b.A1, 32, 0, 32, b.C1, 32, 0, 128, H, W);
-    CONV(R_CONV2_0, b.C1, 32, 0, 32, b.A2, 64, 0, 256, H1, W1);
-    CONV(R_CONV2_3, b.A2, 64, 0, 64, b.C2, 64, 0, 256, H1, W1);
-    CONV(R_CONV3_0, b.C2, 64, 0, 64, b.A3, 128, 0, 512, H2, W2);
-    CONV(R_CONV3_3, b.A3, 128, 0, 128, b.C3, 128, 0, 512, H2, W2);
-    CNM_TRY(cnm_upsample2x_c4_f32(b.C3, 128, 0, b.U3, 128, 0, N, 128, H3, W3, s));     // shared by both decoders
+    auto G = [](int C) { return (C + E::GD - 1) / E::GD; };
+    const int g64 = G(64), g128 = G(128), g256 = G(256), g512 = G(512);
+#define CONV(L, in, Gin, out, Cout, HH, WW) \
+    CNM_TRY(E::conv(in, Gin, 0, Gin, out, G(Cout), 0, Cout, wt[L], N, HH, WW, 3, kRefineLayers[L].stride, s))
+    CONV(R_CONV1_0, b.X, g64 + 1, b.A1, 128, H, W);
+    CONV(R_CONV1_3, b.A1, g128, b.C1, 128, H, W);
+    CONV(R_CONV2_0, b.C1, g128, b.A2, 256, H1, W1);
+    CONV(R_CONV2_3, b.A2, g256, b.C2, 256, H1, W1);
+    CONV(R_CONV3_0, b.C2, g256, b.A3, 512, H2, W2);
+    CONV(R_CONV3_3, b.A3, g512, b.C3, 512, H2, W2);
+    CNM_TRY(E::up(b.C3, g512, b.U3, N, H3, W3, s));                                    // shared by both decoders
     for (int br = 0; br < 2; ++br) {                                                   // 0: depth (:341-351), 1: prob (:357-365)
         const int L = R_BRANCH0 + 6 * br;
-        float* feat = (br == 0 && iconv1_depth_c4) ? iconv1_depth_c4 : b.I1;
-        CONV(L + 0, b.U3, 128, 0, 128, b.UC3, 64, 0, 256, H2, W2);
-        CONV2(L + 1, b.UC3, 64, b.C2, 64, b.I3, 64, 256, H2, W2);
-        CNM_TRY(cnm_upsample2x_c4_f32(b.I3, 64, 0, b.U2, 64, 0, N, 64, H2, W2, s));
-        CONV(L + 2, b.U2, 64, 0, 64, b.UC2, 32, 0, 128, H1, W1);
-        CONV2(L + 3, b.UC2, 32, b.C1, 32, b.I2, 32, 128, H1, W1);
-        CNM_TRY(cnm_upsample2x_c4_f32(b.I2, 32, 0, b.U1, 32, 0, N, 32, H1, W1, s));
-        CONV(L + 4, b.U1, 32, 0, 32, b.UC1, 16, 0, 64, H, W);
-        CONV(L + 5, b.UC1, 16, 0, 16, feat, 16, 0, 64, H, W);
-        CNM_TRY(cnm_head_sigmoid_c4_f32(feat, 16, 0, 64, wt[R_HEAD0 + br].w, wt[R_HEAD0 + br].b,
-                                        br == 0 ? idepth_scale : 1.0f, br == 0 ? disp_refined : prob_map,
-                                        nullptr, 0, 0, N, H, W, s));
+        float* feat = (br == 0 && iconv1_depth) ? iconv1_depth : b.I1;
+        CONV(L + 0, b.U3, g512, b.UC3, 256, H2, W2);
+        CNM_TRY(E::conv2(b.UC3, g256, b.C2, g256, b.I3, g256, 256, wt[L + 1], N, H2, W2, s));
+        CNM_TRY(E::up(b.I3, g256, b.U2, N, H2, W2, s));
+        CONV(L + 2, b.U2, g256, b.UC2, 128, H1, W1);
+        CNM_TRY(E::conv2(b.UC2, g128, b.C1, g128, b.I2, g128, 128, wt[L + 3], N, H1, W1, s));
+        CNM_TRY(E::up(b.I2, g128, b.U1, N, H1, W1, s));
+        CONV(L + 4, b.U1, g128, b.UC1, 64, H, W);
+        CONV(L + 5, b.UC1, g64, feat, 64, H, W);
+        CNM_TRY(E::head(feat, g64, 64, wt[R_HEAD0 + br], br == 0 ? idepth_scale : 1.0f, br == 0 ? disp_refined : prob_map,
+                        nullptr, 0, 0, N, H, W, s));
     }
 #undef CONV
-#undef CONV2
     return CNM_OK;
 }
 
@@ -219,20 +283,36 @@ extern "C" int cnm_refinenet_forward_f32(const cnm_layer_weights* wt, float idep
     CNM_REQUIRE(H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0, CNM_ERR_BAD_SHAPE);
     for (int i = 0; i < R_NUM; ++i) CNM_REQUIRE(wt[i].w && wt[i].b, CNM_ERR_BAD_ARG);
     RefineBufs b;
-    CNM_REQUIRE(carve_refine(ws, N, H, W, &b) <= ws_floats, CNM_ERR_WORKSPACE);
+    CNM_REQUIRE(carve_refine<EngF32>(ws, N, H, W, &b) <= ws_floats, CNM_ERR_WORKSPACE);
     CNM_TRY(cnm_refine_assemble_c4_f32(idepth01, idepth02, idepth_stride, iconv01, G1_total, g1, iconv02, G2_total, g2, b.X, N, 64, H, W, stream));  // :332-333
-    return refinenet_body(wt, idepth_scale, b, disp_refined, prob_map, iconv1_depth_c4, N, H, W, stream);
+    return refinenet_body<EngF32>(wt, idepth_scale, b, disp_refined, prob_map, iconv1_depth_c4, N, H, W, stream);
+}
+
+template <class E>
+static int refinenet_forward_multi(const cnm_layer_weights* wt, float idepth_scale,
+                                   const float* idepth_pairs, const float* iconv_pairs, int S,
+                                   float* disp_refined, float* prob_map, float* iconv1_depth,
+                                   float* ws, size_t ws_floats, int B, int H, int W, void* stream) {
+    CNM_REQUIRE(wt && idepth_pairs && iconv_pairs && disp_refined && prob_map && ws && B > 0 && S >= 2 && S % 2 == 0, CNM_ERR_BAD_ARG);
+    CNM_REQUIRE(H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0, CNM_ERR_BAD_SHAPE);
+    for (int i = 0; i < R_NUM; ++i) CNM_REQUIRE(wt[i].w && wt[i].b, CNM_ERR_BAD_ARG);
+    RefineBufs b;
+    CNM_REQUIRE(carve_refine<E>(ws, B, H, W, &b) <= ws_floats, CNM_ERR_WORKSPACE);
+    CNM_TRY(E::assemble_multi(idepth_pairs, iconv_pairs, b.X, B, S, H, W, stream));
+    return refinenet_body<E>(wt, idepth_scale, b, disp_refined, prob_map, iconv1_depth, B, H, W, stream);
 }
 
 extern "C" int cnm_refinenet_forward_multi_f32(const cnm_layer_weights* wt, float idepth_scale,
                                                const float* idepth_pairs, const float* iconv_pairs_c4, int S,
                                                float* disp_refined, float* prob_map, float* iconv1_depth_c4,
                                                float* ws, size_t ws_floats, int B, int H, int W, void* stream) {
-    CNM_REQUIRE(wt && idepth_pairs && iconv_pairs_c4 && disp_refined && prob_map && ws && B > 0 && S >= 2 && S % 2 == 0, CNM_ERR_BAD_ARG);
-    CNM_REQUIRE(H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0, CNM_ERR_BAD_SHAPE);
-    for (int i = 0; i < R_NUM; ++i) CNM_REQUIRE(wt[i].w && wt[i].b, CNM_ERR_BAD_ARG);
-    RefineBufs b;
-    CNM_REQUIRE(carve_refine(ws, B, H, W, &b) <= ws_floats, CNM_ERR_WORKSPACE);
-    CNM_TRY(cnm_refine_assemble_multi_c4_f32(idepth_pairs, iconv_pairs_c4, b.X, B, S, 64, H, W, stream));
-    return refinenet_body(wt, idepth_scale, b, disp_refined, prob_map, iconv1_depth_c4, B, H, W, stream);
+    return refinenet_forward_multi<EngF32>(wt, idepth_scale, idepth_pairs, iconv_pairs_c4, S, disp_refined, prob_map, iconv1_depth_c4, ws, ws_floats, B, H, W, stream);
+}
+
+extern "C" int cnm_refinenet_forward_multi_f16(const cnm_layer_weights* wt, float idepth_scale,
+                                               const float* idepth_pairs, const void* iconv_pairs_c8, int S,
+                                               float* disp_refined, float* prob_map, void* iconv1_depth_c8,
+                                               float* ws, size_t ws_floats, int B, int H, int W, void* stream) {
+    return refinenet_forward_multi<EngF16>(wt, idepth_scale, idepth_pairs, static_cast<const float*>(iconv_pairs_c8), S, disp_refined, prob_map,
+                                           static_cast<float*>(iconv1_depth_c8), ws, ws_floats, B, H, W, stream);
 }

@@ -49,6 +49,9 @@
 #ifndef SWEEP_ASM_DMA
 #define SWEEP_ASM_DMA 0       // 1: LDS-DMA from inline asm + counted vmcnt (measured: no gain over the builtin, kept for study)
 #endif
+#ifndef SWEEP_MINW
+#define SWEEP_MINW 1           // __launch_bounds__ min waves per SIMD (register cap)
+#endif
 #define SWEEP_NT (SWEEP_TW * SWEEP_TH)   // threads per workgroup (256 or 512)
 
 struct SweepArgs {
@@ -243,8 +246,10 @@ __device__ long long sweep_trace[4096][40];  // debug builds only: s_memtime sta
 #define TRACE(slot) do {} while (0)
 #endif
 
-template <int LAYOUT>   // 0: volume [P,D,H,W]   1: c4 [P,D/4+1,H,W,4]
-__global__ __launch_bounds__(SWEEP_NT) void planesweep_kernel(const SweepArgs a) {
+typedef _Float16 sw_f16x8 __attribute__((ext_vector_type(8)));
+
+template <int LAYOUT>   // 0: volume [P,D,H,W] fp32   1: c4 [P,D/4+1,H,W,4] fp32   2: c8 [P,D/8+1,H,W,8] fp16
+__global__ __launch_bounds__(SWEEP_NT, SWEEP_MINW) void planesweep_kernel(const SweepArgs a) {
     static_assert((SWEEP_NT == 256 || SWEEP_NT == 512) && (SWEEP_TW & (SWEEP_TW - 1)) == 0 && SWEEP_TW <= 64 &&
                   SWEEP_PG % 4 == 0 && SWEEP_PG % SWEEP_BATCH == 0 && CNM_MAX_PLANES % SWEEP_PG == 0, "tile");
     // one LDS object (a second __shared__ array makes hipcc drain the LDS-DMA queue early): two texel
@@ -376,12 +381,21 @@ __global__ __launch_bounds__(SWEEP_NT) void planesweep_kernel(const SweepArgs a)
 #pragma unroll
             for (int j = 0; j < SWEEP_PG; ++j)
                 if (d0 + j < D) a.out[((size_t)p * D + d0 + j) * HW + (size_t)y * W + x] = pend[j];
-        } else {
+        } else if (LAYOUT == 1) {
 #pragma unroll
             for (int q = 0; q < SWEEP_PG / 4; ++q)
                 if (d0 + 4 * q < D)
                     *reinterpret_cast<float4*>(a.out + c4_offset(p, D / 4 + 1, (d0 >> 2) + q, HW, y * W + x)) =
                         make_float4(pend[4 * q], pend[4 * q + 1], pend[4 * q + 2], pend[4 * q + 3]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < SWEEP_PG / 8; ++q)
+                if (d0 + 8 * q < D) {
+                    sw_f16x8 h;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) h[j] = (_Float16)pend[8 * q + j];
+                    *reinterpret_cast<sw_f16x8*>(a.out + c4_offset(p, D / 8 + 1, (d0 >> 3) + q, HW, y * W + x)) = h;
+                }
         }
     };
     TRACE(1);
@@ -479,6 +493,10 @@ __global__ __launch_bounds__(SWEEP_NT) void planesweep_kernel(const SweepArgs a)
     TRACE(39);
     if (LAYOUT == 1 && pvalid)
         *reinterpret_cast<float4*>(a.out + c4_offset(p, D / 4 + 1, D / 4, HW, y * W + x)) = make_float4(rr, rg, rb, 0.f);
+    if (LAYOUT == 2 && pvalid) {
+        const sw_f16x8 h = {(_Float16)rr, (_Float16)rg, (_Float16)rb, 0, 0, 0, 0, 0};
+        *reinterpret_cast<sw_f16x8*>(a.out + c4_offset(p, D / 8 + 1, D / 8, HW, y * W + x)) = h;
+    }
 }
 
 extern "C" size_t cnm_planesweep_workspace_floats(int B, int S, int H, int W) {
@@ -493,6 +511,7 @@ static int sweep_launch(int layout, const float* ref, const float* src, const fl
     CNM_REQUIRE(((uintptr_t)ws & 15) == 0, CNM_ERR_BAD_ARG);
     CNM_REQUIRE(B > 0 && S > 0 && H > 0 && W > 0 && D >= 2 && D <= CNM_MAX_PLANES, CNM_ERR_BAD_ARG);
     CNM_REQUIRE(layout == 0 || D % 4 == 0, CNM_ERR_BAD_ARG);
+    CNM_REQUIRE(layout != 2 || (D % 8 == 0 && SWEEP_PG % 8 == 0), CNM_ERR_BAD_ARG);
     CNM_REQUIRE((long long)B * S <= 65535, CNM_ERR_BAD_ARG);
     SweepArgs a;
     a.ref = ref; a.src = src; a.hmkt = hmkt; a.out = out;
@@ -509,7 +528,8 @@ static int sweep_launch(int layout, const float* ref, const float* src, const fl
     }
     dim3 grid(cnm_ceil_div(W, SWEEP_TW), cnm_ceil_div(H, SWEEP_TH), B * S);
     if (layout == 0) planesweep_kernel<0><<<grid, SWEEP_NT, 0, cnm_stream(stream)>>>(a);
-    else planesweep_kernel<1><<<grid, SWEEP_NT, 0, cnm_stream(stream)>>>(a);
+    else if (layout == 1) planesweep_kernel<1><<<grid, SWEEP_NT, 0, cnm_stream(stream)>>>(a);
+    else planesweep_kernel<2><<<grid, SWEEP_NT, 0, cnm_stream(stream)>>>(a);
     CNM_LAUNCH_CHECK();
     return CNM_OK;
 }
@@ -524,4 +544,10 @@ extern "C" int cnm_planesweep_cat_c4_f32(const float* ref, const float* src, con
                                          float* ws, size_t ws_floats, int B, int S, int H, int W, int D,
                                          double idepth_min, double idepth_max, void* stream) {
     return sweep_launch(1, ref, src, hmkt, x, ws, ws_floats, B, S, H, W, D, idepth_min, idepth_max, stream);
+}
+
+extern "C" int cnm_planesweep_cat_c8_f16(const float* ref, const float* src, const float* hmkt, void* x,
+                                         float* ws, size_t ws_floats, int B, int S, int H, int W, int D,
+                                         double idepth_min, double idepth_max, void* stream) {
+    return sweep_launch(2, ref, src, hmkt, static_cast<float*>(x), ws, ws_floats, B, S, H, W, D, idepth_min, idepth_max, stream);
 }

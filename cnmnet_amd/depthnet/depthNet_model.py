@@ -67,7 +67,10 @@ def _init_like_reference(module):
 class _EngineNet(nn.Module):
     _NET = None
 
-    def _engine_init(self):
+    def _engine_init(self, precision="f32"):
+        if precision not in ("f32", "f16"):
+            raise ValueError("precision must be 'f32' or 'f16'")
+        self.precision = precision  # 'f16': fp16 storage + f16 MFMA (BASELINE config 5); eval only
         self._layers = None        # engine layer table (resolved lazily: needs the library)
         self._packed = None        # [(w, b)] device tensors, one per engine layer
         self._packed_key = None
@@ -81,7 +84,7 @@ class _EngineNet(nn.Module):
 
     def _param_key(self):
         ts = list(self.parameters()) + list(self.buffers())
-        return (str(ts[0].device), tuple(t._version for t in ts), tuple(t.data_ptr() for t in ts[:4]))
+        return (self.precision, str(ts[0].device), tuple(t._version for t in ts), tuple(t.data_ptr() for t in ts[:4]))
 
     def _first_cin(self):
         return None
@@ -100,8 +103,9 @@ class _EngineNet(nn.Module):
                 packed.append((ops.pack_head(w), conv.bias.detach().contiguous()))
             else:
                 bn = self._sub(L["bn_key"])
-                packed.append(ops.pack_conv(w, (bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var),
-                                            rot=L["rot"], eps=bn.eps))
+                pack = ops.pack_conv_f16 if self.precision == "f16" else ops.pack_conv
+                packed.append(pack(w, (bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var),
+                                   rot=L["rot"], eps=bn.eps))
         arr = (_lib.LayerWeights * len(packed))()
         for i, (w, b) in enumerate(packed):
             arr[i].w, arr[i].b = w.data_ptr(), b.data_ptr()
@@ -139,10 +143,10 @@ class depthNet(_EngineNet):
     with reference checkpoints holds at planes=64."""
     _NET = _lib.NET_DEPTH
 
-    def __init__(self, idepth_scale=3, planes=64):
+    def __init__(self, idepth_scale=3, planes=64, precision="f32"):
         super().__init__()
-        if planes % 4 or not (4 <= planes <= 128):
-            raise ValueError("planes must be a multiple of 4 in [4,128]")
+        if planes % 4 or not (4 <= planes <= 128) or (precision == "f16" and planes % 8):
+            raise ValueError("planes must be a multiple of 4 (8 for f16) in [4,128]")
         self.idepth_scale, self.planes = idepth_scale, planes
         self.conv1 = _down(3 + planes, 128, 7)
         self.conv2 = _down(128, 256, 5)
@@ -155,7 +159,7 @@ class depthNet(_EngineNet):
         self.upconv2, self.iconv2, self.disp2 = _up(256, 128, 3), _same(257, 128, 3), _head(128)
         self.upconv1, self.iconv1, self.disp1 = _up(128, 64, 3), _same(65, 64, 3), _head(64)
         _init_like_reference(self)
-        self._engine_init()
+        self._engine_init(precision)
 
     def forward_pairs(self, ref, src, ref_cam, src_cam):
         """ref [B,3,H,W], src [B,S,3,H,W], ref_cam [B,2,4,4], src_cam [B,S,2,4,4]
@@ -168,16 +172,20 @@ class depthNet(_EngineNet):
         if H % 32 or W % 32:
             raise ValueError("image height and width must be multiples of 32 (got %dx%d)" % (H, W))
         if self.training:
+            if self.precision != "f32":
+                raise NotImplementedError("training runs in fp32; the f16 engine is inference-only")
             return self._forward_train(ref, src, ref_cam, src_cam)
         self._ensure_packed()
         lib, P, dev = _lib.load(), B * S, ref.device
         ref, src, ref_cam, src_cam = (t.contiguous() for t in (ref, src, ref_cam, src_cam))
         disp = [torch.empty(P, 1, H >> i, W >> i, device=dev, dtype=torch.float32) for i in range(4)]
-        feat = torch.empty(P, 16, H, W, 4, device=dev, dtype=torch.float32)
-        n = lib.cnm_depthnet_workspace_floats(P, H, W, self.planes)
+        f16 = self.precision == "f16"
+        feat = (torch.empty(P, 8, H, W, 8, device=dev, dtype=torch.float16) if f16
+                else torch.empty(P, 16, H, W, 4, device=dev, dtype=torch.float32))
+        n = (lib.cnm_depthnet_workspace_floats_f16 if f16 else lib.cnm_depthnet_workspace_floats)(P, H, W, self.planes)
         ws = self._workspace(dev, n)
         with torch.cuda.device(dev):
-            _lib.check(lib.cnm_depthnet_forward_f32(
+            _lib.check((lib.cnm_depthnet_forward_f16 if f16 else lib.cnm_depthnet_forward_f32)(
                 self._weights_arr, float(self.idepth_scale), self.planes,
                 ref.data_ptr(), src.data_ptr(), ref_cam.data_ptr(), src_cam.data_ptr(),
                 disp[0].data_ptr(), disp[1].data_ptr(), disp[2].data_ptr(), disp[3].data_ptr(), feat.data_ptr(),
@@ -210,6 +218,10 @@ class depthNet(_EngineNet):
 
     def forward(self, left_image, right_image, left_cam, right_cam):
         disp, feat_c4 = self.forward_pairs(left_image, right_image.unsqueeze(1), left_cam, right_cam.unsqueeze(1))
+        if self.precision == "f16":
+            iconv1 = ops.c8_to_nchw(feat_c4, 64)
+            iconv1._cnm_c8 = feat_c4
+            return disp, iconv1
         iconv1 = ag.C4ToNCHW.apply(feat_c4, 64) if self.training else ops.c4_to_nchw(feat_c4, 64)
         iconv1._cnm_c4 = feat_c4           # lets DepthRefineNet skip the NCHW->c4 round trip
         return disp, iconv1
@@ -219,7 +231,7 @@ class DepthRefineNet(_EngineNet):
     """Occlusion-aware two-view fusion (reference depthNet_model.py:268-370)."""
     _NET = _lib.NET_REFINE
 
-    def __init__(self, base_channels_num=32, idepth_scale=2):
+    def __init__(self, base_channels_num=32, idepth_scale=2, precision="f32"):
         super().__init__()
         self.base_channels_num, self.idepth_scale = base_channels_num, idepth_scale
         self.conv1, self.conv2, self.conv3 = _down(67, 128, 3), _down(128, 256, 3), _down(256, 512, 3)
@@ -232,7 +244,7 @@ class DepthRefineNet(_EngineNet):
             setattr(self, "iconv1_" + tag, _same(64, 64, 3))
             setattr(self, "disp_refine" if tag == "depth" else "prob", _head(64))
         _init_like_reference(self)
-        self._engine_init()
+        self._engine_init(precision)
 
     def forward_c4(self, idepth01, idepth02, idepth_stride, f1, G1_total, g1, f2, G2_total, g2, N, H, W, return_volume=False):
         """Raw-view entry used by the frame pipeline (no layout conversion)."""
@@ -254,17 +266,23 @@ class DepthRefineNet(_EngineNet):
         """S (even) sources per frame from ONE depthNet.forward_pairs call: disp1 [B*S,1,H,W] and
         iconv1 c4 [B*S,16,H,W,4]; even sources average into side 1, odd into side 2
         (reference eval.py:656-663 for S=4, :917-929 for S=6; S=2 is the plain two-view case)."""
-        self._require_gpu(idepth_pairs, feat_pairs_c4)
+        self._require_gpu(idepth_pairs)
         self._ensure_packed()
         P, _, H, W = idepth_pairs.shape
         B = P // S
         lib, dev = _lib.load(), idepth_pairs.device
+        f16 = self.precision == "f16"
+        if f16 != (feat_pairs_c4.dtype == torch.float16):
+            raise _lib.EngineError("feature layout/dtype does not match the refine net's precision (%s)" % self.precision)
         disp = torch.empty(B, 1, H, W, device=dev, dtype=torch.float32)
         prob = torch.empty_like(disp)
-        vol = torch.empty(B, 16, H, W, 4, device=dev, dtype=torch.float32) if return_volume else None
+        vol = None
+        if return_volume:
+            vol = (torch.empty(B, 8, H, W, 8, device=dev, dtype=torch.float16) if f16
+                   else torch.empty(B, 16, H, W, 4, device=dev, dtype=torch.float32))
         ws = self._workspace(dev, lib.cnm_refinenet_workspace_floats(B, H, W))
         with torch.cuda.device(dev):
-            _lib.check(lib.cnm_refinenet_forward_multi_f32(
+            _lib.check((lib.cnm_refinenet_forward_multi_f16 if f16 else lib.cnm_refinenet_forward_multi_f32)(
                 self._weights_arr, float(self.idepth_scale), idepth_pairs.contiguous().data_ptr(), feat_pairs_c4.data_ptr(), S,
                 disp.data_ptr(), prob.data_ptr(), vol.data_ptr() if vol is not None else 0,
                 ws.data_ptr(), ws.numel(), B, H, W, torch.cuda.current_stream().cuda_stream))
@@ -300,6 +318,20 @@ class DepthRefineNet(_EngineNet):
             raise ValueError("image height and width must be multiples of 8 (got %dx%d)" % (H, W))
         f1 = getattr(iconv01, "_cnm_c4", None)
         f2 = getattr(iconv02, "_cnm_c4", None)
+        if self.precision == "f16":
+            if self.training:
+                raise NotImplementedError("training runs in fp32; the f16 engine is inference-only")
+            h1 = getattr(iconv01, "_cnm_c8", None); h2 = getattr(iconv02, "_cnm_c8", None)
+            h1 = h1 if h1 is not None else ops.nchw_to_c8(iconv01)
+            h2 = h2 if h2 is not None else ops.nchw_to_c8(iconv02)
+            pairs_f = torch.stack((h1, h2), 1).reshape(2 * N, 8, H, W, 8)          # pair p = 2n + side
+            pairs_d = torch.stack((idepth01, idepth02), 1).reshape(2 * N, 1, H, W)
+            disp, prob, vol = self.forward_multi(pairs_d, pairs_f, 2, ReturnVolume)
+            if not ReturnVolume:
+                return disp, prob
+            out = ops.c8_to_nchw(vol, 64)
+            out._cnm_c8 = vol
+            return disp, prob, out
         if self.training:
             f1 = f1 if f1 is not None else ag.NCHWToC4.apply(iconv01)
             f2 = f2 if f2 is not None else ag.NCHWToC4.apply(iconv02)

@@ -123,6 +123,54 @@ def pack_conv(weight, bn=None, bias=None, rot=0, eps=1e-5):
     return wp, bp
 
 
+def pack_conv_f16(weight, bn=None, bias=None, rot=0, eps=1e-5):
+    """fp16 twin of pack_conv: -> (w_packed half tensor, b_packed float tensor)."""
+    _dev(weight, bias, *(bn or ()))
+    lib = _lib.load()
+    Cout, Cin, k, _ = weight.shape
+    wp = torch.empty(lib.cnm_packed_conv_halfs(Cout, Cin, k), device=weight.device, dtype=torch.float16)
+    bp = torch.empty(Cout, device=weight.device, dtype=torch.float32)
+    g, b, m, v = [_c(t) for t in bn] if bn else (None, None, None, None)
+    with torch.cuda.device(weight.device):
+        _lib.check(lib.cnm_pack_conv_bn_f16(_p(_c(weight)), _p(g), _p(b), _p(m), _p(v), _p(bias), eps,
+                                            Cout, Cin, k, rot, wp.data_ptr(), _p(bp), _stream()))
+    return wp, bp
+
+
+def nchw_to_c8(x):
+    """fp32 NCHW -> fp16 c8 [N,ceil(C/8),H,W,8]."""
+    _dev(x)
+    x = _c(x)
+    N, Cc, H, W = x.shape
+    G = (Cc + 7) // 8
+    out = torch.empty(N, G, H, W, 8, device=x.device, dtype=torch.float16)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().cnm_nchw_to_c8_f16(_p(x), out.data_ptr(), G, 0, N, Cc, H, W, _stream()))
+    return out
+
+
+def c8_to_nchw(x, channels=None):
+    """fp16 c8 -> fp32 NCHW."""
+    N, G, H, W, _ = x.shape
+    Cc = channels or 8 * G
+    out = torch.empty(N, Cc, H, W, device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().cnm_c8_to_nchw_f16(x.contiguous().data_ptr(), G, 0, _p(out), N, Cc, H, W, _stream()))
+    return out
+
+
+def conv2d_c8(x, w_packed, b_packed, Cout, ksize, stride=1, relu=True):
+    """fp16 c8 conv: x [N,G,H,W,8] half -> [N,Cout/8,Ho,Wo,8] half."""
+    N, G, H, W, _ = x.shape
+    pad = (ksize - 1) // 2
+    Ho, Wo = (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1
+    out = torch.empty(N, Cout // 8, Ho, Wo, 8, device=x.device, dtype=torch.float16)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().cnm_conv2d_c8_f16(x.data_ptr(), G, 0, G, out.data_ptr(), Cout // 8, 0, Cout, w_packed.data_ptr(), _p(b_packed),
+                                                 N, H, W, ksize, stride, int(relu), _stream()))
+    return out
+
+
 def pack_head(weight):
     _dev(weight)
     Cc = weight.shape[1]

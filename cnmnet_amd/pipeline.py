@@ -28,7 +28,7 @@ class FramePipeline(torch.nn.Module):
         disp_pairs, feat = self.depth_net.forward_pairs(ref, src, cams[:, 0], cams[:, 1:])
         d1 = disp_pairs[0]                                   # [B*S,1,H,W], pair p = b*S + s
         HW = H * W
-        if S == 2:
+        if S == 2 and self.refine_net.precision == "f32":
             flat = d1.view(-1)
             id1, id2 = flat, flat[HW:]                       # side s of image b starts at (b*S+s)*HW
             disp, prob, _ = self.refine_net.forward_c4(id1, id2, S * HW, feat, S * 16, 0, feat, S * 16, 16, B, H, W)

@@ -191,6 +191,48 @@ int cnm_refinenet_forward_multi_f32(const cnm_layer_weights* weights, float idep
                                     float* disp_refined, float* prob_map, float* iconv1_depth_c4,
                                     float* ws, size_t ws_floats, int B, int H, int W, void* stream);
 
+/* ---------------------------------------------------------------- fp16 path (BASELINE config 5)
+ * Same operators on fp16 storage: activations "c8" = [N][G][H][W][8 halfs], channel c = 8g + j, 16 bytes per
+ * (pixel, group) exactly like c4, so views are again (base, G_total, g0) with G counted in 8-channel groups.
+ * Convolutions run on v_mfma_f32_32x32x16_f16 with fp32 accumulation, fp32 bias/ReLU, fp16 store; the plane
+ * sweep computes in fp32 and stores fp16; heads and normals stay fp32.  Tolerance vs the fp32 path is stated in
+ * tests/test_gpu_fp16.py.  Weights: [Kpad/32][round64(Cout)][32 halfs], k = (ky*ks+kx)*8*Gin + cpacked. */
+size_t cnm_packed_conv_halfs(int Cout, int Cin, int ksize);
+int cnm_pack_conv_bn_f16(const float* w_oihw, const float* bn_gamma, const float* bn_beta,
+                         const float* bn_mean, const float* bn_var, const float* bias, float eps,
+                         int Cout, int Cin, int ksize, int rot, void* w_packed_f16, float* b_packed, void* stream);
+int cnm_conv2d_c8_f16(const void* in, int Gin_total, int gin0, int Gin,
+                      void* out, int Gout_total, int gout0, int Cout,
+                      const void* w_packed_f16, const float* b_packed,
+                      int N, int H, int W, int ksize, int stride, int relu, void* stream);
+int cnm_conv2d_cat2_c8_f16(const void* in_a, int Ga_total, int ga0, int Ga,
+                           const void* in_b, int Gb_total, int gb0, int Gb,
+                           void* out, int Gout_total, int gout0, int Cout,
+                           const void* w_packed_f16, const float* b_packed,
+                           int N, int H, int W, int ksize, int stride, int relu, void* stream);
+int cnm_planesweep_cat_c8_f16(const float* ref, const float* src, const float* hmkt, void* x,
+                              float* ws, size_t ws_floats, int B, int S, int H, int W, int D,
+                              double idepth_min, double idepth_max, void* stream);
+int cnm_upsample2x_c8_f16(const void* in, int Gin_total, int gin0, void* out, int Gout_total, int gout0,
+                          int N, int G, int H, int W, void* stream);
+int cnm_head_sigmoid_c8_f16(const void* in, int Gin_total, int gin0, int C,
+                            const float* w_head, const float* bias, float scale,
+                            float* disp, void* up_out, int up_Gtotal, int up_g,
+                            int N, int H, int W, void* stream);
+int cnm_refine_assemble_multi_c8_f16(const float* idepth_pairs, const void* feat_pairs_c8, void* x,
+                                     int B, int S, int C, int H, int W, void* stream);
+int cnm_nchw_to_c8_f16(const float* nchw, void* c8, int G_total, int g0, int N, int C, int H, int W, void* stream);
+int cnm_c8_to_nchw_f16(const void* c8, int G_total, int g0, float* nchw, int N, int C, int H, int W, void* stream);
+size_t cnm_depthnet_workspace_floats_f16(int P, int H, int W, int D);
+int cnm_depthnet_forward_f16(const cnm_layer_weights* weights, float idepth_scale, int D,
+                             const float* ref, const float* src, const float* ref_cam, const float* src_cam,
+                             float* disp1, float* disp2, float* disp3, float* disp4, void* iconv1_c8,
+                             float* ws, size_t ws_floats, int B, int S, int H, int W, void* stream);
+int cnm_refinenet_forward_multi_f16(const cnm_layer_weights* weights, float idepth_scale,
+                                    const float* idepth_pairs, const void* iconv_pairs_c8, int S,
+                                    float* disp_refined, float* prob_map, void* iconv1_depth_c8,
+                                    float* ws, size_t ws_floats, int B, int H, int W, void* stream);
+
 /* ---------------------------------------------------------------- training path
  * The reference trains with stock autograd (train.py:164-310).  These are the backward operators of
  * the conv stack on c4 activations; the Python side wires them into torch.autograd.Functions

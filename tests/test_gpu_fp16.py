@@ -1,0 +1,69 @@
+"""GPU (-m gpu): the fp16 path (BASELINE config 5: MFMA-f16 convs + fp16 cost-volume storage) against the fp32
+oracle.  STATED TOLERANCE: fp16 storage carries 11 bits (5e-4 relative) per activation through 24 conv layers
+with fp32 accumulation.  Measured on the golden frame (random weights, inverse-depth range [0,3]): depthNet disp1
+max 1.3e-2 / q99.9 1.1e-2, iconv features 1.0e-3 of their maximum, refined inverse depth max 3.1e-2, probability
+5.8e-3 (the fp32 path on the same frame: 3.6e-5 / 3.5e-6 / 4.8e-5 / 8.2e-6).  Bars: 3e-2 on depthNet inverse depth,
+6e-2 on the refined map, 2e-2 on probability, 5e-3 relative on features.  Normals are computed in fp32/fp64 from the
+fp16 net's depth and inherit its depth error."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from cnmnet_amd import synthetic as syn
+from conftest import torch_state
+from oracle import ref_arrangement as ra
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _load(module, seed):
+    shapes = {k: tuple(v.shape) for k, v in module.state_dict().items()}
+    module.load_state_dict(torch_state(syn.state_dict_like(shapes, seed=seed, randomize_bn=True)))
+    return module.eval()
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,rot,N,H,W", [(67, 128, 7, 1, 3, 2, 24, 40), (128, 128, 7, 2, 0, 1, 32, 32),
+                                                          (513, 256, 3, 1, 0, 1, 12, 20), (65, 64, 3, 1, 0, 3, 20, 28), (512, 512, 3, 2, 0, 2, 6, 8)])
+def test_conv_f16_vs_fp32_torch(dev, cin, cout, k, stride, rot, N, H, W):
+    from cnmnet_amd import ops
+    rng = np.random.default_rng(cin + k)
+    x = T(rng.standard_normal((N, cin, H, W)).astype(np.float32)); w = T((rng.standard_normal((cout, cin, k, k)) * 0.05).astype(np.float32))
+    bias = T(rng.normal(0, 0.2, cout).astype(np.float32))
+    # reference on the fp16-ROUNDED operands in fp32: isolates the kernel (fp32 accumulate) from the input rounding
+    xh, wh = x.half().float(), w.half().float()
+    want = F.relu(F.conv2d(xh, wh, bias, stride=stride, padding=(k - 1) // 2)).numpy()
+    xr = torch.cat((x[:, rot:], x[:, :rot]), 1) if rot else x
+    wp, bp = ops.pack_conv_f16(w.to(dev), None, bias.to(dev), rot)
+    got = ops.c8_to_nchw(ops.conv2d_c8(ops.nchw_to_c8(xr.to(dev)), wp, bp, cout, k, stride, True), cout).cpu().numpy()
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() < 1.5e-3 * scale, (np.abs(got - want).max(), scale)     # output rounding to fp16: 2^-11 relative
+
+
+def test_frame_f16_vs_fp32_oracle(dev, golden):
+    from cnmnet_amd.depthnet import depthNet, DepthRefineNet
+    from cnmnet_amd.pipeline import FramePipeline
+    g, gr = golden("depthnet_64x96.npz"), golden("refine_64x96.npz")
+    img, cams = syn.frames(2, 2, 64, 96, seed=int(g["seed"]))
+    dn = _load(depthNet(3.0, 64, precision="f16"), int(g["weight_seed"])).to(dev)
+    rn = _load(DepthRefineNet(32, 3.0, precision="f16"), int(gr["weight_seed"])).to(dev)
+    L, lc = T(img[:, 0]).to(dev), T(cams[:, 0]).to(dev)
+    with torch.no_grad():
+        o1, f1 = dn(L, T(img[:, 1]).to(dev), lc, T(cams[:, 1]).to(dev))           # module-level API
+        o2, f2 = dn(L, T(img[:, 2]).to(dev), lc, T(cams[:, 2]).to(dev))
+        disp, prob = rn(idepth01=o1[0], idepth02=o2[0], iconv01=f1, iconv02=f2)
+        out = FramePipeline(dn, rn, k_size=9)(T(img).to(dev), T(cams).to(dev))    # fused pipeline
+    for i in range(4):
+        assert np.abs(o1[i].cpu().numpy() - g["disp%d" % (i + 1)]).max() < 3e-2
+    ch = list(g["iconv1_channels"])
+    assert np.abs(f1[:, ch].cpu().numpy() - g["iconv1"]).max() < 5e-3 * np.abs(g["iconv1"]).max()
+    assert np.abs(disp.cpu().numpy() - gr["disp_refined"]).max() < 6e-2 and np.abs(prob.cpu().numpy() - gr["prob_map"]).max() < 2e-2
+    assert float((out["disp"] - disp).abs().max()) < 1e-6 and float((out["prob"] - prob).abs().max()) < 1e-6   # both routes agree
+    assert torch.isfinite(out["normal"]).all()

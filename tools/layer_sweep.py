@@ -63,3 +63,17 @@ if __name__ == "__main__":
     print("planesweep nchw (B pairs): %.3f ms" % ms)
     up = torch.randn(16, 32, 96, 128, 4, device=dev)
     ms = time_call(lambda: ops.upsample2x_c4(up)); print("upsample 128ch ->192x256 x16: %.3f ms, %.1f GB/s" % (ms, up.numel() * 4 * 5 / ms / 1e6))
+    # fp16 conv stack (BASELINE config 5 shapes)
+    tot_g = tot_ms = 0
+    for net, N in ((0, a.pairs), (1, a.pairs // 2)):
+        layers = [L for L in _lib.net_layers(net) if not L["is_head"]]
+        for L, lv in zip(layers, DEPTH_LEVEL if net == 0 else REFINE_LEVEL):
+            cin = L["Cin"] if not (net == 0 and L["conv_key"] == "conv1.0") else 67
+            h, w = a.H >> lv, a.W >> lv
+            x = torch.randn(N, (cin + 7) // 8, h, w, 8, device=dev).half()
+            wp, bp = ops.pack_conv_f16(torch.randn(L["Cout"], cin, L["ksize"], L["ksize"], device=dev) * 0.01)
+            ms = time_call(lambda: ops.conv2d_c8(x, wp, bp, L["Cout"], L["ksize"], L["stride"], True))
+            gflop = 2.0 * L["Cout"] * cin * L["ksize"] ** 2 * (h // L["stride"]) * (w // L["stride"]) * N / 1e9
+            if net == 0 and lv in (0, 2, 4) and L["stride"] == 1: print("f16 %-16s %8.3f ms %7.1f TFLOP/s" % (L["conv_key"], ms, gflop / ms))
+            tot_g += gflop; tot_ms += ms
+    print("f16 conv total %.1f GFLOP %.2f ms -> %.1f TFLOP/s" % (tot_g, tot_ms, tot_g / tot_ms))
