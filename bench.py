@@ -155,6 +155,7 @@ def main():
     ap.add_argument("--frames-per-gpu", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the step as one captured HIP graph (measured: no gain, the host already runs ahead of the GPU)")
     ap.add_argument("--precision", choices=["f32", "f16"], default="f32",
                     help="f16 = BASELINE config 5 path (fp16 storage + f16 MFMA; tolerance in tests/test_gpu_fp16.py); not the headline")
     a = ap.parse_args()
@@ -187,12 +188,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    run = pipe
+    if a.graph:
+        from cnmnet_amd.pipeline import GraphedFramePipeline
+        run = GraphedFramePipeline(pipe, img, cams)                  # one hipGraph launch per step; inputs stay resident
     for _ in range(a.warmup):
-        out = pipe(img, cams)
+        out = run(img, cams)
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        out = pipe(img, cams)
+        out = run(img, cams)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -209,7 +214,8 @@ def main():
                 "dtype": "f32" if a.precision == "f32" else "f16 storage / f32 accumulate", "data": "synthetic",
                 "config": {"workload": "CNMNet eval frame: 2x depthNet + DepthRefineNet + Depth2normal(k=9), 1 ref + 2 src, "
                                        "256x192, 64 planes, batch=%d frames per GPU (BASELINE configs[1])" % B,
-                           "frames_per_gpu": B, "sharding": "independent frame shards per GPU, no collective"}}
+                           "frames_per_gpu": B, "sharding": "independent frame shards per GPU, no collective",
+                           "launch": "hipGraph replay" if a.graph else "per-kernel, asynchronous"}}
         if not a.no_roofline and a.precision == "f32":
             line["roofline"], line["roofline_planesweep"] = kernel_rooflines(dev, B)
         if world == 1 and not a.no_cpu_baseline:
