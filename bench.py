@@ -57,10 +57,10 @@ def event_ms(fn, iters, warm=2):
 def conv_tile(cout, m):
     """Mirror of the tile heuristic in cnmnet_amd/csrc/conv_mfma.hip (conv_dispatch)."""
     if cout % 128 == 0 and (cout // 128) * -(-m // 128) >= 512:
-        return "conv_mfma_f32_kernel<128,128>"
+        return "conv_mfma_f32_kernel<128, 128, 1, false>"
     if (cout // 64) * -(-m // 128) >= 512:
-        return "conv_mfma_f32_kernel<64,128>"
-    return "conv_mfma_f32_kernel<64,64>"
+        return "conv_mfma_f32_kernel<64, 128, 1, false>"
+    return "conv_mfma_f32_kernel<64, 64, 1, false>"
 
 
 def kernel_rooflines(dev, frames):
