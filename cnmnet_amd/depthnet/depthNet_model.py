@@ -175,6 +175,13 @@ class depthNet(_EngineNet):
             if self.precision != "f32":
                 raise NotImplementedError("training runs in fp32; the f16 engine is inference-only")
             return self._forward_train(ref, src, ref_cam, src_cam)
+        # the conv kernels address activations with 32-bit byte offsets (< 4 GB per tensor); the widest one holds
+        # 128 channels at full resolution = 512 B (fp32) per pixel and pair -> split very large batches by frames
+        max_pairs = int(3.9e9 // ((512 if self.precision == "f32" else 256) * H * W))
+        if B * S > max_pairs and B > 1:
+            nb = max(1, max_pairs // S)
+            parts = [self.forward_pairs(ref[i:i + nb], src[i:i + nb], ref_cam[i:i + nb], src_cam[i:i + nb]) for i in range(0, B, nb)]
+            return [torch.cat([p[0][k] for p in parts], 0) for k in range(4)], torch.cat([p[1] for p in parts], 0)
         self._ensure_packed()
         lib, P, dev = _lib.load(), B * S, ref.device
         ref, src, ref_cam, src_cam = (t.contiguous() for t in (ref, src, ref_cam, src_cam))
