@@ -49,6 +49,9 @@
 #ifndef SWEEP_ASM_DMA
 #define SWEEP_ASM_DMA 0       // 1: LDS-DMA from inline asm + counted vmcnt (measured: no gain over the builtin, kept for study)
 #endif
+#ifndef SWEEP_HYBRID
+#define SWEEP_HYBRID 0          // 1: odd planes of every batch gather their taps from the texture through L1 (TA path)
+#endif                         //    while even planes read the LDS box: the two data paths share the load
 #ifndef SWEEP_MINW
 #define SWEEP_MINW 1           // __launch_bounds__ min waves per SIMD (register cap)
 #endif
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(256) void sweep_texture_kernel(const float* __restr
 // Out-of-image texels are zeros in the staged box, coordinates are clamped into it: no bounds tests.
 // The .w lane of every texel is exactly zero; it is carried through the packed math (adds 0) so the
 // taps stay single 128-bit reads.
-struct SweepTap { int off; f32x2 w1; };      // off: texel index of tap (0,0) in the LDS box
+struct SweepTap { int off; f32x2 w1; float xf, yf; };      // off: texel index of tap (0,0) in the LDS box; (xf,yf) box-relative
 
 __device__ __forceinline__ SweepTap sweep_coords(f32x2 r0f, f32x2 rmaxf, float rwf, f32x2 a01, float a2,
                                                  f32x2 k01, float k2, float z) {
@@ -179,7 +182,7 @@ __device__ __forceinline__ SweepTap sweep_coords(f32x2 r0f, f32x2 rmaxf, float r
     return t;
 #endif
     t.off = (int)fmaf(yf, rwf, xf);                                          // exact: integers < 2^24
-    t.w1 = i - fl;
+    t.w1 = i - fl; t.xf = xf; t.yf = yf;
     return t;
 }
 
@@ -445,10 +448,17 @@ __global__ __launch_bounds__(SWEEP_NT, SWEEP_MINW) void planesweep_kernel(const 
             float4 tx[2][BT][4];
 #pragma unroll
             for (int u = 0; u < BT; ++u) tap[0][u] = sweep_coords(r0f, rmaxf, rwf, a01, a2, k01, k2, zs[u]);
+            const float twpf = (float)TWp;
+            const float4* tbox = texp + (size_t)(cur.ry0 + 2) * TWp + (cur.rx0 + 2);      // texture address of the box origin
 #pragma unroll
             for (int u = 0; u < BT; ++u) {
-                const float4* q = tb + tap[0][u].off;
-                tx[0][u][0] = q[0]; tx[0][u][1] = q[1]; tx[0][u][2] = q[rw]; tx[0][u][3] = q[rw + 1];
+                if (SWEEP_HYBRID && (u & 1)) {
+                    const float4* q = tbox + (int)fmaf(tap[0][u].yf, twpf, tap[0][u].xf);
+                    tx[0][u][0] = q[0]; tx[0][u][1] = q[1]; tx[0][u][2] = q[TWp]; tx[0][u][3] = q[TWp + 1];
+                } else {
+                    const float4* q = tb + tap[0][u].off;
+                    tx[0][u][0] = q[0]; tx[0][u][1] = q[1]; tx[0][u][2] = q[rw]; tx[0][u][3] = q[rw + 1];
+                }
             }
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
@@ -458,8 +468,13 @@ __global__ __launch_bounds__(SWEEP_NT, SWEEP_MINW) void planesweep_kernel(const 
                     for (int u = 0; u < BT; ++u) tap[n][u] = sweep_coords(r0f, rmaxf, rwf, a01, a2, k01, k2, zs[BT * (k + 1) + u]);
 #pragma unroll
                     for (int u = 0; u < BT; ++u) {
-                        const float4* q = tb + tap[n][u].off;
-                        tx[n][u][0] = q[0]; tx[n][u][1] = q[1]; tx[n][u][2] = q[rw]; tx[n][u][3] = q[rw + 1];
+                        if (SWEEP_HYBRID && (u & 1)) {
+                            const float4* q = tbox + (int)fmaf(tap[n][u].yf, twpf, tap[n][u].xf);
+                            tx[n][u][0] = q[0]; tx[n][u][1] = q[1]; tx[n][u][2] = q[TWp]; tx[n][u][3] = q[TWp + 1];
+                        } else {
+                            const float4* q = tb + tap[n][u].off;
+                            tx[n][u][0] = q[0]; tx[n][u][1] = q[1]; tx[n][u][2] = q[rw]; tx[n][u][3] = q[rw + 1];
+                        }
                     }
                 }
 #pragma unroll
@@ -499,6 +514,61 @@ __global__ __launch_bounds__(SWEEP_NT, SWEEP_MINW) void planesweep_kernel(const 
     }
 }
 
+// ------------------------------------------------------------------ K1, direct variant (no LDS)
+// Same arithmetic; the four taps of a sample are 16-byte loads from the zero-bordered RGBA texture through L1/L2.
+// No footprint boxes, no staging, no barriers, low register count (8 waves per SIMD hide the gather latency).
+#ifndef SWEEP_DIRECT_UNROLL
+#define SWEEP_DIRECT_UNROLL 4
+#endif
+template <int LAYOUT>
+__global__ __launch_bounds__(256) void planesweep_direct_kernel(const SweepArgs a) {
+    __shared__ float zsh[CNM_MAX_PLANES];
+    if (threadIdx.x < CNM_MAX_PLANES) zsh[threadIdx.x] = a.z[threadIdx.x];
+    __syncthreads();
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int p = blockIdx.z, b = p / a.S;
+    const int H = a.H, W = a.W, HW = H * W, D = a.D, TWp = W + 4;
+    if (x >= W || y >= H) return;
+    const float* hk = a.hmkt + (size_t)p * 12;
+    const float fx_ = (float)x, fy_ = (float)y;
+    const f32x2 a01 = {fmaf(hk[0], fx_, fmaf(hk[1], fy_, hk[2])), fmaf(hk[3], fx_, fmaf(hk[4], fy_, hk[5]))};
+    const float a2 = fmaf(hk[6], fx_, fmaf(hk[7], fy_, hk[8])), k2 = hk[11];
+    const f32x2 k01 = {hk[9], hk[10]};
+    const float* refp = a.ref + (size_t)b * 3 * HW + (size_t)y * W + x;
+    const float rr = refp[0], rg = refp[HW], rb = refp[2 * HW];
+    const f32x2 ref_rg = {rr, rg}, ref_b0 = {rb, 0.f};
+    const float4* texp = a.tex + (size_t)p * (H + 4) * TWp + 2 * TWp + 2;          // texel (0,0)
+    const f32x2 r0f = {-2.f, -2.f}, rmaxf = {(float)(W + 2), (float)(H + 2)};      // tap (0,0) clamped to [-2, W] x [-2, H]
+    const float rwf = (float)TWp;
+    for (int d0 = 0; d0 < D; d0 += SWEEP_DIRECT_UNROLL) {
+        SweepTap tap[SWEEP_DIRECT_UNROLL];
+        float4 tx[SWEEP_DIRECT_UNROLL][4];
+        float cost[SWEEP_DIRECT_UNROLL];
+#pragma unroll
+        for (int u = 0; u < SWEEP_DIRECT_UNROLL; ++u) tap[u] = sweep_coords(r0f, rmaxf, rwf, a01, a2, k01, k2, zsh[d0 + u]);
+#pragma unroll
+        for (int u = 0; u < SWEEP_DIRECT_UNROLL; ++u) {
+            const float4* q = texp + (tap[u].off - 2 * TWp - 2);                   // off is relative to texel (-2,-2)
+            tx[u][0] = q[0]; tx[u][1] = q[1]; tx[u][2] = q[TWp]; tx[u][3] = q[TWp + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < SWEEP_DIRECT_UNROLL; ++u)
+            cost[u] = sweep_blend(tx[u][0], tx[u][1], tx[u][2], tx[u][3], tap[u].w1, ref_rg, ref_b0);
+        if (LAYOUT == 0) {
+#pragma unroll
+            for (int u = 0; u < SWEEP_DIRECT_UNROLL; ++u)
+                if (d0 + u < D) a.out[((size_t)p * D + d0 + u) * HW + (size_t)y * W + x] = cost[u];
+        } else {
+#pragma unroll
+            for (int q = 0; q < SWEEP_DIRECT_UNROLL / 4; ++q)
+                *reinterpret_cast<float4*>(a.out + c4_offset(p, D / 4 + 1, (d0 >> 2) + q, HW, y * W + x)) =
+                    make_float4(cost[4 * q], cost[4 * q + 1], cost[4 * q + 2], cost[4 * q + 3]);
+        }
+    }
+    if (LAYOUT == 1)
+        *reinterpret_cast<float4*>(a.out + c4_offset(p, D / 4 + 1, D / 4, HW, y * W + x)) = make_float4(rr, rg, rb, 0.f);
+}
+
 extern "C" size_t cnm_planesweep_workspace_floats(int B, int S, int H, int W) {
     if (B <= 0 || S <= 0 || H <= 0 || W <= 0) return 0;
     return (size_t)B * S * (H + 4) * (W + 4) * 4;
@@ -527,6 +597,15 @@ static int sweep_launch(int layout, const float* ref, const float* src, const fl
         sweep_texture_kernel<<<blocks, 256, 0, cnm_stream(stream)>>>(src, reinterpret_cast<float4*>(ws), B * S, H, W);
     }
     dim3 grid(cnm_ceil_div(W, SWEEP_TW), cnm_ceil_div(H, SWEEP_TH), B * S);
+#ifdef SWEEP_USE_DIRECT
+    if (layout <= 1 && D % SWEEP_DIRECT_UNROLL == 0) {
+        dim3 g2(cnm_ceil_div(W, 64), cnm_ceil_div(H, 4), B * S);
+        if (layout == 0) planesweep_direct_kernel<0><<<g2, 256, 0, cnm_stream(stream)>>>(a);
+        else planesweep_direct_kernel<1><<<g2, 256, 0, cnm_stream(stream)>>>(a);
+        CNM_LAUNCH_CHECK();
+        return CNM_OK;
+    }
+#endif
     if (layout == 0) planesweep_kernel<0><<<grid, SWEEP_NT, 0, cnm_stream(stream)>>>(a);
     else if (layout == 1) planesweep_kernel<1><<<grid, SWEEP_NT, 0, cnm_stream(stream)>>>(a);
     else planesweep_kernel<2><<<grid, SWEEP_NT, 0, cnm_stream(stream)>>>(a);
