@@ -26,3 +26,13 @@ def golden():
 def torch_state(np_state):
     import torch
     return {k: torch.from_numpy(np.asarray(v)) for k, v in np_state.items()}
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _engine_library():
+    """Build libcnm_engine.so once if the tree has not been built yet (hipcc cross-compiles without a GPU)."""
+    from cnmnet_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        from cnmnet_amd.build import build
+        build(verbose=False)
+    yield
