@@ -1,0 +1,242 @@
+// Winograd F(2x2,3x3) convolution for the 3x3 stride-1 layers (53 % of a frame's conv FLOPs), fp32 MFMA.
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A     per 2x2 output tile, 4x4 input window d, 3x3 filter g:
+//   16 multiplies per 4 outputs instead of 36 -> 2.25x fewer MFMA flops than the direct implicit GEMM, same fp32
+//   data, transform coefficients in {0, +-1, +-1/2} (error growth ~1e-7 relative: far inside the 1e-3 parity bar).
+//
+// One fused kernel (no transformed tensors in HBM):
+//   workgroup = 4 waves = 64 couts x 64 tiles (2x2 outputs each); per 16-channel chunk
+//     - every thread gathers the 4x4 window of ONE (tile, channel-quad) with 16 buffer loads (out-of-range = 0:
+//       zero padding and ragged tails for free), transforms it in registers (B^T d B, adds only) and writes the
+//       16 frequency points to LDS  V[xi][tile][ci];
+//     - every wave owns 32 couts x 32 tiles for ALL 16 frequency points: per point 2 x (ds_read_b128 of V +
+//       16-byte weight fragment straight from L2 in MFMA operand order) -> 8 v_mfma_f32_32x32x2_f32;
+//       256 accumulator registers per lane (one wave per SIMD, 512-register budget);
+//   epilogue: the 16 frequency values of each (cout, tile) sit in ONE lane -> A^T M A in registers, bias, ReLU,
+//   four float4 stores (c4 layout).
+// The window loads of chunk c+1 are issued before the MFMA phase of chunk c (register prefetch).
+#include "cnm_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct WinoArgs {
+    const float* in; const float* in2; float* out; const float* u; const float* bias;
+    unsigned in_bytes, in2_bytes;
+    int N, H, W, TH, TW;                 // TH = H/2, TW = W/2 tiles
+    int Gin_tot, gin0, Gin2_tot, gin2_0, Gsplit, Gin;
+    int Gout_tot, gout0, Cout;
+    int nchunks, T, relu;                // T = N*TH*TW tiles
+};
+
+__device__ __forceinline__ float4 wino_load(const float* base, unsigned bytes, unsigned voff) {
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes, 0x00020000);
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+#define F4OP(r, a, op, b) do { (r).x = (a).x op (b).x; (r).y = (a).y op (b).y; (r).z = (a).z op (b).z; (r).w = (a).w op (b).w; } while (0)
+
+__global__ __launch_bounds__(256, 1) void conv3x3_winograd_f32_kernel(const WinoArgs a) {
+    constexpr int LDV = 20;                                              // 16 ci + 4 pad floats per (xi, tile) row
+    __shared__ __attribute__((aligned(16))) float V[16 * 64 * LDV];      // 80 KB
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wc = wave >> 1, wt = wave & 1;
+    const int tilesC = a.Cout / 64;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int cblk = tile % tilesC, t0 = (tile / tilesC) * 64;
+    const int HW = a.H * a.W, THW = a.TH * a.TW;
+
+    // ---- loader: thread = (tile tl, channel quad qd of the chunk)
+    const int tl = t & 63, qd = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int tg = t0 + tl;
+    const bool tvalid = tg < a.T;
+    int img, py, px;
+    { const int tt = tvalid ? tg : 0; img = tt / THW; const int rem = tt - img * THW; const int ty = rem / a.TW; py = 2 * ty - 1; px = 2 * (rem - ty * a.TW) - 1; }
+    float4 d[16];
+    auto gather = [&](int chunk) {
+        const int g = chunk * 4 + qd;                                   // channel group of the (possibly concatenated) input
+        const bool s1 = g < a.Gsplit;
+        const float* base = s1 ? a.in : a.in2;
+        const unsigned bytes = s1 ? a.in_bytes : a.in2_bytes;
+        const unsigned gofs = s1 ? (unsigned)((img * a.Gin_tot + a.gin0 + g) * HW) : (unsigned)((img * a.Gin2_tot + a.gin2_0 + g - a.Gsplit) * HW);
+        const bool gok = tvalid && g < a.Gin;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int iy = py + i, ix = px + j;
+                const bool ok = gok && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                d[i * 4 + j] = wino_load(base, bytes, ok ? (gofs + (unsigned)(iy * a.W + ix)) * 16u : 0xFFFFFFFFu);
+            }
+    };
+    auto transform_store = [&]() {                                       // V = B^T d B, B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+        float4 m[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            F4OP(m[0 * 4 + j], d[0 * 4 + j], -, d[2 * 4 + j]);
+            F4OP(m[1 * 4 + j], d[1 * 4 + j], +, d[2 * 4 + j]);
+            F4OP(m[2 * 4 + j], d[2 * 4 + j], -, d[1 * 4 + j]);
+            F4OP(m[3 * 4 + j], d[1 * 4 + j], -, d[3 * 4 + j]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float4 v0, v1, v2, v3;
+            F4OP(v0, m[i * 4 + 0], -, m[i * 4 + 2]);
+            F4OP(v1, m[i * 4 + 1], +, m[i * 4 + 2]);
+            F4OP(v2, m[i * 4 + 2], -, m[i * 4 + 1]);
+            F4OP(v3, m[i * 4 + 1], -, m[i * 4 + 3]);
+            float* dst = V + ((size_t)(i * 4) * 64 + tl) * LDV + qd * 4;
+            *reinterpret_cast<float4*>(dst) = v0;
+            *reinterpret_cast<float4*>(dst + 64 * LDV) = v1;
+            *reinterpret_cast<float4*>(dst + 2 * 64 * LDV) = v2;
+            *reinterpret_cast<float4*>(dst + 3 * 64 * LDV) = v3;
+        }
+    };
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int x = 0; x < 16; ++x)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+
+    // weights in MFMA operand order: [chunk][xi][cout block of 32][kq][lane][4]
+    const int cb = cblk * 2 + wc, ncb = a.Cout / 32;
+    const float4* ubase = reinterpret_cast<const float4*>(a.u) + lane;
+    const float* vrow = V + (size_t)(wt * 32 + (lane & 31)) * LDV + (lane >> 5) * 4;
+
+    constexpr int WD = 16;                                               // weight-fragment prefetch depth (steps of 4 MFMAs)
+    float4 af[WD];
+    gather(0);
+    {
+        const float4* uc = ubase + ((size_t)0 * ncb + cb) * 2 * 64;
+#pragma unroll
+        for (int s = 0; s < WD; ++s) af[s] = uc[((size_t)(s >> 1) * ncb * 2 + (s & 1)) * 64];
+    }
+    for (int c = 0; c < a.nchunks; ++c) {
+        __syncthreads();                                                 // every wave is done reading V of chunk c-1
+        transform_store();
+        __syncthreads();
+        const float4* uc = ubase + ((size_t)(c * 16) * ncb + cb) * 2 * 64;
+        const float4* un = ubase + ((size_t)((c + 1 < a.nchunks ? c + 1 : c) * 16) * ncb + cb) * 2 * 64;
+        gather(c + 1);                                                   // next chunk's windows (past the end: all out of range = 0, no traffic)
+        float4 bf = *reinterpret_cast<const float4*>(vrow);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const int x = s >> 1;
+            const float4 aw = af[s % WD];
+            const float4 bw = bf;
+            if (s + 1 < 32) bf = *reinterpret_cast<const float4*>(vrow + (size_t)((s + 1) >> 1) * 64 * LDV + ((s + 1) & 1) * 8);
+            acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.x, bw.x, acc[x], 0, 0, 0);
+            const int sn = s + WD;                                       // refill this slot (wraps into the next chunk)
+            af[s % WD] = sn < 32 ? uc[((size_t)(sn >> 1) * ncb * 2 + (sn & 1)) * 64]
+                                 : un[((size_t)((sn - 32) >> 1) * ncb * 2 + (sn & 1)) * 64];
+            acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.y, bw.y, acc[x], 0, 0, 0);
+            acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.z, bw.z, acc[x], 0, 0, 0);
+            acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.w, bw.w, acc[x], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---- epilogue: Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1]; acc row = cout (r&3)+8*(r>>2)+4*(lane>>5), col = tile lane&31
+    const int to = t0 + wt * 32 + (lane & 31);
+    if (to >= a.T) return;
+    const int oimg = to / THW, orem = to - oimg * THW, oty = orem / a.TW, otx = orem - oty * a.TW;
+    const int opix = (2 * oty) * a.W + 2 * otx;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int co = cblk * 64 + wc * 32 + 8 * q + 4 * (lane >> 5);
+        const float4 b = a.bias ? *reinterpret_cast<const float4*>(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float y[4][4];                                                   // [pixel 2a+b][channel e]
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = 4 * q + e;
+            float s0[4], s1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s0[j] = acc[0 * 4 + j][r] + acc[1 * 4 + j][r] + acc[2 * 4 + j][r];
+                s1[j] = acc[1 * 4 + j][r] - acc[2 * 4 + j][r] - acc[3 * 4 + j][r];
+            }
+            y[0][e] = s0[0] + s0[1] + s0[2]; y[1][e] = s0[1] - s0[2] - s0[3];
+            y[2][e] = s1[0] + s1[1] + s1[2]; y[3][e] = s1[1] - s1[2] - s1[3];
+        }
+        const float bb[4] = {b.x, b.y, b.z, b.w};
+        float* obase = a.out + c4_offset(oimg, a.Gout_tot, a.gout0 + (co >> 2), HW, 0);
+#pragma unroll
+        for (int pq = 0; pq < 4; ++pq) {
+            float4 v = make_float4(y[pq][0] + bb[0], y[pq][1] + bb[1], y[pq][2] + bb[2], y[pq][3] + bb[3]);
+            if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<float4*>(obase + (size_t)(opix + (pq >> 1) * a.W + (pq & 1)) * 4) = v;
+        }
+    }
+}
+
+// U = G g G^T (with the folded BatchNorm scale), packed in MFMA A-operand order
+// [chunk][xi][cout/32][kq][lane][4]:  value(co = cb*32 + (lane&31), ci = chunk*16 + kq*8 + 4*(lane>>5) + e).
+__global__ void pack_winograd_kernel(const float* __restrict__ w, const float* __restrict__ gamma, const float* __restrict__ var,
+                                     float eps, int Cout, int Cin, int rot, int nchunks, float* __restrict__ up) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int ncb = Cout / 32;
+    const long long total = (long long)nchunks * 16 * ncb * 2 * 64 * 4;
+    if (idx >= total) return;
+    const int e = (int)(idx & 3), lane = (int)((idx >> 2) & 63), kq = (int)((idx >> 8) & 1);
+    long long r = idx >> 9;
+    const int cb = (int)(r % ncb); r /= ncb;
+    const int xi = (int)(r % 16), chunk = (int)(r / 16);
+    const int co = cb * 32 + (lane & 31), cp = chunk * 16 + kq * 8 + 4 * (lane >> 5) + e;
+    float v = 0.f;
+    if (cp < Cin) {
+        const int ci = (cp + rot) % Cin;
+        const float* g = w + ((size_t)co * Cin + ci) * 9;
+        const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+        const int ai = xi >> 2, bi = xi & 3;
+        double s = 0;
+        for (int p = 0; p < 3; ++p) for (int q = 0; q < 3; ++q) s += G[ai][p] * (double)g[p * 3 + q] * G[bi][q];
+        if (gamma) s *= (double)gamma[co] / sqrt((double)var[co] + (double)eps);
+        v = (float)s;
+    }
+    up[idx] = v;
+}
+
+extern "C" size_t cnm_packed_winograd_floats(int Cout, int Cin) {
+    if (Cout <= 0 || Cin <= 0 || Cout % 64) return 0;
+    const int nchunks = (4 * ((Cin + 3) / 4) + 15) / 16;
+    return (size_t)nchunks * 16 * Cout * 16;
+}
+
+extern "C" int cnm_pack_winograd_bn_f32(const float* w_oihw, const float* bn_gamma, const float* bn_var, float eps,
+                                        int Cout, int Cin, int rot, float* u_packed, void* stream) {
+    CNM_REQUIRE(w_oihw && u_packed && Cout > 0 && Cout % 64 == 0 && Cin > 0 && rot >= 0 && rot < Cin, CNM_ERR_BAD_ARG);
+    CNM_REQUIRE(!bn_gamma == !bn_var, CNM_ERR_BAD_ARG);
+    const int nchunks = (4 * ((Cin + 3) / 4) + 15) / 16;
+    const long long total = (long long)nchunks * 16 * Cout * 16;
+    pack_winograd_kernel<<<(unsigned)cnm_ceil_div_ll(total, 256), 256, 0, cnm_stream(stream)>>>(w_oihw, bn_gamma, bn_var, eps, Cout, Cin, rot, nchunks, u_packed);
+    CNM_LAUNCH_CHECK();
+    return CNM_OK;
+}
+
+extern "C" int cnm_conv3x3_winograd_c4_f32(const float* in_a, int Ga_total, int ga0, int Ga,
+                                           const float* in_b, int Gb_total, int gb0, int Gb,
+                                           float* out, int Gout_total, int gout0, int Cout,
+                                           const float* u_packed, const float* b_packed,
+                                           int N, int H, int W, int relu, void* stream) {
+    CNM_REQUIRE(in_a && out && u_packed && N > 0 && H > 0 && W > 0 && Ga > 0 && Gb >= 0, CNM_ERR_BAD_ARG);
+    CNM_REQUIRE(H % 2 == 0 && W % 2 == 0, CNM_ERR_BAD_SHAPE);
+    CNM_REQUIRE(Cout > 0 && Cout % 64 == 0 && gout0 >= 0 && gout0 + Cout / 4 <= Gout_total, CNM_ERR_BAD_ARG);
+    CNM_REQUIRE(ga0 >= 0 && ga0 + Ga <= Ga_total && (Gb == 0 || (in_b && gb0 >= 0 && gb0 + Gb <= Gb_total)), CNM_ERR_BAD_ARG);
+    WinoArgs a;
+    a.in = in_a; a.in2 = Gb ? in_b : in_a; a.out = out; a.u = u_packed; a.bias = b_packed;
+    const unsigned long long b1 = (unsigned long long)N * Ga_total * H * W * 16ull;
+    const unsigned long long b2 = Gb ? (unsigned long long)N * Gb_total * H * W * 16ull : b1;
+    CNM_REQUIRE(b1 < 0xFFFFFFFFull && b2 < 0xFFFFFFFFull, CNM_ERR_BAD_ARG);
+    a.in_bytes = (unsigned)b1; a.in2_bytes = (unsigned)b2;
+    a.N = N; a.H = H; a.W = W; a.TH = H / 2; a.TW = W / 2;
+    a.Gin_tot = Ga_total; a.gin0 = ga0; a.Gin2_tot = Gb ? Gb_total : Ga_total; a.gin2_0 = Gb ? gb0 : ga0; a.Gsplit = Ga; a.Gin = Ga + Gb;
+    a.Gout_tot = Gout_total; a.gout0 = gout0; a.Cout = Cout;
+    a.nchunks = (4 * a.Gin + 15) / 16; a.T = N * a.TH * a.TW; a.relu = relu;
+    const int nblocks = (Cout / 64) * cnm_ceil_div(a.T, 64);
+    conv3x3_winograd_f32_kernel<<<nblocks, 256, 0, cnm_stream(stream)>>>(a);
+    CNM_LAUNCH_CHECK();
+    return CNM_OK;
+}

@@ -110,6 +110,20 @@ int cnm_conv2d_cat2_c4_f32(const float* in_a, int Ga_total, int ga0, int Ga,
                            const float* w_packed, const float* b_packed,
                            int N, int H, int W, int ksize, int stride, int relu, void* stream);
 
+/* Winograd F(2x2,3x3) twin of cnm_conv2d_cat2_c4_f32 for ksize 3, stride 1, even H and W (the reference's
+ * nn.Conv2d(.., 3, 1, 1) layers: depthNet_model.py:77-86 conv_layer, :90-98 upconv, DepthRefineNet :248-285):
+ * 2.25x fewer multiplies, fp32 data and accumulation, transforms in {0,+-1,+-1/2}.  u_packed comes from
+ * cnm_pack_winograd_bn_f32 (G g G^T with the folded BatchNorm scale, MFMA operand order); b_packed is the
+ * bias vector cnm_pack_conv_bn_f32 produces.  Gb = 0 -> single input view. */
+size_t cnm_packed_winograd_floats(int Cout, int Cin);
+int cnm_pack_winograd_bn_f32(const float* w_oihw, const float* bn_gamma, const float* bn_var, float eps,
+                             int Cout, int Cin, int rot, float* u_packed, void* stream);
+int cnm_conv3x3_winograd_c4_f32(const float* in_a, int Ga_total, int ga0, int Ga,
+                                const float* in_b, int Gb_total, int gb0, int Gb,
+                                float* out, int Gout_total, int gout0, int Cout,
+                                const float* u_packed, const float* b_packed,
+                                int N, int H, int W, int relu, void* stream);
+
 /* nn.Upsample(scale_factor=2, mode='bilinear') with align_corners=False
  * (depthNet_model.py:94,105) on a c4 view: [N,G,H,W,4] -> [N,G,2H,2W,4]. */
 int cnm_upsample2x_c4_f32(const float* in, int Gin_total, int gin0,
