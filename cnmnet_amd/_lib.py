@@ -20,7 +20,7 @@ class LayerInfo(C.Structure):
 
 
 class LayerWeights(C.Structure):
-    _fields_ = [("w", c_fp), ("b", c_fp)]
+    _fields_ = [("w", c_fp), ("b", c_fp), ("u", c_fp)]
 
 
 # name -> (restype, argtypes); mirrors include/cnm_engine.h declaration by declaration
@@ -113,8 +113,8 @@ def load():
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch
         fn.restype, fn.argtypes = res, args
-    if lib.cnm_abi_version() != 1:
-        raise EngineError("libcnm_engine.so ABI version %d, expected 1" % lib.cnm_abi_version())
+    if lib.cnm_abi_version() != 2:
+        raise EngineError("libcnm_engine.so ABI version %d, expected 2" % lib.cnm_abi_version())
     _lib = lib
     return lib
 

@@ -23,7 +23,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 struct WinoArgs {
     const float* in; const float* in2; float* out; const float* u; const float* bias;
     unsigned in_bytes, in2_bytes;
-    int N, H, W, TH, TW;                 // TH = H/2, TW = W/2 tiles
+    int N, H, W, TH, TW;                 // TH = ceil(H/2), TW = ceil(W/2) tiles
     int Gin_tot, gin0, Gin2_tot, gin2_0, Gsplit, Gin;
     int Gout_tot, gout0, Cout;
     int nchunks, T, relu;                // T = N*TH*TW tiles
@@ -167,7 +167,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_winograd_f32_kernel(const Wino
         for (int pq = 0; pq < 4; ++pq) {
             float4 v = make_float4(y[pq][0] + bb[0], y[pq][1] + bb[1], y[pq][2] + bb[2], y[pq][3] + bb[3]);
             if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            *reinterpret_cast<float4*>(obase + (size_t)(opix + (pq >> 1) * a.W + (pq & 1)) * 4) = v;
+            if (2 * oty + (pq >> 1) < a.H && 2 * otx + (pq & 1) < a.W)    // odd H / W: the last tile row / column is half outside
+                *reinterpret_cast<float4*>(obase + (size_t)(opix + (pq >> 1) * a.W + (pq & 1)) * 4) = v;
         }
     }
 }
@@ -222,7 +223,6 @@ extern "C" int cnm_conv3x3_winograd_c4_f32(const float* in_a, int Ga_total, int 
                                            const float* u_packed, const float* b_packed,
                                            int N, int H, int W, int relu, void* stream) {
     CNM_REQUIRE(in_a && out && u_packed && N > 0 && H > 0 && W > 0 && Ga > 0 && Gb >= 0, CNM_ERR_BAD_ARG);
-    CNM_REQUIRE(H % 2 == 0 && W % 2 == 0, CNM_ERR_BAD_SHAPE);
     CNM_REQUIRE(Cout > 0 && Cout % 64 == 0 && gout0 >= 0 && gout0 + Cout / 4 <= Gout_total, CNM_ERR_BAD_ARG);
     CNM_REQUIRE(ga0 >= 0 && ga0 + Ga <= Ga_total && (Gb == 0 || (in_b && gb0 >= 0 && gb0 + Gb <= Gb_total)), CNM_ERR_BAD_ARG);
     WinoArgs a;
@@ -231,7 +231,7 @@ extern "C" int cnm_conv3x3_winograd_c4_f32(const float* in_a, int Ga_total, int 
     const unsigned long long b2 = Gb ? (unsigned long long)N * Gb_total * H * W * 16ull : b1;
     CNM_REQUIRE(b1 < 0xFFFFFFFFull && b2 < 0xFFFFFFFFull, CNM_ERR_BAD_ARG);
     a.in_bytes = (unsigned)b1; a.in2_bytes = (unsigned)b2;
-    a.N = N; a.H = H; a.W = W; a.TH = H / 2; a.TW = W / 2;
+    a.N = N; a.H = H; a.W = W; a.TH = (H + 1) / 2; a.TW = (W + 1) / 2;
     a.Gin_tot = Ga_total; a.gin0 = ga0; a.Gin2_tot = Gb ? Gb_total : Ga_total; a.gin2_0 = Gb ? gb0 : ga0; a.Gsplit = Ga; a.Gin = Ga + Gb;
     a.Gout_tot = Gout_total; a.gout0 = gout0; a.Cout = Cout;
     a.nchunks = (4 * a.Gin + 15) / 16; a.T = N * a.TH * a.TW; a.relu = relu;

@@ -403,7 +403,7 @@ __global__ __launch_bounds__(SWEEP_NT, SWEEP_MINW) void planesweep_kernel(const 
     };
     TRACE(1);
     // counted waits need a fixed number of stores per wave and group: full tiles and full groups only
-    const bool counted = __builtin_amdgcn_readfirstlane((tx0 + SWEEP_TW <= W) && (ty0 + SWEEP_TH <= H) && (D % SWEEP_PG == 0) && !SWEEP_DEFER);
+    [[maybe_unused]] const bool counted = __builtin_amdgcn_readfirstlane((tx0 + SWEEP_TW <= W) && (ty0 + SWEEP_TH <= H) && (D % SWEEP_PG == 0) && !SWEEP_DEFER);
     SweepBox cur = box_of(0);
     if (cur.staged) stage(cur, tex[0]);
     TRACE(2);

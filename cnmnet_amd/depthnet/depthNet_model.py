@@ -16,6 +16,7 @@ or eager-torch fallback.
 """
 import ctypes
 
+import os
 import torch
 import torch.nn as nn
 
@@ -72,7 +73,8 @@ class _EngineNet(nn.Module):
             raise ValueError("precision must be 'f32' or 'f16'")
         self.precision = precision  # 'f16': fp16 storage + f16 MFMA (BASELINE config 5); eval only
         self._layers = None        # engine layer table (resolved lazily: needs the library)
-        self._packed = None        # [(w, b)] device tensors, one per engine layer
+        self.winograd = os.environ.get("CNM_WINOGRAD", "1") != "0"   # fp32 3x3 stride-1 layers in the Winograd domain
+        self._packed = None        # [(w, b[, u])] device tensors, one per engine layer
         self._packed_key = None
         self._weights_arr = None
         self._ws = {}
@@ -84,7 +86,7 @@ class _EngineNet(nn.Module):
 
     def _param_key(self):
         ts = list(self.parameters()) + list(self.buffers())
-        return (self.precision, str(ts[0].device), tuple(t._version for t in ts), tuple(t.data_ptr() for t in ts[:4]))
+        return (self.precision, self.winograd, str(ts[0].device), tuple(t._version for t in ts), tuple(t.data_ptr() for t in ts[:4]))
 
     def _first_cin(self):
         return None
@@ -104,11 +106,15 @@ class _EngineNet(nn.Module):
             else:
                 bn = self._sub(L["bn_key"])
                 pack = ops.pack_conv_f16 if self.precision == "f16" else ops.pack_conv
-                packed.append(pack(w, (bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var),
-                                   rot=L["rot"], eps=bn.eps))
+                bnp = (bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var)
+                wp, bp = pack(w, bnp, rot=L["rot"], eps=bn.eps)
+                # fp32 3x3 stride-1 layers run in the Winograd domain (cnm_conv3x3_winograd_c4_f32)
+                wino = (self.precision == "f32" and self.winograd and L["ksize"] == 3 and L["stride"] == 1 and L["Cout"] % 64 == 0)
+                packed.append((wp, bp, ops.pack_winograd(w, bnp, rot=L["rot"], eps=bn.eps)) if wino else (wp, bp))
         arr = (_lib.LayerWeights * len(packed))()
-        for i, (w, b) in enumerate(packed):
-            arr[i].w, arr[i].b = w.data_ptr(), b.data_ptr()
+        for i, t in enumerate(packed):
+            arr[i].w, arr[i].b = t[0].data_ptr(), t[1].data_ptr()
+            arr[i].u = t[2].data_ptr() if len(t) > 2 else None
         self._packed, self._weights_arr, self._packed_key = packed, arr, key
 
     def _workspace(self, device, nfloats):

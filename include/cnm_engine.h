@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define CNM_ABI_VERSION 1
+#define CNM_ABI_VERSION 2
 
 typedef enum cnm_status {
     CNM_OK = 0,
@@ -110,7 +110,7 @@ int cnm_conv2d_cat2_c4_f32(const float* in_a, int Ga_total, int ga0, int Ga,
                            const float* w_packed, const float* b_packed,
                            int N, int H, int W, int ksize, int stride, int relu, void* stream);
 
-/* Winograd F(2x2,3x3) twin of cnm_conv2d_cat2_c4_f32 for ksize 3, stride 1, even H and W (the reference's
+/* Winograd F(2x2,3x3) twin of cnm_conv2d_cat2_c4_f32 for ksize 3, stride 1 (the reference's
  * nn.Conv2d(.., 3, 1, 1) layers: depthNet_model.py:77-86 conv_layer, :90-98 upconv, DepthRefineNet :248-285):
  * 2.25x fewer multiplies, fp32 data and accumulation, transforms in {0,+-1,+-1/2}.  u_packed comes from
  * cnm_pack_winograd_bn_f32 (G g G^T with the folded BatchNorm scale, MFMA operand order); b_packed is the
@@ -175,7 +175,10 @@ typedef struct cnm_layer_info {
 int cnm_net_num_layers(int net);
 int cnm_net_layer(int net, int index, cnm_layer_info* info);   /* D=64 table */
 
-typedef struct cnm_layer_weights { const float* w; const float* b; } cnm_layer_weights;
+/* w, b: cnm_pack_conv_bn_* (or cnm_pack_head_f32) outputs.  u: optional Winograd-domain filter of
+ * cnm_pack_winograd_bn_f32 -- when non-NULL the fp32 executors run that 3x3 stride-1 layer through
+ * cnm_conv3x3_winograd_c4_f32 (w may then be NULL); ignored by heads, other layers and the fp16 engine. */
+typedef struct cnm_layer_weights { const float* w; const float* b; const float* u; } cnm_layer_weights;
 
 /* depthNet.forward (depthNet_model.py:226-263) for P = B*S (ref,src) pairs.
  * weights[i] = packed tensors of layer i of the CNM_NET_DEPTH table (conv1.0 packed with

@@ -142,6 +142,48 @@ def test_conv_cat2_equals_concat(dev, ops):
     assert np.abs(got - want).max() < 2e-5 * np.abs(want).max() + 1e-5
 
 
+@pytest.mark.parametrize("cin,cout,rot,N,H,W", [
+    (513, 256, 0, 1, 12, 20), (65, 64, 0, 3, 20, 28), (35, 64, 3, 1, 9, 13), (64, 128, 0, 4, 64, 64), (67, 128, 3, 2, 15, 20),
+    (512, 512, 0, 2, 6, 8), (128, 64, 0, 1, 1, 1), (16, 64, 0, 1, 7, 130)])
+def test_conv3x3_winograd(dev, ops, cin, cout, rot, N, H, W):
+    """Winograd F(2x2,3x3) twin of the 3x3 stride-1 conv+BN+ReLU: odd sizes, ragged Cin, rotated first layer."""
+    rng = np.random.default_rng(cin * 11 + H)
+    x = T(rng.standard_normal((N, cin, H, W)).astype(np.float32))
+    conv = torch.nn.Conv2d(cin, cout, 3, padding=1, bias=False)
+    bnp = [T(a.astype(np.float32)) for a in (rng.uniform(0.5, 1.5, cout), rng.normal(0, 0.2, cout), rng.normal(0, 0.2, cout), rng.uniform(0.5, 1.5, cout))]
+    with torch.no_grad():
+        sc = bnp[0].double() / torch.sqrt(bnp[3].double() + 1e-5)
+        want = F.relu(F.conv2d(x.double(), conv.weight.double(), padding=1) * sc[None, :, None, None]
+                      + (bnp[1].double() - bnp[2].double() * sc)[None, :, None, None]).numpy()
+    bnd = tuple(t.to(dev) for t in bnp)
+    _, bp = ops.pack_conv(conv.weight.detach().to(dev), bnd, rot=rot)
+    up = ops.pack_winograd(conv.weight.detach().to(dev), bnd, rot=rot)
+    xr = torch.cat((x[:, rot:], x[:, :rot]), 1) if rot else x
+    got = ops.c4_to_nchw(ops.conv3x3_winograd_c4(ops.nchw_to_c4(xr.to(dev)), up, bp, cout, True), cout).cpu().numpy()
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() < 2e-5 * max(np.abs(want).max(), 1.0) + 1e-5, np.abs(got - want).max()
+
+
+def test_conv3x3_winograd_cat2_and_views(dev, ops):
+    """Two-source read (torch.cat without the copy) and writing into a channel-group slice of a wider buffer."""
+    from cnmnet_amd import _lib
+    rng = np.random.default_rng(5)
+    a = T(rng.standard_normal((2, 256, 12, 16)).astype(np.float32)); b = T(rng.standard_normal((2, 4, 12, 16)).astype(np.float32))
+    w = T((rng.standard_normal((128, 257, 3, 3)) * 0.02).astype(np.float32))
+    want = F.conv2d(torch.cat((a, b[:, :1]), 1).double(), w.double(), padding=1).numpy()
+    up = ops.pack_winograd(w.to(dev))
+    bc = ops.nchw_to_c4(b.to(dev)); bc[..., 1:] = 0                      # the 257th channel rides in a zero-padded group
+    got = ops.c4_to_nchw(ops.conv3x3_winograd_c4(ops.nchw_to_c4(a.to(dev)), up, torch.zeros(128, device=dev), 128, False, x2=bc)).cpu().numpy()
+    assert np.abs(got - want).max() < 2e-5 * np.abs(want).max() + 1e-5
+    wide = torch.full((2, 40, 12, 16, 4), 7.0, device=dev)               # output view: groups [5, 37) of 40
+    ac = ops.nchw_to_c4(a.to(dev))
+    _lib.check(_lib.load().cnm_conv3x3_winograd_c4_f32(ac.data_ptr(), 64, 0, 64, bc.data_ptr(), 1, 0, 1, wide.data_ptr(), 40, 5, 128,
+                                                       up.data_ptr(), None, 2, 12, 16, 0, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert (wide[:, :5] == 7).all() and (wide[:, 37:] == 7).all()
+    np.testing.assert_array_equal(ops.c4_to_nchw(wide[:, 5:37].contiguous()).cpu().numpy(), got)
+
+
 def test_upsample_head_layout(dev, ops, golden):
     g = golden("upsample2x_5x7.npz")
     x = T(np.concatenate([g["x"], g["x"] * 2], 1))                       # 4 channels -> one c4 group
@@ -186,6 +228,25 @@ def test_depthnet_and_refine_golden(dev, golden):
     assert _stats(prob.cpu().numpy(), gr["prob_map"])[2] < 1e-3
     assert _stats(vf[:, ch].cpu().numpy(), gr["iconv1_depth"])[2] < 1e-4 * np.abs(gr["iconv1_depth"]).max()
     assert torch.equal(disp, disp2) and torch.equal(prob, prob2)
+
+
+def test_winograd_and_direct_networks_agree(dev):
+    """The fp32 executors with and without the Winograd layers: same frame, outputs within 1e-4 (both are inside the
+    1e-3 parity bar against the reference's golden outputs, checked above for the default = Winograd path)."""
+    from cnmnet_amd.depthnet import depthNet, DepthRefineNet
+    img, cams = syn.frames(1, 2, 64, 96, seed=21)
+    outs = []
+    for wino in (True, False):
+        net = _load(depthNet(3.0), 5).to(dev); net.winograd = wino
+        ref = _load(DepthRefineNet(32, 3.0), 6).to(dev); ref.winograd = wino
+        with torch.no_grad():
+            o1, f1 = net(T(img[:, 0]).to(dev), T(img[:, 1]).to(dev), T(cams[:, 0]).to(dev), T(cams[:, 1]).to(dev))
+            o2, f2 = net(T(img[:, 0]).to(dev), T(img[:, 2]).to(dev), T(cams[:, 0]).to(dev), T(cams[:, 2]).to(dev))
+            d, p = ref(o1[0], o2[0], f1, f2)
+        outs.append([t.cpu().numpy() for t in (o1[0], o1[3], d, p)])
+    for a, b in zip(*outs):
+        assert np.abs(a - b).max() < 1e-4, np.abs(a - b).max()
+    assert any(np.abs(a - b).max() > 0 for a, b in zip(*outs))           # the two paths really are different kernels
 
 
 @pytest.mark.parametrize("planes,S", [(32, 1), (96, 2)])
