@@ -8,14 +8,23 @@
 //   workgroup = 4 waves = 64 couts x 64 tiles (2x2 outputs each); per 16-channel chunk
 //     - every thread gathers the 4x4 window of ONE (tile, channel-quad) with 16 buffer loads (out-of-range = 0:
 //       zero padding and ragged tails for free), transforms it in registers (B^T d B, adds only) and writes the
-//       16 frequency points to LDS  V[xi][tile][ci];
+//       16 frequency points to LDS  V[xi][tile][ci]  (double buffered, XOR-swizzled rows);
 //     - every wave owns 32 couts x 32 tiles for ALL 16 frequency points: per point 2 x (ds_read_b128 of V +
 //       16-byte weight fragment straight from L2 in MFMA operand order) -> 8 v_mfma_f32_32x32x2_f32;
 //       256 accumulator registers per lane (one wave per SIMD, 512-register budget);
 //   epilogue: the 16 frequency values of each (cout, tile) sit in ONE lane -> A^T M A in registers, bias, ReLU,
 //   four float4 stores (c4 layout).
-// The window loads of chunk c+1 are issued before the MFMA phase of chunk c (register prefetch).
+// Software pipeline (one wave per SIMD, so the overlap is inside the wave): while the MFMAs of chunk c run, the
+// same wave transforms chunk c+1 into the other V buffer, gathers the windows of chunk c+2 and keeps 16 weight
+// fragments in flight; one barrier per chunk.
 #include "cnm_common.h"
+
+#ifndef WINO_ABL_GATHER
+#define WINO_ABL_GATHER 0   // ablation switches (timing studies only; results are wrong when set)
+#endif
+#ifndef WINO_ABL_REFILL
+#define WINO_ABL_REFILL 0
+#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -38,8 +47,12 @@ __device__ __forceinline__ float4 wino_load(const float* base, unsigned bytes, u
 #define F4OP(r, a, op, b) do { (r).x = (a).x op (b).x; (r).y = (a).y op (b).y; (r).z = (a).z op (b).z; (r).w = (a).w op (b).w; } while (0)
 
 __global__ __launch_bounds__(256, 1) void conv3x3_winograd_f32_kernel(const WinoArgs a) {
-    constexpr int LDV = 20;                                              // 16 ci + 4 pad floats per (xi, tile) row
-    __shared__ __attribute__((aligned(16))) float V[16 * 64 * LDV];      // 80 KB
+    // V[buf][xi][tile][16 ci]: rows of 64 B, the four 16-byte slots of a row XOR-swizzled with ((tile >> 2) & 3) so that
+    // 16 consecutive rows cover all 64 banks:
+    // both the b128 writes (lanes = tiles, one slot) and the b128 operand reads are bank-conflict free without padding;
+    // two buffers (128 KB): chunk c+1 is transformed while chunk c feeds the MFMAs.
+    constexpr int VBUF = 16 * 64 * 16;
+    __shared__ __attribute__((aligned(16))) float V[2 * VBUF];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wc = wave >> 1, wt = wave & 1;
     const int tilesC = a.Cout / 64;
@@ -54,44 +67,46 @@ __global__ __launch_bounds__(256, 1) void conv3x3_winograd_f32_kernel(const Wino
     int img, py, px;
     { const int tt = tvalid ? tg : 0; img = tt / THW; const int rem = tt - img * THW; const int ty = rem / a.TW; py = 2 * ty - 1; px = 2 * (rem - ty * a.TW) - 1; }
     float4 d[16];
-    auto gather = [&](int chunk) {
+    // window loads of one chunk, issuable one at a time (spread over the MFMA steps: a burst of 16 would hold the
+    // wave -- and the other three -- at the texture addresser while the matrix pipe drains)
+    const float* gbase; unsigned gbytes, gofs; bool gok;
+    auto gather_begin = [&](int chunk) {
         const int g = chunk * 4 + qd;                                   // channel group of the (possibly concatenated) input
         const bool s1 = g < a.Gsplit;
-        const float* base = s1 ? a.in : a.in2;
-        const unsigned bytes = s1 ? a.in_bytes : a.in2_bytes;
-        const unsigned gofs = s1 ? (unsigned)((img * a.Gin_tot + a.gin0 + g) * HW) : (unsigned)((img * a.Gin2_tot + a.gin2_0 + g - a.Gsplit) * HW);
-        const bool gok = tvalid && g < a.Gin;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int iy = py + i, ix = px + j;
-                const bool ok = gok && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-                d[i * 4 + j] = wino_load(base, bytes, ok ? (gofs + (unsigned)(iy * a.W + ix)) * 16u : 0xFFFFFFFFu);
-            }
+        gbase = s1 ? a.in : a.in2;
+        gbytes = s1 ? a.in_bytes : a.in2_bytes;
+        gofs = s1 ? (unsigned)((img * a.Gin_tot + a.gin0 + g) * HW) : (unsigned)((img * a.Gin2_tot + a.gin2_0 + g - a.Gsplit) * HW);
+        gok = tvalid & (g < a.Gin);
     };
-    auto transform_store = [&]() {                                       // V = B^T d B, B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
-        float4 m[16];
+    auto gather_load = [&](int ij) {
+        const int iy = py + (ij >> 2), ix = px + (ij & 3);
+        const bool ok = gok & ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)a.W);
+        d[ij] = wino_load(gbase, gbytes, ok ? (gofs + (unsigned)(iy * a.W + ix)) * 16u : 0xFFFFFFFFu);
+    };
+    auto gather = [&](int chunk) {
+        gather_begin(chunk);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            F4OP(m[0 * 4 + j], d[0 * 4 + j], -, d[2 * 4 + j]);
-            F4OP(m[1 * 4 + j], d[1 * 4 + j], +, d[2 * 4 + j]);
-            F4OP(m[2 * 4 + j], d[2 * 4 + j], -, d[1 * 4 + j]);
-            F4OP(m[3 * 4 + j], d[1 * 4 + j], -, d[3 * 4 + j]);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float4 v0, v1, v2, v3;
-            F4OP(v0, m[i * 4 + 0], -, m[i * 4 + 2]);
-            F4OP(v1, m[i * 4 + 1], +, m[i * 4 + 2]);
-            F4OP(v2, m[i * 4 + 2], -, m[i * 4 + 1]);
-            F4OP(v3, m[i * 4 + 1], -, m[i * 4 + 3]);
-            float* dst = V + ((size_t)(i * 4) * 64 + tl) * LDV + qd * 4;
-            *reinterpret_cast<float4*>(dst) = v0;
-            *reinterpret_cast<float4*>(dst + 64 * LDV) = v1;
-            *reinterpret_cast<float4*>(dst + 2 * 64 * LDV) = v2;
-            *reinterpret_cast<float4*>(dst + 3 * 64 * LDV) = v3;
-        }
+        for (int ij = 0; ij < 16; ++ij) gather_load(ij);
+    };
+    float4 m[16];
+    const int wslot = (qd ^ ((tl >> 2) & 3)) * 4;
+    auto column_pass = [&](int j) {                                      // m = B^T d, B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+        F4OP(m[0 * 4 + j], d[0 * 4 + j], -, d[2 * 4 + j]);
+        F4OP(m[1 * 4 + j], d[1 * 4 + j], +, d[2 * 4 + j]);
+        F4OP(m[2 * 4 + j], d[2 * 4 + j], -, d[1 * 4 + j]);
+        F4OP(m[3 * 4 + j], d[1 * 4 + j], -, d[3 * 4 + j]);
+    };
+    auto row_pass = [&](int i, float* Vdst) {                            // V = m B, four frequency points of row i to LDS
+        float4 v0, v1, v2, v3;
+        F4OP(v0, m[i * 4 + 0], -, m[i * 4 + 2]);
+        F4OP(v1, m[i * 4 + 1], +, m[i * 4 + 2]);
+        F4OP(v2, m[i * 4 + 2], -, m[i * 4 + 1]);
+        F4OP(v3, m[i * 4 + 1], -, m[i * 4 + 3]);
+        float* dst = Vdst + ((size_t)(i * 4) * 64 + tl) * 16 + wslot;
+        *reinterpret_cast<float4*>(dst) = v0;
+        *reinterpret_cast<float4*>(dst + 64 * 16) = v1;
+        *reinterpret_cast<float4*>(dst + 2 * 64 * 16) = v2;
+        *reinterpret_cast<float4*>(dst + 3 * 64 * 16) = v3;
     };
 
     f32x16 acc[16];
@@ -103,7 +118,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_winograd_f32_kernel(const Wino
     // weights in MFMA operand order: [chunk][xi][cout block of 32][kq][lane][4]
     const int cb = cblk * 2 + wc, ncb = a.Cout / 32;
     const float4* ubase = reinterpret_cast<const float4*>(a.u) + lane;
-    const float* vrow = V + (size_t)(wt * 32 + (lane & 31)) * LDV + (lane >> 5) * 4;
+    const int rrow = wt * 32 + (lane & 31);
+    const int voff0 = rrow * 16 + ((lane >> 5) ^ ((rrow >> 2) & 3)) * 4;      // kq = 0: slot (lane>>5)
+    const int voff1 = rrow * 16 + ((2 + (lane >> 5)) ^ ((rrow >> 2) & 3)) * 4;  // kq = 1: slot 2 + (lane>>5)
 
     constexpr int WD = 16;                                               // weight-fragment prefetch depth (steps of 4 MFMAs)
     float4 af[WD];
@@ -113,30 +130,57 @@ __global__ __launch_bounds__(256, 1) void conv3x3_winograd_f32_kernel(const Wino
 #pragma unroll
         for (int s = 0; s < WD; ++s) af[s] = uc[((size_t)(s >> 1) * ncb * 2 + (s & 1)) * 64];
     }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) column_pass(j);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) row_pass(i, V);
+    gather(1);
+    __syncthreads();
     for (int c = 0; c < a.nchunks; ++c) {
-        __syncthreads();                                                 // every wave is done reading V of chunk c-1
-        transform_store();
-        __syncthreads();
+        const float* Vc = V + (c & 1) * VBUF;
+        float* Vn = V + ((c + 1) & 1) * VBUF;
         const float4* uc = ubase + ((size_t)(c * 16) * ncb + cb) * 2 * 64;
         const float4* un = ubase + ((size_t)((c + 1 < a.nchunks ? c + 1 : c) * 16) * ncb + cb) * 2 * 64;
-        gather(c + 1);                                                   // next chunk's windows (past the end: all out of range = 0, no traffic)
-        float4 bf = *reinterpret_cast<const float4*>(vrow);
+        // double step ds = (frequency pair p, k-quad kq): the two points' MFMAs alternate, so consecutive MFMAs never
+        // chain on the same accumulator
+        float4 bf0 = *reinterpret_cast<const float4*>(Vc + voff0);
+        float4 bf1 = *reinterpret_cast<const float4*>(Vc + 64 * 16 + voff0);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int s = 0; s < 32; ++s) {
-            const int x = s >> 1;
-            const float4 aw = af[s % WD];
-            const float4 bw = bf;
-            if (s + 1 < 32) bf = *reinterpret_cast<const float4*>(vrow + (size_t)((s + 1) >> 1) * 64 * LDV + ((s + 1) & 1) * 8);
-            acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.x, bw.x, acc[x], 0, 0, 0);
-            const int sn = s + WD;                                       // refill this slot (wraps into the next chunk)
-            af[s % WD] = sn < 32 ? uc[((size_t)(sn >> 1) * ncb * 2 + (sn & 1)) * 64]
-                                 : un[((size_t)((sn - 32) >> 1) * ncb * 2 + (sn & 1)) * 64];
-            acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.y, bw.y, acc[x], 0, 0, 0);
-            acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.z, bw.z, acc[x], 0, 0, 0);
-            acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.w, bw.w, acc[x], 0, 0, 0);
+        for (int ds = 0; ds < 16; ++ds) {
+            const int p2 = (ds >> 1) * 2, kq = ds & 1;
+            const int sa = p2 * 2 + kq, sb = sa + 2;                     // fragment slots (step = xi*2 + kq)
+            const float4 a0 = af[sa % WD], a1 = af[sb % WD];
+            const float4 b0 = bf0, b1 = bf1;
+            if (ds + 1 < 16) {
+                const int np2 = ((ds + 1) >> 1) * 2, nkq = (ds + 1) & 1;
+                bf0 = *reinterpret_cast<const float4*>(Vc + (size_t)np2 * 64 * 16 + (nkq ? voff1 : voff0));
+                bf1 = *reinterpret_cast<const float4*>(Vc + (size_t)(np2 + 1) * 64 * 16 + (nkq ? voff1 : voff0));
+            }
+            acc[p2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc[p2], 0, 0, 0);
+            acc[p2 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, acc[p2 + 1], 0, 0, 0);
+            if (!WINO_ABL_REFILL) {                                      // refill both slots (wraps into the next chunk)
+                const int na = sa + WD, nb = sb + WD;
+                af[sa % WD] = na < 32 ? uc[((size_t)(na >> 1) * ncb * 2 + (na & 1)) * 64] : un[((size_t)((na - 32) >> 1) * ncb * 2 + (na & 1)) * 64];
+                af[sb % WD] = nb < 32 ? uc[((size_t)(nb >> 1) * ncb * 2 + (nb & 1)) * 64] : un[((size_t)((nb - 32) >> 1) * ncb * 2 + (nb & 1)) * 64];
+            }
+            // the input transform of chunk c+1 rides in the shadow of the MFMAs (windows gathered one phase earlier;
+            // past the last chunk they are all out of range = 0, written to the idle buffer, never read)
+            if (ds < 2) { column_pass(2 * ds); column_pass(2 * ds + 1); }
+            else if (ds < 4) { row_pass(2 * (ds - 2), Vn); row_pass(2 * (ds - 2) + 1, Vn); }
+            if (!WINO_ABL_GATHER && ds >= 2 && ds < 10) {               // d is free once the column passes are done
+                if (ds == 2) gather_begin(c + 2);
+                gather_load(2 * (ds - 2)); gather_load(2 * (ds - 2) + 1);
+            }
+            acc[p2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc[p2], 0, 0, 0);
+            acc[p2 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, acc[p2 + 1], 0, 0, 0);
+            acc[p2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, acc[p2], 0, 0, 0);
+            acc[p2 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b1.z, acc[p2 + 1], 0, 0, 0);
+            acc[p2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, acc[p2], 0, 0, 0);
+            acc[p2 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, acc[p2 + 1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        __syncthreads();                                                 // V[c+1] complete, V[c] free for chunk c+2
     }
 
     // ---- epilogue: Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1]; acc row = cout (r&3)+8*(r>>2)+4*(lane>>5), col = tile lane&31

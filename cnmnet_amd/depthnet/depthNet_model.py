@@ -73,7 +73,7 @@ class _EngineNet(nn.Module):
             raise ValueError("precision must be 'f32' or 'f16'")
         self.precision = precision  # 'f16': fp16 storage + f16 MFMA (BASELINE config 5); eval only
         self._layers = None        # engine layer table (resolved lazily: needs the library)
-        self.winograd = os.environ.get("CNM_WINOGRAD", "1") != "0"   # fp32 3x3 stride-1 layers in the Winograd domain
+        self.winograd = os.environ.get("CNM_WINOGRAD", "1") != "0"   # fp32 stride-1 layers in the Winograd domain
         self._packed = None        # [(w, b[, u])] device tensors, one per engine layer
         self._packed_key = None
         self._weights_arr = None
@@ -108,8 +108,8 @@ class _EngineNet(nn.Module):
                 pack = ops.pack_conv_f16 if self.precision == "f16" else ops.pack_conv
                 bnp = (bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var)
                 wp, bp = pack(w, bnp, rot=L["rot"], eps=bn.eps)
-                # fp32 3x3 stride-1 layers run in the Winograd domain (cnm_conv3x3_winograd_c4_f32)
-                wino = (self.precision == "f32" and self.winograd and L["ksize"] == 3 and L["stride"] == 1 and L["Cout"] % 64 == 0)
+                # fp32 stride-1 layers run in the Winograd domain (3x3: F(2x2,3x3); 5x5 / 7x7: row-wise F(2,k))
+                wino = (self.precision == "f32" and self.winograd and L["ksize"] in (3, 5, 7) and L["stride"] == 1 and L["Cout"] % 64 == 0)
                 packed.append((wp, bp, ops.pack_winograd(w, bnp, rot=L["rot"], eps=bn.eps)) if wino else (wp, bp))
         arr = (_lib.LayerWeights * len(packed))()
         for i, t in enumerate(packed):
