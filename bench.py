@@ -10,7 +10,7 @@ resident in HBM.  N GPUs = N independent shards (weak scaling, no data-path coll
     python bench.py [--gpus N --steps K --warmup W]          # N>1: launched by torch.distributed.run
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline           dominant kernel (fp32-MFMA implicit-GEMM conv): achieved TFLOP/s vs 157.3 dense fp32 MFMA
+  roofline           dominant kernel (fp32-MFMA convolution: Winograd or implicit GEMM): executed TFLOP/s vs 157.3 dense fp32 MFMA
   roofline_planesweep  fused warp + cost-volume kernel: algorithmic GB/s vs 8 TB/s HBM
   cpu_baseline       the oracle's reference-arrangement torch-CPU graph on this box's host cores
 """
@@ -63,9 +63,22 @@ def conv_tile(cout, m):
     return "conv_mfma_f32_kernel<64, 64, 1, false>"
 
 
+def conv_kernel(L, m):
+    """Mirror of the fp32 executors' layer -> kernel choice (cnmnet_amd/csrc/nets.hip EngF32::conv) and the share of
+    the direct-convolution flops the kernel really executes on the matrix cores (Winograd executes fewer)."""
+    k, s = L["ksize"], L["stride"]
+    if s == 1 and k == 3:
+        return "conv3x3_winograd_f32_kernel", 16.0 / 36.0            # F(2x2,3x3): 16 multiplies per 4 outputs instead of 36
+    if s == 1 and k in (5, 7):
+        return "conv_rows_winograd_f32_kernel<%d>" % k, (k + 1) / (2.0 * k)   # F(2,k) along rows
+    return conv_tile(L["Cout"], m), 1.0
+
+
 def kernel_rooflines(dev, frames):
     """Per-kernel HIP-event timing of the dominant kernels at exactly the shapes of the timed
-    region: every conv layer of both nets (grouped by kernel instance) and the plane sweep."""
+    region: every conv layer of both nets (grouped by kernel instance) and the plane sweep.
+    `achieved` counts the flops the kernel EXECUTES on the matrix cores (what the MFMA roofline bounds);
+    `algorithmic` is the direct-convolution-equivalent rate (2*Cout*Cin*k*k per output pixel)."""
     from cnmnet_amd import _lib, ops, synthetic as syn
     per_kernel = {}
     for net, n_img, levels in ((_lib.NET_DEPTH, frames * SRC, DEPTH_LEVEL), (_lib.NET_REFINE, frames, REFINE_LEVEL)):
@@ -74,19 +87,32 @@ def kernel_rooflines(dev, frames):
             cin = 3 + PLANES if (net == _lib.NET_DEPTH and L["conv_key"] == "conv1.0") else L["Cin"]
             h, w = H >> lv, W >> lv
             x = torch.randn(n_img, (cin + 3) // 4, h, w, 4, device=dev)
-            wp, bp = ops.pack_conv(torch.randn(L["Cout"], cin, L["ksize"], L["ksize"], device=dev) * 0.02)
-            ms = event_ms(lambda: ops.conv2d_c4(x, wp, bp, L["Cout"], L["ksize"], L["stride"], True), iters=3, warm=1)
+            wt = torch.randn(L["Cout"], cin, L["ksize"], L["ksize"], device=dev) * 0.02
             ho, wo = h // L["stride"], w // L["stride"]
+            name, executed = conv_kernel(L, n_img * ho * wo)
+            wp, bp = ops.pack_conv(wt)
+            if name.startswith("conv3x3_winograd"):
+                up = ops.pack_winograd(wt)
+                fn = lambda: ops.conv3x3_winograd_c4(x, up, bp, L["Cout"], True)
+            elif name.startswith("conv_rows_winograd"):
+                up = ops.pack_winograd(wt)
+                fn = lambda: ops.conv_rows_winograd_c4(x, up, bp, L["Cout"], L["ksize"], True)
+            else:
+                fn = lambda: ops.conv2d_c4(x, wp, bp, L["Cout"], L["ksize"], L["stride"], True)
+            ms = event_ms(fn, iters=3, warm=1)
             flop = 2.0 * L["Cout"] * cin * L["ksize"] ** 2 * ho * wo * n_img
-            k = per_kernel.setdefault(conv_tile(L["Cout"], n_img * ho * wo), [0.0, 0.0, 0])
-            k[0] += flop; k[1] += ms; k[2] += 1
-            del x, wp, bp
-    name, (flop, ms, launches) = max(per_kernel.items(), key=lambda kv: kv[1][1])
-    conv = {"kernel": name, "bound": "mfma", "achieved": flop / ms / 1e9, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-            "frac": flop / ms / 1e9 / MFMA_F32_PEAK_TF, "traffic": None, "launches_per_step": launches,
-            "avg_launch_ms": ms / launches,
-            "all_conv": {"achieved": sum(v[0] for v in per_kernel.values()) / sum(v[1] for v in per_kernel.values()) / 1e9,
-                         "ms_per_step": sum(v[1] for v in per_kernel.values())}}
+            k = per_kernel.setdefault(name, [0.0, 0.0, 0, 0.0])
+            k[0] += flop; k[1] += ms; k[2] += 1; k[3] += flop * executed
+            del x, wt, wp, bp
+    name, (flop, ms, launches, exe) = max(per_kernel.items(), key=lambda kv: kv[1][1])
+    tot_ms = sum(v[1] for v in per_kernel.values())
+    conv = {"kernel": name, "bound": "mfma", "achieved": exe / ms / 1e9, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+            "frac": exe / ms / 1e9 / MFMA_F32_PEAK_TF, "traffic": None, "launches_per_step": launches,
+            "avg_launch_ms": ms / launches, "algorithmic": flop / ms / 1e9,
+            "note": "achieved = flops executed on the matrix cores; algorithmic = direct-convolution-equivalent rate",
+            "all_conv": {"achieved": sum(v[3] for v in per_kernel.values()) / tot_ms / 1e9,
+                         "algorithmic": sum(v[0] for v in per_kernel.values()) / tot_ms / 1e9, "ms_per_step": tot_ms,
+                         "per_kernel_ms": {k: round(v[1], 3) for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1][1])}}}
     img, cams = syn.frames(frames, SRC, H, W, seed=99)
     img, cams = torch.from_numpy(img).to(dev), torch.from_numpy(cams).to(dev)
     ref, src = img[:, 0].contiguous(), img[:, 1:].contiguous()

@@ -27,6 +27,10 @@
 #endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt -- here that would wait, at
+// every chunk, for the weight fragments and windows deliberately left in flight across the barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct WinoArgs {
@@ -122,19 +126,35 @@ __global__ __launch_bounds__(256, 1) void conv3x3_winograd_f32_kernel(const Wino
     const int voff0 = rrow * 16 + ((lane >> 5) ^ ((rrow >> 2) & 3)) * 4;      // kq = 0: slot (lane>>5)
     const int voff1 = rrow * 16 + ((2 + (lane >> 5)) ^ ((rrow >> 2) & 3)) * 4;  // kq = 1: slot 2 + (lane>>5)
 
-    constexpr int WD = 16;                                               // weight-fragment prefetch depth (steps of 4 MFMAs)
+    constexpr int WD = 16;                                               // weight fragments in flight (steps of 4 MFMAs): half a chunk
     float4 af[WD];
+    // VMEM issue schedule of double step ds in the phase of chunk c: refill the two fragment slots just consumed
+    // (they wrap into chunk c+1 from ds = 8 on), and from ds = 2 (column passes done, d free) two window loads of
+    // chunk c+2.  The prologue replays the SAME order as a phase "c = -1" without MFMAs, so the loads in flight at
+    // the loop head are ordered identically on both paths into the loop and the compiler's vmcnt counts are exact
+    // instead of a conservative minimum.
+    auto vmem_ds = [&](int ds, int c, const float4* uc, const float4* un) {
+        const int sa = (ds >> 1) * 4 + (ds & 1), sb = sa + 2;
+        const int na = sa + WD, nb = sb + WD;
+        if (!WINO_ABL_REFILL && (uc || na >= 32)) {
+            af[sa % WD] = na < 32 ? uc[((size_t)(na >> 1) * ncb * 2 + (na & 1)) * 64] : un[((size_t)((na - 32) >> 1) * ncb * 2 + (na & 1)) * 64];
+            af[sb % WD] = nb < 32 ? uc[((size_t)(nb >> 1) * ncb * 2 + (nb & 1)) * 64] : un[((size_t)((nb - 32) >> 1) * ncb * 2 + (nb & 1)) * 64];
+        }
+        if (!WINO_ABL_GATHER && ds >= 2 && ds < 10) {
+            if (ds == 2) gather_begin(c + 2);
+            gather_load(2 * (ds - 2)); gather_load(2 * (ds - 2) + 1);
+        }
+    };
     gather(0);
-    {
-        const float4* uc = ubase + ((size_t)0 * ncb + cb) * 2 * 64;
-#pragma unroll
-        for (int s = 0; s < WD; ++s) af[s] = uc[((size_t)(s >> 1) * ncb * 2 + (s & 1)) * 64];
-    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) column_pass(j);
 #pragma unroll
     for (int i = 0; i < 4; ++i) row_pass(i, V);
-    gather(1);
+    {
+        const float4* u0 = ubase + ((size_t)0 * ncb + cb) * 2 * 64;
+#pragma unroll
+        for (int ds = 0; ds < 16; ++ds) { vmem_ds(ds, -1, nullptr, u0); __builtin_amdgcn_sched_barrier(0); }   // first half of chunk 0's weights, windows of chunk 1
+    }
     __syncthreads();
     for (int c = 0; c < a.nchunks; ++c) {
         const float* Vc = V + (c & 1) * VBUF;
@@ -159,19 +179,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_winograd_f32_kernel(const Wino
             }
             acc[p2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc[p2], 0, 0, 0);
             acc[p2 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, acc[p2 + 1], 0, 0, 0);
-            if (!WINO_ABL_REFILL) {                                      // refill both slots (wraps into the next chunk)
-                const int na = sa + WD, nb = sb + WD;
-                af[sa % WD] = na < 32 ? uc[((size_t)(na >> 1) * ncb * 2 + (na & 1)) * 64] : un[((size_t)((na - 32) >> 1) * ncb * 2 + (na & 1)) * 64];
-                af[sb % WD] = nb < 32 ? uc[((size_t)(nb >> 1) * ncb * 2 + (nb & 1)) * 64] : un[((size_t)((nb - 32) >> 1) * ncb * 2 + (nb & 1)) * 64];
-            }
             // the input transform of chunk c+1 rides in the shadow of the MFMAs (windows gathered one phase earlier;
             // past the last chunk they are all out of range = 0, written to the idle buffer, never read)
             if (ds < 2) { column_pass(2 * ds); column_pass(2 * ds + 1); }
             else if (ds < 4) { row_pass(2 * (ds - 2), Vn); row_pass(2 * (ds - 2) + 1, Vn); }
-            if (!WINO_ABL_GATHER && ds >= 2 && ds < 10) {               // d is free once the column passes are done
-                if (ds == 2) gather_begin(c + 2);
-                gather_load(2 * (ds - 2)); gather_load(2 * (ds - 2) + 1);
-            }
+            vmem_ds(ds, c, uc, un);
             acc[p2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc[p2], 0, 0, 0);
             acc[p2 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, acc[p2 + 1], 0, 0, 0);
             acc[p2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, acc[p2], 0, 0, 0);
@@ -180,7 +192,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_winograd_f32_kernel(const Wino
             acc[p2 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, acc[p2 + 1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();                                                 // V[c+1] complete, V[c] free for chunk c+2
+        lds_barrier();                                                   // V[c+1] complete, V[c] free for chunk c+2
     }
 
     // ---- epilogue: Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1]; acc row = cout (r&3)+8*(r>>2)+4*(lane>>5), col = tile lane&31

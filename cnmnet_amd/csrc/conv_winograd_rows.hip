@@ -16,13 +16,32 @@
 // and the gather of chunk c+2 ride in the shadow of the MFMAs of chunk c; one barrier per chunk.
 #include "cnm_common.h"
 
+#ifndef ROWS_ABL
+#define ROWS_ABL 0   // ablation bit mask for timing studies (results are wrong when set): 1 no gather, 2 no weight refill, 4 no transform
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt -- here that would wait, at
+// every chunk, for the weight fragments and windows deliberately left in flight across the barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// float4 as two packed pairs: the arithmetic below compiles to v_pk_{add,mul,fma}_f32
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct __attribute__((aligned(16))) f4p { v2f lo, hi; };
+__device__ __forceinline__ f4p f4_add(f4p a, f4p b) { return {a.lo + b.lo, a.hi + b.hi}; }
+__device__ __forceinline__ f4p f4_sub(f4p a, f4p b) { return {a.lo - b.lo, a.hi - b.hi}; }
+__device__ __forceinline__ f4p f4_mul(float c, f4p a) { const v2f cc = {c, c}; return {cc * a.lo, cc * a.hi}; }
+__device__ __forceinline__ f4p f4_fma(float c, f4p a, f4p b) {
+    const v2f cc = {c, c};
+    return {__builtin_elementwise_fma(cc, a.lo, b.lo), __builtin_elementwise_fma(cc, a.hi, b.hi)};
+}
 
 template <int R> struct RowWino;
 // F(2,5), interpolation points 0, 1, -1, 2, -2, inf
 template <> struct RowWino<5> {
-    static constexpr float BT[6][6] = {{4, 0, -5, 0, 1, 0}, {0, -4, -4, 1, 1, 0}, {0, 4, -4, -1, 1, 0}, {0, -2, -1, 2, 1, 0}, {0, 2, -1, -2, 1, 0}, {0, 4, 0, -5, 0, 1}};
+    static constexpr float BT[6][6]  /* documentation: the kernel uses the factored form in transform_group */ = {{4, 0, -5, 0, 1, 0}, {0, -4, -4, 1, 1, 0}, {0, 4, -4, -1, 1, 0}, {0, -2, -1, 2, 1, 0}, {0, 2, -1, -2, 1, 0}, {0, 4, 0, -5, 0, 1}};
     static constexpr float AT1[6] = {0, 1, -1, 2, -2, 1};   // AT0 = {1, ..., 1, 0}
     static constexpr double G[6][5] = {{1. / 4, 0, 0, 0, 0}, {-1. / 6, -1. / 6, -1. / 6, -1. / 6, -1. / 6}, {-1. / 6, 1. / 6, -1. / 6, 1. / 6, -1. / 6}, {1. / 24, 1. / 12, 1. / 6, 1. / 3, 2. / 3}, {1. / 24, -1. / 12, 1. / 6, -1. / 3, 2. / 3}, {0, 0, 0, 0, 1}};
 };
@@ -99,23 +118,33 @@ __global__ __launch_bounds__(256, 1) void conv_rows_winograd_f32_kernel(const Ro
             for (int j = 0; j < NX; ++j) gather_load(it, j);
         }
     };
-    auto transform = [&](int it, int k0, int k1, float* Vdst) {          // V[k] = sum_j BT[k][j] d[j] for k in [k0, k1)
+    // V = BT d in NG = (R+1)/2 groups of two frequency points (even/odd factorisation of the +-p point pairs, packed
+    // fp32 math): group 0 = (V0, V_R) [points 0, inf], group i = (V_{2i-1}, V_{2i}) [points +p_i, -p_i].
+    constexpr int NG = NX / 2;
+    auto transform_group = [&](int it, int grp, float* Vdst) {
         const int wslot = ((qd0 + 2 * it) ^ ((tl >> 2) & 3)) * 4;
-#pragma unroll
-        for (int k = 0; k < NX; ++k) {
-            if (k < k0 || k >= k1) continue;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            bool first = true;
-#pragma unroll
-            for (int j = 0; j < NX; ++j) {
-                const float cf = WM::BT[k][j];
-                if (cf == 0.f) continue;
-                const float4 x = d[it][j];
-                if (first) { v = make_float4(cf * x.x, cf * x.y, cf * x.z, cf * x.w); first = false; }
-                else { v.x = fmaf(cf, x.x, v.x); v.y = fmaf(cf, x.y, v.y); v.z = fmaf(cf, x.z, v.z); v.w = fmaf(cf, x.w, v.w); }
+        const f4p* x = reinterpret_cast<const f4p*>(&d[it][0]);
+        f4p va, vb; int ka, kb;
+        if constexpr (R == 7) {
+            if (grp == 0) { va = f4_fma(5.25f, f4_sub(x[2], x[4]), f4_sub(x[6], x[0])); vb = f4_fma(5.25f, f4_sub(x[3], x[5]), f4_sub(x[7], x[1])); ka = 0; kb = 7; }
+            else {
+                f4p e, o;
+                if (grp == 1) { e = f4_fma(-4.25f, x[4], f4_add(x[2], x[6])); o = f4_fma(-4.25f, x[3], f4_add(x[1], x[5])); }
+                else if (grp == 2) { e = f4_fma(0.25f, x[2], f4_fma(-1.25f, x[4], x[6])); o = f4_fma(0.5f, x[1], f4_fma(-2.5f, x[3], f4_mul(2.f, x[5]))); }
+                else { e = f4_fma(4.f, x[2], f4_fma(-5.f, x[4], x[6])); o = f4_fma(2.f, x[1], f4_fma(-2.5f, x[3], f4_mul(0.5f, x[5]))); }
+                va = f4_add(e, o); vb = f4_sub(e, o); ka = 2 * grp - 1; kb = 2 * grp;
             }
-            *reinterpret_cast<float4*>(Vdst + ((size_t)k * TT + tl) * 16 + wslot) = v;
+        } else {
+            if (grp == 0) { va = f4_fma(4.f, x[0], f4_fma(-5.f, x[2], x[4])); vb = f4_fma(4.f, x[1], f4_fma(-5.f, x[3], x[5])); ka = 0; kb = 5; }
+            else {
+                f4p e, o;
+                if (grp == 1) { e = f4_fma(-4.f, x[2], x[4]); o = f4_fma(-4.f, x[1], x[3]); }
+                else { e = f4_sub(x[4], x[2]); o = f4_mul(2.f, f4_sub(x[3], x[1])); }
+                va = f4_add(e, o); vb = f4_sub(e, o); ka = 2 * grp - 1; kb = 2 * grp;
+            }
         }
+        *reinterpret_cast<f4p*>(Vdst + ((size_t)ka * TT + tl) * 16 + wslot) = va;
+        *reinterpret_cast<f4p*>(Vdst + ((size_t)kb * TT + tl) * 16 + wslot) = vb;
     };
 
     f32x16 acc[NX * 2];
@@ -132,15 +161,30 @@ __global__ __launch_bounds__(256, 1) void conv_rows_winograd_f32_kernel(const Ro
     const int voff1 = rrow * 16 + ((2 + (lane >> 5)) ^ ((lane >> 2) & 3)) * 4;
 
     float4 af[NSTEP];                                                    // one whole chunk of weight fragments in flight
-    gather();
+    // VMEM issue schedule of step s (weight fragment s of chunk `uchunk`, then two window loads of the item whose
+    // registers the transform has just released).  The prologue replays the SAME order without MFMAs, so the loads
+    // in flight at the loop head are ordered identically on both paths into the loop and the compiler's vmcnt
+    // counts are exact instead of a conservative minimum.
+    auto vmem_step = [&](int s, const float4* uchunk) {
+        if (!(ROWS_ABL & 2)) af[s] = uchunk[((size_t)(s >> 1) * ncb * 2 + (s & 1)) * 64];
+        if (!(ROWS_ABL & 1) && s >= NG && s < NG + NX) {
+            const int l0 = (s - NG) * 2;
+            if (l0 == 0) gather_begin(0);
+            if (l0 == NX) gather_begin(1);
+            gather_load(l0 / NX, l0 % NX);
+            gather_load((l0 + 1) / NX, (l0 + 1) % NX);
+        }
+    };
+    gather();                                                            // chunk 0
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int grp = 0; grp < NG; ++grp) transform_group(it, grp, V);
     {
         const float4* uc = ubase + ((size_t)0 * ncb + cb) * 2 * 64;
 #pragma unroll
-        for (int s = 0; s < NSTEP; ++s) af[s] = uc[((size_t)(s >> 1) * ncb * 2 + (s & 1)) * 64];
+        for (int s = 0; s < NSTEP; ++s) { vmem_step(s, uc); __builtin_amdgcn_sched_barrier(0); }   // weights of chunk 0, windows of chunk 1
     }
-    transform(0, 0, NX, V);
-    transform(1, 0, NX, V);
-    gather();
     __syncthreads();
     for (int c = 0; c < a.nchunks; ++c) {
         const float* Vc = V + (c & 1) * VBUF;
@@ -161,22 +205,11 @@ __global__ __launch_bounds__(256, 1) void conv_rows_winograd_f32_kernel(const Ro
             }
             acc[2 * x] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.x, b0.x, acc[2 * x], 0, 0, 0);
             acc[2 * x + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.x, b1.x, acc[2 * x + 1], 0, 0, 0);
-            af[s] = un[((size_t)x * ncb * 2 + (s & 1)) * 64];            // same slot of the next chunk
-            // input transform of chunk c+1 / gather of chunk c+2 in the shadow of the MFMAs (past the last chunk the
-            // windows are all out of range = 0 and land in the idle buffer)
-            if (s < 4) transform(s >> 1, (s & 1) ? NX / 2 : 0, (s & 1) ? NX : NX / 2, Vn);
-            {                                                            // item 0's windows from step 2 (d[0] consumed), item 1's after
-                constexpr int LPS = 2;                                   // loads per step
-                const int l0 = (s - 2) * LPS;
-                if (s >= 2 && l0 < 2 * NX) {
-#pragma unroll
-                    for (int l = l0; l < l0 + LPS && l < 2 * NX; ++l) {
-                        if (l == 0) gather_begin(0);
-                        if (l == NX) gather_begin(1);
-                        gather_load(l / NX, l % NX);
-                    }
-                }
-            }
+            // in the shadow of the MFMAs: one transform group of chunk c+1 per step (item 0 in steps [0, NG), item 1 in
+            // [NG, 2 NG)), then this step's loads: the same fragment slot of chunk c+1 and two windows of chunk c+2
+            // (past the last chunk the windows are all out of range = 0 and land in the idle buffer)
+            if (!(ROWS_ABL & 4) && s < 2 * NG) transform_group(s / NG, s % NG, Vn);
+            vmem_step(s, un);
             acc[2 * x] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.y, b0.y, acc[2 * x], 0, 0, 0);
             acc[2 * x + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.y, b1.y, acc[2 * x + 1], 0, 0, 0);
             acc[2 * x] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.z, b0.z, acc[2 * x], 0, 0, 0);
@@ -185,7 +218,7 @@ __global__ __launch_bounds__(256, 1) void conv_rows_winograd_f32_kernel(const Ro
             acc[2 * x + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.w, b1.w, acc[2 * x + 1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();                                                 // V[c+1] complete, V[c] free for chunk c+2
+        lds_barrier();                                                   // V[c+1] complete, V[c] free for chunk c+2
     }
 
     // ---- epilogue: y0 = sum_{k<NX-1} M_k, y1 = sum_k AT1[k] M_k; acc row = cout (r&3)+8*(r>>2)+4*(lane>>5), col = tile lane&31
