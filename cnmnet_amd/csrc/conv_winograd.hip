@@ -145,16 +145,17 @@ __global__ __launch_bounds__(256, 1) void conv3x3_winograd_f32_kernel(const Wino
             gather_load(2 * (ds - 2)); gather_load(2 * (ds - 2) + 1);
         }
     };
+    {                                                                    // prologue: everything that does not depend on LDS goes out first
+        const float4* u0 = ubase + ((size_t)0 * ncb + cb) * 2 * 64;
+#pragma unroll
+        for (int s = 0; s < WD; ++s) af[s] = u0[((size_t)(s >> 1) * ncb * 2 + (s & 1)) * 64];   // first half of chunk 0's weights
+    }
     gather(0);
 #pragma unroll
     for (int j = 0; j < 4; ++j) column_pass(j);
 #pragma unroll
     for (int i = 0; i < 4; ++i) row_pass(i, V);
-    {
-        const float4* u0 = ubase + ((size_t)0 * ncb + cb) * 2 * 64;
-#pragma unroll
-        for (int ds = 0; ds < 16; ++ds) { vmem_ds(ds, -1, nullptr, u0); __builtin_amdgcn_sched_barrier(0); }   // first half of chunk 0's weights, windows of chunk 1
-    }
+    gather(1);
     __syncthreads();
     for (int c = 0; c < a.nchunks; ++c) {
         const float* Vc = V + (c & 1) * VBUF;

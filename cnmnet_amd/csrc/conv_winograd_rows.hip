@@ -175,16 +175,17 @@ __global__ __launch_bounds__(256, 1) void conv_rows_winograd_f32_kernel(const Ro
             gather_load((l0 + 1) / NX, (l0 + 1) % NX);
         }
     };
+    {                                                                    // prologue: everything that does not depend on LDS goes out first
+        const float4* u0 = ubase + ((size_t)0 * ncb + cb) * 2 * 64;
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) af[s] = u0[((size_t)(s >> 1) * ncb * 2 + (s & 1)) * 64];   // weights of chunk 0
+    }
     gather();                                                            // chunk 0
 #pragma unroll
     for (int it = 0; it < 2; ++it)
 #pragma unroll
         for (int grp = 0; grp < NG; ++grp) transform_group(it, grp, V);
-    {
-        const float4* uc = ubase + ((size_t)0 * ncb + cb) * 2 * 64;
-#pragma unroll
-        for (int s = 0; s < NSTEP; ++s) { vmem_step(s, uc); __builtin_amdgcn_sched_barrier(0); }   // weights of chunk 0, windows of chunk 1
-    }
+    gather();                                                            // chunk 1
     __syncthreads();
     for (int c = 0; c < a.nchunks; ++c) {
         const float* Vc = V + (c & 1) * VBUF;
