@@ -62,21 +62,27 @@ extern "C" int cnm_pack_head_f32(const float* w_oihw, int C, float* w_head, void
     return CNM_OK;
 }
 
-// One lane per output pixel; consecutive lanes = consecutive x, so every float4 tap load
-// is coalesced across the wave; the 9*C weights are wave-uniform (scalar loads).
+// Workgroup = 64 consecutive output pixels x 4 channel slices (one wave per slice): consecutive lanes =
+// consecutive x, so every float4 tap load is coalesced across the wave; the 9*C weights of a slice are
+// wave-uniform (scalar loads); the four partial sums meet in LDS in a fixed order.  (One lane per pixel over all
+// channels left the low-resolution heads with a few dozen workgroups and a 4608-tap serial loop.)
 __global__ __launch_bounds__(256) void head_sigmoid_c4_kernel(const float* __restrict__ in, int Gin_tot, int gin0, int G,
                                                               const float* __restrict__ wh, const float* __restrict__ bias,
                                                               float scale, float* __restrict__ disp,
                                                               float* __restrict__ up_out, int up_Gtot, int up_g,
                                                               int N, int H, int W) {
+    __shared__ float part[4][64];
     const int HW = H * W;
     const long long total = (long long)N * HW;
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int n = (int)(idx / HW), pix = (int)(idx - (long long)n * HW);
+    const int lane = threadIdx.x & 63, slice = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long idx = (long long)blockIdx.x * 64 + lane;
+    const bool live = idx < total;
+    const long long ii = live ? idx : 0;
+    const int n = (int)(ii / HW), pix = (int)(ii - (long long)n * HW);
     const int y = pix / W, x = pix - y * W;
+    const int gper = (G + 3) / 4, gbeg = slice * gper, gend = min(G, gbeg + gper);
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-    for (int g = 0; g < G; ++g) {
+    for (int g = gbeg; g < gend; ++g) {
         const float4* base = reinterpret_cast<const float4*>(in + c4_offset(n, Gin_tot, gin0 + g, HW, 0));
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
@@ -85,14 +91,17 @@ __global__ __launch_bounds__(256) void head_sigmoid_c4_kernel(const float* __res
             for (int kx = 0; kx < 3; ++kx) {
                 const int ix = x + kx - 1;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = base[iy * W + ix];
+                if (live && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = base[iy * W + ix];
                 const float4 w = *reinterpret_cast<const float4*>(wh + (size_t)(ky * 3 + kx) * (G * 4) + g * 4);
                 acc0 = fmaf(v.x, w.x, acc0); acc1 = fmaf(v.y, w.y, acc1);
                 acc2 = fmaf(v.z, w.z, acc2); acc3 = fmaf(v.w, w.w, acc3);
             }
         }
     }
-    const float s = (acc0 + acc1) + (acc2 + acc3) + bias[0];
+    part[slice][lane] = (acc0 + acc1) + (acc2 + acc3);
+    __syncthreads();
+    if (slice != 0 || !live) return;
+    const float s = ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) + bias[0];
     const float d = scale / (1.f + expf(-s));
     disp[idx] = d;
     if (up_out) {
@@ -112,7 +121,7 @@ extern "C" int cnm_head_sigmoid_c4_f32(const float* in, int Gin_total, int gin0,
     CNM_REQUIRE(gin0 >= 0 && gin0 + C / 4 <= Gin_total, CNM_ERR_BAD_ARG);
     CNM_REQUIRE(!up_out || (up_g >= 0 && up_g < up_Gtotal), CNM_ERR_BAD_ARG);
     const long long total = (long long)N * H * W;
-    head_sigmoid_c4_kernel<<<(unsigned)cnm_ceil_div_ll(total, 256), 256, 0, cnm_stream(stream)>>>(
+    head_sigmoid_c4_kernel<<<(unsigned)cnm_ceil_div_ll(total, 64), 256, 0, cnm_stream(stream)>>>(
         in, Gin_total, gin0, C / 4, w_head, bias, scale, disp, up_out, up_Gtotal, up_g, N, H, W);
     CNM_LAUNCH_CHECK();
     return CNM_OK;
