@@ -14,6 +14,21 @@ def _s():
     return torch.cuda.current_stream().cuda_stream
 
 
+WINOGRAD = True     # stride-1 3x3 / 5x5 / 7x7 convolutions (forward and data gradient) through the Winograd kernels
+
+
+def _winograd_ok(k, stride, cout):
+    return WINOGRAD and stride == 1 and k in (3, 5, 7) and cout % 64 == 0
+
+
+def _winograd_conv(x, weight, rot):
+    Cout, _, k, _ = weight.shape
+    up = ops.pack_winograd(weight, None, rot)
+    if k == 3:
+        return ops.conv3x3_winograd_c4(x, up, None, Cout, relu=False)
+    return ops.conv_rows_winograd_c4(x, up, None, Cout, k, relu=False)
+
+
 class ConvC4(torch.autograd.Function):
     """y = conv2d(x, weight, stride, padding=(k-1)//2) on c4 tensors, no bias.
     x [N,ceil(Cin/4),H,W,4] (channels possibly rotated by `rot`), weight OIHW; Cout % 4 == 0, >= 16."""
@@ -22,8 +37,11 @@ class ConvC4(torch.autograd.Function):
     def forward(ctx, x, weight, stride, rot):
         x = x.contiguous()
         Cout, Cin, k, _ = weight.shape
-        wp, _ = ops.pack_conv(weight.detach(), None, None, rot)
-        y = ops.conv2d_c4(x, wp, None, Cout, k, stride, relu=False)
+        if _winograd_ok(k, stride, Cout):
+            y = _winograd_conv(x, weight.detach(), rot)
+        else:
+            wp, _ = ops.pack_conv(weight.detach(), None, None, rot)
+            y = ops.conv2d_c4(x, wp, None, Cout, k, stride, relu=False)
         ctx.save_for_backward(x, weight)
         ctx.stride, ctx.rot = stride, rot
         return y
@@ -37,7 +55,10 @@ class ConvC4(torch.autograd.Function):
         lib, dev = _lib.load(), x.device
         dx = dw = None
         with torch.cuda.device(dev):
-            if ctx.needs_input_grad[0]:
+            if ctx.needs_input_grad[0] and ctx.rot == 0 and _winograd_ok(k, ctx.stride, Cin):
+                # stride 1: dx = conv(dy, w') with w'[ci][co] = w[co][ci] rotated by 180 degrees -- the same Winograd kernels
+                dx = _winograd_conv(dy, weight.detach().flip(2, 3).transpose(0, 1).contiguous(), 0)
+            elif ctx.needs_input_grad[0]:
                 wd = torch.empty(lib.cnm_packed_dgrad_floats(Cout, Cin, k), device=dev, dtype=torch.float32)
                 _lib.check(lib.cnm_pack_conv_dgrad_f32(weight.detach().contiguous().data_ptr(), Cout, Cin, k, ctx.rot, wd.data_ptr(), _s()))
                 dx = torch.empty_like(x)
