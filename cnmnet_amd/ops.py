@@ -70,13 +70,14 @@ def plane_sweep_volume(left, right, left_cam, right_cam, idepth_scale=3.0, plane
     return vol
 
 
-def plane_sweep_cat_c4(ref, src, hmkt, idepth_scale=3.0, planes=64, ws=None):
+def plane_sweep_cat_c4(ref, src, hmkt, idepth_scale=3.0, planes=64, ws=None, out=None):
     """ref [B,3,H,W], src [B,S,3,H,W], hmkt [B*S,12] -> c4 conv input [B*S, planes/4+1, H, W, 4]."""
-    _dev(ref, src, hmkt)
+    _dev(ref, src, hmkt, out)
     lo, hi = idepth_range(idepth_scale)
     ref, src = _c(ref), _c(src)
     B, S, _, H, W = src.shape
-    x = torch.empty(B * S, planes // 4 + 1, H, W, 4, device=ref.device, dtype=torch.float32)
+    x = out if out is not None else torch.empty(B * S, planes // 4 + 1, H, W, 4, device=ref.device, dtype=torch.float32)
+    assert x.shape == (B * S, planes // 4 + 1, H, W, 4) and x.is_contiguous()
     lib = _lib.load()
     if ws is None:
         ws = torch.empty(lib.cnm_planesweep_workspace_floats(B, S, H, W), device=ref.device, dtype=torch.float32)
