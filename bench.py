@@ -63,6 +63,21 @@ def conv_tile(cout, m):
     return "conv_mfma_f32_kernel<64, 64, 1, false>"
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC pass (profiles/r1_pmc_traffic.json: rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate runs of this script, gfx950 read correction applied).  Counters cannot be
+    collected from inside the timed process, so this is the number of the last profiled build, or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
+            table = json.load(f)["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None
+    for name, v in table.items():
+        if name.replace("void ", "").startswith(kernel):
+            return v["fetch_bytes_corrected"] + v["write_bytes"]
+    return None
+
+
 def conv_kernel(L, m):
     """Mirror of the fp32 executors' layer -> kernel choice (cnmnet_amd/csrc/nets.hip EngF32::conv) and the share of
     the direct-convolution flops the kernel really executes on the matrix cores (Winograd executes fewer)."""
@@ -107,7 +122,8 @@ def kernel_rooflines(dev, frames):
     name, (flop, ms, launches, exe) = max(per_kernel.items(), key=lambda kv: kv[1][1])
     tot_ms = sum(v[1] for v in per_kernel.values())
     conv = {"kernel": name, "bound": "mfma", "achieved": exe / ms / 1e9, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-            "frac": exe / ms / 1e9 / MFMA_F32_PEAK_TF, "traffic": None, "launches_per_step": launches,
+            "frac": exe / ms / 1e9 / MFMA_F32_PEAK_TF, "traffic": pmc_traffic(name),
+            "traffic_note": "HBM bytes per average launch, PMC pass committed under profiles/ (not live)", "launches_per_step": launches,
             "avg_launch_ms": ms / launches, "algorithmic": flop / ms / 1e9,
             "note": "achieved = flops executed on the matrix cores; algorithmic = direct-convolution-equivalent rate",
             "all_conv": {"achieved": sum(v[3] for v in per_kernel.values()) / tot_ms / 1e9,
@@ -132,7 +148,7 @@ def kernel_rooflines(dev, frames):
     pairs = frames * SRC
     byts = frames * 3 * H * W * 4 + pairs * 3 * H * W * 4 + pairs * (PLANES + 3) * H * W * 4
     sweep = {"kernel": "planesweep_kernel<1>", "bound": "hbm", "achieved": byts / ms / 1e6, "peak": HBM_PEAK_GBS,
-             "unit": "GB/s", "frac": byts / ms / 1e6 / HBM_PEAK_GBS, "traffic": None,
+             "unit": "GB/s", "frac": byts / ms / 1e6 / HBM_PEAK_GBS, "traffic": pmc_traffic("planesweep_kernel<1>"),
              "algorithmic_bytes_per_launch": byts, "avg_launch_ms": ms,
              "note": "avg_launch_ms = sweep_texture_kernel (pre-pass) + planesweep_kernel, timed as HIP-graph replays"}
     return conv, sweep
