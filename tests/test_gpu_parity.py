@@ -286,6 +286,25 @@ def test_depthnet_other_plane_counts_vs_oracle(dev, planes, S):
             assert _stats(ops.c4_to_nchw(feat[s::S].contiguous()).cpu().numpy(), f.numpy())[2] < 1e-4 * float(f.abs().max())
 
 
+def test_config4_full_size_properties(dev):
+    """BASELINE config 4 shape (640x480, 96 planes, 1 ref + 4 src) -- too large for the CPU oracle, so size-independent
+    properties: duplicated sources (s0,s1,s0,s1) give bit-for-bit the S=2 result of (s0,s1) (the fusion averages equal
+    things), outputs are finite, inverse depth stays inside (0, idepth_scale), normals are unit vectors (or zero).
+    H/32 = 15 is odd: the Winograd kernels' half-outside last tile row is exercised."""
+    from cnmnet_amd.depthnet import depthNet, DepthRefineNet
+    from cnmnet_amd.pipeline import FramePipeline
+    img, cams = syn.frames(1, 2, 480, 640, seed=7)
+    img, cams = T(img).to(dev), T(cams).to(dev)
+    pipe = FramePipeline(_load(depthNet(3.0, 96), 3).to(dev), _load(DepthRefineNet(32, 3.0), 4).to(dev), k_size=9)
+    a = pipe(torch.cat((img, img[:, 1:]), 1), torch.cat((cams, cams[:, 1:]), 1))
+    b = pipe(img, cams)
+    assert torch.equal(a["disp"], b["disp"]) and torch.equal(a["normal"], b["normal"])
+    assert torch.isfinite(b["disp"]).all() and torch.isfinite(b["normal"]).all()
+    assert float(b["disp"].min()) > 0 and float(b["disp"].max()) < 3.0
+    n = b["normal"].norm(dim=1)                                         # unit vectors (degenerate windows give the zero vector, as in the reference)
+    assert bool((((n - 1).abs() < 1e-4) | (n < 1e-6)).all())
+
+
 @pytest.mark.parametrize("S", [4, 6])
 def test_multi_source_frame_vs_oracle(dev, S):
     """a-8: 4- and 6-source fusion (eval.py:635-663, :885-929) through the frame pipeline."""
