@@ -23,7 +23,7 @@
 #include "cnm_common.h"
 
 #ifndef WINO_ABL
-#define WINO_ABL 0   // ablation bit mask for timing studies (results are wrong when set): 1 no gather, 2 no weight refill, 4 no transform
+#define WINO_ABL 0   // ablation bit mask for timing studies (results are wrong when set): 1 no gather, 2 no weight refill, 4 no transform, 8 windows from one cache line, 16 weights from one fragment
 #endif
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt -- here that would wait, at
@@ -43,11 +43,6 @@ struct WinoArgs {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ float2 wino_load2(const float* base, unsigned bytes, unsigned voff) {
-    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes, 0x00020000);
-    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, 0, 0);
-    return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
-}
 #define F2OP(r, a, op, b) do { (r).x = (a).x op (b).x; (r).y = (a).y op (b).y; } while (0)
 
 __global__ __launch_bounds__(256, 2) void conv3x3_winograd_f32_kernel(const WinoArgs a) {
@@ -63,22 +58,43 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd_f32_kernel(const Wino
     const int tl = t & 31, hh = (t >> 5) & 1, qd = wave;
     const int tg = t0 + tl;
     const bool tvalid = tg < a.T;
-    int img, py, px;
-    { const int tt = tvalid ? tg : 0; img = tt / THW; const int rem = tt - img * THW; const int ty = rem / a.TW; py = 2 * ty - 1; px = 2 * (rem - ty * a.TW) - 1; }
+    // Window offsets are loop-invariant per thread: off[ij] = byte offset of window pixel (i, j) in the first input view
+    // (image term included), 0xFFFFFFFF outside the image / past the last tile (buffer loads return 0 there).  Per
+    // chunk only SCALAR state changes: the channel-group offset (the load's soffset), the view (buffer resource) and a
+    // zero-length resource for the ragged channel tail -- no vector instruction per load (VALU time is MFMA time).
+    unsigned off[16];
+    unsigned imgdelta;                                                   // image term of view 2 minus view 1
+    {
+        const int tt = tvalid ? tg : 0; const int img = tt / THW; const int rem = tt - img * THW; const int ty = rem / a.TW;
+        const int py = 2 * ty - 1, px = 2 * (rem - ty * a.TW) - 1;
+        const unsigned imgterm = (unsigned)img * (unsigned)a.Gin_tot * (unsigned)HW * 16u;
+        imgdelta = (unsigned)img * (unsigned)a.Gin2_tot * (unsigned)HW * 16u - imgterm;
+#pragma unroll
+        for (int ij = 0; ij < 16; ++ij) {
+            const int iy = py + (ij >> 2), ix = px + (ij & 3);
+            const bool ok = tvalid & ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)a.W);
+            off[ij] = ok ? imgterm + (unsigned)(iy * a.W + ix) * 16u + hh * 8u : 0xFFFFFFFFu;
+        }
+    }
     float2 d[16];
-    const float* gbase; unsigned gbytes, gofs; bool gok;
+    bool view2 = false;                                                  // wave-uniform: off[] already rebased to the second view
+    __amdgpu_buffer_rsrc_t grsrc; unsigned gsoff;
     auto gather_begin = [&](int chunk) {
-        const int g = chunk * 4 + qd;
+        const int g = chunk * 4 + qd;                                   // channel group of the (possibly concatenated) input
         const bool s1 = g < a.Gsplit;
-        gbase = s1 ? a.in : a.in2;
-        gbytes = s1 ? a.in_bytes : a.in2_bytes;
-        gofs = s1 ? (unsigned)((img * a.Gin_tot + a.gin0 + g) * HW) : (unsigned)((img * a.Gin2_tot + a.gin2_0 + g - a.Gsplit) * HW);
-        gok = tvalid & (g < a.Gin);
+        if (!s1 && !view2) {                                            // once per wave, when its quad crosses into the second view
+            view2 = true;
+#pragma unroll
+            for (int ij = 0; ij < 16; ++ij) off[ij] = off[ij] == 0xFFFFFFFFu ? off[ij] : off[ij] + imgdelta;
+        }
+        const unsigned bytes = g < a.Gin ? (s1 ? a.in_bytes : a.in2_bytes) : 0u;
+        grsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s1 ? a.in : a.in2), 0, bytes, 0x00020000);
+        gsoff = (unsigned)(s1 ? a.gin0 + g : a.gin2_0 + g - a.Gsplit) * (unsigned)HW * 16u;
     };
     auto gather_load = [&](int ij) {
-        const int iy = py + (ij >> 2), ix = px + (ij & 3);
-        const bool ok = gok & ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)a.W);
-        d[ij] = wino_load2(gbase, gbytes, ok ? (gofs + (unsigned)(iy * a.W + ix)) * 16u + hh * 8u : 0xFFFFFFFFu);
+        const u32x2 v = (WINO_ABL & 8) ? __builtin_amdgcn_raw_buffer_load_b64(grsrc, (unsigned)(t & 63) * 8u, 0, 0)   // same loads, L1-resident footprint
+                                       : __builtin_amdgcn_raw_buffer_load_b64(grsrc, off[ij], gsoff, 0);
+        d[ij] = make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
     };
     float2 m[16];
     const int wofs = tl * 16 + (qd ^ ((tl >> 2) & 3)) * 4 + hh * 2;
@@ -149,7 +165,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd_f32_kernel(const Wino
             }
             acc[x][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw.x, b0.x, acc[x][0], 0, 0, 0);
             acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw.x, b1.x, acc[x][1], 0, 0, 0);
-            if (!(WINO_ABL & 2)) af[x % WD] = x + WD < 16 ? uc[(size_t)(x + WD) * 64] : un[(size_t)(x + WD - 16) * 64];
+            if (WINO_ABL & 16) af[x % WD] = ubase[0];                    // same loads, one L1-resident fragment
+            else if (!(WINO_ABL & 2)) af[x % WD] = x + WD < 16 ? uc[(size_t)(x + WD) * 64] : un[(size_t)(x + WD - 16) * 64];
             if (!(WINO_ABL & 4)) {
                 if (x < 2) { column_pass(2 * x); column_pass(2 * x + 1); }
                 else if (x < 4) { row_pass(2 * (x - 2), Vn); row_pass(2 * (x - 2) + 1, Vn); }
