@@ -8,19 +8,20 @@
 //   and accumulation; Toom-Cook points {0,+-1,+-2,+-1/2,inf} (R=7), {0,+-1,+-2,inf} (R=5), tables from
 //   tools/wino1d_matrices.py (exact in rationals; measured fp32 error ~4e-6 of the output scale).
 //
-// Same machine as conv_winograd.hip: workgroup = 4 waves = 64 couts x 128 row-tiles, every wave 32 couts x 64 tiles
-// for ALL R+1 frequency points (<= 256 accumulator registers, one wave per SIMD); per 16-deep chunk of the
-// (ky, ci) reduction every thread gathers the R+1 pixel windows of TWO (tile, channel-quad) items with buffer loads
-// (out of range = 0), transforms them in registers and writes V[xi][tile][k] to LDS (double buffered, swizzled);
-// weight fragments come straight from L2 in MFMA operand order, one whole chunk ahead; the transform of chunk c+1
-// and the gather of chunk c+2 ride in the shadow of the MFMAs of chunk c; one barrier per chunk.
+// Same machine as conv_winograd.hip: workgroup = 4 waves = 64 couts x 64 row-tiles, TWO workgroups per CU; every wave
+// 16 couts x 64 tiles for ALL R+1 frequency points on v_mfma_f32_16x16x4_f32 (128 / 96 accumulator registers); per
+// 16-deep chunk of the (ky, ci) reduction every thread gathers the R+1 pixel window of ONE (tile, channel-quad) with
+// buffer loads (out of range = 0), transforms it in registers and writes V[xi][tile][k] to LDS (double buffered,
+// swizzled); per frequency point one 16-byte weight fragment straight from L2 (MFMA operand order, private to the
+// wave, one whole chunk ahead) and four ds_read_b128 of V feed 16 MFMAs; the transform of chunk c+1 and the gather of
+// chunk c+2 ride between the MFMAs of chunk c; one LDS-only barrier per chunk.
 #include "cnm_common.h"
 
 #ifndef ROWS_ABL
 #define ROWS_ABL 0   // ablation bit mask for timing studies (results are wrong when set): 1 no gather, 2 no weight refill, 4 no transform
 #endif
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt -- here that would wait, at
 // every chunk, for the weight fragments and windows deliberately left in flight across the barrier.
@@ -61,69 +62,52 @@ struct RowArgs {
     int nchunks, T, relu;                // T = N*H*TW tiles
 };
 
-__device__ __forceinline__ float4 rw_load(const float* base, unsigned bytes, unsigned voff) {
-    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes, 0x00020000);
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
-    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
-
 template <int R>
-__global__ __launch_bounds__(256, 1) void conv_rows_winograd_f32_kernel(const RowArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_rows_winograd_f32_kernel(const RowArgs a) {
     using WM = RowWino<R>;
-    constexpr int NX = R + 1, TT = 128, NSTEP = NX * 2;
+    constexpr int NX = R + 1, TT = 64, NG = NX / 2;
     constexpr int VBUF = NX * TT * 16;                                   // V[buf][xi][tile][16 k], slots XOR-swizzled with ((tile >> 2) & 3)
-    __shared__ __attribute__((aligned(16))) float V[2 * VBUF];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wc = wave >> 1, wt = wave & 1;
+    __shared__ __attribute__((aligned(16))) float V[2 * VBUF];           // 64 KB (R = 7) / 48 KB (R = 5)
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int tilesC = a.Cout / 64;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int cblk = tile % tilesC, t0 = (tile / tilesC) * TT;
     const int HW = a.H * a.W, THW = a.H * a.TW;
 
-    // ---- loader: thread = tile tl, channel quads qd0 and qd0 + 2 of the chunk
-    const int tl = t & 127, qd0 = __builtin_amdgcn_readfirstlane(t >> 7);
+    // ---- loader: thread = (tile tl, channel quad qd = wave of the chunk)
+    const int tl = lane, qd = wave;
     const int tg = t0 + tl;
     const bool tvalid = tg < a.T;
     int img, py, px;
     { const int tt = tvalid ? tg : 0; img = tt / THW; const int rem = tt - img * THW; py = rem / a.TW; px = 2 * (rem - py * a.TW) - R / 2; }
-    float4 d[2][NX];
-    int ky[2], gq[2];                                                    // (kernel row, channel group) of the next chunk's two quads
+    // per-thread invariants of the window loads: x offset and x validity of the R+1 pixels; per chunk the (kernel row,
+    // channel group) pair is wave-uniform, only the row validity is per lane: two vector instructions per load
+    unsigned xoff[NX]; bool xok[NX];
 #pragma unroll
-    for (int it = 0; it < 2; ++it) { const int q = qd0 + 2 * it; ky[it] = q / a.Gin; gq[it] = q - ky[it] * a.Gin; }
-    // window loads of the next chunk in sequence, issuable one at a time (spread over the MFMA steps: a burst of
-    // 16 would hold all four waves at the texture addresser while the matrix pipe drains)
-    const float* gbase[2]; unsigned gbytes[2], gofs[2]; bool gok[2];
-    auto gather_begin = [&](int it) {
-        const int g = gq[it];
+    for (int j = 0; j < NX; ++j) { const int ix = px + j; xok[j] = tvalid & ((unsigned)ix < (unsigned)a.W); xoff[j] = (unsigned)ix * 16u; }
+    float4 d[NX];
+    int ky = qd / a.Gin, gq = qd - ky * a.Gin;                           // (kernel row, channel group) of the next chunk to gather
+    __amdgpu_buffer_rsrc_t grsrc; unsigned gbase; bool gok;
+    auto gather_begin = [&]() {
+        const int g = gq;
         const bool s1 = g < a.Gsplit;
-        gbase[it] = s1 ? a.in : a.in2;
-        gbytes[it] = s1 ? a.in_bytes : a.in2_bytes;
-        const int iy = py + ky[it] - R / 2;
-        gofs[it] = (s1 ? (unsigned)((img * a.Gin_tot + a.gin0 + g) * HW) : (unsigned)((img * a.Gin2_tot + a.gin2_0 + g - a.Gsplit) * HW)) + (unsigned)(iy * a.W);
-        gok[it] = tvalid & (ky[it] < R) & ((unsigned)iy < (unsigned)a.H);
-        gq[it] += 4;                                                     // advance to the following chunk's quad
+        grsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s1 ? a.in : a.in2), 0, s1 ? a.in_bytes : a.in2_bytes, 0x00020000);
+        const int iy = py + ky - R / 2;
+        gbase = ((s1 ? (unsigned)((img * a.Gin_tot + a.gin0 + g) * HW) : (unsigned)((img * a.Gin2_tot + a.gin2_0 + g - a.Gsplit) * HW)) + (unsigned)(iy * a.W)) * 16u;
+        gok = (ky < R) & ((unsigned)iy < (unsigned)a.H);
+        gq += 4;                                                         // advance to the following chunk's quad
 #pragma unroll
-        for (int w = 0; w < 4; ++w) { const bool wrap = gq[it] >= a.Gin; gq[it] -= wrap ? a.Gin : 0; ky[it] += wrap; }   // Gin >= 1: at most 4 wraps
+        for (int w = 0; w < 4; ++w) { const bool wrap = gq >= a.Gin; gq -= wrap ? a.Gin : 0; ky += wrap; }   // Gin >= 1: at most 4 wraps
     };
-    auto gather_load = [&](int it, int j) {
-        const int ix = px + j;
-        const bool ok = gok[it] & ((unsigned)ix < (unsigned)a.W);
-        d[it][j] = rw_load(gbase[it], gbytes[it], ok ? (gofs[it] + (unsigned)ix) * 16u : 0xFFFFFFFFu);
+    auto gather_load = [&](int j) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(grsrc, (gok & xok[j]) ? gbase + xoff[j] : 0xFFFFFFFFu, 0, 0);
+        d[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
     };
-    auto gather = [&]() {
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            gather_begin(it);
-#pragma unroll
-            for (int j = 0; j < NX; ++j) gather_load(it, j);
-        }
-    };
-    // V = BT d in NG = (R+1)/2 groups of two frequency points (even/odd factorisation of the +-p point pairs, packed
-    // fp32 math): group 0 = (V0, V_R) [points 0, inf], group i = (V_{2i-1}, V_{2i}) [points +p_i, -p_i].
-    constexpr int NG = NX / 2;
-    auto transform_group = [&](int it, int grp, float* Vdst) {
-        const int wslot = ((qd0 + 2 * it) ^ ((tl >> 2) & 3)) * 4;
-        const f4p* x = reinterpret_cast<const f4p*>(&d[it][0]);
+    // V = BT d in NG = (R+1)/2 groups of two frequency points (even/odd factorisation of the +-p point pairs):
+    // group 0 = (V0, V_R) [points 0, inf], group i = (V_{2i-1}, V_{2i}) [points +p_i, -p_i].
+    const int wofs = tl * 16 + (qd ^ ((tl >> 2) & 3)) * 4;
+    auto transform_group = [&](int grp, float* Vdst) {
+        const f4p* x = reinterpret_cast<const f4p*>(&d[0]);
         f4p va, vb; int ka, kb;
         if constexpr (R == 7) {
             if (grp == 0) { va = f4_fma(5.25f, f4_sub(x[2], x[4]), f4_sub(x[6], x[0])); vb = f4_fma(5.25f, f4_sub(x[3], x[5]), f4_sub(x[7], x[1])); ka = 0; kb = 7; }
@@ -143,139 +127,122 @@ __global__ __launch_bounds__(256, 1) void conv_rows_winograd_f32_kernel(const Ro
                 va = f4_add(e, o); vb = f4_sub(e, o); ka = 2 * grp - 1; kb = 2 * grp;
             }
         }
-        *reinterpret_cast<f4p*>(Vdst + ((size_t)ka * TT + tl) * 16 + wslot) = va;
-        *reinterpret_cast<f4p*>(Vdst + ((size_t)kb * TT + tl) * 16 + wslot) = vb;
+        *reinterpret_cast<f4p*>(Vdst + (size_t)ka * TT * 16 + wofs) = va;
+        *reinterpret_cast<f4p*>(Vdst + (size_t)kb * TT * 16 + wofs) = vb;
     };
 
-    f32x16 acc[NX * 2];
+    f32x4 acc[NX][4];
 #pragma unroll
-    for (int x = 0; x < NX * 2; ++x)
+    for (int x = 0; x < NX; ++x)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+        for (int b = 0; b < 4; ++b) acc[x][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // weights in MFMA operand order: [chunk][xi][cout block of 32][kq][lane][4]
-    const int cb = cblk * 2 + wc, ncb = a.Cout / 32;
-    const float4* ubase = reinterpret_cast<const float4*>(a.u) + lane;
-    const int rrow = wt * 64 + (lane & 31);                              // + 32 for the second tile block (same swizzle: 32 % 16 == 0)
-    const int voff0 = rrow * 16 + ((lane >> 5) ^ ((lane >> 2) & 3)) * 4;
-    const int voff1 = rrow * 16 + ((2 + (lane >> 5)) ^ ((lane >> 2) & 3)) * 4;
+    // weights in MFMA operand order: [chunk][cout/16][xi][lane][4], lane (i = l&15, kg = l>>4) = U[xi][co 16cb+i][k 16chunk+4kg+e]
+    const int cb16 = cblk * 4 + wave, ncb16 = a.Cout / 16;
+    const float4* ubase = reinterpret_cast<const float4*>(a.u) + lane + (size_t)cb16 * NX * 64;
+    const size_t ustride = (size_t)ncb16 * NX * 64;                      // float4 per chunk
+    const int rtile = lane & 15, kg = lane >> 4;
+    const int voff = rtile * 16 + (kg ^ ((rtile >> 2) & 3)) * 4;         // tile block tb adds tb*16 rows (same swizzle: 16 % 16 == 0)
 
-    float4 af[NSTEP];                                                    // one whole chunk of weight fragments in flight
-    // VMEM issue schedule of step s (weight fragment s of chunk `uchunk`, then two window loads of the item whose
-    // registers the transform has just released).  The prologue replays the SAME order without MFMAs, so the loads
-    // in flight at the loop head are ordered identically on both paths into the loop and the compiler's vmcnt
-    // counts are exact instead of a conservative minimum.
-    auto vmem_step = [&](int s, const float4* uchunk) {
-        if (!(ROWS_ABL & 2)) af[s] = uchunk[((size_t)(s >> 1) * ncb * 2 + (s & 1)) * 64];
-        if (!(ROWS_ABL & 1) && s >= NG && s < NG + NX) {
-            const int l0 = (s - NG) * 2;
-            if (l0 == 0) gather_begin(0);
-            if (l0 == NX) gather_begin(1);
-            gather_load(l0 / NX, l0 % NX);
-            gather_load((l0 + 1) / NX, (l0 + 1) % NX);
-        }
-    };
-    {                                                                    // prologue: everything that does not depend on LDS goes out first
-        const float4* u0 = ubase + ((size_t)0 * ncb + cb) * 2 * 64;
+    float4 af[NX];                                                       // one whole chunk of weight fragments in flight
 #pragma unroll
-        for (int s = 0; s < NSTEP; ++s) af[s] = u0[((size_t)(s >> 1) * ncb * 2 + (s & 1)) * 64];   // weights of chunk 0
-    }
-    gather();                                                            // chunk 0
+    for (int x = 0; x < NX; ++x) af[x] = ubase[(size_t)x * 64];
+    gather_begin();                                                      // chunk 0
 #pragma unroll
-    for (int it = 0; it < 2; ++it)
+    for (int j = 0; j < NX; ++j) gather_load(j);
 #pragma unroll
-        for (int grp = 0; grp < NG; ++grp) transform_group(it, grp, V);
-    gather();                                                            // chunk 1
-    __syncthreads();
+    for (int grp = 0; grp < NG; ++grp) transform_group(grp, V);
+    gather_begin();                                                      // chunk 1
+#pragma unroll
+    for (int j = 0; j < NX; ++j) gather_load(j);
+    lds_barrier();
     for (int c = 0; c < a.nchunks; ++c) {
         const float* Vc = V + (c & 1) * VBUF;
         float* Vn = V + ((c + 1) & 1) * VBUF;
-        const float4* un = ubase + ((size_t)((c + 1 < a.nchunks ? c + 1 : c) * NX) * ncb + cb) * 2 * 64;
-        float4 bf0 = *reinterpret_cast<const float4*>(Vc + voff0);
-        float4 bf1 = *reinterpret_cast<const float4*>(Vc + 32 * 16 + voff0);
+        const float4* un = ubase + (size_t)(c + 1 < a.nchunks ? c + 1 : c) * ustride;
+        float4 bf[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) bf[b] = *reinterpret_cast<const float4*>(Vc + b * 16 * 16 + voff);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int s = 0; s < NSTEP; ++s) {
-            const int x = s >> 1;
-            const float4 aw = af[s];
-            const float4 b0 = bf0, b1 = bf1;
-            if (s + 1 < NSTEP) {
-                const float* vp = Vc + (size_t)((s + 1) >> 1) * TT * 16 + (((s + 1) & 1) ? voff1 : voff0);
-                bf0 = *reinterpret_cast<const float4*>(vp);
-                bf1 = *reinterpret_cast<const float4*>(vp + 32 * 16);
+        for (int x = 0; x < NX; ++x) {                                   // one frequency point per step: 16 MFMAs
+            const float4 aw = af[x];
+            float4 bw[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bw[b] = bf[b];
+            if (x + 1 < NX) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) bf[b] = *reinterpret_cast<const float4*>(Vc + (size_t)(x + 1) * TT * 16 + b * 16 * 16 + voff);
             }
-            acc[2 * x] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.x, b0.x, acc[2 * x], 0, 0, 0);
-            acc[2 * x + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.x, b1.x, acc[2 * x + 1], 0, 0, 0);
-            // in the shadow of the MFMAs: one transform group of chunk c+1 per step (item 0 in steps [0, NG), item 1 in
-            // [NG, 2 NG)), then this step's loads: the same fragment slot of chunk c+1 and two windows of chunk c+2
-            // (past the last chunk the windows are all out of range = 0 and land in the idle buffer)
-            if (!(ROWS_ABL & 4) && s < 2 * NG) transform_group(s / NG, s % NG, Vn);
-            vmem_step(s, un);
-            acc[2 * x] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.y, b0.y, acc[2 * x], 0, 0, 0);
-            acc[2 * x + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.y, b1.y, acc[2 * x + 1], 0, 0, 0);
-            acc[2 * x] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.z, b0.z, acc[2 * x], 0, 0, 0);
-            acc[2 * x + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.z, b1.z, acc[2 * x + 1], 0, 0, 0);
-            acc[2 * x] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.w, b0.w, acc[2 * x], 0, 0, 0);
-            acc[2 * x + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.w, b1.w, acc[2 * x + 1], 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[x][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw.x, bw[b].x, acc[x][b], 0, 0, 0);
+            if (!(ROWS_ABL & 2)) af[x] = un[(size_t)x * 64];             // same slot of the next chunk
+            // between the MFMAs: one transform group of chunk c+1 per step, then (registers free) the windows of chunk
+            // c+2, two loads per step (past the last chunk all out of range = 0, written to the idle buffer)
+            if (!(ROWS_ABL & 4) && x < NG) transform_group(x, Vn);
+            if (!(ROWS_ABL & 1) && x >= NG) {
+                if (x == NG) gather_begin();
+                gather_load(2 * (x - NG)); gather_load(2 * (x - NG) + 1);
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[x][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw.y, bw[b].y, acc[x][b], 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[x][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw.z, bw[b].z, acc[x][b], 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[x][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw.w, bw[b].w, acc[x][b], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         lds_barrier();                                                   // V[c+1] complete, V[c] free for chunk c+2
     }
 
-    // ---- epilogue: y0 = sum_{k<NX-1} M_k, y1 = sum_k AT1[k] M_k; acc row = cout (r&3)+8*(r>>2)+4*(lane>>5), col = tile lane&31
+    // ---- epilogue: y0 = sum_{k<NX-1} M_k, y1 = sum_k AT1[k] M_k; acc row = cout 4*(lane>>4)+r (one c4 group), col = tile lane&15 (+16 tb)
+    const int co = cblk * 64 + wave * 16 + 4 * kg;
+    const float4 bias = a.bias ? *reinterpret_cast<const float4*>(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float bb[4] = {bias.x, bias.y, bias.z, bias.w};
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-        const int to = t0 + wt * 64 + nb * 32 + (lane & 31);
+    for (int tb = 0; tb < 4; ++tb) {
+        const int to = t0 + tb * 16 + rtile;
         if (to >= a.T) continue;
         const int oimg = to / THW, orem = to - oimg * THW, oy = orem / a.TW, otx = orem - oy * a.TW;
-        const int opix = oy * a.W + 2 * otx;
-        const bool two = 2 * otx + 1 < a.W;
+        float y0[4], y1[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int co = cblk * 64 + wc * 32 + 8 * q + 4 * (lane >> 5);
-            const float4 b = a.bias ? *reinterpret_cast<const float4*>(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
-            float y0[4], y1[4];
+        for (int r = 0; r < 4; ++r) {
+            float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int r = 4 * q + e;
-                float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-                for (int k = 0; k < NX; ++k) {
-                    const float m = acc[2 * k + nb][r];
-                    if (k < NX - 1) s0 += m;
-                    if (WM::AT1[k] != 0.f) s1 = fmaf(WM::AT1[k], m, s1);
-                }
-                y0[e] = s0; y1[e] = s1;
+            for (int k = 0; k < NX; ++k) {
+                const float m = acc[k][tb][r];
+                if (k < NX - 1) s0 += m;
+                if (WM::AT1[k] != 0.f) s1 = fmaf(WM::AT1[k], m, s1);
             }
-            float4 v0 = make_float4(y0[0] + b.x, y0[1] + b.y, y0[2] + b.z, y0[3] + b.w);
-            float4 v1 = make_float4(y1[0] + b.x, y1[1] + b.y, y1[2] + b.z, y1[3] + b.w);
-            if (a.relu) {
-                v0.x = fmaxf(v0.x, 0.f); v0.y = fmaxf(v0.y, 0.f); v0.z = fmaxf(v0.z, 0.f); v0.w = fmaxf(v0.w, 0.f);
-                v1.x = fmaxf(v1.x, 0.f); v1.y = fmaxf(v1.y, 0.f); v1.z = fmaxf(v1.z, 0.f); v1.w = fmaxf(v1.w, 0.f);
-            }
-            float* op = a.out + c4_offset(oimg, a.Gout_tot, a.gout0 + (co >> 2), HW, opix);
-            *reinterpret_cast<float4*>(op) = v0;
-            if (two) *reinterpret_cast<float4*>(op + 4) = v1;
+            y0[r] = s0 + bb[r]; y1[r] = s1 + bb[r];
         }
+        float4 v0 = make_float4(y0[0], y0[1], y0[2], y0[3]), v1 = make_float4(y1[0], y1[1], y1[2], y1[3]);
+        if (a.relu) {
+            v0.x = fmaxf(v0.x, 0.f); v0.y = fmaxf(v0.y, 0.f); v0.z = fmaxf(v0.z, 0.f); v0.w = fmaxf(v0.w, 0.f);
+            v1.x = fmaxf(v1.x, 0.f); v1.y = fmaxf(v1.y, 0.f); v1.z = fmaxf(v1.z, 0.f); v1.w = fmaxf(v1.w, 0.f);
+        }
+        float* op = a.out + c4_offset(oimg, a.Gout_tot, a.gout0 + (co >> 2), HW, oy * a.W + 2 * otx);
+        *reinterpret_cast<float4*>(op) = v0;
+        if (2 * otx + 1 < a.W) *reinterpret_cast<float4*>(op + 4) = v1;
     }
 }
 
 // U[xi][co][k = 4*(ky*Gin4 + g) + e] = (sum_j G[xi][j] w[co][ci][ky][j]) * BN scale, in MFMA A-operand order
-// [chunk][xi][cout/32][kq][lane][4]:  co = cb*32 + (lane&31), k = chunk*16 + kq*8 + 4*(lane>>5) + e.
+// [chunk][cout/16][xi][lane][4]:  co = cb*16 + (lane&15), k = chunk*16 + 4*(lane>>4) + e.
 template <int R>
 __global__ void pack_rows_winograd_kernel(const float* __restrict__ w, const float* __restrict__ gamma, const float* __restrict__ var,
                                           float eps, int Cout, int Cin, int rot, int nchunks, float* __restrict__ up) {
     constexpr int NX = R + 1;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int ncb = Cout / 32, Gin4 = (Cin + 3) / 4;
-    const long long total = (long long)nchunks * NX * ncb * 2 * 64 * 4;
+    const int ncb16 = Cout / 16, Gin4 = (Cin + 3) / 4;
+    const long long total = (long long)nchunks * ncb16 * NX * 64 * 4;
     if (idx >= total) return;
-    const int e = (int)(idx & 3), lane = (int)((idx >> 2) & 63), kq = (int)((idx >> 8) & 1);
-    long long r = idx >> 9;
-    const int cb = (int)(r % ncb); r /= ncb;
-    const int xi = (int)(r % NX), chunk = (int)(r / NX);
-    const int co = cb * 32 + (lane & 31);
-    const int q = chunk * 4 + kq * 2 + (lane >> 5);
+    const int e = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
+    long long r = idx >> 8;
+    const int xi = (int)(r % NX); r /= NX;
+    const int cb = (int)(r % ncb16), chunk = (int)(r / ncb16);
+    const int co = cb * 16 + (lane & 15);
+    const int q = chunk * 4 + (lane >> 4);
     const int ky = q / Gin4, cp = 4 * (q - ky * Gin4) + e;
     float v = 0.f;
     if (ky < R && cp < Cin) {
@@ -327,7 +294,7 @@ extern "C" int cnm_conv_rows_winograd_c4_f32(const float* in_a, int Ga_total, in
     a.Gin_tot = Ga_total; a.gin0 = ga0; a.Gin2_tot = Gb ? Gb_total : Ga_total; a.gin2_0 = Gb ? gb0 : ga0; a.Gsplit = Ga; a.Gin = Ga + Gb;
     a.Gout_tot = Gout_total; a.gout0 = gout0; a.Cout = Cout;
     a.nchunks = (ksize * a.Gin + 3) / 4; a.T = N * H * a.TW; a.relu = relu;
-    const int nblocks = (Cout / 64) * cnm_ceil_div(a.T, 128);
+    const int nblocks = (Cout / 64) * cnm_ceil_div(a.T, 64);
     if (ksize == 5) conv_rows_winograd_f32_kernel<5><<<nblocks, 256, 0, cnm_stream(stream)>>>(a);
     else conv_rows_winograd_f32_kernel<7><<<nblocks, 256, 0, cnm_stream(stream)>>>(a);
     CNM_LAUNCH_CHECK();
