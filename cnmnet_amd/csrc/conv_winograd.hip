@@ -22,6 +22,12 @@
 // accumulators per wave = one wave per SIMD: 8-70 % slower, most on the short-K and low-resolution layers.)
 #include "cnm_common.h"
 
+#ifndef WINO_WD
+#define WINO_WD 8        // weight fragments in flight per wave
+#endif
+#ifndef WINO_GSTART
+#define WINO_GSTART 6    // first step of the window loads of the chunk two ahead (8 steps, two loads each)
+#endif
 #ifndef WINO_ABL
 #define WINO_ABL 0   // ablation bit mask for timing studies (results are wrong when set): 1 no gather, 2 no weight refill, 4 no transform, 8 windows from one cache line, 16 weights from one fragment
 #endif
@@ -130,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd_f32_kernel(const Wino
     const int voffA = rtile * 16 + (kg ^ ((rtile >> 2) & 3)) * 4;        // tile block 0: tiles 0..15
     const int voffB = (16 + rtile) * 16 + (kg ^ (((16 + rtile) >> 2) & 3)) * 4;
 
-    constexpr int WD = 8;                                                // weight fragments in flight (steps of 8 MFMAs): half a chunk
+    constexpr int WD = WINO_WD;                                          // weight fragments in flight (steps of 8 MFMAs)
     float4 af[WD];
     {
 #pragma unroll
@@ -171,9 +177,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd_f32_kernel(const Wino
                 if (x < 2) { column_pass(2 * x); column_pass(2 * x + 1); }
                 else if (x < 4) { row_pass(2 * (x - 2), Vn); row_pass(2 * (x - 2) + 1, Vn); }
             }
-            if (!(WINO_ABL & 1) && x >= 2 && x < 10) {
-                if (x == 2) gather_begin(c + 2);
-                gather_load(2 * (x - 2)); gather_load(2 * (x - 2) + 1);
+            if (!(WINO_ABL & 1) && x >= WINO_GSTART && x < WINO_GSTART + 8) {
+                if (x == WINO_GSTART) gather_begin(c + 2);
+                gather_load(2 * (x - WINO_GSTART)); gather_load(2 * (x - WINO_GSTART) + 1);
             }
             acc[x][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw.y, b0.y, acc[x][0], 0, 0, 0);
             acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw.y, b1.y, acc[x][1], 0, 0, 0);
