@@ -84,8 +84,8 @@ def conv_kernel(L, m):
     k, s = L["ksize"], L["stride"]
     if s == 1 and k == 3:
         return "conv3x3_winograd_f32_kernel", 16.0 / 36.0            # F(2x2,3x3): 16 multiplies per 4 outputs instead of 36
-    if s == 1 and k in (5, 7):
-        return "conv_rows_winograd_f32_kernel<%d>" % k, (k + 1) / (2.0 * k)   # F(2,k) along rows
+    if k in (5, 7):                                                  # F(2,k) along rows; stride 2: two F(2,ceil(k/2)) column phases
+        return "conv_rows_winograd_f32_kernel<%d, %d>" % (k, s), ((k + 1) / (2.0 * k) if s == 1 else ((k + 1) // 2 + 1) / float(k))
     return conv_tile(L["Cout"], m), 1.0
 
 
@@ -110,8 +110,8 @@ def kernel_rooflines(dev, frames):
                 up = ops.pack_winograd(wt)
                 fn = lambda: ops.conv3x3_winograd_c4(x, up, bp, L["Cout"], True)
             elif name.startswith("conv_rows_winograd"):
-                up = ops.pack_winograd(wt)
-                fn = lambda: ops.conv_rows_winograd_c4(x, up, bp, L["Cout"], L["ksize"], True)
+                up = ops.pack_winograd(wt, stride=L["stride"])
+                fn = lambda: ops.conv_rows_winograd_c4(x, up, bp, L["Cout"], L["ksize"], True, stride=L["stride"])
             else:
                 fn = lambda: ops.conv2d_c4(x, wp, bp, L["Cout"], L["ksize"], L["stride"], True)
             ms = event_ms(fn, iters=3, warm=1)

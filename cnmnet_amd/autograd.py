@@ -26,7 +26,7 @@ def _winograd_conv(x, weight, rot):
     up = ops.pack_winograd(weight, None, rot)
     if k == 3:
         return ops.conv3x3_winograd_c4(x, up, None, Cout, relu=False)
-    return ops.conv_rows_winograd_c4(x, up, None, Cout, k, relu=False)
+    return ops.conv_rows_winograd_c4(x, up, None, Cout, k, relu=False, stride=1)
 
 
 class ConvC4(torch.autograd.Function):

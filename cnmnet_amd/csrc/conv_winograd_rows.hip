@@ -53,54 +53,87 @@ template <> struct RowWino<7> {
     static constexpr double G[8][7] = {{-1, 0, 0, 0, 0, 0, 0}, {-2. / 9, -2. / 9, -2. / 9, -2. / 9, -2. / 9, -2. / 9, -2. / 9}, {-2. / 9, 2. / 9, -2. / 9, 2. / 9, -2. / 9, 2. / 9, -2. / 9}, {1. / 90, 1. / 45, 2. / 45, 4. / 45, 8. / 45, 16. / 45, 32. / 45}, {1. / 90, -1. / 45, 2. / 45, -4. / 45, 8. / 45, -16. / 45, 32. / 45}, {32. / 45, 16. / 45, 8. / 45, 4. / 45, 2. / 45, 1. / 45, 1. / 90}, {32. / 45, -16. / 45, 8. / 45, -4. / 45, 2. / 45, -1. / 45, 1. / 90}, {0, 0, 0, 0, 0, 0, 1}};
 };
 
+// F(2,4), interpolation points 0, 1, -1, 2, inf  (even / odd column phases of the 7-tap stride-2 rows)
+template <> struct RowWino<4> {
+    static constexpr float AT1[5] = {0, 1, -1, 2, 1};
+    static constexpr double G[5][4] = {{1. / 2, 0, 0, 0}, {-1. / 2, -1. / 2, -1. / 2, -1. / 2}, {-1. / 6, 1. / 6, -1. / 6, 1. / 6}, {1. / 6, 1. / 3, 2. / 3, 4. / 3}, {0, 0, 0, 1}};
+};
+// F(2,3), interpolation points 0, 1, -1, inf  (column phases of the 5-tap stride-2 rows)
+template <> struct RowWino<3> {
+    static constexpr float AT1[4] = {0, 1, -1, 1};
+    static constexpr double G[4][3] = {{-1, 0, 0}, {1. / 2, 1. / 2, 1. / 2}, {1. / 2, -1. / 2, 1. / 2}, {0, 0, 1}};
+};
+
+// Stride 2: out[y][X] = sum_ky sum_p sum_j w[ky][2j + 2 START + p + R/2] in[2y + ky - R/2][2 (X + j + START) + p]: the
+// two column phases p of the input are stride-1 correlations with RT = ceil(R/2) taps (the shorter phase padded
+// with a zero tap), both transformed with the same F(2,RT) and accumulated in the same frequency-domain registers;
+// (RT+1) instead of R multiplies per two outputs and kernel row: 1.4x (R=7) / 1.25x (R=5) fewer MFMA flops.
+template <int R, int S> struct RowCfg {
+    static constexpr int RT = S == 1 ? R : (R + 1) / 2;                 // taps seen by the transform
+    static constexpr int NX = RT + 1;                                    // frequency points
+    static constexpr int START = -(RT / 2);                              // first window sample relative to the tile's first output (phase samples)
+    static constexpr int NKP = R * S;                                    // (kernel row, column phase) pairs in the reduction
+};
+
 struct RowArgs {
     const float* in; const float* in2; float* out; const float* u; const float* bias;
     unsigned in_bytes, in2_bytes;
-    int N, H, W, TW;                     // TW = ceil(W/2) tiles per row
+    int N, H, W, Ho, Wo, TW;             // input H x W, output Ho x Wo, TW = ceil(Wo/2) tiles per row
     int Gin_tot, gin0, Gin2_tot, gin2_0, Gsplit, Gin;
     int Gout_tot, gout0, Cout;
-    int nchunks, T, relu;                // T = N*H*TW tiles
+    int nchunks, T, relu;                // T = N*Ho*TW tiles
 };
 
-template <int R>
+template <int R, int S>
 __global__ __launch_bounds__(256, 2) void conv_rows_winograd_f32_kernel(const RowArgs a) {
-    using WM = RowWino<R>;
-    constexpr int NX = R + 1, TT = 64, NG = NX / 2;
+    using CF = RowCfg<R, S>;
+    using WM = RowWino<CF::RT>;
+    constexpr int NX = CF::NX, TT = 64, NG = (NX + 1) / 2;
     constexpr int VBUF = NX * TT * 16;                                   // V[buf][xi][tile][16 k], slots XOR-swizzled with ((tile >> 2) & 3)
-    __shared__ __attribute__((aligned(16))) float V[2 * VBUF];           // 64 KB (R = 7) / 48 KB (R = 5)
+    __shared__ __attribute__((aligned(16))) float V[2 * VBUF];           // 64 KB (R = 7) / 48 KB (R = 5) / less for stride 2
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int tilesC = a.Cout / 64;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int cblk = tile % tilesC, t0 = (tile / tilesC) * TT;
-    const int HW = a.H * a.W, THW = a.H * a.TW;
+    const int HW = a.H * a.W, HWo = a.Ho * a.Wo, THW = a.Ho * a.TW;
 
     // ---- loader: thread = (tile tl, channel quad qd = wave of the chunk)
     const int tl = lane, qd = wave;
     const int tg = t0 + tl;
     const bool tvalid = tg < a.T;
-    int img, py, px;
-    { const int tt = tvalid ? tg : 0; img = tt / THW; const int rem = tt - img * THW; py = rem / a.TW; px = 2 * (rem - py * a.TW) - R / 2; }
-    // per-thread invariants of the window loads: x offset and x validity of the R+1 pixels; per chunk the (kernel row,
-    // channel group) pair is wave-uniform, only the row validity is per lane: two vector instructions per load
-    unsigned xoff[NX]; bool xok[NX];
+    int img, py, ptx;
+    { const int tt = tvalid ? tg : 0; img = tt / THW; const int rem = tt - img * THW; py = rem / a.TW; ptx = rem - py * a.TW; }
+    // per-thread invariants of the window loads: x offset and x validity of the NX samples (per column phase for
+    // stride 2); per chunk the (kernel row, phase, channel group) triple is wave-uniform, only the row validity is per
+    // lane: two vector instructions per load
+    unsigned xoff[S][NX]; bool xok[S][NX];
 #pragma unroll
-    for (int j = 0; j < NX; ++j) { const int ix = px + j; xok[j] = tvalid & ((unsigned)ix < (unsigned)a.W); xoff[j] = (unsigned)ix * 16u; }
+    for (int p = 0; p < S; ++p)
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const int ix = S == 1 ? 2 * ptx - R / 2 + j : 2 * (2 * ptx + j + CF::START) + p;
+            xok[p][j] = tvalid & ((unsigned)ix < (unsigned)a.W); xoff[p][j] = (unsigned)ix * 16u;
+        }
     float4 d[NX];
-    int ky = qd / a.Gin, gq = qd - ky * a.Gin;                           // (kernel row, channel group) of the next chunk to gather
-    __amdgpu_buffer_rsrc_t grsrc; unsigned gbase; bool gok;
+    int kp = qd / a.Gin, gq = qd - kp * a.Gin;                           // (kernel row [, phase]) and channel group of the next chunk to gather
+    __amdgpu_buffer_rsrc_t grsrc; unsigned gbase; bool gok; int gph;
     auto gather_begin = [&]() {
         const int g = gq;
         const bool s1 = g < a.Gsplit;
         grsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s1 ? a.in : a.in2), 0, s1 ? a.in_bytes : a.in2_bytes, 0x00020000);
-        const int iy = py + ky - R / 2;
+        const int ky = S == 1 ? kp : kp >> 1;
+        gph = S == 1 ? 0 : kp & 1;
+        const int iy = S * py + ky - R / 2;
         gbase = ((s1 ? (unsigned)((img * a.Gin_tot + a.gin0 + g) * HW) : (unsigned)((img * a.Gin2_tot + a.gin2_0 + g - a.Gsplit) * HW)) + (unsigned)(iy * a.W)) * 16u;
-        gok = (ky < R) & ((unsigned)iy < (unsigned)a.H);
+        gok = (kp < CF::NKP) & ((unsigned)iy < (unsigned)a.H);
         gq += 4;                                                         // advance to the following chunk's quad
 #pragma unroll
-        for (int w = 0; w < 4; ++w) { const bool wrap = gq >= a.Gin; gq -= wrap ? a.Gin : 0; ky += wrap; }   // Gin >= 1: at most 4 wraps
+        for (int w = 0; w < 4; ++w) { const bool wrap = gq >= a.Gin; gq -= wrap ? a.Gin : 0; kp += wrap; }   // Gin >= 1: at most 4 wraps
     };
     auto gather_load = [&](int j) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(grsrc, (gok & xok[j]) ? gbase + xoff[j] : 0xFFFFFFFFu, 0, 0);
+        const bool ok = gok & (S == 1 ? xok[0][j] : (gph ? xok[S - 1][j] : xok[0][j]));
+        const unsigned xo = S == 1 ? xoff[0][j] : (gph ? xoff[S - 1][j] : xoff[0][j]);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(grsrc, ok ? gbase + xo : 0xFFFFFFFFu, 0, 0);
         d[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
     };
     // V = BT d in NG = (R+1)/2 groups of two frequency points (even/odd factorisation of the +-p point pairs):
@@ -108,8 +141,8 @@ __global__ __launch_bounds__(256, 2) void conv_rows_winograd_f32_kernel(const Ro
     const int wofs = tl * 16 + (qd ^ ((tl >> 2) & 3)) * 4;
     auto transform_group = [&](int grp, float* Vdst) {
         const f4p* x = reinterpret_cast<const f4p*>(&d[0]);
-        f4p va, vb; int ka, kb;
-        if constexpr (R == 7) {
+        f4p va, vb; int ka, kb = -1;
+        if constexpr (CF::RT == 7) {
             if (grp == 0) { va = f4_fma(5.25f, f4_sub(x[2], x[4]), f4_sub(x[6], x[0])); vb = f4_fma(5.25f, f4_sub(x[3], x[5]), f4_sub(x[7], x[1])); ka = 0; kb = 7; }
             else {
                 f4p e, o;
@@ -118,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void conv_rows_winograd_f32_kernel(const Ro
                 else { e = f4_fma(4.f, x[2], f4_fma(-5.f, x[4], x[6])); o = f4_fma(2.f, x[1], f4_fma(-2.5f, x[3], f4_mul(0.5f, x[5]))); }
                 va = f4_add(e, o); vb = f4_sub(e, o); ka = 2 * grp - 1; kb = 2 * grp;
             }
-        } else {
+        } else if constexpr (CF::RT == 5) {
             if (grp == 0) { va = f4_fma(4.f, x[0], f4_fma(-5.f, x[2], x[4])); vb = f4_fma(4.f, x[1], f4_fma(-5.f, x[3], x[5])); ka = 0; kb = 5; }
             else {
                 f4p e, o;
@@ -126,9 +159,17 @@ __global__ __launch_bounds__(256, 2) void conv_rows_winograd_f32_kernel(const Ro
                 else { e = f4_sub(x[4], x[2]); o = f4_mul(2.f, f4_sub(x[3], x[1])); }
                 va = f4_add(e, o); vb = f4_sub(e, o); ka = 2 * grp - 1; kb = 2 * grp;
             }
+        } else if constexpr (CF::RT == 4) {                              // BT = [2 -1 -2 1 0; 0 -2 -1 1 0; 0 2 -3 1 0; 0 -1 0 1 0; 0 2 -1 -2 1]
+            const f4p v3 = f4_sub(x[3], x[1]);
+            if (grp == 0) { va = f4_fma(2.f, f4_sub(x[0], x[2]), v3); vb = f4_fma(-2.f, v3, f4_sub(x[4], x[2])); ka = 0; kb = 4; }
+            else if (grp == 1) { const f4p q = f4_sub(x[3], x[2]); va = f4_fma(-2.f, x[1], q); vb = f4_fma(2.f, f4_sub(x[1], x[2]), q); ka = 1; kb = 2; }
+            else { va = v3; ka = 3; }
+        } else {                                                         // RT == 3: BT = [-1 0 1 0; 0 1 1 0; 0 -1 1 0; 0 -1 0 1]
+            if (grp == 0) { va = f4_sub(x[2], x[0]); vb = f4_sub(x[3], x[1]); ka = 0; kb = 3; }
+            else { va = f4_add(x[1], x[2]); vb = f4_sub(x[2], x[1]); ka = 1; kb = 2; }
         }
         *reinterpret_cast<f4p*>(Vdst + (size_t)ka * TT * 16 + wofs) = va;
-        *reinterpret_cast<f4p*>(Vdst + (size_t)kb * TT * 16 + wofs) = vb;
+        if (kb >= 0) *reinterpret_cast<f4p*>(Vdst + (size_t)kb * TT * 16 + wofs) = vb;
     };
 
     f32x4 acc[NX][4];
@@ -180,9 +221,11 @@ __global__ __launch_bounds__(256, 2) void conv_rows_winograd_f32_kernel(const Ro
             // between the MFMAs: one transform group of chunk c+1 per step, then (registers free) the windows of chunk
             // c+2, two loads per step (past the last chunk all out of range = 0, written to the idle buffer)
             if (!(ROWS_ABL & 4) && x < NG) transform_group(x, Vn);
-            if (!(ROWS_ABL & 1) && x >= NG) {
+            if (!(ROWS_ABL & 1) && x >= NG) {                            // LPS loads per step, spread over the steps after the transform
+                constexpr int LPS = (NX + (NX - NG) - 1) / (NX - NG);
                 if (x == NG) gather_begin();
-                gather_load(2 * (x - NG)); gather_load(2 * (x - NG) + 1);
+#pragma unroll
+                for (int l = LPS * (x - NG); l < LPS * (x - NG + 1) && l < NX; ++l) gather_load(l);
             }
 #pragma unroll
             for (int b = 0; b < 4; ++b) acc[x][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw.y, bw[b].y, acc[x][b], 0, 0, 0);
@@ -221,18 +264,20 @@ __global__ __launch_bounds__(256, 2) void conv_rows_winograd_f32_kernel(const Ro
             v0.x = fmaxf(v0.x, 0.f); v0.y = fmaxf(v0.y, 0.f); v0.z = fmaxf(v0.z, 0.f); v0.w = fmaxf(v0.w, 0.f);
             v1.x = fmaxf(v1.x, 0.f); v1.y = fmaxf(v1.y, 0.f); v1.z = fmaxf(v1.z, 0.f); v1.w = fmaxf(v1.w, 0.f);
         }
-        float* op = a.out + c4_offset(oimg, a.Gout_tot, a.gout0 + (co >> 2), HW, oy * a.W + 2 * otx);
+        float* op = a.out + c4_offset(oimg, a.Gout_tot, a.gout0 + (co >> 2), HWo, oy * a.Wo + 2 * otx);
         *reinterpret_cast<float4*>(op) = v0;
-        if (2 * otx + 1 < a.W) *reinterpret_cast<float4*>(op + 4) = v1;
+        if (2 * otx + 1 < a.Wo) *reinterpret_cast<float4*>(op + 4) = v1;
     }
 }
 
-// U[xi][co][k = 4*(ky*Gin4 + g) + e] = (sum_j G[xi][j] w[co][ci][ky][j]) * BN scale, in MFMA A-operand order
-// [chunk][cout/16][xi][lane][4]:  co = cb*16 + (lane&15), k = chunk*16 + 4*(lane>>4) + e.
-template <int R>
+// U[xi][co][k = 4*(kp*Gin4 + g) + e] = (sum_j G[xi][j] w'[co][ci][kp][j]) * BN scale, in MFMA A-operand order
+// [chunk][cout/16][xi][lane][4]:  co = cb*16 + (lane&15), k = chunk*16 + 4*(lane>>4) + e.  Stride 1: kp = kernel row,
+// w' = the row's taps; stride 2: kp = (kernel row, column phase), w' = that phase's taps (zero where it has none).
+template <int R, int S>
 __global__ void pack_rows_winograd_kernel(const float* __restrict__ w, const float* __restrict__ gamma, const float* __restrict__ var,
                                           float eps, int Cout, int Cin, int rot, int nchunks, float* __restrict__ up) {
-    constexpr int NX = R + 1;
+    using CF = RowCfg<R, S>;
+    constexpr int NX = CF::NX;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int ncb16 = Cout / 16, Gin4 = (Cin + 3) / 4;
     const long long total = (long long)nchunks * ncb16 * NX * 64 * 4;
@@ -243,35 +288,43 @@ __global__ void pack_rows_winograd_kernel(const float* __restrict__ w, const flo
     const int cb = (int)(r % ncb16), chunk = (int)(r / ncb16);
     const int co = cb * 16 + (lane & 15);
     const int q = chunk * 4 + (lane >> 4);
-    const int ky = q / Gin4, cp = 4 * (q - ky * Gin4) + e;
+    const int kp = q / Gin4, cp = 4 * (q - kp * Gin4) + e;
     float v = 0.f;
-    if (ky < R && cp < Cin) {
+    if (kp < CF::NKP && cp < Cin) {
         const int ci = (cp + rot) % Cin;
+        const int ky = S == 1 ? kp : kp >> 1, ph = S == 1 ? 0 : kp & 1;
         const float* g = w + (((size_t)co * Cin + ci) * R + ky) * R;
         double s = 0;
-        for (int j = 0; j < R; ++j) s += RowWino<R>::G[xi][j] * (double)g[j];
+        for (int j = 0; j < CF::RT; ++j) {
+            const int kx = S == 1 ? j : 2 * j + 2 * CF::START + ph + R / 2;
+            if (kx >= 0 && kx < R) s += RowWino<CF::RT>::G[xi][j] * (double)g[kx];
+        }
         if (gamma) s *= (double)gamma[co] / sqrt((double)var[co] + (double)eps);
         v = (float)s;
     }
     up[idx] = v;
 }
 
-static int rows_chunks(int Cin, int ksize) { return (ksize * ((Cin + 3) / 4) + 3) / 4; }
+static int rows_chunks(int Cin, int ksize, int stride) { return (ksize * stride * ((Cin + 3) / 4) + 3) / 4; }
+static int rows_points(int ksize, int stride) { return (stride == 1 ? ksize : (ksize + 1) / 2) + 1; }
 
-extern "C" size_t cnm_packed_winograd_rows_floats(int Cout, int Cin, int ksize) {
-    if (Cout <= 0 || Cin <= 0 || Cout % 64 || (ksize != 5 && ksize != 7)) return 0;
-    return (size_t)rows_chunks(Cin, ksize) * (ksize + 1) * Cout * 16;
+extern "C" size_t cnm_packed_winograd_rows_floats(int Cout, int Cin, int ksize, int stride) {
+    if (Cout <= 0 || Cin <= 0 || Cout % 64 || (ksize != 5 && ksize != 7) || (stride != 1 && stride != 2)) return 0;
+    return (size_t)rows_chunks(Cin, ksize, stride) * rows_points(ksize, stride) * Cout * 16;
 }
 
 extern "C" int cnm_pack_winograd_rows_bn_f32(const float* w_oihw, const float* bn_gamma, const float* bn_var, float eps,
-                                             int Cout, int Cin, int ksize, int rot, float* u_packed, void* stream) {
+                                             int Cout, int Cin, int ksize, int stride, int rot, float* u_packed, void* stream) {
     CNM_REQUIRE(w_oihw && u_packed && Cout > 0 && Cout % 64 == 0 && Cin > 0 && rot >= 0 && rot < Cin, CNM_ERR_BAD_ARG);
-    CNM_REQUIRE((ksize == 5 || ksize == 7) && !bn_gamma == !bn_var, CNM_ERR_BAD_ARG);
-    const int nchunks = rows_chunks(Cin, ksize);
-    const long long total = (long long)nchunks * (ksize + 1) * Cout * 16;
+    CNM_REQUIRE((ksize == 5 || ksize == 7) && (stride == 1 || stride == 2) && !bn_gamma == !bn_var, CNM_ERR_BAD_ARG);
+    const int nchunks = rows_chunks(Cin, ksize, stride);
+    const long long total = (long long)nchunks * rows_points(ksize, stride) * Cout * 16;
     const unsigned nb = (unsigned)cnm_ceil_div_ll(total, 256);
-    if (ksize == 5) pack_rows_winograd_kernel<5><<<nb, 256, 0, cnm_stream(stream)>>>(w_oihw, bn_gamma, bn_var, eps, Cout, Cin, rot, nchunks, u_packed);
-    else pack_rows_winograd_kernel<7><<<nb, 256, 0, cnm_stream(stream)>>>(w_oihw, bn_gamma, bn_var, eps, Cout, Cin, rot, nchunks, u_packed);
+    hipStream_t st = cnm_stream(stream);
+#define CNM_PACK_ROWS(R, S) pack_rows_winograd_kernel<R, S><<<nb, 256, 0, st>>>(w_oihw, bn_gamma, bn_var, eps, Cout, Cin, rot, nchunks, u_packed)
+    if (ksize == 5 && stride == 1) CNM_PACK_ROWS(5, 1); else if (ksize == 5) CNM_PACK_ROWS(5, 2);
+    else if (stride == 1) CNM_PACK_ROWS(7, 1); else CNM_PACK_ROWS(7, 2);
+#undef CNM_PACK_ROWS
     CNM_LAUNCH_CHECK();
     return CNM_OK;
 }
@@ -280,8 +333,9 @@ extern "C" int cnm_conv_rows_winograd_c4_f32(const float* in_a, int Ga_total, in
                                              const float* in_b, int Gb_total, int gb0, int Gb,
                                              float* out, int Gout_total, int gout0, int Cout,
                                              const float* u_packed, const float* b_packed,
-                                             int N, int H, int W, int ksize, int relu, void* stream) {
+                                             int N, int H, int W, int ksize, int stride, int relu, void* stream) {
     CNM_REQUIRE(in_a && out && u_packed && N > 0 && H > 0 && W > 0 && Ga > 0 && Gb >= 0 && (ksize == 5 || ksize == 7), CNM_ERR_BAD_ARG);
+    CNM_REQUIRE(stride == 1 || stride == 2, CNM_ERR_BAD_ARG);
     CNM_REQUIRE(Cout > 0 && Cout % 64 == 0 && gout0 >= 0 && gout0 + Cout / 4 <= Gout_total, CNM_ERR_BAD_ARG);
     CNM_REQUIRE(ga0 >= 0 && ga0 + Ga <= Ga_total && (Gb == 0 || (in_b && gb0 >= 0 && gb0 + Gb <= Gb_total)), CNM_ERR_BAD_ARG);
     RowArgs a;
@@ -290,13 +344,17 @@ extern "C" int cnm_conv_rows_winograd_c4_f32(const float* in_a, int Ga_total, in
     const unsigned long long b2 = Gb ? (unsigned long long)N * Gb_total * H * W * 16ull : b1;
     CNM_REQUIRE(b1 < 0xFFFFFFFFull && b2 < 0xFFFFFFFFull, CNM_ERR_BAD_ARG);
     a.in_bytes = (unsigned)b1; a.in2_bytes = (unsigned)b2;
-    a.N = N; a.H = H; a.W = W; a.TW = (W + 1) / 2;
+    const int pad = ksize / 2;
+    a.N = N; a.H = H; a.W = W; a.Ho = (H + 2 * pad - ksize) / stride + 1; a.Wo = (W + 2 * pad - ksize) / stride + 1; a.TW = (a.Wo + 1) / 2;
     a.Gin_tot = Ga_total; a.gin0 = ga0; a.Gin2_tot = Gb ? Gb_total : Ga_total; a.gin2_0 = Gb ? gb0 : ga0; a.Gsplit = Ga; a.Gin = Ga + Gb;
     a.Gout_tot = Gout_total; a.gout0 = gout0; a.Cout = Cout;
-    a.nchunks = (ksize * a.Gin + 3) / 4; a.T = N * H * a.TW; a.relu = relu;
+    a.nchunks = (ksize * stride * a.Gin + 3) / 4; a.T = N * a.Ho * a.TW; a.relu = relu;
     const int nblocks = (Cout / 64) * cnm_ceil_div(a.T, 64);
-    if (ksize == 5) conv_rows_winograd_f32_kernel<5><<<nblocks, 256, 0, cnm_stream(stream)>>>(a);
-    else conv_rows_winograd_f32_kernel<7><<<nblocks, 256, 0, cnm_stream(stream)>>>(a);
+    hipStream_t st = cnm_stream(stream);
+    if (ksize == 5 && stride == 1) conv_rows_winograd_f32_kernel<5, 1><<<nblocks, 256, 0, st>>>(a);
+    else if (ksize == 5) conv_rows_winograd_f32_kernel<5, 2><<<nblocks, 256, 0, st>>>(a);
+    else if (stride == 1) conv_rows_winograd_f32_kernel<7, 1><<<nblocks, 256, 0, st>>>(a);
+    else conv_rows_winograd_f32_kernel<7, 2><<<nblocks, 256, 0, st>>>(a);
     CNM_LAUNCH_CHECK();
     return CNM_OK;
 }

@@ -108,9 +108,10 @@ class _EngineNet(nn.Module):
                 pack = ops.pack_conv_f16 if self.precision == "f16" else ops.pack_conv
                 bnp = (bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var)
                 wp, bp = pack(w, bnp, rot=L["rot"], eps=bn.eps)
-                # fp32 stride-1 layers run in the Winograd domain (3x3: F(2x2,3x3); 5x5 / 7x7: row-wise F(2,k))
-                wino = (self.precision == "f32" and self.winograd and L["ksize"] in (3, 5, 7) and L["stride"] == 1 and L["Cout"] % 64 == 0)
-                packed.append((wp, bp, ops.pack_winograd(w, bnp, rot=L["rot"], eps=bn.eps)) if wino else (wp, bp))
+                # fp32 layers in the Winograd domain: 3x3 stride 1 (F(2x2,3x3)); 5x5 / 7x7 stride 1 and 2 (row-wise)
+                wino = (self.precision == "f32" and self.winograd and L["Cout"] % 64 == 0 and
+                        ((L["ksize"] == 3 and L["stride"] == 1) or L["ksize"] in (5, 7)))
+                packed.append((wp, bp, ops.pack_winograd(w, bnp, rot=L["rot"], eps=bn.eps, stride=L["stride"])) if wino else (wp, bp))
         arr = (_lib.LayerWeights * len(packed))()
         for i, t in enumerate(packed):
             arr[i].w, arr[i].b = t[0].data_ptr(), t[1].data_ptr()

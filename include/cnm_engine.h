@@ -124,18 +124,20 @@ int cnm_conv3x3_winograd_c4_f32(const float* in_a, int Ga_total, int ga0, int Ga
                                 const float* u_packed, const float* b_packed,
                                 int N, int H, int W, int relu, void* stream);
 
-/* Row-wise Winograd F(2,R) twin of cnm_conv2d_cat2_c4_f32 for ksize R = 5 or 7, stride 1 (the reference's
- * conv1.0 = nn.Conv2d(3+D, 128, 7, 1, 3) and conv2.0 = nn.Conv2d(128, 256, 5, 1, 2), depthNet_model.py:137-148
- * via conv_layer :77-86): the transform runs along image rows, the R kernel rows stay in the GEMM reduction;
- * (R+1)/2 instead of R multiplies per output and kernel row.  u_packed from cnm_pack_winograd_rows_bn_f32. */
-size_t cnm_packed_winograd_rows_floats(int Cout, int Cin, int ksize);
+/* Row-wise Winograd twin of cnm_conv2d_cat2_c4_f32 for ksize R = 5 or 7, stride 1 or 2 (the reference's
+ * conv1 = nn.Conv2d(3+D, 128, 7, 1, 3) / (128, 128, 7, 2, 3) and conv2 = nn.Conv2d(128, 256, 5, 1, 2) /
+ * (256, 256, 5, 2, 2), depthNet_model.py:137-148 via conv_layer :77-86): the transform runs along image rows, the R
+ * kernel rows stay in the GEMM reduction.  Stride 1: F(2,R), (R+1)/2 instead of R multiplies per output and kernel
+ * row; stride 2: the two column phases of the input are F(2,ceil(R/2)) correlations accumulated together,
+ * ceil(R/2)+1 instead of R multiplies.  u_packed from cnm_pack_winograd_rows_bn_f32 (same ksize and stride). */
+size_t cnm_packed_winograd_rows_floats(int Cout, int Cin, int ksize, int stride);
 int cnm_pack_winograd_rows_bn_f32(const float* w_oihw, const float* bn_gamma, const float* bn_var, float eps,
-                                  int Cout, int Cin, int ksize, int rot, float* u_packed, void* stream);
+                                  int Cout, int Cin, int ksize, int stride, int rot, float* u_packed, void* stream);
 int cnm_conv_rows_winograd_c4_f32(const float* in_a, int Ga_total, int ga0, int Ga,
                                   const float* in_b, int Gb_total, int gb0, int Gb,
                                   float* out, int Gout_total, int gout0, int Cout,
                                   const float* u_packed, const float* b_packed,
-                                  int N, int H, int W, int ksize, int relu, void* stream);
+                                  int N, int H, int W, int ksize, int stride, int relu, void* stream);
 
 /* nn.Upsample(scale_factor=2, mode='bilinear') with align_corners=False
  * (depthNet_model.py:94,105) on a c4 view: [N,G,H,W,4] -> [N,G,2H,2W,4]. */
@@ -190,8 +192,8 @@ int cnm_net_layer(int net, int index, cnm_layer_info* info);   /* D=64 table */
 
 /* w, b: cnm_pack_conv_bn_* (or cnm_pack_head_f32) outputs.  u: optional Winograd-domain filter of
  * cnm_pack_winograd_bn_f32 (3x3) / cnm_pack_winograd_rows_bn_f32 (5x5, 7x7) -- when non-NULL the fp32 executors
- * run that stride-1 layer through cnm_conv3x3_winograd_c4_f32 / cnm_conv_rows_winograd_c4_f32 (w may then be
- * NULL); ignored by heads, stride-2 layers and the fp16 engine. */
+ * run that layer (3x3 stride 1; 5x5 / 7x7 stride 1 or 2) through cnm_conv3x3_winograd_c4_f32 /
+ * cnm_conv_rows_winograd_c4_f32 (w may then be NULL); ignored by heads, 3x3 stride-2 layers and the fp16 engine. */
 typedef struct cnm_layer_weights { const float* w; const float* b; const float* u; } cnm_layer_weights;
 
 /* depthNet.forward (depthNet_model.py:226-263) for P = B*S (ref,src) pairs.
