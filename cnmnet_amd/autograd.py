@@ -18,15 +18,15 @@ WINOGRAD = True     # stride-1 3x3 / 5x5 / 7x7 convolutions (forward and data gr
 
 
 def _winograd_ok(k, stride, cout):
-    return WINOGRAD and stride == 1 and k in (3, 5, 7) and cout % 64 == 0
+    return WINOGRAD and cout % 64 == 0 and ((stride == 1 and k == 3) or (stride in (1, 2) and k in (5, 7)))
 
 
-def _winograd_conv(x, weight, rot):
+def _winograd_conv(x, weight, rot, stride=1):
     Cout, _, k, _ = weight.shape
-    up = ops.pack_winograd(weight, None, rot)
+    up = ops.pack_winograd(weight, None, rot, stride=stride)
     if k == 3:
         return ops.conv3x3_winograd_c4(x, up, None, Cout, relu=False)
-    return ops.conv_rows_winograd_c4(x, up, None, Cout, k, relu=False, stride=1)
+    return ops.conv_rows_winograd_c4(x, up, None, Cout, k, relu=False, stride=stride)
 
 
 class ConvC4(torch.autograd.Function):
@@ -38,7 +38,7 @@ class ConvC4(torch.autograd.Function):
         x = x.contiguous()
         Cout, Cin, k, _ = weight.shape
         if _winograd_ok(k, stride, Cout):
-            y = _winograd_conv(x, weight.detach(), rot)
+            y = _winograd_conv(x, weight.detach(), rot, stride)
         else:
             wp, _ = ops.pack_conv(weight.detach(), None, None, rot)
             y = ops.conv2d_c4(x, wp, None, Cout, k, stride, relu=False)
@@ -55,7 +55,7 @@ class ConvC4(torch.autograd.Function):
         lib, dev = _lib.load(), x.device
         dx = dw = None
         with torch.cuda.device(dev):
-            if ctx.needs_input_grad[0] and ctx.rot == 0 and _winograd_ok(k, ctx.stride, Cin):
+            if ctx.needs_input_grad[0] and ctx.rot == 0 and ctx.stride == 1 and _winograd_ok(k, 1, Cin):
                 # stride 1: dx = conv(dy, w') with w'[ci][co] = w[co][ci] rotated by 180 degrees -- the same Winograd kernels
                 dx = _winograd_conv(dy, weight.detach().flip(2, 3).transpose(0, 1).contiguous(), 0)
             elif ctx.needs_input_grad[0]:
