@@ -29,6 +29,33 @@ def _winograd_conv(x, weight, rot, stride=1):
     return ops.conv_rows_winograd_c4(x, up, None, Cout, k, relu=False, stride=stride)
 
 
+def _stride2_dgrad_phases(weight):
+    """Data gradient of a stride-2 convolution (odd k, pad k//2, even H and W) as four stride-1 convolutions of dY,
+    one per pixel phase (a, b) of dX -- no structural zeros:
+        dX[2i+a, 2j+b] = sum_{u,v} dY[i + c_a - u, j + c_b - v] . w[:, :, r_a + 2u, r_b + 2v],   r = (phase + pad) % 2,
+    c = (phase + pad - r) / 2.  Returns [(a, b, w')] with w' [Cin, Cout, K', K'] (K' = 3 or 5, zero-embedded) such that
+    dX_phase = conv2d(dY, w', stride 1, pad K'//2)."""
+    Cout, Cin, k, _ = weight.shape
+    pad = k // 2
+    taps = []
+    for ph in (0, 1):
+        r = (ph + pad) % 2
+        c = (ph + pad - r) // 2
+        U = len(range(r, k, 2))
+        taps.append((r, c - (U - 1), c))                                 # sub-kernel rows r::2, tap u at offset c - u: offsets [c-U+1, c]
+    wt = weight.transpose(0, 1)                                          # [Cin, Cout, k, k] view
+    out = []
+    for a in (0, 1):
+        for b in (0, 1):
+            (ra, loa, hia), (rb, lob, hib) = taps[a], taps[b]
+            K = 3 if max(abs(loa), abs(hia), abs(lob), abs(hib)) <= 1 else 5
+            wp = weight.new_zeros(Cin, Cout, K, K)
+            # offsets descend with the tap index: the flipped sub-kernel fills one contiguous window of w'
+            wp[:, :, loa + K // 2:hia + K // 2 + 1, lob + K // 2:hib + K // 2 + 1] = wt[:, :, ra::2, rb::2].flip(2, 3)
+            out.append((a, b, wp))
+    return out
+
+
 class ConvC4(torch.autograd.Function):
     """y = conv2d(x, weight, stride, padding=(k-1)//2) on c4 tensors, no bias.
     x [N,ceil(Cin/4),H,W,4] (channels possibly rotated by `rot`), weight OIHW; Cout % 4 == 0, >= 16."""
@@ -58,6 +85,13 @@ class ConvC4(torch.autograd.Function):
             if ctx.needs_input_grad[0] and ctx.rot == 0 and ctx.stride == 1 and _winograd_ok(k, 1, Cin):
                 # stride 1: dx = conv(dy, w') with w'[ci][co] = w[co][ci] rotated by 180 degrees -- the same Winograd kernels
                 dx = _winograd_conv(dy, weight.detach().flip(2, 3).transpose(0, 1).contiguous(), 0)
+            elif (ctx.needs_input_grad[0] and ctx.rot == 0 and ctx.stride == 2 and WINOGRAD and Cin % 64 == 0
+                  and H % 2 == 0 and W % 2 == 0):
+                # stride 2: four stride-1 Winograd convolutions of dY, one per pixel phase of dX (sub-pixel
+                # decomposition: the zero-upsampled dY with its 3/4 structural zeros never exists)
+                dx = torch.empty_like(x)
+                for a, b, wp in _stride2_dgrad_phases(weight.detach()):
+                    dx[:, :, a::2, b::2] = _winograd_conv(dy, wp, 0)
             elif ctx.needs_input_grad[0]:
                 wd = torch.empty(lib.cnm_packed_dgrad_floats(Cout, Cin, k), device=dev, dtype=torch.float32)
                 _lib.check(lib.cnm_pack_conv_dgrad_f32(weight.detach().contiguous().data_ptr(), Cout, Cin, k, ctx.rot, wd.data_ptr(), _s()))
