@@ -29,6 +29,7 @@ import torch         # noqa: E402
 H, W, PLANES, SRC, KSIZE = 192, 256, 64, 2, 9
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_32x32x2_f32)
+WINO4_MIN_WORKGROUPS = 384     # include/cnm_engine.h CNM_WINO4_MIN_WORKGROUPS (executor's F(4x4,3x3) / F(2x2,3x3) switch)
 DEPTH_LEVEL = [0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 4, 4, 3, 3, 2, 2, 1, 1, 0, 0]      # input resolution level per conv layer
 REFINE_LEVEL = [0, 0, 1, 1, 2, 2, 2, 2, 1, 1, 0, 0, 2, 2, 1, 1, 0, 0]
 
@@ -78,11 +79,13 @@ def pmc_traffic(kernel):
     return None
 
 
-def conv_kernel(L, m):
+def conv_kernel(L, m, m4=0):
     """Mirror of the fp32 executors' layer -> kernel choice (cnmnet_amd/csrc/nets.hip EngF32::conv) and the share of
     the direct-convolution flops the kernel really executes on the matrix cores (Winograd executes fewer)."""
     k, s = L["ksize"], L["stride"]
     if s == 1 and k == 3:
+        if L["Cout"] // 64 * -(-m4 // 16) >= WINO4_MIN_WORKGROUPS:
+            return "conv3x3_winograd4_f32_kernel", 36.0 / 144.0          # F(4x4,3x3): 36 multiplies per 16 outputs instead of 144
         return "conv3x3_winograd_f32_kernel", 16.0 / 36.0            # F(2x2,3x3): 16 multiplies per 4 outputs instead of 36
     if k in (5, 7):                                                  # F(2,k) along rows; stride 2: two F(2,ceil(k/2)) column phases
         return "conv_rows_winograd_f32_kernel<%d, %d>" % (k, s), ((k + 1) / (2.0 * k) if s == 1 else ((k + 1) // 2 + 1) / float(k))
@@ -104,9 +107,12 @@ def kernel_rooflines(dev, frames):
             x = torch.randn(n_img, (cin + 3) // 4, h, w, 4, device=dev)
             wt = torch.randn(L["Cout"], cin, L["ksize"], L["ksize"], device=dev) * 0.02
             ho, wo = h // L["stride"], w // L["stride"]
-            name, executed = conv_kernel(L, n_img * ho * wo)
+            name, executed = conv_kernel(L, n_img * ho * wo, n_img * -(-ho // 4) * -(-wo // 4))
             wp, bp = ops.pack_conv(wt)
-            if name.startswith("conv3x3_winograd"):
+            if name.startswith("conv3x3_winograd4"):
+                up = ops.pack_winograd4(wt)
+                fn = lambda: ops.conv3x3_winograd4_c4(x, up, bp, L["Cout"], True)
+            elif name.startswith("conv3x3_winograd"):
                 up = ops.pack_winograd(wt)
                 fn = lambda: ops.conv3x3_winograd_c4(x, up, bp, L["Cout"], True)
             elif name.startswith("conv_rows_winograd"):

@@ -20,7 +20,7 @@ class LayerInfo(C.Structure):
 
 
 class LayerWeights(C.Structure):
-    _fields_ = [("w", c_fp), ("b", c_fp), ("u", c_fp)]
+    _fields_ = [("w", c_fp), ("b", c_fp), ("u", c_fp), ("u4", c_fp)]
 
 
 # name -> (restype, argtypes); mirrors include/cnm_engine.h declaration by declaration
@@ -41,6 +41,11 @@ PROTOTYPES = {
     "cnm_pack_winograd_bn_f32": (c_i, [c_fp, c_fp, c_fp, c_f, c_i, c_i, c_i, c_fp, c_fp]),
     "cnm_conv3x3_winograd_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp,
                                           c_i, c_i, c_i, c_i, c_fp]),
+    "cnm_tune_wino4_min_workgroups": (c_i, [c_i]),
+    "cnm_packed_winograd4_floats": (c_sz, [c_i, c_i]),
+    "cnm_pack_winograd4_bn_f32": (c_i, [c_fp, c_fp, c_fp, c_f, c_i, c_i, c_i, c_fp, c_fp]),
+    "cnm_conv3x3_winograd4_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp,
+                                           c_i, c_i, c_i, c_i, c_fp]),
     "cnm_packed_winograd_rows_floats": (c_sz, [c_i, c_i, c_i, c_i]),
     "cnm_pack_winograd_rows_bn_f32": (c_i, [c_fp, c_fp, c_fp, c_f, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp]),
     "cnm_conv_rows_winograd_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp,
@@ -117,8 +122,8 @@ def load():
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch
         fn.restype, fn.argtypes = res, args
-    if lib.cnm_abi_version() != 2:
-        raise EngineError("libcnm_engine.so ABI version %d, expected 2" % lib.cnm_abi_version())
+    if lib.cnm_abi_version() != 3:
+        raise EngineError("libcnm_engine.so ABI version %d, expected 3" % lib.cnm_abi_version())
     _lib = lib
     return lib
 

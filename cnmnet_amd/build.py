@@ -11,7 +11,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libcnm_engine.so")
-SOURCES = ["planesweep.hip", "conv_mfma.hip", "conv_winograd.hip", "conv_winograd_rows.hip", "pointwise.hip", "geometry.hip", "nets.hip", "train_ops.hip", "half_ops.hip"]
+SOURCES = ["planesweep.hip", "conv_mfma.hip", "conv_winograd.hip", "conv_winograd4.hip", "conv_winograd_rows.hip", "pointwise.hip", "geometry.hip", "nets.hip", "train_ops.hip", "half_ops.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

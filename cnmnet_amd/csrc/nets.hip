@@ -79,13 +79,24 @@ int cnm_refine_assemble_multi_c8_f16(const float*, const void*, void*, int, int,
 int cnm_planesweep_cat_c8_f16(const float*, const float*, const float*, void*, float*, size_t, int, int, int, int, int, double, double, void*);
 }
 
+// F(4x4,3x3) workgroups cover 64 couts x 16 tiles of 4x4 outputs: worth it only when they fill the chip twice over
+static int g_wino4_min_workgroups = CNM_WINO4_MIN_WORKGROUPS;         // the engine's only process-wide state: a tuning knob
+extern "C" int cnm_tune_wino4_min_workgroups(int n) { const int old = g_wino4_min_workgroups; if (n > 0) g_wino4_min_workgroups = n; return old; }
+static inline bool wino4_fills_chip(int Cout, int N, int H, int W) {
+    const long long tiles = (long long)N * ((H + 3) / 4) * ((W + 3) / 4);
+    return (Cout / 64) * ((tiles + 15) / 16) >= g_wino4_min_workgroups;
+}
+
 struct EngF32 {
     static constexpr int GD = 4;
     static int conv(const float* in, int Gt, int g0, int Gin, float* out, int Gto, int go0, int Cout, const cnm_layer_weights& w, int N, int H, int W, int k, int st, void* s) {
+        if (w.u4 && k == 3 && st == 1 && wino4_fills_chip(Cout, N, H, W))
+            return cnm_conv3x3_winograd4_c4_f32(in, Gt, g0, Gin, nullptr, 0, 0, 0, out, Gto, go0, Cout, w.u4, w.b, N, H, W, 1, s);
         if (w.u && k == 3 && st == 1) return cnm_conv3x3_winograd_c4_f32(in, Gt, g0, Gin, nullptr, 0, 0, 0, out, Gto, go0, Cout, w.u, w.b, N, H, W, 1, s);
         if (w.u && (k == 5 || k == 7)) return cnm_conv_rows_winograd_c4_f32(in, Gt, g0, Gin, nullptr, 0, 0, 0, out, Gto, go0, Cout, w.u, w.b, N, H, W, k, st, 1, s);
         return cnm_conv2d_c4_f32(in, Gt, g0, Gin, out, Gto, go0, Cout, w.w, w.b, N, H, W, k, st, 1, s); }
     static int conv2(const float* a, int Ga, const float* b, int Gb, float* out, int Gto, int Cout, const cnm_layer_weights& w, int N, int H, int W, void* s) {
+        if (w.u4 && wino4_fills_chip(Cout, N, H, W)) return cnm_conv3x3_winograd4_c4_f32(a, Ga, 0, Ga, b, Gb, 0, Gb, out, Gto, 0, Cout, w.u4, w.b, N, H, W, 1, s);
         if (w.u) return cnm_conv3x3_winograd_c4_f32(a, Ga, 0, Ga, b, Gb, 0, Gb, out, Gto, 0, Cout, w.u, w.b, N, H, W, 1, s);
         return cnm_conv2d_cat2_c4_f32(a, Ga, 0, Ga, b, Gb, 0, Gb, out, Gto, 0, Cout, w.w, w.b, N, H, W, 3, 1, 1, s); }
     static int up(const float* in, int G, float* out, int N, int H, int W, void* s) { return cnm_upsample2x_c4_f32(in, G, 0, out, G, 0, N, G, H, W, s); }
@@ -161,7 +172,7 @@ static int depthnet_forward(const cnm_layer_weights* wt, float idepth_scale, int
     CNM_REQUIRE(H > 0 && W > 0 && H % 32 == 0 && W % 32 == 0, CNM_ERR_BAD_SHAPE);
     double idmin, idmax;
     CNM_TRY(cnm_idepth_range_host((double)idepth_scale, &idmin, &idmax));
-    for (int i = 0; i < D_NUM; ++i) CNM_REQUIRE((wt[i].w || wt[i].u) && wt[i].b, CNM_ERR_BAD_ARG);
+    for (int i = 0; i < D_NUM; ++i) CNM_REQUIRE((wt[i].w || wt[i].u || wt[i].u4) && wt[i].b, CNM_ERR_BAD_ARG);
     const int P = B * S;
     DepthBufs b;
     CNM_REQUIRE(carve_depth<E>(ws, P, H, W, D, &b) <= ws_floats, CNM_ERR_WORKSPACE);
@@ -284,7 +295,7 @@ extern "C" int cnm_refinenet_forward_f32(const cnm_layer_weights* wt, float idep
                                          float* ws, size_t ws_floats, int N, int H, int W, void* stream) {
     CNM_REQUIRE(wt && idepth01 && idepth02 && iconv01 && iconv02 && disp_refined && prob_map && ws && N > 0, CNM_ERR_BAD_ARG);
     CNM_REQUIRE(H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0, CNM_ERR_BAD_SHAPE);
-    for (int i = 0; i < R_NUM; ++i) CNM_REQUIRE((wt[i].w || wt[i].u) && wt[i].b, CNM_ERR_BAD_ARG);
+    for (int i = 0; i < R_NUM; ++i) CNM_REQUIRE((wt[i].w || wt[i].u || wt[i].u4) && wt[i].b, CNM_ERR_BAD_ARG);
     RefineBufs b;
     CNM_REQUIRE(carve_refine<EngF32>(ws, N, H, W, &b) <= ws_floats, CNM_ERR_WORKSPACE);
     CNM_TRY(cnm_refine_assemble_c4_f32(idepth01, idepth02, idepth_stride, iconv01, G1_total, g1, iconv02, G2_total, g2, b.X, N, 64, H, W, stream));  // :332-333
@@ -298,7 +309,7 @@ static int refinenet_forward_multi(const cnm_layer_weights* wt, float idepth_sca
                                    float* ws, size_t ws_floats, int B, int H, int W, void* stream) {
     CNM_REQUIRE(wt && idepth_pairs && iconv_pairs && disp_refined && prob_map && ws && B > 0 && S >= 2 && S % 2 == 0, CNM_ERR_BAD_ARG);
     CNM_REQUIRE(H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0, CNM_ERR_BAD_SHAPE);
-    for (int i = 0; i < R_NUM; ++i) CNM_REQUIRE((wt[i].w || wt[i].u) && wt[i].b, CNM_ERR_BAD_ARG);
+    for (int i = 0; i < R_NUM; ++i) CNM_REQUIRE((wt[i].w || wt[i].u || wt[i].u4) && wt[i].b, CNM_ERR_BAD_ARG);
     RefineBufs b;
     CNM_REQUIRE(carve_refine<E>(ws, B, H, W, &b) <= ws_floats, CNM_ERR_WORKSPACE);
     CNM_TRY(E::assemble_multi(idepth_pairs, iconv_pairs, b.X, B, S, H, W, stream));

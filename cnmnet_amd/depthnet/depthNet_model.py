@@ -74,6 +74,7 @@ class _EngineNet(nn.Module):
         self.precision = precision  # 'f16': fp16 storage + f16 MFMA (BASELINE config 5); eval only
         self._layers = None        # engine layer table (resolved lazily: needs the library)
         self.winograd = os.environ.get("CNM_WINOGRAD", "1") != "0"   # fp32 stride-1 layers in the Winograd domain
+        self.winograd4 = os.environ.get("CNM_WINOGRAD4", "1") != "0"  # large 3x3 layers: F(4x4,3x3) instead of F(2x2,3x3)
         self._packed = None        # [(w, b[, u])] device tensors, one per engine layer
         self._packed_key = None
         self._weights_arr = None
@@ -86,7 +87,7 @@ class _EngineNet(nn.Module):
 
     def _param_key(self):
         ts = list(self.parameters()) + list(self.buffers())
-        return (self.precision, self.winograd, str(ts[0].device), tuple(t._version for t in ts), tuple(t.data_ptr() for t in ts[:4]))
+        return (self.precision, self.winograd, self.winograd4, str(ts[0].device), tuple(t._version for t in ts), tuple(t.data_ptr() for t in ts[:4]))
 
     def _first_cin(self):
         return None
@@ -111,11 +112,18 @@ class _EngineNet(nn.Module):
                 # fp32 layers in the Winograd domain: 3x3 stride 1 (F(2x2,3x3)); 5x5 / 7x7 stride 1 and 2 (row-wise)
                 wino = (self.precision == "f32" and self.winograd and L["Cout"] % 64 == 0 and
                         ((L["ksize"] == 3 and L["stride"] == 1) or L["ksize"] in (5, 7)))
-                packed.append((wp, bp, ops.pack_winograd(w, bnp, rot=L["rot"], eps=bn.eps, stride=L["stride"])) if wino else (wp, bp))
+                if not wino:
+                    packed.append((wp, bp))
+                else:
+                    up = ops.pack_winograd(w, bnp, rot=L["rot"], eps=bn.eps, stride=L["stride"])
+                    # 3x3: also the F(4x4,3x3) filter; the executor picks per call by tile count (CNM_WINO4_MIN_WORKGROUPS)
+                    u4 = ops.pack_winograd4(w, bnp, rot=L["rot"], eps=bn.eps) if (L["ksize"] == 3 and self.winograd4) else None
+                    packed.append((wp, bp, up, u4))
         arr = (_lib.LayerWeights * len(packed))()
         for i, t in enumerate(packed):
             arr[i].w, arr[i].b = t[0].data_ptr(), t[1].data_ptr()
             arr[i].u = t[2].data_ptr() if len(t) > 2 else None
+            arr[i].u4 = t[3].data_ptr() if len(t) > 3 and t[3] is not None else None
         self._packed, self._weights_arr, self._packed_key = packed, arr, key
 
     def _workspace(self, device, nfloats):
