@@ -20,6 +20,12 @@
 // The executors use it for layers with enough tiles to fill the chip (conv_winograd.hip otherwise).
 #include "cnm_common.h"
 
+#ifndef WINO4_ABL
+#define WINO4_ABL 0       // ablation bit mask for timing studies (results are wrong when set): 1 no gather, 2 no weight refill, 4 no transform, 8 windows from one line, 16 weights from one fragment
+#endif
+#ifndef WINO4_LPS
+#define WINO4_LPS 4      // window loads per step (divides 36)
+#endif
 #ifndef WINO4_WD
 #define WINO4_WD 6        // weight fragments in flight per wave (divides 36; 9 and more spill)
 #endif
@@ -98,7 +104,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd4_f32_kernel(const Win
         gsoff = (unsigned)(s1 ? a.gin0 + g : a.gin2_0 + g - a.Gsplit) * (unsigned)HW * 16u;
     };
     auto gather_load = [&](int ij) {
-        d[ij] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(grsrc, sat_add(roff[ij / 6], coff[ij % 6]), gsoff, 0));
+        d[ij] = __uint_as_float((WINO4_ABL & 8) ? __builtin_amdgcn_raw_buffer_load_b32(grsrc, (unsigned)lane * 4u, 0, 0)
+                                                 : __builtin_amdgcn_raw_buffer_load_b32(grsrc, sat_add(roff[ij / 6], coff[ij % 6]), gsoff, 0));
     };
     const int wofs = tl * 16 + (qd ^ ((tl >> 2) & 3)) * 4 + cc;
     auto column_pass = [&](int j) { WINO4_BT(d[0 * 6 + j], d[1 * 6 + j], d[2 * 6 + j], d[3 * 6 + j], d[4 * 6 + j], d[5 * 6 + j]); };
@@ -147,14 +154,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd4_f32_kernel(const Win
             const float4 bw = bf;
             if (x + 1 < NXI) bf = *reinterpret_cast<const float4*>(Vc + (size_t)(x + 1) * TT * 16 + voff);
             acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw.x, bw.x, acc[x], 0, 0, 0);
-            af[x % WD] = x + WD < NXI ? uc[(size_t)(x + WD) * 64] : un[(size_t)(x + WD - NXI) * 64];
-            // between the MFMAs: the transform of chunk c+1 (steps 0..11), then the window of chunk c+2 (two loads per
-            // step; past the last chunk all out of range = 0, written to the idle buffer)
-            if (x < 6) column_pass(x);
-            else if (x < 12) row_pass(x - 6, Vn);
-            else if (x < 30) {
+            if (WINO4_ABL & 16) af[x % WD] = ubase[0];
+            else if (!(WINO4_ABL & 2)) af[x % WD] = x + WD < NXI ? uc[(size_t)(x + WD) * 64] : un[(size_t)(x + WD - NXI) * 64];
+            // between the MFMAs: the transform of chunk c+1 (steps 0..11), then the window of chunk c+2 (WINO4_LPS loads
+            // per step; past the last chunk all out of range = 0, written to the idle buffer)
+            if (x < 6) { if (!(WINO4_ABL & 4)) column_pass(x); }
+            else if (x < 12) { if (!(WINO4_ABL & 4)) row_pass(x - 6, Vn); }
+            else if (x < 12 + 36 / WINO4_LPS && !(WINO4_ABL & 1)) {      // row-major (column-major issue order measured 5 % slower: worse line locality)
                 if (x == 12) gather_begin(c + 2);
-                gather_load(2 * (x - 12)); gather_load(2 * (x - 12) + 1);
+#pragma unroll
+                for (int l = WINO4_LPS * (x - 12); l < WINO4_LPS * (x - 11); ++l) gather_load(l);
             }
             acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw.y, bw.y, acc[x], 0, 0, 0);
             acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw.z, bw.z, acc[x], 0, 0, 0);
