@@ -23,10 +23,20 @@ def _winograd_ok(k, stride, cout):
 
 def _winograd_conv(x, weight, rot, stride=1):
     Cout, _, k, _ = weight.shape
+    if k == 3 and _winograd4_fills_chip(x, Cout):                        # large layers: F(4x4,3x3)
+        return ops.conv3x3_winograd4_c4(x, ops.pack_winograd4(weight, None, rot), None, Cout, relu=False)
     up = ops.pack_winograd(weight, None, rot, stride=stride)
     if k == 3:
         return ops.conv3x3_winograd_c4(x, up, None, Cout, relu=False)
     return ops.conv_rows_winograd_c4(x, up, None, Cout, k, relu=False, stride=stride)
+
+
+WINOGRAD4_MIN_WORKGROUPS = 384   # same switch point as the inference executors (include/cnm_engine.h)
+
+
+def _winograd4_fills_chip(x, Cout):
+    N, _, H, W, _ = x.shape
+    return (Cout // 64) * -(-(N * -(-H // 4) * -(-W // 4)) // 16) >= WINOGRAD4_MIN_WORKGROUPS
 
 
 def _stride2_dgrad_phases(weight):
