@@ -85,8 +85,10 @@ def conv_kernel(L, m, m4=0):
     k, s = L["ksize"], L["stride"]
     if s == 1 and k == 3:
         if L["Cout"] // 64 * -(-m4 // 16) >= WINO4_MIN_WORKGROUPS:
-            return "conv3x3_winograd4_f32_kernel", 36.0 / 144.0          # F(4x4,3x3): 36 multiplies per 16 outputs instead of 144
+            return "conv_winograd36_f32_kernel<4, 3>", 36.0 / 144.0      # F(4x4,3x3): 36 multiplies per 16 outputs instead of 144
         return "conv3x3_winograd_f32_kernel", 16.0 / 36.0            # F(2x2,3x3): 16 multiplies per 4 outputs instead of 36
+    if k == 5 and s == 1 and L["Cout"] // 64 * -(-(m // 4) // 16) >= WINO4_MIN_WORKGROUPS:
+        return "conv_winograd36_f32_kernel<2, 5>", 36.0 / 100.0          # F(2x2,5x5): 36 multiplies per 4 outputs instead of 100
     if k in (5, 7):                                                  # F(2,k) along rows; stride 2: two F(2,ceil(k/2)) column phases
         return "conv_rows_winograd_f32_kernel<%d, %d>" % (k, s), ((k + 1) / (2.0 * k) if s == 1 else ((k + 1) // 2 + 1) / float(k))
     return conv_tile(L["Cout"], m), 1.0
@@ -109,9 +111,9 @@ def kernel_rooflines(dev, frames):
             ho, wo = h // L["stride"], w // L["stride"]
             name, executed = conv_kernel(L, n_img * ho * wo, n_img * -(-ho // 4) * -(-wo // 4))
             wp, bp = ops.pack_conv(wt)
-            if name.startswith("conv3x3_winograd4"):
+            if name.startswith("conv3x3_winograd4") or name.startswith("conv_winograd36"):
                 up = ops.pack_winograd4(wt)
-                fn = lambda: ops.conv3x3_winograd4_c4(x, up, bp, L["Cout"], True)
+                fn = lambda: ops.conv3x3_winograd4_c4(x, up, bp, L["Cout"], True, ksize=L["ksize"])
             elif name.startswith("conv3x3_winograd"):
                 up = ops.pack_winograd(wt)
                 fn = lambda: ops.conv3x3_winograd_c4(x, up, bp, L["Cout"], True)

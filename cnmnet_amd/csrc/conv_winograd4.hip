@@ -55,13 +55,20 @@ struct Wino4Args {
         const float e2 = x4 - x2, o2 = x3 - x1;                                                                 \
         x0 = t0; x1 = e1 + o1; x2 = e1 - o1; x3 = fmaf(2.f, o2, e2); x4 = fmaf(-2.f, o2, e2); x5 = t5;          \
     } while (0)
-// A^T (4 outputs from 6 points): rows [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+// A^T of F(2,5) (2 outputs from the same 6 points): rows [1 1 1 1 1 0; 0 1 -1 2 -2 1]
+#define WINO2_AT(y0, y1, m0, m1, m2, m3, m4, m5) do {                                                           \
+        const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;                                     \
+        y0 = m0 + s1 + s2; y1 = fmaf(2.f, d2, d1) + m5;                                                         \
+    } while (0)
+// A^T of F(4,3) (4 outputs from 6 points): rows [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
 #define WINO4_AT(y0, y1, y2, y3, m0, m1, m2, m3, m4, m5) do {                                                   \
         const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;                                     \
         y0 = m0 + s1 + s2; y1 = fmaf(2.f, d2, d1); y2 = fmaf(4.f, s2, s1); y3 = fmaf(8.f, d2, d1) + m5;         \
     } while (0)
 
-__global__ __launch_bounds__(256, 2) void conv3x3_winograd4_f32_kernel(const Wino4Args a) {
+template <int M, int R>                                                  // M x M outputs per tile, R x R filter, M + R - 1 == 6
+__global__ __launch_bounds__(256, 2) void conv_winograd36_f32_kernel(const Wino4Args a) {
+    static_assert(M + R - 1 == 6, "36-point kernel");
     constexpr int TT = 16, NXI = 36, VBUF = NXI * TT * 16;               // V[buf][xi][tile][16 ci], slots XOR-swizzled with ((tile >> 2) & 3)
     __shared__ __attribute__((aligned(16))) float V[2 * VBUF];           // 72 KB
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -78,7 +85,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd4_f32_kernel(const Win
         const int tg = t0 + tl;
         const bool tvalid = tg < a.T;
         const int tt = tvalid ? tg : 0; const int img = tt / THW; const int rem = tt - img * THW; const int ty = rem / a.TW;
-        const int py = 4 * ty - 1, px = 4 * (rem - ty * a.TW) - 1;
+        const int py = M * ty - R / 2, px = M * (rem - ty * a.TW) - R / 2;
         const unsigned imgterm = (unsigned)img * (unsigned)a.Gin_tot * (unsigned)HW * 16u;
         imgdelta = (unsigned)img * (unsigned)a.Gin2_tot * (unsigned)HW * 16u - imgterm;
 #pragma unroll
@@ -180,29 +187,35 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd4_f32_kernel(const Win
     const int co = cblk * 64 + wave * 16 + 4 * kg;
     const float4 b = a.bias ? *reinterpret_cast<const float4*>(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
     const float bb[4] = {b.x, b.y, b.z, b.w};
-    float y[16][4];                                                      // [pixel 4*py+px][channel r]
+    float y[M * M][4];                                                   // [pixel M*py+px][channel r]
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        float s[4][6];                                                   // A^T M: 4 rows x 6 columns
+        float s[M][6];                                                   // A^T M: M rows x 6 columns
 #pragma unroll
-        for (int j = 0; j < 6; ++j)
-            WINO4_AT(s[0][j], s[1][j], s[2][j], s[3][j], acc[0 * 6 + j][r], acc[1 * 6 + j][r], acc[2 * 6 + j][r], acc[3 * 6 + j][r], acc[4 * 6 + j][r], acc[5 * 6 + j][r]);
+        for (int j = 0; j < 6; ++j) {
+            if constexpr (M == 4) WINO4_AT(s[0][j], s[1][j], s[2][j], s[3][j], acc[0 * 6 + j][r], acc[1 * 6 + j][r], acc[2 * 6 + j][r], acc[3 * 6 + j][r], acc[4 * 6 + j][r], acc[5 * 6 + j][r]);
+            else WINO2_AT(s[0][j], s[1][j], acc[0 * 6 + j][r], acc[1 * 6 + j][r], acc[2 * 6 + j][r], acc[3 * 6 + j][r], acc[4 * 6 + j][r], acc[5 * 6 + j][r]);
+        }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            WINO4_AT(y[i * 4 + 0][r], y[i * 4 + 1][r], y[i * 4 + 2][r], y[i * 4 + 3][r], s[i][0], s[i][1], s[i][2], s[i][3], s[i][4], s[i][5]);
+        for (int i = 0; i < M; ++i) {
+            if constexpr (M == 4) WINO4_AT(y[i * 4 + 0][r], y[i * 4 + 1][r], y[i * 4 + 2][r], y[i * 4 + 3][r], s[i][0], s[i][1], s[i][2], s[i][3], s[i][4], s[i][5]);
+            else WINO2_AT(y[i * 2 + 0][r], y[i * 2 + 1][r], s[i][0], s[i][1], s[i][2], s[i][3], s[i][4], s[i][5]);
+        }
     }
     float* obase = a.out + c4_offset(oimg, a.Gout_tot, a.gout0 + (co >> 2), HW, 0);
 #pragma unroll
-    for (int p = 0; p < 16; ++p) {
-        const int oy = 4 * oty + (p >> 2), ox = 4 * otx + (p & 3);
+    for (int p = 0; p < M * M; ++p) {
+        const int oy = M * oty + p / M, ox = M * otx + p % M;
         float4 v = make_float4(y[p][0] + bb[0], y[p][1] + bb[1], y[p][2] + bb[2], y[p][3] + bb[3]);
         if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         if (oy < a.H && ox < a.W) *reinterpret_cast<float4*>(obase + (size_t)(oy * a.W + ox) * 4) = v;   // ragged H / W: partial last tiles
     }
 }
 
-// U = G g G^T for F(4,3) (with the folded BatchNorm scale), packed in MFMA A-operand order [chunk][cout/16][xi][lane][4].
-__global__ void pack_winograd4_kernel(const float* __restrict__ w, const float* __restrict__ gamma, const float* __restrict__ var,
+// U = G g G^T for F(4,3) / F(2,5) (same six points; with the folded BatchNorm scale), packed in MFMA A-operand order
+// [chunk][cout/16][xi][lane][4].
+template <int R>
+__global__ void pack_winograd36_kernel(const float* __restrict__ w, const float* __restrict__ gamma, const float* __restrict__ var,
                                       float eps, int Cout, int Cin, int rot, int nchunks, float* __restrict__ up) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int ncb16 = Cout / 16;
@@ -216,11 +229,13 @@ __global__ void pack_winograd4_kernel(const float* __restrict__ w, const float* 
     float v = 0.f;
     if (cp < Cin) {
         const int ci = (cp + rot) % Cin;
-        const float* g = w + ((size_t)co * Cin + ci) * 9;
-        const double G[6][3] = {{1. / 4, 0, 0}, {-1. / 6, -1. / 6, -1. / 6}, {-1. / 6, 1. / 6, -1. / 6}, {1. / 24, 1. / 12, 1. / 6}, {1. / 24, -1. / 12, 1. / 6}, {0, 0, 1}};
+        const float* g = w + ((size_t)co * Cin + ci) * R * R;
+        const double G3[6][3] = {{1. / 4, 0, 0}, {-1. / 6, -1. / 6, -1. / 6}, {-1. / 6, 1. / 6, -1. / 6}, {1. / 24, 1. / 12, 1. / 6}, {1. / 24, -1. / 12, 1. / 6}, {0, 0, 1}};
+        const double G5[6][5] = {{1. / 4, 0, 0, 0, 0}, {-1. / 6, -1. / 6, -1. / 6, -1. / 6, -1. / 6}, {-1. / 6, 1. / 6, -1. / 6, 1. / 6, -1. / 6},
+                                 {1. / 24, 1. / 12, 1. / 6, 1. / 3, 2. / 3}, {1. / 24, -1. / 12, 1. / 6, -1. / 3, 2. / 3}, {0, 0, 0, 0, 1}};
         const int ai = xi / 6, bi = xi % 6;
         double s = 0;
-        for (int p = 0; p < 3; ++p) for (int q = 0; q < 3; ++q) s += G[ai][p] * (double)g[p * 3 + q] * G[bi][q];
+        for (int p = 0; p < R; ++p) for (int q = 0; q < R; ++q) s += (R == 3 ? G3[ai][p] * G3[bi][q] : G5[ai][p] * G5[bi][q]) * (double)g[p * R + q];
         if (gamma) s *= (double)gamma[co] / sqrt((double)var[co] + (double)eps);
         v = (float)s;
     }
@@ -233,22 +248,22 @@ extern "C" size_t cnm_packed_winograd4_floats(int Cout, int Cin) {
     return (size_t)nchunks * 36 * Cout * 16;
 }
 
-extern "C" int cnm_pack_winograd4_bn_f32(const float* w_oihw, const float* bn_gamma, const float* bn_var, float eps,
-                                         int Cout, int Cin, int rot, float* u_packed, void* stream) {
+static int pack36(const float* w_oihw, const float* bn_gamma, const float* bn_var, float eps, int Cout, int Cin, int ksize, int rot,
+                  float* u_packed, void* stream) {
     CNM_REQUIRE(w_oihw && u_packed && Cout > 0 && Cout % 64 == 0 && Cin > 0 && rot >= 0 && rot < Cin, CNM_ERR_BAD_ARG);
     CNM_REQUIRE(!bn_gamma == !bn_var, CNM_ERR_BAD_ARG);
     const int nchunks = (4 * ((Cin + 3) / 4) + 15) / 16;
     const long long total = (long long)nchunks * 36 * Cout * 16;
-    pack_winograd4_kernel<<<(unsigned)cnm_ceil_div_ll(total, 256), 256, 0, cnm_stream(stream)>>>(w_oihw, bn_gamma, bn_var, eps, Cout, Cin, rot, nchunks, u_packed);
+    const unsigned nb = (unsigned)cnm_ceil_div_ll(total, 256);
+    if (ksize == 3) pack_winograd36_kernel<3><<<nb, 256, 0, cnm_stream(stream)>>>(w_oihw, bn_gamma, bn_var, eps, Cout, Cin, rot, nchunks, u_packed);
+    else pack_winograd36_kernel<5><<<nb, 256, 0, cnm_stream(stream)>>>(w_oihw, bn_gamma, bn_var, eps, Cout, Cin, rot, nchunks, u_packed);
     CNM_LAUNCH_CHECK();
     return CNM_OK;
 }
 
-extern "C" int cnm_conv3x3_winograd4_c4_f32(const float* in_a, int Ga_total, int ga0, int Ga,
-                                            const float* in_b, int Gb_total, int gb0, int Gb,
-                                            float* out, int Gout_total, int gout0, int Cout,
-                                            const float* u_packed, const float* b_packed,
-                                            int N, int H, int W, int relu, void* stream) {
+static int conv36(const float* in_a, int Ga_total, int ga0, int Ga, const float* in_b, int Gb_total, int gb0, int Gb,
+                  float* out, int Gout_total, int gout0, int Cout, const float* u_packed, const float* b_packed,
+                  int N, int H, int W, int ksize, int relu, void* stream) {
     CNM_REQUIRE(in_a && out && u_packed && N > 0 && H > 0 && W > 0 && Ga > 0 && Gb >= 0, CNM_ERR_BAD_ARG);
     CNM_REQUIRE(Cout > 0 && Cout % 64 == 0 && gout0 >= 0 && gout0 + Cout / 4 <= Gout_total, CNM_ERR_BAD_ARG);
     CNM_REQUIRE(ga0 >= 0 && ga0 + Ga <= Ga_total && (Gb == 0 || (in_b && gb0 >= 0 && gb0 + Gb <= Gb_total)), CNM_ERR_BAD_ARG);
@@ -258,12 +273,41 @@ extern "C" int cnm_conv3x3_winograd4_c4_f32(const float* in_a, int Ga_total, int
     const unsigned long long b2 = Gb ? (unsigned long long)N * Gb_total * H * W * 16ull : b1;
     CNM_REQUIRE(b1 < 0xFFFFFFFFull && b2 < 0xFFFFFFFFull, CNM_ERR_BAD_ARG);
     a.in_bytes = (unsigned)b1; a.in2_bytes = (unsigned)b2;
-    a.N = N; a.H = H; a.W = W; a.TH = (H + 3) / 4; a.TW = (W + 3) / 4;
+    const int m = ksize == 3 ? 4 : 2;                                    // outputs per tile side
+    a.N = N; a.H = H; a.W = W; a.TH = (H + m - 1) / m; a.TW = (W + m - 1) / m;
     a.Gin_tot = Ga_total; a.gin0 = ga0; a.Gin2_tot = Gb ? Gb_total : Ga_total; a.gin2_0 = Gb ? gb0 : ga0; a.Gsplit = Ga; a.Gin = Ga + Gb;
     a.Gout_tot = Gout_total; a.gout0 = gout0; a.Cout = Cout;
     a.nchunks = (4 * a.Gin + 15) / 16; a.T = N * a.TH * a.TW; a.relu = relu;
     const int nblocks = (Cout / 64) * cnm_ceil_div(a.T, 16);
-    conv3x3_winograd4_f32_kernel<<<nblocks, 256, 0, cnm_stream(stream)>>>(a);
+    if (ksize == 3) conv_winograd36_f32_kernel<4, 3><<<nblocks, 256, 0, cnm_stream(stream)>>>(a);
+    else conv_winograd36_f32_kernel<2, 5><<<nblocks, 256, 0, cnm_stream(stream)>>>(a);
     CNM_LAUNCH_CHECK();
     return CNM_OK;
+}
+
+extern "C" int cnm_pack_winograd4_bn_f32(const float* w_oihw, const float* bn_gamma, const float* bn_var, float eps,
+                                         int Cout, int Cin, int rot, float* u_packed, void* stream) {
+    return pack36(w_oihw, bn_gamma, bn_var, eps, Cout, Cin, 3, rot, u_packed, stream);
+}
+
+extern "C" int cnm_conv3x3_winograd4_c4_f32(const float* in_a, int Ga_total, int ga0, int Ga,
+                                            const float* in_b, int Gb_total, int gb0, int Gb,
+                                            float* out, int Gout_total, int gout0, int Cout,
+                                            const float* u_packed, const float* b_packed,
+                                            int N, int H, int W, int relu, void* stream) {
+    return conv36(in_a, Ga_total, ga0, Ga, in_b, Gb_total, gb0, Gb, out, Gout_total, gout0, Cout, u_packed, b_packed, N, H, W, 3, relu, stream);
+}
+
+// F(2x2,5x5): the same 36-point machine with 2x2 output tiles (25 -> 9 multiplies per output; the row-wise kernel needs 15)
+extern "C" int cnm_pack_winograd5x5_bn_f32(const float* w_oihw, const float* bn_gamma, const float* bn_var, float eps,
+                                           int Cout, int Cin, int rot, float* u_packed, void* stream) {
+    return pack36(w_oihw, bn_gamma, bn_var, eps, Cout, Cin, 5, rot, u_packed, stream);
+}
+
+extern "C" int cnm_conv5x5_winograd_c4_f32(const float* in_a, int Ga_total, int ga0, int Ga,
+                                           const float* in_b, int Gb_total, int gb0, int Gb,
+                                           float* out, int Gout_total, int gout0, int Cout,
+                                           const float* u_packed, const float* b_packed,
+                                           int N, int H, int W, int relu, void* stream) {
+    return conv36(in_a, Ga_total, ga0, Ga, in_b, Gb_total, gb0, Gb, out, Gout_total, gout0, Cout, u_packed, b_packed, N, H, W, 5, relu, stream);
 }

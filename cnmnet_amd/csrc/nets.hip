@@ -82,8 +82,8 @@ int cnm_planesweep_cat_c8_f16(const float*, const float*, const float*, void*, f
 // F(4x4,3x3) workgroups cover 64 couts x 16 tiles of 4x4 outputs: worth it only when they fill the chip twice over
 static int g_wino4_min_workgroups = CNM_WINO4_MIN_WORKGROUPS;         // the engine's only process-wide state: a tuning knob
 extern "C" int cnm_tune_wino4_min_workgroups(int n) { const int old = g_wino4_min_workgroups; if (n > 0) g_wino4_min_workgroups = n; return old; }
-static inline bool wino4_fills_chip(int Cout, int N, int H, int W) {
-    const long long tiles = (long long)N * ((H + 3) / 4) * ((W + 3) / 4);
+static inline bool wino4_fills_chip(int Cout, int N, int H, int W, int m = 4) {   // m x m outputs per tile
+    const long long tiles = (long long)N * ((H + m - 1) / m) * ((W + m - 1) / m);
     return (Cout / 64) * ((tiles + 15) / 16) >= g_wino4_min_workgroups;
 }
 
@@ -93,6 +93,8 @@ struct EngF32 {
         if (w.u4 && k == 3 && st == 1 && wino4_fills_chip(Cout, N, H, W))
             return cnm_conv3x3_winograd4_c4_f32(in, Gt, g0, Gin, nullptr, 0, 0, 0, out, Gto, go0, Cout, w.u4, w.b, N, H, W, 1, s);
         if (w.u && k == 3 && st == 1) return cnm_conv3x3_winograd_c4_f32(in, Gt, g0, Gin, nullptr, 0, 0, 0, out, Gto, go0, Cout, w.u, w.b, N, H, W, 1, s);
+        if (w.u4 && k == 5 && st == 1 && wino4_fills_chip(Cout, N, H, W, 2))
+            return cnm_conv5x5_winograd_c4_f32(in, Gt, g0, Gin, nullptr, 0, 0, 0, out, Gto, go0, Cout, w.u4, w.b, N, H, W, 1, s);
         if (w.u && (k == 5 || k == 7)) return cnm_conv_rows_winograd_c4_f32(in, Gt, g0, Gin, nullptr, 0, 0, 0, out, Gto, go0, Cout, w.u, w.b, N, H, W, k, st, 1, s);
         return cnm_conv2d_c4_f32(in, Gt, g0, Gin, out, Gto, go0, Cout, w.w, w.b, N, H, W, k, st, 1, s); }
     static int conv2(const float* a, int Ga, const float* b, int Gb, float* out, int Gto, int Cout, const cnm_layer_weights& w, int N, int H, int W, void* s) {

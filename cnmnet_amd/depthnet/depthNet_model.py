@@ -116,8 +116,9 @@ class _EngineNet(nn.Module):
                     packed.append((wp, bp))
                 else:
                     up = ops.pack_winograd(w, bnp, rot=L["rot"], eps=bn.eps, stride=L["stride"])
-                    # 3x3: also the F(4x4,3x3) filter; the executor picks per call by tile count (CNM_WINO4_MIN_WORKGROUPS)
-                    u4 = ops.pack_winograd4(w, bnp, rot=L["rot"], eps=bn.eps) if (L["ksize"] == 3 and self.winograd4) else None
+                    # 3x3 / 5x5 stride 1: also the 36-point filter (F(4x4,3x3) / F(2x2,5x5)); the executor picks per call by tile count
+                    u4 = (ops.pack_winograd4(w, bnp, rot=L["rot"], eps=bn.eps)
+                          if (L["ksize"] in (3, 5) and L["stride"] == 1 and self.winograd4) else None)
                     packed.append((wp, bp, up, u4))
         arr = (_lib.LayerWeights * len(packed))()
         for i, t in enumerate(packed):

@@ -219,26 +219,28 @@ def pack_winograd(weight, bn=None, rot=0, eps=1e-5, stride=1):
 
 
 def pack_winograd4(weight, bn=None, rot=0, eps=1e-5):
-    """3x3 weight [Cout,Cin,3,3] (+ BatchNorm gamma/var fold) -> F(4x4,3x3) Winograd-domain packed filter."""
+    """36-point Winograd-domain packed filter: 3x3 weight -> F(4x4,3x3); 5x5 weight -> F(2x2,5x5)."""
     _dev(weight, *(bn or ()))
     lib = _lib.load()
     Cout, Cin, k, _ = weight.shape
-    assert k == 3
+    assert k in (3, 5)
     up = torch.empty(lib.cnm_packed_winograd4_floats(Cout, Cin), device=weight.device, dtype=torch.float32)
     g, v = (_c(bn[0]), _c(bn[3])) if bn else (None, None)
+    fn = lib.cnm_pack_winograd4_bn_f32 if k == 3 else lib.cnm_pack_winograd5x5_bn_f32
     with torch.cuda.device(weight.device):
-        _lib.check(lib.cnm_pack_winograd4_bn_f32(_p(_c(weight)), _p(g), _p(v), eps, Cout, Cin, rot, _p(up), _stream()))
+        _lib.check(fn(_p(_c(weight)), _p(g), _p(v), eps, Cout, Cin, rot, _p(up), _stream()))
     return up
 
 
-def conv3x3_winograd4_c4(x, u_packed, b_packed, Cout, relu=True, x2=None):
-    """Winograd F(4x4,3x3) twin of conv2d_c4(ksize=3, stride=1)."""
+def conv3x3_winograd4_c4(x, u_packed, b_packed, Cout, relu=True, x2=None, ksize=3):
+    """36-point Winograd twin of conv2d_c4(stride=1): ksize 3 -> F(4x4,3x3), ksize 5 -> F(2x2,5x5)."""
     _dev(x, u_packed, b_packed, x2)
     N, G, H, W, _ = x.shape
     out = torch.empty(N, Cout // 4, H, W, 4, device=x.device, dtype=torch.float32)
     G2 = x2.shape[1] if x2 is not None else 0
+    fn = _lib.load().cnm_conv3x3_winograd4_c4_f32 if ksize == 3 else _lib.load().cnm_conv5x5_winograd_c4_f32
     with torch.cuda.device(x.device):
-        _lib.check(_lib.load().cnm_conv3x3_winograd4_c4_f32(_p(x), G, 0, G, _p(x2) if x2 is not None else None, G2, 0, G2,
+        _lib.check(fn(_p(x), G, 0, G, _p(x2) if x2 is not None else None, G2, 0, G2,
                                                             _p(out), Cout // 4, 0, Cout, _p(u_packed), _p(b_packed),
                                                             N, H, W, int(relu), _stream()))
     return out

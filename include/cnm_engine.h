@@ -141,6 +141,17 @@ int cnm_conv3x3_winograd4_c4_f32(const float* in_a, int Ga_total, int ga0, int G
                                  const float* u_packed, const float* b_packed,
                                  int N, int H, int W, int relu, void* stream);
 
+/* Winograd F(2x2,5x5) for the 5x5 stride-1 layer (conv2.0 = nn.Conv2d(128, 256, 5, 1, 2), depthNet_model.py:141-144):
+ * the 36-point machine of the F(4x4,3x3) kernel with 2x2 output tiles; 9 instead of 25 multiplies per output (the
+ * row-wise kernel: 15).  u_packed from cnm_pack_winograd5x5_bn_f32, size cnm_packed_winograd4_floats(Cout, Cin). */
+int cnm_pack_winograd5x5_bn_f32(const float* w_oihw, const float* bn_gamma, const float* bn_var, float eps,
+                                int Cout, int Cin, int rot, float* u_packed, void* stream);
+int cnm_conv5x5_winograd_c4_f32(const float* in_a, int Ga_total, int ga0, int Ga,
+                                const float* in_b, int Gb_total, int gb0, int Gb,
+                                float* out, int Gout_total, int gout0, int Cout,
+                                const float* u_packed, const float* b_packed,
+                                int N, int H, int W, int relu, void* stream);
+
 /* Row-wise Winograd twin of cnm_conv2d_cat2_c4_f32 for ksize R = 5 or 7, stride 1 or 2 (the reference's
  * conv1 = nn.Conv2d(3+D, 128, 7, 1, 3) / (128, 128, 7, 2, 3) and conv2 = nn.Conv2d(128, 256, 5, 1, 2) /
  * (256, 256, 5, 2, 2), depthNet_model.py:137-148 via conv_layer :77-86): the transform runs along image rows, the R
@@ -211,8 +222,9 @@ int cnm_net_layer(int net, int index, cnm_layer_info* info);   /* D=64 table */
  * cnm_pack_winograd_bn_f32 (3x3) / cnm_pack_winograd_rows_bn_f32 (5x5, 7x7) -- when non-NULL the fp32 executors
  * run that layer (3x3 stride 1; 5x5 / 7x7 stride 1 or 2) through cnm_conv3x3_winograd_c4_f32 /
  * cnm_conv_rows_winograd_c4_f32 (w may then be NULL); ignored by heads, 3x3 stride-2 layers and the fp16 engine.
- * u4: optional F(4x4,3x3) filter of cnm_pack_winograd4_bn_f32 for 3x3 stride-1 layers: used instead of u when the
- * layer has enough 4x4 tiles to fill the chip (>= CNM_WINO4_MIN_WORKGROUPS workgroups of 64 couts x 16 tiles). */
+ * u4: optional 36-point filter -- cnm_pack_winograd4_bn_f32 (F(4x4,3x3)) for 3x3 stride-1 layers,
+ * cnm_pack_winograd5x5_bn_f32 (F(2x2,5x5)) for 5x5 stride-1 layers: used instead of u when the layer has enough tiles
+ * to fill the chip (>= CNM_WINO4_MIN_WORKGROUPS workgroups of 64 couts x 16 tiles). */
 typedef struct cnm_layer_weights { const float* w; const float* b; const float* u; const float* u4; } cnm_layer_weights;
 
 /* depthNet.forward (depthNet_model.py:226-263) for P = B*S (ref,src) pairs.

@@ -207,6 +207,24 @@ def test_conv3x3_winograd4(dev, ops, cin, cout, rot, N, H, W):
     assert np.abs(got - want).max() < 2e-4 * max(np.abs(want).max(), 1.0), np.abs(got - want).max()
 
 
+@pytest.mark.parametrize("cin,cout,rot,N,H,W", [(128, 256, 0, 1, 16, 24), (6, 64, 0, 2, 7, 31), (35, 64, 3, 1, 9, 13), (8, 64, 0, 1, 1, 1), (64, 64, 0, 2, 40, 48)])
+def test_conv5x5_winograd(dev, ops, cin, cout, rot, N, H, W):
+    """Winograd F(2x2,5x5) (36-point kernel with 2x2 output tiles) twin of the 5x5 stride-1 conv+BN+ReLU."""
+    rng = np.random.default_rng(cin * 19 + H)
+    x = T(rng.standard_normal((N, cin, H, W)).astype(np.float32))
+    w = T((rng.standard_normal((cout, cin, 5, 5)) * (2.0 / (cin * 25)) ** 0.5).astype(np.float32))
+    bnp = [T(a.astype(np.float32)) for a in (rng.uniform(0.5, 1.5, cout), rng.normal(0, 0.2, cout), rng.normal(0, 0.2, cout), rng.uniform(0.5, 1.5, cout))]
+    sc = bnp[0].double() / torch.sqrt(bnp[3].double() + 1e-5)
+    want = F.relu(F.conv2d(x.double(), w.double(), padding=2) * sc[None, :, None, None] + (bnp[1].double() - bnp[2].double() * sc)[None, :, None, None]).numpy()
+    bnd = tuple(t.to(dev) for t in bnp)
+    _, bp = ops.pack_conv(w.to(dev), bnd, rot=rot)
+    up = ops.pack_winograd4(w.to(dev), bnd, rot=rot)
+    xr = torch.cat((x[:, rot:], x[:, :rot]), 1) if rot else x
+    got = ops.c4_to_nchw(ops.conv3x3_winograd4_c4(ops.nchw_to_c4(xr.to(dev)), up, bp, cout, True, ksize=5), cout).cpu().numpy()
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() < 2e-4 * max(np.abs(want).max(), 1.0), np.abs(got - want).max()
+
+
 def test_winograd4_networks_golden(dev, golden):
     """Both nets with EVERY 3x3 stride-1 layer forced through F(4x4,3x3) (the executors normally pick it only for layers
     with >= CNM_WINO4_MIN_WORKGROUPS workgroups, i.e. never at this 64x96 size) against the reference's golden outputs:

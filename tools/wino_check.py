@@ -26,16 +26,16 @@ for (N, Cin, Cout, H, W) in cases:
     x = torch.randn(N, Cin, H, W, device=dev)
     xc = ops.nchw_to_c4(x)
     wp, bp = ops.pack_conv(w, bn=bn)
-    up = ops.pack_winograd4(w, bn=bn) if (K == 3 and ALG == 4) else ops.pack_winograd(w, bn=bn, stride=ST)
+    up = ops.pack_winograd4(w, bn=bn) if (K in (3, 5) and ALG == 4) else ops.pack_winograd(w, bn=bn, stride=ST)
     y0 = ops.conv2d_c4(xc, wp, bp, Cout, K, ST, True)
-    y1 = ((ops.conv3x3_winograd4_c4(xc, up, bp, Cout, True) if ALG == 4 else ops.conv3x3_winograd_c4(xc, up, bp, Cout, True)) if K == 3 else ops.conv_rows_winograd_c4(xc, up, bp, Cout, K, True, stride=ST))
+    y1 = (ops.conv3x3_winograd4_c4(xc, up, bp, Cout, True, ksize=K) if (ALG == 4 and K in (3, 5)) else (ops.conv3x3_winograd_c4(xc, up, bp, Cout, True) if K == 3 else ops.conv_rows_winograd_c4(xc, up, bp, Cout, K, True, stride=ST)))
     ref = torch.nn.functional.conv2d(x.double(), w.double(), stride=ST, padding=K // 2)
     sc = (bn[0] / torch.sqrt(bn[3] + 1e-5)).double()
     ref = torch.relu(ref * sc[None, :, None, None] + (bn[1].double() - bn[2].double() * sc)[None, :, None, None])
     e0 = (ops.c4_to_nchw(y0).double() - ref).abs().max().item()
     e1 = (ops.c4_to_nchw(y1).double() - ref).abs().max().item()
     t0 = timeit(lambda: ops.conv2d_c4(xc, wp, bp, Cout, K, ST, True))
-    t1 = timeit(lambda: ((ops.conv3x3_winograd4_c4(xc, up, bp, Cout, True) if ALG == 4 else ops.conv3x3_winograd_c4(xc, up, bp, Cout, True)) if K == 3 else ops.conv_rows_winograd_c4(xc, up, bp, Cout, K, True, stride=ST)))
+    t1 = timeit(lambda: (ops.conv3x3_winograd4_c4(xc, up, bp, Cout, True, ksize=K) if (ALG == 4 and K in (3, 5)) else (ops.conv3x3_winograd_c4(xc, up, bp, Cout, True) if K == 3 else ops.conv_rows_winograd_c4(xc, up, bp, Cout, K, True, stride=ST))))
     fl = 2.0 * N * (H // ST) * (W // ST) * Cout * Cin * K * K
     print("N%d %4d->%3d %3dx%3d  direct err %.2e %.3f ms %.0f TF | wino err %.2e %.3f ms %.0f TF(eff)  x%.2f" %
           (N, Cin, Cout, H, W, e0, t0, fl / t0 / 1e9, e1, t1, fl / t1 / 1e9, t0 / t1), flush=True)
