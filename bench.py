@@ -90,7 +90,9 @@ def conv_kernel(L, m, m4=0):
     if k == 5 and s == 1 and L["Cout"] // 64 * -(-(m // 4) // 16) >= WINO4_MIN_WORKGROUPS:
         return "conv_winograd36_f32_kernel<2, 5>", 36.0 / 100.0          # F(2x2,5x5): 36 multiplies per 4 outputs instead of 100
     if k in (5, 7):                                                  # F(2,k) along rows; stride 2: two F(2,ceil(k/2)) column phases
-        return "conv_rows_winograd_f32_kernel<%d, %d>" % (k, s), ((k + 1) / (2.0 * k) if s == 1 else ((k + 1) // 2 + 1) / float(k))
+        if k == 7 and s == 1:
+            return "conv_rows_winograd_f32_kernel<7, 1, 4>", 10.0 / 28.0      # F(4,7): 10 multiplies per 4 outputs and kernel row instead of 28
+        return "conv_rows_winograd_f32_kernel<%d, %d, 2>" % (k, s), ((k + 1) / (2.0 * k) if s == 1 else ((k + 1) // 2 + 1) / float(k))
     return conv_tile(L["Cout"], m), 1.0
 
 

@@ -25,10 +25,10 @@ def _winograd_conv(x, weight, rot, stride=1):
     Cout, _, k, _ = weight.shape
     if k == 3 and _winograd4_fills_chip(x, Cout):                        # large layers: F(4x4,3x3)
         return ops.conv3x3_winograd4_c4(x, ops.pack_winograd4(weight, None, rot), None, Cout, relu=False)
-    up = ops.pack_winograd(weight, None, rot, stride=stride)
+    up = ops.pack_winograd(weight, None, rot, stride=stride, tile=2)    # training keeps the more accurate F(2,k) rows
     if k == 3:
         return ops.conv3x3_winograd_c4(x, up, None, Cout, relu=False)
-    return ops.conv_rows_winograd_c4(x, up, None, Cout, k, relu=False, stride=stride)
+    return ops.conv_rows_winograd_c4(x, up, None, Cout, k, relu=False, stride=stride, tile=2)
 
 
 WINOGRAD4_MIN_WORKGROUPS = 384   # same switch point as the inference executors (include/cnm_engine.h)

@@ -64,16 +64,45 @@ template <> struct RowWino<3> {
     static constexpr double G[4][3] = {{-1, 0, 0}, {1. / 2, 1. / 2, 1. / 2}, {1. / 2, -1. / 2, 1. / 2}, {0, 0, 1}};
 };
 
+// F(4,7), interpolation points 0, +-1, +-2, +-1/2, +-3/2, inf: 10 multiplies per 4 outputs and kernel row (conv1.0).
+// Measured fp32 error of the 1-D algorithm 2.5e-5 on O(1) outputs (F(2,7): 5.7e-6); tools/wino1d_matrices.py.
+template <> struct RowWino<74> {
+    static constexpr float BT[10][10] = {
+        {9. / 4, 0, -205. / 16, 0, 273. / 16, 0, -15. / 2, 0, 1, 0},
+        {0, -9. / 4, -9. / 4, 169. / 16, 169. / 16, -13. / 2, -13. / 2, 1, 1, 0}, {0, 9. / 4, -9. / 4, -169. / 16, 169. / 16, 13. / 2, -13. / 2, -1, 1, 0},
+        {0, -9. / 8, -9. / 16, 49. / 8, 49. / 16, -7, -7. / 2, 2, 1, 0}, {0, 9. / 8, -9. / 16, -49. / 8, 49. / 16, 7, -7. / 2, -2, 1, 0},
+        {0, -9. / 2, -9, 61. / 8, 61. / 4, -29. / 8, -29. / 4, 1. / 2, 1, 0}, {0, 9. / 2, -9, -61. / 8, 61. / 4, 29. / 8, -29. / 4, -1. / 2, 1, 0},
+        {0, -3. / 2, -1, 63. / 8, 21. / 4, -63. / 8, -21. / 4, 3. / 2, 1, 0}, {0, 3. / 2, -1, -63. / 8, 21. / 4, 63. / 8, -21. / 4, -3. / 2, 1, 0},
+        {0, 9. / 4, 0, -205. / 16, 0, 273. / 16, 0, -15. / 2, 0, 1}};
+    static constexpr float AT[4][10] = {{1, 1, 1, 1, 1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 1. / 2, -1. / 2, 3. / 2, -3. / 2, 0},
+                                        {0, 1, 1, 4, 4, 1. / 4, 1. / 4, 9. / 4, 9. / 4, 0}, {0, 1, -1, 8, -8, 1. / 8, -1. / 8, 27. / 8, -27. / 8, 1}};
+    static constexpr double G[10][7] = {
+        {4. / 9, 0, 0, 0, 0, 0, 0},
+        {8. / 45, 8. / 45, 8. / 45, 8. / 45, 8. / 45, 8. / 45, 8. / 45}, {8. / 45, -8. / 45, 8. / 45, -8. / 45, 8. / 45, -8. / 45, 8. / 45},
+        {2. / 315, 4. / 315, 8. / 315, 16. / 315, 32. / 315, 64. / 315, 128. / 315}, {2. / 315, -4. / 315, 8. / 315, -16. / 315, 32. / 315, -64. / 315, 128. / 315},
+        {-16. / 45, -8. / 45, -4. / 45, -2. / 45, -1. / 45, -1. / 90, -1. / 180}, {-16. / 45, 8. / 45, -4. / 45, 2. / 45, -1. / 45, 1. / 90, -1. / 180},
+        {-16. / 315, -8. / 105, -4. / 35, -6. / 35, -9. / 35, -27. / 70, -81. / 140}, {-16. / 315, 8. / 105, -4. / 35, 6. / 35, -9. / 35, 27. / 70, -81. / 140},
+        {0, 0, 0, 0, 0, 0, 1}};
+};
+
 // Stride 2: out[y][X] = sum_ky sum_p sum_j w[ky][2j + 2 START + p + R/2] in[2y + ky - R/2][2 (X + j + START) + p]: the
 // two column phases p of the input are stride-1 correlations with RT = ceil(R/2) taps (the shorter phase padded
 // with a zero tap), both transformed with the same F(2,RT) and accumulated in the same frequency-domain registers;
 // (RT+1) instead of R multiplies per two outputs and kernel row: 1.4x (R=7) / 1.25x (R=5) fewer MFMA flops.
-template <int R, int S> struct RowCfg {
+template <int R, int S, int M> struct RowCfg {                            // M outputs per tile (2, or 4 for the 7-tap stride-1 rows)
     static constexpr int RT = S == 1 ? R : (R + 1) / 2;                 // taps seen by the transform
-    static constexpr int NX = RT + 1;                                    // frequency points
+    static constexpr int NX = RT + M - 1;                                // frequency points
+    static constexpr int ID = M == 2 ? RT : 10 * RT + M;                // table key
+    static constexpr int NB = M == 2 ? 4 : 3;                            // 16-tile blocks per wave (accumulators: NX * NB * 4)
     static constexpr int START = -(RT / 2);                              // first window sample relative to the tile's first output (phase samples)
     static constexpr int NKP = R * S;                                    // (kernel row, column phase) pairs in the reduction
 };
+
+// output-transform coefficient AT[i][k]: the two-output tables store only row 1 (row 0 = 1 ... 1 0)
+template <int ID, int M> __device__ __forceinline__ constexpr float at_coef(int i, int k) {
+    if constexpr (M == 2) return i == 0 ? (k < (int)(sizeof(RowWino<ID>::AT1) / sizeof(float)) - 1 ? 1.f : 0.f) : RowWino<ID>::AT1[k];
+    else return RowWino<ID>::AT[i][k];
+}
 
 struct RowArgs {
     const float* in; const float* in2; float* out; const float* u; const float* bias;
@@ -84,11 +113,11 @@ struct RowArgs {
     int nchunks, T, relu;                // T = N*Ho*TW tiles
 };
 
-template <int R, int S>
+template <int R, int S, int M>
 __global__ __launch_bounds__(256, 2) void conv_rows_winograd_f32_kernel(const RowArgs a) {
-    using CF = RowCfg<R, S>;
-    using WM = RowWino<CF::RT>;
-    constexpr int NX = CF::NX, TT = 64, NG = (NX + 1) / 2;
+    using CF = RowCfg<R, S, M>;
+    using WM = RowWino<CF::ID>;
+    constexpr int NX = CF::NX, NB = CF::NB, TT = 16 * NB, NG = (NX + 1) / 2;
     constexpr int VBUF = NX * TT * 16;                                   // V[buf][xi][tile][16 k], slots XOR-swizzled with ((tile >> 2) & 3)
     __shared__ __attribute__((aligned(16))) float V[2 * VBUF];           // 64 KB (R = 7) / 48 KB (R = 5) / less for stride 2
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -100,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void conv_rows_winograd_f32_kernel(const Ro
     // ---- loader: thread = (tile tl, channel quad qd = wave of the chunk)
     const int tl = lane, qd = wave;
     const int tg = t0 + tl;
-    const bool tvalid = tg < a.T;
+    const bool tvalid = (tl < TT) & (tg < a.T);                         // TT = 48: the last 16 lanes of a wave carry no tile
     int img, py, ptx;
     { const int tt = tvalid ? tg : 0; img = tt / THW; const int rem = tt - img * THW; py = rem / a.TW; ptx = rem - py * a.TW; }
     // per-thread invariants of the window loads: x offset and x validity of the NX samples (per column phase for
@@ -111,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void conv_rows_winograd_f32_kernel(const Ro
     for (int p = 0; p < S; ++p)
 #pragma unroll
         for (int j = 0; j < NX; ++j) {
-            const int ix = S == 1 ? 2 * ptx - R / 2 + j : 2 * (2 * ptx + j + CF::START) + p;
+            const int ix = S == 1 ? M * ptx - R / 2 + j : 2 * (2 * ptx + j + CF::START) + p;
             xok[p][j] = tvalid & ((unsigned)ix < (unsigned)a.W); xoff[p][j] = (unsigned)ix * 16u;
         }
     float4 d[NX];
@@ -142,7 +171,22 @@ __global__ __launch_bounds__(256, 2) void conv_rows_winograd_f32_kernel(const Ro
     auto transform_group = [&](int grp, float* Vdst) {
         const f4p* x = reinterpret_cast<const f4p*>(&d[0]);
         f4p va, vb; int ka, kb = -1;
-        if constexpr (CF::RT == 7) {
+        if constexpr (CF::ID == 74) {                                    // 10 points: rows 0 / 9, then four +-p pairs (even / odd parts from the table)
+            f4p e = f4_mul(0.f, x[0]), o = e; bool fe = true, fo = true;
+            const int k = grp == 0 ? 0 : 2 * grp - 1;
+#pragma unroll
+            for (int j = 0; j < 10; ++j) {
+                const float cf = WM::BT[k][j];
+                if (cf == 0.f) continue;
+                if (grp == 0 || (j & 1) == 0) { e = fe ? f4_mul(cf, x[j]) : f4_fma(cf, x[j], e); fe = false; }
+                else { o = fo ? f4_mul(cf, x[j]) : f4_fma(cf, x[j], o); fo = false; }
+            }
+            if (grp == 0) {
+                va = e; ka = 0; kb = 9; bool f9 = true;
+#pragma unroll
+                for (int j = 0; j < 10; ++j) { const float cf = WM::BT[9][j]; if (cf == 0.f) continue; vb = f9 ? f4_mul(cf, x[j]) : f4_fma(cf, x[j], vb); f9 = false; }
+            } else { va = f4_add(e, o); vb = f4_sub(e, o); ka = k; kb = k + 1; }
+        } else if constexpr (CF::RT == 7) {
             if (grp == 0) { va = f4_fma(5.25f, f4_sub(x[2], x[4]), f4_sub(x[6], x[0])); vb = f4_fma(5.25f, f4_sub(x[3], x[5]), f4_sub(x[7], x[1])); ka = 0; kb = 7; }
             else {
                 f4p e, o;
@@ -168,15 +212,17 @@ __global__ __launch_bounds__(256, 2) void conv_rows_winograd_f32_kernel(const Ro
             if (grp == 0) { va = f4_sub(x[2], x[0]); vb = f4_sub(x[3], x[1]); ka = 0; kb = 3; }
             else { va = f4_add(x[1], x[2]); vb = f4_sub(x[2], x[1]); ka = 1; kb = 2; }
         }
-        *reinterpret_cast<f4p*>(Vdst + (size_t)ka * TT * 16 + wofs) = va;
-        if (kb >= 0) *reinterpret_cast<f4p*>(Vdst + (size_t)kb * TT * 16 + wofs) = vb;
+        if (TT == 64 || tl < TT) {
+            *reinterpret_cast<f4p*>(Vdst + (size_t)ka * TT * 16 + wofs) = va;
+            if (kb >= 0) *reinterpret_cast<f4p*>(Vdst + (size_t)kb * TT * 16 + wofs) = vb;
+        }
     };
 
-    f32x4 acc[NX][4];
+    f32x4 acc[NX][NB];
 #pragma unroll
     for (int x = 0; x < NX; ++x)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[x][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < NB; ++b) acc[x][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // weights in MFMA operand order: [chunk][cout/16][xi][lane][4], lane (i = l&15, kg = l>>4) = U[xi][co 16cb+i][k 16chunk+4kg+e]
     const int cb16 = cblk * 4 + wave, ncb16 = a.Cout / 16;
@@ -185,9 +231,10 @@ __global__ __launch_bounds__(256, 2) void conv_rows_winograd_f32_kernel(const Ro
     const int rtile = lane & 15, kg = lane >> 4;
     const int voff = rtile * 16 + (kg ^ ((rtile >> 2) & 3)) * 4;         // tile block tb adds tb*16 rows (same swizzle: 16 % 16 == 0)
 
-    float4 af[NX];                                                       // one whole chunk of weight fragments in flight
+    constexpr int WD = NX > 8 ? NX / 2 : NX;                             // weight fragments in flight: a whole chunk, half of one for 10 points (registers)
+    float4 af[WD];
 #pragma unroll
-    for (int x = 0; x < NX; ++x) af[x] = ubase[(size_t)x * 64];
+    for (int x = 0; x < WD; ++x) af[x] = ubase[(size_t)x * 64];
     gather_begin();                                                      // chunk 0
 #pragma unroll
     for (int j = 0; j < NX; ++j) gather_load(j);
@@ -200,24 +247,25 @@ __global__ __launch_bounds__(256, 2) void conv_rows_winograd_f32_kernel(const Ro
     for (int c = 0; c < a.nchunks; ++c) {
         const float* Vc = V + (c & 1) * VBUF;
         float* Vn = V + ((c + 1) & 1) * VBUF;
+        const float4* uc = ubase + (size_t)c * ustride;
         const float4* un = ubase + (size_t)(c + 1 < a.nchunks ? c + 1 : c) * ustride;
-        float4 bf[4];
+        float4 bf[NB];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) bf[b] = *reinterpret_cast<const float4*>(Vc + b * 16 * 16 + voff);
+        for (int b = 0; b < NB; ++b) bf[b] = *reinterpret_cast<const float4*>(Vc + b * 16 * 16 + voff);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int x = 0; x < NX; ++x) {                                   // one frequency point per step: 16 MFMAs
-            const float4 aw = af[x];
-            float4 bw[4];
+            const float4 aw = af[x % WD];
+            float4 bw[NB];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) bw[b] = bf[b];
+            for (int b = 0; b < NB; ++b) bw[b] = bf[b];
             if (x + 1 < NX) {
 #pragma unroll
-                for (int b = 0; b < 4; ++b) bf[b] = *reinterpret_cast<const float4*>(Vc + (size_t)(x + 1) * TT * 16 + b * 16 * 16 + voff);
+                for (int b = 0; b < NB; ++b) bf[b] = *reinterpret_cast<const float4*>(Vc + (size_t)(x + 1) * TT * 16 + b * 16 * 16 + voff);
             }
 #pragma unroll
-            for (int b = 0; b < 4; ++b) acc[x][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw.x, bw[b].x, acc[x][b], 0, 0, 0);
-            if (!(ROWS_ABL & 2)) af[x] = un[(size_t)x * 64];             // same slot of the next chunk
+            for (int b = 0; b < NB; ++b) acc[x][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw.x, bw[b].x, acc[x][b], 0, 0, 0);
+            if (!(ROWS_ABL & 2)) af[x % WD] = x + WD < NX ? uc[(size_t)(x + WD) * 64] : un[(size_t)(x + WD - NX) * 64];   // WD steps ahead (wraps into the next chunk)
             // between the MFMAs: one transform group of chunk c+1 per step, then (registers free) the windows of chunk
             // c+2, two loads per step (past the last chunk all out of range = 0, written to the idle buffer)
             if (!(ROWS_ABL & 4) && x < NG) transform_group(x, Vn);
@@ -228,55 +276,53 @@ __global__ __launch_bounds__(256, 2) void conv_rows_winograd_f32_kernel(const Ro
                 for (int l = LPS * (x - NG); l < LPS * (x - NG + 1) && l < NX; ++l) gather_load(l);
             }
 #pragma unroll
-            for (int b = 0; b < 4; ++b) acc[x][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw.y, bw[b].y, acc[x][b], 0, 0, 0);
+            for (int b = 0; b < NB; ++b) acc[x][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw.y, bw[b].y, acc[x][b], 0, 0, 0);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) acc[x][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw.z, bw[b].z, acc[x][b], 0, 0, 0);
+            for (int b = 0; b < NB; ++b) acc[x][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw.z, bw[b].z, acc[x][b], 0, 0, 0);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) acc[x][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw.w, bw[b].w, acc[x][b], 0, 0, 0);
+            for (int b = 0; b < NB; ++b) acc[x][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw.w, bw[b].w, acc[x][b], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         lds_barrier();                                                   // V[c+1] complete, V[c] free for chunk c+2
     }
 
-    // ---- epilogue: y0 = sum_{k<NX-1} M_k, y1 = sum_k AT1[k] M_k; acc row = cout 4*(lane>>4)+r (one c4 group), col = tile lane&15 (+16 tb)
+    // ---- epilogue: y_i = sum_k AT[i][k] M_k, i < M; acc row = cout 4*(lane>>4)+r (one c4 group), col = tile lane&15 (+16 tb)
     const int co = cblk * 64 + wave * 16 + 4 * kg;
     const float4 bias = a.bias ? *reinterpret_cast<const float4*>(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
     const float bb[4] = {bias.x, bias.y, bias.z, bias.w};
 #pragma unroll
-    for (int tb = 0; tb < 4; ++tb) {
+    for (int tb = 0; tb < NB; ++tb) {
         const int to = t0 + tb * 16 + rtile;
         if (to >= a.T) continue;
         const int oimg = to / THW, orem = to - oimg * THW, oy = orem / a.TW, otx = orem - oy * a.TW;
-        float y0[4], y1[4];
+        float* op = a.out + c4_offset(oimg, a.Gout_tot, a.gout0 + (co >> 2), HWo, oy * a.Wo + M * otx);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float s0 = 0.f, s1 = 0.f;
+        for (int i = 0; i < M; ++i) {
+            float y[4];
 #pragma unroll
-            for (int k = 0; k < NX; ++k) {
-                const float m = acc[k][tb][r];
-                if (k < NX - 1) s0 += m;
-                if (WM::AT1[k] != 0.f) s1 = fmaf(WM::AT1[k], m, s1);
+            for (int r = 0; r < 4; ++r) {
+                float sacc = bb[r];
+#pragma unroll
+                for (int k = 0; k < NX; ++k) {
+                    const float cf = at_coef<CF::ID, M>(i, k);
+                    if (cf == 1.f) sacc += acc[k][tb][r];
+                    else if (cf == -1.f) sacc -= acc[k][tb][r];
+                    else if (cf != 0.f) sacc = fmaf(cf, acc[k][tb][r], sacc);
+                }
+                y[r] = a.relu ? fmaxf(sacc, 0.f) : sacc;
             }
-            y0[r] = s0 + bb[r]; y1[r] = s1 + bb[r];
+            if (M * otx + i < a.Wo) *reinterpret_cast<float4*>(op + 4 * i) = make_float4(y[0], y[1], y[2], y[3]);
         }
-        float4 v0 = make_float4(y0[0], y0[1], y0[2], y0[3]), v1 = make_float4(y1[0], y1[1], y1[2], y1[3]);
-        if (a.relu) {
-            v0.x = fmaxf(v0.x, 0.f); v0.y = fmaxf(v0.y, 0.f); v0.z = fmaxf(v0.z, 0.f); v0.w = fmaxf(v0.w, 0.f);
-            v1.x = fmaxf(v1.x, 0.f); v1.y = fmaxf(v1.y, 0.f); v1.z = fmaxf(v1.z, 0.f); v1.w = fmaxf(v1.w, 0.f);
-        }
-        float* op = a.out + c4_offset(oimg, a.Gout_tot, a.gout0 + (co >> 2), HWo, oy * a.Wo + 2 * otx);
-        *reinterpret_cast<float4*>(op) = v0;
-        if (2 * otx + 1 < a.Wo) *reinterpret_cast<float4*>(op + 4) = v1;
     }
 }
 
 // U[xi][co][k = 4*(kp*Gin4 + g) + e] = (sum_j G[xi][j] w'[co][ci][kp][j]) * BN scale, in MFMA A-operand order
 // [chunk][cout/16][xi][lane][4]:  co = cb*16 + (lane&15), k = chunk*16 + 4*(lane>>4) + e.  Stride 1: kp = kernel row,
 // w' = the row's taps; stride 2: kp = (kernel row, column phase), w' = that phase's taps (zero where it has none).
-template <int R, int S>
+template <int R, int S, int M>
 __global__ void pack_rows_winograd_kernel(const float* __restrict__ w, const float* __restrict__ gamma, const float* __restrict__ var,
                                           float eps, int Cout, int Cin, int rot, int nchunks, float* __restrict__ up) {
-    using CF = RowCfg<R, S>;
+    using CF = RowCfg<R, S, M>;
     constexpr int NX = CF::NX;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int ncb16 = Cout / 16, Gin4 = (Cin + 3) / 4;
@@ -297,7 +343,7 @@ __global__ void pack_rows_winograd_kernel(const float* __restrict__ w, const flo
         double s = 0;
         for (int j = 0; j < CF::RT; ++j) {
             const int kx = S == 1 ? j : 2 * j + 2 * CF::START + ph + R / 2;
-            if (kx >= 0 && kx < R) s += RowWino<CF::RT>::G[xi][j] * (double)g[kx];
+            if (kx >= 0 && kx < R) s += RowWino<CF::ID>::G[xi][j] * (double)g[kx];
         }
         if (gamma) s *= (double)gamma[co] / sqrt((double)var[co] + (double)eps);
         v = (float)s;
@@ -306,24 +352,25 @@ __global__ void pack_rows_winograd_kernel(const float* __restrict__ w, const flo
 }
 
 static int rows_chunks(int Cin, int ksize, int stride) { return (ksize * stride * ((Cin + 3) / 4) + 3) / 4; }
-static int rows_points(int ksize, int stride) { return (stride == 1 ? ksize : (ksize + 1) / 2) + 1; }
+static bool rows_tile_ok(int ksize, int stride, int tile) { return tile == 2 || (tile == 4 && ksize == 7 && stride == 1); }   // outputs per tile: F(4,7) exists for the 7-tap stride-1 rows
+static int rows_points(int ksize, int stride, int tile) { return (stride == 1 ? ksize : (ksize + 1) / 2) + tile - 1; }
 
-extern "C" size_t cnm_packed_winograd_rows_floats(int Cout, int Cin, int ksize, int stride) {
-    if (Cout <= 0 || Cin <= 0 || Cout % 64 || (ksize != 5 && ksize != 7) || (stride != 1 && stride != 2)) return 0;
-    return (size_t)rows_chunks(Cin, ksize, stride) * rows_points(ksize, stride) * Cout * 16;
+extern "C" size_t cnm_packed_winograd_rows_floats(int Cout, int Cin, int ksize, int stride, int tile) {
+    if (Cout <= 0 || Cin <= 0 || Cout % 64 || (ksize != 5 && ksize != 7) || (stride != 1 && stride != 2) || !rows_tile_ok(ksize, stride, tile)) return 0;
+    return (size_t)rows_chunks(Cin, ksize, stride) * rows_points(ksize, stride, tile) * Cout * 16;
 }
 
 extern "C" int cnm_pack_winograd_rows_bn_f32(const float* w_oihw, const float* bn_gamma, const float* bn_var, float eps,
-                                             int Cout, int Cin, int ksize, int stride, int rot, float* u_packed, void* stream) {
+                                             int Cout, int Cin, int ksize, int stride, int tile, int rot, float* u_packed, void* stream) {
     CNM_REQUIRE(w_oihw && u_packed && Cout > 0 && Cout % 64 == 0 && Cin > 0 && rot >= 0 && rot < Cin, CNM_ERR_BAD_ARG);
-    CNM_REQUIRE((ksize == 5 || ksize == 7) && (stride == 1 || stride == 2) && !bn_gamma == !bn_var, CNM_ERR_BAD_ARG);
+    CNM_REQUIRE((ksize == 5 || ksize == 7) && (stride == 1 || stride == 2) && rows_tile_ok(ksize, stride, tile) && !bn_gamma == !bn_var, CNM_ERR_BAD_ARG);
     const int nchunks = rows_chunks(Cin, ksize, stride);
-    const long long total = (long long)nchunks * rows_points(ksize, stride) * Cout * 16;
+    const long long total = (long long)nchunks * rows_points(ksize, stride, tile) * Cout * 16;
     const unsigned nb = (unsigned)cnm_ceil_div_ll(total, 256);
     hipStream_t st = cnm_stream(stream);
-#define CNM_PACK_ROWS(R, S) pack_rows_winograd_kernel<R, S><<<nb, 256, 0, st>>>(w_oihw, bn_gamma, bn_var, eps, Cout, Cin, rot, nchunks, u_packed)
-    if (ksize == 5 && stride == 1) CNM_PACK_ROWS(5, 1); else if (ksize == 5) CNM_PACK_ROWS(5, 2);
-    else if (stride == 1) CNM_PACK_ROWS(7, 1); else CNM_PACK_ROWS(7, 2);
+#define CNM_PACK_ROWS(R, S, M) pack_rows_winograd_kernel<R, S, M><<<nb, 256, 0, st>>>(w_oihw, bn_gamma, bn_var, eps, Cout, Cin, rot, nchunks, u_packed)
+    if (ksize == 5 && stride == 1) CNM_PACK_ROWS(5, 1, 2); else if (ksize == 5) CNM_PACK_ROWS(5, 2, 2);
+    else if (stride == 1 && tile == 4) CNM_PACK_ROWS(7, 1, 4); else if (stride == 1) CNM_PACK_ROWS(7, 1, 2); else CNM_PACK_ROWS(7, 2, 2);
 #undef CNM_PACK_ROWS
     CNM_LAUNCH_CHECK();
     return CNM_OK;
@@ -333,9 +380,9 @@ extern "C" int cnm_conv_rows_winograd_c4_f32(const float* in_a, int Ga_total, in
                                              const float* in_b, int Gb_total, int gb0, int Gb,
                                              float* out, int Gout_total, int gout0, int Cout,
                                              const float* u_packed, const float* b_packed,
-                                             int N, int H, int W, int ksize, int stride, int relu, void* stream) {
+                                             int N, int H, int W, int ksize, int stride, int tile, int relu, void* stream) {
     CNM_REQUIRE(in_a && out && u_packed && N > 0 && H > 0 && W > 0 && Ga > 0 && Gb >= 0 && (ksize == 5 || ksize == 7), CNM_ERR_BAD_ARG);
-    CNM_REQUIRE(stride == 1 || stride == 2, CNM_ERR_BAD_ARG);
+    CNM_REQUIRE((stride == 1 || stride == 2) && rows_tile_ok(ksize, stride, tile), CNM_ERR_BAD_ARG);
     CNM_REQUIRE(Cout > 0 && Cout % 64 == 0 && gout0 >= 0 && gout0 + Cout / 4 <= Gout_total, CNM_ERR_BAD_ARG);
     CNM_REQUIRE(ga0 >= 0 && ga0 + Ga <= Ga_total && (Gb == 0 || (in_b && gb0 >= 0 && gb0 + Gb <= Gb_total)), CNM_ERR_BAD_ARG);
     RowArgs a;
@@ -345,16 +392,18 @@ extern "C" int cnm_conv_rows_winograd_c4_f32(const float* in_a, int Ga_total, in
     CNM_REQUIRE(b1 < 0xFFFFFFFFull && b2 < 0xFFFFFFFFull, CNM_ERR_BAD_ARG);
     a.in_bytes = (unsigned)b1; a.in2_bytes = (unsigned)b2;
     const int pad = ksize / 2;
-    a.N = N; a.H = H; a.W = W; a.Ho = (H + 2 * pad - ksize) / stride + 1; a.Wo = (W + 2 * pad - ksize) / stride + 1; a.TW = (a.Wo + 1) / 2;
+    const int m = tile;
+    a.N = N; a.H = H; a.W = W; a.Ho = (H + 2 * pad - ksize) / stride + 1; a.Wo = (W + 2 * pad - ksize) / stride + 1; a.TW = (a.Wo + m - 1) / m;
     a.Gin_tot = Ga_total; a.gin0 = ga0; a.Gin2_tot = Gb ? Gb_total : Ga_total; a.gin2_0 = Gb ? gb0 : ga0; a.Gsplit = Ga; a.Gin = Ga + Gb;
     a.Gout_tot = Gout_total; a.gout0 = gout0; a.Cout = Cout;
     a.nchunks = (ksize * stride * a.Gin + 3) / 4; a.T = N * a.Ho * a.TW; a.relu = relu;
-    const int nblocks = (Cout / 64) * cnm_ceil_div(a.T, 64);
+    const int nblocks = (Cout / 64) * cnm_ceil_div(a.T, m == 4 ? 48 : 64);
     hipStream_t st = cnm_stream(stream);
-    if (ksize == 5 && stride == 1) conv_rows_winograd_f32_kernel<5, 1><<<nblocks, 256, 0, st>>>(a);
-    else if (ksize == 5) conv_rows_winograd_f32_kernel<5, 2><<<nblocks, 256, 0, st>>>(a);
-    else if (stride == 1) conv_rows_winograd_f32_kernel<7, 1><<<nblocks, 256, 0, st>>>(a);
-    else conv_rows_winograd_f32_kernel<7, 2><<<nblocks, 256, 0, st>>>(a);
+    if (ksize == 5 && stride == 1) conv_rows_winograd_f32_kernel<5, 1, 2><<<nblocks, 256, 0, st>>>(a);
+    else if (ksize == 5) conv_rows_winograd_f32_kernel<5, 2, 2><<<nblocks, 256, 0, st>>>(a);
+    else if (stride == 1 && tile == 4) conv_rows_winograd_f32_kernel<7, 1, 4><<<nblocks, 256, 0, st>>>(a);
+    else if (stride == 1) conv_rows_winograd_f32_kernel<7, 1, 2><<<nblocks, 256, 0, st>>>(a);
+    else conv_rows_winograd_f32_kernel<7, 2, 2><<<nblocks, 256, 0, st>>>(a);
     CNM_LAUNCH_CHECK();
     return CNM_OK;
 }

@@ -200,21 +200,27 @@ def conv2d_c4(x, w_packed, b_packed, Cout, ksize, stride=1, relu=True, x2=None):
     return out
 
 
-def pack_winograd(weight, bn=None, rot=0, eps=1e-5, stride=1):
+def rows_tile(ksize, stride, fast=True):
+    """Outputs per tile of the row-wise Winograd kernels: 4 (F(4,7)) for the 7-tap stride-1 rows when `fast`, else 2."""
+    return 4 if (fast and ksize == 7 and stride == 1) else 2
+
+
+def pack_winograd(weight, bn=None, rot=0, eps=1e-5, stride=1, tile=None):
     """weight [Cout,Cin,k,k] (+ BatchNorm gamma/var fold) -> Winograd-domain packed filter:
     k = 3 (stride 1): F(2x2,3x3); k = 5, 7 (stride 1 or 2): row-wise F(2,k) / two F(2,ceil(k/2)) column phases."""
     _dev(weight, *(bn or ()))
     lib = _lib.load()
     Cout, Cin, k, _ = weight.shape
     assert k in (3, 5, 7) and (stride == 1 or (stride == 2 and k != 3))
-    n = lib.cnm_packed_winograd_floats(Cout, Cin) if k == 3 else lib.cnm_packed_winograd_rows_floats(Cout, Cin, k, stride)
+    tile = rows_tile(k, stride) if tile is None else tile
+    n = lib.cnm_packed_winograd_floats(Cout, Cin) if k == 3 else lib.cnm_packed_winograd_rows_floats(Cout, Cin, k, stride, tile)
     up = torch.empty(n, device=weight.device, dtype=torch.float32)
     g, v = (_c(bn[0]), _c(bn[3])) if bn else (None, None)
     with torch.cuda.device(weight.device):
         if k == 3:
             _lib.check(lib.cnm_pack_winograd_bn_f32(_p(_c(weight)), _p(g), _p(v), eps, Cout, Cin, rot, _p(up), _stream()))
         else:
-            _lib.check(lib.cnm_pack_winograd_rows_bn_f32(_p(_c(weight)), _p(g), _p(v), eps, Cout, Cin, k, stride, rot, _p(up), _stream()))
+            _lib.check(lib.cnm_pack_winograd_rows_bn_f32(_p(_c(weight)), _p(g), _p(v), eps, Cout, Cin, k, stride, tile, rot, _p(up), _stream()))
     return up
 
 
@@ -246,18 +252,19 @@ def conv3x3_winograd4_c4(x, u_packed, b_packed, Cout, relu=True, x2=None, ksize=
     return out
 
 
-def conv_rows_winograd_c4(x, u_packed, b_packed, Cout, ksize, relu=True, x2=None, stride=1):
+def conv_rows_winograd_c4(x, u_packed, b_packed, Cout, ksize, relu=True, x2=None, stride=1, tile=None):
     """Row-wise Winograd twin of conv2d_c4(ksize=5|7, stride=1|2)."""
     _dev(x, u_packed, b_packed, x2)
     N, G, H, W, _ = x.shape
     pad = ksize // 2
+    tile = rows_tile(ksize, stride) if tile is None else tile
     Ho, Wo = (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1
     out = torch.empty(N, Cout // 4, Ho, Wo, 4, device=x.device, dtype=torch.float32)
     G2 = x2.shape[1] if x2 is not None else 0
     with torch.cuda.device(x.device):
         _lib.check(_lib.load().cnm_conv_rows_winograd_c4_f32(_p(x), G, 0, G, _p(x2) if x2 is not None else None, G2, 0, G2,
                                                              _p(out), Cout // 4, 0, Cout, _p(u_packed), _p(b_packed),
-                                                             N, H, W, ksize, stride, int(relu), _stream()))
+                                                             N, H, W, ksize, stride, tile, int(relu), _stream()))
     return out
 
 
