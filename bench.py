@@ -92,7 +92,9 @@ def conv_kernel(L, m, m4=0):
     if k in (5, 7):                                                  # F(2,k) along rows; stride 2: two F(2,ceil(k/2)) column phases
         if k == 7 and s == 1:
             return "conv_rows_winograd_f32_kernel<7, 1, 4>", 10.0 / 28.0      # F(4,7): 10 multiplies per 4 outputs and kernel row instead of 28
-        return "conv_rows_winograd_f32_kernel<%d, %d, 2>" % (k, s), ((k + 1) / (2.0 * k) if s == 1 else ((k + 1) // 2 + 1) / float(k))
+        if s == 2:                                                   # two column phases x F(4,ceil(k/2)): (ceil(k/2)+3)/2 multiplies per output and kernel row
+            return "conv_rows_winograd_f32_kernel<%d, 2, 4>" % k, ((k + 1) // 2 + 3) / 2.0 / k
+        return "conv_rows_winograd_f32_kernel<%d, %d, 2>" % (k, s), (k + 1) / (2.0 * k)
     return conv_tile(L["Cout"], m), 1.0
 
 

@@ -85,6 +85,21 @@ template <> struct RowWino<74> {
         {0, 0, 0, 0, 0, 0, 1}};
 };
 
+// F(4,4), interpolation points 0, +-1, +-1/2, 2, inf (column phases of the 7-tap stride-2 rows, 4 outputs per tile)
+template <> struct RowWino<44> {
+    static constexpr float BT[7][7] = {{-1. / 2, 1. / 4, 5. / 2, -5. / 4, -2, 1, 0}, {0, 1. / 2, 1. / 4, -9. / 4, -1, 1, 0}, {0, -1. / 2, 3. / 4, 7. / 4, -3, 1, 0},
+                                       {0, 1, 3. / 2, -2, -3. / 2, 1, 0}, {0, -1, 5. / 2, 0, -5. / 2, 1, 0}, {0, 1. / 4, 0, -5. / 4, 0, 1, 0},
+                                       {0, -1. / 2, 1. / 4, 5. / 2, -5. / 4, -2, 1}};
+    static constexpr float AT[4][7] = {{1, 1, 1, 1, 1, 1, 0}, {0, 1, -1, 1. / 2, -1. / 2, 2, 0}, {0, 1, 1, 1. / 4, 1. / 4, 4, 0}, {0, 1, -1, 1. / 8, -1. / 8, 8, 1}};
+    static constexpr double G[7][4] = {{-2, 0, 0, 0}, {-2. / 3, -2. / 3, -2. / 3, -2. / 3}, {-2. / 9, 2. / 9, -2. / 9, 2. / 9}, {16. / 9, 8. / 9, 4. / 9, 2. / 9},
+                                       {16. / 15, -8. / 15, 4. / 15, -2. / 15}, {2. / 45, 4. / 45, 8. / 45, 16. / 45}, {0, 0, 0, 1}};
+};
+// F(4,3), interpolation points 0, +-1, +-2, inf (column phases of the 5-tap stride-2 rows, 4 outputs per tile; B^T of F(2,5))
+template <> struct RowWino<34> {
+    static constexpr float AT[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
+    static constexpr double G[6][3] = {{1. / 4, 0, 0}, {-1. / 6, -1. / 6, -1. / 6}, {-1. / 6, 1. / 6, -1. / 6}, {1. / 24, 1. / 12, 1. / 6}, {1. / 24, -1. / 12, 1. / 6}, {0, 0, 1}};
+};
+
 // Stride 2: out[y][X] = sum_ky sum_p sum_j w[ky][2j + 2 START + p + R/2] in[2y + ky - R/2][2 (X + j + START) + p]: the
 // two column phases p of the input are stride-1 correlations with RT = ceil(R/2) taps (the shorter phase padded
 // with a zero tap), both transformed with the same F(2,RT) and accumulated in the same frequency-domain registers;
@@ -93,7 +108,7 @@ template <int R, int S, int M> struct RowCfg {                            // M o
     static constexpr int RT = S == 1 ? R : (R + 1) / 2;                 // taps seen by the transform
     static constexpr int NX = RT + M - 1;                                // frequency points
     static constexpr int ID = M == 2 ? RT : 10 * RT + M;                // table key
-    static constexpr int NB = M == 2 ? 4 : 3;                            // 16-tile blocks per wave (accumulators: NX * NB * 4)
+    static constexpr int NB = NX * 16 <= 128 ? 4 : 3;                    // 16-tile blocks per wave (accumulators: NX * NB * 4 <= 128)
     static constexpr int START = -(RT / 2);                              // first window sample relative to the tile's first output (phase samples)
     static constexpr int NKP = R * S;                                    // (kernel row, column phase) pairs in the reduction
 };
@@ -140,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void conv_rows_winograd_f32_kernel(const Ro
     for (int p = 0; p < S; ++p)
 #pragma unroll
         for (int j = 0; j < NX; ++j) {
-            const int ix = S == 1 ? M * ptx - R / 2 + j : 2 * (2 * ptx + j + CF::START) + p;
+            const int ix = S == 1 ? M * ptx - R / 2 + j : 2 * (M * ptx + j + CF::START) + p;
             xok[p][j] = tvalid & ((unsigned)ix < (unsigned)a.W); xoff[p][j] = (unsigned)ix * 16u;
         }
     float4 d[NX];
@@ -186,6 +201,14 @@ __global__ __launch_bounds__(256, 2) void conv_rows_winograd_f32_kernel(const Ro
 #pragma unroll
                 for (int j = 0; j < 10; ++j) { const float cf = WM::BT[9][j]; if (cf == 0.f) continue; vb = f9 ? f4_mul(cf, x[j]) : f4_fma(cf, x[j], vb); f9 = false; }
             } else { va = f4_add(e, o); vb = f4_sub(e, o); ka = k; kb = k + 1; }
+        } else if constexpr (CF::ID == 44) {                             // 7 points without +-p structure: rows straight from the table, two per step
+            auto row = [&](int k) { f4p v = f4_mul(0.f, x[0]); bool f = true;
+#pragma unroll
+                for (int j = 0; j < 7; ++j) { const float cf = WM::BT[k][j]; if (cf == 0.f) continue; v = f ? f4_mul(cf, x[j]) : f4_fma(cf, x[j], v); f = false; }
+                return v; };
+            if (grp == 0) { va = row(0); vb = row(6); ka = 0; kb = 6; }
+            else if (grp < 3) { va = row(2 * grp - 1); vb = row(2 * grp); ka = 2 * grp - 1; kb = 2 * grp; }
+            else { va = row(5); ka = 5; }
         } else if constexpr (CF::RT == 7) {
             if (grp == 0) { va = f4_fma(5.25f, f4_sub(x[2], x[4]), f4_sub(x[6], x[0])); vb = f4_fma(5.25f, f4_sub(x[3], x[5]), f4_sub(x[7], x[1])); ka = 0; kb = 7; }
             else {
@@ -195,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void conv_rows_winograd_f32_kernel(const Ro
                 else { e = f4_fma(4.f, x[2], f4_fma(-5.f, x[4], x[6])); o = f4_fma(2.f, x[1], f4_fma(-2.5f, x[3], f4_mul(0.5f, x[5]))); }
                 va = f4_add(e, o); vb = f4_sub(e, o); ka = 2 * grp - 1; kb = 2 * grp;
             }
-        } else if constexpr (CF::RT == 5) {
+        } else if constexpr (CF::ID == 5 || CF::ID == 34) {              // six points 0, +-1, +-2, inf: F(2,5) and F(4,3)
             if (grp == 0) { va = f4_fma(4.f, x[0], f4_fma(-5.f, x[2], x[4])); vb = f4_fma(4.f, x[1], f4_fma(-5.f, x[3], x[5])); ka = 0; kb = 5; }
             else {
                 f4p e, o;
@@ -352,7 +375,7 @@ __global__ void pack_rows_winograd_kernel(const float* __restrict__ w, const flo
 }
 
 static int rows_chunks(int Cin, int ksize, int stride) { return (ksize * stride * ((Cin + 3) / 4) + 3) / 4; }
-static bool rows_tile_ok(int ksize, int stride, int tile) { return tile == 2 || (tile == 4 && ksize == 7 && stride == 1); }   // outputs per tile: F(4,7) exists for the 7-tap stride-1 rows
+static bool rows_tile_ok(int ksize, int stride, int tile) { return tile == 2 || (tile == 4 && !(ksize == 5 && stride == 1)); }   // 4 outputs per tile: F(4,7), and the stride-2 phases F(4,4) / F(4,3)
 static int rows_points(int ksize, int stride, int tile) { return (stride == 1 ? ksize : (ksize + 1) / 2) + tile - 1; }
 
 extern "C" size_t cnm_packed_winograd_rows_floats(int Cout, int Cin, int ksize, int stride, int tile) {
@@ -369,8 +392,8 @@ extern "C" int cnm_pack_winograd_rows_bn_f32(const float* w_oihw, const float* b
     const unsigned nb = (unsigned)cnm_ceil_div_ll(total, 256);
     hipStream_t st = cnm_stream(stream);
 #define CNM_PACK_ROWS(R, S, M) pack_rows_winograd_kernel<R, S, M><<<nb, 256, 0, st>>>(w_oihw, bn_gamma, bn_var, eps, Cout, Cin, rot, nchunks, u_packed)
-    if (ksize == 5 && stride == 1) CNM_PACK_ROWS(5, 1, 2); else if (ksize == 5) CNM_PACK_ROWS(5, 2, 2);
-    else if (stride == 1 && tile == 4) CNM_PACK_ROWS(7, 1, 4); else if (stride == 1) CNM_PACK_ROWS(7, 1, 2); else CNM_PACK_ROWS(7, 2, 2);
+    if (ksize == 5 && stride == 1) CNM_PACK_ROWS(5, 1, 2); else if (ksize == 5 && tile == 4) CNM_PACK_ROWS(5, 2, 4); else if (ksize == 5) CNM_PACK_ROWS(5, 2, 2);
+    else if (stride == 1 && tile == 4) CNM_PACK_ROWS(7, 1, 4); else if (stride == 1) CNM_PACK_ROWS(7, 1, 2); else if (tile == 4) CNM_PACK_ROWS(7, 2, 4); else CNM_PACK_ROWS(7, 2, 2);
 #undef CNM_PACK_ROWS
     CNM_LAUNCH_CHECK();
     return CNM_OK;
@@ -397,12 +420,14 @@ extern "C" int cnm_conv_rows_winograd_c4_f32(const float* in_a, int Ga_total, in
     a.Gin_tot = Ga_total; a.gin0 = ga0; a.Gin2_tot = Gb ? Gb_total : Ga_total; a.gin2_0 = Gb ? gb0 : ga0; a.Gsplit = Ga; a.Gin = Ga + Gb;
     a.Gout_tot = Gout_total; a.gout0 = gout0; a.Cout = Cout;
     a.nchunks = (ksize * stride * a.Gin + 3) / 4; a.T = N * a.Ho * a.TW; a.relu = relu;
-    const int nblocks = (Cout / 64) * cnm_ceil_div(a.T, m == 4 ? 48 : 64);
+    const int nblocks = (Cout / 64) * cnm_ceil_div(a.T, (ksize == 7 && stride == 1 && m == 4) ? 48 : 64);
     hipStream_t st = cnm_stream(stream);
     if (ksize == 5 && stride == 1) conv_rows_winograd_f32_kernel<5, 1, 2><<<nblocks, 256, 0, st>>>(a);
+    else if (ksize == 5 && tile == 4) conv_rows_winograd_f32_kernel<5, 2, 4><<<nblocks, 256, 0, st>>>(a);
     else if (ksize == 5) conv_rows_winograd_f32_kernel<5, 2, 2><<<nblocks, 256, 0, st>>>(a);
     else if (stride == 1 && tile == 4) conv_rows_winograd_f32_kernel<7, 1, 4><<<nblocks, 256, 0, st>>>(a);
     else if (stride == 1) conv_rows_winograd_f32_kernel<7, 1, 2><<<nblocks, 256, 0, st>>>(a);
+    else if (tile == 4) conv_rows_winograd_f32_kernel<7, 2, 4><<<nblocks, 256, 0, st>>>(a);
     else conv_rows_winograd_f32_kernel<7, 2, 2><<<nblocks, 256, 0, st>>>(a);
     CNM_LAUNCH_CHECK();
     return CNM_OK;

@@ -201,8 +201,9 @@ def conv2d_c4(x, w_packed, b_packed, Cout, ksize, stride=1, relu=True, x2=None):
 
 
 def rows_tile(ksize, stride, fast=True):
-    """Outputs per tile of the row-wise Winograd kernels: 4 (F(4,7)) for the 7-tap stride-1 rows when `fast`, else 2."""
-    return 4 if (fast and ksize == 7 and stride == 1) else 2
+    """Outputs per tile of the row-wise Winograd kernels: 4 when `fast` (F(4,7); stride 2: F(4,4) / F(4,3) column phases)
+    except for the 5-tap stride-1 rows (that layer runs on the 36-point 2-D kernel), else 2."""
+    return 4 if (fast and not (ksize == 5 and stride == 1)) else 2
 
 
 def pack_winograd(weight, bn=None, rot=0, eps=1e-5, stride=1, tile=None):

@@ -157,9 +157,10 @@ int cnm_conv5x5_winograd_c4_f32(const float* in_a, int Ga_total, int ga0, int Ga
  * (256, 256, 5, 2, 2), depthNet_model.py:137-148 via conv_layer :77-86): the transform runs along image rows, the R
  * kernel rows stay in the GEMM reduction.  Stride 1: F(2,R), (R+1)/2 instead of R multiplies per output and kernel
  * row; stride 2: the two column phases of the input are F(2,ceil(R/2)) correlations accumulated together,
- * ceil(R/2)+1 instead of R multiplies.  tile = outputs per tile along the row: 2, or 4 for ksize 7 stride 1 (F(4,7):
- * 10 multiplies per 4 outputs and kernel row, 1.6x fewer than F(2,7); measured error 3e-4 on O(1) outputs against
- * 5e-5 for tile 2 -- the inference executors use it, the training path keeps tile 2).
+ * ceil(R/2)+1 instead of R multiplies.  tile = outputs per tile along the row: 2, or 4 (not for ksize 5 stride 1):
+ * F(4,7) -- 10 multiplies per 4 outputs and kernel row, 1.6x fewer than F(2,7), measured error 3e-4 on O(1) outputs
+ * against 5e-5 for tile 2 -- and F(4,4) / F(4,3) column phases for stride 2 (1.4x / 1.33x fewer than tile 2).  The
+ * inference executors use tile 4, the training path keeps tile 2.
  * u_packed from cnm_pack_winograd_rows_bn_f32 (same ksize, stride and tile). */
 size_t cnm_packed_winograd_rows_floats(int Cout, int Cin, int ksize, int stride, int tile);
 int cnm_pack_winograd_rows_bn_f32(const float* w_oihw, const float* bn_gamma, const float* bn_var, float eps,

@@ -172,8 +172,8 @@ def test_conv3x3_winograd(dev, ops, cin, cout, rot, N, H, W):
 def test_conv_rows_winograd(dev, ops, cin, cout, k, stride, rot, N, H, W, tile):
     """Row-wise Winograd twin of the 5x5 / 7x7 conv+BN+ReLU (stride 1: F(2,k); stride 2: two F(2,ceil(k/2)) column
     phases): odd sizes, ragged Cin, rotated first layer."""
-    if tile == 4 and not (k == 7 and stride == 1):
-        pytest.skip("F(4,k) exists for the 7-tap stride-1 rows only")
+    if tile == 4 and k == 5 and stride == 1:
+        pytest.skip("no 4-output tiles for the 5-tap stride-1 rows (that layer runs on the 36-point 2-D kernel)")
     rng = np.random.default_rng(cin * 13 + k)
     x = T(rng.standard_normal((N, cin, H, W)).astype(np.float32))
     w = T((rng.standard_normal((cout, cin, k, k)) * (2.0 / (cin * k * k)) ** 0.5).astype(np.float32))
