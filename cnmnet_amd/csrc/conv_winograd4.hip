@@ -24,10 +24,10 @@
 #define WINO4_ABL 0       // ablation bit mask for timing studies (results are wrong when set): 1 no gather, 2 no weight refill, 4 no transform, 8 windows from one line, 16 weights from one fragment
 #endif
 #ifndef WINO4_LPS
-#define WINO4_LPS 4      // window loads per step (divides 36)
+#define WINO4_LPS 4      // window loads per double step (divides 36; at most 12 double steps are available)
 #endif
 #ifndef WINO4_WD
-#define WINO4_WD 6        // weight fragments in flight per wave (divides 36; 9 and more spill)
+#define WINO4_WD 4        // weight fragments in flight per wave (even, divides 36; 6 and more spill)
 #endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -153,28 +153,42 @@ __global__ __launch_bounds__(256, 2) void conv_winograd36_f32_kernel(const Wino4
         float* Vn = V + ((c + 1) & 1) * VBUF;
         const float4* uc = ubase + (size_t)c * ustride;
         const float4* un = ubase + (size_t)(c + 1 < a.nchunks ? c + 1 : c) * ustride;
-        float4 bf = *reinterpret_cast<const float4*>(Vc + voff);
+        // double step xp = frequency points (2 xp, 2 xp + 1): their MFMAs alternate, so consecutive MFMAs never chain on
+        // the same accumulator (one 16-tile block per wave: a single point per step would be one dependent chain)
+        float4 bf0 = *reinterpret_cast<const float4*>(Vc + voff);
+        float4 bf1 = *reinterpret_cast<const float4*>(Vc + TT * 16 + voff);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int x = 0; x < NXI; ++x) {                                  // one frequency point per step: 4 MFMAs
-            const float4 aw = af[x % WD];
-            const float4 bw = bf;
-            if (x + 1 < NXI) bf = *reinterpret_cast<const float4*>(Vc + (size_t)(x + 1) * TT * 16 + voff);
-            acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw.x, bw.x, acc[x], 0, 0, 0);
-            if (WINO4_ABL & 16) af[x % WD] = ubase[0];
-            else if (!(WINO4_ABL & 2)) af[x % WD] = x + WD < NXI ? uc[(size_t)(x + WD) * 64] : un[(size_t)(x + WD - NXI) * 64];
-            // between the MFMAs: the transform of chunk c+1 (steps 0..11), then the window of chunk c+2 (WINO4_LPS loads
-            // per step; past the last chunk all out of range = 0, written to the idle buffer)
-            if (x < 6) { if (!(WINO4_ABL & 4)) column_pass(x); }
-            else if (x < 12) { if (!(WINO4_ABL & 4)) row_pass(x - 6, Vn); }
-            else if (x < 12 + 36 / WINO4_LPS && !(WINO4_ABL & 1)) {      // row-major (column-major issue order measured 5 % slower: worse line locality)
-                if (x == 12) gather_begin(c + 2);
-#pragma unroll
-                for (int l = WINO4_LPS * (x - 12); l < WINO4_LPS * (x - 11); ++l) gather_load(l);
+        for (int xp = 0; xp < NXI / 2; ++xp) {
+            const int x0 = 2 * xp, x1 = x0 + 1;
+            const float4 a0 = af[x0 % WD], a1 = af[x1 % WD];
+            const float4 b0 = bf0, b1 = bf1;
+            if (xp + 1 < NXI / 2) {
+                bf0 = *reinterpret_cast<const float4*>(Vc + (size_t)(x0 + 2) * TT * 16 + voff);
+                bf1 = *reinterpret_cast<const float4*>(Vc + (size_t)(x1 + 2) * TT * 16 + voff);
             }
-            acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw.y, bw.y, acc[x], 0, 0, 0);
-            acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw.z, bw.z, acc[x], 0, 0, 0);
-            acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw.w, bw.w, acc[x], 0, 0, 0);
+            acc[x0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc[x0], 0, 0, 0);
+            acc[x1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, acc[x1], 0, 0, 0);
+            if (WINO4_ABL & 16) { af[x0 % WD] = ubase[0]; af[x1 % WD] = ubase[0]; }
+            else if (!(WINO4_ABL & 2)) {
+                af[x0 % WD] = x0 + WD < NXI ? uc[(size_t)(x0 + WD) * 64] : un[(size_t)(x0 + WD - NXI) * 64];
+                af[x1 % WD] = x1 + WD < NXI ? uc[(size_t)(x1 + WD) * 64] : un[(size_t)(x1 + WD - NXI) * 64];
+            }
+            // between the MFMAs: the transform of chunk c+1 (double steps 0..5), then the window of chunk c+2 (WINO4_LPS
+            // loads per double step; past the last chunk all out of range = 0, written to the idle buffer)
+            if (xp < 3) { if (!(WINO4_ABL & 4)) { column_pass(2 * xp); column_pass(2 * xp + 1); } }
+            else if (xp < 6) { if (!(WINO4_ABL & 4)) { row_pass(2 * (xp - 3), Vn); row_pass(2 * (xp - 3) + 1, Vn); } }
+            else if (xp < 6 + 36 / WINO4_LPS && !(WINO4_ABL & 1)) {      // row-major (column-major issue order measured 5 % slower: worse line locality)
+                if (xp == 6) gather_begin(c + 2);
+#pragma unroll
+                for (int l = WINO4_LPS * (xp - 6); l < WINO4_LPS * (xp - 5); ++l) gather_load(l);
+            }
+            acc[x0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc[x0], 0, 0, 0);
+            acc[x1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, acc[x1], 0, 0, 0);
+            acc[x0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc[x0], 0, 0, 0);
+            acc[x1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, acc[x1], 0, 0, 0);
+            acc[x0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc[x0], 0, 0, 0);
+            acc[x1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, acc[x1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         lds_barrier4();                                                  // V[c+1] complete, V[c] free for chunk c+2
