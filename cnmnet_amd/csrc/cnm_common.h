@@ -11,18 +11,6 @@ static inline hipStream_t cnm_stream(void* s) { return reinterpret_cast<hipStrea
 static inline int cnm_ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline long long cnm_ceil_div_ll(long long a, long long b) { return (a + b - 1) / b; }
 
-// Compute units of the current device (grid size of the persistent kernels); queried once per device.
-static inline int cnm_num_cus() {
-    static int cached[16] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
-    if (!cached[dev]) {
-        int n = 0;
-        cached[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
-    }
-    return cached[dev];
-}
-
 // Offset (in floats) of element (n, g, pix, 0) of a c4 view [N][G_total][HW][4].
 __host__ __device__ static inline size_t c4_offset(int n, int G_total, int g, int HW, int pix) {
     return (((size_t)n * G_total + g) * (size_t)HW + pix) * 4;
