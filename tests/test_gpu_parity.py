@@ -409,6 +409,28 @@ def test_error_behaviour(dev):
         inverse_warp(x, x[:, 0], torch.zeros(1, 4, 4, device=dev), cam[:, 1, :3, :3], cam[:, 1, :3, :3])
 
 
+def test_winograd_api_argument_errors(dev):
+    """The Winograd entry points reject what they cannot run (negative status, nothing launched)."""
+    from cnmnet_amd import _lib
+    lib = _lib.load()
+    x = torch.zeros(1, 16, 8, 8, 4, device=dev); y = torch.zeros(1, 16, 8, 8, 4, device=dev); u = torch.zeros(1 << 20, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    bad = _lib.EngineError
+    assert lib.cnm_packed_winograd_floats(60, 64) == 0 and lib.cnm_packed_winograd4_floats(96, 8) == 0      # Cout % 64
+    assert lib.cnm_packed_winograd_rows_floats(64, 64, 3, 1, 2) == 0                                        # ksize 3 has no row kernel
+    assert lib.cnm_packed_winograd_rows_floats(64, 64, 5, 1, 4) == 0                                        # no 4-output tiles for 5x5 stride 1
+    assert lib.cnm_packed_winograd_rows_floats(64, 64, 7, 2, 4) > 0 and lib.cnm_packed_winograd_rows_floats(64, 64, 7, 3, 2) == 0
+    for call in (lambda: lib.cnm_conv3x3_winograd_c4_f32(x.data_ptr(), 16, 0, 16, None, 0, 0, 0, y.data_ptr(), 16, 0, 48, u.data_ptr(), None, 1, 8, 8, 0, s),
+                 lambda: lib.cnm_conv3x3_winograd4_c4_f32(x.data_ptr(), 16, 4, 16, None, 0, 0, 0, y.data_ptr(), 16, 0, 64, u.data_ptr(), None, 1, 8, 8, 0, s),
+                 lambda: lib.cnm_conv5x5_winograd_c4_f32(None, 16, 0, 16, None, 0, 0, 0, y.data_ptr(), 16, 0, 64, u.data_ptr(), None, 1, 8, 8, 0, s),
+                 lambda: lib.cnm_conv_rows_winograd_c4_f32(x.data_ptr(), 16, 0, 16, None, 0, 0, 0, y.data_ptr(), 16, 0, 64, u.data_ptr(), None, 1, 8, 8, 5, 1, 4, 0, s),
+                 lambda: lib.cnm_conv_rows_winograd_c4_f32(x.data_ptr(), 16, 0, 16, None, 0, 0, 0, y.data_ptr(), 8, 0, 64, u.data_ptr(), None, 1, 8, 8, 7, 1, 2, 0, s)):
+        with pytest.raises(bad):
+            _lib.check(call())
+    old = lib.cnm_tune_wino4_min_workgroups(0)                           # query only
+    assert old == lib.cnm_tune_wino4_min_workgroups(123) and lib.cnm_tune_wino4_min_workgroups(old) == 123
+
+
 # ------------------------------------------------------------------ K6 / K7
 @pytest.mark.parametrize("k", [9, 5])
 def test_depth2normal_golden(dev, golden, k):
