@@ -1,20 +1,23 @@
-// Row-wise Winograd F(2,R) convolution for the RxR stride-1 layers with R = 5, 7 (depthNet conv2.0 and conv1.0:
-// 34 % of a frame's conv FLOPs), fp32 MFMA.
+// Row-wise Winograd convolution for the 5x5 / 7x7 layers (depthNet conv1.*, conv2.*: 42 % of a frame's conv FLOPs),
+// fp32 MFMA.  template <R, S, M>: filter size, stride, outputs per tile along the row.
 //
-// A 2-D F(2x2,RxR) needs (R+1)^2 = 36 / 64 frequency points -- more accumulators than a wave has registers -- so the
-// transform runs along image rows only and the R kernel rows stay in the GEMM reduction:
-//     out[y, 2t..2t+1] = AT  sum_{ky, ci} [ (G w[co, ci, ky, :]) (.) (BT in[ci, y+ky-R/2, 2t-R/2 .. 2t+R/2+1]) ]
-//   (R+1)/2 multiplies per output and kernel row instead of R: 1.75x (R=7) / 1.67x (R=5) fewer MFMA flops, fp32 data
-//   and accumulation; Toom-Cook points {0,+-1,+-2,+-1/2,inf} (R=7), {0,+-1,+-2,inf} (R=5), tables from
-//   tools/wino1d_matrices.py (exact in rationals; measured fp32 error ~4e-6 of the output scale).
+// A 2-D F(m x m, R x R) needs (m+R-1)^2 frequency points -- for R = 7 more accumulators than a wave has registers --
+// so the transform runs along image rows only and the R kernel rows stay in the GEMM reduction:
+//     out[y, M t .. M t + M-1] = AT  sum_{ky, ci} [ (G w[co, ci, ky, :]) (.) (BT in[ci, y+ky-R/2, M t - R/2 .. ]) ]
+//   (M+R-1)/M multiplies per output and kernel row instead of R:  F(2,7) 4, F(4,7) 2.5 (conv1.0), F(2,5) 3;
+//   stride 2 (S = 2): the two column phases of an input row are stride-1 correlations with ceil(R/2) taps, both run
+//   through the same F(M,ceil(R/2)) and accumulate in the same frequency-domain registers: F(4,4) 3.5 instead of 7
+//   (conv1.3), F(4,3) 3 instead of 5 (conv2.3).  fp32 data and accumulation; Toom-Cook tables from
+//   tools/wino1d_matrices.py (exact in rationals); measured per-layer fp32 error: tiles of 2 ~5e-5, F(4,7) ~3e-4 on
+//   O(1) outputs (the training path keeps tiles of 2).
 //
-// Same machine as conv_winograd.hip: workgroup = 4 waves = 64 couts x 64 row-tiles, TWO workgroups per CU; every wave
-// 16 couts x 64 tiles for ALL R+1 frequency points on v_mfma_f32_16x16x4_f32 (128 / 96 accumulator registers); per
-// 16-deep chunk of the (ky, ci) reduction every thread gathers the R+1 pixel window of ONE (tile, channel-quad) with
-// buffer loads (out of range = 0), transforms it in registers and writes V[xi][tile][k] to LDS (double buffered,
-// swizzled); per frequency point one 16-byte weight fragment straight from L2 (MFMA operand order, private to the
-// wave, one whole chunk ahead) and four ds_read_b128 of V feed 16 MFMAs; the transform of chunk c+1 and the gather of
-// chunk c+2 ride between the MFMAs of chunk c; one LDS-only barrier per chunk.
+// Same machine as conv_winograd.hip: workgroup = 4 waves = 64 couts x 64 (48 for F(4,7)) row-tiles, TWO workgroups per
+// CU; every wave 16 couts x all tiles x ALL frequency points on v_mfma_f32_16x16x4_f32 (<= 128 accumulator
+// registers); per 16-deep chunk of the (ky [, phase], ci) reduction every thread gathers the window of ONE (tile,
+// channel-quad) with buffer loads (out of range = 0), transforms it in registers and writes V[xi][tile][k] to LDS
+// (double buffered, swizzled); per frequency point one 16-byte weight fragment straight from L2 (MFMA operand order,
+// private to the wave) and one ds_read_b128 of V per 16-tile block feed 12-16 MFMAs; the transform of chunk c+1 and the
+// gather of chunk c+2 ride between the MFMAs of chunk c; one LDS-only barrier per chunk.
 #include "cnm_common.h"
 
 #ifndef ROWS_ABL
