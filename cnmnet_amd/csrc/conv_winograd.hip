@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd_f32_kernel(const Wino
         d[ij] = make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
     };
     float2 m[16];
-    const int wofs = tl * 16 + (qd ^ ((tl >> 2) & 3)) * 4 + hh * 2;
+    const int wofs = tl * 16 + (qd ^ ((tl >> 1) & 3)) * 4 + hh * 2;
     auto column_pass = [&](int j) {
         F2OP(m[0 * 4 + j], d[0 * 4 + j], -, d[2 * 4 + j]);
         F2OP(m[1 * 4 + j], d[1 * 4 + j], +, d[2 * 4 + j]);
@@ -133,8 +133,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd_f32_kernel(const Wino
     const float4* ubase = reinterpret_cast<const float4*>(a.u) + lane + (size_t)cb16 * 16 * 64;
     const size_t ustride = (size_t)ncb16 * 16 * 64;                      // float4 per chunk
     const int rtile = lane & 15, kg = lane >> 4;
-    const int voffA = rtile * 16 + (kg ^ ((rtile >> 2) & 3)) * 4;        // tile block 0: tiles 0..15
-    const int voffB = (16 + rtile) * 16 + (kg ^ (((16 + rtile) >> 2) & 3)) * 4;
+    const int voffA = rtile * 16 + (kg ^ ((rtile >> 1) & 3)) * 4;        // tile block 0: tiles 0..15
+    const int voffB = (16 + rtile) * 16 + (kg ^ (((16 + rtile) >> 1) & 3)) * 4;
 
     constexpr int WD = WINO_WD;                                          // weight fragments in flight (steps of 8 MFMAs)
     float4 af[WD];

@@ -69,7 +69,7 @@ struct Wino4Args {
 template <int M, int R>                                                  // M x M outputs per tile, R x R filter, M + R - 1 == 6
 __global__ __launch_bounds__(256, 2) void conv_winograd36_f32_kernel(const Wino4Args a) {
     static_assert(M + R - 1 == 6, "36-point kernel");
-    constexpr int TT = 16, NXI = 36, VBUF = NXI * TT * 16;               // V[buf][xi][tile][16 ci], slots XOR-swizzled with ((tile >> 2) & 3)
+    constexpr int TT = 16, NXI = 36, VBUF = NXI * TT * 16;               // V[buf][xi][tile][16 ci], slots XOR-swizzled with ((tile >> 1) & 3): conflict-free for the four non-contiguous 16-lane groups of ds_read_b128 and for the writes
     __shared__ __attribute__((aligned(16))) float V[2 * VBUF];           // 72 KB
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int tilesC = a.Cout / 64;
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void conv_winograd36_f32_kernel(const Wino4
         d[ij] = __uint_as_float((WINO4_ABL & 8) ? __builtin_amdgcn_raw_buffer_load_b32(grsrc, (unsigned)lane * 4u, 0, 0)
                                                  : __builtin_amdgcn_raw_buffer_load_b32(grsrc, sat_add(roff[ij / 6], coff[ij % 6]), gsoff, 0));
     };
-    const int wofs = tl * 16 + (qd ^ ((tl >> 2) & 3)) * 4 + cc;
+    const int wofs = tl * 16 + (qd ^ ((tl >> 1) & 3)) * 4 + cc;
     auto column_pass = [&](int j) { WINO4_BT(d[0 * 6 + j], d[1 * 6 + j], d[2 * 6 + j], d[3 * 6 + j], d[4 * 6 + j], d[5 * 6 + j]); };
     auto row_pass = [&](int i, float* Vdst) {
         WINO4_BT(d[i * 6 + 0], d[i * 6 + 1], d[i * 6 + 2], d[i * 6 + 3], d[i * 6 + 4], d[i * 6 + 5]);
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void conv_winograd36_f32_kernel(const Wino4
     const float4* ubase = reinterpret_cast<const float4*>(a.u) + lane + (size_t)cb16 * NXI * 64;
     const size_t ustride = (size_t)ncb16 * NXI * 64;                     // float4 per chunk
     const int rtile = lane & 15, kg = lane >> 4;
-    const int voff = rtile * 16 + (kg ^ ((rtile >> 2) & 3)) * 4;
+    const int voff = rtile * 16 + (kg ^ ((rtile >> 1) & 3)) * 4;
 
     constexpr int WD = WINO4_WD;                                         // weight fragments in flight (steps of 4 MFMAs)
     float4 af[WD];

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void conv_rows_winograd_f32_kernel(const Ro
     using CF = RowCfg<R, S, M>;
     using WM = RowWino<CF::ID>;
     constexpr int NX = CF::NX, NB = CF::NB, TT = 16 * NB, NG = (NX + 1) / 2;
-    constexpr int VBUF = NX * TT * 16;                                   // V[buf][xi][tile][16 k], slots XOR-swizzled with ((tile >> 2) & 3)
+    constexpr int VBUF = NX * TT * 16;                                   // V[buf][xi][tile][16 k], slots XOR-swizzled with ((tile >> 1) & 3): conflict-free for the four non-contiguous 16-lane groups of ds_read_b128 and for the writes
     __shared__ __attribute__((aligned(16))) float V[2 * VBUF];           // 64 KB (R = 7) / 48 KB (R = 5) / less for stride 2
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int tilesC = a.Cout / 64;
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void conv_rows_winograd_f32_kernel(const Ro
     };
     // V = BT d in NG = (R+1)/2 groups of two frequency points (even/odd factorisation of the +-p point pairs):
     // group 0 = (V0, V_R) [points 0, inf], group i = (V_{2i-1}, V_{2i}) [points +p_i, -p_i].
-    const int wofs = tl * 16 + (qd ^ ((tl >> 2) & 3)) * 4;
+    const int wofs = tl * 16 + (qd ^ ((tl >> 1) & 3)) * 4;
     auto transform_group = [&](int grp, float* Vdst) {
         const f4p* x = reinterpret_cast<const f4p*>(&d[0]);
         f4p va, vb; int ka, kb = -1;
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void conv_rows_winograd_f32_kernel(const Ro
     const float4* ubase = reinterpret_cast<const float4*>(a.u) + lane + (size_t)cb16 * NX * 64;
     const size_t ustride = (size_t)ncb16 * NX * 64;                      // float4 per chunk
     const int rtile = lane & 15, kg = lane >> 4;
-    const int voff = rtile * 16 + (kg ^ ((rtile >> 2) & 3)) * 4;         // tile block tb adds tb*16 rows (same swizzle: 16 % 16 == 0)
+    const int voff = rtile * 16 + (kg ^ ((rtile >> 1) & 3)) * 4;         // tile block tb adds tb*16 rows (same swizzle: 16 % 16 == 0)
 
     constexpr int WD = NX > 8 ? NX / 2 : NX;                             // weight fragments in flight: a whole chunk, half of one for 10 points (registers)
     float4 af[WD];
