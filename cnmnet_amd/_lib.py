@@ -95,6 +95,7 @@ PROTOTYPES = {
     "cnm_bn_train_backward_c4_f32": (c_i, [c_fp] * 6 + [c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp]),
     "cnm_upsample2x_backward_c4_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp]),
     "cnm_depth2normal_f32": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    "cnm_plane_normals_f32": (c_i, [c_fp, c_fp, c_fp, c_i, c_fp, c_i, c_i, c_i, c_i, c_fp]),
     "cnm_depth2normal_backward_f32": (c_i, [c_fp] * 6 + [c_i, c_i, c_i, c_i, c_i, c_fp]),
     "cnm_inverse_warp_backward_depth_f32": (c_i, [c_fp] * 7 + [c_i, c_i, c_i, c_i, c_fp]),
     "cnm_intrinsics_inverse_f32": (c_i, [c_fp, c_ll, c_fp, c_i, c_fp]),

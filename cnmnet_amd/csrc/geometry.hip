@@ -361,3 +361,57 @@ extern "C" int cnm_inverse_warp_f32(const float* feat, const float* depth, const
     CNM_LAUNCH_CHECK();
     return CNM_OK;
 }
+
+// ------------------------------------------------------------------ plane-instance regularisation of a normal map
+// Reference depth_util.py:205-238 (Depth2normal with planes_num) and :243-278 (get_normal_by_planes): for every image b
+// and plane instance i < planes_num[b], IN ORDER (instances may overlap; later ones see earlier overwrites):
+//   mean = sum_pix(n * seg_i) / sum_pix(seg_i);   loss += mean_pix(1 - cos(mean, seg_i ? n : 0));   n = seg_i ? mean : n
+// One launch per instance index, one workgroup per image: pass 1 reduces the masked sum (fp64), pass 2 applies the
+// mean and reduces the loss term into loss_terms[b * P + i] (summed by the caller in a fixed order: deterministic).
+__global__ __launch_bounds__(1024) void plane_normals_kernel(float* __restrict__ normal, const unsigned char* __restrict__ seg,
+                                                             const int* __restrict__ planes_num, float* __restrict__ loss_terms,
+                                                             int P, int HW, int inst) {
+    const int b = blockIdx.x, t = threadIdx.x;
+    if (inst >= planes_num[b]) return;                                   // uniform per workgroup
+    float* n = normal + (size_t)b * 3 * HW;
+    const unsigned char* m = seg + ((size_t)b * P + inst) * HW;
+    __shared__ double red[4][16];
+    double sx = 0, sy = 0, sz = 0, cnt = 0;
+    for (int p = t; p < HW; p += 1024)
+        if (m[p]) { sx += n[p]; sy += n[p + HW]; sz += n[p + 2 * (size_t)HW]; cnt += 1; }
+    auto block_sum4 = [&](double& a, double& b2, double& c, double& d) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); b2 += __shfl_down(b2, o); c += __shfl_down(c, o); d += __shfl_down(d, o); }
+        if ((t & 63) == 0) { red[0][t >> 6] = a; red[1][t >> 6] = b2; red[2][t >> 6] = c; red[3][t >> 6] = d; }
+        __syncthreads();
+        a = b2 = c = d = 0;
+        for (int w = 0; w < 16; ++w) { a += red[0][w]; b2 += red[1][w]; c += red[2][w]; d += red[3][w]; }   // same order in every thread
+        __syncthreads();
+    };
+    block_sum4(sx, sy, sz, cnt);
+    const float mx = (float)(sx / cnt), my = (float)(sy / cnt), mz = (float)(sz / cnt);   // 0/0 = NaN for an empty instance, as the reference
+    const float mnorm = fmaxf(sqrtf(mx * mx + my * my + mz * mz), 1e-8f);                // F.cosine_similarity: each norm clamped at eps = 1e-8
+    double ls = 0, z0 = 0, z1 = 0, z2 = 0;
+    for (int p = t; p < HW; p += 1024) {
+        float sim = 0.f * (mx + my + mz);                                // outside the instance the second operand is the zero vector (NaN mean of an empty instance propagates, as in the reference)
+        if (m[p]) {
+            const float x = n[p], y = n[p + HW], z = n[p + 2 * (size_t)HW];
+            sim = (mx * x + my * y + mz * z) / (mnorm * fmaxf(sqrtf(x * x + y * y + z * z), 1e-8f));
+            n[p] = mx; n[p + HW] = my; n[p + 2 * (size_t)HW] = mz;
+        }
+        ls += 1.0 - (double)sim;
+    }
+    block_sum4(ls, z0, z1, z2);
+    if (t == 0 && loss_terms) loss_terms[b * P + inst] = (float)(ls / HW);
+}
+
+extern "C" int cnm_plane_normals_f32(float* normal, const unsigned char* instance_segs, const int* planes_num, int max_planes_num,
+                                     float* loss_terms, int B, int P, int H, int W, void* stream) {
+    CNM_REQUIRE(normal && instance_segs && planes_num && B > 0 && B <= 65535 && P > 0 && H > 0 && W > 0, CNM_ERR_BAD_ARG);
+    CNM_REQUIRE(max_planes_num >= 0 && max_planes_num <= P, CNM_ERR_BAD_ARG);
+    for (int i = 0; i < max_planes_num; ++i) {
+        plane_normals_kernel<<<B, 1024, 0, cnm_stream(stream)>>>(normal, instance_segs, planes_num, loss_terms, P, H * W, i);
+        CNM_LAUNCH_CHECK();
+    }
+    return CNM_OK;
+}

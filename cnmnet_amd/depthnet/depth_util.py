@@ -21,8 +21,8 @@ def process_camera_parameters(left_cam, right_cam, pixel_coordinates=None):
 
 
 class Depth2normal(nn.Module):
-    """depth [B,H,W], intrinsic_inv [B,3,3] -> (normal [B,3,H,W], points [B,3,H,W])
-    (reference depth_util.py:140-203)."""
+    """depth [B,H,W], intrinsic_inv [B,3,3] -> (normal [B,3,H,W], points [B,3,H,W]) (reference depth_util.py:140-203);
+    with instance_segs [B,P,H,W] bool and planes_num [B] -> (normal, loss, points) (reference :205-238)."""
 
     def __init__(self, k_size=9):
         super().__init__()
@@ -30,9 +30,16 @@ class Depth2normal(nn.Module):
 
     def forward(self, depth, intrinsic_inv, instance_segs=None, planes_num=None):
         if planes_num is not None:
-            raise NotImplementedError("plane-instance regularisation (reference depth_util.py:205-238) is not "
-                                      "built yet (SURVEY.md section 8f rank 4); no call site in eval.py uses it")
+            # plane branch (reference :205-238): -> (normal, loss, points); inference semantics (no autograd through it)
+            normal, points = ops.depth2normal(depth.detach(), intrinsic_inv, self.k_size)
+            normal, loss = ops.plane_normals(normal, instance_segs, planes_num)
+            return normal, loss, points
         if torch.is_grad_enabled() and depth.requires_grad:
             from ..autograd import Depth2NormalFn
             return Depth2NormalFn.apply(depth, intrinsic_inv, self.k_size, False)
         return ops.depth2normal(depth, intrinsic_inv, self.k_size)
+
+
+def get_normal_by_planes(gt_normal, instance_segs, planes_num):
+    """Reference depth_util.py:243-278: every plane instance's pixels take the instance's mean normal."""
+    return ops.plane_normals(gt_normal, instance_segs, planes_num, with_loss=False)[0]

@@ -315,6 +315,25 @@ def depth2normal(depth, intrinsic_inv, k_size=9, input_is_idepth=False):
     return normal, points
 
 
+def plane_normals(normal, instance_segs, planes_num, with_loss=True):
+    """Plane-instance regularisation (reference depth_util.py:205-238 / :243-278): normal [B,3,H,W] float32,
+    instance_segs [B,P,H,W] bool, planes_num [B] ints -> (regularised normal (new tensor), loss scalar tensor or None)."""
+    _dev(normal)
+    B, _, H, W = normal.shape
+    P = instance_segs.shape[1]
+    pn = torch.as_tensor(planes_num, dtype=torch.int32)
+    pmax = int(pn.max()) if pn.numel() else 0
+    if pn.numel() != B or pmax > P or int(pn.min()) < 0:
+        raise ValueError("planes_num must hold B counts in [0, %d]" % P)
+    out = normal.contiguous().clone()
+    seg = instance_segs.to(device=normal.device, dtype=torch.uint8).contiguous()
+    pn = pn.to(normal.device)
+    terms = torch.zeros(B, P, device=normal.device, dtype=torch.float32) if with_loss else None
+    with torch.cuda.device(normal.device):
+        _lib.check(_lib.load().cnm_plane_normals_f32(_p(out), seg.data_ptr(), pn.data_ptr(), pmax, _p(terms), B, P, H, W, _stream()))
+    return out, (terms.sum() if with_loss else None)
+
+
 def intrinsics_inverse(cam):
     """cam [B,2,4,4] (any batch stride) -> K^-1 [B,3,3]   (train.py:201-202, eval.py:271)"""
     _dev(cam)

@@ -347,6 +347,15 @@ int cnm_upsample2x_backward_c4_f32(const float* dy, float* dx, int N, int G, int
 int cnm_depth2normal_f32(const float* depth, const float* K_inv, float* normal, float* points,
                          int B, int H, int W, int ksize, int input_is_idepth, void* stream);
 
+/* Plane-instance regularisation of a normal map, in place: the plane branch of Depth2normal.forward
+ * (depth_util.py:205-238) and get_normal_by_planes (:243-278).  normal [B,3,H,W]; instance_segs [B,P,H,W] bytes
+ * (non-zero = inside); planes_num [B] ints on the DEVICE, max_planes_num = their maximum (host).  For every image
+ * and instance i < planes_num[b], in order: the instance's pixels are replaced by their mean normal, and
+ * loss_terms[b*P+i] = mean over ALL pixels of 1 - cos(mean, inside ? normal : 0) (the reference's loss is the
+ * sum of these terms; loss_terms may be NULL; entries of unused instances are left untouched). */
+int cnm_plane_normals_f32(float* normal, const unsigned char* instance_segs, const int* planes_num, int max_planes_num,
+                          float* loss_terms, int B, int P, int H, int W, void* stream);
+
 /* Backward of cnm_depth2normal_f32 w.r.t. its depth (or inverse-depth) input, as needed by the normal losses of
  * train.py:204-263: grad_normal [B,3,H,W], grad_points [B,3,H,W] or NULL -> grad_depth [B,H,W].
  * ws: 9*B*H*W floats.  The validity mask (0 < z < 10) and the det < 1e-5 branch are treated as constants. */

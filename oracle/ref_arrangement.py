@@ -207,6 +207,24 @@ def depth_to_normal(depth, K_inv, k_size=9):
     return n.view(B, H, W, 3).permute(0, 3, 1, 2), pts
 
 
+def plane_normals(normal, instance_segs, planes_num, with_loss=True):
+    """Plane branch of Depth2normal.forward (depth_util.py:205-238) / get_normal_by_planes (:243-278) on a [B,3,H,W] map:
+    instances in order, each replaced by its mean normal; loss = sum of mean(1 - cos(mean, inside ? n : 0))."""
+    n = normal.permute(0, 2, 3, 1).clone()                                            # [B,H,W,3]
+    B, H, W, _ = n.shape
+    loss = torch.zeros((), dtype=normal.dtype)
+    for b in range(B):
+        for i in range(int(planes_num[b])):
+            m = instance_segs[b, i].bool()                                            # [H,W]
+            mean = (n[b] * m.unsqueeze(-1).to(n.dtype)).reshape(-1, 3).sum(0) / m.sum().to(n.dtype)   # :221-225
+            reg = mean.expand(H, W, 3)
+            orig = torch.where(m.unsqueeze(-1), n[b], torch.zeros_like(n[b]))         # :228
+            if with_loss:
+                loss = loss + (1 - F.cosine_similarity(reg.reshape(-1, 3), orig.reshape(-1, 3), dim=1)).mean()   # :230-233
+            n[b] = torch.where(m.unsqueeze(-1), reg, n[b])                            # :235-236
+    return n.permute(0, 3, 1, 2), (loss if with_loss else None)
+
+
 # --------------------------------------------------------------------------
 # inverse warp                                         inverse_warp.py:46-118
 # --------------------------------------------------------------------------

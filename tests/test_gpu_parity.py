@@ -451,6 +451,29 @@ def test_depth2normal_golden(dev, golden, k):
     np.testing.assert_allclose(np.moveaxis(n, 1, -1)[bad], np.moveaxis(n64, 1, -1)[bad], atol=2e-5)
 
 
+def test_plane_normals_golden(dev, golden):
+    """Plane-instance regularisation (depth_util.py:205-278) against the imported reference: overlapping instances,
+    the loss, the 3-tuple return of Depth2normal, get_normal_by_planes, and an empty instance (NaN mean as the reference)."""
+    from cnmnet_amd.depthnet import Depth2normal, get_normal_by_planes
+    from cnmnet_amd import ops
+    g = golden("planes_24x32.npz")
+    depth, kinv, seg = T(g["depth"]).to(dev), T(g["K_inv"]).to(dev), T(g["seg"]).to(dev)
+    n, loss, pts = Depth2normal(9)(depth, kinv, seg, g["planes_num"])
+    assert np.abs(n.cpu().numpy() - g["normal_reg"]).max() < 1e-4            # 1e-3 bar on normals (north_star); measured ~1e-6
+    assert abs(float(loss) - float(g["loss"])) < 1e-4
+    n0, p0 = Depth2normal(9)(depth, kinv)
+    assert torch.equal(pts, p0) and np.abs(n0.cpu().numpy() - g["normal_plain"]).max() < 1e-4
+    byp = get_normal_by_planes(T(g["normal_plain"]).to(dev), seg, g["planes_num"])
+    assert np.abs(byp.cpu().numpy() - g["normal_by_planes"]).max() < 1e-5
+    keep, _ = ops.plane_normals(n0, seg, [0, 0])
+    assert torch.equal(keep, n0)                                              # no instances: unchanged, input not modified in place
+    empty = torch.zeros_like(seg)
+    out, l = ops.plane_normals(n0, empty, [1, 0])
+    assert torch.equal(out, n0) and torch.isnan(l)                           # empty instance: 0/0 mean -> NaN loss, map untouched
+    with pytest.raises(ValueError):
+        ops.plane_normals(n0, seg, [21, 0])
+
+
 def test_inverse_warp_golden(dev, golden):
     from cnmnet_amd.depthnet import inverse_warp, pixel2cam
     g = golden("inverse_warp_32x64.npz")

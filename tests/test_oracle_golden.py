@@ -136,3 +136,17 @@ def test_upsample_check_vector(golden):
     np.testing.assert_allclose(cf.upsample2x_bilinear(np.array([[0.0, 4.0, 8.0]]))[0], [0, 1, 3, 5, 7, 8])
     g = golden("upsample2x_5x7.npz")
     np.testing.assert_allclose(cf.upsample2x_bilinear(g["x"]), g["y"], atol=1e-6)
+
+
+def test_plane_normals_oracle_vs_reference_golden(golden):
+    """Plane branch of Depth2normal / get_normal_by_planes (depth_util.py:205-278), overlapping instances included."""
+    import torch
+    from oracle import ref_arrangement as ra
+    g = golden("planes_24x32.npz")
+    n, pts = ra.depth_to_normal(torch.from_numpy(g["depth"]), torch.from_numpy(g["K_inv"]), 9)
+    assert np.abs(n.numpy() - g["normal_plain"]).max() < 1e-5
+    reg, loss = ra.plane_normals(n, torch.from_numpy(g["seg"]), g["planes_num"])
+    assert np.abs(reg.numpy() - g["normal_reg"]).max() < 1e-5
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    byp, none = ra.plane_normals(torch.from_numpy(g["normal_plain"]), torch.from_numpy(g["seg"]), g["planes_num"], with_loss=False)
+    assert none is None and np.abs(byp.numpy() - g["normal_by_planes"]).max() < 1e-6
