@@ -227,3 +227,55 @@ class TrainStep(TrainStepWoNormal):
         self.optimizer.step()
         return {"loss": float(loss.detach()), "loss_normal": float(ln.detach()), "loss_normal_refined": float(lnr.detach()),
                 "loss_depth_refined": float(loss_depth_refined.detach()), "prob_loss": float(prob_loss.detach())}
+
+
+# ------------------------------------------------------------------ epoch loop and checkpoints (train.py:59-140, :395-410)
+def checkpoint_name(epoch, idepth_scale):
+    return "network_epoch_%d_scale_%d.pt" % (epoch, int(idepth_scale))                      # train.py:410
+
+
+def save_checkpoint(path, step, epoch, global_step):
+    """The reference's checkpoint dictionary (train.py:403-409): un-prefixed state_dicts of both nets + optimizer."""
+    torch.save({"epoch": epoch, "global_step": global_step,
+                "depth_network_state_dict": step.depth_net.state_dict(),
+                "depth_refine_network_state_dict": step.refine_net.state_dict(),
+                "optimizer": step.optimizer.state_dict()}, path)
+
+
+def resume(path, step, with_optimizer=False):
+    """train.py:92-106: load both nets (a checkpoint without the refine net is accepted), return (start_epoch, global_step).
+    The reference leaves the optimizer state behind (`:103` commented out); `with_optimizer=True` restores it."""
+    from .eval7scenes import load_checkpoint
+    ck = torch.load(path, map_location="cpu")
+    load_checkpoint(ck, step.depth_net, step.refine_net if "depth_refine_network_state_dict" in ck else None)
+    if with_optimizer and "optimizer" in ck:
+        step.optimizer.load_state_dict(ck["optimizer"])
+    return int(ck["epoch"]), int(ck["global_step"])
+
+
+def fit(step, loader, num_epochs, checkpoint_dir=None, idepth_scale=3.0, start_epoch=0, global_step=0, device="cuda:0",
+        print_interval=10, log=print, rank=0, max_steps=None):
+    """The reference's main loop: epochs start_epoch+1 .. num_epochs-1 (train.py:140), the first four epochs after (re)start are the
+    inverse-depth-only warm-up where the step has one (`(epoch - start_epoch) < 5`, train.py:556-560), a checkpoint every len(loader)//8 iterations
+    (:401-410; rank 0 only).  `step` is a TrainStep / TrainStepWoNormal; batches come from scannet.training_loader."""
+    import os
+    import time
+    every = max(1, len(loader) // 8)
+    for epoch in range(start_epoch + 1, num_epochs):
+        tic = time.time()
+        for it, batch in enumerate(loader):
+            s = {k: v.to(device, non_blocking=True) for k, v in batch.items() if torch.is_tensor(v)}
+            if isinstance(step, TrainStep):
+                out = step(s["rgbs"], s["cameras"], s["disparities"], s["depths"], s["normals"])
+            else:
+                out = step(s["rgbs"], s["cameras"], s["disparities"], s["depths"], warmup_epoch=(epoch - start_epoch) < 5)
+            global_step += 1
+            if rank == 0 and it % print_interval == 0:
+                log("epoch %d iter %d/%d  %s  %.3f s/iter" % (epoch, it, len(loader), "  ".join("%s %.4f" % kv for kv in out.items()),
+                                                               (time.time() - tic) / (it + 1)))
+            if rank == 0 and checkpoint_dir is not None and it % every == 0:
+                os.makedirs(checkpoint_dir, exist_ok=True)
+                save_checkpoint(os.path.join(checkpoint_dir, checkpoint_name(epoch, idepth_scale)), step, epoch, global_step)
+            if max_steps is not None and global_step >= max_steps:
+                return epoch, global_step
+    return num_epochs - 1, global_step

@@ -1,5 +1,7 @@
 """GPU (-m gpu): the training path -- backward operators against torch CPU autograd,
 then a whole train-mode forward/backward of both nets against the oracle in train mode."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -244,3 +246,31 @@ def test_scannet_loader_feeds_train_step(dev, tmp_path):
     logs = [step(s["rgbs"], s["cameras"], s["disparities"], s["depths"], s["normals"]) for _ in range(3)]
     assert all(np.isfinite(l["loss"]) for l in logs), logs
     assert logs[-1]["loss"] < logs[0]["loss"], logs
+
+
+def test_fit_checkpoints_and_resume(dev, tmp_path):
+    """Epoch loop of train.py:140-410 on a tiny scene: checkpoints carry the reference's keys and file name, load into
+    fresh nets (also with DataParallel's 'module.' prefix), and resuming continues from the stored epoch / step."""
+    from cnmnet_amd import scannet as sn
+    from cnmnet_amd.depthnet import depthNet, DepthRefineNet
+    from cnmnet_amd.trainer import TrainStepWoNormal, fit, resume, checkpoint_name
+    lst = sn.write_synthetic_scene(str(tmp_path / "data"), num_frames=4, height=64, width=96, seed=4)
+    dl = sn.training_loader(lst, str(tmp_path / "data"), 64, 96, batch_size=1, shuffle=True, source_depths=True)
+    step = TrainStepWoNormal(_load(depthNet(3.0), 93).to(dev), _load(DepthRefineNet(32, 3.0), 94).to(dev))
+    lines = []
+    epoch, gs = fit(step, dl, num_epochs=3, checkpoint_dir=str(tmp_path / "ck"), device=dev, log=lines.append, print_interval=1)
+    assert (epoch, gs) == (2, 4) and len(lines) == 4
+    path = str(tmp_path / "ck" / checkpoint_name(2, 3.0))
+    assert os.path.basename(path) == "network_epoch_2_scale_3.pt" and os.path.exists(path)
+    ck = torch.load(path, map_location="cpu")
+    assert set(ck) == {"epoch", "global_step", "depth_network_state_dict", "depth_refine_network_state_dict", "optimizer"}
+    fresh = TrainStepWoNormal(depthNet(3.0).to(dev), DepthRefineNet(32, 3.0).to(dev))
+    assert resume(path, fresh, with_optimizer=True) == (2, ck["global_step"])
+    for a, b in zip(step.depth_net.state_dict().values(), fresh.depth_net.state_dict().values()):
+        assert torch.equal(a.cpu(), b.cpu())
+    ck["depth_network_state_dict"] = {"module." + k: v for k, v in ck["depth_network_state_dict"].items()}
+    del ck["depth_refine_network_state_dict"]
+    torch.save(ck, path)
+    assert resume(path, fresh)[0] == 2
+    e2, g2 = fit(fresh, dl, num_epochs=4, start_epoch=2, global_step=gs, device=dev, log=lines.append)
+    assert (e2, g2) == (3, gs + 2)
