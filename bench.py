@@ -219,6 +219,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step as one captured HIP graph (measured: no gain, the host already runs ahead of the GPU)")
+    ap.add_argument("--side-stream", type=int, default=-1, help="A/B: cnm_tune_refine_side_stream value (0 = everything on the caller's stream)")
     ap.add_argument("--precision", choices=["f32", "f16"], default="f32",
                     help="f16 = BASELINE config 5 path (fp16 storage + f16 MFMA; tolerance in tests/test_gpu_fp16.py); not the headline")
     a = ap.parse_args()
@@ -239,6 +240,9 @@ def main():
     from cnmnet_amd import synthetic as syn
     from cnmnet_amd.depthnet import depthNet, DepthRefineNet
     from cnmnet_amd.pipeline import FramePipeline
+    if a.side_stream >= 0:
+        from cnmnet_amd import _lib
+        _lib.load().cnm_tune_refine_side_stream(a.side_stream)
     pipe = FramePipeline(load_weights(depthNet(3.0, PLANES, precision=a.precision), 1).to(dev),
                          load_weights(DepthRefineNet(32, 3.0, precision=a.precision), 2).to(dev),
                          k_size=KSIZE, normals=True)

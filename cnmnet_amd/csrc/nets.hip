@@ -1,7 +1,8 @@
 // Whole-network executors: depthNet.forward and DepthRefineNet.forward
 // (reference depthnet/depthNet_model.py:226-263 and :331-370) as fixed launch sequences
-// over a caller-owned workspace.  No allocation, no synchronisation, no global state:
-// everything is enqueued on the caller's stream, so a forward can be captured in a hipGraph.
+// over a caller-owned workspace.  No allocation, no host synchronisation: everything is ordered on the caller's stream
+// (the refine net's second decoder forks onto a side stream and joins back with events), so a forward can be captured
+// in a hipGraph.  Process-wide state is limited to tuning knobs and the per-thread side streams.
 //
 // Concatenations are never copied: a producer writes straight into the channel-group slice
 // of its consumer's input buffer (CAT* below), or the consumer reads two views (cat2 conv).
@@ -85,6 +86,32 @@ extern "C" int cnm_tune_wino4_min_workgroups(int n) { const int old = g_wino4_mi
 static inline bool wino4_fills_chip(int Cout, int N, int H, int W, int m = 4) {   // m x m outputs per tile
     const long long tiles = (long long)N * ((H + m - 1) / m) * ((W + m - 1) / m);
     return (Cout / 64) * ((tiles + 15) / 16) >= g_wino4_min_workgroups;
+}
+
+// The depth and the probability decoder (depthNet_model.py:341-351 / :357-365) share only their inputs, and their
+// layers launch 384-768 workgroups on 512 slots; run side by side they backfill each other's tail and the bandwidth-
+// bound upsample / head launches hide under the other decoder's MFMA work.  The second decoder runs on a side stream
+// forked from and joined back into the caller's stream with events, so callers still see one ordered stream (and a
+// hipGraph capture of the caller's stream records both).  One side stream per (host thread, device), created on
+// first use and kept.  (Tried and dropped: depthNet's three intermediate heads on the side stream, -0.05 ms.)
+struct SideStream { hipStream_t stream; hipEvent_t fork, join; bool ok; };
+static int g_refine_side_stream = 1;
+extern "C" int cnm_tune_refine_side_stream(int on) { const int old = g_refine_side_stream; if (on >= 0) g_refine_side_stream = on ? 1 : 0; return old; }
+static SideStream* side_stream() {
+    constexpr int kMaxDev = 64;
+    thread_local SideStream tl[kMaxDev] = {};
+    thread_local bool tried[kMaxDev] = {};
+    int dev = 0;
+    if (!g_refine_side_stream || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
+    SideStream& x = tl[dev];
+    if (!tried[dev]) {
+        tried[dev] = true;
+        x.ok = hipStreamCreateWithFlags(&x.stream, hipStreamNonBlocking) == hipSuccess &&
+               hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) == hipSuccess &&
+               hipEventCreateWithFlags(&x.join, hipEventDisableTiming) == hipSuccess;
+        if (!x.ok) (void)hipGetLastError();
+    }
+    return x.ok ? &x : nullptr;
 }
 
 struct EngF32 {
@@ -236,16 +263,24 @@ extern "C" int cnm_depthnet_forward_f16(const cnm_layer_weights* wt, float idept
 }
 
 // ------------------------------------------------------------------ refine net
-struct RefineBufs { float *X, *A1, *C1, *A2, *C2, *A3, *C3, *U3, *UC3, *I3, *U2, *UC2, *I2, *U1, *UC1, *I1; };
+struct DecoderBufs { float *UC3, *I3, *U2, *UC2, *I2, *U1, *UC1, *I1; };     // one set per decoder: the two run concurrently
+struct RefineBufs { float *X, *A1, *C1, *A2, *C2, *A3, *C3, *U3; DecoderBufs d[2]; };
+
+
 
 template <class E>
 static size_t carve_refine(float* ws, int N, int H, int W, RefineBufs* b) {
     Carver c{ws, 0};
     const size_t q = (size_t)N * H * W * 4;
     auto G = [](int C) { return (size_t)((C + E::GD - 1) / E::GD); };
-    b->X = c.take(q * (G(64) + 1)); b->A1 = c.take(q * G(128)); b->U1 = c.take(q * G(128)); b->UC1 = c.take(q * G(64)); b->I1 = c.take(q * G(64));
-    b->C1 = c.take(q / 4 * G(128)); b->A2 = c.take(q / 4 * G(256)); b->U2 = c.take(q / 4 * G(256)); b->UC2 = c.take(q / 4 * G(128)); b->I2 = c.take(q / 4 * G(128));
-    b->C2 = c.take(q / 16 * G(256)); b->A3 = c.take(q / 16 * G(512)); b->U3 = c.take(q / 16 * G(512)); b->UC3 = c.take(q / 16 * G(256)); b->I3 = c.take(q / 16 * G(256));
+    b->X = c.take(q * (G(64) + 1)); b->A1 = c.take(q * G(128));
+    b->C1 = c.take(q / 4 * G(128)); b->A2 = c.take(q / 4 * G(256));
+    b->C2 = c.take(q / 16 * G(256)); b->A3 = c.take(q / 16 * G(512)); b->U3 = c.take(q / 16 * G(512));
+    for (DecoderBufs& d : b->d) {
+        d.U1 = c.take(q * G(128)); d.UC1 = c.take(q * G(64)); d.I1 = c.take(q * G(64));
+        d.U2 = c.take(q / 4 * G(256)); d.UC2 = c.take(q / 4 * G(128)); d.I2 = c.take(q / 4 * G(128));
+        d.UC3 = c.take(q / 16 * G(256)); d.I3 = c.take(q / 16 * G(256));
+    }
     b->C3 = c.take(q / 64 * G(512));
     return c.used;
 }
@@ -271,19 +306,36 @@ static int refinenet_body(const cnm_layer_weights* wt, float idepth_scale, const
     CONV(R_CONV3_0, b.C2, g256, b.A3, 512, H2, W2);
     CONV(R_CONV3_3, b.A3, g512, b.C3, 512, H2, W2);
     CNM_TRY(E::up(b.C3, g512, b.U3, N, H3, W3, s));                                    // shared by both decoders
-    for (int br = 0; br < 2; ++br) {                                                   // 0: depth (:341-351), 1: prob (:357-365)
-        const int L = R_BRANCH0 + 6 * br;
-        float* feat = (br == 0 && iconv1_depth) ? iconv1_depth : b.I1;
-        CONV(L + 0, b.U3, g512, b.UC3, 256, H2, W2);
-        CNM_TRY(E::conv2(b.UC3, g256, b.C2, g256, b.I3, g256, 256, wt[L + 1], N, H2, W2, s));
-        CNM_TRY(E::up(b.I3, g256, b.U2, N, H2, W2, s));
-        CONV(L + 2, b.U2, g256, b.UC2, 128, H1, W1);
-        CNM_TRY(E::conv2(b.UC2, g128, b.C1, g128, b.I2, g128, 128, wt[L + 3], N, H1, W1, s));
-        CNM_TRY(E::up(b.I2, g128, b.U1, N, H1, W1, s));
-        CONV(L + 4, b.U1, g128, b.UC1, 64, H, W);
-        CONV(L + 5, b.UC1, g64, feat, 64, H, W);
-        CNM_TRY(E::head(feat, g64, 64, wt[R_HEAD0 + br], br == 0 ? idepth_scale : 1.0f, br == 0 ? disp_refined : prob_map,
-                        nullptr, 0, 0, N, H, W, s));
+    SideStream* side = side_stream();
+    void* st[2] = {s, side ? (void*)side->stream : s};
+    if (side) {
+        if (hipEventRecord(side->fork, (hipStream_t)s) != hipSuccess || hipStreamWaitEvent(side->stream, side->fork, 0) != hipSuccess) return CNM_ERR_LAUNCH;
+    }
+#undef CONV
+#define CONV(L, in, Gin, out, Cout, HH, WW) \
+    CNM_TRY(E::conv(in, Gin, 0, Gin, out, G(Cout), 0, Cout, wt[L], N, HH, WW, 3, kRefineLayers[L].stride, q))
+    for (int step = 0; step < 9; ++step) {
+        for (int br = 0; br < 2; ++br) {                                               // 0: depth (:341-351), 1: prob (:357-365)
+            const int L = R_BRANCH0 + 6 * br;
+            const DecoderBufs& d = b.d[br];
+            void* q = st[br];
+            float* feat = (br == 0 && iconv1_depth) ? iconv1_depth : d.I1;
+            switch (step) {
+                case 0: CONV(L + 0, b.U3, g512, d.UC3, 256, H2, W2); break;
+                case 1: CNM_TRY(E::conv2(d.UC3, g256, b.C2, g256, d.I3, g256, 256, wt[L + 1], N, H2, W2, q)); break;
+                case 2: CNM_TRY(E::up(d.I3, g256, d.U2, N, H2, W2, q)); break;
+                case 3: CONV(L + 2, d.U2, g256, d.UC2, 128, H1, W1); break;
+                case 4: CNM_TRY(E::conv2(d.UC2, g128, b.C1, g128, d.I2, g128, 128, wt[L + 3], N, H1, W1, q)); break;
+                case 5: CNM_TRY(E::up(d.I2, g128, d.U1, N, H1, W1, q)); break;
+                case 6: CONV(L + 4, d.U1, g128, d.UC1, 64, H, W); break;
+                case 7: CONV(L + 5, d.UC1, g64, feat, 64, H, W); break;
+                case 8: CNM_TRY(E::head(feat, g64, 64, wt[R_HEAD0 + br], br == 0 ? idepth_scale : 1.0f, br == 0 ? disp_refined : prob_map,
+                                        nullptr, 0, 0, N, H, W, q)); break;
+            }
+        }
+    }
+    if (side) {
+        if (hipEventRecord(side->join, side->stream) != hipSuccess || hipStreamWaitEvent((hipStream_t)s, side->join, 0) != hipSuccess) return CNM_ERR_LAUNCH;
     }
 #undef CONV
     return CNM_OK;

@@ -36,9 +36,13 @@ extern "C" {
 
 #define CNM_ABI_VERSION 3
 #define CNM_WINO4_MIN_WORKGROUPS 384
-/* Tuning knob (the engine's only process-wide state): workgroup count from which the fp32 executors prefer the
- * F(4x4,3x3) kernel; n <= 0 only queries.  Returns the previous value. */
+/* Tuning knobs (the engine's only process-wide state).  Each returns the previous value.
+ * wino4_min_workgroups: workgroup count from which the fp32 executors prefer the F(4x4,3x3) kernel; n <= 0 only queries.
+ * refine_side_stream: 1 (default) runs DepthRefineNet's probability decoder on an engine-owned side stream, forked from
+ *   and joined back into the caller's stream with events (the two decoders of depthNet_model.py:341-365 are independent);
+ *   0 keeps every launch on the caller's stream; on < 0 only queries. */
 int cnm_tune_wino4_min_workgroups(int n);
+int cnm_tune_refine_side_stream(int on);
 
 typedef enum cnm_status {
     CNM_OK = 0,
