@@ -137,7 +137,7 @@ def kernel_rooflines(dev, frames):
             "frac": exe / ms / 1e9 / MFMA_F32_PEAK_TF, "traffic": pmc_traffic(name),
             "traffic_note": "HBM bytes per average launch, PMC pass committed under profiles/ (not live)", "launches_per_step": launches,
             "avg_launch_ms": ms / launches, "algorithmic": flop / ms / 1e9,
-            "note": "achieved = flops executed on the matrix cores; algorithmic = direct-convolution-equivalent rate",
+            "note": "achieved = flops executed on the matrix cores; algorithmic = direct-convolution-equivalent rate; avg_launch_ms times each layer alone -- compare with profiles/r1_bench_kernel_stats_serial.csv (in the default run the two refine decoders overlap on two streams, which stretches rocprof's per-launch durations while shortening the step)",
             "all_conv": {"achieved": sum(v[3] for v in per_kernel.values()) / tot_ms / 1e9,
                          "algorithmic": sum(v[0] for v in per_kernel.values()) / tot_ms / 1e9, "ms_per_step": tot_ms,
                          "per_kernel_ms": {k: round(v[1], 3) for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1][1])}}}

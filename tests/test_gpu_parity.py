@@ -341,6 +341,67 @@ def test_winograd_and_direct_networks_agree(dev):
     assert any(np.abs(a - b).max() > 0 for a, b in zip(*outs))           # the two paths really are different kernels
 
 
+def test_refine_side_stream_is_invisible(dev):
+    """DepthRefineNet's second decoder runs on an engine-owned side stream (nets.hip): outputs are bit-identical with the
+    knob off, on a non-default caller stream, from two host threads at once, and inside a captured HIP graph."""
+    import threading
+    from cnmnet_amd import _lib
+    from cnmnet_amd.depthnet import DepthRefineNet
+    lib = _lib.load()
+    rng = np.random.default_rng(8)
+    N, H, W = 3, 64, 96
+    i1 = T(rng.uniform(0.2, 2.5, (N, 1, H, W)).astype(np.float32)).to(dev)
+    i2 = T(rng.uniform(0.2, 2.5, (N, 1, H, W)).astype(np.float32)).to(dev)
+    f1 = T(rng.standard_normal((N, 64, H, W)).astype(np.float32)).to(dev)
+    f2 = T(rng.standard_normal((N, 64, H, W)).astype(np.float32)).to(dev)
+    net = _load(DepthRefineNet(32, 3.0), 6).to(dev)
+    def run():
+        with torch.no_grad():
+            d, p, v = net(i1, i2, f1, f2, ReturnVolume=True)
+        return d.clone(), p.clone(), v.clone()
+    assert lib.cnm_tune_refine_side_stream(-1) == 1                     # default: on
+    on = run()
+    assert lib.cnm_tune_refine_side_stream(0) == 1
+    off = run()
+    assert lib.cnm_tune_refine_side_stream(1) == 0
+    for a, b in zip(on, off):
+        assert torch.equal(a, b)
+    st = torch.cuda.Stream(device=dev)
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        other = run()
+    st.synchronize()
+    for a, b in zip(on, other):
+        assert torch.equal(a, b)
+    results = {}
+    def worker(k):                                                      # each thread: its own net (own workspace), own stream and side stream
+        torch.cuda.set_device(dev)
+        mine = _load(DepthRefineNet(32, 3.0), 6).to(dev)
+        s2 = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(s2), torch.no_grad():
+            for _ in range(3):
+                d, p = mine(i1, i2, f1, f2)
+            s2.synchronize()
+        results[k] = (d, p)
+    torch.cuda.synchronize()
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    for k in range(2):
+        assert torch.equal(results[k][0], on[0]) and torch.equal(results[k][1], on[1])
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        run()
+    torch.cuda.current_stream().wait_stream(side)
+    with torch.cuda.graph(g):
+        with torch.no_grad():
+            gd, gp = net(i1, i2, f1, f2)
+    gd.zero_(); gp.zero_()
+    g.replay(); torch.cuda.synchronize()
+    assert torch.equal(gd, on[0]) and torch.equal(gp, on[1])
+
+
 @pytest.mark.parametrize("planes,S", [(32, 1), (96, 2)])
 def test_depthnet_other_plane_counts_vs_oracle(dev, planes, S):
     """BASELINE configs 1 and 4 use 32 / 96 planes, which the reference cannot run; oracle =
