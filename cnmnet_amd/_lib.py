@@ -20,7 +20,7 @@ class LayerInfo(C.Structure):
 
 
 class LayerWeights(C.Structure):
-    _fields_ = [("w", c_fp), ("b", c_fp), ("u", c_fp), ("u4", c_fp)]
+    _fields_ = [("w", c_fp), ("b", c_fp), ("u", c_fp), ("u4", c_fp), ("uu", c_fp), ("bu", c_fp), ("wr", c_fp)]
 
 
 # name -> (restype, argtypes); mirrors include/cnm_engine.h declaration by declaration
@@ -43,10 +43,15 @@ PROTOTYPES = {
                                           c_i, c_i, c_i, c_i, c_fp]),
     "cnm_tune_wino4_min_workgroups": (c_i, [c_i]),
     "cnm_tune_refine_side_stream": (c_i, [c_i]),
+    "cnm_tune_upsampled_min_pixels": (c_i, [c_i]),
     "cnm_packed_winograd4_floats": (c_sz, [c_i, c_i]),
     "cnm_pack_winograd4_bn_f32": (c_i, [c_fp, c_fp, c_fp, c_f, c_i, c_i, c_i, c_fp, c_fp]),
     "cnm_conv3x3_winograd4_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp,
                                            c_i, c_i, c_i, c_i, c_fp]),
+    "cnm_conv3x3_upsampled_winograd4_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    "cnm_packed_upsampled_ring_floats": (c_sz, [c_i, c_i]),
+    "cnm_pack_upsampled_ring_f32": (c_i, [c_fp, c_fp, c_fp, c_f, c_i, c_i, c_fp, c_fp]),
+    "cnm_conv3x3_upsampled_ring_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp]),
     "cnm_pack_winograd5x5_bn_f32": (c_i, [c_fp, c_fp, c_fp, c_f, c_i, c_i, c_i, c_fp, c_fp]),
     "cnm_conv5x5_winograd_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp,
                                           c_i, c_i, c_i, c_i, c_fp]),
@@ -127,8 +132,8 @@ def load():
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch
         fn.restype, fn.argtypes = res, args
-    if lib.cnm_abi_version() != 3:
-        raise EngineError("libcnm_engine.so ABI version %d, expected 3" % lib.cnm_abi_version())
+    if lib.cnm_abi_version() != 4:
+        raise EngineError("libcnm_engine.so ABI version %d, expected 4" % lib.cnm_abi_version())
     _lib = lib
     return lib
 

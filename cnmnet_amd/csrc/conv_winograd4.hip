@@ -46,6 +46,7 @@ struct Wino4Args {
     int Gin_tot, gin0, Gin2_tot, gin2_0, Gsplit, Gin;
     int Gout_tot, gout0, Cout;
     int nchunks, T, relu;                // T = N*TH*TW tiles
+    int ring;                            // fused upsampling: leave the one-pixel output ring without bias / ReLU for the ring kernel
 };
 
 // B^T (6 points): rows [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1], in place
@@ -66,9 +67,17 @@ struct Wino4Args {
         y0 = m0 + s1 + s2; y1 = fmaf(2.f, d2, d1); y2 = fmaf(4.f, s2, s1); y3 = fmaf(8.f, d2, d1) + m5;         \
     } while (0)
 
-template <int M, int R>                                                  // M x M outputs per tile, R x R filter, M + R - 1 == 6
+// UPS: the convolution runs on the bilinear 2x upsampling of its input without materialising it.  Upsample-then-3x3 is,
+// per output phase (row parity a, column parity b), a 3x3 convolution of the LOW-resolution input with a composed filter
+// (ops.compose_upsample_filters); the four phases are four blocks of "virtual" output channels (Cout = 4 x real, phase
+// major) written pixel-shuffled: virtual channel (2a+b) Cr + c at low-resolution (y, x) -> channel c at (2y+a, 2x+b).
+// The composition equals the convolution of the upsampled image with REPLICATE padding (window samples outside the
+// low-resolution image are clamped, not zeroed); the one-pixel output ring where zero padding differs is corrected by
+// conv_upsampled_ring_kernel, so ring pixels are stored before bias / ReLU here.
+template <int M, int R, bool UPS = false>                                // M x M outputs per tile, R x R filter, M + R - 1 == 6
 __global__ __launch_bounds__(256, 2) void conv_winograd36_f32_kernel(const Wino4Args a) {
     static_assert(M + R - 1 == 6, "36-point kernel");
+    static_assert(!UPS || (M == 4 && R == 3), "fused upsampling: F(4x4,3x3) only");
     constexpr int TT = 16, NXI = 36, VBUF = NXI * TT * 16;               // V[buf][xi][tile][16 ci], slots XOR-swizzled with ((tile >> 1) & 3): conflict-free for the four non-contiguous 16-lane groups of ds_read_b128 and for the writes
     __shared__ __attribute__((aligned(16))) float V[2 * VBUF];           // 72 KB
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -90,7 +99,8 @@ __global__ __launch_bounds__(256, 2) void conv_winograd36_f32_kernel(const Wino4
         imgdelta = (unsigned)img * (unsigned)a.Gin2_tot * (unsigned)HW * 16u - imgterm;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            const int iy = py + i, ix = px + i;
+            int iy = py + i, ix = px + i;
+            if constexpr (UPS) { iy = min(max(iy, 0), a.H - 1); ix = min(max(ix, 0), a.W - 1); }
             roff[i] = (tvalid & ((unsigned)iy < (unsigned)a.H)) ? imgterm + (unsigned)(iy * a.W) * 16u + cc * 4u : 0xFFFFFFFFu;
             coff[i] = (unsigned)ix < (unsigned)a.W ? (unsigned)ix * 16u : 0xFFFFFFFFu;
         }
@@ -216,6 +226,24 @@ __global__ __launch_bounds__(256, 2) void conv_winograd36_f32_kernel(const Wino4
             else WINO2_AT(y[i * 2 + 0][r], y[i * 2 + 1][r], s[i][0], s[i][1], s[i][2], s[i][3], s[i][4], s[i][5]);
         }
     }
+    if constexpr (UPS) {
+        const int Cr = a.Cout >> 2, ph = co / Cr, cr = co - ph * Cr, pa = ph >> 1, pb = ph & 1;
+        const int Ho = 2 * a.H, Wo = 2 * a.W;
+        float* obase = a.out + c4_offset(oimg, a.Gout_tot, a.gout0 + (cr >> 2), 4 * HW, 0);
+#pragma unroll
+        for (int p = 0; p < M * M; ++p) {
+            const int ly = M * oty + p / M, lx = M * otx + p % M;
+            const int oy = 2 * ly + pa, ox = 2 * lx + pb;
+            const bool ring = (oy == 0) | (oy == Ho - 1) | (ox == 0) | (ox == Wo - 1);   // finished by the ring kernel (zero instead of replicate padding)
+            float4 v = make_float4(y[p][0], y[p][1], y[p][2], y[p][3]);
+            if (!ring || !a.ring) {
+                v = make_float4(v.x + bb[0], v.y + bb[1], v.z + bb[2], v.w + bb[3]);
+                if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            }
+            if (ly < a.H && lx < a.W) *reinterpret_cast<float4*>(obase + (size_t)(oy * Wo + ox) * 4) = v;
+        }
+        return;
+    }
     float* obase = a.out + c4_offset(oimg, a.Gout_tot, a.gout0 + (co >> 2), HW, 0);
 #pragma unroll
     for (int p = 0; p < M * M; ++p) {
@@ -277,9 +305,10 @@ static int pack36(const float* w_oihw, const float* bn_gamma, const float* bn_va
 
 static int conv36(const float* in_a, int Ga_total, int ga0, int Ga, const float* in_b, int Gb_total, int gb0, int Gb,
                   float* out, int Gout_total, int gout0, int Cout, const float* u_packed, const float* b_packed,
-                  int N, int H, int W, int ksize, int relu, void* stream) {
+                  int N, int H, int W, int ksize, int relu, void* stream, int ups = 0, int ring = 0) {
     CNM_REQUIRE(in_a && out && u_packed && N > 0 && H > 0 && W > 0 && Ga > 0 && Gb >= 0, CNM_ERR_BAD_ARG);
     CNM_REQUIRE(Cout > 0 && Cout % 64 == 0 && gout0 >= 0 && gout0 + Cout / 4 <= Gout_total, CNM_ERR_BAD_ARG);
+    CNM_REQUIRE(!ups || ksize == 3, CNM_ERR_BAD_ARG);
     CNM_REQUIRE(ga0 >= 0 && ga0 + Ga <= Ga_total && (Gb == 0 || (in_b && gb0 >= 0 && gb0 + Gb <= Gb_total)), CNM_ERR_BAD_ARG);
     Wino4Args a;
     a.in = in_a; a.in2 = Gb ? in_b : in_a; a.out = out; a.u = u_packed; a.bias = b_packed;
@@ -290,10 +319,11 @@ static int conv36(const float* in_a, int Ga_total, int ga0, int Ga, const float*
     const int m = ksize == 3 ? 4 : 2;                                    // outputs per tile side
     a.N = N; a.H = H; a.W = W; a.TH = (H + m - 1) / m; a.TW = (W + m - 1) / m;
     a.Gin_tot = Ga_total; a.gin0 = ga0; a.Gin2_tot = Gb ? Gb_total : Ga_total; a.gin2_0 = Gb ? gb0 : ga0; a.Gsplit = Ga; a.Gin = Ga + Gb;
-    a.Gout_tot = Gout_total; a.gout0 = gout0; a.Cout = Cout;
-    a.nchunks = (4 * a.Gin + 15) / 16; a.T = N * a.TH * a.TW; a.relu = relu;
-    const int nblocks = (Cout / 64) * cnm_ceil_div(a.T, 16);
-    if (ksize == 3) conv_winograd36_f32_kernel<4, 3><<<nblocks, 256, 0, cnm_stream(stream)>>>(a);
+    a.Gout_tot = Gout_total; a.gout0 = gout0; a.Cout = ups ? 4 * Cout : Cout;     // fused upsampling: four phases of virtual output channels
+    a.nchunks = (4 * a.Gin + 15) / 16; a.T = N * a.TH * a.TW; a.relu = relu; a.ring = ring;
+    const int nblocks = (a.Cout / 64) * cnm_ceil_div(a.T, 16);
+    if (ups) conv_winograd36_f32_kernel<4, 3, true><<<nblocks, 256, 0, cnm_stream(stream)>>>(a);
+    else if (ksize == 3) conv_winograd36_f32_kernel<4, 3><<<nblocks, 256, 0, cnm_stream(stream)>>>(a);
     else conv_winograd36_f32_kernel<2, 5><<<nblocks, 256, 0, cnm_stream(stream)>>>(a);
     CNM_LAUNCH_CHECK();
     return CNM_OK;
@@ -312,6 +342,18 @@ extern "C" int cnm_conv3x3_winograd4_c4_f32(const float* in_a, int Ga_total, int
     return conv36(in_a, Ga_total, ga0, Ga, in_b, Gb_total, gb0, Gb, out, Gout_total, gout0, Cout, u_packed, b_packed, N, H, W, 3, relu, stream);
 }
 
+// 3x3 convolution of the bilinear 2x upsampling of `in` ([N][G][H][W][4] -> out [N][Gout][2H][2W][4]) on the
+// low-resolution input: u_packed / b_packed are packed from the four composed phase filters as 4*Cout output channels
+// (phase major).  with_ring = 0: complete result with REPLICATE padding of the upsampled image (differs from the
+// reference's zero padding on the one-pixel output ring); with_ring = 1: ring pixels are left un-biased / un-activated
+// for cnm_conv3x3_upsampled_ring_c4_f32, which turns them into the zero-padding result.
+extern "C" int cnm_conv3x3_upsampled_winograd4_c4_f32(const float* in, int Gin_total, int gin0, int Gin,
+                                                      float* out, int Gout_total, int gout0, int Cout,
+                                                      const float* u_packed, const float* b_packed,
+                                                      int N, int H, int W, int relu, int with_ring, void* stream) {
+    return conv36(in, Gin_total, gin0, Gin, nullptr, 0, 0, 0, out, Gout_total, gout0, Cout, u_packed, b_packed, N, H, W, 3, relu, stream, 1, with_ring);
+}
+
 // F(2x2,5x5): the same 36-point machine with 2x2 output tiles (25 -> 9 multiplies per output; the row-wise kernel needs 15)
 extern "C" int cnm_pack_winograd5x5_bn_f32(const float* w_oihw, const float* bn_gamma, const float* bn_var, float eps,
                                            int Cout, int Cin, int rot, float* u_packed, void* stream) {
@@ -324,4 +366,243 @@ extern "C" int cnm_conv5x5_winograd_c4_f32(const float* in_a, int Ga_total, int 
                                            const float* u_packed, const float* b_packed,
                                            int N, int H, int W, int relu, void* stream) {
     return conv36(in_a, Ga_total, ga0, Ga, in_b, Gb_total, gb0, Gb, out, Gout_total, gout0, Cout, u_packed, b_packed, N, H, W, 5, relu, stream);
+}
+
+// ------------------------------------------------------------------ ring of the fused upsample + 3x3
+// The composed phase filters convolve the upsampled image with replicate padding; the reference zero-pads it.  The two
+// differ only on the one-pixel ring of the output, by the filter taps that land outside the image:
+//     out[co][Y][X] = pre[co][Y][X] - sum_{(ky,kx): (Y+ky-1, X+kx-1) outside} sum_ci w[co][ci][ky][kx] up[ci][clamp(Y+ky-1)][clamp(X+kx-1)]
+// (pre = what the main kernel stored for ring pixels: no bias, no ReLU).  Workgroup = 64 couts x 64 consecutive pixels of
+// one side (top / bottom row, left / right column without the corners); the 66 upsampled border samples a block needs are
+// interpolated from the low-resolution input into LDS once per 16-channel chunk and feed the three taps of the side as
+// shifted B operands of v_mfma_f32_16x16x4_f32; the two extra taps of a corner pixel are added by the row block that
+// owns it.  w_ring: [tap 9][chunk][cout/16][lane][4] in MFMA A-operand order (cnm_pack_upsampled_ring_f32).
+struct RingArgs {
+    const float* in; float* out; const float* wr; const float* bias;
+    int N, H, W, Gin_tot, gin0, Gin, Gout_tot, gout0, Cout, nchunks, relu;
+    int nrow, ncol;                      // 64-pixel blocks per row side / per column side
+};
+
+__device__ __forceinline__ float4 ring_up_sample(const float4* __restrict__ base, int H, int W, int Y, int X) {   // upsample2x_c4_kernel's arithmetic
+    const float sy = fmaxf((Y + 0.5f) * 0.5f - 0.5f, 0.f), sx = fmaxf((X + 0.5f) * 0.5f - 0.5f, 0.f);
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+    const float ly = sy - y0, lx = sx - x0, hy = 1.f - ly, hx = 1.f - lx;
+    const float4 p00 = base[y0 * W + x0], p01 = base[y0 * W + x1], p10 = base[y1 * W + x0], p11 = base[y1 * W + x1];
+    float4 v;
+    v.x = hy * (hx * p00.x + lx * p01.x) + ly * (hx * p10.x + lx * p11.x);
+    v.y = hy * (hx * p00.y + lx * p01.y) + ly * (hx * p10.y + lx * p11.y);
+    v.z = hy * (hx * p00.z + lx * p01.z) + ly * (hx * p10.z + lx * p11.z);
+    v.w = hy * (hx * p00.w + lx * p01.w) + ly * (hx * p10.w + lx * p11.w);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void conv_upsampled_ring_kernel(const RingArgs a) {
+    // The reduction is short and latency-bound (a few dozen workgroups, 8-32 chunks each): the four waves split the
+    // chunks (wave w takes chunks w, w+4, ...), each staging its own chunk in a private LDS region (no workgroup
+    // barrier in the loop) for all 64 couts, and the four partial sums meet in LDS at the end.
+    constexpr int LD = 20;                                               // row pitch in floats: conflict-free ds_read_b128
+    constexpr int LSZ = 66 * LD + 4 * 16;                                // border samples j' = 0..65 (16 channels) + up to 4 corner samples
+    __shared__ __attribute__((aligned(16))) float smem[4 * 16 * 64 * 4]; // 64 KB: per-wave staging first, then the partial sums
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    float* Ls = smem + wave * LSZ;
+    float* Es = Ls + 66 * LD;
+    const int Ho = 2 * a.H, Wo = 2 * a.W, HW = a.H * a.W;
+    const int tilesC = a.Cout / 64, segs = 2 * a.nrow + 2 * a.ncol;
+    int b = blockIdx.x;
+    const int cblk = b % tilesC; b /= tilesC;
+    const int seg = b % segs, img = b / segs;
+    // side 0 top, 1 bottom, 2 left, 3 right; p0 = first pixel of the block along the side
+    const int side = seg < a.nrow ? 0 : seg < 2 * a.nrow ? 1 : seg < 2 * a.nrow + a.ncol ? 2 : 3;
+    const int p0 = 64 * (side == 0 ? seg : side == 1 ? seg - a.nrow : side == 2 ? seg - 2 * a.nrow : seg - 2 * a.nrow - a.ncol);
+    const bool rowside = side < 2;
+    const int len = rowside ? Wo : Ho - 2;                               // pixels along the side
+    // corner extras of a row block: e = 2 * (right corner) + k, k-th of the two taps on the column outside the image
+    //   top:    taps (1,kx),(2,kx) read up[0][X], up[1][X];   bottom: taps (0,kx),(1,kx) read up[Ho-2][X], up[Ho-1][X]
+    const bool hasL = rowside && p0 == 0, hasR = rowside && (Wo - 1 - p0) < 64 && (Wo - 1 - p0) >= 0;
+    const int jR = Wo - 1 - p0;                                          // block-local index of the right corner pixel
+
+    f32x4 acc[4][4];                                                     // [cout group of 16][pixel block of 16]
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[g][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ncb16 = a.Cout / 16;
+    const float4* wbase = reinterpret_cast<const float4*>(a.wr) + lane + (size_t)(cblk * 4) * 64;
+    const size_t tapstride = (size_t)a.nchunks * ncb16 * 64, chunkstride = (size_t)ncb16 * 64;
+    const int col = lane & 15, kg = lane >> 4;
+
+    for (int c = wave; c < a.nchunks; c += 4) {
+        // all global loads of the chunk first (weights of the three taps, then the four low-resolution texels of each
+        // border sample), arithmetic after: the loop is a latency chain, not a throughput problem
+        float4 af[3][4];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int tap = side == 0 ? s : side == 1 ? 6 + s : side == 2 ? 3 * s : 3 * s + 2;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) af[s][g] = wbase[(size_t)tap * tapstride + (size_t)c * chunkstride + (size_t)g * 64];
+        }
+        float4 tx[5][4]; float lyv[5], lxv[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int it = lane + 64 * i, j = min(it >> 2, 65), q = it & 3, g = c * 4 + q;
+            int Y, X;
+            if (rowside) { Y = side == 0 ? 0 : Ho - 1; X = min(max(p0 + j - 1, 0), Wo - 1); }
+            else { X = side == 2 ? 0 : Wo - 1; Y = min(p0 + j, Ho - 1); }
+            const float sy = fmaxf((Y + 0.5f) * 0.5f - 0.5f, 0.f), sx = fmaxf((X + 0.5f) * 0.5f - 0.5f, 0.f);
+            const int y0 = (int)sy, x0 = (int)sx;
+            const int y1 = min(y0 + 1, a.H - 1), x1 = min(x0 + 1, a.W - 1);
+            lyv[i] = sy - y0; lxv[i] = sx - x0;
+            const float4* base = reinterpret_cast<const float4*>(a.in + c4_offset(img, a.Gin_tot, a.gin0 + min(g, a.Gin - 1), HW, 0));
+            tx[i][0] = base[y0 * a.W + x0]; tx[i][1] = base[y0 * a.W + x1]; tx[i][2] = base[y1 * a.W + x0]; tx[i][3] = base[y1 * a.W + x1];
+        }
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int it = lane + 64 * i, j = it >> 2, q = it & 3, g = c * 4 + q;
+            const float ly = lyv[i], lx = lxv[i], hy = 1.f - ly, hx = 1.f - lx;
+            const float4 p00 = tx[i][0], p01 = tx[i][1], p10 = tx[i][2], p11 = tx[i][3];
+            float4 v;                                                    // upsample2x_c4_kernel's arithmetic
+            v.x = hy * (hx * p00.x + lx * p01.x) + ly * (hx * p10.x + lx * p11.x);
+            v.y = hy * (hx * p00.y + lx * p01.y) + ly * (hx * p10.y + lx * p11.y);
+            v.z = hy * (hx * p00.z + lx * p01.z) + ly * (hx * p10.z + lx * p11.z);
+            v.w = hy * (hx * p00.w + lx * p01.w) + ly * (hx * p10.w + lx * p11.w);
+            if (g >= a.Gin) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (it < 66 * 4) *reinterpret_cast<float4*>(Ls + j * LD + q * 4) = v;
+        }
+        if ((hasL || hasR) && lane < 16) {                               // lane = (extra e = lane >> 2, quad q = lane & 3)
+            const int e = lane >> 2, q = lane & 3, g = c * 4 + q;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool right = e >> 1;
+            if (g < a.Gin && (right ? hasR : hasL)) {
+                const float4* base = reinterpret_cast<const float4*>(a.in + c4_offset(img, a.Gin_tot, a.gin0 + g, HW, 0));
+                v = ring_up_sample(base, a.H, a.W, side == 0 ? (e & 1) : Ho - 2 + (e & 1), right ? Wo - 1 : 0);
+            }
+            *reinterpret_cast<float4*>(Es + e * 16 + q * 4) = v;
+        }
+        __builtin_amdgcn_wave_barrier();                                 // wave-private region: LDS operations of one wave complete in order
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            float4 bw[4];
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk) bw[blk] = *reinterpret_cast<const float4*>(Ls + (blk * 16 + col + s) * LD + kg * 4);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 aw = af[s][g];
+#pragma unroll
+                for (int blk = 0; blk < 4; ++blk) {
+                    acc[g][blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw.x, bw[blk].x, acc[g][blk], 0, 0, 0);
+                    acc[g][blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw.y, bw[blk].y, acc[g][blk], 0, 0, 0);
+                    acc[g][blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw.z, bw[blk].z, acc[g][blk], 0, 0, 0);
+                    acc[g][blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw.w, bw[blk].w, acc[g][blk], 0, 0, 0);
+                }
+            }
+        }
+        if (hasL || hasR) {                                              // workgroup-uniform
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool right = e >> 1;
+                if (!(right ? hasR : hasL)) continue;
+                const int k = e & 1, jc = right ? jR : 0;
+                const int ky = side == 0 ? 1 + k : k, kx = right ? 2 : 0;
+                float4 bw = *reinterpret_cast<const float4*>(Es + e * 16 + kg * 4);
+                if (col != (jc & 15)) bw = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 aw = wbase[(size_t)(ky * 3 + kx) * tapstride + (size_t)c * chunkstride + (size_t)g * 64];
+#pragma unroll
+                    for (int blk = 0; blk < 4; ++blk) {
+                        if (blk != (jc >> 4)) continue;
+                        acc[g][blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw.x, bw.x, acc[g][blk], 0, 0, 0);
+                        acc[g][blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw.y, bw.y, acc[g][blk], 0, 0, 0);
+                        acc[g][blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw.z, bw.z, acc[g][blk], 0, 0, 0);
+                        acc[g][blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw.w, bw.w, acc[g][blk], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                                 // reads done before the next chunk overwrites the region
+    }
+
+    // ---- the four partial sums meet: wave w finishes cout group w
+    __syncthreads();
+    f32x4* red = reinterpret_cast<f32x4*>(smem);                         // [src wave][cout group][pixel block][lane]
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) red[((wave * 4 + g) * 4 + blk) * 64 + lane] = acc[g][blk];
+    __syncthreads();
+    f32x4 sum[4];
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) {
+        sum[blk] = red[((0 * 4 + wave) * 4 + blk) * 64 + lane];
+#pragma unroll
+        for (int src = 1; src < 4; ++src) sum[blk] += red[((src * 4 + wave) * 4 + blk) * 64 + lane];
+    }
+
+    // ---- epilogue: row = cout 4*kg + r of group `wave`, col = pixel blk*16 + col: out = act(pre - correction + bias)
+    const int co = cblk * 64 + wave * 16 + 4 * kg;
+    const float4 bias = a.bias ? *reinterpret_cast<const float4*>(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) {
+        const int j = p0 + blk * 16 + col;
+        if (j >= len) continue;
+        const int Y = side == 0 ? 0 : side == 1 ? Ho - 1 : 1 + j, X = side == 2 ? 0 : side == 3 ? Wo - 1 : j;
+        float4* o = reinterpret_cast<float4*>(a.out + c4_offset(img, a.Gout_tot, a.gout0 + (co >> 2), Ho * Wo, Y * Wo + X));
+        float4 v = *o;
+        v.x = v.x - sum[blk][0] + bias.x; v.y = v.y - sum[blk][1] + bias.y; v.z = v.z - sum[blk][2] + bias.z; v.w = v.w - sum[blk][3] + bias.w;
+        if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *o = v;
+    }
+}
+
+// w_ring[tap][chunk][cout/16][lane][4] = w[co = 16 cb + (lane & 15)][ci = 16 chunk + 4 (lane >> 4) + e][tap] * BatchNorm scale
+__global__ void pack_upsampled_ring_kernel(const float* __restrict__ w, const float* __restrict__ gamma, const float* __restrict__ var,
+                                           float eps, int Cout, int Cin, int nchunks, float* __restrict__ wr) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int ncb16 = Cout / 16;
+    const long long total = 9ll * nchunks * ncb16 * 64 * 4;
+    if (idx >= total) return;
+    const int e = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
+    long long r = idx >> 8;
+    const int cb = (int)(r % ncb16); r /= ncb16;
+    const int chunk = (int)(r % nchunks), tap = (int)(r / nchunks);
+    const int co = cb * 16 + (lane & 15), ci = chunk * 16 + 4 * (lane >> 4) + e;
+    float v = 0.f;
+    if (ci < Cin) {
+        const double sc = gamma ? (double)gamma[co] / sqrt((double)var[co] + (double)eps) : 1.0;
+        v = (float)((double)w[((size_t)co * Cin + ci) * 9 + tap] * sc);
+    }
+    wr[idx] = v;
+}
+
+extern "C" size_t cnm_packed_upsampled_ring_floats(int Cout, int Cin) {
+    if (Cout <= 0 || Cin <= 0 || Cout % 64) return 0;
+    return (size_t)9 * ((4 * ((Cin + 3) / 4) + 15) / 16) * Cout * 16;
+}
+
+extern "C" int cnm_pack_upsampled_ring_f32(const float* w_oihw, const float* bn_gamma, const float* bn_var, float eps,
+                                           int Cout, int Cin, float* w_ring, void* stream) {
+    CNM_REQUIRE(w_oihw && w_ring && Cout > 0 && Cout % 64 == 0 && Cin > 0 && !bn_gamma == !bn_var, CNM_ERR_BAD_ARG);
+    const int nchunks = (4 * ((Cin + 3) / 4) + 15) / 16;
+    const long long total = 9ll * nchunks * Cout * 16;
+    pack_upsampled_ring_kernel<<<(unsigned)cnm_ceil_div_ll(total, 256), 256, 0, cnm_stream(stream)>>>(w_oihw, bn_gamma, bn_var, eps, Cout, Cin, nchunks, w_ring);
+    CNM_LAUNCH_CHECK();
+    return CNM_OK;
+}
+
+extern "C" int cnm_conv3x3_upsampled_ring_c4_f32(const float* in, int Gin_total, int gin0, int Gin,
+                                                 float* out, int Gout_total, int gout0, int Cout,
+                                                 const float* w_ring, const float* b_packed,
+                                                 int N, int H, int W, int relu, void* stream) {
+    CNM_REQUIRE(in && out && w_ring && N > 0 && H > 1 && W > 1 && Gin > 0, CNM_ERR_BAD_ARG);
+    CNM_REQUIRE(Cout > 0 && Cout % 64 == 0 && gout0 >= 0 && gout0 + Cout / 4 <= Gout_total && gin0 >= 0 && gin0 + Gin <= Gin_total, CNM_ERR_BAD_ARG);
+    RingArgs a;
+    a.in = in; a.out = out; a.wr = w_ring; a.bias = b_packed;
+    a.N = N; a.H = H; a.W = W; a.Gin_tot = Gin_total; a.gin0 = gin0; a.Gin = Gin; a.Gout_tot = Gout_total; a.gout0 = gout0; a.Cout = Cout;
+    a.nchunks = (4 * Gin + 15) / 16; a.relu = relu;
+    a.nrow = cnm_ceil_div(2 * W, 64); a.ncol = cnm_ceil_div(2 * H - 2, 64);
+    const int nblocks = N * (2 * a.nrow + 2 * a.ncol) * (Cout / 64);
+    conv_upsampled_ring_kernel<<<nblocks, 256, 0, cnm_stream(stream)>>>(a);
+    CNM_LAUNCH_CHECK();
+    return CNM_OK;
 }

@@ -114,8 +114,21 @@ static SideStream* side_stream() {
     return x.ok ? &x : nullptr;
 }
 
+// up_conv layers: one fused pass over the low-resolution input when the upsampled tensor is big and the ring is cheap
+static int g_upsampled_min_pixels = CNM_UPSAMPLED_MIN_PIXELS;
+extern "C" int cnm_tune_upsampled_min_pixels(int n) { const int old = g_upsampled_min_pixels; if (n > 0) g_upsampled_min_pixels = n; return old; }
+
 struct EngF32 {
     static constexpr int GD = 4;
+    // nn.Upsample(2, bilinear) + conv3x3 + BN + ReLU (up_conv_layer, depthNet_model.py:89-112): in [N][G][H][W] -> out at 2H x 2W
+    static int upconv(const float* in, int G, float* up_tmp, float* out, int Gto, int go0, int Cout, const cnm_layer_weights& w, int N, int H, int W, void* s) {
+        if (w.uu && w.bu && w.wr && G * 4 <= 256 && (long long)N * 4 * H * W >= g_upsampled_min_pixels) {
+            const int e = cnm_conv3x3_upsampled_winograd4_c4_f32(in, G, 0, G, out, Gto, go0, Cout, w.uu, w.bu, N, H, W, 1, 1, s);
+            return e != CNM_OK ? e : cnm_conv3x3_upsampled_ring_c4_f32(in, G, 0, G, out, Gto, go0, Cout, w.wr, w.b, N, H, W, 1, s);
+        }
+        const int e = up(in, G, up_tmp, N, H, W, s);
+        return e != CNM_OK ? e : conv(up_tmp, G, 0, G, out, Gto, go0, Cout, w, N, 2 * H, 2 * W, 3, 1, s);
+    }
     static int conv(const float* in, int Gt, int g0, int Gin, float* out, int Gto, int go0, int Cout, const cnm_layer_weights& w, int N, int H, int W, int k, int st, void* s) {
         if (w.u4 && k == 3 && st == 1 && wino4_fills_chip(Cout, N, H, W))
             return cnm_conv3x3_winograd4_c4_f32(in, Gt, g0, Gin, nullptr, 0, 0, 0, out, Gto, go0, Cout, w.u4, w.b, N, H, W, 1, s);
@@ -138,6 +151,10 @@ struct EngF32 {
 
 struct EngF16 {
     static constexpr int GD = 8;
+    static int upconv(const float* in, int G, float* up_tmp, float* out, int Gto, int go0, int Cout, const cnm_layer_weights& w, int N, int H, int W, void* s) {
+        const int e = up(in, G, up_tmp, N, H, W, s);
+        return e != CNM_OK ? e : conv(up_tmp, G, 0, G, out, Gto, go0, Cout, w, N, 2 * H, 2 * W, 3, 1, s);
+    }
     static int conv(const float* in, int Gt, int g0, int Gin, float* out, int Gto, int go0, int Cout, const cnm_layer_weights& w, int N, int H, int W, int k, int st, void* s) {
         return cnm_conv2d_c8_f16(in, Gt, g0, Gin, out, Gto, go0, Cout, w.w, w.b, N, H, W, k, st, 1, s); }
     static int conv2(const float* a, int Ga, const float* b, int Gb, float* out, int Gto, int Cout, const cnm_layer_weights& w, int N, int H, int W, void* s) {
@@ -225,23 +242,18 @@ static int depthnet_forward(const cnm_layer_weights* wt, float idepth_scale, int
     CONV(D_CONV5_0, b.CAT5, 2 * g512, g512, g512, b.A5, g512, 0, 512, H4, W4);
     CONV(D_CONV5_3, b.A5, g512, 0, g512, b.C5, g512, 0, 512, H4, W4);
     // decoder                                                                  :241-261
-    CNM_TRY(E::up(b.C5, g512, b.U5, P, H5, W5, s));
-    CONV(D_UPCONV5, b.U5, g512, 0, g512, b.CAT5, 2 * g512, 0, 512, H4, W4);
+    CNM_TRY(E::upconv(b.C5, g512, b.U5, b.CAT5, 2 * g512, 0, 512, wt[D_UPCONV5], P, H5, W5, s));
     CONV(D_ICONV5, b.CAT5, 2 * g512, 0, 2 * g512, b.I5, g512, 0, 512, H4, W4);
-    CNM_TRY(E::up(b.I5, g512, b.U4, P, H4, W4, s));
-    CONV(D_UPCONV4, b.U4, g512, 0, g512, b.CAT4, 2 * g512, 0, 512, H3, W3);
+    CNM_TRY(E::upconv(b.I5, g512, b.U4, b.CAT4, 2 * g512, 0, 512, wt[D_UPCONV4], P, H4, W4, s));
     CONV(D_ICONV4, b.CAT4, 2 * g512, 0, 2 * g512, b.I4, g512, 0, 512, H3, W3);
     CNM_TRY(E::head(b.I4, g512, 512, wt[D_DISP4], idepth_scale, disp4, b.CAT3, 2 * g256 + 1, 2 * g256, P, H3, W3, s));
-    CNM_TRY(E::up(b.I4, g512, b.U3, P, H3, W3, s));
-    CONV(D_UPCONV3, b.U3, g512, 0, g512, b.CAT3, 2 * g256 + 1, 0, 256, H2, W2);
+    CNM_TRY(E::upconv(b.I4, g512, b.U3, b.CAT3, 2 * g256 + 1, 0, 256, wt[D_UPCONV3], P, H3, W3, s));
     CONV(D_ICONV3, b.CAT3, 2 * g256 + 1, 0, 2 * g256 + 1, b.I3, g256, 0, 256, H2, W2);
     CNM_TRY(E::head(b.I3, g256, 256, wt[D_DISP3], idepth_scale, disp3, b.CAT2, 2 * g128 + 1, 2 * g128, P, H2, W2, s));
-    CNM_TRY(E::up(b.I3, g256, b.U2, P, H2, W2, s));
-    CONV(D_UPCONV2, b.U2, g256, 0, g256, b.CAT2, 2 * g128 + 1, 0, 128, H1, W1);
+    CNM_TRY(E::upconv(b.I3, g256, b.U2, b.CAT2, 2 * g128 + 1, 0, 128, wt[D_UPCONV2], P, H2, W2, s));
     CONV(D_ICONV2, b.CAT2, 2 * g128 + 1, 0, 2 * g128 + 1, b.I2, g128, 0, 128, H1, W1);
     CNM_TRY(E::head(b.I2, g128, 128, wt[D_DISP2], idepth_scale, disp2, b.CAT1, g64 + 1, g64, P, H1, W1, s));
-    CNM_TRY(E::up(b.I2, g128, b.U1, P, H1, W1, s));
-    CONV(D_UPCONV1, b.U1, g128, 0, g128, b.CAT1, g64 + 1, 0, 64, H, W);
+    CNM_TRY(E::upconv(b.I2, g128, b.U1, b.CAT1, g64 + 1, 0, 64, wt[D_UPCONV1], P, H1, W1, s));
     CONV(D_ICONV1, b.CAT1, g64 + 1, 0, g64 + 1, iconv1, g64, 0, 64, H, W);
     CNM_TRY(E::head(iconv1, g64, 64, wt[D_DISP1], idepth_scale, disp1, nullptr, 0, 0, P, H, W, s));
 #undef CONV
@@ -323,11 +335,11 @@ static int refinenet_body(const cnm_layer_weights* wt, float idepth_scale, const
             switch (step) {
                 case 0: CONV(L + 0, b.U3, g512, d.UC3, 256, H2, W2); break;
                 case 1: CNM_TRY(E::conv2(d.UC3, g256, b.C2, g256, d.I3, g256, 256, wt[L + 1], N, H2, W2, q)); break;
-                case 2: CNM_TRY(E::up(d.I3, g256, d.U2, N, H2, W2, q)); break;
-                case 3: CONV(L + 2, d.U2, g256, d.UC2, 128, H1, W1); break;
+                case 2: break;
+                case 3: CNM_TRY(E::upconv(d.I3, g256, d.U2, d.UC2, g128, 0, 128, wt[L + 2], N, H2, W2, q)); break;
                 case 4: CNM_TRY(E::conv2(d.UC2, g128, b.C1, g128, d.I2, g128, 128, wt[L + 3], N, H1, W1, q)); break;
-                case 5: CNM_TRY(E::up(d.I2, g128, d.U1, N, H1, W1, q)); break;
-                case 6: CONV(L + 4, d.U1, g128, d.UC1, 64, H, W); break;
+                case 5: break;
+                case 6: CNM_TRY(E::upconv(d.I2, g128, d.U1, d.UC1, g64, 0, 64, wt[L + 4], N, H1, W1, q)); break;
                 case 7: CONV(L + 5, d.UC1, g64, feat, 64, H, W); break;
                 case 8: CNM_TRY(E::head(feat, g64, 64, wt[R_HEAD0 + br], br == 0 ? idepth_scale : 1.0f, br == 0 ? disp_refined : prob_map,
                                         nullptr, 0, 0, N, H, W, q)); break;

@@ -75,6 +75,7 @@ class _EngineNet(nn.Module):
         self._layers = None        # engine layer table (resolved lazily: needs the library)
         self.winograd = os.environ.get("CNM_WINOGRAD", "1") != "0"   # fp32 stride-1 layers in the Winograd domain
         self.winograd4 = os.environ.get("CNM_WINOGRAD4", "1") != "0"  # large 3x3 layers: F(4x4,3x3) instead of F(2x2,3x3)
+        self.fused_upsample = os.environ.get("CNM_FUSED_UPSAMPLE", "1") != "0"   # up_conv layers: upsample folded into the conv (composed phase filters)
         self._packed = None        # [(w, b[, u])] device tensors, one per engine layer
         self._packed_key = None
         self._weights_arr = None
@@ -87,7 +88,7 @@ class _EngineNet(nn.Module):
 
     def _param_key(self):
         ts = list(self.parameters()) + list(self.buffers())
-        return (self.precision, self.winograd, self.winograd4, str(ts[0].device), tuple(t._version for t in ts), tuple(t.data_ptr() for t in ts[:4]))
+        return (self.precision, self.winograd, self.winograd4, self.fused_upsample, str(ts[0].device), tuple(t._version for t in ts), tuple(t.data_ptr() for t in ts[:4]))
 
     def _first_cin(self):
         return None
@@ -119,12 +120,17 @@ class _EngineNet(nn.Module):
                     # 3x3 / 5x5 stride 1: also the 36-point filter (F(4x4,3x3) / F(2x2,5x5)); the executor picks per call by tile count
                     u4 = (ops.pack_winograd4(w, bnp, rot=L["rot"], eps=bn.eps)
                           if (L["ksize"] in (3, 5) and L["stride"] == 1 and self.winograd4) else None)
-                    packed.append((wp, bp, up, u4))
+                    # up_conv layers the executor may run fused with their bilinear upsampling (<= 256 input channels)
+                    fused = (ops.pack_winograd4_upsampled(w, bnp, eps=bn.eps)
+                             if (u4 is not None and L["ksize"] == 3 and L["conv_key"].startswith("upconv") and L["Cin"] <= 256
+                                 and self.fused_upsample) else (None, None, None))
+                    packed.append((wp, bp, up, u4) + tuple(fused))
         arr = (_lib.LayerWeights * len(packed))()
         for i, t in enumerate(packed):
             arr[i].w, arr[i].b = t[0].data_ptr(), t[1].data_ptr()
             arr[i].u = t[2].data_ptr() if len(t) > 2 else None
             arr[i].u4 = t[3].data_ptr() if len(t) > 3 and t[3] is not None else None
+            arr[i].uu, arr[i].bu, arr[i].wr = [t[j].data_ptr() if len(t) > 6 and t[j] is not None else None for j in (4, 5, 6)]
         self._packed, self._weights_arr, self._packed_key = packed, arr, key
 
     def _workspace(self, device, nfloats):

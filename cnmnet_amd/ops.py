@@ -253,6 +253,53 @@ def conv3x3_winograd4_c4(x, u_packed, b_packed, Cout, relu=True, x2=None, ksize=
     return out
 
 
+# rows of the bilinear 2x upsampling (align_corners=False) seen by a 3-tap window, as weights on low-resolution rows
+# (i-1, i, i+1): [output parity a][tap k] -- hi-res row 2i+a+k-1
+_UPS_TAPS = (((0.75, 0.25, 0.0), (0.25, 0.75, 0.0), (0.0, 0.75, 0.25)),
+             ((0.25, 0.75, 0.0), (0.0, 0.75, 0.25), (0.0, 0.25, 0.75)))
+
+
+def compose_upsample_filters(weight):
+    """3x3 filter applied AFTER nn.Upsample(scale_factor=2, mode='bilinear') == four 3x3 filters (one per output row /
+    column parity) applied to the low-resolution image: [Cout,Cin,3,3] -> [4*Cout,Cin,3,3], phase (2a+b) major.
+    Exact away from the image border (the composition corresponds to replicate padding of the upsampled image)."""
+    U = torch.tensor(_UPS_TAPS, dtype=torch.float64, device=weight.device)
+    wv = torch.einsum("oikl,akp,blq->aboipq", weight.double(), U, U)
+    return wv.reshape(4 * weight.shape[0], weight.shape[1], 3, 3).float().contiguous()
+
+
+def pack_winograd4_upsampled(weight, bn=None, eps=1e-5):
+    """(u_packed, b_packed, w_ring) for conv3x3_upsampled_winograd4_c4: the composed phase filters as 4*Cout output
+    channels, the folded bias four times, and the plain filter in MFMA order for the ring pass."""
+    _dev(weight, *(bn or ()))
+    lib = _lib.load()
+    Cout, Cin = weight.shape[:2]
+    rep = tuple(t.repeat(4) for t in bn) if bn else None
+    wr = torch.empty(lib.cnm_packed_upsampled_ring_floats(Cout, Cin), device=weight.device, dtype=torch.float32)
+    g, v = (_c(bn[0]), _c(bn[3])) if bn else (None, None)
+    with torch.cuda.device(weight.device):
+        _lib.check(lib.cnm_pack_upsampled_ring_f32(_p(_c(weight)), _p(g), _p(v), eps, Cout, Cin, _p(wr), _stream()))
+    return pack_winograd4(compose_upsample_filters(weight), rep, 0, eps), pack_conv(weight, bn, eps=eps)[1].repeat(4).contiguous(), wr
+
+
+def conv3x3_upsampled_winograd4_c4(x, u_packed, b_packed, Cout, relu=True, w_ring=None, out=None):
+    """conv3x3(upsample2x(x)) + bias (+ ReLU) without materialising the upsampled tensor: x [N,G,H,W,4] -> [N,Cout/4,2H,2W,4].
+    With w_ring (pack_winograd4_upsampled) the ring pass follows and the result is the reference's zero-padded one;
+    without it the upsampled image is replicate-padded (differs on the one-pixel output ring)."""
+    _dev(x, u_packed, b_packed, w_ring)
+    N, G, H, W, _ = x.shape
+    if out is None:
+        out = torch.empty(N, Cout // 4, 2 * H, 2 * W, 4, device=x.device, dtype=torch.float32)
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        _lib.check(lib.cnm_conv3x3_upsampled_winograd4_c4_f32(_p(x), G, 0, G, _p(out), Cout // 4, 0, Cout, _p(u_packed), _p(b_packed),
+                                                              N, H, W, int(relu), int(w_ring is not None), _stream()))
+        if w_ring is not None:
+            _lib.check(lib.cnm_conv3x3_upsampled_ring_c4_f32(_p(x), G, 0, G, _p(out), Cout // 4, 0, Cout, _p(w_ring), _p(b_packed),
+                                                             N, H, W, int(relu), _stream()))
+    return out
+
+
 def conv_rows_winograd_c4(x, u_packed, b_packed, Cout, ksize, relu=True, x2=None, stride=1, tile=None):
     """Row-wise Winograd twin of conv2d_c4(ksize=5|7, stride=1|2)."""
     _dev(x, u_packed, b_packed, x2)

@@ -34,8 +34,9 @@
 extern "C" {
 #endif
 
-#define CNM_ABI_VERSION 3
+#define CNM_ABI_VERSION 4
 #define CNM_WINO4_MIN_WORKGROUPS 384
+#define CNM_UPSAMPLED_MIN_PIXELS 196608      /* 16 images x 96 x 128 */
 /* Tuning knobs (the engine's only process-wide state).  Each returns the previous value.
  * wino4_min_workgroups: workgroup count from which the fp32 executors prefer the F(4x4,3x3) kernel; n <= 0 only queries.
  * refine_side_stream: 1 (default) runs DepthRefineNet's probability decoder on an engine-owned side stream, forked from
@@ -43,6 +44,11 @@ extern "C" {
  *   0 keeps every launch on the caller's stream; on < 0 only queries. */
 int cnm_tune_wino4_min_workgroups(int n);
 int cnm_tune_refine_side_stream(int on);
+/* upsampled_min_pixels: an up_conv_layer (bilinear x2 + 3x3, depthNet_model.py:89-112) runs as ONE fused pass over its
+ *   low-resolution input (cnm_conv3x3_upsampled_winograd4_c4_f32 + ring pass) when its output has at least this many
+ *   pixels over the batch and at most 256 input channels -- below that the ring pass costs more than the upsampled
+ *   tensor's round trip; n <= 0 only queries, INT_MAX switches the fused path off. */
+int cnm_tune_upsampled_min_pixels(int n);
 
 typedef enum cnm_status {
     CNM_OK = 0,
@@ -156,6 +162,31 @@ int cnm_conv5x5_winograd_c4_f32(const float* in_a, int Ga_total, int ga0, int Ga
                                 const float* u_packed, const float* b_packed,
                                 int N, int H, int W, int relu, void* stream);
 
+/* nn.Upsample(scale_factor=2, mode='bilinear') followed by Conv2d(3x3, pad 1) + folded BatchNorm + ReLU -- the
+ * reference's up_conv_layer (depthNet_model.py:89-112) -- as ONE pass over the LOW-resolution input: upsample-then-3x3
+ * equals, per output row / column parity, a 3x3 filter on the low-resolution image; the four composed filters are packed
+ * (cnm_pack_winograd4_bn_f32 with 4*Cout output channels, phase major; bias replicated four times) and the F(4x4,3x3)
+ * kernel writes its 4*Cout virtual channels pixel-shuffled.  in [N][Gin_total][H][W][4] -> out [N][Gout_total][2H][2W][4].
+ * The composition corresponds to REPLICATE padding of the upsampled image; the reference zero-pads, which differs on the
+ * one-pixel output ring only: with_ring = 1 leaves the ring pre-activation and cnm_conv3x3_upsampled_ring_c4_f32
+ * (w_ring from cnm_pack_upsampled_ring_f32) finishes it; with_ring = 0 returns the replicate-padding result. */
+int cnm_conv3x3_upsampled_winograd4_c4_f32(const float* in, int Gin_total, int gin0, int Gin,
+                                           float* out, int Gout_total, int gout0, int Cout,
+                                           const float* u_packed, const float* b_packed,
+                                           int N, int H, int W, int relu, int with_ring, void* stream);
+
+/* Ring pass of the fused upsample + 3x3 convolution: subtracts, on the one-pixel output ring, the filter taps that the
+ * replicate-padded composition added beyond the reference's zero padding, then applies bias and ReLU there.
+ * w_ring = the plain 3x3 filter with the folded BatchNorm scale in MFMA operand order
+ * (cnm_packed_upsampled_ring_floats floats); b_packed = the layer's folded bias (Cout floats). */
+size_t cnm_packed_upsampled_ring_floats(int Cout, int Cin);
+int cnm_pack_upsampled_ring_f32(const float* w_oihw, const float* bn_gamma, const float* bn_var, float eps,
+                                int Cout, int Cin, float* w_ring, void* stream);
+int cnm_conv3x3_upsampled_ring_c4_f32(const float* in, int Gin_total, int gin0, int Gin,
+                                      float* out, int Gout_total, int gout0, int Cout,
+                                      const float* w_ring, const float* b_packed,
+                                      int N, int H, int W, int relu, void* stream);
+
 /* Row-wise Winograd twin of cnm_conv2d_cat2_c4_f32 for ksize R = 5 or 7, stride 1 or 2 (the reference's
  * conv1 = nn.Conv2d(3+D, 128, 7, 1, 3) / (128, 128, 7, 2, 3) and conv2 = nn.Conv2d(128, 256, 5, 1, 2) /
  * (256, 256, 5, 2, 2), depthNet_model.py:137-148 via conv_layer :77-86): the transform runs along image rows, the R
@@ -232,8 +263,12 @@ int cnm_net_layer(int net, int index, cnm_layer_info* info);   /* D=64 table */
  * cnm_conv_rows_winograd_c4_f32 (w may then be NULL); ignored by heads, 3x3 stride-2 layers and the fp16 engine.
  * u4: optional 36-point filter -- cnm_pack_winograd4_bn_f32 (F(4x4,3x3)) for 3x3 stride-1 layers,
  * cnm_pack_winograd5x5_bn_f32 (F(2x2,5x5)) for 5x5 stride-1 layers: used instead of u when the layer has enough tiles
- * to fill the chip (>= CNM_WINO4_MIN_WORKGROUPS workgroups of 64 couts x 16 tiles). */
-typedef struct cnm_layer_weights { const float* w; const float* b; const float* u; const float* u4; } cnm_layer_weights;
+ * to fill the chip (>= CNM_WINO4_MIN_WORKGROUPS workgroups of 64 couts x 16 tiles).
+ * uu, bu, wr: optional, up_conv layers only -- the four composed upsample-then-3x3 phase filters packed as 4*Cout
+ * output channels (cnm_pack_winograd4_bn_f32), the folded bias four times, and the ring-pass filter
+ * (cnm_pack_upsampled_ring_f32); all three or none. */
+typedef struct cnm_layer_weights { const float* w; const float* b; const float* u; const float* u4;
+                                   const float* uu; const float* bu; const float* wr; } cnm_layer_weights;
 
 /* depthNet.forward (depthNet_model.py:226-263) for P = B*S (ref,src) pairs.
  * weights[i] = packed tensors of layer i of the CNM_NET_DEPTH table (conv1.0 packed with

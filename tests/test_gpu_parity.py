@@ -229,6 +229,70 @@ def test_conv5x5_winograd(dev, ops, cin, cout, rot, N, H, W):
     assert np.abs(got - want).max() < 2e-4 * max(np.abs(want).max(), 1.0), np.abs(got - want).max()
 
 
+@pytest.mark.parametrize("cin,cout,N,H,W", [(128, 64, 2, 24, 32), (20, 128, 1, 3, 40), (64, 64, 2, 9, 21), (256, 128, 1, 12, 16), (8, 64, 3, 2, 2), (36, 64, 1, 33, 70)])
+def test_conv3x3_upsampled_fused(dev, ops, cin, cout, N, H, W):
+    """up_conv_layer (reference depthNet_model.py:89-112: bilinear x2, conv3x3, BN, ReLU) as ONE pass over the
+    low-resolution input (composed phase filters + ring pass) against torch in float64: interior, edges and corners,
+    ragged tiles, blocks that hold both corners (2W <= 64), several 64-pixel ring blocks per side."""
+    rng = np.random.default_rng(cin * 23 + H)
+    x = T(rng.standard_normal((N, cin, H, W)).astype(np.float32))
+    w = T((rng.standard_normal((cout, cin, 3, 3)) * (2.0 / (cin * 9)) ** 0.5).astype(np.float32))
+    bnp = [T(a.astype(np.float32)) for a in (rng.uniform(0.5, 1.5, cout), rng.normal(0, 0.2, cout), rng.normal(0, 0.2, cout), rng.uniform(0.5, 1.5, cout))]
+    sc = bnp[0].double() / torch.sqrt(bnp[3].double() + 1e-5)
+    up = F.interpolate(x.double(), scale_factor=2, mode="bilinear", align_corners=False)
+    pre = F.conv2d(up, w.double(), padding=1) * sc[None, :, None, None] + (bnp[1].double() - bnp[2].double() * sc)[None, :, None, None]
+    want = F.relu(pre).numpy()
+    bnd = tuple(t.to(dev) for t in bnp)
+    uu, bu, wr = ops.pack_winograd4_upsampled(w.to(dev), bnd)
+    xc = ops.nchw_to_c4(x.to(dev))
+    got = ops.c4_to_nchw(ops.conv3x3_upsampled_winograd4_c4(xc, uu, bu, cout, True, wr), cout).cpu().numpy()
+    assert got.shape == want.shape == (N, cout, 2 * H, 2 * W)
+    tol = 2e-4 * max(np.abs(want).max(), 1.0)
+    err = np.abs(got - want)
+    assert err.max() < tol, (err.max(), np.unravel_index(err.argmax(), err.shape))
+    # without the ring pass the result is the replicate-padding one: identical inside, different on the ring only
+    rep = ops.c4_to_nchw(ops.conv3x3_upsampled_winograd4_c4(xc, uu, bu, cout, True), cout).cpu().numpy()
+    assert np.abs(rep - want)[:, :, 1:-1, 1:-1].max() < tol
+    assert np.abs(rep - want).max() > 10 * tol
+    # writing into a channel-group slice of a wider buffer, no ReLU
+    wide = torch.full((N, cout // 4 + 3, 2 * H, 2 * W, 4), 7.0, device=dev)
+    from cnmnet_amd import _lib
+    lib, P = _lib.load(), (lambda t_: t_.data_ptr())
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.cnm_conv3x3_upsampled_winograd4_c4_f32(P(xc), xc.shape[1], 0, xc.shape[1], P(wide), cout // 4 + 3, 2, cout, P(uu), P(bu), N, H, W, 0, 1, st))
+    _lib.check(lib.cnm_conv3x3_upsampled_ring_c4_f32(P(xc), xc.shape[1], 0, xc.shape[1], P(wide), cout // 4 + 3, 2, cout, P(wr), P(bu), N, H, W, 0, st))
+    torch.cuda.synchronize()
+    assert float(wide[:, :2].min()) == 7.0 and float(wide[:, -1].max()) == 7.0
+    lin = ops.c4_to_nchw(wide[:, 2:2 + cout // 4].contiguous(), cout).cpu().numpy()
+    assert np.abs(lin - pre.numpy()).max() < tol
+
+
+def test_fused_upsample_networks_agree(dev):
+    """Both nets with every eligible up_conv layer fused (threshold lowered to 1 pixel) against the same nets with the
+    fused path off: same frame, outputs within 1e-4 -- and against the golden frame, the 1e-3 bar."""
+    from cnmnet_amd import _lib
+    from cnmnet_amd.depthnet import depthNet, DepthRefineNet
+    lib = _lib.load()
+    img, cams = syn.frames(2, 2, 64, 96, seed=31)
+    outs = []
+    old = lib.cnm_tune_upsampled_min_pixels(1)
+    old4 = lib.cnm_tune_wino4_min_workgroups(1)
+    try:
+        for fused in (True, False):
+            net = _load(depthNet(3.0), 5).to(dev); net.fused_upsample = fused
+            ref = _load(DepthRefineNet(32, 3.0), 6).to(dev); ref.fused_upsample = fused
+            with torch.no_grad():
+                o1, f1 = net(T(img[:, 0]).to(dev), T(img[:, 1]).to(dev), T(cams[:, 0]).to(dev), T(cams[:, 1]).to(dev))
+                o2, f2 = net(T(img[:, 0]).to(dev), T(img[:, 2]).to(dev), T(cams[:, 0]).to(dev), T(cams[:, 2]).to(dev))
+                d, p = ref(o1[0], o2[0], f1, f2)
+            outs.append([t.cpu().numpy() for t in (o1[0], o1[1], d, p)])
+    finally:
+        lib.cnm_tune_upsampled_min_pixels(old); lib.cnm_tune_wino4_min_workgroups(old4)
+    for a, b in zip(*outs):
+        assert np.abs(a - b).max() < 1e-4, np.abs(a - b).max()
+    assert any(np.abs(a - b).max() > 0 for a, b in zip(*outs))           # the fused path really ran
+
+
 def test_winograd4_networks_golden(dev, golden):
     """Both nets with EVERY 3x3 stride-1 layer forced through F(4x4,3x3) (the executors normally pick it only for layers
     with >= CNM_WINO4_MIN_WORKGROUPS workgroups, i.e. never at this 64x96 size) against the reference's golden outputs:
