@@ -30,6 +30,7 @@ H, W, PLANES, SRC, KSIZE = 192, 256, 64, 2, 9
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_32x32x2_f32)
 WINO4_MIN_WORKGROUPS = 384     # include/cnm_engine.h CNM_WINO4_MIN_WORKGROUPS (executor's F(4x4,3x3) / F(2x2,3x3) switch)
+UPSAMPLED_MIN_PIXELS = 196608   # include/cnm_engine.h CNM_UPSAMPLED_MIN_PIXELS (executor's fused upsample + conv switch for up_conv layers)
 DEPTH_LEVEL = [0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 4, 4, 3, 3, 2, 2, 1, 1, 0, 0]      # input resolution level per conv layer
 REFINE_LEVEL = [0, 0, 1, 1, 2, 2, 2, 2, 1, 1, 0, 0, 2, 2, 1, 1, 0, 0]
 
@@ -85,10 +86,10 @@ def conv_kernel(L, m, m4=0):
     k, s = L["ksize"], L["stride"]
     if s == 1 and k == 3:
         if L["Cout"] // 64 * -(-m4 // 16) >= WINO4_MIN_WORKGROUPS:
-            return "conv_winograd36_f32_kernel<4, 3>", 36.0 / 144.0      # F(4x4,3x3): 36 multiplies per 16 outputs instead of 144
+            return "conv_winograd36_f32_kernel<4, 3, false>", 36.0 / 144.0      # F(4x4,3x3): 36 multiplies per 16 outputs instead of 144
         return "conv3x3_winograd_f32_kernel", 16.0 / 36.0            # F(2x2,3x3): 16 multiplies per 4 outputs instead of 36
     if k == 5 and s == 1 and L["Cout"] // 64 * -(-(m // 4) // 16) >= WINO4_MIN_WORKGROUPS:
-        return "conv_winograd36_f32_kernel<2, 5>", 36.0 / 100.0          # F(2x2,5x5): 36 multiplies per 4 outputs instead of 100
+        return "conv_winograd36_f32_kernel<2, 5, false>", 36.0 / 100.0          # F(2x2,5x5): 36 multiplies per 4 outputs instead of 100
     if k in (5, 7):                                                  # F(2,k) along rows; stride 2: two F(2,ceil(k/2)) column phases
         if k == 7 and s == 1:
             return "conv_rows_winograd_f32_kernel<7, 1, 4>", 10.0 / 28.0      # F(4,7): 10 multiplies per 4 outputs and kernel row instead of 28
@@ -115,6 +116,23 @@ def kernel_rooflines(dev, frames):
             ho, wo = h // L["stride"], w // L["stride"]
             name, executed = conv_kernel(L, n_img * ho * wo, n_img * -(-ho // 4) * -(-wo // 4))
             wp, bp = ops.pack_conv(wt)
+            flop = 2.0 * L["Cout"] * cin * L["ksize"] ** 2 * ho * wo * n_img
+            if L["conv_key"].startswith("upconv") and cin <= 256 and n_img * ho * wo >= UPSAMPLED_MIN_PIXELS:
+                # up_conv layer fused with its upsampling (nets.hip EngF32::upconv): the F(4x4,3x3) kernel on the low-resolution
+                # input with the four composed phase filters (same multiplies as on the upsampled image), then the ring pass
+                lib, st = _lib.load(), torch.cuda.current_stream().cuda_stream
+                xl = torch.randn(n_img, cin // 4, h // 2, w // 2, 4, device=dev)
+                uu, bu, wr = ops.pack_winograd4_upsampled(wt)
+                out = torch.empty(n_img, L["Cout"] // 4, h, w, 4, device=dev)
+                args = (xl.data_ptr(), cin // 4, 0, cin // 4, out.data_ptr(), L["Cout"] // 4, 0, L["Cout"])
+                ms = event_ms(lambda: lib.cnm_conv3x3_upsampled_winograd4_c4_f32(*args, uu.data_ptr(), bu.data_ptr(), n_img, h // 2, w // 2, 1, 1, st), iters=3, warm=1)
+                k = per_kernel.setdefault("conv_winograd36_f32_kernel<4, 3, true>", [0.0, 0.0, 0, 0.0])
+                k[0] += flop; k[1] += ms; k[2] += 1; k[3] += flop * 36.0 / 144.0
+                ms = event_ms(lambda: lib.cnm_conv3x3_upsampled_ring_c4_f32(*args, wr.data_ptr(), bu.data_ptr(), n_img, h // 2, w // 2, 1, st), iters=3, warm=1)
+                k = per_kernel.setdefault("conv_upsampled_ring_kernel", [0.0, 0.0, 0, 0.0])
+                k[1] += ms; k[2] += 1; k[3] += 2.0 * L["Cout"] * cin * 3 * (2 * (h + w) - 4) * n_img
+                del x, xl, wt, wp, bp, uu, bu, wr, out
+                continue
             if name.startswith("conv3x3_winograd4") or name.startswith("conv_winograd36"):
                 up = ops.pack_winograd4(wt)
                 fn = lambda: ops.conv3x3_winograd4_c4(x, up, bp, L["Cout"], True, ksize=L["ksize"])
@@ -127,7 +145,6 @@ def kernel_rooflines(dev, frames):
             else:
                 fn = lambda: ops.conv2d_c4(x, wp, bp, L["Cout"], L["ksize"], L["stride"], True)
             ms = event_ms(fn, iters=3, warm=1)
-            flop = 2.0 * L["Cout"] * cin * L["ksize"] ** 2 * ho * wo * n_img
             k = per_kernel.setdefault(name, [0.0, 0.0, 0, 0.0])
             k[0] += flop; k[1] += ms; k[2] += 1; k[3] += flop * executed
             del x, wt, wp, bp
