@@ -113,6 +113,83 @@ __global__ __launch_bounds__(256) void head_sigmoid_c4_kernel(const float* __res
     }
 }
 
+// High-resolution heads: the kernel above reads every input texel nine times through L1 (three rows x three columns
+// per output), which is what bounds it at 192x256.  Here a lane owns one image column of a 62 x HR pixel tile and walks
+// down the rows: each texel is loaded ONCE per tile (float4, coalesced), its left / right neighbours come from the
+// adjacent lanes (wave shift), and a loaded row feeds the three output rows it touches from registers.  Lanes 0 and 63
+// only supply halo columns (62 outputs per 64 lanes).  Waves = 4 channel slices, partial sums meet in LDS.
+// whole-wave shifts by one lane on the VALU (DPP wave_shr / wave_shl, gfx9): lane i receives lane i-1 / i+1
+__device__ __forceinline__ float lane_shr1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xF, 0xF, false)); }
+__device__ __forceinline__ float lane_shl1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xF, 0xF, false)); }
+
+template <int HR>
+__global__ __launch_bounds__(256) void head_sigmoid_c4_rows_kernel(const float* __restrict__ in, int Gin_tot, int gin0, int G,
+                                                                   const float* __restrict__ wh, const float* __restrict__ bias,
+                                                                   float scale, float* __restrict__ disp,
+                                                                   float* __restrict__ up_out, int up_Gtot, int up_g,
+                                                                   int N, int H, int W, int tilesX, int tilesY) {
+    __shared__ float part[4][HR][64];
+    const int HW = H * W;
+    const int lane = threadIdx.x & 63, slice = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int b = blockIdx.x;
+    const int tx = b % tilesX; b /= tilesX;
+    const int ty = b % tilesY, n = b / tilesY;
+    const int x = tx * 62 - 1 + lane, y0 = ty * HR;
+    const bool xin = (unsigned)x < (unsigned)W;
+    const int gper = (G + 3) / 4, gbeg = slice * gper, gend = min(G, gbeg + gper);
+    float acc[HR];
+#pragma unroll
+    for (int r = 0; r < HR; ++r) acc[r] = 0.f;
+    for (int g = gbeg; g < gend; ++g) {
+        const float4* base = reinterpret_cast<const float4*>(in + c4_offset(n, Gin_tot, gin0 + g, HW, 0));
+        float4 row[HR + 2];
+#pragma unroll
+        for (int i = 0; i < HR + 2; ++i) {                               // input rows y0-1 .. y0+HR: all loads first
+            const int iy = y0 + i - 1;
+            row[i] = (xin && (unsigned)iy < (unsigned)H) ? base[iy * W + x] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float4 wk[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wk[k] = *reinterpret_cast<const float4*>(wh + (size_t)k * (G * 4) + g * 4);   // wave-uniform
+#pragma unroll
+        for (int i = 0; i < HR + 2; ++i) {
+            const float4 c = row[i];
+            float4 l, r;                                                 // columns x-1 / x+1 from lanes-1 / +1 (lanes 0 / 63 get garbage: halo lanes, no output)
+            l.x = lane_shr1(c.x); l.y = lane_shr1(c.y); l.z = lane_shr1(c.z); l.w = lane_shr1(c.w);
+            r.x = lane_shl1(c.x); r.y = lane_shl1(c.y); r.z = lane_shl1(c.z); r.w = lane_shl1(c.w);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int o = i - ky;                                    // output row of the tile this input row feeds through kernel row ky
+                if (o < 0 || o >= HR) continue;
+                const float4 w0 = wk[ky * 3 + 0], w1 = wk[ky * 3 + 1], w2 = wk[ky * 3 + 2];
+                float a = acc[o];
+                a = fmaf(l.x, w0.x, a); a = fmaf(l.y, w0.y, a); a = fmaf(l.z, w0.z, a); a = fmaf(l.w, w0.w, a);
+                a = fmaf(c.x, w1.x, a); a = fmaf(c.y, w1.y, a); a = fmaf(c.z, w1.z, a); a = fmaf(c.w, w1.w, a);
+                a = fmaf(r.x, w2.x, a); a = fmaf(r.y, w2.y, a); a = fmaf(r.z, w2.z, a); a = fmaf(r.w, w2.w, a);
+                acc[o] = a;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < HR; ++r) part[slice][r][lane] = acc[r];
+    __syncthreads();
+    // 256 threads finish HR x 64 sums: thread t -> (row t >> 6 + 4 k, lane)
+    for (int r = slice; r < HR; r += 4) {
+        const int y = y0 + r;
+        if (lane == 0 || lane == 63 || !xin || y >= H) continue;
+        const float s = ((part[0][r][lane] + part[1][r][lane]) + (part[2][r][lane] + part[3][r][lane])) + bias[0];
+        const float d = scale / (1.f + expf(-s));
+        disp[(size_t)n * HW + y * W + x] = d;
+        if (up_out) {
+            const int Wo = 2 * W;
+            float* o = up_out + c4_offset(n, up_Gtot, up_g, 4 * HW, (2 * y) * Wo + 2 * x);
+            const float4 v = make_float4(d, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(o) = v; *reinterpret_cast<float4*>(o + 4) = v;
+            *reinterpret_cast<float4*>(o + (size_t)Wo * 4) = v; *reinterpret_cast<float4*>(o + (size_t)Wo * 4 + 4) = v;
+        }
+    }
+}
+
 extern "C" int cnm_head_sigmoid_c4_f32(const float* in, int Gin_total, int gin0, int C,
                                        const float* w_head, const float* bias, float scale,
                                        float* disp, float* up_out, int up_Gtotal, int up_g,
@@ -121,6 +198,14 @@ extern "C" int cnm_head_sigmoid_c4_f32(const float* in, int Gin_total, int gin0,
     CNM_REQUIRE(gin0 >= 0 && gin0 + C / 4 <= Gin_total, CNM_ERR_BAD_ARG);
     CNM_REQUIRE(!up_out || (up_g >= 0 && up_g < up_Gtotal), CNM_ERR_BAD_ARG);
     const long long total = (long long)N * H * W;
+    if (total >= 8ll * 96 * 128 && W >= 62) {                             // enough tiles to fill the chip: the row-walking kernel
+        constexpr int HR = 8;
+        const int tilesX = cnm_ceil_div(W, 62), tilesY = cnm_ceil_div(H, HR);
+        head_sigmoid_c4_rows_kernel<HR><<<(unsigned)(N * tilesX * tilesY), 256, 0, cnm_stream(stream)>>>(
+            in, Gin_total, gin0, C / 4, w_head, bias, scale, disp, up_out, up_Gtotal, up_g, N, H, W, tilesX, tilesY);
+        CNM_LAUNCH_CHECK();
+        return CNM_OK;
+    }
     head_sigmoid_c4_kernel<<<(unsigned)cnm_ceil_div_ll(total, 64), 256, 0, cnm_stream(stream)>>>(
         in, Gin_total, gin0, C / 4, w_head, bias, scale, disp, up_out, up_Gtotal, up_g, N, H, W);
     CNM_LAUNCH_CHECK();

@@ -269,7 +269,7 @@ def test_conv3x3_upsampled_fused(dev, ops, cin, cout, N, H, W):
 
 def test_fused_upsample_networks_agree(dev):
     """Both nets with every eligible up_conv layer fused (threshold lowered to 1 pixel) against the same nets with the
-    fused path off: same frame, outputs within 1e-4 -- and against the golden frame, the 1e-3 bar."""
+    fused path off: same frame, outputs within 1e-4 (the golden frame with the fused layers: test_winograd4_networks_golden)."""
     from cnmnet_amd import _lib
     from cnmnet_amd.depthnet import depthNet, DepthRefineNet
     lib = _lib.load()
@@ -301,6 +301,7 @@ def test_winograd4_networks_golden(dev, golden):
     from cnmnet_amd.depthnet import depthNet, DepthRefineNet
     lib = _lib.load()
     old = lib.cnm_tune_wino4_min_workgroups(1)
+    oldu = lib.cnm_tune_upsampled_min_pixels(1)                          # and every eligible up_conv layer fused with its upsampling
     try:
         g, gr = golden("depthnet_64x96.npz"), golden("refine_64x96.npz")
         img, cams = syn.frames(2, 2, 64, 96, seed=int(g["seed"]))
@@ -317,7 +318,7 @@ def test_winograd4_networks_golden(dev, golden):
         print("F(4x4) golden errors (disp1..4, refined, prob):", ["%.1e" % e for e in errs])
         assert max(errs) < 1e-3, errs
     finally:
-        lib.cnm_tune_wino4_min_workgroups(old)
+        lib.cnm_tune_wino4_min_workgroups(old); lib.cnm_tune_upsampled_min_pixels(oldu)
 
 
 def test_conv3x3_winograd_cat2_and_views(dev, ops):
@@ -358,6 +359,23 @@ def test_upsample_head_layout(dev, ops, golden):
     assert (cat[:, 4, :, :, 1:] == 0).all() and torch.isnan(cat[:, :4]).all()
     y = T(rng.standard_normal((3, 67, 6, 10)).astype(np.float32)).to(dev)   # ragged channel count round trip
     np.testing.assert_array_equal(ops.c4_to_nchw(ops.nchw_to_c4(y), 67).cpu().numpy(), y.cpu().numpy())
+
+
+@pytest.mark.parametrize("N,C,H,W,with_up", [(2, 64, 192, 256, False), (3, 20, 150, 250, True), (8, 128, 96, 128, True), (1, 8, 1600, 62, False)])
+def test_head_rows_kernel(dev, ops, N, C, H, W, with_up):
+    """High-resolution heads take the row-walking kernel (one load per texel, neighbours from adjacent lanes): tiles
+    that end inside the image (W % 62, H % 8 != 0), image borders, the nearest-upsampled copy into a concat slot."""
+    rng = np.random.default_rng(C + H)
+    f = T(rng.standard_normal((N, C, H, W)).astype(np.float32))
+    w = T((rng.standard_normal((1, C, 3, 3)) * (1.0 / (9 * C)) ** 0.5).astype(np.float32)); bias = T(np.array([-0.2], np.float32))
+    want = 2.0 * torch.sigmoid(F.conv2d(f.double(), w.double(), bias.double(), padding=1))
+    cat = torch.full((N, 3, 2 * H, 2 * W, 4), float("nan"), device=dev) if with_up else None
+    got = ops.head_sigmoid_c4(ops.nchw_to_c4(f.to(dev)), ops.pack_head(w.to(dev)), bias.to(dev), 2.0, up_out=cat, up_group=1)
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), atol=3e-6, rtol=1e-5)
+    if with_up:
+        upw = F.interpolate(want, scale_factor=2, mode="nearest")
+        np.testing.assert_allclose(cat[:, 1, :, :, 0].cpu().numpy(), upw[:, 0].numpy(), atol=3e-6, rtol=1e-5)
+        assert (cat[:, 1, :, :, 1:] == 0).all() and torch.isnan(cat[:, 0]).all() and torch.isnan(cat[:, 2]).all()
 
 
 # ------------------------------------------------------------------ whole nets vs the reference's outputs
