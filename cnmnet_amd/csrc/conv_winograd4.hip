@@ -372,15 +372,15 @@ extern "C" int cnm_conv5x5_winograd_c4_f32(const float* in_a, int Ga_total, int 
 // The composed phase filters convolve the upsampled image with replicate padding; the reference zero-pads it.  The two
 // differ only on the one-pixel ring of the output, by the filter taps that land outside the image:
 //     out[co][Y][X] = pre[co][Y][X] - sum_{(ky,kx): (Y+ky-1, X+kx-1) outside} sum_ci w[co][ci][ky][kx] up[ci][clamp(Y+ky-1)][clamp(X+kx-1)]
-// (pre = what the main kernel stored for ring pixels: no bias, no ReLU).  Workgroup = 64 couts x 64 consecutive pixels of
-// one side (top / bottom row, left / right column without the corners); the 66 upsampled border samples a block needs are
+// (pre = what the main kernel stored for ring pixels: no bias, no ReLU).  Workgroup = 64 couts x 32 consecutive pixels of
+// one side (top / bottom row, left / right column without the corners); the 34 upsampled border samples a block needs are
 // interpolated from the low-resolution input into LDS once per 16-channel chunk and feed the three taps of the side as
 // shifted B operands of v_mfma_f32_16x16x4_f32; the two extra taps of a corner pixel are added by the row block that
 // owns it.  w_ring: [tap 9][chunk][cout/16][lane][4] in MFMA A-operand order (cnm_pack_upsampled_ring_f32).
 struct RingArgs {
     const float* in; float* out; const float* wr; const float* bias;
     int N, H, W, Gin_tot, gin0, Gin, Gout_tot, gout0, Cout, nchunks, relu;
-    int nrow, ncol;                      // 64-pixel blocks per row side / per column side
+    int nrow, ncol;                      // 32-pixel blocks per row side / per column side
 };
 
 __device__ __forceinline__ float4 ring_up_sample(const float4* __restrict__ base, int H, int W, int Y, int X) {   // upsample2x_c4_kernel's arithmetic
@@ -401,12 +401,13 @@ __global__ __launch_bounds__(256) void conv_upsampled_ring_kernel(const RingArgs
     // The reduction is short and latency-bound (a few dozen workgroups, 8-32 chunks each): the four waves split the
     // chunks (wave w takes chunks w, w+4, ...), each staging its own chunk in a private LDS region (no workgroup
     // barrier in the loop) for all 64 couts, and the four partial sums meet in LDS at the end.
+    constexpr int PB = 2, NPX = 16 * PB;                                 // 16-pixel MFMA blocks / pixels per workgroup
     constexpr int LD = 20;                                               // row pitch in floats: conflict-free ds_read_b128
-    constexpr int LSZ = 66 * LD + 4 * 16;                                // border samples j' = 0..65 (16 channels) + up to 4 corner samples
-    __shared__ __attribute__((aligned(16))) float smem[4 * 16 * 64 * 4]; // 64 KB: per-wave staging first, then the partial sums
+    constexpr int LSZ = (NPX + 2) * LD + 4 * 16;                         // border samples j' = 0..NPX+1 (16 channels) + up to 4 corner samples
+    __shared__ __attribute__((aligned(16))) float smem[4 * LSZ];         // 12 KB (fits next to two 72 KB convolution workgroups): per-wave staging, then the partial sums
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     float* Ls = smem + wave * LSZ;
-    float* Es = Ls + 66 * LD;
+    float* Es = Ls + (NPX + 2) * LD;
     const int Ho = 2 * a.H, Wo = 2 * a.W, HW = a.H * a.W;
     const int tilesC = a.Cout / 64, segs = 2 * a.nrow + 2 * a.ncol;
     int b = blockIdx.x;
@@ -414,19 +415,19 @@ __global__ __launch_bounds__(256) void conv_upsampled_ring_kernel(const RingArgs
     const int seg = b % segs, img = b / segs;
     // side 0 top, 1 bottom, 2 left, 3 right; p0 = first pixel of the block along the side
     const int side = seg < a.nrow ? 0 : seg < 2 * a.nrow ? 1 : seg < 2 * a.nrow + a.ncol ? 2 : 3;
-    const int p0 = 64 * (side == 0 ? seg : side == 1 ? seg - a.nrow : side == 2 ? seg - 2 * a.nrow : seg - 2 * a.nrow - a.ncol);
+    const int p0 = NPX * (side == 0 ? seg : side == 1 ? seg - a.nrow : side == 2 ? seg - 2 * a.nrow : seg - 2 * a.nrow - a.ncol);
     const bool rowside = side < 2;
     const int len = rowside ? Wo : Ho - 2;                               // pixels along the side
     // corner extras of a row block: e = 2 * (right corner) + k, k-th of the two taps on the column outside the image
     //   top:    taps (1,kx),(2,kx) read up[0][X], up[1][X];   bottom: taps (0,kx),(1,kx) read up[Ho-2][X], up[Ho-1][X]
-    const bool hasL = rowside && p0 == 0, hasR = rowside && (Wo - 1 - p0) < 64 && (Wo - 1 - p0) >= 0;
+    const bool hasL = rowside && p0 == 0, hasR = rowside && (Wo - 1 - p0) < NPX && (Wo - 1 - p0) >= 0;
     const int jR = Wo - 1 - p0;                                          // block-local index of the right corner pixel
 
-    f32x4 acc[4][4];                                                     // [cout group of 16][pixel block of 16]
+    f32x4 acc[4][PB];                                                    // [cout group of 16][pixel block of 16]
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[g][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < PB; ++i) acc[g][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int ncb16 = a.Cout / 16;
     const float4* wbase = reinterpret_cast<const float4*>(a.wr) + lane + (size_t)(cblk * 4) * 64;
     const size_t tapstride = (size_t)a.nchunks * ncb16 * 64, chunkstride = (size_t)ncb16 * 64;
@@ -442,10 +443,11 @@ __global__ __launch_bounds__(256) void conv_upsampled_ring_kernel(const RingArgs
 #pragma unroll
             for (int g = 0; g < 4; ++g) af[s][g] = wbase[(size_t)tap * tapstride + (size_t)c * chunkstride + (size_t)g * 64];
         }
-        float4 tx[5][4]; float lyv[5], lxv[5];
+        constexpr int NIT = ((NPX + 2) * 4 + 63) / 64;
+        float4 tx[NIT][4]; float lyv[NIT], lxv[NIT];
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int it = lane + 64 * i, j = min(it >> 2, 65), q = it & 3, g = c * 4 + q;
+        for (int i = 0; i < NIT; ++i) {
+            const int it = lane + 64 * i, j = min(it >> 2, NPX + 1), q = it & 3, g = c * 4 + q;
             int Y, X;
             if (rowside) { Y = side == 0 ? 0 : Ho - 1; X = min(max(p0 + j - 1, 0), Wo - 1); }
             else { X = side == 2 ? 0 : Wo - 1; Y = min(p0 + j, Ho - 1); }
@@ -457,7 +459,7 @@ __global__ __launch_bounds__(256) void conv_upsampled_ring_kernel(const RingArgs
             tx[i][0] = base[y0 * a.W + x0]; tx[i][1] = base[y0 * a.W + x1]; tx[i][2] = base[y1 * a.W + x0]; tx[i][3] = base[y1 * a.W + x1];
         }
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
+        for (int i = 0; i < NIT; ++i) {
             const int it = lane + 64 * i, j = it >> 2, q = it & 3, g = c * 4 + q;
             const float ly = lyv[i], lx = lxv[i], hy = 1.f - ly, hx = 1.f - lx;
             const float4 p00 = tx[i][0], p01 = tx[i][1], p10 = tx[i][2], p11 = tx[i][3];
@@ -467,7 +469,7 @@ __global__ __launch_bounds__(256) void conv_upsampled_ring_kernel(const RingArgs
             v.z = hy * (hx * p00.z + lx * p01.z) + ly * (hx * p10.z + lx * p11.z);
             v.w = hy * (hx * p00.w + lx * p01.w) + ly * (hx * p10.w + lx * p11.w);
             if (g >= a.Gin) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (it < 66 * 4) *reinterpret_cast<float4*>(Ls + j * LD + q * 4) = v;
+            if (it < (NPX + 2) * 4) *reinterpret_cast<float4*>(Ls + j * LD + q * 4) = v;
         }
         if ((hasL || hasR) && lane < 16) {                               // lane = (extra e = lane >> 2, quad q = lane & 3)
             const int e = lane >> 2, q = lane & 3, g = c * 4 + q;
@@ -482,14 +484,14 @@ __global__ __launch_bounds__(256) void conv_upsampled_ring_kernel(const RingArgs
         __builtin_amdgcn_wave_barrier();                                 // wave-private region: LDS operations of one wave complete in order
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
-            float4 bw[4];
+            float4 bw[PB];
 #pragma unroll
-            for (int blk = 0; blk < 4; ++blk) bw[blk] = *reinterpret_cast<const float4*>(Ls + (blk * 16 + col + s) * LD + kg * 4);
+            for (int blk = 0; blk < PB; ++blk) bw[blk] = *reinterpret_cast<const float4*>(Ls + (blk * 16 + col + s) * LD + kg * 4);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float4 aw = af[s][g];
 #pragma unroll
-                for (int blk = 0; blk < 4; ++blk) {
+                for (int blk = 0; blk < PB; ++blk) {
                     acc[g][blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw.x, bw[blk].x, acc[g][blk], 0, 0, 0);
                     acc[g][blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw.y, bw[blk].y, acc[g][blk], 0, 0, 0);
                     acc[g][blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw.z, bw[blk].z, acc[g][blk], 0, 0, 0);
@@ -510,7 +512,7 @@ __global__ __launch_bounds__(256) void conv_upsampled_ring_kernel(const RingArgs
                 for (int g = 0; g < 4; ++g) {
                     const float4 aw = wbase[(size_t)(ky * 3 + kx) * tapstride + (size_t)c * chunkstride + (size_t)g * 64];
 #pragma unroll
-                    for (int blk = 0; blk < 4; ++blk) {
+                    for (int blk = 0; blk < PB; ++blk) {
                         if (blk != (jc >> 4)) continue;
                         acc[g][blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw.x, bw.x, acc[g][blk], 0, 0, 0);
                         acc[g][blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw.y, bw.y, acc[g][blk], 0, 0, 0);
@@ -523,27 +525,30 @@ __global__ __launch_bounds__(256) void conv_upsampled_ring_kernel(const RingArgs
         __builtin_amdgcn_wave_barrier();                                 // reads done before the next chunk overwrites the region
     }
 
-    // ---- the four partial sums meet: wave w finishes cout group w
-    __syncthreads();
-    f32x4* red = reinterpret_cast<f32x4*>(smem);                         // [src wave][cout group][pixel block][lane]
+    // ---- the four partial sums meet, one cout group per round (8 KB): wave w finishes cout group w
+    f32x4* red = reinterpret_cast<f32x4*>(smem);                         // [src wave][pixel block][lane]
+    f32x4 sum[PB];
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+    for (int g = 0; g < 4; ++g) {
+        __syncthreads();                                                 // staging reads / previous round's sums done
 #pragma unroll
-        for (int blk = 0; blk < 4; ++blk) red[((wave * 4 + g) * 4 + blk) * 64 + lane] = acc[g][blk];
-    __syncthreads();
-    f32x4 sum[4];
+        for (int blk = 0; blk < PB; ++blk) red[(wave * PB + blk) * 64 + lane] = acc[g][blk];
+        __syncthreads();
+        if (wave == g) {
 #pragma unroll
-    for (int blk = 0; blk < 4; ++blk) {
-        sum[blk] = red[((0 * 4 + wave) * 4 + blk) * 64 + lane];
+            for (int blk = 0; blk < PB; ++blk) {
+                sum[blk] = red[blk * 64 + lane];
 #pragma unroll
-        for (int src = 1; src < 4; ++src) sum[blk] += red[((src * 4 + wave) * 4 + blk) * 64 + lane];
+                for (int src = 1; src < 4; ++src) sum[blk] += red[(src * PB + blk) * 64 + lane];
+            }
+        }
     }
 
     // ---- epilogue: row = cout 4*kg + r of group `wave`, col = pixel blk*16 + col: out = act(pre - correction + bias)
     const int co = cblk * 64 + wave * 16 + 4 * kg;
     const float4 bias = a.bias ? *reinterpret_cast<const float4*>(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int blk = 0; blk < 4; ++blk) {
+    for (int blk = 0; blk < PB; ++blk) {
         const int j = p0 + blk * 16 + col;
         if (j >= len) continue;
         const int Y = side == 0 ? 0 : side == 1 ? Ho - 1 : 1 + j, X = side == 2 ? 0 : side == 3 ? Wo - 1 : j;
@@ -600,7 +605,7 @@ extern "C" int cnm_conv3x3_upsampled_ring_c4_f32(const float* in, int Gin_total,
     a.in = in; a.out = out; a.wr = w_ring; a.bias = b_packed;
     a.N = N; a.H = H; a.W = W; a.Gin_tot = Gin_total; a.gin0 = gin0; a.Gin = Gin; a.Gout_tot = Gout_total; a.gout0 = gout0; a.Cout = Cout;
     a.nchunks = (4 * Gin + 15) / 16; a.relu = relu;
-    a.nrow = cnm_ceil_div(2 * W, 64); a.ncol = cnm_ceil_div(2 * H - 2, 64);
+    a.nrow = cnm_ceil_div(2 * W, 32); a.ncol = cnm_ceil_div(2 * H - 2, 32);              // 32-pixel blocks (conv_upsampled_ring_kernel NPX)
     const int nblocks = N * (2 * a.nrow + 2 * a.ncol) * (Cout / 64);
     conv_upsampled_ring_kernel<<<nblocks, 256, 0, cnm_stream(stream)>>>(a);
     CNM_LAUNCH_CHECK();
