@@ -43,6 +43,7 @@ struct WinoArgs {
     int Gin_tot, gin0, Gin2_tot, gin2_0, Gsplit, Gin;
     int Gout_tot, gout0, Cout;
     int nchunks, T, relu;                // T = N*TH*TW tiles
+    int s2;                              // stride 2: keep only output (0,0) of every 2x2 tile -> out is TH x TW
 };
 
 // Weight fragments: [chunk][cout/16][xi][lane][4], lane (i = l&15, kg = l>>4) holds U[xi][co = 16 cb + i][ci = 16 chunk + 4 kg + e].
@@ -214,6 +215,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd_f32_kernel(const Wino
             y[0][r] = s0[0] + s0[1] + s0[2]; y[1][r] = s0[1] - s0[2] - s0[3];
             y[2][r] = s1[0] + s1[1] + s1[2]; y[3][r] = s1[1] - s1[2] - s1[3];
         }
+        if (a.s2) {                                                      // conv(stride 2, pad 1)[y][x] = conv(stride 1)[2y][2x] = element (0,0) of tile (y, x)
+            float4 v = make_float4(y[0][0] + bb[0], y[0][1] + bb[1], y[0][2] + bb[2], y[0][3] + bb[3]);
+            if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<float4*>(a.out + c4_offset(oimg, a.Gout_tot, a.gout0 + (co >> 2), THW, orem)) = v;
+            continue;
+        }
         float* obase = a.out + c4_offset(oimg, a.Gout_tot, a.gout0 + (co >> 2), HW, 0);
 #pragma unroll
         for (int pq = 0; pq < 4; ++pq) {
@@ -267,7 +274,7 @@ extern "C" int cnm_pack_winograd_bn_f32(const float* w_oihw, const float* bn_gam
     return CNM_OK;
 }
 
-extern "C" int cnm_conv3x3_winograd_c4_f32(const float* in_a, int Ga_total, int ga0, int Ga,
+static int conv3x3_winograd_launch(int s2, const float* in_a, int Ga_total, int ga0, int Ga,
                                            const float* in_b, int Gb_total, int gb0, int Gb,
                                            float* out, int Gout_total, int gout0, int Cout,
                                            const float* u_packed, const float* b_packed,
@@ -284,9 +291,27 @@ extern "C" int cnm_conv3x3_winograd_c4_f32(const float* in_a, int Ga_total, int 
     a.N = N; a.H = H; a.W = W; a.TH = (H + 1) / 2; a.TW = (W + 1) / 2;
     a.Gin_tot = Ga_total; a.gin0 = ga0; a.Gin2_tot = Gb ? Gb_total : Ga_total; a.gin2_0 = Gb ? gb0 : ga0; a.Gsplit = Ga; a.Gin = Ga + Gb;
     a.Gout_tot = Gout_total; a.gout0 = gout0; a.Cout = Cout;
-    a.nchunks = (4 * a.Gin + 15) / 16; a.T = N * a.TH * a.TW; a.relu = relu;
+    a.nchunks = (4 * a.Gin + 15) / 16; a.T = N * a.TH * a.TW; a.relu = relu; a.s2 = s2;
     const int nblocks = (Cout / 64) * cnm_ceil_div(a.T, 32);
     conv3x3_winograd_f32_kernel<<<nblocks, 256, 0, cnm_stream(stream)>>>(a);
     CNM_LAUNCH_CHECK();
     return CNM_OK;
+}
+
+extern "C" int cnm_conv3x3_winograd_c4_f32(const float* in_a, int Ga_total, int ga0, int Ga,
+                                           const float* in_b, int Gb_total, int gb0, int Gb,
+                                           float* out, int Gout_total, int gout0, int Cout,
+                                           const float* u_packed, const float* b_packed,
+                                           int N, int H, int W, int relu, void* stream) {
+    return conv3x3_winograd_launch(0, in_a, Ga_total, ga0, Ga, in_b, Gb_total, gb0, Gb, out, Gout_total, gout0, Cout, u_packed, b_packed, N, H, W, relu, stream);
+}
+
+// Stride 2 (pad 1) through the same kernel: out[y][x] = element (0,0) of the F(2x2,3x3) tile (y, x); out is
+// ceil(H/2) x ceil(W/2).  16 multiplies per kept output instead of 9, but 64 couts x 32 output pixels per workgroup and
+// a 16-deep reduction step: for the 12x16 -> 6x8 layers the implicit-GEMM kernel has under a hundred workgroups.
+extern "C" int cnm_conv3x3_s2_winograd_c4_f32(const float* in, int Gin_total, int gin0, int Gin,
+                                              float* out, int Gout_total, int gout0, int Cout,
+                                              const float* u_packed, const float* b_packed,
+                                              int N, int H, int W, int relu, void* stream) {
+    return conv3x3_winograd_launch(1, in, Gin_total, gin0, Gin, nullptr, 0, 0, 0, out, Gout_total, gout0, Cout, u_packed, b_packed, N, H, W, relu, stream);
 }

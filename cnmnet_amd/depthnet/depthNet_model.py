@@ -112,7 +112,7 @@ class _EngineNet(nn.Module):
                 wp, bp = pack(w, bnp, rot=L["rot"], eps=bn.eps)
                 # fp32 layers in the Winograd domain: 3x3 stride 1 (F(2x2,3x3)); 5x5 / 7x7 stride 1 and 2 (row-wise)
                 wino = (self.precision == "f32" and self.winograd and L["Cout"] % 64 == 0 and
-                        ((L["ksize"] == 3 and L["stride"] == 1) or L["ksize"] in (5, 7)))
+                        (L["ksize"] == 3 or L["ksize"] in (5, 7)))            # 3x3 stride 2: F(2x2) filter for the low-resolution layers (nets.hip)
                 if not wino:
                     packed.append((wp, bp))
                 else:

@@ -212,7 +212,7 @@ def pack_winograd(weight, bn=None, rot=0, eps=1e-5, stride=1, tile=None):
     _dev(weight, *(bn or ()))
     lib = _lib.load()
     Cout, Cin, k, _ = weight.shape
-    assert k in (3, 5, 7) and (stride == 1 or (stride == 2 and k != 3))
+    assert k in (3, 5, 7) and stride in (1, 2)                          # k = 3: one filter serves stride 1 and the stride-2 mode
     tile = rows_tile(k, stride) if tile is None else tile
     n = lib.cnm_packed_winograd_floats(Cout, Cin) if k == 3 else lib.cnm_packed_winograd_rows_floats(Cout, Cin, k, stride, tile)
     up = torch.empty(n, device=weight.device, dtype=torch.float32)
@@ -237,6 +237,17 @@ def pack_winograd4(weight, bn=None, rot=0, eps=1e-5):
     with torch.cuda.device(weight.device):
         _lib.check(fn(_p(_c(weight)), _p(g), _p(v), eps, Cout, Cin, rot, _p(up), _stream()))
     return up
+
+
+def conv3x3_s2_winograd_c4(x, u_packed, b_packed, Cout, relu=True):
+    """3x3 stride-2 pad-1 conv through the F(2x2,3x3) kernel (element (0,0) of every tile): -> [N,Cout/4,ceil(H/2),ceil(W/2),4]."""
+    _dev(x, u_packed, b_packed)
+    N, G, H, W, _ = x.shape
+    out = torch.empty(N, Cout // 4, (H + 1) // 2, (W + 1) // 2, 4, device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().cnm_conv3x3_s2_winograd_c4_f32(_p(x), G, 0, G, _p(out), Cout // 4, 0, Cout, _p(u_packed), _p(b_packed),
+                                                              N, H, W, int(relu), _stream()))
+    return out
 
 
 def conv3x3_winograd4_c4(x, u_packed, b_packed, Cout, relu=True, x2=None, ksize=3):

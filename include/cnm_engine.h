@@ -137,6 +137,13 @@ int cnm_conv3x3_winograd_c4_f32(const float* in_a, int Ga_total, int ga0, int Ga
                                 float* out, int Gout_total, int gout0, int Cout,
                                 const float* u_packed, const float* b_packed,
                                 int N, int H, int W, int relu, void* stream);
+/* 3x3 stride-2 (pad 1) twin on the same kernel and the same packed filter: keeps element (0,0) of every 2x2 tile
+ * (out [N][Gout_total][ceil(H/2)][ceil(W/2)][4]).  The executors use it where the implicit-GEMM kernel would launch
+ * fewer than 256 workgroups (depthNet conv5.3 at 192x256). */
+int cnm_conv3x3_s2_winograd_c4_f32(const float* in, int Gin_total, int gin0, int Gin,
+                                   float* out, int Gout_total, int gout0, int Cout,
+                                   const float* u_packed, const float* b_packed,
+                                   int N, int H, int W, int relu, void* stream);
 
 /* Winograd F(4x4,3x3) variant of cnm_conv3x3_winograd_c4_f32: 36 instead of 64 multiplies per 16 outputs (1.78x fewer
  * than F(2x2,3x3)); fp32 data and accumulation, transform constants up to 8: per-layer error 1-3e-5 on O(1) outputs.

@@ -229,6 +229,23 @@ def test_conv5x5_winograd(dev, ops, cin, cout, rot, N, H, W):
     assert np.abs(got - want).max() < 2e-4 * max(np.abs(want).max(), 1.0), np.abs(got - want).max()
 
 
+@pytest.mark.parametrize("cin,cout,N,H,W", [(512, 512, 2, 12, 16), (64, 64, 3, 7, 9), (20, 128, 1, 1, 1), (36, 64, 2, 10, 33)])
+def test_conv3x3_stride2_winograd(dev, ops, cin, cout, N, H, W):
+    """3x3 stride-2 pad-1 conv + BN + ReLU through the F(2x2,3x3) kernel (one kept output per tile): odd sizes too."""
+    rng = np.random.default_rng(cin * 29 + H)
+    x = T(rng.standard_normal((N, cin, H, W)).astype(np.float32))
+    w = T((rng.standard_normal((cout, cin, 3, 3)) * (2.0 / (cin * 9)) ** 0.5).astype(np.float32))
+    bnp = [T(a.astype(np.float32)) for a in (rng.uniform(0.5, 1.5, cout), rng.normal(0, 0.2, cout), rng.normal(0, 0.2, cout), rng.uniform(0.5, 1.5, cout))]
+    sc = bnp[0].double() / torch.sqrt(bnp[3].double() + 1e-5)
+    want = F.relu(F.conv2d(x.double(), w.double(), stride=2, padding=1) * sc[None, :, None, None] + (bnp[1].double() - bnp[2].double() * sc)[None, :, None, None]).numpy()
+    bnd = tuple(t.to(dev) for t in bnp)
+    _, bp = ops.pack_conv(w.to(dev), bnd)
+    up = ops.pack_winograd(w.to(dev), bnd, stride=2)
+    got = ops.c4_to_nchw(ops.conv3x3_s2_winograd_c4(ops.nchw_to_c4(x.to(dev)), up, bp, cout, True), cout).cpu().numpy()
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() < 2e-5 * max(np.abs(want).max(), 1.0) + 1e-5, np.abs(got - want).max()
+
+
 @pytest.mark.parametrize("cin,cout,N,H,W", [(128, 64, 2, 24, 32), (20, 128, 1, 3, 40), (64, 64, 2, 9, 21), (256, 128, 1, 12, 16), (8, 64, 3, 2, 2), (36, 64, 1, 33, 70)])
 def test_conv3x3_upsampled_fused(dev, ops, cin, cout, N, H, W):
     """up_conv_layer (reference depthNet_model.py:89-112: bilinear x2, conv3x3, BN, ReLU) as ONE pass over the
