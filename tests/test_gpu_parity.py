@@ -310,6 +310,52 @@ def test_fused_upsample_networks_agree(dev):
     assert any(np.abs(a - b).max() > 0 for a, b in zip(*outs))           # the fused path really ran
 
 
+def test_bench_configuration_vs_oracle(dev):
+    """The benchmark's own workload and dispatch -- 8 frames x (1 ref + 2 src), 192x256, 64 planes, default thresholds
+    (row-wise F(4,7), F(2x2,5x5), F(4x4,3x3), fused up_conv layers, side-stream decoders, row-walking heads) -- against
+    the CPU oracle on two of the eight frames: inverse depth, probability and normals inside the 1e-3 bar."""
+    from cnmnet_amd.depthnet import depthNet, DepthRefineNet
+    from cnmnet_amd.pipeline import FramePipeline
+    B, S, H, W = 8, 2, 192, 256
+    img, cams = syn.frames(B, S, H, W, seed=1234)
+
+    def load(module, seed, head_scale):
+        # at this size the seeded weights drive the heads' sigmoids into saturation (refined inverse depth exactly 0 on
+        # 90 % of the pixels: a comparison would see nothing); scaled heads put the outputs mid-range on every pixel
+        # (oracle: inverse depth 0.74 .. 1.66, probability 0.28 .. 0.56, a valid normal everywhere)
+        shapes = {k: tuple(v.shape) for k, v in module.state_dict().items()}
+        w = syn.state_dict_like(shapes, seed=seed, randomize_bn=True)
+        w = {k: (v * head_scale if (v.ndim == 4 and v.shape[0] == 1) else v) for k, v in w.items()}
+        module.load_state_dict(torch_state(w))
+        return module.eval()
+
+    pipe = FramePipeline(load(depthNet(3.0), 41, 0.2).to(dev), load(DepthRefineNet(32, 3.0), 42, 0.05).to(dev), k_size=9)
+    with torch.no_grad():
+        out = pipe(T(img).to(dev), T(cams).to(dev))
+    cpu_d, cpu_r = load(ra.DepthNetCPU(3.0), 41, 0.2), load(ra.DepthRefineNetCPU(32, 3.0), 42, 0.05)
+    for b in (0, 5):
+        with torch.no_grad():
+            want = ra.frame_forward(cpu_d, cpu_r, T(img[b:b + 1, 0]), T(img[b:b + 1, 1]), T(img[b:b + 1, 2]),
+                                    T(cams[b:b + 1, 0]), T(cams[b:b + 1, 1]), T(cams[b:b + 1, 2]))
+        errs = {k: float((out[k][b:b + 1].cpu() - want[k]).abs().max()) for k in ("disp", "prob", "disp_a", "disp_b")}
+        nerr = (out["normal"][b:b + 1].cpu() - want["normal"]).abs().amax(1).flatten()
+        print("frame %d: max|err| %s, normal q99 %.2e" % (b, {k: "%.1e" % v for k, v in errs.items()}, float(nerr.quantile(0.99))))
+        assert float(want["disp"].min()) > 0.5 and float(want["disp"].max()) < 2.0 and float((want["normal"].abs().amax(1) > 0).float().mean()) == 1.0
+        assert max(errs.values()) < 1e-3, (b, errs)
+        assert float(nerr.quantile(0.99)) < 1e-3, float(nerr.quantile(0.99))
+        # The tail of that normal error is the REFERENCE's rounding, not the engine's: the same least-squares fit on the
+        # oracle's depth in float64 is met by the fp32 reference arrangement only to q99 9e-4 / max 3.5e-3 (81-point normal
+        # equations inverted in fp32), while the engine (fp64 window sums) stays within 1e-3 of it on EVERY pixel even
+        # though its depth input carries the conv stack's own 2e-5.
+        if b != 0:
+            continue                                                   # the float64 fit takes ~40 s of host time: one frame
+        n64, _ = ra.depth_to_normal(1.0 / want["disp"].double().squeeze(1), T(cams[b:b + 1, 0])[:, 1, :3, :3].double().inverse(), 9)
+        e_gpu = float((out["normal"][b:b + 1].cpu().double() - n64).abs().max())
+        e_ref = float((want["normal"].double() - n64).abs().max())
+        print("          normals vs the float64 fit: engine max %.1e, fp32 reference arrangement max %.1e" % (e_gpu, e_ref))
+        assert e_gpu < 1e-3, e_gpu
+
+
 def test_winograd4_networks_golden(dev, golden):
     """Both nets with EVERY 3x3 stride-1 layer forced through F(4x4,3x3) (the executors normally pick it only for layers
     with >= CNM_WINO4_MIN_WORKGROUPS workgroups, i.e. never at this 64x96 size) against the reference's golden outputs:
