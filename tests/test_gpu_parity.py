@@ -635,6 +635,18 @@ def test_winograd_api_argument_errors(dev):
             _lib.check(call())
     old = lib.cnm_tune_wino4_min_workgroups(0)                           # query only
     assert old == lib.cnm_tune_wino4_min_workgroups(123) and lib.cnm_tune_wino4_min_workgroups(old) == 123
+    # fused upsample + conv, its ring pass, the stride-2 mode
+    assert lib.cnm_packed_upsampled_ring_floats(96, 8) == 0 and lib.cnm_packed_upsampled_ring_floats(64, 20) == 9 * 2 * 64 * 16
+    big = torch.zeros(1, 16, 16, 16, 4, device=dev)
+    for call in (lambda: lib.cnm_conv3x3_upsampled_winograd4_c4_f32(x.data_ptr(), 16, 0, 16, big.data_ptr(), 16, 0, 48, u.data_ptr(), None, 1, 8, 8, 0, 0, s),    # Cout % 64
+                 lambda: lib.cnm_conv3x3_upsampled_winograd4_c4_f32(x.data_ptr(), 16, 0, 16, big.data_ptr(), 8, 0, 64, u.data_ptr(), None, 1, 8, 8, 0, 0, s),     # slice outside the buffer
+                 lambda: lib.cnm_conv3x3_upsampled_ring_c4_f32(x.data_ptr(), 16, 0, 16, big.data_ptr(), 16, 0, 64, None, None, 1, 8, 8, 0, s),                     # no ring filter
+                 lambda: lib.cnm_conv3x3_upsampled_ring_c4_f32(x.data_ptr(), 16, 8, 16, big.data_ptr(), 16, 0, 64, u.data_ptr(), None, 1, 8, 8, 0, s),             # input view outside
+                 lambda: lib.cnm_conv3x3_s2_winograd_c4_f32(x.data_ptr(), 16, 0, 16, y.data_ptr(), 16, 0, 100, u.data_ptr(), None, 1, 8, 8, 0, s),
+                 lambda: lib.cnm_pack_upsampled_ring_f32(u.data_ptr(), u.data_ptr(), None, 1e-5, 64, 64, u.data_ptr(), s)):                                        # gamma without var
+        with pytest.raises(bad):
+            _lib.check(call())
+    assert lib.cnm_tune_upsampled_min_pixels(0) == lib.cnm_tune_upsampled_min_pixels(-5) > 0                    # queries leave the value alone
 
 
 # ------------------------------------------------------------------ K6 / K7
