@@ -249,12 +249,17 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
         a.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (the engine has no CPU path)"
-    dev = torch.device("cuda", local)
+    # functional test of the N > 1 path on a one-GPU box: CNM_BENCH_BACKEND=gloo CNM_BENCH_DEVICE=0 puts every rank on GPU 0
+    backend = os.environ.get("CNM_BENCH_BACKEND", "nccl")
+    dev = torch.device("cuda", int(os.environ.get("CNM_BENCH_DEVICE", local)))
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from cnmnet_amd import synthetic as syn
     from cnmnet_amd.depthnet import depthNet, DepthRefineNet
@@ -289,7 +294,7 @@ def main():
     elapsed = time.perf_counter() - t0
     assert bool(torch.isfinite(out["disp"]).all()) and bool(torch.isfinite(out["normal"]).all())
     from cnmnet_amd import sharding
-    elapsed = sharding.job_elapsed(elapsed, dist, dev)            # max over ranks
+    elapsed = sharding.job_elapsed(elapsed, dist, dev if backend == "nccl" else "cpu")            # max over ranks
 
     line = None
     if rank == 0:
