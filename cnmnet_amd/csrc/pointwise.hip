@@ -66,12 +66,13 @@ extern "C" int cnm_pack_head_f32(const float* w_oihw, int C, float* w_head, void
 // consecutive x, so every float4 tap load is coalesced across the wave; the 9*C weights of a slice are
 // wave-uniform (scalar loads); the four partial sums meet in LDS in a fixed order.  (One lane per pixel over all
 // channels left the low-resolution heads with a few dozen workgroups and a 4608-tap serial loop.)
-__global__ __launch_bounds__(256) void head_sigmoid_c4_kernel(const float* __restrict__ in, int Gin_tot, int gin0, int G,
+template <int NS>                                                        // channel slices = waves per workgroup (4, or 16 for the 256- / 512-channel heads)
+__global__ __launch_bounds__(64 * NS) void head_sigmoid_c4_kernel(const float* __restrict__ in, int Gin_tot, int gin0, int G,
                                                               const float* __restrict__ wh, const float* __restrict__ bias,
                                                               float scale, float* __restrict__ disp,
                                                               float* __restrict__ up_out, int up_Gtot, int up_g,
                                                               int N, int H, int W) {
-    __shared__ float part[4][64];
+    __shared__ float part[NS][64];
     const int HW = H * W;
     const long long total = (long long)N * HW;
     const int lane = threadIdx.x & 63, slice = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256) void head_sigmoid_c4_kernel(const float* __res
     const long long ii = live ? idx : 0;
     const int n = (int)(ii / HW), pix = (int)(ii - (long long)n * HW);
     const int y = pix / W, x = pix - y * W;
-    const int gper = (G + 3) / 4, gbeg = slice * gper, gend = min(G, gbeg + gper);
+    const int gper = (G + NS - 1) / NS, gbeg = slice * gper, gend = min(G, gbeg + gper);
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
     for (int g = gbeg; g < gend; ++g) {
         const float4* base = reinterpret_cast<const float4*>(in + c4_offset(n, Gin_tot, gin0 + g, HW, 0));
@@ -101,7 +102,10 @@ __global__ __launch_bounds__(256) void head_sigmoid_c4_kernel(const float* __res
     part[slice][lane] = (acc0 + acc1) + (acc2 + acc3);
     __syncthreads();
     if (slice != 0 || !live) return;
-    const float s = ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) + bias[0];
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < NS; q += 4) s += (part[q][lane] + part[q + 1][lane]) + (part[q + 2][lane] + part[q + 3][lane]);   // fixed order
+    s += bias[0];
     const float d = scale / (1.f + expf(-s));
     disp[idx] = d;
     if (up_out) {
@@ -206,7 +210,10 @@ extern "C" int cnm_head_sigmoid_c4_f32(const float* in, int Gin_total, int gin0,
         CNM_LAUNCH_CHECK();
         return CNM_OK;
     }
-    head_sigmoid_c4_kernel<<<(unsigned)cnm_ceil_div_ll(total, 64), 256, 0, cnm_stream(stream)>>>(
+    if (C >= 256)                                                        // deep low-resolution heads: 16 waves share the 9*C-tap reduction of 64 pixels
+        head_sigmoid_c4_kernel<16><<<(unsigned)cnm_ceil_div_ll(total, 64), 1024, 0, cnm_stream(stream)>>>(
+            in, Gin_total, gin0, C / 4, w_head, bias, scale, disp, up_out, up_Gtotal, up_g, N, H, W);
+    else head_sigmoid_c4_kernel<4><<<(unsigned)cnm_ceil_div_ll(total, 64), 256, 0, cnm_stream(stream)>>>(
         in, Gin_total, gin0, C / 4, w_head, bias, scale, disp, up_out, up_Gtotal, up_g, N, H, W);
     CNM_LAUNCH_CHECK();
     return CNM_OK;
