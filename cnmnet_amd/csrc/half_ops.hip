@@ -49,18 +49,26 @@ extern "C" int cnm_upsample2x_c8_f16(const void* in, int Gin_total, int gin0, vo
 }
 
 // ------------------------------------------------------------------ disparity head (fp32 weights, fp32 output)
-__global__ __launch_bounds__(256) void head_sigmoid_c8h_kernel(const float* __restrict__ in, int Gin_tot, int gin0, int G,
-                                                               const float* __restrict__ wh, const float* __restrict__ bias,
-                                                               float scale, float* __restrict__ disp,
-                                                               float* __restrict__ up_out, int up_Gtot, int up_g,
-                                                               int N, int H, int W) {
+// Workgroup = 64 consecutive pixels x NS channel slices (one wave per slice), partial sums meet in LDS in a fixed order
+// (same scheme as head_sigmoid_c4_kernel; one lane per pixel over all channels was a 4608-tap serial loop on the 512-channel head).
+template <int NS>
+__global__ __launch_bounds__(64 * NS) void head_sigmoid_c8h_kernel(const float* __restrict__ in, int Gin_tot, int gin0, int G,
+                                                                   const float* __restrict__ wh, const float* __restrict__ bias,
+                                                                   float scale, float* __restrict__ disp,
+                                                                   float* __restrict__ up_out, int up_Gtot, int up_g,
+                                                                   int N, int H, int W) {
+    __shared__ float part[NS][64];
     const int HW = H * W;
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)N * HW) return;
-    const int n = (int)(idx / HW), pix = (int)(idx - (long long)n * HW);
+    const long long total = (long long)N * HW;
+    const int lane = threadIdx.x & 63, slice = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long idx = (long long)blockIdx.x * 64 + lane;
+    const bool live = idx < total;
+    const long long ii = live ? idx : 0;
+    const int n = (int)(ii / HW), pix = (int)(ii - (long long)n * HW);
     const int y = pix / W, x = pix - y * W;
+    const int gper = (G + NS - 1) / NS, gbeg = slice * gper, gend = min(G, gbeg + gper);
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int g = 0; g < G; ++g) {
+    for (int g = gbeg; g < gend; ++g) {
         const size_t b = c4_offset(n, Gin_tot, gin0 + g, HW, 0);
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
@@ -68,7 +76,7 @@ __global__ __launch_bounds__(256) void head_sigmoid_c8h_kernel(const float* __re
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const int ix = x + kx - 1;
-                if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) continue;
+                if (!live || (unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) continue;
                 const f16x8 v = ld8(in, b + (size_t)(iy * W + ix) * 4);
                 const float* w = wh + (size_t)(ky * 3 + kx) * (G * 8) + g * 8;
 #pragma unroll
@@ -76,7 +84,13 @@ __global__ __launch_bounds__(256) void head_sigmoid_c8h_kernel(const float* __re
             }
         }
     }
-    const float s = (acc[0] + acc[1]) + (acc[2] + acc[3]) + bias[0];
+    part[slice][lane] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    __syncthreads();
+    if (slice != 0 || !live) return;
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < NS; q += 4) s += (part[q][lane] + part[q + 1][lane]) + (part[q + 2][lane] + part[q + 3][lane]);
+    s += bias[0];
     const float d = scale / (1.f + expf(-s));
     disp[idx] = d;
     if (up_out) {
@@ -94,7 +108,9 @@ extern "C" int cnm_head_sigmoid_c8_f16(const void* in, int Gin_total, int gin0, 
     CNM_REQUIRE(in && w_head && bias && disp && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, CNM_ERR_BAD_ARG);
     CNM_REQUIRE(gin0 >= 0 && gin0 + C / 8 <= Gin_total && (!up_out || (up_g >= 0 && up_g < up_Gtotal)), CNM_ERR_BAD_ARG);
     const long long total = (long long)N * H * W;
-    head_sigmoid_c8h_kernel<<<(unsigned)cnm_ceil_div_ll(total, 256), 256, 0, cnm_stream(stream)>>>(
+    if (C >= 256) head_sigmoid_c8h_kernel<16><<<(unsigned)cnm_ceil_div_ll(total, 64), 1024, 0, cnm_stream(stream)>>>(
+        static_cast<const float*>(in), Gin_total, gin0, C / 8, w_head, bias, scale, disp, static_cast<float*>(up_out), up_Gtotal, up_g, N, H, W);
+    else head_sigmoid_c8h_kernel<4><<<(unsigned)cnm_ceil_div_ll(total, 64), 256, 0, cnm_stream(stream)>>>(
         static_cast<const float*>(in), Gin_total, gin0, C / 8, w_head, bias, scale, disp, static_cast<float*>(up_out), up_Gtotal, up_g, N, H, W);
     CNM_LAUNCH_CHECK();
     return CNM_OK;
