@@ -96,6 +96,8 @@ def conv_kernel(L, m, m4=0):
         if s == 2:                                                   # two column phases x F(4,ceil(k/2)): (ceil(k/2)+3)/2 multiplies per output and kernel row
             return "conv_rows_winograd_f32_kernel<%d, 2, 4>" % k, ((k + 1) // 2 + 3) / 2.0 / k
         return "conv_rows_winograd_f32_kernel<%d, %d, 2>" % (k, s), (k + 1) / (2.0 * k)
+    if k == 3 and s == 2 and (L["Cout"] // 64) * -(-m // 64) >= 256 and (L["Cout"] // 64) * -(-(m // 4) // 48) >= 384:
+        return "conv_rows_winograd_f32_kernel<3, 2, 4>", 10.0 / 12.0       # two F(4,2) column phases: 10 multiplies per 4 outputs and kernel row instead of 12
     if k == 3 and s == 2 and (L["Cout"] // 64) * -(-m // 64) < 256:     # too few implicit-GEMM tiles: F(2x2,3x3) kernel keeping one output per tile
         return "conv3x3_winograd_f32_kernel", 16.0 / 9.0
     return conv_tile(L["Cout"], m), 1.0
@@ -142,7 +144,7 @@ def kernel_rooflines(dev, frames):
                 up = ops.pack_winograd(wt)
                 fn = (lambda: ops.conv3x3_s2_winograd_c4(x, up, bp, L["Cout"], True)) if L["stride"] == 2 else (lambda: ops.conv3x3_winograd_c4(x, up, bp, L["Cout"], True))
             elif name.startswith("conv_rows_winograd"):
-                up = ops.pack_winograd(wt, stride=L["stride"])
+                up = ops.pack_winograd_rows(wt, stride=2, tile=4) if L["ksize"] == 3 else ops.pack_winograd(wt, stride=L["stride"])
                 fn = lambda: ops.conv_rows_winograd_c4(x, up, bp, L["Cout"], L["ksize"], True, stride=L["stride"])
             else:
                 fn = lambda: ops.conv2d_c4(x, wp, bp, L["Cout"], L["ksize"], L["stride"], True)

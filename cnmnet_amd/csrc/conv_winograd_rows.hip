@@ -97,6 +97,12 @@ template <> struct RowWino<44> {
     static constexpr double G[7][4] = {{-2, 0, 0, 0}, {-2. / 3, -2. / 3, -2. / 3, -2. / 3}, {-2. / 9, 2. / 9, -2. / 9, 2. / 9}, {16. / 9, 8. / 9, 4. / 9, 2. / 9},
                                        {16. / 15, -8. / 15, 4. / 15, -2. / 15}, {2. / 45, 4. / 45, 8. / 45, 16. / 45}, {0, 0, 0, 1}};
 };
+// F(4,2), interpolation points 0, 1, -1, 2, inf (column phases of the 3-tap stride-2 rows, 4 outputs per tile; B^T of F(2,4)):
+// 5 multiplies per 4 outputs, phase and kernel row instead of 6 -- the 3x3 stride-2 layers leave the implicit-GEMM kernel
+template <> struct RowWino<24> {
+    static constexpr float AT[4][5] = {{1, 1, 1, 1, 0}, {0, 1, -1, 2, 0}, {0, 1, 1, 4, 0}, {0, 1, -1, 8, 1}};
+    static constexpr double G[5][2] = {{1. / 2, 0}, {-1. / 2, -1. / 2}, {-1. / 6, 1. / 6}, {1. / 6, 1. / 3}, {0, 1}};
+};
 // F(4,3), interpolation points 0, +-1, +-2, inf (column phases of the 5-tap stride-2 rows, 4 outputs per tile; B^T of F(2,5))
 template <> struct RowWino<34> {
     static constexpr float AT[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
@@ -111,7 +117,7 @@ template <int R, int S, int M> struct RowCfg {                            // M o
     static constexpr int RT = S == 1 ? R : (R + 1) / 2;                 // taps seen by the transform
     static constexpr int NX = RT + M - 1;                                // frequency points
     static constexpr int ID = M == 2 ? RT : 10 * RT + M;                // table key
-    static constexpr int NB = NX * 16 <= 128 ? 4 : 3;                    // 16-tile blocks per wave (accumulators: NX * NB * 4 <= 128)
+    static constexpr int NB = (NX * 16 <= 128 && ID != 24) ? 4 : 3;      // 16-tile blocks per wave (accumulators: NX * NB * 4 <= 128); F(4,2): 3, so that 8 images of 96x128 / 16 of 24x32 outputs make 512 workgroups
     static constexpr int START = -(RT / 2);                              // first window sample relative to the tile's first output (phase samples)
     static constexpr int NKP = R * S;                                    // (kernel row, column phase) pairs in the reduction
 };
@@ -231,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void conv_rows_winograd_f32_kernel(const Ro
                 else { e = f4_sub(x[4], x[2]); o = f4_mul(2.f, f4_sub(x[3], x[1])); }
                 va = f4_add(e, o); vb = f4_sub(e, o); ka = 2 * grp - 1; kb = 2 * grp;
             }
-        } else if constexpr (CF::RT == 4) {                              // BT = [2 -1 -2 1 0; 0 -2 -1 1 0; 0 2 -3 1 0; 0 -1 0 1 0; 0 2 -1 -2 1]
+        } else if constexpr (CF::RT == 4 || CF::ID == 24) {              // five points 0, 1, -1, 2, inf (F(2,4) and F(4,2)): BT = [2 -1 -2 1 0; 0 -2 -1 1 0; 0 2 -3 1 0; 0 -1 0 1 0; 0 2 -1 -2 1]
             const f4p v3 = f4_sub(x[3], x[1]);
             if (grp == 0) { va = f4_fma(2.f, f4_sub(x[0], x[2]), v3); vb = f4_fma(-2.f, v3, f4_sub(x[4], x[2])); ka = 0; kb = 4; }
             else if (grp == 1) { const f4p q = f4_sub(x[3], x[2]); va = f4_fma(-2.f, x[1], q); vb = f4_fma(2.f, f4_sub(x[1], x[2]), q); ka = 1; kb = 2; }
@@ -380,24 +386,26 @@ __global__ void pack_rows_winograd_kernel(const float* __restrict__ w, const flo
 }
 
 static int rows_chunks(int Cin, int ksize, int stride) { return (ksize * stride * ((Cin + 3) / 4) + 3) / 4; }
+static bool rows_ksize_ok(int ksize, int stride, int tile) { return ksize == 5 || ksize == 7 || (ksize == 3 && stride == 2 && tile == 4); }   // 3x3: stride 2 only (stride 1 has the 2-D kernels)
 static bool rows_tile_ok(int ksize, int stride, int tile) { return tile == 2 || (tile == 4 && !(ksize == 5 && stride == 1)); }   // 4 outputs per tile: F(4,7), and the stride-2 phases F(4,4) / F(4,3)
 static int rows_points(int ksize, int stride, int tile) { return (stride == 1 ? ksize : (ksize + 1) / 2) + tile - 1; }
 
 extern "C" size_t cnm_packed_winograd_rows_floats(int Cout, int Cin, int ksize, int stride, int tile) {
-    if (Cout <= 0 || Cin <= 0 || Cout % 64 || (ksize != 5 && ksize != 7) || (stride != 1 && stride != 2) || !rows_tile_ok(ksize, stride, tile)) return 0;
+    if (Cout <= 0 || Cin <= 0 || Cout % 64 || !rows_ksize_ok(ksize, stride, tile) || (stride != 1 && stride != 2) || !rows_tile_ok(ksize, stride, tile)) return 0;
     return (size_t)rows_chunks(Cin, ksize, stride) * rows_points(ksize, stride, tile) * Cout * 16;
 }
 
 extern "C" int cnm_pack_winograd_rows_bn_f32(const float* w_oihw, const float* bn_gamma, const float* bn_var, float eps,
                                              int Cout, int Cin, int ksize, int stride, int tile, int rot, float* u_packed, void* stream) {
     CNM_REQUIRE(w_oihw && u_packed && Cout > 0 && Cout % 64 == 0 && Cin > 0 && rot >= 0 && rot < Cin, CNM_ERR_BAD_ARG);
-    CNM_REQUIRE((ksize == 5 || ksize == 7) && (stride == 1 || stride == 2) && rows_tile_ok(ksize, stride, tile) && !bn_gamma == !bn_var, CNM_ERR_BAD_ARG);
+    CNM_REQUIRE(rows_ksize_ok(ksize, stride, tile) && (stride == 1 || stride == 2) && rows_tile_ok(ksize, stride, tile) && !bn_gamma == !bn_var, CNM_ERR_BAD_ARG);
     const int nchunks = rows_chunks(Cin, ksize, stride);
     const long long total = (long long)nchunks * rows_points(ksize, stride, tile) * Cout * 16;
     const unsigned nb = (unsigned)cnm_ceil_div_ll(total, 256);
     hipStream_t st = cnm_stream(stream);
 #define CNM_PACK_ROWS(R, S, M) pack_rows_winograd_kernel<R, S, M><<<nb, 256, 0, st>>>(w_oihw, bn_gamma, bn_var, eps, Cout, Cin, rot, nchunks, u_packed)
-    if (ksize == 5 && stride == 1) CNM_PACK_ROWS(5, 1, 2); else if (ksize == 5 && tile == 4) CNM_PACK_ROWS(5, 2, 4); else if (ksize == 5) CNM_PACK_ROWS(5, 2, 2);
+    if (ksize == 3) CNM_PACK_ROWS(3, 2, 4);
+    else if (ksize == 5 && stride == 1) CNM_PACK_ROWS(5, 1, 2); else if (ksize == 5 && tile == 4) CNM_PACK_ROWS(5, 2, 4); else if (ksize == 5) CNM_PACK_ROWS(5, 2, 2);
     else if (stride == 1 && tile == 4) CNM_PACK_ROWS(7, 1, 4); else if (stride == 1) CNM_PACK_ROWS(7, 1, 2); else if (tile == 4) CNM_PACK_ROWS(7, 2, 4); else CNM_PACK_ROWS(7, 2, 2);
 #undef CNM_PACK_ROWS
     CNM_LAUNCH_CHECK();
@@ -409,7 +417,7 @@ extern "C" int cnm_conv_rows_winograd_c4_f32(const float* in_a, int Ga_total, in
                                              float* out, int Gout_total, int gout0, int Cout,
                                              const float* u_packed, const float* b_packed,
                                              int N, int H, int W, int ksize, int stride, int tile, int relu, void* stream) {
-    CNM_REQUIRE(in_a && out && u_packed && N > 0 && H > 0 && W > 0 && Ga > 0 && Gb >= 0 && (ksize == 5 || ksize == 7), CNM_ERR_BAD_ARG);
+    CNM_REQUIRE(in_a && out && u_packed && N > 0 && H > 0 && W > 0 && Ga > 0 && Gb >= 0 && rows_ksize_ok(ksize, stride, tile), CNM_ERR_BAD_ARG);
     CNM_REQUIRE((stride == 1 || stride == 2) && rows_tile_ok(ksize, stride, tile), CNM_ERR_BAD_ARG);
     CNM_REQUIRE(Cout > 0 && Cout % 64 == 0 && gout0 >= 0 && gout0 + Cout / 4 <= Gout_total, CNM_ERR_BAD_ARG);
     CNM_REQUIRE(ga0 >= 0 && ga0 + Ga <= Ga_total && (Gb == 0 || (in_b && gb0 >= 0 && gb0 + Gb <= Gb_total)), CNM_ERR_BAD_ARG);
@@ -425,9 +433,10 @@ extern "C" int cnm_conv_rows_winograd_c4_f32(const float* in_a, int Ga_total, in
     a.Gin_tot = Ga_total; a.gin0 = ga0; a.Gin2_tot = Gb ? Gb_total : Ga_total; a.gin2_0 = Gb ? gb0 : ga0; a.Gsplit = Ga; a.Gin = Ga + Gb;
     a.Gout_tot = Gout_total; a.gout0 = gout0; a.Cout = Cout;
     a.nchunks = (ksize * stride * a.Gin + 3) / 4; a.T = N * a.Ho * a.TW; a.relu = relu;
-    const int nblocks = (Cout / 64) * cnm_ceil_div(a.T, (ksize == 7 && stride == 1 && m == 4) ? 48 : 64);
+    const int nblocks = (Cout / 64) * cnm_ceil_div(a.T, ((ksize == 7 && stride == 1 && m == 4) || ksize == 3) ? 48 : 64);
     hipStream_t st = cnm_stream(stream);
-    if (ksize == 5 && stride == 1) conv_rows_winograd_f32_kernel<5, 1, 2><<<nblocks, 256, 0, st>>>(a);
+    if (ksize == 3) conv_rows_winograd_f32_kernel<3, 2, 4><<<nblocks, 256, 0, st>>>(a);
+    else if (ksize == 5 && stride == 1) conv_rows_winograd_f32_kernel<5, 1, 2><<<nblocks, 256, 0, st>>>(a);
     else if (ksize == 5 && tile == 4) conv_rows_winograd_f32_kernel<5, 2, 4><<<nblocks, 256, 0, st>>>(a);
     else if (ksize == 5) conv_rows_winograd_f32_kernel<5, 2, 2><<<nblocks, 256, 0, st>>>(a);
     else if (stride == 1 && tile == 4) conv_rows_winograd_f32_kernel<7, 1, 4><<<nblocks, 256, 0, st>>>(a);

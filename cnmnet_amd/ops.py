@@ -225,6 +225,22 @@ def pack_winograd(weight, bn=None, rot=0, eps=1e-5, stride=1, tile=None):
     return up
 
 
+def pack_winograd_rows(weight, bn=None, rot=0, eps=1e-5, stride=2, tile=4):
+    """Row-wise Winograd filter for any supported (ksize, stride, tile) -- in particular 3x3 stride 2 (two F(4,2) column
+    phases), which pack_winograd serves with the F(2x2,3x3) filter instead."""
+    _dev(weight, *(bn or ()))
+    lib = _lib.load()
+    Cout, Cin, k, _ = weight.shape
+    n = lib.cnm_packed_winograd_rows_floats(Cout, Cin, k, stride, tile)
+    if n == 0:
+        raise _lib.EngineError("no row-wise Winograd kernel for ksize %d stride %d tile %d (Cout %d)" % (k, stride, tile, Cout))
+    up = torch.empty(n, device=weight.device, dtype=torch.float32)
+    g, v = (_c(bn[0]), _c(bn[3])) if bn else (None, None)
+    with torch.cuda.device(weight.device):
+        _lib.check(lib.cnm_pack_winograd_rows_bn_f32(_p(_c(weight)), _p(g), _p(v), eps, Cout, Cin, k, stride, tile, rot, _p(up), _stream()))
+    return up
+
+
 def pack_winograd4(weight, bn=None, rot=0, eps=1e-5):
     """36-point Winograd-domain packed filter: 3x3 weight -> F(4x4,3x3); 5x5 weight -> F(2x2,5x5)."""
     _dev(weight, *(bn or ()))

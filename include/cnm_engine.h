@@ -203,7 +203,9 @@ int cnm_conv3x3_upsampled_ring_c4_f32(const float* in, int Gin_total, int gin0, 
  * F(4,7) -- 10 multiplies per 4 outputs and kernel row, 1.6x fewer than F(2,7), measured error 3e-4 on O(1) outputs
  * against 5e-5 for tile 2 -- and F(4,4) / F(4,3) column phases for stride 2 (1.4x / 1.33x fewer than tile 2).  The
  * inference executors use tile 4, the training path keeps tile 2.
- * u_packed from cnm_pack_winograd_rows_bn_f32 (same ksize, stride and tile). */
+ * u_packed from cnm_pack_winograd_rows_bn_f32 (same ksize, stride and tile).
+ * Also ksize 3 with stride 2 and tile 4: two F(4,2) column phases (5 multiplies per 4 outputs, phase and kernel row
+ * instead of 6); in cnm_layer_weights such a filter goes into u4 of a 3x3 stride-2 layer (u holds the F(2x2,3x3) filter). */
 size_t cnm_packed_winograd_rows_floats(int Cout, int Cin, int ksize, int stride, int tile);
 int cnm_pack_winograd_rows_bn_f32(const float* w_oihw, const float* bn_gamma, const float* bn_var, float eps,
                                   int Cout, int Cin, int ksize, int stride, int tile, int rot, float* u_packed, void* stream);

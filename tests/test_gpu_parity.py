@@ -229,6 +229,27 @@ def test_conv5x5_winograd(dev, ops, cin, cout, rot, N, H, W):
     assert np.abs(got - want).max() < 2e-4 * max(np.abs(want).max(), 1.0), np.abs(got - want).max()
 
 
+@pytest.mark.parametrize("cin,cout,rot,N,H,W", [(128, 128, 0, 2, 48, 64), (35, 64, 3, 1, 9, 13), (64, 64, 0, 3, 7, 10), (256, 256, 0, 1, 24, 32), (8, 64, 0, 1, 2, 2), (20, 64, 0, 2, 33, 101)])
+def test_conv3x3_stride2_rows(dev, ops, cin, cout, rot, N, H, W):
+    """3x3 stride-2 pad-1 conv + BN + ReLU as two F(4,2) column phases along rows (5 multiplies per 4 outputs, phase and
+    kernel row): odd sizes, ragged tiles of 4 outputs, ragged Cin, rotated input channels."""
+    rng = np.random.default_rng(cin * 31 + H)
+    x = T(rng.standard_normal((N, cin, H, W)).astype(np.float32))
+    w = T((rng.standard_normal((cout, cin, 3, 3)) * (2.0 / (cin * 9)) ** 0.5).astype(np.float32))
+    bnp = [T(a.astype(np.float32)) for a in (rng.uniform(0.5, 1.5, cout), rng.normal(0, 0.2, cout), rng.normal(0, 0.2, cout), rng.uniform(0.5, 1.5, cout))]
+    sc = bnp[0].double() / torch.sqrt(bnp[3].double() + 1e-5)
+    want = F.relu(F.conv2d(x.double(), w.double(), stride=2, padding=1) * sc[None, :, None, None] + (bnp[1].double() - bnp[2].double() * sc)[None, :, None, None]).numpy()
+    bnd = tuple(t.to(dev) for t in bnp)
+    _, bp = ops.pack_conv(w.to(dev), bnd, rot=rot)
+    up = ops.pack_winograd_rows(w.to(dev), bnd, rot=rot, stride=2, tile=4)
+    xr = torch.cat((x[:, rot:], x[:, :rot]), 1) if rot else x
+    got = ops.c4_to_nchw(ops.conv_rows_winograd_c4(ops.nchw_to_c4(xr.to(dev)), up, bp, cout, 3, True, stride=2, tile=4), cout).cpu().numpy()
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() < 5e-5 * max(np.abs(want).max(), 1.0) + 1e-5, np.abs(got - want).max()
+    with pytest.raises(Exception):
+        ops.pack_winograd_rows(w.to(dev), bnd, stride=1, tile=4)          # 3x3 stride 1 has no row kernel
+
+
 @pytest.mark.parametrize("cin,cout,N,H,W", [(512, 512, 2, 12, 16), (64, 64, 3, 7, 9), (20, 128, 1, 1, 1), (36, 64, 2, 10, 33)])
 def test_conv3x3_stride2_winograd(dev, ops, cin, cout, N, H, W):
     """3x3 stride-2 pad-1 conv + BN + ReLU through the F(2x2,3x3) kernel (one kept output per tile): odd sizes too."""
