@@ -334,7 +334,7 @@ def test_fused_upsample_networks_agree(dev):
 def test_bench_configuration_vs_oracle(dev):
     """The benchmark's own workload and dispatch -- 8 frames x (1 ref + 2 src), 192x256, 64 planes, default thresholds
     (row-wise F(4,7), F(2x2,5x5), F(4x4,3x3), fused up_conv layers, side-stream decoders, row-walking heads) -- against
-    the CPU oracle on two of the eight frames: inverse depth, probability and normals inside the 1e-3 bar."""
+    the CPU oracle on one of the eight frames: inverse depth, probability and normals inside the 1e-3 bar."""
     from cnmnet_amd.depthnet import depthNet, DepthRefineNet
     from cnmnet_amd.pipeline import FramePipeline
     B, S, H, W = 8, 2, 192, 256
@@ -354,7 +354,7 @@ def test_bench_configuration_vs_oracle(dev):
     with torch.no_grad():
         out = pipe(T(img).to(dev), T(cams).to(dev))
     cpu_d, cpu_r = load(ra.DepthNetCPU(3.0), 41, 0.2), load(ra.DepthRefineNetCPU(32, 3.0), 42, 0.05)
-    for b in (0, 5):
+    for b in (3,):                                                       # one frame of the batch: the CPU oracle takes ~35 s per frame here
         with torch.no_grad():
             want = ra.frame_forward(cpu_d, cpu_r, T(img[b:b + 1, 0]), T(img[b:b + 1, 1]), T(img[b:b + 1, 2]),
                                     T(cams[b:b + 1, 0]), T(cams[b:b + 1, 1]), T(cams[b:b + 1, 2]))
@@ -368,8 +368,6 @@ def test_bench_configuration_vs_oracle(dev):
         # oracle's depth in float64 is met by the fp32 reference arrangement only to q99 9e-4 / max 3.5e-3 (81-point normal
         # equations inverted in fp32), while the engine (fp64 window sums) stays within 1e-3 of it on EVERY pixel even
         # though its depth input carries the conv stack's own 2e-5.
-        if b != 0:
-            continue                                                   # the float64 fit takes ~40 s of host time: one frame
         n64, _ = ra.depth_to_normal(1.0 / want["disp"].double().squeeze(1), T(cams[b:b + 1, 0])[:, 1, :3, :3].double().inverse(), 9)
         e_gpu = float((out["normal"][b:b + 1].cpu().double() - n64).abs().max())
         e_ref = float((want["normal"].double() - n64).abs().max())
