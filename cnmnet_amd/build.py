@@ -14,6 +14,9 @@ LIB = os.path.join(LIBDIR, "libcnm_engine.so")
 SOURCES = ["planesweep.hip", "conv_mfma.hip", "conv_winograd.hip", "conv_winograd4.hip", "conv_winograd_rows.hip", "pointwise.hip", "geometry.hip", "nets.hip", "train_ops.hip", "half_ops.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# per-file extras: the plane sweep's blend must stay on full-rate scalar v_fma_f32 (the SLP vectoriser would
+# pack it into half-rate v_pk_fma_f32 plus the moves that feed them)
+FILE_FLAGS = {"planesweep.hip": ["-fno-slp-vectorize"]}
 
 
 def _stale(target, deps):
@@ -30,8 +33,8 @@ def build(force=False, verbose=True):
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(LIBDIR, src.replace(".hip", ".o"))
-        if force or _stale(o, [s] + headers):
-            cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+        if force or _stale(o, [s, os.path.abspath(__file__)] + headers):
+            cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(src, []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)

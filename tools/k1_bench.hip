@@ -1,94 +1,120 @@
-// Standalone micro-benchmark of the plane-sweep kernel (GPU box):
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DSWEEP_...=..] tools/k1_bench.hip -o /tmp/k1 && /tmp/k1
+// Standalone check + micro-benchmark of the plane-sweep kernel (GPU box):
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize [-DSWEEP_...=..] tools/k1_bench.hip -o /tmp/k1 && /tmp/k1
 // Synthetic geometry as cnmnet_amd/synthetic.py: K = [[1.125W,0,W/2],[0,1.5H,H/2]], small rotation, +-0.1 m baseline.
+// Every run compares the c4 output of pair 0 .. NCHECK-1 with a float64 closed-form evaluation on the host
+// (explicit per-corner zero padding), and the NCHW layout with the c4 layout bit for bit.
 #include "../cnmnet_amd/csrc/planesweep.hip"
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
 #include <vector>
 
-__global__ __launch_bounds__(256) void ref_empty_kernel(float* out) {
-    __shared__ float4 t[2048];
-    t[threadIdx.x] = make_float4(1, 2, 3, 4);
-    __syncthreads();
-    if (out == nullptr) out[0] = t[threadIdx.x ^ 1].x;
-}
 __global__ __launch_bounds__(256) void ref_store_kernel(float* out, int G, int HW, int W) {   // pure output stream, same grid
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), p = blockIdx.z;
     for (int g = 0; g < G; ++g)
         *reinterpret_cast<float4*>(out + c4_offset(p, G, g, HW, y * W + x)) = make_float4(g, x, y, p);
 }
 
+static double host_sample(const float* img, int H, int W, double ix, double iy) {   // grid_sample bilinear, zeros padding
+    if (!(std::fabs(ix) < 1e7) || !(std::fabs(iy) < 1e7)) return 0.0;
+    const double fx = std::floor(ix), fy = std::floor(iy);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const double wx = ix - fx, wy = iy - fy;
+    auto at = [&](int yy, int xx) -> double { return (xx >= 0 && xx < W && yy >= 0 && yy < H) ? img[(size_t)yy * W + xx] : 0.0; };
+    return (1 - wx) * (1 - wy) * at(y0, x0) + wx * (1 - wy) * at(y0, x0 + 1) + (1 - wx) * wy * at(y0 + 1, x0) + wx * wy * at(y0 + 1, x0 + 1);
+}
+
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 8, S = 2, H = argc > 2 ? atoi(argv[2]) : 192, W = argc > 3 ? atoi(argv[3]) : 256, D = argc > 4 ? atoi(argv[4]) : 64;
+    const char* tag = argc > 5 ? argv[5] : "k1";
+    const double geom = argc > 6 ? atof(argv[6]) : 1.0;          // scales rotation and baseline (stress: 4 .. 20)
+    const int ncheck = argc > 7 ? atoi(argv[7]) : 2;
     const int P = B * S; const size_t HW = (size_t)H * W;
+    setvbuf(stdout, nullptr, _IONBF, 0);
     std::vector<float> ref(B * 3 * HW), src(P * 3 * HW), hmkt(P * 12);
     srand(1);
     for (auto& v : ref) v = (rand() / (float)RAND_MAX - 0.5f) * 3.f;
     for (auto& v : src) v = (rand() / (float)RAND_MAX - 0.5f) * 3.f;
     const double fx = 1.125 * W, fy = 1.5 * H, cx = W / 2.0, cy = H / 2.0;
     for (int p = 0; p < P; ++p) {
-        const double ry = ((p * 37) % 7 - 3) * 0.01, rz = ((p * 11) % 5 - 2) * 0.008, tx = (p & 1) ? -0.1 : 0.1;
+        const double ry = ((p * 37) % 7 - 3) * 0.01 * geom, rz = ((p * 11) % 5 - 2) * 0.008 * geom, tx = ((p & 1) ? -0.1 : 0.1) * geom;
         const double R[9] = {cos(ry) * cos(rz), -sin(rz), sin(ry), sin(rz), cos(rz), 0, -sin(ry), 0, cos(ry)};
         const double K[9] = {fx, 0, cx, 0, fy, cy, 0, 0, 1}, Ki[9] = {1 / fx, 0, -cx / fx, 0, 1 / fy, -cy / fy, 0, 0, 1};
         double RKi[9], Hm[9];
         for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double s = 0; for (int k = 0; k < 3; ++k) s += R[i * 3 + k] * Ki[k * 3 + j]; RKi[i * 3 + j] = s; }
         for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double s = 0; for (int k = 0; k < 3; ++k) s += K[i * 3 + k] * RKi[k * 3 + j]; Hm[i * 3 + j] = s; }
         for (int i = 0; i < 9; ++i) hmkt[p * 12 + i] = (float)Hm[i];
-        const double T[3] = {tx, 0.01, -0.01};
+        const double T[3] = {tx, 0.01 * geom, -0.01 * geom};
         for (int i = 0; i < 3; ++i) hmkt[p * 12 + 9 + i] = (float)(K[i * 3] * T[0] + K[i * 3 + 1] * T[1] + K[i * 3 + 2] * T[2]);
     }
-    float *dref, *dsrc, *dh, *dout, *dws; const size_t wsn = cnm_planesweep_workspace_floats(B, S, H, W); hipMalloc(&dws, wsn * 4);
-    const size_t outn = (size_t)P * (D / 4 + 1) * HW * 4;
-    hipMalloc(&dref, ref.size() * 4); hipMalloc(&dsrc, src.size() * 4); hipMalloc(&dh, hmkt.size() * 4); hipMalloc(&dout, outn * 4);
+    float *dref, *dsrc, *dh, *dout, *dvol, *dws; const size_t wsn = cnm_planesweep_workspace_floats(B, S, H, W); hipMalloc(&dws, wsn * 4 + 16);
+    const size_t outn = (size_t)P * (D / 4 + 1) * HW * 4, voln = (size_t)P * D * HW;
+    hipMalloc(&dref, ref.size() * 4); hipMalloc(&dsrc, src.size() * 4); hipMalloc(&dh, hmkt.size() * 4); hipMalloc(&dout, outn * 4); hipMalloc(&dvol, voln * 4);
     hipMemcpy(dref, ref.data(), ref.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dsrc, src.data(), src.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(dh, hmkt.data(), hmkt.size() * 4, hipMemcpyHostToDevice);
-    for (int i = 0; i < 5; ++i) cnm_planesweep_cat_c4_f32(dref, dsrc, dh, dout, dws, wsn, B, S, H, W, D, 0.1, 3.0, nullptr);
+    hipMemset(dout, 0xff, outn * 4); hipMemset(dvol, 0xff, voln * 4);
+    int nb = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, planesweep_kernel<1>, SWEEP_NT, 0);
+    for (int i = 0; i < 5; ++i) {
+        const int rc = cnm_planesweep_cat_c4_f32(dref, dsrc, dh, dout, dws, wsn, B, S, H, W, D, 0.1, 3.0, nullptr);
+        if (rc != 0) { printf("launch failed: %d\n", rc); return 1; }
+    }
+    if (hipDeviceSynchronize() != hipSuccess) { printf("kernel fault: %s\n", hipGetErrorString(hipGetLastError())); return 1; }
+    printf("   c4 launches ok\n");
+    if (cnm_planesweep_volume_nchw_f32(dref, dsrc, dh, dvol, dws, wsn, B, S, H, W, D, 0.1, 3.0, nullptr) != 0 || hipDeviceSynchronize() != hipSuccess) { printf("nchw fault\n"); return 1; }
+    printf("   nchw launch ok\n");
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int iters = 50;
     hipEventRecord(e0);
     for (int i = 0; i < iters; ++i) cnm_planesweep_cat_c4_f32(dref, dsrc, dh, dout, dws, wsn, B, S, H, W, D, 0.1, 3.0, nullptr);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= iters;
-    std::vector<float> out(outn); hipMemcpy(out.data(), dout, outn * 4, hipMemcpyDeviceToHost);
+    cnm_planesweep_volume_nchw_f32(dref, dsrc, dh, dvol, dws, wsn, B, S, H, W, D, 0.1, 3.0, nullptr);
+    std::vector<float> out(outn), vol(voln);
+    hipMemcpy(out.data(), dout, outn * 4, hipMemcpyDeviceToHost); hipMemcpy(vol.data(), dvol, voln * 4, hipMemcpyDeviceToHost);
     double cs = 0; for (size_t i = 0; i < outn; i += 7) cs += out[i];
-    {
-        dim3 grid(W / 64, H / 4, P);   // reference kernels use 64x4 tiles of 256 threads
-        hipEventRecord(e0);
-        for (int i = 0; i < iters; ++i) ref_empty_kernel<<<grid, 256>>>(dout);
-        hipEventRecord(e1); hipEventSynchronize(e1);
-        float t; hipEventElapsedTime(&t, e0, e1); printf("   (empty kernel, same grid, 32 KB LDS: %.1f us)\n", t / iters * 1e3);
+    // ---- layouts agree bit for bit; ref group present
+    size_t nmis = 0;
+    for (int p = 0; p < P; ++p) for (int d = 0; d < D; ++d) for (size_t q = 0; q < HW; ++q) {
+        const float a = out[c4_offset(p, D / 4 + 1, d >> 2, (int)HW, (int)q) + (d & 3)], b = vol[((size_t)p * D + d) * HW + q];
+        if (!(a == b)) ++nmis;
+    }
+    for (int p = 0; p < P; ++p) for (size_t q = 0; q < HW; q += 5) for (int c = 0; c < 3; ++c)
+        if (out[c4_offset(p, D / 4 + 1, D / 4, (int)HW, (int)q) + c] != ref[((size_t)(p / S) * 3 + c) * HW + q]) ++nmis;
+    // ---- float64 closed form on the host
+    double emax = 0, esum = 0; size_t ecnt = 0, nbig = 0;
+    const double step = (3.0 - 0.1) / (D - 1.0);
+    for (int p = 0; p < ncheck && p < P; ++p) {
+        const float* hk = &hmkt[p * 12];
+        for (int d = 0; d < D; ++d) {
+            const double z = (double)(float)(1.0 / (0.1 + d * step));
+            for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) {
+                const double t0 = ((double)hk[0] * x + (double)hk[1] * y + hk[2]) * z + hk[9];
+                const double t1 = ((double)hk[3] * x + (double)hk[4] * y + hk[5]) * z + hk[10];
+                const double t2 = ((double)hk[6] * x + (double)hk[7] * y + hk[8]) * z + hk[11] + 1e-6;
+                const double ix = t0 / t2 - 0.5, iy = t1 / t2 - 0.5;
+                double c = 0;
+                for (int ch = 0; ch < 3; ++ch)
+                    c += std::fabs(host_sample(&src[((size_t)p * 3 + ch) * HW], H, W, ix, iy) - ref[((size_t)(p / S) * 3 + ch) * HW + (size_t)y * W + x]);
+                const double e = std::fabs(c - out[c4_offset(p, D / 4 + 1, d >> 2, (int)HW, y * W + x) + (d & 3)]);
+                if (!(e <= emax)) emax = e;
+                if (e > 1e-3) ++nbig;
+                esum += e; ++ecnt;
+            }
+        }
+    }
+    printf("   check: layouts mismatching %zu | vs float64 closed form (%d pairs): max %.3e  mean %.3e  >1e-3: %zu of %zu\n", nmis, ncheck, emax, esum / (ecnt + 1e-9), nbig, ecnt);
+#ifdef SWEEP_STATS
+    { unsigned int st[4]; hipMemcpyFromSymbol(st, HIP_SYMBOL(sweep_stats), 16); const double nl = 5 + iters + 1;   // launches so far
+      printf("   per launch: workgroups %.0f, boxes staged %.0f, octets gathered from global %.0f, texels per box %.0f\n", st[0] / nl, st[1] / nl, st[2] / nl, (double)st[3] / (st[1] + 1e-9)); }
+#endif
+    if (argc <= 8) {
+        dim3 grid(W / 64, H / 4, P);
         hipEventRecord(e0);
         for (int i = 0; i < iters; ++i) ref_store_kernel<<<grid, 256>>>(dout, D / 4 + 1, H * W, W);
         hipEventRecord(e1); hipEventSynchronize(e1);
-        hipEventElapsedTime(&t, e0, e1); printf("   (pure c4 store stream, same grid: %.1f us = %.0f GB/s)\n", t / iters * 1e3, (double)P * (D + 4) * HW * 4 / (t / iters) / 1e6);
+        float t; hipEventElapsedTime(&t, e0, e1); printf("   (pure c4 store stream, same output: %.1f us = %.0f GB/s)\n", t / iters * 1e3, (double)P * (D + 4) * HW * 4 / (t / iters) / 1e6);
     }
-    {   // texture pre-pass alone
-        hipEventRecord(e0);
-        for (int i = 0; i < iters; ++i) sweep_texture_kernel<<<8192, 256>>>(dsrc, reinterpret_cast<float4*>(dws), P, H, W);
-        hipEventRecord(e1); hipEventSynchronize(e1);
-        float t; hipEventElapsedTime(&t, e0, e1); printf("   (texture pre-pass alone: %.1f us)\n", t / iters * 1e3);
-    }
-#ifdef SWEEP_TRACE
-    {
-        static long long tr[4096][40]; hipMemcpyFromSymbol(tr, HIP_SYMBOL(sweep_trace), sizeof(tr));
-        const int ng = (D + SWEEP_PG - 1) / SWEEP_PG; const int nb = 3072 < 4096 ? 3072 : 4096;
-        double pro = 0, box0 = 0, wait = 0, issue = 0, comp = 0, tot = 0, tail = 0;
-        for (int b = 0; b < nb; ++b) {
-            pro += tr[b][1] - tr[b][0]; box0 += tr[b][2] - tr[b][1]; tot += tr[b][39] - tr[b][0];
-            for (int g = 0; g < ng; ++g) { wait += tr[b][4 + 4 * g] - tr[b][3 + 4 * g]; issue += tr[b][5 + 4 * g] - tr[b][4 + 4 * g]; comp += tr[b][6 + 4 * g] - tr[b][5 + 4 * g]; }
-            tail += tr[b][39] - tr[b][6 + 4 * (ng - 1)];
-        }
-        printf("   trace (s_memtime ticks, avg per workgroup of wave 0): total %.0f | prologue %.0f box0+stage0 %.0f | per group: barrier-wait %.0f  stores+dma-issue %.0f  compute %.0f | tail %.0f\n",
-               tot / nb, pro / nb, box0 / nb, wait / nb / ng, issue / nb / ng, comp / nb / ng, tail / nb);
-        long long t0 = tr[0][0], t1 = tr[0][39]; for (int b = 0; b < nb; ++b) { if (tr[b][0] < t0) t0 = tr[b][0]; if (tr[b][39] > t1) t1 = tr[b][39]; }
-        printf("   kernel span %lld ticks\n", t1 - t0);
-    }
-#endif
-#ifdef SWEEP_STATS
-    { unsigned int st[2]; hipMemcpyFromSymbol(st, HIP_SYMBOL(sweep_stats), 8); printf("   groups staged %u, fallback %u (%.2f%%)\n", st[0], st[1], 100.0 * st[1] / (st[0] + st[1] + 1e-9)); }
-#endif
     const double bytes = (double)B * 3 * HW * 4 + (double)P * 3 * HW * 4 + (double)P * (D + 3) * HW * 4;
-    printf("%-40s %8.1f us  %7.1f GB/s (%.1f%% of 8 TB/s)  checksum %.6e\n", argc > 5 ? argv[5] : "k1", ms * 1e3, bytes / ms / 1e6, bytes / ms / 1e6 / 80.0, cs);
+    printf("%-44s %8.1f us  %7.1f GB/s (%.1f%% of 8 TB/s)  blocks/CU %d  checksum %.6e\n", tag, ms * 1e3, bytes / ms / 1e6, bytes / ms / 1e6 / 80.0, nb, cs);
     return 0;
 }
