@@ -166,12 +166,12 @@ def kernel_rooflines(dev, frames):
     img, cams = torch.from_numpy(img).to(dev), torch.from_numpy(cams).to(dev)
     ref, src = img[:, 0].contiguous(), img[:, 1:].contiguous()
     hmkt = ops.homography_terms(cams[:, 0], cams[:, 1:])
-    ws = torch.empty(_lib.load().cnm_planesweep_workspace_floats(frames, SRC, H, W), device=dev)
-    # bursts of 20 back-to-back launches through the C ABI (ctypes: ~10 us of host time per call, the kernel pair takes
-    # ~110 us, so the queue never runs dry; the Python operator path with its allocations would measure the host)
+    ws = torch.zeros(_lib.load().cnm_planesweep_workspace_floats(frames, SRC, H, W), device=dev)   # tile queue: zero on entry
+    # bursts of 25 back-to-back launches through the C ABI (ctypes: ~10 us of host time per call, the kernel takes
+    # ~80 us, so the queue never runs dry; the Python operator path with its allocations would measure the host)
     out = ops.plane_sweep_cat_c4(ref, src, hmkt, 3.0, PLANES, ws=ws)
     torch.cuda.synchronize()
-    lib, reps = _lib.load(), 20
+    lib, reps = _lib.load(), 25
     lo, hi = ops.idepth_range(3.0)
     args = (ref.data_ptr(), src.data_ptr(), hmkt.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), frames, SRC, H, W, PLANES, lo, hi,
             torch.cuda.current_stream().cuda_stream)
@@ -179,7 +179,7 @@ def kernel_rooflines(dev, frames):
     def burst():
         for _ in range(reps):
             _lib.check(lib.cnm_planesweep_cat_c4_f32(*args))
-    ms = event_ms(burst, iters=5, warm=2) / reps
+    ms = event_ms(burst, iters=4, warm=2) / reps                          # 100 timed launches
     # algorithmic bytes per launch (cat-emit variant): per pair read ref 3HW*4 + read src 3HW*4
     # + write (D+3)HW*4; ref counted once per frame because one launch covers both sources of a frame
     pairs = frames * SRC
@@ -187,7 +187,7 @@ def kernel_rooflines(dev, frames):
     sweep = {"kernel": "planesweep_kernel<1>", "bound": "hbm", "achieved": byts / ms / 1e6, "peak": HBM_PEAK_GBS,
              "unit": "GB/s", "frac": byts / ms / 1e6 / HBM_PEAK_GBS, "traffic": pmc_traffic("planesweep_kernel<1>"),
              "algorithmic_bytes_per_launch": byts, "avg_launch_ms": ms,
-             "note": "avg_launch_ms = sweep_texture_kernel (pre-pass) + planesweep_kernel, bursts of 20 back-to-back launches between HIP events"}
+             "note": "one persistent launch per call (no pre-pass); avg_launch_ms over 4 bursts of 25 back-to-back launches between HIP events on the launch stream"}
     return conv, sweep
 
 

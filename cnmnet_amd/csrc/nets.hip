@@ -188,8 +188,8 @@ static size_t carve_depth(float* ws, int P, int H, int W, int D, DepthBufs* b) {
     Carver c{ws, 0};
     const size_t q = (size_t)P * H * W * 4;     // floats (= 16 bytes x pixels) of one channel group at full resolution
     auto G = [](int C) { return (size_t)((C + E::GD - 1) / E::GD); };
+    b->TEX = c.take(4);                         // FIRST and never reused: the plane sweep's tile queue, zero between calls
     b->hmkt = c.take((size_t)P * 12);
-    b->TEX = c.take((size_t)P * (H + 4) * (W + 4) * 4);
     b->X0 = c.take(q * (G(D) + 1));
     b->A1 = c.take(q * G(128));        b->U1 = c.take(q * G(128));       b->CAT1 = c.take(q * (G(64) + 1));
     b->CAT2 = c.take(q / 4 * (2 * G(128) + 1));  b->A2 = c.take(q / 4 * G(256));   b->U2 = c.take(q / 4 * G(256));   b->I2 = c.take(q / 4 * G(128));
@@ -233,7 +233,7 @@ static int depthnet_forward(const cnm_layer_weights* wt, float idepth_scale, int
     CNM_TRY(E::conv(in, Gt, g0, Gin, out, Gto, go0, Cout, wt[L], P, HH, WW, kDepthLayers[L].ksize, kDepthLayers[L].stride, s))
     // geometry + cost volume                                                   depthNet_model.py:228-233
     CNM_TRY(cnm_homography_terms_f32(ref_cam, src_cam, b.hmkt, B, S, s));
-    CNM_TRY(E::sweep(ref, src, b.hmkt, b.X0, b.TEX, (size_t)P * (H + 4) * (W + 4) * 4, B, S, H, W, D, idmin, idmax, s));
+    CNM_TRY(E::sweep(ref, src, b.hmkt, b.X0, b.TEX, 4, B, S, H, W, D, idmin, idmax, s));
     // encoder                                                                  :235-239
     CONV(D_CONV1_0, b.X0, G0, 0, G0, b.A1, g128, 0, 128, H, W);
     CONV(D_CONV1_3, b.A1, g128, 0, g128, b.CAT2, 2 * g128 + 1, g128, 128, H, W);              // conv1 -> skip slot of iconv2

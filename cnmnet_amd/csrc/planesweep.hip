@@ -6,21 +6,26 @@
 // K1 replaces depthNet.getVolume (reference depthnet/depthNet_model.py:185-224), i.e.
 //    64 x ~12 ATen launches per pair, with ONE launch over all pairs, planes and pixels.
 //
-// K1 = ONE launch on the caller's stream (gfx950, 64-lane waves):
-//   workgroup = 8 waves = 64 x 8 pixel tile, one lane per reference pixel, all D planes walked by that lane;
-//   the (u,v,1) homography product and the reference RGB stay in registers for the whole sweep.
-//   The footprint of the tile in the source image over a run of planes (projective map => extremes at the
-//   4 tile corners x the 2 end planes of every 8-plane octet) is staged ONCE into LDS as pre-differenced
-//   texels: 12 floats (P, dP/dx, dP/dy, d2P/dxdy per channel, zero outside the image) = three 16-byte
-//   units, built from the planar source by bounds-checked buffer loads (no texture pre-pass, no workspace).
-//   A bilinear sample is then P + wu*dx + wv*dy + wu*wv*dxy: three ds_read_b128 of ONE texel and 9 FMAs
-//   for the three channels instead of four taps and 12 weighted products, and every blend instruction is a
-//   full-rate scalar v_fma_f32 (packed fp32 issues at half rate on gfx950).  The run of planes per box is
-//   chosen per workgroup: the largest power-of-two number of octets whose boxes all fit the LDS budget
-//   (all 64 planes at the benchmark geometry), so there is one barrier pair per box instead of one per
-//   16 planes.  Octets whose footprint does not fit (extreme geometry, points behind the source camera)
-//   gather the same texels from global memory with the same arithmetic.  Output leaves the registers as
-//   coalesced stores: float4 (4 planes of one pixel) in the c4 layout, one float per plane for NCHW.
+// K1 = ONE launch on the caller's stream (gfx950, 64-lane waves), persistent workgroups:
+//   The grid is sized to the chip (two 8-wave workgroups per CU).  A workgroup sweeps 64 x 8 pixel tiles drawn
+//   from a ticket counter (the last tiles are handed out as two half sweeps so the launch has no tile-long
+//   tail); one lane per reference pixel walks the planes, with the per-pixel camera terms and the reference RGB
+//   in registers; the next tile's camera terms / reference pixel / ticket travel while the current one is swept.
+//   Per tile, wave 0 projects the 4 tile corners on the 2 end planes of every 8-plane octet (projective map =>
+//   extremes there): the footprint of the tile in the source image per octet, merged (DPP) into runs of 2, 4, 8,
+//   16 octets; the longest run whose footprint fits the LDS budget is staged ONCE into LDS as pre-differenced
+//   texels: 12 floats (P, dP/dx, dP/dy, d2P/dxdy per channel, zero outside the image) = three 16-byte units,
+//   built from the planar source by range-checked buffer loads (6 per texel, the x+1 neighbour comes from the
+//   next lane by DPP; no texture pre-pass).  A bilinear sample is then P + wu*dx + wv*dy + wu*wv*dxy: three
+//   ds_read_b128 of ONE texel and 9 FMAs for the three channels instead of four taps and 12 weighted products.
+//   Coordinates use the parallax form u' = a0/a2 + (k0 - (a0/a2) k2) / (a2 z + k2): one v_rcp_f32 and two FMAs
+//   per plane (the reciprocal's rounding is scaled by the parallax, not by the coordinate).  The kernel is
+//   VALU-issue bound on gfx950 (a wave64 fp32 op issues in ~3 cycles, conversions / med3 / 24-bit integer
+//   multiplies in ~4.5, v_rcp_f32 in ~8.5, anything with an SGPR source in ~4.8: tools/valu_forms.hip), so the
+//   design minimises issued instructions: all hot operands in VGPRs, scalar (not packed) FMAs, serial work on
+//   one wave.  Octets whose footprint does not fit (extreme geometry, points behind the source camera, a2 near
+//   zero) gather the same texels from global memory with the general division form.  Output leaves the registers
+//   as coalesced stores: float4 (4 planes of one pixel) in the c4 layout, one float per plane for NCHW.
 // HBM-bound by design: algorithmic bytes per pair = 3HW*4 (ref) + 3HW*4 (src) + D*HW*4 (volume)
 // (+ 4HW*4 for the ref group when emitting the concatenated conv input).
 #include "cnm_common.h"
@@ -36,12 +41,13 @@
 #define SWEEP_MINW 4                // waves per SIMD the register allocation must allow (2 workgroups x 8 waves per CU)
 #endif
 #ifndef SWEEP_AHEAD
-#define SWEEP_AHEAD 2               // samples whose texel reads are in flight ahead of the blend
+#define SWEEP_AHEAD 1               // samples whose texel reads are in flight ahead of the blend
 #endif
 #define SWEEP_MAX_OCT (CNM_MAX_PLANES / 8)
 
 struct SweepArgs {
     const float* ref; const float* src; const float* hmkt; float* out;
+    unsigned int* queue;            // [0] tile tickets, [1] workgroups that have left; zero between launches
     int B, S, H, W, D;
     double idmin, idstep;           // plane d lies at depth 1 / (idmin + d * idstep)
 };
@@ -123,33 +129,55 @@ __device__ __forceinline__ float sweep_depth(const SweepArgs& a, int d) {
     return (float)(1.0 / s);
 }
 
-// One pre-differenced texel of the zero-extended source image at (x, y):
+// lane l reads lane l+1 / a lane of its quad, half row or row (DPP: no LDS traffic)
+__device__ __forceinline__ float sweep_next_lane(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xF, 0xF, false));   // wave_shl:1
+}
+template <int CTRL> __device__ __forceinline__ float sweep_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL> __device__ __forceinline__ int sweep_dpp(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
+#define SWEEP_DPP_XOR1 0xB1         // quad_perm:[1,0,3,2]
+#define SWEEP_DPP_XOR2 0x4E         // quad_perm:[2,3,0,1]
+#define SWEEP_DPP_HALF_MIRROR 0x141 // lane 7-l of the 8-lane half row
+#define SWEEP_DPP_ROR8 0x128        // row_ror:8 = lane l^8 of the 16-lane row
+
+// A pre-differenced texel of the zero-extended source image at (x, y): three 16-byte units
 //   u0 = (Pr, Pg, Pb, dxr)  u1 = (dxg, dxb, dyr, dyg)  u2 = (dyb, dxyr, dxyg, dxyb)
 //   dx = P(x+1,y) - P(x,y), dy = P(x,y+1) - P(x,y), dxy = (P(x+1,y+1) - P(x,y+1)) - dx; P = 0 outside the image,
-// so grid_sample's per-corner zeros padding (depthNet_model.py:220) is carried by the data.
+// so grid_sample's per-corner zeros padding (depthNet_model.py:220) is carried by the data, and a bilinear
+// sample at fractions (wu, wv) is P + wu dx + wv dy + wu wv dxy.
 struct SweepTexel { float4 u0, u1, u2; };
 
-__device__ __forceinline__ SweepTexel sweep_texel(__amdgpu_buffer_rsrc_t rsrc, int x, int y, int W, int H, unsigned chan_bytes) {
-    const bool x0 = (unsigned)x < (unsigned)W, x1 = (unsigned)(x + 1) < (unsigned)W;
-    const bool y0 = (unsigned)y < (unsigned)H, y1 = (unsigned)(y + 1) < (unsigned)H;
-    const unsigned o = (unsigned)(y * W + x) * 4u, row = (unsigned)W * 4u;
-    const unsigned a00 = (x0 && y0) ? o : 0xFFFFFFFFu, a01 = (x1 && y0) ? o + 4u : 0xFFFFFFFFu;      // out of range: the
-    const unsigned a10 = (x0 && y1) ? o + row : 0xFFFFFFFFu, a11 = (x1 && y1) ? o + row + 4u : 0xFFFFFFFFu;   // load returns 0
-    float p00[3], dx[3], dy[3], dxy[3];
+__device__ __forceinline__ SweepTexel sweep_texel_pack(const float p00[3], const float p01[3], const float p10[3], const float p11[3]) {
+    float dx[3], dy[3], dxy[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const unsigned so = c * chan_bytes;
-        const float v00 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, a00, so, 0));
-        const float v01 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, a01, so, 0));
-        const float v10 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, a10, so, 0));
-        const float v11 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, a11, so, 0));
-        p00[c] = v00; dx[c] = v01 - v00; dy[c] = v10 - v00; dxy[c] = (v11 - v10) - dx[c];
-    }
+    for (int c = 0; c < 3; ++c) { dx[c] = p01[c] - p00[c]; dy[c] = p10[c] - p00[c]; dxy[c] = (p11[c] - p10[c]) - dx[c]; }
     SweepTexel t;
     t.u0 = make_float4(p00[0], p00[1], p00[2], dx[0]);
     t.u1 = make_float4(dx[1], dx[2], dy[0], dy[1]);
     t.u2 = make_float4(dy[2], dxy[0], dxy[1], dxy[2]);
     return t;
+}
+
+// the same texel gathered from global memory (octets whose footprint does not fit the LDS box);
+// out-of-image corners: buffer offset 0xFFFFFFFF is out of range and the load returns 0
+__device__ __forceinline__ SweepTexel sweep_texel_global(__amdgpu_buffer_rsrc_t rsrc, int x, int y, int W, int H, unsigned chan_bytes) {
+    const bool x0 = (unsigned)x < (unsigned)W, x1 = (unsigned)(x + 1) < (unsigned)W;
+    const bool y0 = (unsigned)y < (unsigned)H, y1 = (unsigned)(y + 1) < (unsigned)H;
+    const unsigned o = (unsigned)(y * W + x) * 4u, row = (unsigned)W * 4u;
+    const unsigned a00 = (x0 && y0) ? o : 0xFFFFFFFFu, a01 = (x1 && y0) ? o + 4u : 0xFFFFFFFFu;
+    const unsigned a10 = (x0 && y1) ? o + row : 0xFFFFFFFFu, a11 = (x1 && y1) ? o + row + 4u : 0xFFFFFFFFu;
+    float p00[3], p01[3], p10[3], p11[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const unsigned so = c * chan_bytes;
+        p00[c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, a00, so, 0));
+        p01[c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, a01, so, 0));
+        p10[c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, a10, so, 0));
+        p11[c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, a11, so, 0));
+    }
+    return sweep_texel_pack(p00, p01, p10, p11);
 }
 
 // box: rx0, ry0 = image coordinates of box texel (0,0); rw x rh texels.  The box is the tile's footprint clipped to
@@ -160,23 +188,34 @@ struct SweepBox { int rx0, ry0, rw, rh; };
 __device__ unsigned int sweep_stats[4];     // debug builds only: workgroups, staged boxes, octets gathered from global, box texels
 #endif
 
-// A sample = coordinates (sweep_coords), three 16-byte reads of one texel, blend (sweep_blend).  The sweep loop
-// issues the reads SWEEP_AHEAD samples before the blend that consumes them.
 struct SweepCoord { unsigned xi, yi; float wu, wv; };
 
-__device__ __forceinline__ SweepCoord sweep_coords(float cu, float cv, float umax, float vmax, float a0, float a1, float a2,
-                                                   float k0, float k1, float k2e, float z) {
-    const float den = fmaf(a2, z, k2e);                                      // depthNet_model.py:210-212 (k2e = k2 + 1e-6)
-    float r = __builtin_amdgcn_rcpf(den);
-    r = fmaf(fmaf(-den, r, 1.0f), r, r);                                     // one Newton step: ~0.5 ulp reciprocal
-    float iu = fmaf(fmaf(a0, z, k0), r, cu);                                 // :213 + grid_sample unnormalise (u' - 0.5),
-    float iv = fmaf(fmaf(a1, z, k1), r, cv);                                 // relative to the box origin
+__device__ __forceinline__ SweepCoord sweep_split(float iu, float iv, float umax, float vmax) {
     iu = __builtin_amdgcn_fmed3f(iu, 0.f, umax);
     iv = __builtin_amdgcn_fmed3f(iv, 0.f, vmax);
     SweepCoord c;
     c.xi = (unsigned)iu; c.yi = (unsigned)iv;                                // floor (coordinates are >= 0 here)
     c.wu = __builtin_amdgcn_fractf(iu); c.wv = __builtin_amdgcn_fractf(iv);
     return c;
+}
+
+// General form, depthNet_model.py:210-213: (u', v') = (a0 z + k0, a1 z + k1) / (a2 z + k2 + 1e-6), minus the half
+// pixel of grid_sample's unnormalisation and the box origin (cu, cv).
+__device__ __forceinline__ SweepCoord sweep_coords(float cu, float cv, float umax, float vmax, float a0, float a1, float a2,
+                                                   float k0, float k1, float k2e, float z) {
+    const float den = fmaf(a2, z, k2e);
+    float r = __builtin_amdgcn_rcpf(den);
+    r = fmaf(fmaf(-den, r, 1.0f), r, r);                                     // one Newton step: ~0.5 ulp reciprocal
+    return sweep_split(fmaf(fmaf(a0, z, k0), r, cu), fmaf(fmaf(a1, z, k1), r, cv), umax, vmax);
+}
+
+// Parallax form of the same map: u' = a0/a2 + (k0 - (a0/a2) k2e) / (a2 z + k2e) = U + A r.  U (the image of the point
+// at infinity) and A are per-pixel constants, so a plane costs one reciprocal and two FMAs, and the reciprocal's
+// rounding is scaled by the parallax |A r| instead of the coordinate |u'|: the plain v_rcp_f32 (1 ulp) is enough.
+__device__ __forceinline__ SweepCoord sweep_coords_parallax(float ug, float vg, float umax, float vmax, float pa, float pb,
+                                                            float a2, float k2e, float z) {
+    const float r = __builtin_amdgcn_rcpf(fmaf(a2, z, k2e));
+    return sweep_split(fmaf(pa, r, ug), fmaf(pb, r, vg), umax, vmax);
 }
 
 __device__ __forceinline__ float sweep_blend(const float4 u0, const float4 u1, const float4 u2, float wu, float wv,
@@ -188,236 +227,369 @@ __device__ __forceinline__ float sweep_blend(const float4 u0, const float4 u1, c
     return (__builtin_fabsf(er) + __builtin_fabsf(eg)) + __builtin_fabsf(eb);   // :222-223
 }
 
+// Persistent workgroups: the grid is sized to the chip (two 8-wave workgroups per CU) and a workgroup sweeps tile
+// blockIdx.x, then tiles drawn from a ticket counter in the caller's workspace (ws[0]: tickets, ws[1]: exits; both
+// are zero between launches - the last workgroup to leave resets them).  Per tile: footprints (wave 0) ->
+// [stage box -> sweep its planes]*.  The ticket, the camera terms and the reference pixel of the NEXT tile are
+// fetched while the current one is swept.
 template <int LAYOUT>   // 0: volume [P,D,H,W] fp32   1: c4 [P,D/4+1,H,W,4] fp32   2: c8 [P,D/8+1,H,W,8] fp16
 __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_MINW, SWEEP_MINW))) void planesweep_kernel(const SweepArgs a) {
-    // one LDS object: texel box | plane depths | plane groups | header
-    __shared__ float4 smem[3 * SWEEP_CAP + CNM_MAX_PLANES / 4 + 2 * SWEEP_MAX_OCT + 1];
+    // one LDS object: texel box | plane depths | plane groups (two tile parities) | header (level, next tile) x 2
+    __shared__ float4 smem[3 * SWEEP_CAP + CNM_MAX_PLANES / 4 + 2 * 2 * SWEEP_MAX_OCT + 1];
     float4* const box = smem;
     float* const zsh = reinterpret_cast<float*>(smem + 3 * SWEEP_CAP);
     int (*const grp)[8] = reinterpret_cast<int (*)[8]>(smem + 3 * SWEEP_CAP + CNM_MAX_PLANES / 4);
-    int* const hdr = reinterpret_cast<int*>(smem + 3 * SWEEP_CAP + CNM_MAX_PLANES / 4 + 2 * SWEEP_MAX_OCT);
+    int* const hdr = reinterpret_cast<int*>(smem + 3 * SWEEP_CAP + CNM_MAX_PLANES / 4 + 4 * SWEEP_MAX_OCT);
 
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int tx0 = blockIdx.x * SWEEP_TW, ty0 = blockIdx.y * SWEEP_TH;
-    const int x = tx0 + lane, y = ty0 + (tid >> 6);
-    const int p = blockIdx.z, b = p / a.S;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = a.H, W = a.W, HW = H * W, D = a.D;
-    const bool pvalid = x < W && y < H;
     const int noct = (D + 7) >> 3;
+    const int ntx = (W + SWEEP_TW - 1) / SWEEP_TW, nty = (H + SWEEP_TH - 1) / SWEEP_TH, tiles_per_pair = ntx * nty;
+    const int ntiles = a.B * a.S * tiles_per_pair;
+    const unsigned chan_bytes = (unsigned)HW * 4u;
+    const size_t plane = (size_t)HW * (LAYOUT == 0 ? 1 : 4);                 // floats per plane / per 16-byte channel group
     if (tid < CNM_MAX_PLANES) zsh[tid] = tid < D ? sweep_depth(a, tid) : 0.f;
 
-    const float* hk = a.hmkt + (size_t)p * 12;
-    const float h00 = hk[0], h01 = hk[1], h02 = hk[2], h10 = hk[3], h11 = hk[4], h12 = hk[5];
-    const float h20 = hk[6], h21 = hk[7], h22 = hk[8], k0 = hk[9], k1 = hk[10], k2 = hk[11];
-    const float k2e = k2 + 1e-6f;
-    const float fx_ = (float)x, fy_ = (float)y;
-    const float a0 = fmaf(h00, fx_, fmaf(h01, fy_, h02)), a1 = fmaf(h10, fx_, fmaf(h11, fy_, h12));
-    const float a2 = fmaf(h20, fx_, fmaf(h21, fy_, h22));
+    // Work units: whole tiles first; the last tiles (one per resident workgroup) are cut into two half sweeps, so the
+    // launch does not end with a tile-long tail of half-empty CUs.
+    const int nsplit = noct > 1 ? min(ntiles, (int)gridDim.x) : 0, nfull = ntiles - nsplit, nunits = nfull + 2 * nsplit;
+    const float inv_tpp = 1.0f / (float)tiles_per_pair, inv_ntx = 1.0f / (float)ntx;
+    struct Unit { int p, tx0, ty0, obeg, ocnt; };
+    auto decode = [&](int u) {                                               // unit -> pair, tile origin, octet range
+        Unit q; q.obeg = 0; q.ocnt = noct;
+        int t = u;
+        if (u >= nfull) {
+            const int v = u - nfull, h0 = (noct + 1) >> 1;
+            if (v & 1) { q.obeg = h0; q.ocnt = noct - h0; } else q.ocnt = h0;
+            t = nfull + (v >> 1);
+        }
+        q.p = (int)(((float)t + 0.5f) * inv_tpp);                            // exact for t < 2^20 (checked by the launcher)
+        const int rem = t - q.p * tiles_per_pair, tyi = (int)(((float)rem + 0.5f) * inv_ntx);
+        q.tx0 = (rem - tyi * ntx) * SWEEP_TW; q.ty0 = tyi * SWEEP_TH;
+        return q;
+    };
+    // camera terms (lane i < 12 holds term i) and reference pixel of a unit's tile
+    auto tile_loads = [&](const Unit& q, float& hkv, float (&refv)[3]) {
+        const int x = q.tx0 + lane, y = q.ty0 + wave;
+        hkv = a.hmkt[(size_t)q.p * 12 + min(lane, 11)];
+        refv[0] = refv[1] = refv[2] = 0.f;
+        if (x < W && y < H) {
+            const float* refp = a.ref + (size_t)(q.p / a.S) * 3 * HW + (size_t)y * W + x;
+            refv[0] = refp[0]; refv[1] = refp[HW]; refv[2] = refp[2 * HW];
+        }
+    };
+    int unit = blockIdx.x;
+    float hkv = 0.f, refv[3] = {0.f, 0.f, 0.f};
+    Unit cur = decode(min(unit, nunits - 1));
+    if (unit < nunits) tile_loads(cur, hkv, refv);
 
-    float rr = 0.f, rg = 0.f, rb = 0.f;
-    if (pvalid) {
-        const float* refp = a.ref + (size_t)b * 3 * HW + (size_t)y * W + x;
-        rr = refp[0]; rg = refp[HW]; rb = refp[2 * HW];
-    }
-    const unsigned chan_bytes = (unsigned)HW * 4u;
-    const unsigned long long srcb = reinterpret_cast<unsigned long long>(a.src + (size_t)p * 3 * HW);
-    const unsigned src_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)srcb);       // descriptor pinned to SGPRs
-    const unsigned src_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(srcb >> 32));
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<float*>((unsigned long long)src_lo | ((unsigned long long)src_hi << 32)), 0, 3 * chan_bytes, 0x00020000);
+    for (int parity = 0; unit < nunits; parity ^= 1) {
+        // the ticket of the unit after this one travels while wave 0 works out the footprints
+        int ticket = unit + (int)gridDim.x;                                 // without a queue: a fixed stride
+        if (tid == 0 && a.queue) ticket = (int)gridDim.x + (int)atomicAdd(a.queue, 1u);
+        const int p = cur.p, tx0 = cur.tx0, ty0 = cur.ty0, obeg = cur.obeg, ocnt = cur.ocnt;
+        const int x = tx0 + lane, y = ty0 + wave;
+        const bool pvalid = x < W && y < H;
+        float hq[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) hq[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hkv), i));
+        const float h00 = hq[0], h01 = hq[1], h02 = hq[2], h10 = hq[3], h11 = hq[4], h12 = hq[5];
+        const float h20 = hq[6], h21 = hq[7], h22 = hq[8], k0 = hq[9], k1 = hq[10], k2 = hq[11];
+        const float k2e = k2 + 1e-6f;
+        const float rr = refv[0], rg = refv[1], rb = refv[2];
+        const float fx_ = (float)x, fy_ = (float)y;
+        const float a0 = fmaf(h00, fx_, fmaf(h01, fy_, h02)), a1 = fmaf(h10, fx_, fmaf(h11, fy_, h12));
+        float a2 = fmaf(h20, fx_, fmaf(h21, fy_, h22));
+        const unsigned long long srcb = reinterpret_cast<unsigned long long>(a.src + (size_t)p * 3 * HW);
+        const unsigned src_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)srcb);   // descriptor pinned to SGPRs
+        const unsigned src_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(srcb >> 32));
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<float*>((unsigned long long)src_lo | ((unsigned long long)src_hi << 32)), 0, 3 * chan_bytes, 0x00020000);
 
-    // ---- footprints, wave 0: lane (8j + c) projects tile corner (c & 3) on the first (c < 4) / last plane of
-    // octet j; an 8-lane min/max gives the octet's box.  Lane o then owns octet o, and four xor-merges give the
-    // boxes of every aligned run of 2, 4, 8, 16 octets.  The longest run whose boxes all fit the LDS budget wins.
-    if (tid < 64) {
-        const int cxi = (lane & 1) ? min(tx0 + SWEEP_TW - 1, W - 1) : tx0;
-        const int cyi = (lane & 2) ? min(ty0 + SWEEP_TH - 1, H - 1) : ty0;
-        const float cxf = (float)cxi, cyf = (float)cyi;
-        const float ca0 = fmaf(h00, cxf, fmaf(h01, cyf, h02));
-        const float ca1 = fmaf(h10, cxf, fmaf(h11, cyf, h12));
-        const float ca2 = fmaf(h20, cxf, fmaf(h21, cyf, h22));
-        int ox0 = 0, oy0 = 0, ox1 = 0, oy1 = 0, ook = 0;                     // lane o (< 16): footprint of octet o
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-            const int o = min(pass * 8 + (lane >> 3), noct - 1);
-            const int d0 = o * 8, d1 = min(d0 + 8, D) - 1;
-            const float zc = sweep_depth(a, (lane & 4) ? d1 : d0);
-            const float den = fmaf(ca2, zc, k2) + 1e-6f;
-            float rc = __builtin_amdgcn_rcpf(den);
-            rc = fmaf(fmaf(-den, rc, 1.0f), rc, rc);
-            const float u = fmaf(ca0, zc, k0) * rc, v = fmaf(ca1, zc, k1) * rc;
-            int okc = (den > 1e-4f) && (fabsf(u) < 1e6f) && (fabsf(v) < 1e6f);
-            float umin = u, umax = u, vmin = v, vmax = v;
-#pragma unroll
-            for (int m = 1; m < 8; m <<= 1) {
-                umin = fminf(umin, __shfl_xor(umin, m, 8)); umax = fmaxf(umax, __shfl_xor(umax, m, 8));
-                vmin = fminf(vmin, __shfl_xor(vmin, m, 8)); vmax = fmaxf(vmax, __shfl_xor(vmax, m, 8));
-                okc &= __shfl_xor(okc, m, 8);
+        if (tid < 64) {
+            const int cxi = (lane & 1) ? min(tx0 + SWEEP_TW - 1, W - 1) : tx0;
+            const int cyi = (lane & 2) ? min(ty0 + SWEEP_TH - 1, H - 1) : ty0;
+            const float cxf = (float)cxi, cyf = (float)cyi;
+            const float ca0 = fmaf(h00, cxf, fmaf(h01, cyf, h02));
+            const float ca1 = fmaf(h10, cxf, fmaf(h11, cyf, h12));
+            const float ca2 = fmaf(h20, cxf, fmaf(h21, cyf, h22));
+            // the parallax form needs a2 (linear over the tile: extremes at the corners) away from zero, one sign
+            const bool parallax_ok = __ballot(!(fabsf(ca2) >= 0.25f)) == 0 && (__ballot(ca2 < 0.f) == 0 || __ballot(ca2 > 0.f) == 0);
+            const float idmin = (float)a.idmin, idstep = (float)a.idstep;       // fp32 depths are enough for a box with margins
+            int bx0[2], by0[2], bx1[2], by1[2], bok[2];
+            bool live[2];
+            bx0[1] = by0[1] = 1 << 28; bx1[1] = by1[1] = -(1 << 28); bok[1] = 1; live[1] = false;   // neutral second pass
+    #pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                if (q == 1 && ocnt <= 8) break;
+                const int oct = q * 8 + (lane >> 3);                         // octet of this unit
+                live[q] = oct < ocnt;
+                const int o = obeg + min(oct, ocnt - 1);
+                const int d0 = o * 8, d1 = min(d0 + 8, D) - 1;
+                const float zc = __builtin_amdgcn_rcpf(fmaf((float)((lane & 4) ? d1 : d0), idstep, idmin));
+                const float den = fmaf(ca2, zc, k2) + 1e-6f;
+                float rc = __builtin_amdgcn_rcpf(den);
+                rc = fmaf(fmaf(-den, rc, 1.0f), rc, rc);
+                const float u = fmaf(ca0, zc, k0) * rc, v = fmaf(ca1, zc, k1) * rc;
+                int okc = (den > 1e-4f) && (fabsf(u) < 1e6f) && (fabsf(v) < 1e6f);
+                float umin = u, umax = u, vmin = v, vmax = v;
+    #define SWEEP_RED8(CTRL) \
+                umin = fminf(umin, sweep_dpp<CTRL>(umin)); umax = fmaxf(umax, sweep_dpp<CTRL>(umax)); \
+                vmin = fminf(vmin, sweep_dpp<CTRL>(vmin)); vmax = fmaxf(vmax, sweep_dpp<CTRL>(vmax)); okc &= sweep_dpp<CTRL>(okc);
+                SWEEP_RED8(SWEEP_DPP_XOR1) SWEEP_RED8(SWEEP_DPP_XOR2) SWEEP_RED8(SWEEP_DPP_HALF_MIRROR)
+    #undef SWEEP_RED8
+                // texel indices floor(u - 0.5) of the samples, one texel of safety margin either side, clipped to
+                // [-2, W] x [-2, H] (the outermost column / row of that range is all zeros)
+                bx0[q] = (int)fminf(fmaxf(floorf(umin - 0.5f) - 1.f, -2.f), (float)W);
+                bx1[q] = (int)fminf(fmaxf(floorf(umax - 0.5f) + 1.f, (float)bx0[q]), (float)W);
+                by0[q] = (int)fminf(fmaxf(floorf(vmin - 0.5f) - 1.f, -2.f), (float)H);
+                by1[q] = (int)fminf(fmaxf(floorf(vmax - 0.5f) + 1.f, (float)by0[q]), (float)H);
+                bok[q] = okc;
+                if (!live[q]) { bx0[q] = 1 << 28; by0[q] = 1 << 28; bx1[q] = -(1 << 28); by1[q] = -(1 << 28); bok[q] = 1; }   // neutral
             }
-            // texel indices floor(u - 0.5) of the samples, one texel of safety margin either side, clipped to
-            // [-2, W] x [-2, H] (the outermost column / row of that range is all zeros)
-            const int bx0 = (int)fminf(fmaxf(floorf(umin - 0.5f) - 1.f, -2.f), (float)W);
-            const int bx1 = (int)fminf(fmaxf(floorf(umax - 0.5f) + 1.f, (float)bx0), (float)W);
-            const int by0 = (int)fminf(fmaxf(floorf(vmin - 0.5f) - 1.f, -2.f), (float)H);
-            const int by1 = (int)fminf(fmaxf(floorf(vmax - 0.5f) + 1.f, (float)by0), (float)H);
-            const int srcl = 8 * (lane & 7);                                 // lanes 8j .. 8j+7 hold octet (8 pass + j)
-            const int sx0 = __shfl(bx0, srcl), sy0 = __shfl(by0, srcl), sx1 = __shfl(bx1, srcl), sy1 = __shfl(by1, srcl);
-            const int sok = __shfl(okc, srcl);
-            if ((lane >> 3) == pass) { ox0 = sx0; oy0 = sy0; ox1 = sx1; oy1 = sy1; ook = sok; }
-        }
-        const bool live = lane < noct;
-        if (!live) { ox0 = 1 << 28; oy0 = 1 << 28; ox1 = -(1 << 28); oy1 = -(1 << 28); ook = 1; }   // neutral for the merges
-        int lx0[5], ly0[5], lx1[5], ly1[5], lok[5];
-        lx0[0] = ox0; ly0[0] = oy0; lx1[0] = ox1; ly1[0] = oy1; lok[0] = ook;
-#pragma unroll
-        for (int L = 1; L < 5; ++L) {
-            const int m = 1 << (L - 1);
-            lx0[L] = min(lx0[L - 1], __shfl_xor(lx0[L - 1], m)); ly0[L] = min(ly0[L - 1], __shfl_xor(ly0[L - 1], m));
-            lx1[L] = max(lx1[L - 1], __shfl_xor(lx1[L - 1], m)); ly1[L] = max(ly1[L - 1], __shfl_xor(ly1[L - 1], m));
-            lok[L] = lok[L - 1] & __shfl_xor(lok[L - 1], m);
-        }
-        int level = 0;
-        int gx0 = lx0[0], gy0 = ly0[0], gx1 = lx1[0], gy1 = ly1[0], gst = 0;
-#pragma unroll
-        for (int L = 0; L < 5; ++L) {
-            const int fits = lok[L] && (lx1[L] - lx0[L] + 1) * (ly1[L] - ly0[L] + 1) <= SWEEP_CAP;
-            if (L == 0) gst = fits;
-            const bool all_fit = __ballot(live && !fits) == 0;
-            if (L > 0 && all_fit) { level = L; gx0 = lx0[L]; gy0 = ly0[L]; gx1 = lx1[L]; gy1 = ly1[L]; gst = 1; }
-        }
-        // (all_fit is monotone: a run that fits implies its halves fit, so the last level taken is the largest)
-        level = __builtin_amdgcn_readfirstlane(level);
-        if (live && (lane & ((1 << level) - 1)) == 0) {
-            int* gq = grp[lane >> level];
-            gq[0] = gx0; gq[1] = gy0; gq[2] = gx1 - gx0 + 1; gq[3] = gy1 - gy0 + 1; gq[4] = gst;
-        }
-        if (lane == 0) { hdr[0] = level; }
-    }
-    __syncthreads();
-    const int level = __builtin_amdgcn_readfirstlane(hdr[0]);
-    const int ngroups = (noct + (1 << level) - 1) >> level;
-
-    const int pix = y * W + x;
-    // per-lane base of the pair's output + wave-uniform plane offsets (kept on the scalar unit)
-    // octets are visited in order, so the output address is a running per-lane pointer
-    float* optr = a.out + (LAYOUT == 0 ? (size_t)p * D * HW + pix
-                                       : c4_offset(p, LAYOUT == 1 ? D / 4 + 1 : D / 8 + 1, 0, HW, pix));
-    const size_t plane = (size_t)HW * (LAYOUT == 0 ? 1 : 4);                 // floats per plane / per 16-byte channel group
-    for (int g = 0; g < ngroups; ++g) {
-        SweepBox bx;
-        bx.rx0 = __builtin_amdgcn_readfirstlane(grp[g][0]); bx.ry0 = __builtin_amdgcn_readfirstlane(grp[g][1]);
-        bx.rw = __builtin_amdgcn_readfirstlane(grp[g][2]); bx.rh = __builtin_amdgcn_readfirstlane(grp[g][3]);
-        const bool staged = __builtin_amdgcn_readfirstlane(grp[g][4]) != 0;
-#ifdef SWEEP_STATS
-        if (tid == 0) {
-            if (g == 0) atomicAdd(&sweep_stats[0], 1u);
-            if (staged) { atomicAdd(&sweep_stats[1], 1u); atomicAdd(&sweep_stats[3], (unsigned)(bx.rw * bx.rh)); }
-            else atomicAdd(&sweep_stats[2], (unsigned)(min((g + 1) << level, noct) - (g << level)));
-        }
-#endif
-        if (staged) {
-            if (g > 0) __syncthreads();                                      // every wave is done with the previous box
-            const int n = bx.rw * bx.rh;
-            const float inv_rw = 1.0f / (float)bx.rw;
-            for (int i = tid; i < n; i += SWEEP_NT) {
-                const int r = (int)(((float)i + 0.5f) * inv_rw), c = i - r * bx.rw;   // exact for n <= SWEEP_CAP
-                const SweepTexel t = sweep_texel(rsrc, bx.rx0 + c, bx.ry0 + r, W, H, chan_bytes);
-                box[3 * i] = t.u0; box[3 * i + 1] = t.u1; box[3 * i + 2] = t.u2;
+            int level = 0, gx0[2], gy0[2], gx1[2], gy1[2], gst[2];
+    #pragma unroll
+            for (int L = 0; L < 5; ++L) {
+                if (L == 1) {
+    #pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        bx0[q] = min(bx0[q], sweep_dpp<SWEEP_DPP_ROR8>(bx0[q])); by0[q] = min(by0[q], sweep_dpp<SWEEP_DPP_ROR8>(by0[q]));
+                        bx1[q] = max(bx1[q], sweep_dpp<SWEEP_DPP_ROR8>(bx1[q])); by1[q] = max(by1[q], sweep_dpp<SWEEP_DPP_ROR8>(by1[q]));
+                        bok[q] &= sweep_dpp<SWEEP_DPP_ROR8>(bok[q]);
+                    }
+                } else if (L == 2 || L == 3) {
+                    const int m = L == 2 ? 16 : 32;
+    #pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        bx0[q] = min(bx0[q], __shfl_xor(bx0[q], m)); by0[q] = min(by0[q], __shfl_xor(by0[q], m));
+                        bx1[q] = max(bx1[q], __shfl_xor(bx1[q], m)); by1[q] = max(by1[q], __shfl_xor(by1[q], m));
+                        bok[q] &= __shfl_xor(bok[q], m);
+                    }
+                } else if (L == 4) {
+                    bx0[0] = bx0[1] = min(bx0[0], bx0[1]); by0[0] = by0[1] = min(by0[0], by0[1]);
+                    bx1[0] = bx1[1] = max(bx1[0], bx1[1]); by1[0] = by1[1] = max(by1[0], by1[1]);
+                    bok[0] = bok[1] = bok[0] & bok[1];
+                }
+                bool bad = false;
+                int fits[2];
+    #pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int rw = bx1[q] - bx0[q] + 1, rh = by1[q] - by0[q] + 1;
+                    // capacity in texels, and in staging items ((rw + 1) rh over four passes of 8 x 63 lanes)
+                    fits[q] = bok[q] && rw <= SWEEP_CAP && rh <= SWEEP_CAP && rw * rh <= SWEEP_CAP && (rw + 1) * rh <= 4 * 8 * 63;
+                    const bool run_live = ((q * 8 + (lane >> 3)) & ~((1 << L) - 1)) < ocnt;
+                    bad |= run_live && !fits[q];
+                }
+                const bool all_fit = __ballot(bad) == 0;
+                if (L == 0 || all_fit) {                                          // monotone: a run that fits implies its halves fit
+                    level = L;
+    #pragma unroll
+                    for (int q = 0; q < 2; ++q) { gx0[q] = bx0[q]; gy0[q] = by0[q]; gx1[q] = bx1[q]; gy1[q] = by1[q]; gst[q] = fits[q]; }
+                }
             }
-            __syncthreads();
-        } else {                                                             // whole zero-extended image as the "box"
-            bx.rx0 = -2; bx.ry0 = -2; bx.rw = W + 3; bx.rh = H + 3;
+            level = __builtin_amdgcn_readfirstlane(level);
+    #pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int oct = q * 8 + (lane >> 3);
+                if ((lane & 7) == 0 && oct < ocnt && (oct & ((1 << level) - 1)) == 0) {
+                    int* gq = grp[parity * SWEEP_MAX_OCT + (oct >> level)];
+                    gq[0] = gx0[q]; gq[1] = gy0[q]; gq[2] = gx1[q] - gx0[q] + 1; gq[3] = gy1[q] - gy0[q] + 1;
+                    gq[4] = gst[q] && parallax_ok;
+                }
+            }
+            if (lane == 0) { hdr[2 * parity] = level; hdr[2 * parity + 1] = ticket; }
         }
-        const float cu = -(0.5f + (float)bx.rx0), cv = -(0.5f + (float)bx.ry0);
-        const float umax = (float)(bx.rw - 1), vmax = (float)(bx.rh - 1);
-        const int o_end = min((g + 1) << level, noct);
-        for (int o = g << level; o < o_end; ++o) {
-            const int d0 = o * 8;
-            float cost[8];
+        __syncthreads();   // groups parked; every wave has left the previous tile (its box is free)
+        const int level = __builtin_amdgcn_readfirstlane(hdr[2 * parity]);
+        const int next_unit = __builtin_amdgcn_readfirstlane(hdr[2 * parity + 1]);
+        const int ngroups = (ocnt + (1 << level) - 1) >> level;
+        cur = decode(min(next_unit, nunits - 1));
+        if (next_unit < nunits) tile_loads(cur, hkv, refv);
+
+        // parallax-form constants of this pixel (only used with staged boxes, i.e. when a2 is safely non-zero)
+        const float a2s = fabsf(a2) >= 0.125f ? a2 : 1.f;
+        float ra = __builtin_amdgcn_rcpf(a2s);
+        ra = fmaf(fmaf(-a2s, ra, 1.0f), ra, ra);
+        float pu = a0 * ra, pv = a1 * ra;
+        pu = fmaf(fmaf(-a2s, pu, a0), ra, pu); pv = fmaf(fmaf(-a2s, pv, a1), ra, pv);   // correctly rounded quotients but for rare ties
+        const float pa = fmaf(-pu, k2e, k0), pb = fmaf(-pv, k2e, k1);
+        float k2v = k2e;
+        asm("" : "+v"(k2v));                                                 // VALU operands from VGPRs: an SGPR source
+        asm("" : "+v"(a2));                                                  // costs the FMA its full issue rate on gfx950
+
+        const int pix = y * W + x;
+        // octets are visited in order, so the output address is a running per-lane pointer
+        float* optr = a.out + (LAYOUT == 0 ? ((size_t)p * D + 8 * obeg) * HW + pix
+                                           : c4_offset(p, LAYOUT == 1 ? D / 4 + 1 : D / 8 + 1, LAYOUT == 1 ? 2 * obeg : obeg, HW, pix));
+        for (int g = 0; g < ngroups; ++g) {
+            SweepBox bx;
+            bx.rx0 = __builtin_amdgcn_readfirstlane(grp[parity * SWEEP_MAX_OCT + g][0]); bx.ry0 = __builtin_amdgcn_readfirstlane(grp[parity * SWEEP_MAX_OCT + g][1]);
+            bx.rw = __builtin_amdgcn_readfirstlane(grp[parity * SWEEP_MAX_OCT + g][2]); bx.rh = __builtin_amdgcn_readfirstlane(grp[parity * SWEEP_MAX_OCT + g][3]);
+            const bool staged = __builtin_amdgcn_readfirstlane(grp[parity * SWEEP_MAX_OCT + g][4]) != 0;
+    #ifdef SWEEP_STATS
+            if (tid == 0) {
+                if (g == 0) atomicAdd(&sweep_stats[0], 1u);
+                if (staged) { atomicAdd(&sweep_stats[1], 1u); atomicAdd(&sweep_stats[3], (unsigned)(bx.rw * bx.rh)); }
+                else atomicAdd(&sweep_stats[2], (unsigned)(min((g + 1) << level, ocnt) - (g << level)));
+            }
+    #endif
             if (staged) {
-                SweepCoord cd[8];
-                float4 tx[8][3];
-                float zz[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) zz[j] = zsh[d0 + j];             // broadcast reads, d0 + j < CNM_MAX_PLANES
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < 8 + SWEEP_AHEAD; ++j) {
-                    if (j < 8) {
-                        cd[j] = sweep_coords(cu, cv, umax, vmax, a0, a1, a2, k0, k1, k2e, zz[j]);
-                        unsigned off;                                        // byte offset of texel (yi, xi) in the box
-                        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(off) : "v"(cd[j].yi), "s"(bx.rw), "v"(cd[j].xi));
-                        asm("v_mul_u32_u24 %0, %1, 48" : "=v"(off) : "v"(off));
-                        const float4* t = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(box) + off);
-                        tx[j][0] = t[0]; tx[j][1] = t[1]; tx[j][2] = t[2];
+                // ---- stage the box: rh rows of rw texels + one halo column, as items i = r (rw + 1) + c dealt 63 per
+                // wave pass (lane 63 repeats the next pass' first item: it only feeds lane 62).  A lane loads column c of
+                // image rows y and y + 1, column c + 1 comes from the next lane.  All loads of the box are issued first.
+                if (g > 0) __syncthreads();                                      // every wave is done with the previous box
+                const int pitch = bx.rw + 1, n = pitch * bx.rh;
+                const float inv_pitch = 1.0f / (float)pitch;
+                float p0[4][3], p1[4][3];
+                int dst[4];
+    #pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (k * 8 * 63 >= n) break;                                   // wave-uniform: passes the box does not need
+                    const int i = (k * 8 + wave) * 63 + lane;
+                    const int r = (int)(((float)i + 0.5f) * inv_pitch), c = i - r * pitch;     // exact for i < 2^21 / pitch
+                    const int xx = bx.rx0 + c, yy = bx.ry0 + r;
+                    const bool in = i < n, xin = (unsigned)xx < (unsigned)W;
+                    const unsigned o = (unsigned)(yy * W + xx) * 4u;
+                    const unsigned o0 = (in && xin && (unsigned)yy < (unsigned)H) ? o : 0xFFFFFFFFu;
+                    const unsigned o1 = (in && xin && (unsigned)(yy + 1) < (unsigned)H) ? o + (unsigned)W * 4u : 0xFFFFFFFFu;
+                    dst[k] = (in && c < bx.rw && lane < 63) ? r * bx.rw + c : -1;
+    #pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) {
+                        p0[k][ch] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, o0, ch * chan_bytes, 0));
+                        p1[k][ch] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, o1, ch * chan_bytes, 0));
                     }
-                    if (j >= SWEEP_AHEAD) {
-                        const int i = j - SWEEP_AHEAD;
-                        cost[i] = sweep_blend(tx[i][0], tx[i][1], tx[i][2], cd[i].wu, cd[i].wv, rr, rg, rb);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
                 }
-            } else {
-#pragma unroll 1
-                for (int j = 0; j < 8; ++j) {
-                    const SweepCoord cj = sweep_coords(cu, cv, umax, vmax, a0, a1, a2, k0, k1, k2e, zsh[d0 + j]);
-                    const SweepTexel t = sweep_texel(rsrc, (int)cj.xi + bx.rx0, (int)cj.yi + bx.ry0, W, H, chan_bytes);
-                    const float c = sweep_blend(t.u0, t.u1, t.u2, cj.wu, cj.wv, rr, rg, rb);
-#pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) if (jj == j) cost[jj] = c;
+    #pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (k * 8 * 63 >= n) break;
+                    float q0[3], q1[3];
+    #pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) { q0[ch] = sweep_next_lane(p0[k][ch]); q1[ch] = sweep_next_lane(p1[k][ch]); }
+                    const SweepTexel t = sweep_texel_pack(p0[k], q0, p1[k], q1);
+                    if (dst[k] >= 0) { float4* tb = box + 3 * dst[k]; tb[0] = t.u0; tb[1] = t.u1; tb[2] = t.u2; }
                 }
+                __syncthreads();
+            } else {                                                             // whole zero-extended image as the "box"
+                bx.rx0 = -2; bx.ry0 = -2; bx.rw = W + 3; bx.rh = H + 3;
             }
-            if (LAYOUT == 0) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    if (pvalid && d0 + j < D) *optr = cost[j];
+            const float cu = -(0.5f + (float)bx.rx0), cv = -(0.5f + (float)bx.ry0);
+            float umax = (float)(bx.rw - 1), vmax = (float)(bx.rh - 1);
+            const float ug = pu + cu, vg = pv + cv;
+            unsigned rwv = (unsigned)bx.rw;
+            asm("" : "+v"(umax)); asm("" : "+v"(vmax)); asm("" : "+v"(rwv));
+            const int o_end = obeg + min((g + 1) << level, ocnt);
+            for (int o = obeg + (g << level); o < o_end; ++o) {
+                const int d0 = o * 8;
+                float cost[8];
+                if (staged) {
+                    SweepCoord cd[8];
+                    float4 tx[8][3];
+                    float zz[8];
+    #pragma unroll
+                    for (int j = 0; j < 8; ++j) zz[j] = zsh[d0 + j];             // broadcast reads, d0 + j < CNM_MAX_PLANES
+                    __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                    for (int j = 0; j < 8 + SWEEP_AHEAD; ++j) {
+                        if (j < 8) {
+                            cd[j] = sweep_coords_parallax(ug, vg, umax, vmax, pa, pb, a2, k2v, zz[j]);
+                            unsigned off;                                        // byte offset of texel (yi, xi) in the box
+                            asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(off) : "v"(cd[j].yi), "v"(rwv), "v"(cd[j].xi));
+                            asm("v_mul_u32_u24 %0, %1, 48" : "=v"(off) : "v"(off));
+                            const float4* t = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(box) + off);
+                            tx[j][0] = t[0]; tx[j][1] = t[1]; tx[j][2] = t[2];
+                        }
+                        if (j >= SWEEP_AHEAD) {
+                            const int i = j - SWEEP_AHEAD;
+                            cost[i] = sweep_blend(tx[i][0], tx[i][1], tx[i][2], cd[i].wu, cd[i].wv, rr, rg, rb);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
+    #pragma unroll 1
+                    for (int j = 0; j < 8; ++j) {
+                        const SweepCoord cj = sweep_coords(cu, cv, umax, vmax, a0, a1, a2, k0, k1, k2e, zsh[d0 + j]);
+                        const SweepTexel t = sweep_texel_global(rsrc, (int)cj.xi + bx.rx0, (int)cj.yi + bx.ry0, W, H, chan_bytes);
+                        const float c = sweep_blend(t.u0, t.u1, t.u2, cj.wu, cj.wv, rr, rg, rb);
+    #pragma unroll
+                        for (int jj = 0; jj < 8; ++jj) if (jj == j) cost[jj] = c;
+                    }
+                }
+                if (LAYOUT == 0) {
+    #pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        if (pvalid && d0 + j < D) *optr = cost[j];
+                        optr += plane;
+                    }
+                } else if (LAYOUT == 1) {
+    #pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        if (pvalid && d0 + 4 * q < D)
+                            *reinterpret_cast<float4*>(optr) = make_float4(cost[4 * q], cost[4 * q + 1], cost[4 * q + 2], cost[4 * q + 3]);
+                        if (d0 + 4 * q < D) optr += plane;
+                    }
+                } else {
+                    sw_f16x8 h;
+    #pragma unroll
+                    for (int j = 0; j < 8; ++j) h[j] = (_Float16)cost[j];
+                    if (pvalid) *reinterpret_cast<sw_f16x8*>(optr) = h;
                     optr += plane;
                 }
-            } else if (LAYOUT == 1) {
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    if (pvalid && d0 + 4 * q < D)
-                        *reinterpret_cast<float4*>(optr) = make_float4(cost[4 * q], cost[4 * q + 1], cost[4 * q + 2], cost[4 * q + 3]);
-                    if (d0 + 4 * q < D) optr += plane;
-                }
-            } else {
-                sw_f16x8 h;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) h[j] = (_Float16)cost[j];
-                if (pvalid) *reinterpret_cast<sw_f16x8*>(optr) = h;
-                optr += plane;
             }
         }
+        // optr now points at the channel group behind the D planes: the reference image (depthNet_model.py:233)
+        if (LAYOUT == 1 && pvalid && obeg + ocnt == noct) *reinterpret_cast<float4*>(optr) = make_float4(rr, rg, rb, 0.f);
+        if (LAYOUT == 2 && pvalid && obeg + ocnt == noct) {
+            const sw_f16x8 h = {(_Float16)rr, (_Float16)rg, (_Float16)rb, 0, 0, 0, 0, 0};
+            *reinterpret_cast<sw_f16x8*>(optr) = h;
+        }
+        unit = next_unit;
     }
-    // optr now points at the channel group behind the D planes: the reference image (depthNet_model.py:233)
-    if (LAYOUT == 1 && pvalid) *reinterpret_cast<float4*>(optr) = make_float4(rr, rg, rb, 0.f);
-    if (LAYOUT == 2 && pvalid) {
-        const sw_f16x8 h = {(_Float16)rr, (_Float16)rg, (_Float16)rb, 0, 0, 0, 0, 0};
-        *reinterpret_cast<sw_f16x8*>(optr) = h;
-    }
+    // every workgroup draws exactly one ticket beyond the last unit; the last one to leave rearms the counters
+    if (tid == 0 && a.queue && atomicAdd(a.queue + 1, 1u) == gridDim.x - 1) { a.queue[0] = 0u; a.queue[1] = 0u; }
 }
 
-// The sweep needs no scratch any more; the argument stays in the ABI (callers size it with this query).
+// Scratch of the sweep: the tile queue of the persistent workgroups, ws[0] = tickets drawn, ws[1] = workgroups that
+// have left.  Contract: the words are ZERO when a call starts and the call leaves them zero (the last workgroup to
+// leave rearms them), so a workspace is zeroed once, when it is allocated.  ws == nullptr selects a fixed
+// tile-to-workgroup stride instead (no scratch, slower when tiles differ in cost).
 extern "C" size_t cnm_planesweep_workspace_floats(int B, int S, int H, int W) {
     if (B <= 0 || S <= 0 || H <= 0 || W <= 0) return 0;
     return 4;
 }
 
+// workgroups the chip holds at once (SWEEP_MINW waves per SIMD = that many 256-thread quarters per CU); one query per device
+static int sweep_resident_workgroups() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+    if (cached[dev] == 0) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return -1;
+        cached[dev] = cus * (SWEEP_MINW * 256 / SWEEP_NT);
+    }
+    return cached[dev];
+}
+
 static int sweep_launch(int layout, const float* ref, const float* src, const float* hmkt, float* out,
                         float* ws, size_t ws_floats, int B, int S, int H, int W, int D,
                         double idepth_min, double idepth_max, void* stream) {
-    (void)ws; (void)ws_floats;
     CNM_REQUIRE(ref && src && hmkt && out, CNM_ERR_BAD_ARG);
+    CNM_REQUIRE(ws == nullptr || (((uintptr_t)ws & 15) == 0 && ws_floats >= 4), CNM_ERR_WORKSPACE);
     CNM_REQUIRE(B > 0 && S > 0 && H > 0 && W > 0 && D >= 2 && D <= CNM_MAX_PLANES, CNM_ERR_BAD_ARG);
     CNM_REQUIRE(layout == 0 || D % 4 == 0, CNM_ERR_BAD_ARG);
     CNM_REQUIRE(layout != 2 || D % 8 == 0, CNM_ERR_BAD_ARG);
-    CNM_REQUIRE((long long)B * S <= 65535 && (long long)H * W * 12 < (1ll << 31), CNM_ERR_BAD_ARG);
+    CNM_REQUIRE((long long)H * W * 12 < (1ll << 31), CNM_ERR_BAD_ARG);
+    const long long ntiles = (long long)cnm_ceil_div(W, SWEEP_TW) * cnm_ceil_div(H, SWEEP_TH) * B * S;
+    CNM_REQUIRE(ntiles < (1ll << 20), CNM_ERR_BAD_ARG);                      // the kernel decodes tile ids with fp32 reciprocals
     SweepArgs a;
     a.ref = ref; a.src = src; a.hmkt = hmkt; a.out = out;
+    a.queue = reinterpret_cast<unsigned int*>(ws);
     a.B = B; a.S = S; a.H = H; a.W = W; a.D = D;
     a.idmin = idepth_min;
     a.idstep = (idepth_max - idepth_min) / (D - 1.0);                        // depthNet_model.py:194
-    dim3 grid(cnm_ceil_div(W, SWEEP_TW), cnm_ceil_div(H, SWEEP_TH), B * S);
+    const int slots = sweep_resident_workgroups();
+    CNM_REQUIRE(slots > 0, CNM_ERR_LAUNCH);
+    const dim3 grid((unsigned)(ntiles < slots ? ntiles : slots));
     if (layout == 0) planesweep_kernel<0><<<grid, SWEEP_NT, 0, cnm_stream(stream)>>>(a);
     else if (layout == 1) planesweep_kernel<1><<<grid, SWEEP_NT, 0, cnm_stream(stream)>>>(a);
     else planesweep_kernel<2><<<grid, SWEEP_NT, 0, cnm_stream(stream)>>>(a);

@@ -138,7 +138,8 @@ class _EngineNet(nn.Module):
     def _workspace(self, device, nfloats):
         ws = self._ws.get(str(device))
         if ws is None or ws.numel() < nfloats:
-            self._ws = {str(device): torch.empty(nfloats, device=device, dtype=torch.float32)}
+            # zeros: the head of the workspace is the plane sweep's tile queue (zero on entry, left zero by every call)
+            self._ws = {str(device): torch.zeros(nfloats, device=device, dtype=torch.float32)}
             ws = self._ws[str(device)]
         return ws
 

@@ -63,7 +63,7 @@ def plane_sweep_volume(left, right, left_cam, right_cam, idepth_scale=3.0, plane
     hmkt = homography_terms(left_cam, right_cam.unsqueeze(1))
     vol = torch.empty(B, planes, H, W, device=left.device, dtype=torch.float32)
     lib = _lib.load()
-    ws = torch.empty(lib.cnm_planesweep_workspace_floats(B, 1, H, W), device=left.device, dtype=torch.float32)
+    ws = torch.zeros(lib.cnm_planesweep_workspace_floats(B, 1, H, W), device=left.device, dtype=torch.float32)   # tile queue: zero on entry
     with torch.cuda.device(left.device):
         _lib.check(lib.cnm_planesweep_volume_nchw_f32(_p(left), _p(right), _p(hmkt), _p(vol), _p(ws), ws.numel(),
                                                       B, 1, H, W, planes, lo, hi, _stream()))
@@ -80,7 +80,7 @@ def plane_sweep_cat_c4(ref, src, hmkt, idepth_scale=3.0, planes=64, ws=None, out
     assert x.shape == (B * S, planes // 4 + 1, H, W, 4) and x.is_contiguous()
     lib = _lib.load()
     if ws is None:
-        ws = torch.empty(lib.cnm_planesweep_workspace_floats(B, S, H, W), device=ref.device, dtype=torch.float32)
+        ws = torch.zeros(lib.cnm_planesweep_workspace_floats(B, S, H, W), device=ref.device, dtype=torch.float32)   # tile queue: zero on entry
     with torch.cuda.device(ref.device):
         _lib.check(lib.cnm_planesweep_cat_c4_f32(_p(ref), _p(src), _p(hmkt), _p(x), _p(ws), ws.numel(),
                                                  B, S, H, W, planes, lo, hi, _stream()))

@@ -85,8 +85,12 @@ int cnm_idepth_range_host(double idepth_scale, double* idepth_min, double* idept
  * _c4   : x [B*S][G][H][W][4], G = D/4+1 -- groups 0..D/4-1 = cost planes, last group =
  *         (ref r,g,b,0): the concatenated conv1 input of depthNet_model.py:233 with the
  *         three image channels rotated to the end.  D must be a multiple of 4.
- * ws: 16-byte aligned scratch of cnm_planesweep_workspace_floats(B,S,H,W) floats (the sources
- *     re-laid as zero-bordered RGBA textures by a pre-pass on the same stream). */
+ * ws: 16-byte aligned scratch of cnm_planesweep_workspace_floats(B,S,H,W) floats: the tile queue of the
+ *     persistent sweep (tickets drawn, workgroups gone).  The words must be ZERO when a call starts; the
+ *     call leaves them zero, so a workspace is zeroed once, when it is allocated, and may then be reused by
+ *     any number of calls that are ordered on one stream (two calls in flight at once need two workspaces).
+ *     ws == NULL is allowed: tiles are then dealt to the workgroups with a fixed stride (no scratch, slower
+ *     when tiles differ in cost). */
 size_t cnm_planesweep_workspace_floats(int B, int S, int H, int W);
 int cnm_planesweep_volume_nchw_f32(const float* ref, const float* src, const float* hmkt, float* volume,
                                    float* ws, size_t ws_floats, int B, int S, int H, int W, int D,

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <vector>
+#include <algorithm>
 
 __global__ __launch_bounds__(256) void ref_store_kernel(float* out, int G, int HW, int W) {   // pure output stream, same grid
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), p = blockIdx.z;
@@ -47,7 +48,7 @@ int main(int argc, char** argv) {
         const double T[3] = {tx, 0.01 * geom, -0.01 * geom};
         for (int i = 0; i < 3; ++i) hmkt[p * 12 + 9 + i] = (float)(K[i * 3] * T[0] + K[i * 3 + 1] * T[1] + K[i * 3 + 2] * T[2]);
     }
-    float *dref, *dsrc, *dh, *dout, *dvol, *dws; const size_t wsn = cnm_planesweep_workspace_floats(B, S, H, W); hipMalloc(&dws, wsn * 4 + 16);
+    float *dref, *dsrc, *dh, *dout, *dvol, *dws; const size_t wsn = cnm_planesweep_workspace_floats(B, S, H, W); hipMalloc(&dws, wsn * 4 + 16); hipMemset(dws, 0, wsn * 4 + 16);
     const size_t outn = (size_t)P * (D / 4 + 1) * HW * 4, voln = (size_t)P * D * HW;
     hipMalloc(&dref, ref.size() * 4); hipMalloc(&dsrc, src.size() * 4); hipMalloc(&dh, hmkt.size() * 4); hipMalloc(&dout, outn * 4); hipMalloc(&dvol, voln * 4);
     hipMemcpy(dref, ref.data(), ref.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dsrc, src.data(), src.size() * 4, hipMemcpyHostToDevice);
