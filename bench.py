@@ -7,12 +7,17 @@ A "frame" (BASELINE.json) = 1 reference + 2 source views at 256x192 with 64 dept
 frames per GPU (BASELINE config[1]: "1 ref + 2 src, 256x192, 64 planes, batch=8"), inputs
 resident in HBM.  N GPUs = N independent shards (weak scaling, no data-path collective).
 
-    python bench.py [--gpus N --steps K --warmup W]          # N>1: launched by torch.distributed.run
+    python bench.py [--gpus N --steps K --warmup W]
+        N > 1: either started under torch.distributed.run (one rank per GPU, RANK / WORLD_SIZE in the environment), or
+        plain `python bench.py --gpus N`, which starts the N ranks itself as child processes and relays rank 0's line
 
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline           dominant kernel (fp32-MFMA convolution: Winograd or implicit GEMM): executed TFLOP/s vs 157.3 dense fp32 MFMA
   roofline_planesweep  fused warp + cost-volume kernel: algorithmic GB/s vs 8 TB/s HBM
   cpu_baseline       the oracle's reference-arrangement torch-CPU graph on this box's host cores
+  step_ms            per-step HIP-event times on the launch stream: median, p10, p90 (the headline uses the wall clock)
+  f16 / config4      secondary measurements (BASELINE configs[4] precision at the headline shape; configs[3] 640x480x96,
+                     1 ref + 4 src, batch 4): frames/s, never the headline value
 """
 import argparse
 import json
@@ -203,6 +208,16 @@ def host_cpu_quota():
     return n
 
 
+def cpu_model():
+    try:
+        for l in open("/proc/cpuinfo"):
+            if l.startswith("model name"):
+                return l.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
 def cpu_baseline(budget_s=20.0):
     """The oracle's torch-CPU reference-arrangement graph (bit-identical to the imported reference,
     tests/test_oracle_vs_reference.py) timed on this box's host cores: kind = "port".  Thread count:
@@ -231,15 +246,72 @@ def cpu_baseline(budget_s=20.0):
     dt = sum(one() for _ in range(n)) / n
     return {"value": 1.0 / dt, "unit": "frames/s", "cores": threads, "kind": "port",
             "sample": "%d frames (1 ref + 2 src, 256x192, 64 planes, batch 1) after warm-up; torch %s CPU ops in the "
-                      "reference's arrangement, %d threads (host CPU quota %d of %d logical CPUs)"
-                      % (n, torch.__version__, threads, quota, os.cpu_count())}
+                      "reference's arrangement, %d threads (host CPU quota %d of %d logical CPUs) on %s"
+                      % (n, torch.__version__, threads, quota, os.cpu_count(), cpu_model())}
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes under torch.distributed.run
+    (one per GPU, rendezvous on 127.0.0.1), relay rank 0's JSON line and return the launcher's exit code.  The parent
+    never initialises the GPU and never replaces itself."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    for l in lines[-1:]:
+        print(l, flush=True)
+    if r.returncode == 0 and not lines:
+        print(r.stdout[-2000:], file=sys.stderr)
+        return 1
+    return r.returncode
+
+
+def timed_steps(run, img, cams, steps, sync):
+    """K steps between two barriers: wall clock of the region, and per-step HIP-event times on the launch stream."""
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    sync()
+    t0 = time.perf_counter()
+    out = None
+    for i in range(steps):
+        ev[i].record()
+        out = run(img, cams)
+    ev[steps].record()
+    torch.cuda.synchronize()
+    sync()
+    elapsed = time.perf_counter() - t0
+    per = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(steps))
+    q = lambda f: per[min(len(per) - 1, int(f * len(per)))]
+    return out, elapsed, {"median": q(0.5), "p10": q(0.1), "p90": q(0.9), "n": steps}
+
+
+def secondary(dev, precision, B, S, Hh, Ww, D, steps=10, warmup=3):
+    """A secondary workload through the same pipeline: frames/s (wall clock between synchronisations) and step time."""
+    from cnmnet_amd import synthetic as syn
+    from cnmnet_amd.depthnet import depthNet, DepthRefineNet
+    from cnmnet_amd.pipeline import FramePipeline
+    pipe = FramePipeline(load_weights(depthNet(3.0, D, precision=precision), 1).to(dev),
+                         load_weights(DepthRefineNet(32, 3.0, precision=precision), 2).to(dev), k_size=KSIZE, normals=True)
+    img, cams = syn.frames(B, S, Hh, Ww, seed=4321)
+    img, cams = torch.from_numpy(img).to(dev), torch.from_numpy(cams).to(dev)
+    for _ in range(warmup):
+        pipe(img, cams)
+    out, elapsed, per = timed_steps(pipe, img, cams, steps, torch.cuda.synchronize)
+    assert bool(torch.isfinite(out["disp"]).all())
+    return {"value": B * steps / elapsed, "unit": "frames/s", "ms_per_step": 1e3 * elapsed / steps, "step_ms": per,
+            "workload": "%d frames, 1 ref + %d src, %dx%d, %d planes" % (B, S, Ww, Hh, D)}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-secondary", action="store_true", help="skip the f16 and config-4 secondary measurements")
     ap.add_argument("--frames-per-gpu", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -249,10 +321,10 @@ def main():
                     help="f16 = BASELINE config 5 path (fp16 storage + f16 MFMA; tolerance in tests/test_gpu_fp16.py); not the headline")
     a = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(self_launch(a.gpus))                    # nothing has touched the GPU in this process: children do the work
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
         a.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (the engine has no CPU path)"
     # functional test of the N > 1 path on a one-GPU box: CNM_BENCH_BACKEND=gloo CNM_BENCH_DEVICE=0 puts every rank on GPU 0
@@ -291,22 +363,20 @@ def main():
         run = GraphedFramePipeline(pipe, img, cams)                  # one hipGraph launch per step; inputs stay resident
     for _ in range(a.warmup):
         out = run(img, cams)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        out = run(img, cams)
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    out, rank_elapsed, step_ms = timed_steps(run, img, cams, a.steps, barrier)   # barrier + synchronize on both sides
     assert bool(torch.isfinite(out["disp"]).all()) and bool(torch.isfinite(out["normal"]).all())
     from cnmnet_amd import sharding
-    elapsed = sharding.job_elapsed(elapsed, dist, dev if backend == "nccl" else "cpu")            # max over ranks
+    red_dev = dev if backend == "nccl" else "cpu"
+    elapsed = sharding.job_elapsed(rank_elapsed, dist, red_dev)                                   # max over ranks
+    fastest = -sharding.job_elapsed(-rank_elapsed, dist, red_dev)                                 # min over ranks
 
     line = None
     if rank == 0:
         frames = world * B * a.steps
         line = {"metric": "frames/sec (ref+2src, 256x192, 64 planes)", "value": frames / elapsed, "unit": "frames/s",
                 "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+                "step_ms": step_ms, "per_rank_frames_per_s": {"min": B * a.steps / elapsed, "max": B * a.steps / fastest},
+                "barrier_bracketed_wall_s": elapsed,
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "f32" if a.precision == "f32" else "f16 storage / f32 accumulate", "data": "synthetic",
                 "config": {"workload": "CNMNet eval frame: 2x depthNet + DepthRefineNet + Depth2normal(k=9), 1 ref + 2 src, "
@@ -315,6 +385,15 @@ def main():
                            "launch": "hipGraph replay" if a.graph else "per-kernel, asynchronous"}}
         if not a.no_roofline and a.precision == "f32":
             line["roofline"], line["roofline_planesweep"] = kernel_rooflines(dev, B)
+        if world == 1 and not a.no_secondary and a.precision == "f32":
+            del pipe, run, out
+            torch.cuda.empty_cache()
+            line["f16"] = dict(secondary(dev, "f16", B, SRC, H, W, PLANES), dtype="f16 storage / f32 accumulate",
+                               tolerance="inverse depth within 3e-2 (depthNet) / 6e-2 (refined) of the fp32 engine on a [0,3] range, tests/test_gpu_fp16.py")
+            torch.cuda.empty_cache()
+            line["config4"] = dict(secondary(dev, "f32", 4, 4, 480, 640, 96, steps=5, warmup=2), dtype="f32",
+                                   note="BASELINE configs[3]; plane sweep = 125.3 MB algorithmic per (ref, src) pair")
+            torch.cuda.empty_cache()
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
             line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]

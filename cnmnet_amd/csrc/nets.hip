@@ -328,31 +328,36 @@ static int refinenet_body(const cnm_layer_weights* wt, float idepth_scale, const
         if (hipEventRecord(side->fork, (hipStream_t)s) != hipSuccess || hipStreamWaitEvent(side->stream, side->fork, 0) != hipSuccess) return CNM_ERR_LAUNCH;
     }
 #undef CONV
+    // Between the fork and the join nothing returns early: a failed launch ends the loop, and the side stream is
+    // joined back in every case (kernels already queued on it must be ordered before the caller's stream goes on, and
+    // a stream capture must not be left with an unjoined branch).
 #define CONV(L, in, Gin, out, Cout, HH, WW) \
-    CNM_TRY(E::conv(in, Gin, 0, Gin, out, G(Cout), 0, Cout, wt[L], N, HH, WW, 3, kRefineLayers[L].stride, q))
-    for (int step = 0; step < 7; ++step) {                                             // launches interleaved decoder by decoder
-        for (int br = 0; br < 2; ++br) {                                               // 0: depth (:341-351), 1: prob (:357-365)
+    rc = E::conv(in, Gin, 0, Gin, out, G(Cout), 0, Cout, wt[L], N, HH, WW, 3, kRefineLayers[L].stride, q)
+    int rc = CNM_OK;
+    for (int step = 0; step < 7 && rc == CNM_OK; ++step) {                             // launches interleaved decoder by decoder
+        for (int br = 0; br < 2 && rc == CNM_OK; ++br) {                               // 0: depth (:341-351), 1: prob (:357-365)
             const int L = R_BRANCH0 + 6 * br;
             const DecoderBufs& d = b.d[br];
             void* q = st[br];
             float* feat = (br == 0 && iconv1_depth) ? iconv1_depth : d.I1;
             switch (step) {
                 case 0: CONV(L + 0, b.U3, g512, d.UC3, 256, H2, W2); break;
-                case 1: CNM_TRY(E::conv2(d.UC3, g256, b.C2, g256, d.I3, g256, 256, wt[L + 1], N, H2, W2, q)); break;
-                case 2: CNM_TRY(E::upconv(d.I3, g256, d.U2, d.UC2, g128, 0, 128, wt[L + 2], N, H2, W2, q)); break;
-                case 3: CNM_TRY(E::conv2(d.UC2, g128, b.C1, g128, d.I2, g128, 128, wt[L + 3], N, H1, W1, q)); break;
-                case 4: CNM_TRY(E::upconv(d.I2, g128, d.U1, d.UC1, g64, 0, 64, wt[L + 4], N, H1, W1, q)); break;
+                case 1: rc = E::conv2(d.UC3, g256, b.C2, g256, d.I3, g256, 256, wt[L + 1], N, H2, W2, q); break;
+                case 2: rc = E::upconv(d.I3, g256, d.U2, d.UC2, g128, 0, 128, wt[L + 2], N, H2, W2, q); break;
+                case 3: rc = E::conv2(d.UC2, g128, b.C1, g128, d.I2, g128, 128, wt[L + 3], N, H1, W1, q); break;
+                case 4: rc = E::upconv(d.I2, g128, d.U1, d.UC1, g64, 0, 64, wt[L + 4], N, H1, W1, q); break;
                 case 5: CONV(L + 5, d.UC1, g64, feat, 64, H, W); break;
-                case 6: CNM_TRY(E::head(feat, g64, 64, wt[R_HEAD0 + br], br == 0 ? idepth_scale : 1.0f, br == 0 ? disp_refined : prob_map,
-                                        nullptr, 0, 0, N, H, W, q)); break;
+                case 6: rc = E::head(feat, g64, 64, wt[R_HEAD0 + br], br == 0 ? idepth_scale : 1.0f, br == 0 ? disp_refined : prob_map,
+                                     nullptr, 0, 0, N, H, W, q); break;
             }
         }
     }
     if (side) {
-        if (hipEventRecord(side->join, side->stream) != hipSuccess || hipStreamWaitEvent((hipStream_t)s, side->join, 0) != hipSuccess) return CNM_ERR_LAUNCH;
+        if (hipEventRecord(side->join, side->stream) != hipSuccess || hipStreamWaitEvent((hipStream_t)s, side->join, 0) != hipSuccess)
+            return rc != CNM_OK ? rc : CNM_ERR_LAUNCH;
     }
 #undef CONV
-    return CNM_OK;
+    return rc;
 }
 
 extern "C" int cnm_refinenet_forward_f32(const cnm_layer_weights* wt, float idepth_scale,

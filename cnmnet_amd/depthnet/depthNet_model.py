@@ -248,6 +248,24 @@ class depthNet(_EngineNet):
         d1 = ag.head(i1, self.disp1[0], s)
         return [d1, d2, d3, d4], i1
 
+    def getVolume(self, left_image, right_image, KRKiUV_T, KT_T):
+        """Reference depthNet_model.py:185-224: plane-sweep L1 cost volume [B,planes,H,W] from what
+        process_camera_parameters returns.  KRKiUV_T is either that function's result (the 12 camera terms ride
+        along), a plain [B,3,W*H] grid product in the reference's u-major order (the homography is recovered from
+        it), or the homography itself [B,3,3]."""
+        from .depth_util import homography_from_grid_product
+        self._require_gpu(left_image, right_image, KRKiUV_T, KT_T)
+        B, _, H, W = left_image.shape
+        hmkt = getattr(KRKiUV_T, "hmkt", None)
+        if hmkt is None:
+            if tuple(KRKiUV_T.shape[1:]) == (3, 3) and H * W != 3:
+                hmkt = torch.cat((KRKiUV_T.reshape(B, 9), KT_T.reshape(B, 3)), 1).contiguous()
+            else:
+                if tuple(KRKiUV_T.shape) != (B, 3, H * W):
+                    raise ValueError("KRKiUV_T must be [B,3,H*W] = %s, got %s" % ((B, 3, H * W), tuple(KRKiUV_T.shape)))
+                hmkt = homography_from_grid_product(KRKiUV_T, KT_T, H, W)
+        return ops.plane_sweep_volume_hmkt(left_image, right_image, hmkt.float(), self.idepth_scale, self.planes)
+
     def forward(self, left_image, right_image, left_cam, right_cam):
         disp, feat_c4 = self.forward_pairs(left_image, right_image.unsqueeze(1), left_cam, right_cam.unsqueeze(1))
         if self.precision == "f16":

@@ -5,19 +5,39 @@ import torch.nn as nn
 from .. import ops
 
 
-def get_pixel_coordinates(height, width):
-    """Reference depth_util.py:13-21 builds a [3, W*H] host grid and uploads it on every
-    forward.  The engine derives (u, v, 1) from the thread index, so nothing is needed here;
-    kept (returning the image size) so call sites written against the reference still read."""
-    return (height, width)
+def get_pixel_coordinates(height, width, device=None):
+    """Reference depth_util.py:13-21: homogeneous pixel grid [3, W*H] in u-major order (p = u*H + v), on the GPU.
+    The engine itself never needs it (the grid is implicit in the thread index); it exists so that the reference's
+    own call sequence get_pixel_coordinates -> process_camera_parameters -> getVolume (depthNet_model.py:226-233)
+    runs unchanged."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    u = torch.arange(width, device=device, dtype=torch.float32).repeat_interleave(height)
+    v = torch.arange(height, device=device, dtype=torch.float32).repeat(width)
+    return torch.stack((u, v, torch.ones_like(u)), 0)
 
 
-def process_camera_parameters(left_cam, right_cam, pixel_coordinates=None):
-    """Reference depth_util.py:24-56 returns (KRKiUV [B,3,H*W], KT [B,3,1]).  The engine's
-    equivalent is 12 floats per pair: returns (Hm [B,3,3], KT [B,3,1]) with
-    KRKiUV = Hm @ (u,v,1) left implicit."""
+def process_camera_parameters(left_cam, right_cam, pixel_coordinates):
+    """Reference depth_util.py:24-56: (KRKiUV [B,3,H*W], KT [B,3,1]).  Hm = K_r R K_l^-1 and KT = K_r T come from the
+    engine's camera kernel (fp64 inside, 12 floats per pair); KRKiUV = Hm @ pixel_coordinates is materialised only
+    because the reference's signature returns it."""
     hmkt = ops.homography_terms(left_cam, right_cam.unsqueeze(1))
-    return hmkt[:, :9].reshape(-1, 3, 3), hmkt[:, 9:].reshape(-1, 3, 1)
+    Hm, KT = hmkt[:, :9].reshape(-1, 3, 3), hmkt[:, 9:].reshape(-1, 3, 1).contiguous()
+    KRKiUV = torch.matmul(Hm, pixel_coordinates)
+    KRKiUV.hmkt = hmkt          # the 12 terms ride along (a derived tensor does not inherit them): getVolume uses them as they are
+    return KRKiUV, KT
+
+
+def homography_from_grid_product(KRKiUV, KT, height, width):
+    """Recover the 12 camera terms from a plain KRKiUV tensor [B,3,W*H] (u-major): column p is Hm (u,v,1)^T, so
+    Hm[:,2] = column (0,0) and the other two columns are finite differences across the whole image (far-apart
+    columns keep the fp32 rounding of the product below 1e-7 relative per coefficient)."""
+    c00 = KRKiUV[:, :, 0]
+    cu = KRKiUV[:, :, (width - 1) * height] if width > 1 else c00
+    cv = KRKiUV[:, :, height - 1] if height > 1 else c00
+    h0 = (cu - c00) / max(width - 1, 1)
+    h1 = (cv - c00) / max(height - 1, 1)
+    Hm = torch.stack((h0, h1, c00), 2)                                   # columns of Hm
+    return torch.cat((Hm.reshape(-1, 9), KT.reshape(-1, 3)), 1).contiguous()
 
 
 class Depth2normal(nn.Module):

@@ -24,16 +24,21 @@ INTRINSICS = np.array([[585.0, 0, 320], [0, 585.0, 240], [0, 0, 1]])    # 640x48
 IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
 MIN_DEPTH, MAX_DEPTH = 0.3, 8.0                                          # eval.py:1009-1010, utils/metric.py:149
 
-# source-view offsets (in frames) and the reference-frame index range per number of views
+# source-view offsets (in frames), and the reference-frame subsampling per number of views
 _OFFSETS = {2: (10,), 3: (10, -10), 5: (10, -10, 5, -5), 7: (10, -10, 5, -5, 20, -20)}
+_STRIDE = {2: 10, 3: 3, 5: 3, 7: 9}                                      # eval.py:240, :409, :582, :818 (`if index % k != 0: continue`)
 
 
 def sample_indices(num_frames, views):
-    """[(ref, [sources...])] exactly as the reference enumerates them: eval.py:239 (2 views: range(0, n-10)),
-    :408 (3 views: range(10, n-10)), :581 / :817 (5 and 7 views: range(10, n-20))."""
-    off = _OFFSETS[views]
+    """[(ref, [sources...])] exactly as the reference enumerates AND subsamples them: eval.py:239-240 (2 views:
+    range(0, n-10), every 10th frame), :408-409 (3 views: range(10, n-10), every 3rd), :581-582 (5 views:
+    range(10, n-20), every 3rd), :817-818 (7 views: range(10, n-20), every 9th).
+    With 7 views the reference's first sample is frame 18, whose -20 source is index -2: Python wraps it to the
+    second-to-last frame of the sequence, and so does this list (kept for parity of the evaluated sample set; such
+    a pair has no overlap and simply contributes an uninformative source)."""
+    off, k = _OFFSETS[views], _STRIDE[views]
     lo, hi = (0, num_frames - 10) if views == 2 else (10, num_frames - 10) if views == 3 else (10, num_frames - 20)
-    return [(i, [i + o for o in off]) for i in range(lo, hi)]
+    return [(i, [i + o for o in off]) for i in range(lo, hi) if i % k == 0]
 
 
 def sequence_files(seq_dir):

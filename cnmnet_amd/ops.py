@@ -57,10 +57,15 @@ def plane_sweep_volume(left, right, left_cam, right_cam, idepth_scale=3.0, plane
     """Drop-in for depthNet.getVolume fed by process_camera_parameters
     (depthNet_model.py:185-224): left/right [B,3,H,W], cams [B,2,4,4] -> [B,planes,H,W]."""
     _dev(left, right, left_cam, right_cam)
+    return plane_sweep_volume_hmkt(left, right, homography_terms(left_cam, right_cam.unsqueeze(1)), idepth_scale, planes)
+
+
+def plane_sweep_volume_hmkt(left, right, hmkt, idepth_scale=3.0, planes=64):
+    """getVolume from the 12 camera terms per pair: left/right [B,3,H,W], hmkt [B,12] -> [B,planes,H,W]."""
+    _dev(left, right, hmkt)
     lo, hi = idepth_range(idepth_scale)
-    left, right = _c(left), _c(right)
+    left, right, hmkt = _c(left), _c(right), _c(hmkt)
     B, _, H, W = left.shape
-    hmkt = homography_terms(left_cam, right_cam.unsqueeze(1))
     vol = torch.empty(B, planes, H, W, device=left.device, dtype=torch.float32)
     lib = _lib.load()
     ws = torch.zeros(lib.cnm_planesweep_workspace_floats(B, 1, H, W), device=left.device, dtype=torch.float32)   # tile queue: zero on entry

@@ -20,7 +20,13 @@ from .depthnet.losses import IdepthLoss_234, _valid
 
 
 class BucketedGradAllReduce:
-    """Average gradients across ranks with bucketed, backward-overlapped all-reduces."""
+    """Average gradients across ranks with bucketed, backward-overlapped all-reduces.
+
+    A parameter that receives no gradient in a step (e.g. the whole probability decoder during the warm-up epochs of
+    `train_wo_normal`, reference train.py:555-559) contributes zeros to its bucket -- every rank builds the same
+    graph, so the unused set is the same everywhere and the collective shapes match -- and its `.grad` is left
+    exactly as it was (None stays None): the optimizer then skips it as it does on one device and under the
+    reference's DataParallel, instead of decaying it towards zero."""
 
     def __init__(self, params, dist, bucket_bytes=25 * 2**20):
         self.dist, self.world = dist, dist.get_world_size()
@@ -35,38 +41,48 @@ class BucketedGradAllReduce:
         self.bucket_of = {id(p): i for i, b in enumerate(self.buckets) for p in b}
         self.flat = [torch.zeros(sum(p.numel() for p in b), device=b[0].device, dtype=torch.float32) for b in self.buckets]
         self.pending, self.work = [len(b) for b in self.buckets], [None] * len(self.buckets)
+        self.fired = set()                                 # ids of the parameters whose gradient arrived this step
+        self.hook_launches = self.late_launches = 0        # buckets launched from backward hooks / from finish(), last step
+        self._hook_count = 0
         self.handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
 
     def _hook(self, p):
         i = self.bucket_of[id(p)]
+        self.fired.add(id(p))
         self.pending[i] -= 1
         if self.pending[i] == 0:
+            self._hook_count += 1
             self._launch(i)
 
     def _launch(self, i):
         off = 0
         for p in self.buckets[i]:
             n = p.numel()
-            self.flat[i][off:off + n].copy_((p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1))
+            if id(p) in self.fired:
+                self.flat[i][off:off + n].copy_(p.grad.reshape(-1))
+            else:
+                self.flat[i][off:off + n].zero_()
             off += n
         self.work[i] = self.dist.all_reduce(self.flat[i], op=self.dist.ReduceOp.SUM, async_op=True)
 
     def finish(self):
         """Call after backward(): waits for all buckets and writes the averaged gradients back."""
+        late = 0
         for i, b in enumerate(self.buckets):
-            if self.work[i] is None:                       # parameters that received no gradient this step
+            if self.work[i] is None:                       # a bucket holding parameters without a gradient this step
+                late += 1
                 self._launch(i)
+        for i, b in enumerate(self.buckets):
             self.work[i].wait()
             off = 0
             for p in b:
                 n = p.numel()
-                g = self.flat[i][off:off + n].view_as(p) / self.world
-                if p.grad is None:
-                    p.grad = g.clone()
-                else:
-                    p.grad.copy_(g)
+                if id(p) in self.fired:
+                    p.grad.copy_(self.flat[i][off:off + n].view_as(p) / self.world)
                 off += n
             self.work[i], self.pending[i] = None, len(b)
+        self.hook_launches, self.late_launches, self._hook_count = self._hook_count, late, 0
+        self.fired.clear()
 
     def remove(self):
         for h in self.handles:
@@ -102,6 +118,17 @@ class TrainStepWoNormal:
     def __call__(self, rgbs, cameras, disparities, depths, warmup_epoch=False):
         """rgbs [B,3,3,H,W] (ref, src1, src2), cameras [B,3,2,4,4], disparities / depths [B,V,1,H,W]
         (ground truth of the reference view at index 0).  Returns a dict of detached scalars."""
+        loss, logs = self.losses(rgbs, cameras, disparities, depths, warmup_epoch)
+        self.optimizer.zero_grad(set_to_none=False)                                          # :562-565
+        loss.backward()
+        if self.reducer is not None:
+            self.reducer.finish()
+        self.optimizer.step()
+        return {k: float(v.detach()) for k, v in logs.items()}
+
+    def losses(self, rgbs, cameras, disparities, depths, warmup_epoch=False):
+        """Train-mode forward of both nets on one batch (shard) and the loss mix of train.py:522-559:
+        (loss to back-propagate, dict of logged terms)."""
         self.depth_net.train(); self.refine_net.train()
         gt_id, gt_d = disparities[:, 0], depths[:, 0]
         p01, f01 = self.depth_net(rgbs[:, 0], rgbs[:, 1], cameras[:, 0], cameras[:, 1])     # :509-512
@@ -121,14 +148,8 @@ class TrainStepWoNormal:
             loss = loss_idepth_1 + loss_idepth_234 + loss_idepth_refined
         else:
             loss = loss_depth_1 + loss_depth_refined + (loss_idepth_1 + loss_idepth_234 + loss_idepth_refined) + prob_loss
-        self.optimizer.zero_grad(set_to_none=False)                                          # :562-565
-        loss.backward()
-        if self.reducer is not None:
-            self.reducer.finish()
-        self.optimizer.step()
-        return {"loss": float(loss.detach()), "loss_idepth": float(loss_idepth_1.detach()),
-                "loss_idepth_refined": float(loss_idepth_refined.detach()), "loss_depth_refined": float(loss_depth_refined.detach()),
-                "prob_loss": float(prob_loss.detach())}
+        return loss, {"loss": loss, "loss_idepth": loss_idepth_1, "loss_idepth_refined": loss_idepth_refined,
+                      "loss_depth_refined": loss_depth_refined, "prob_loss": prob_loss}
 
 
 def synthetic_training_sample(B, H, W, seed=0, device="cpu"):

@@ -11,15 +11,31 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_two_rank_bench_line():
-    env = dict(os.environ, CNM_BENCH_BACKEND="gloo", CNM_BENCH_DEVICE="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-roofline"]
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
+def _check_line(r):
+    assert r.returncode == 0, (r.stderr or "")[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]                              # rank 0 prints the one line
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["unit"] == "frames/s"
     assert abs(d["value"] - 2 * 8 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]     # all ranks' frames / slowest rank's time
-    assert "cpu_baseline" not in d                                         # N = 1 only
+    assert "cpu_baseline" not in d and "f16" not in d                      # N = 1 only
+    assert d["step_ms"]["n"] == 3 and d["step_ms"]["p10"] <= d["step_ms"]["median"] <= d["step_ms"]["p90"]
+    assert d["per_rank_frames_per_s"]["min"] <= d["per_rank_frames_per_s"]["max"]
+    assert abs(d["barrier_bracketed_wall_s"] - d["ms_per_step"] * 3e-3) < 1e-9
+
+
+def test_two_rank_bench_line():
+    """Started the way the driver starts N > 1: under torch.distributed.run."""
+    env = dict(os.environ, CNM_BENCH_BACKEND="gloo", CNM_BENCH_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-roofline"]
+    _check_line(subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600))
+
+
+def test_two_rank_bench_self_launch():
+    """Started the way the driver starts N = 1: plain `python bench.py --gpus 2` spawns its own ranks."""
+    env = dict(os.environ, CNM_BENCH_BACKEND="gloo", CNM_BENCH_DEVICE="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-roofline"]
+    _check_line(subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600))

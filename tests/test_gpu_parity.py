@@ -64,6 +64,40 @@ def test_planesweep_golden(dev, ops, golden):
     assert mx < 1e-3, (med, q, mx)
 
 
+def test_reference_call_sequence_getvolume(dev, golden):
+    """The reference's own forward prologue (depthNet_model.py:226-233): get_pixel_coordinates ->
+    process_camera_parameters -> getVolume, with the mirror's names, reproduces the reference's volume; also from a plain
+    KRKiUV tensor (homography recovered from the grid product) and from the homography itself."""
+    from cnmnet_amd.depthnet import depthNet, process_camera_parameters, get_pixel_coordinates
+    g = golden("planesweep_32x64.npz")
+    left, right = T(g["left"]).to(dev), T(g["right"]).to(dev)
+    lc, rc = T(g["left_cam"]).to(dev), T(g["right_cam"]).to(dev)
+    b, c, height, width = left.shape
+    pix = get_pixel_coordinates(height, width)
+    assert tuple(pix.shape) == (3, width * height) and pix.is_cuda
+    want_pix = np.concatenate((np.indices([width, height]).astype(np.float32), np.ones([1, width, height], np.float32)), 0).reshape(3, -1)
+    np.testing.assert_array_equal(pix.cpu().numpy(), want_pix)             # depth_util.py:15-18, u-major
+    KRKiUV, KT = process_camera_parameters(lc, rc, pix)
+    assert tuple(KRKiUV.shape) == (b, 3, height * width) and tuple(KT.shape) == (b, 3, 1)
+    Hm64, KT64 = cf.homography_terms(g["left_cam"], g["right_cam"])        # float64 closed form (pinned to the reference's golden)
+    np.testing.assert_allclose(KRKiUV.cpu().numpy(), Hm64 @ want_pix.astype(np.float64), rtol=2e-5, atol=2e-3)
+    np.testing.assert_allclose(KT.cpu().numpy()[:, :, 0], KT64, rtol=2e-6, atol=1e-5)
+    net = depthNet(3.0).to(dev).eval()
+    vols = [net.getVolume(left, right, KRKiUV, KT),                          # terms ride along
+            net.getVolume(left, right, KRKiUV.clone(), KT.clone()),          # plain tensors: homography recovered
+            net.getVolume(left, right, KRKiUV.hmkt[:, :9].reshape(b, 3, 3), KT)]
+    for i, v in enumerate(vols):
+        v = v.cpu().numpy()
+        assert v.shape == g["volume"].shape
+        med, q, mx = _stats(v[0], g["volume"][0])                            # benign pair
+        assert mx < 1e-3, (i, med, q, mx)
+        med, q, mx = _stats(v, g["volume"])
+        assert med < 2e-5 and q < (2e-3 if i != 1 else 2e-2), (i, med, q, mx)
+    assert torch.equal(vols[0], vols[2])
+    with pytest.raises(ValueError):
+        net.getVolume(left, right, KRKiUV[:, :, :7].clone(), KT)
+
+
 def test_planesweep_scale2(dev, ops, golden):
     g, g2 = golden("planesweep_32x64.npz"), golden("planesweep_scale2_32x64.npz")
     vol = ops.plane_sweep_volume(T(g["left"][:1]).to(dev), T(g["right"][:1]).to(dev), T(g["left_cam"][:1]).to(dev),
@@ -564,6 +598,54 @@ def test_refine_side_stream_is_invisible(dev):
     gd.zero_(); gp.zero_()
     g.replay(); torch.cuda.synchronize()
     assert torch.equal(gd, on[0]) and torch.equal(gp, on[1])
+
+
+def test_refine_operator_error_joins_side_stream(dev):
+    """An operator error between the fork and the join of DepthRefineNet's two decoders (nets.hip refinenet_body):
+    the status comes back, the side stream is joined all the same -- a stream capture around the failing call ends
+    cleanly instead of being left with an unjoined branch -- and the next good call is unaffected."""
+    import ctypes
+    from cnmnet_amd import _lib
+    from cnmnet_amd.depthnet import DepthRefineNet
+    lib = _lib.load()
+    rng = np.random.default_rng(9)
+    N, H, W = 2, 32, 48
+    i1 = T(rng.uniform(0.2, 2.5, (N, 1, H, W)).astype(np.float32)).to(dev)
+    i2 = T(rng.uniform(0.2, 2.5, (N, 1, H, W)).astype(np.float32)).to(dev)
+    f1 = T(rng.standard_normal((N, 64, H, W)).astype(np.float32)).to(dev)
+    f2 = T(rng.standard_normal((N, 64, H, W)).astype(np.float32)).to(dev)
+    net = _load(DepthRefineNet(32, 3.0), 6).to(dev)
+    with torch.no_grad():
+        good = [t.clone() for t in net(i1, i2, f1, f2)]
+    n = len(net._weights_arr)
+    broken = (_lib.LayerWeights * n)()
+    ctypes.memmove(broken, net._weights_arr, ctypes.sizeof(broken))
+    broken[n - 1].u = broken[n - 1].w                                     # passes the entry check (some filter is present) ...
+    broken[n - 1].w = None                                                # ... but the head of the prob decoder, the LAST launch, has none
+    from cnmnet_amd import ops
+    x1, x2 = ops.nchw_to_c4(f1), ops.nchw_to_c4(f2)
+    disp, prob = torch.empty(N, 1, H, W, device=dev), torch.empty(N, 1, H, W, device=dev)
+    ws = net._workspace(dev, lib.cnm_refinenet_workspace_floats(N, H, W))
+
+    def call(weights):
+        return lib.cnm_refinenet_forward_f32(weights, 3.0, i1.data_ptr(), i2.data_ptr(), H * W, x1.data_ptr(), 16, 0, x2.data_ptr(), 16, 0,
+                                             disp.data_ptr(), prob.data_ptr(), 0, ws.data_ptr(), ws.numel(), N, H, W,
+                                             torch.cuda.current_stream().cuda_stream)
+    assert call(net._weights_arr) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(disp, good[0]) and torch.equal(prob, good[1])
+    assert call(broken) < 0                                               # eager: error status, nothing hangs
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(device=dev)                                  # captured: the capture must still end cleanly
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        rc = call(broken)
+    assert rc < 0
+    g.replay(); torch.cuda.synchronize()
+    assert call(net._weights_arr) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(disp, good[0]) and torch.equal(prob, good[1])
 
 
 @pytest.mark.parametrize("planes,S", [(32, 1), (96, 2)])

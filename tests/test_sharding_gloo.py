@@ -101,3 +101,46 @@ def test_bucketed_grad_allreduce_two_ranks_gloo():
         want = g if want is None else [u + v for u, v in zip(want, g)]
     for a, w in zip(res[0][2], want):
         assert torch.allclose(a, w / 2, atol=1e-6)
+
+
+def _unused_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cnmnet_amd.trainer import BucketedGradAllReduce
+        torch.manual_seed(0)
+        used = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 1))
+        idle = torch.nn.Linear(8, 3)                                                # a branch the loss does not touch
+        params = list(idle.parameters()) + list(used.parameters())
+        opt = torch.optim.Adam(params, lr=1e-2, weight_decay=1e-1)
+        red = BucketedGradAllReduce(params, dist, bucket_bytes=64)
+        before = [p.detach().clone() for p in idle.parameters()]
+        x = torch.arange(16, dtype=torch.float32).view(2, 8) * (rank + 1) / 10
+        for _ in range(3):
+            opt.zero_grad(set_to_none=False)
+            used(x).sum().backward()
+            red.finish()
+            opt.step()
+        ok = all(p.grad is None for p in idle.parameters()) and all(torch.equal(a, p.detach()) for a, p in zip(before, idle.parameters()))
+        ok = ok and all((p not in opt.state or len(opt.state[p]) == 0) for p in idle.parameters())
+        out.put((rank, ok, red.late_launches, [p.detach().numpy().tolist() for p in used.parameters()]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_reducer_leaves_unused_parameters_alone_gloo():
+    """Parameters without a gradient (the probability decoder during warm-up epochs) keep grad None on every rank:
+    Adam with weight decay must not touch them (it would decay them towards zero), exactly as on one device."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_unused_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get() for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][1] and res[1][1]
+    assert res[0][2] >= 1                                                           # the idle bucket left from finish(), not from a hook
+    assert res[0][3] == res[1][3]                                                   # the used branch stays in lock step
