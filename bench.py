@@ -389,7 +389,7 @@ def main():
             del pipe, run, out
             torch.cuda.empty_cache()
             line["f16"] = dict(secondary(dev, "f16", B, SRC, H, W, PLANES), dtype="f16 storage / f32 accumulate",
-                               tolerance="inverse depth within 3e-2 (depthNet) / 6e-2 (refined) of the fp32 engine on a [0,3] range, tests/test_gpu_fp16.py")
+                               tolerance="vs the fp32 engine at this size: inverse depth within 2e-2 (depthNet) / 5e-2 (refined) max, 1e-3 mean, on a [0,3] range; probability within 5e-2 max (tests/test_gpu_baseline_sizes.py)")
             torch.cuda.empty_cache()
             line["config4"] = dict(secondary(dev, "f32", 4, 4, 480, 640, 96, steps=5, warmup=2), dtype="f32",
                                    note="BASELINE configs[3]; plane sweep = 125.3 MB algorithmic per (ref, src) pair")

@@ -186,6 +186,8 @@ class depthNet(_EngineNet):
         _init_like_reference(self)
         self._engine_init(precision)
 
+    max_call_bytes = 3.9e9      # the convolution kernels address an activation tensor with 32-bit byte offsets
+
     def forward_pairs(self, ref, src, ref_cam, src_cam):
         """ref [B,3,H,W], src [B,S,3,H,W], ref_cam [B,2,4,4], src_cam [B,S,2,4,4]
         -> ([disp1..4] each [B*S,1,h,w], iconv1 as c4 [B*S,16,H,W,4]); pair p = b*S + s.
@@ -202,7 +204,7 @@ class depthNet(_EngineNet):
             return self._forward_train(ref, src, ref_cam, src_cam)
         # the conv kernels address activations with 32-bit byte offsets (< 4 GB per tensor); the widest one holds
         # 128 channels at full resolution = 512 B (fp32) per pixel and pair -> split very large batches by frames
-        max_pairs = int(3.9e9 // ((512 if self.precision == "f32" else 256) * H * W))
+        max_pairs = int(self.max_call_bytes // ((512 if self.precision == "f32" else 256) * H * W))
         if B * S > max_pairs and B > 1:
             nb = max(1, max_pairs // S)
             parts = [self.forward_pairs(ref[i:i + nb], src[i:i + nb], ref_cam[i:i + nb], src_cam[i:i + nb]) for i in range(0, B, nb)]

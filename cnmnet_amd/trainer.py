@@ -177,13 +177,14 @@ def synthetic_training_sample(B, H, W, seed=0, device="cpu"):
     return {"rgbs": t(img), "cameras": t(cams), "depths": d, "disparities": i, "normals": n}
 
 
-def get_warped_depth_loss(depth_refined, gt_depth_src, pose, intrinsic, intrinsic_inv):
+def get_warped_depth_loss(depth_refined, gt_depth_src, pose, intrinsic, intrinsic_inv, inverse_warp=None):
     """Stand-in for the reference's MISSING `fusion_depth.fuse_depth.get_warped_depth_loss`
     (imported at train.py:34, called at :287-293; not in the repository -- parity unpinned).
     Definition chosen here: sample the source view's ground-truth depth at the
     re-projection of the refined reference depth (`inverse_warp`, gradient w.r.t. the refined depth through the
     sampling position) and take the masked L1 against the refined depth."""
-    from .depthnet.inverse_warp import inverse_warp
+    if inverse_warp is None:
+        from .depthnet.inverse_warp import inverse_warp
     warped = inverse_warp(gt_depth_src.unsqueeze(1), depth_refined, pose, intrinsic, intrinsic_inv).squeeze(1)
     m = (warped > 0) & torch.isfinite(warped) & torch.isfinite(depth_refined) & (depth_refined > 0)
     if not bool(m.any()):
@@ -198,14 +199,30 @@ class TrainStep(TrainStepWoNormal):
     Not restated: the plane-instance inputs the shipped loaders never produce (train.py:147-162) --
     i.e. the `use_normal_refined_by_planes=False` branch (:226-241) is the one built."""
 
-    def __init__(self, depth_net, refine_net, k_size=9, **kw):
+    def __init__(self, depth_net, refine_net, k_size=9, depth2normal=None, inverse_warp=None, intrinsics_inverse=None, **kw):
+        """The three geometry operators default to the engine's (HIP kernels with their backward passes); a test can
+        hand in CPU restatements to evaluate the same loss on the oracle's nets."""
         super().__init__(depth_net, refine_net, **kw)
-        from .depthnet.depth_util import Depth2normal
-        self.depth2normal = Depth2normal(k_size)
+        if depth2normal is None:
+            from .depthnet.depth_util import Depth2normal
+            depth2normal = Depth2normal(k_size)
+        if intrinsics_inverse is None:
+            from . import ops
+            intrinsics_inverse = ops.intrinsics_inverse
+        self.depth2normal, self.inverse_warp, self.intrinsics_inverse = depth2normal, inverse_warp, intrinsics_inverse
 
     def __call__(self, rgbs, cameras, disparities, depths, normals):
+        loss, logs = self.losses(rgbs, cameras, disparities, depths, normals)
+        self.optimizer.zero_grad(set_to_none=False)                                          # :307-310
+        loss.backward()
+        if self.reducer is not None:
+            self.reducer.finish()
+        self.optimizer.step()
+        return {k: float(v.detach()) for k, v in logs.items()}
+
+    def losses(self, rgbs, cameras, disparities, depths, normals):
+        """Train-mode forward and the loss mix of train.py:164-304: (loss to back-propagate, dict of logged terms)."""
         from .depthnet.losses import surface_normal_loss
-        from . import ops
         self.depth_net.train(); self.refine_net.train()
         B = rgbs.shape[0]
         gt_id, gt_d, gt_n = disparities[:, 0], depths[:, 0], normals[:, 0]
@@ -219,7 +236,7 @@ class TrainStep(TrainStepWoNormal):
         d01, d02 = 1.0 / p01[0].squeeze(1), 1.0 / p02[0].squeeze(1)                          # :185-186
         dr = 1.0 / (idr.squeeze(1) + 1e-5)                                                   # :188
         prob_loss = 5 * (L(idr, gt_id, prob) + L(dr.unsqueeze(1), gt_d, prob)) + (1 - prob.mean())   # :193-199
-        k_inv = ops.intrinsics_inverse(cameras[:, 0])                                        # :201-202
+        k_inv = self.intrinsics_inverse(cameras[:, 0])                                       # :201-202
         n01, _ = self.depth2normal(d01, k_inv)                                               # :204-207
         n02, _ = self.depth2normal(d02, k_inv)
         nr, _ = self.depth2normal(dr, k_inv)
@@ -240,14 +257,9 @@ class TrainStep(TrainStepWoNormal):
         ref_inv = torch.linalg.inv(cameras[:, 0, 0])
         for v in (1, 2):                                                                     # :284-293, :304
             pose = (cameras[:, v, 0] @ ref_inv)[:, :3, :].contiguous()
-            loss = loss + get_warped_depth_loss(dr, depths[:, v, 0], pose, K, k_inv)
-        self.optimizer.zero_grad(set_to_none=False)                                          # :307-310
-        loss.backward()
-        if self.reducer is not None:
-            self.reducer.finish()
-        self.optimizer.step()
-        return {"loss": float(loss.detach()), "loss_normal": float(ln.detach()), "loss_normal_refined": float(lnr.detach()),
-                "loss_depth_refined": float(loss_depth_refined.detach()), "prob_loss": float(prob_loss.detach())}
+            loss = loss + get_warped_depth_loss(dr, depths[:, v, 0], pose, K, k_inv, self.inverse_warp)
+        return loss, {"loss": loss, "loss_normal": ln, "loss_normal_refined": lnr, "loss_depth_refined": loss_depth_refined,
+                      "prob_loss": prob_loss}
 
 
 # ------------------------------------------------------------------ epoch loop and checkpoints (train.py:59-140, :395-410)

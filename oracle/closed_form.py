@@ -41,15 +41,18 @@ def bilinear_zero(img, ix, iy):
     return out
 
 
-def plane_sweep_volume(left, right, left_cam, right_cam, idepth_scale=3.0, planes=64):
+def plane_sweep_volume(left, right, left_cam, right_cam, idepth_scale=3.0, planes=64, window=None):
     """cost [B,D,H,W]; ix = u' - 0.5, iy = v' - 0.5 (SURVEY appendix A.2,
-    depthNet_model.py:204-223)."""
+    depthNet_model.py:204-223).  window = (y0, y1, x0, x1) evaluates only that crop of the reference
+    pixels (cost [B,D,y1-y0,x1-x0]) -- for spot checks at sizes where the whole volume takes minutes."""
     left, right = np.asarray(left, np.float64), np.asarray(right, np.float64)
     B, _, H, W = left.shape
     Hm, KT = homography_terms(left_cam, right_cam)
     lo, hi = IDEPTH_RANGE[float(idepth_scale)]
-    ys, xs = np.mgrid[0:H, 0:W].astype(np.float64)
-    vol = np.empty((B, planes, H, W))
+    y0, y1, x0, x1 = (0, H, 0, W) if window is None else window
+    ys, xs = np.mgrid[y0:y1, x0:x1].astype(np.float64)
+    left = left[:, :, y0:y1, x0:x1]
+    vol = np.empty((B, planes, y1 - y0, x1 - x0))
     for b in range(B):
         a = [Hm[b, i, 0] * xs + Hm[b, i, 1] * ys + Hm[b, i, 2] for i in range(3)]
         for d in range(planes):
