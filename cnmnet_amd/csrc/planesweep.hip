@@ -190,9 +190,9 @@ __device__ unsigned int sweep_stats[4];     // debug builds only: workgroups, st
 
 struct SweepCoord { unsigned xi, yi; float wu, wv; };
 
+template <bool CLAMP>
 __device__ __forceinline__ SweepCoord sweep_split(float iu, float iv, float umax, float vmax) {
-    iu = __builtin_amdgcn_fmed3f(iu, 0.f, umax);
-    iv = __builtin_amdgcn_fmed3f(iv, 0.f, vmax);
+    if (CLAMP) { iu = __builtin_amdgcn_fmed3f(iu, 0.f, umax); iv = __builtin_amdgcn_fmed3f(iv, 0.f, vmax); }
     SweepCoord c;
     c.xi = (unsigned)iu; c.yi = (unsigned)iv;                                // floor (coordinates are >= 0 here)
     c.wu = __builtin_amdgcn_fractf(iu); c.wv = __builtin_amdgcn_fractf(iv);
@@ -206,24 +206,28 @@ __device__ __forceinline__ SweepCoord sweep_coords(float cu, float cv, float uma
     const float den = fmaf(a2, z, k2e);
     float r = __builtin_amdgcn_rcpf(den);
     r = fmaf(fmaf(-den, r, 1.0f), r, r);                                     // one Newton step: ~0.5 ulp reciprocal
-    return sweep_split(fmaf(fmaf(a0, z, k0), r, cu), fmaf(fmaf(a1, z, k1), r, cv), umax, vmax);
+    return sweep_split<true>(fmaf(fmaf(a0, z, k0), r, cu), fmaf(fmaf(a1, z, k1), r, cv), umax, vmax);
 }
 
 // Parallax form of the same map: u' = a0/a2 + (k0 - (a0/a2) k2e) / (a2 z + k2e) = U + A r.  U (the image of the point
 // at infinity) and A are per-pixel constants, so a plane costs one reciprocal and two FMAs, and the reciprocal's
 // rounding is scaled by the parallax |A r| instead of the coordinate |u'|: the plain v_rcp_f32 (1 ulp) is enough.
+// CLAMP = false for boxes that were not clipped by the image: every sample of a valid pixel then lies inside the box
+// (margins included) and the two v_med3_f32 are saved; a lane of a ragged tile outside the image may then compute
+// any address - LDS reads beyond the allocation return 0 and its result is never stored.
+template <bool CLAMP>
 __device__ __forceinline__ SweepCoord sweep_coords_parallax(float ug, float vg, float umax, float vmax, float pa, float pb,
                                                             float a2, float k2e, float z) {
     const float r = __builtin_amdgcn_rcpf(fmaf(a2, z, k2e));
-    return sweep_split(fmaf(pa, r, ug), fmaf(pb, r, vg), umax, vmax);
+    return sweep_split<CLAMP>(fmaf(pa, r, ug), fmaf(pb, r, vg), umax, vmax);
 }
 
 __device__ __forceinline__ float sweep_blend(const float4 u0, const float4 u1, const float4 u2, float wu, float wv,
                                              float rr, float rg, float rb) {
-    const float wuv = wu * wv;
-    const float er = fmaf(wuv, u2.y, fmaf(wv, u1.z, fmaf(wu, u0.w, u0.x))) - rr;
-    const float eg = fmaf(wuv, u2.z, fmaf(wv, u1.w, fmaf(wu, u1.x, u0.y))) - rg;
-    const float eb = fmaf(wuv, u2.w, fmaf(wv, u2.x, fmaf(wu, u1.y, u0.z))) - rb;
+    // P + wu dx + wv (dy + wu dxy): three FMAs per channel
+    const float er = fmaf(wv, fmaf(wu, u2.y, u1.z), fmaf(wu, u0.w, u0.x)) - rr;
+    const float eg = fmaf(wv, fmaf(wu, u2.z, u1.w), fmaf(wu, u1.x, u0.y)) - rg;
+    const float eb = fmaf(wv, fmaf(wu, u2.w, u2.x), fmaf(wu, u1.y, u0.z)) - rb;
     return (__builtin_fabsf(er) + __builtin_fabsf(eg)) + __builtin_fabsf(eb);   // :222-223
 }
 
@@ -232,6 +236,36 @@ __device__ __forceinline__ float sweep_blend(const float4 u0, const float4 u1, c
 // are zero between launches - the last workgroup to leave resets them).  Per tile: footprints (wave 0) ->
 // [stage box -> sweep its planes]*.  The ticket, the camera terms and the reference pixel of the NEXT tile are
 // fetched while the current one is swept.
+// Eight planes of one pixel from a staged box: the texel reads of a sample are issued SWEEP_AHEAD samples before the
+// blend that consumes them (counted lgkmcnt waits, one scheduling region per sample).
+template <bool CLAMP>
+__device__ __forceinline__ void sweep_octet(const float4* __restrict__ box, const float* __restrict__ zs, float (&cost)[8],
+                                            float ug, float vg, float umax, float vmax, unsigned rwv, float pa, float pb,
+                                            float a2, float k2v, float rr, float rg, float rb) {
+    SweepCoord cd[8];
+    float4 tx[8][3];
+    float zz[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) zz[j] = zs[j];                               // broadcast reads
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 8 + SWEEP_AHEAD; ++j) {
+        if (j < 8) {
+            cd[j] = sweep_coords_parallax<CLAMP>(ug, vg, umax, vmax, pa, pb, a2, k2v, zz[j]);
+            unsigned off;                                                    // byte offset of texel (yi, xi) in the box
+            asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(off) : "v"(cd[j].yi), "v"(rwv), "v"(cd[j].xi));
+            asm("v_mul_u32_u24 %0, %1, 48" : "=v"(off) : "v"(off));
+            const float4* t = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(box) + off);
+            tx[j][0] = t[0]; tx[j][1] = t[1]; tx[j][2] = t[2];
+        }
+        if (j >= SWEEP_AHEAD) {
+            const int i = j - SWEEP_AHEAD;
+            cost[i] = sweep_blend(tx[i][0], tx[i][1], tx[i][2], cd[i].wu, cd[i].wv, rr, rg, rb);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 template <int LAYOUT>   // 0: volume [P,D,H,W] fp32   1: c4 [P,D/4+1,H,W,4] fp32   2: c8 [P,D/8+1,H,W,8] fp16
 __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_MINW, SWEEP_MINW))) void planesweep_kernel(const SweepArgs a) {
     // one LDS object: texel box | plane depths | plane groups (two tile parities) | header (level, next tile) x 2
@@ -316,10 +350,10 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
             // the parallax form needs a2 (linear over the tile: extremes at the corners) away from zero, one sign
             const bool parallax_ok = __ballot(!(fabsf(ca2) >= 0.25f)) == 0 && (__ballot(ca2 < 0.f) == 0 || __ballot(ca2 > 0.f) == 0);
             const float idmin = (float)a.idmin, idstep = (float)a.idstep;       // fp32 depths are enough for a box with margins
-            int bx0[2], by0[2], bx1[2], by1[2], bok[2];
+            int bx0[2], by0[2], bx1[2], by1[2], bok[2], bcl[2];              // box, footprint usable, box clipped by the image
             bool live[2];
-            bx0[1] = by0[1] = 1 << 28; bx1[1] = by1[1] = -(1 << 28); bok[1] = 1; live[1] = false;   // neutral second pass
-    #pragma unroll
+            bx0[1] = by0[1] = 1 << 28; bx1[1] = by1[1] = -(1 << 28); bok[1] = 1; bcl[1] = 0; live[1] = false;   // neutral second pass
+#pragma unroll
             for (int q = 0; q < 2; ++q) {
                 if (q == 1 && ocnt <= 8) break;
                 const int oct = q * 8 + (lane >> 3);                         // octet of this unit
@@ -333,11 +367,11 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
                 const float u = fmaf(ca0, zc, k0) * rc, v = fmaf(ca1, zc, k1) * rc;
                 int okc = (den > 1e-4f) && (fabsf(u) < 1e6f) && (fabsf(v) < 1e6f);
                 float umin = u, umax = u, vmin = v, vmax = v;
-    #define SWEEP_RED8(CTRL) \
+#define SWEEP_RED8(CTRL) \
                 umin = fminf(umin, sweep_dpp<CTRL>(umin)); umax = fmaxf(umax, sweep_dpp<CTRL>(umax)); \
                 vmin = fminf(vmin, sweep_dpp<CTRL>(vmin)); vmax = fmaxf(vmax, sweep_dpp<CTRL>(vmax)); okc &= sweep_dpp<CTRL>(okc);
                 SWEEP_RED8(SWEEP_DPP_XOR1) SWEEP_RED8(SWEEP_DPP_XOR2) SWEEP_RED8(SWEEP_DPP_HALF_MIRROR)
-    #undef SWEEP_RED8
+#undef SWEEP_RED8
                 // texel indices floor(u - 0.5) of the samples, one texel of safety margin either side, clipped to
                 // [-2, W] x [-2, H] (the outermost column / row of that range is all zeros)
                 bx0[q] = (int)fminf(fmaxf(floorf(umin - 0.5f) - 1.f, -2.f), (float)W);
@@ -345,34 +379,36 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
                 by0[q] = (int)fminf(fmaxf(floorf(vmin - 0.5f) - 1.f, -2.f), (float)H);
                 by1[q] = (int)fminf(fmaxf(floorf(vmax - 0.5f) + 1.f, (float)by0[q]), (float)H);
                 bok[q] = okc;
-                if (!live[q]) { bx0[q] = 1 << 28; by0[q] = 1 << 28; bx1[q] = -(1 << 28); by1[q] = -(1 << 28); bok[q] = 1; }   // neutral
+                bcl[q] = !(floorf(umin - 0.5f) - 1.f >= -2.f && floorf(umax - 0.5f) + 1.f <= (float)W &&
+                           floorf(vmin - 0.5f) - 1.f >= -2.f && floorf(vmax - 0.5f) + 1.f <= (float)H);
+                if (!live[q]) { bx0[q] = 1 << 28; by0[q] = 1 << 28; bx1[q] = -(1 << 28); by1[q] = -(1 << 28); bok[q] = 1; bcl[q] = 0; }   // neutral
             }
-            int level = 0, gx0[2], gy0[2], gx1[2], gy1[2], gst[2];
-    #pragma unroll
+            int level = 0, gx0[2], gy0[2], gx1[2], gy1[2], gst[2], gcl[2];
+#pragma unroll
             for (int L = 0; L < 5; ++L) {
                 if (L == 1) {
-    #pragma unroll
+#pragma unroll
                     for (int q = 0; q < 2; ++q) {
                         bx0[q] = min(bx0[q], sweep_dpp<SWEEP_DPP_ROR8>(bx0[q])); by0[q] = min(by0[q], sweep_dpp<SWEEP_DPP_ROR8>(by0[q]));
                         bx1[q] = max(bx1[q], sweep_dpp<SWEEP_DPP_ROR8>(bx1[q])); by1[q] = max(by1[q], sweep_dpp<SWEEP_DPP_ROR8>(by1[q]));
-                        bok[q] &= sweep_dpp<SWEEP_DPP_ROR8>(bok[q]);
+                        bok[q] &= sweep_dpp<SWEEP_DPP_ROR8>(bok[q]); bcl[q] |= sweep_dpp<SWEEP_DPP_ROR8>(bcl[q]);
                     }
                 } else if (L == 2 || L == 3) {
                     const int m = L == 2 ? 16 : 32;
-    #pragma unroll
+#pragma unroll
                     for (int q = 0; q < 2; ++q) {
                         bx0[q] = min(bx0[q], __shfl_xor(bx0[q], m)); by0[q] = min(by0[q], __shfl_xor(by0[q], m));
                         bx1[q] = max(bx1[q], __shfl_xor(bx1[q], m)); by1[q] = max(by1[q], __shfl_xor(by1[q], m));
-                        bok[q] &= __shfl_xor(bok[q], m);
+                        bok[q] &= __shfl_xor(bok[q], m); bcl[q] |= __shfl_xor(bcl[q], m);
                     }
                 } else if (L == 4) {
                     bx0[0] = bx0[1] = min(bx0[0], bx0[1]); by0[0] = by0[1] = min(by0[0], by0[1]);
                     bx1[0] = bx1[1] = max(bx1[0], bx1[1]); by1[0] = by1[1] = max(by1[0], by1[1]);
-                    bok[0] = bok[1] = bok[0] & bok[1];
+                    bok[0] = bok[1] = bok[0] & bok[1]; bcl[0] = bcl[1] = bcl[0] | bcl[1];
                 }
                 bool bad = false;
                 int fits[2];
-    #pragma unroll
+#pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const int rw = bx1[q] - bx0[q] + 1, rh = by1[q] - by0[q] + 1;
                     // capacity in texels, and in staging items ((rw + 1) rh over four passes of 8 x 63 lanes)
@@ -383,18 +419,18 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
                 const bool all_fit = __ballot(bad) == 0;
                 if (L == 0 || all_fit) {                                          // monotone: a run that fits implies its halves fit
                     level = L;
-    #pragma unroll
-                    for (int q = 0; q < 2; ++q) { gx0[q] = bx0[q]; gy0[q] = by0[q]; gx1[q] = bx1[q]; gy1[q] = by1[q]; gst[q] = fits[q]; }
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) { gx0[q] = bx0[q]; gy0[q] = by0[q]; gx1[q] = bx1[q]; gy1[q] = by1[q]; gst[q] = fits[q]; gcl[q] = bcl[q]; }
                 }
             }
             level = __builtin_amdgcn_readfirstlane(level);
-    #pragma unroll
+#pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int oct = q * 8 + (lane >> 3);
                 if ((lane & 7) == 0 && oct < ocnt && (oct & ((1 << level) - 1)) == 0) {
                     int* gq = grp[parity * SWEEP_MAX_OCT + (oct >> level)];
                     gq[0] = gx0[q]; gq[1] = gy0[q]; gq[2] = gx1[q] - gx0[q] + 1; gq[3] = gy1[q] - gy0[q] + 1;
-                    gq[4] = gst[q] && parallax_ok;
+                    gq[4] = gst[q] && parallax_ok; gq[5] = gcl[q];
                 }
             }
             if (lane == 0) { hdr[2 * parity] = level; hdr[2 * parity + 1] = ticket; }
@@ -426,13 +462,14 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
             bx.rx0 = __builtin_amdgcn_readfirstlane(grp[parity * SWEEP_MAX_OCT + g][0]); bx.ry0 = __builtin_amdgcn_readfirstlane(grp[parity * SWEEP_MAX_OCT + g][1]);
             bx.rw = __builtin_amdgcn_readfirstlane(grp[parity * SWEEP_MAX_OCT + g][2]); bx.rh = __builtin_amdgcn_readfirstlane(grp[parity * SWEEP_MAX_OCT + g][3]);
             const bool staged = __builtin_amdgcn_readfirstlane(grp[parity * SWEEP_MAX_OCT + g][4]) != 0;
-    #ifdef SWEEP_STATS
+            const bool clamp = __builtin_amdgcn_readfirstlane(grp[parity * SWEEP_MAX_OCT + g][5]) != 0;   // box clipped by the image
+#ifdef SWEEP_STATS
             if (tid == 0) {
                 if (g == 0) atomicAdd(&sweep_stats[0], 1u);
                 if (staged) { atomicAdd(&sweep_stats[1], 1u); atomicAdd(&sweep_stats[3], (unsigned)(bx.rw * bx.rh)); }
                 else atomicAdd(&sweep_stats[2], (unsigned)(min((g + 1) << level, ocnt) - (g << level)));
             }
-    #endif
+#endif
             if (staged) {
                 // ---- stage the box: rh rows of rw texels + one halo column, as items i = r (rw + 1) + c dealt 63 per
                 // wave pass (lane 63 repeats the next pass' first item: it only feeds lane 62).  A lane loads column c of
@@ -442,7 +479,7 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
                 const float inv_pitch = 1.0f / (float)pitch;
                 float p0[4][3], p1[4][3];
                 int dst[4];
-    #pragma unroll
+#pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if (k * 8 * 63 >= n) break;                                   // wave-uniform: passes the box does not need
                     const int i = (k * 8 + wave) * 63 + lane;
@@ -453,17 +490,17 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
                     const unsigned o0 = (in && xin && (unsigned)yy < (unsigned)H) ? o : 0xFFFFFFFFu;
                     const unsigned o1 = (in && xin && (unsigned)(yy + 1) < (unsigned)H) ? o + (unsigned)W * 4u : 0xFFFFFFFFu;
                     dst[k] = (in && c < bx.rw && lane < 63) ? r * bx.rw + c : -1;
-    #pragma unroll
+#pragma unroll
                     for (int ch = 0; ch < 3; ++ch) {
                         p0[k][ch] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, o0, ch * chan_bytes, 0));
                         p1[k][ch] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, o1, ch * chan_bytes, 0));
                     }
                 }
-    #pragma unroll
+#pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if (k * 8 * 63 >= n) break;
                     float q0[3], q1[3];
-    #pragma unroll
+#pragma unroll
                     for (int ch = 0; ch < 3; ++ch) { q0[ch] = sweep_next_lane(p0[k][ch]); q1[ch] = sweep_next_lane(p1[k][ch]); }
                     const SweepTexel t = sweep_texel_pack(p0[k], q0, p1[k], q1);
                     if (dst[k] >= 0) { float4* tb = box + 3 * dst[k]; tb[0] = t.u0; tb[1] = t.u1; tb[2] = t.u2; }
@@ -482,46 +519,26 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
                 const int d0 = o * 8;
                 float cost[8];
                 if (staged) {
-                    SweepCoord cd[8];
-                    float4 tx[8][3];
-                    float zz[8];
-    #pragma unroll
-                    for (int j = 0; j < 8; ++j) zz[j] = zsh[d0 + j];             // broadcast reads, d0 + j < CNM_MAX_PLANES
-                    __builtin_amdgcn_sched_barrier(0);
-    #pragma unroll
-                    for (int j = 0; j < 8 + SWEEP_AHEAD; ++j) {
-                        if (j < 8) {
-                            cd[j] = sweep_coords_parallax(ug, vg, umax, vmax, pa, pb, a2, k2v, zz[j]);
-                            unsigned off;                                        // byte offset of texel (yi, xi) in the box
-                            asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(off) : "v"(cd[j].yi), "v"(rwv), "v"(cd[j].xi));
-                            asm("v_mul_u32_u24 %0, %1, 48" : "=v"(off) : "v"(off));
-                            const float4* t = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(box) + off);
-                            tx[j][0] = t[0]; tx[j][1] = t[1]; tx[j][2] = t[2];
-                        }
-                        if (j >= SWEEP_AHEAD) {
-                            const int i = j - SWEEP_AHEAD;
-                            cost[i] = sweep_blend(tx[i][0], tx[i][1], tx[i][2], cd[i].wu, cd[i].wv, rr, rg, rb);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
+                    if (clamp) sweep_octet<true>(box, zsh + d0, cost, ug, vg, umax, vmax, rwv, pa, pb, a2, k2v, rr, rg, rb);
+                    else sweep_octet<false>(box, zsh + d0, cost, ug, vg, umax, vmax, rwv, pa, pb, a2, k2v, rr, rg, rb);
                 } else {
-    #pragma unroll 1
+#pragma unroll 1
                     for (int j = 0; j < 8; ++j) {
                         const SweepCoord cj = sweep_coords(cu, cv, umax, vmax, a0, a1, a2, k0, k1, k2e, zsh[d0 + j]);
                         const SweepTexel t = sweep_texel_global(rsrc, (int)cj.xi + bx.rx0, (int)cj.yi + bx.ry0, W, H, chan_bytes);
                         const float c = sweep_blend(t.u0, t.u1, t.u2, cj.wu, cj.wv, rr, rg, rb);
-    #pragma unroll
+#pragma unroll
                         for (int jj = 0; jj < 8; ++jj) if (jj == j) cost[jj] = c;
                     }
                 }
                 if (LAYOUT == 0) {
-    #pragma unroll
+#pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         if (pvalid && d0 + j < D) *optr = cost[j];
                         optr += plane;
                     }
                 } else if (LAYOUT == 1) {
-    #pragma unroll
+#pragma unroll
                     for (int q = 0; q < 2; ++q) {
                         if (pvalid && d0 + 4 * q < D)
                             *reinterpret_cast<float4*>(optr) = make_float4(cost[4 * q], cost[4 * q + 1], cost[4 * q + 2], cost[4 * q + 3]);
@@ -529,7 +546,7 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
                     }
                 } else {
                     sw_f16x8 h;
-    #pragma unroll
+#pragma unroll
                     for (int j = 0; j < 8; ++j) h[j] = (_Float16)cost[j];
                     if (pvalid) *reinterpret_cast<sw_f16x8*>(optr) = h;
                     optr += plane;
