@@ -297,8 +297,9 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
             if (v & 1) { q.obeg = h0; q.ocnt = noct - h0; } else q.ocnt = h0;
             t = nfull + (v >> 1);
         }
-        q.p = (int)(((float)t + 0.5f) * inv_tpp);                            // exact for t < 2^20 (checked by the launcher)
-        const int rem = t - q.p * tiles_per_pair, tyi = (int)(((float)rem + 0.5f) * inv_ntx);
+        // fp32 reciprocals (exact for t < 2^20, checked by the launcher); back to SGPRs so the rest is scalar arithmetic
+        q.p = __builtin_amdgcn_readfirstlane((int)(((float)t + 0.5f) * inv_tpp));
+        const int rem = t - q.p * tiles_per_pair, tyi = __builtin_amdgcn_readfirstlane((int)(((float)rem + 0.5f) * inv_ntx));
         q.tx0 = (rem - tyi * ntx) * SWEEP_TW; q.ty0 = tyi * SWEEP_TH;
         return q;
     };
@@ -412,7 +413,8 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
                 for (int q = 0; q < 2; ++q) {
                     const int rw = bx1[q] - bx0[q] + 1, rh = by1[q] - by0[q] + 1;
                     // capacity in texels, and in staging items ((rw + 1) rh over four passes of 8 x 63 lanes)
-                    fits[q] = bok[q] && rw <= SWEEP_CAP && rh <= SWEEP_CAP && rw * rh <= SWEEP_CAP && (rw + 1) * rh <= 4 * 8 * 63;
+                    const int rwc = min(max(rw, 0), SWEEP_CAP + 1), rhc = min(max(rh, 0), SWEEP_CAP + 1);   // 24-bit products
+                    fits[q] = bok[q] && __mul24(rwc, rhc) <= SWEEP_CAP && __mul24(rwc + 1, rhc) <= 4 * 8 * 63;
                     const bool run_live = ((q * 8 + (lane >> 3)) & ~((1 << L) - 1)) < ocnt;
                     bad |= run_live && !fits[q];
                 }
@@ -477,19 +479,24 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
                 if (g > 0) __syncthreads();                                      // every wave is done with the previous box
                 const int pitch = bx.rw + 1, n = pitch * bx.rh;
                 const float inv_pitch = 1.0f / (float)pitch;
+                const int origin4 = (bx.ry0 * W + bx.rx0) * 4;                // byte offset of box texel (0,0) in a channel plane
                 float p0[4][3], p1[4][3];
                 int dst[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    if (k * 8 * 63 >= n) break;                                   // wave-uniform: passes the box does not need
+                    if (k * 8 * 63 >= n) break;                               // wave-uniform: passes the box does not need
                     const int i = (k * 8 + wave) * 63 + lane;
-                    const int r = (int)(((float)i + 0.5f) * inv_pitch), c = i - r * pitch;     // exact for i < 2^21 / pitch
+                    const int r = (int)(((float)i + 0.5f) * inv_pitch);      // exact for i < 2^21 / pitch
+                    int c, t, d;                                             // 24-bit multiply-adds (v_mul_lo_u32 is quarter rate)
+                    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(c) : "v"(r), "s"(-pitch), "v"(i));        // c = i - r pitch
+                    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(t) : "v"(r), "s"(W), "v"(c));             // texel offset from the origin
+                    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(r), "s"(bx.rw), "v"(c));         // box texel index
                     const int xx = bx.rx0 + c, yy = bx.ry0 + r;
                     const bool in = i < n, xin = (unsigned)xx < (unsigned)W;
-                    const unsigned o = (unsigned)(yy * W + xx) * 4u;
+                    const unsigned o = (unsigned)(t * 4 + origin4);
                     const unsigned o0 = (in && xin && (unsigned)yy < (unsigned)H) ? o : 0xFFFFFFFFu;
                     const unsigned o1 = (in && xin && (unsigned)(yy + 1) < (unsigned)H) ? o + (unsigned)W * 4u : 0xFFFFFFFFu;
-                    dst[k] = (in && c < bx.rw && lane < 63) ? r * bx.rw + c : -1;
+                    dst[k] = (in && c < bx.rw && lane < 63) ? d : -1;
 #pragma unroll
                     for (int ch = 0; ch < 3; ++ch) {
                         p0[k][ch] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, o0, ch * chan_bytes, 0));
@@ -503,7 +510,12 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
 #pragma unroll
                     for (int ch = 0; ch < 3; ++ch) { q0[ch] = sweep_next_lane(p0[k][ch]); q1[ch] = sweep_next_lane(p1[k][ch]); }
                     const SweepTexel t = sweep_texel_pack(p0[k], q0, p1[k], q1);
-                    if (dst[k] >= 0) { float4* tb = box + 3 * dst[k]; tb[0] = t.u0; tb[1] = t.u1; tb[2] = t.u2; }
+                    if (dst[k] >= 0) {
+                        unsigned off;
+                        asm("v_mul_u32_u24 %0, %1, 48" : "=v"(off) : "v"(dst[k]));
+                        float4* tb = reinterpret_cast<float4*>(reinterpret_cast<char*>(box) + off);
+                        tb[0] = t.u0; tb[1] = t.u1; tb[2] = t.u2;
+                    }
                 }
                 __syncthreads();
             } else {                                                             // whole zero-extended image as the "box"
