@@ -70,18 +70,61 @@ def conv_tile(cout, m):
     return "conv_mfma_f32_kernel<64, 64, 1, false>"
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC pass (profiles/r1_pmc_traffic.json: rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE in separate runs of this script, gfx950 read correction applied).  Counters cannot be
-    collected from inside the timed process, so this is the number of the last profiled build, or None."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
-            table = json.load(f)["kernels"]
-    except (OSError, ValueError, KeyError):
+_LIVE_TRAFFIC = None      # kernel name -> HBM bytes per launch, measured by this run's own PMC passes (live_traffic)
+
+
+def live_traffic(timeout_s=240):
+    """HBM bytes per launch and kernel from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE: separate runs, as the
+    microarchitecture guide prescribes; FETCH_SIZE doubled = the gfx950 wide-read correction) over a short CHILD run of
+    this script.  Counters cannot be read inside the timed process, so the passes run after it, as child processes
+    (`rocprofv3 ... -- python3 bench.py --steps 2 ...`: the interpreter directly behind `--`).  Returns
+    {kernel: bytes} or None when rocprofv3 is unavailable / fails (the committed table is used then)."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
         return None
+    per = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="cnm_pmc_")
+        try:
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--",
+                   sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline",
+                   "--no-secondary", "--no-live-traffic"]
+            r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
+            if r.returncode != 0 or not files:
+                return None
+            tot, ids = collections.defaultdict(float), collections.defaultdict(set)
+            for row in csv.DictReader(open(files[0])):
+                if row["Counter_Name"] == counter:
+                    tot[row["Kernel_Name"]] += float(row["Counter_Value"]); ids[row["Kernel_Name"]].add(row["Dispatch_Id"])
+            per[counter] = {k: tot[k] * 1024.0 / len(ids[k]) for k in tot}               # the counters are in KB
+        except (OSError, subprocess.SubprocessError, KeyError, ValueError):
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    # (corrected, raw): the x2 applies to wide (16 B per lane) coalesced reads; dword gathers are uncalibrated (guide, HBM section)
+    return {k: (2.0 * v + per["WRITE_SIZE"].get(k, 0.0), v + per["WRITE_SIZE"].get(k, 0.0)) for k, v in per["FETCH_SIZE"].items()}
+
+
+def pmc_traffic(kernel, raw=False):
+    """HBM bytes per launch of `kernel` (raw=True: without the x2 read correction): from this run's own PMC passes when they ran (live_traffic), else from the
+    committed pass of the last profiled build (profiles/r2_pmc_traffic.json), else None."""
+    table = _LIVE_TRAFFIC
+    if table is None:
+        try:
+            with open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")) as f:
+                table = {k: (v["fetch_bytes_corrected"] + v["write_bytes"], v["fetch_bytes_corrected"] / 2 + v["write_bytes"])
+                         for k, v in json.load(f)["kernels"].items()}
+        except (OSError, ValueError, KeyError):
+            return None
     for name, v in table.items():
         if name.replace("void ", "").startswith(kernel):
-            return v["fetch_bytes_corrected"] + v["write_bytes"]
+            return v[1 if raw else 0]
     return None
 
 
@@ -160,7 +203,7 @@ def kernel_rooflines(dev, frames):
     name, (flop, ms, launches, exe) = max(per_kernel.items(), key=lambda kv: kv[1][1])
     tot_ms = sum(v[1] for v in per_kernel.values())
     conv = {"kernel": name, "bound": "mfma", "achieved": exe / ms / 1e9, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-            "frac": exe / ms / 1e9 / MFMA_F32_PEAK_TF, "traffic": pmc_traffic(name),
+            "frac": exe / ms / 1e9 / MFMA_F32_PEAK_TF, "traffic": pmc_traffic(name), "traffic_uncorrected": pmc_traffic(name, raw=True),
             "traffic_note": "HBM bytes per average launch, PMC pass committed under profiles/ (not live)", "launches_per_step": launches,
             "avg_launch_ms": ms / launches, "algorithmic": flop / ms / 1e9,
             "note": "achieved = flops executed on the matrix cores; algorithmic = direct-convolution-equivalent rate; avg_launch_ms times each layer alone -- compare with profiles/r1_bench_kernel_stats_serial.csv (in the default run the two refine decoders overlap on two streams, which stretches rocprof's per-launch durations while shortening the step)",
@@ -191,6 +234,7 @@ def kernel_rooflines(dev, frames):
     byts = frames * 3 * H * W * 4 + pairs * 3 * H * W * 4 + pairs * (PLANES + 3) * H * W * 4
     sweep = {"kernel": "planesweep_kernel<1>", "bound": "hbm", "achieved": byts / ms / 1e6, "peak": HBM_PEAK_GBS,
              "unit": "GB/s", "frac": byts / ms / 1e6 / HBM_PEAK_GBS, "traffic": pmc_traffic("planesweep_kernel<1>"),
+             "traffic_uncorrected": pmc_traffic("planesweep_kernel<1>", raw=True),
              "algorithmic_bytes_per_launch": byts, "avg_launch_ms": ms,
              "note": "one persistent launch per call (no pre-pass); avg_launch_ms over 4 bursts of 25 back-to-back launches between HIP events on the launch stream"}
     return conv, sweep
@@ -315,6 +359,7 @@ def main():
     ap.add_argument("--frames-per-gpu", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not run the two PMC child passes; roofline.traffic then comes from profiles/")
     ap.add_argument("--graph", action="store_true", help="replay the step as one captured HIP graph (measured: no gain, the host already runs ahead of the GPU)")
     ap.add_argument("--side-stream", type=int, default=-1, help="A/B: cnm_tune_refine_side_stream value (0 = everything on the caller's stream)")
     ap.add_argument("--precision", choices=["f32", "f16"], default="f32",
@@ -384,7 +429,13 @@ def main():
                            "frames_per_gpu": B, "sharding": "independent frame shards per GPU, no collective",
                            "launch": "hipGraph replay" if a.graph else "per-kernel, asynchronous"}}
         if not a.no_roofline and a.precision == "f32":
+            global _LIVE_TRAFFIC
+            if world == 1 and not a.no_live_traffic:
+                _LIVE_TRAFFIC = live_traffic()
             line["roofline"], line["roofline_planesweep"] = kernel_rooflines(dev, B)
+            src = ("PMC passes of this run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE as child processes, FETCH_SIZE x 2)" if _LIVE_TRAFFIC is not None
+                   else "PMC pass committed under profiles/ (not live)")
+            line["roofline"]["traffic_note"] = line["roofline_planesweep"]["traffic_note"] = "HBM bytes per average launch, " + src
         if world == 1 and not a.no_secondary and a.precision == "f32":
             del pipe, run, out
             torch.cuda.empty_cache()

@@ -1,4 +1,4 @@
-"""CPU: the committed bench line (profiles/r1_bench_line.json, produced by `python bench.py` on the GPU box) carries
+"""CPU: the committed bench line (profiles/r2_bench_line.json, produced by `python bench.py` on the GPU box) carries
 every field the bench contract names, with consistent arithmetic."""
 import json
 import os
@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_contract():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r1_bench_line.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r2_bench_line.json")))
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -28,3 +28,10 @@ def test_committed_bench_line_contract():
     k1 = d["roofline_planesweep"]
     assert k1["bound"] == "hbm" and abs(k1["frac"] - k1["achieved"] / k1["peak"]) < 1e-9
     assert abs(k1["achieved"] - k1["algorithmic_bytes_per_launch"] / k1["avg_launch_ms"] / 1e6) < 1e-6 * k1["achieved"]
+    # round 2: per-step HIP-event percentiles, rank spread, secondary workloads (never the headline), CPU model in the sample
+    st = d["step_ms"]
+    assert st["n"] == d["steps"] >= 50 and st["p10"] <= st["median"] <= st["p90"]
+    assert d["per_rank_frames_per_s"]["min"] <= d["per_rank_frames_per_s"]["max"]
+    for k, dt in (("f16", "f16"), ("config4", "f32")):
+        assert d[k]["unit"] == "frames/s" and d[k]["value"] > 0 and dt in d[k]["dtype"] and d[k]["value"] != d["value"]
+    assert " on " in c["sample"]                                           # "... threads (...) on <CPU model>"

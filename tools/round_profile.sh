@@ -1,8 +1,29 @@
-# Refresh profiles/: default bench line + rocprofv3 kernel stats of the same command (GPU box).
-cd /tmp && export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
-timeout 400 python3 bench.py > gpurun_out/bench_line.json 2> gpurun_out/bench_line.err
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/stats -- python3 bench.py > gpurun_out/bench_prof.json 2> gpurun_out/bench_prof.err
-f=$(find gpurun_out/stats -name '*kernel_stats.csv' | head -1)
-cp "$f" gpurun_out/kernel_stats.csv
-head -12 gpurun_out/kernel_stats.csv | cut -c1-150
+#!/bin/bash
+# Round profile (GPU box): bench line, rocprofv3 kernel summaries (default and one-stream), PMC passes (HBM traffic,
+# matrix-pipe utilisation, plane-sweep VALU counters), training-step kernel summary.  Output: gpurun_out/r2/.
+set -euo pipefail
+cd "${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+export TMPDIR=/tmp
+O=gpurun_out/r2
+rm -rf "$O"; mkdir -p "$O"
+timeout 900 python3 bench.py > "$O/bench_line.json" 2> "$O/bench_line.err" || { tail -5 "$O/bench_line.err"; exit 1; }
+prof() {   # prof <tag> <bench args...>: kernel summary of one bench command
+  local tag=$1; shift
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_$tag" -- python3 bench.py "$@" > "$O/prof_$tag.json" 2> "$O/prof_$tag.err"
+  cp "$(find "$O/stats_$tag" -name '*kernel_stats.csv' | head -1)" "$O/bench_kernel_stats_$tag.csv"
+  rm -rf "$O/stats_$tag"
+}
+prof default --no-cpu-baseline --no-secondary --no-live-traffic
+prof serial --side-stream 0 --no-cpu-baseline --no-secondary --no-live-traffic
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$O/pmc_$C" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-secondary --no-live-traffic > "$O/pmc_$C.log" 2>&1
+done
+python3 tools/pmc_traffic.py "$O/pmc_FETCH_SIZE" "$O/pmc_WRITE_SIZE" "$O/pmc_traffic.json" "$O/pmc_hbm_traffic.txt" > /dev/null
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$O/pmc_mfma" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-secondary --no-live-traffic > "$O/pmc_mfma.log" 2>&1
+python3 tools/pmc_mfma.py "$O/pmc_mfma" "$O/pmc_mfma_util.txt" > /dev/null
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES --output-format csv -d "$O/pmc_valu" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-secondary --no-live-traffic > "$O/pmc_valu.log" 2>&1
+python3 tools/pmc_summary.py "$O/pmc_valu" | grep -i "planesweep" > "$O/pmc_planesweep_valu.txt" || true
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_train" -- python3 tools/train_bench.py > "$O/train_bench.txt" 2> "$O/train_bench.err" || true
+f=$(find "$O/stats_train" -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" "$O/train_kernel_stats.csv"
+rm -rf "$O"/pmc_FETCH_SIZE "$O"/pmc_WRITE_SIZE "$O"/pmc_mfma "$O"/pmc_valu "$O"/stats_train
+ls -la "$O"; head -c 1500 "$O/bench_line.json"; echo; head -6 "$O/bench_kernel_stats_serial.csv" | cut -c1-160; cat "$O/pmc_planesweep_valu.txt"
