@@ -28,9 +28,6 @@
 #ifndef WINO_GSTART
 #define WINO_GSTART 6    // first step of the window loads of the chunk two ahead (8 steps, two loads each)
 #endif
-#ifndef WINO_ABL
-#define WINO_ABL 0   // ablation bit mask for timing studies (results are wrong when set): 1 no gather, 2 no weight refill, 4 no transform, 8 windows from one cache line, 16 weights from one fragment
-#endif
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt -- here that would wait, at
 // every chunk, for the weight fragments and windows deliberately left in flight across the barrier.
@@ -99,8 +96,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd_f32_kernel(const Wino
         gsoff = (unsigned)(s1 ? a.gin0 + g : a.gin2_0 + g - a.Gsplit) * (unsigned)HW * 16u;
     };
     auto gather_load = [&](int ij) {
-        const u32x2 v = (WINO_ABL & 8) ? __builtin_amdgcn_raw_buffer_load_b64(grsrc, (unsigned)(t & 63) * 8u, 0, 0)   // same loads, L1-resident footprint
-                                       : __builtin_amdgcn_raw_buffer_load_b64(grsrc, off[ij], gsoff, 0);
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(grsrc, off[ij], gsoff, 0);
         d[ij] = make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
     };
     float2 m[16];
@@ -172,13 +168,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd_f32_kernel(const Wino
             }
             acc[x][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw.x, b0.x, acc[x][0], 0, 0, 0);
             acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw.x, b1.x, acc[x][1], 0, 0, 0);
-            if (WINO_ABL & 16) af[x % WD] = ubase[0];                    // same loads, one L1-resident fragment
-            else if (!(WINO_ABL & 2)) af[x % WD] = x + WD < 16 ? uc[(size_t)(x + WD) * 64] : un[(size_t)(x + WD - 16) * 64];
-            if (!(WINO_ABL & 4)) {
-                if (x < 2) { column_pass(2 * x); column_pass(2 * x + 1); }
-                else if (x < 4) { row_pass(2 * (x - 2), Vn); row_pass(2 * (x - 2) + 1, Vn); }
-            }
-            if (!(WINO_ABL & 1) && x >= WINO_GSTART && x < WINO_GSTART + 8) {
+            af[x % WD] = x + WD < 16 ? uc[(size_t)(x + WD) * 64] : un[(size_t)(x + WD - 16) * 64];
+            if (x < 2) { column_pass(2 * x); column_pass(2 * x + 1); }
+            else if (x < 4) { row_pass(2 * (x - 2), Vn); row_pass(2 * (x - 2) + 1, Vn); }
+            if (x >= WINO_GSTART && x < WINO_GSTART + 8) {
                 if (x == WINO_GSTART) gather_begin(c + 2);
                 gather_load(2 * (x - WINO_GSTART)); gather_load(2 * (x - WINO_GSTART) + 1);
             }

@@ -20,9 +20,6 @@
 // The executors use it for layers with enough tiles to fill the chip (conv_winograd.hip otherwise).
 #include "cnm_common.h"
 
-#ifndef WINO4_ABL
-#define WINO4_ABL 0       // ablation bit mask for timing studies (results are wrong when set): 1 no gather, 2 no weight refill, 4 no transform, 8 windows from one line, 16 weights from one fragment
-#endif
 #ifndef WINO4_LPS
 #define WINO4_LPS 4      // window loads per double step (divides 36; at most 12 double steps are available)
 #endif
@@ -121,8 +118,7 @@ __global__ __launch_bounds__(256, 2) void conv_winograd36_f32_kernel(const Wino4
         gsoff = (unsigned)(s1 ? a.gin0 + g : a.gin2_0 + g - a.Gsplit) * (unsigned)HW * 16u;
     };
     auto gather_load = [&](int ij) {
-        d[ij] = __uint_as_float((WINO4_ABL & 8) ? __builtin_amdgcn_raw_buffer_load_b32(grsrc, (unsigned)lane * 4u, 0, 0)
-                                                 : __builtin_amdgcn_raw_buffer_load_b32(grsrc, sat_add(roff[ij / 6], coff[ij % 6]), gsoff, 0));
+        d[ij] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(grsrc, sat_add(roff[ij / 6], coff[ij % 6]), gsoff, 0));
     };
     const int wofs = tl * 16 + (qd ^ ((tl >> 1) & 3)) * 4 + cc;
     auto column_pass = [&](int j) { WINO4_BT(d[0 * 6 + j], d[1 * 6 + j], d[2 * 6 + j], d[3 * 6 + j], d[4 * 6 + j], d[5 * 6 + j]); };
@@ -179,16 +175,13 @@ __global__ __launch_bounds__(256, 2) void conv_winograd36_f32_kernel(const Wino4
             }
             acc[x0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc[x0], 0, 0, 0);
             acc[x1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, acc[x1], 0, 0, 0);
-            if (WINO4_ABL & 16) { af[x0 % WD] = ubase[0]; af[x1 % WD] = ubase[0]; }
-            else if (!(WINO4_ABL & 2)) {
-                af[x0 % WD] = x0 + WD < NXI ? uc[(size_t)(x0 + WD) * 64] : un[(size_t)(x0 + WD - NXI) * 64];
-                af[x1 % WD] = x1 + WD < NXI ? uc[(size_t)(x1 + WD) * 64] : un[(size_t)(x1 + WD - NXI) * 64];
-            }
+            af[x0 % WD] = x0 + WD < NXI ? uc[(size_t)(x0 + WD) * 64] : un[(size_t)(x0 + WD - NXI) * 64];
+            af[x1 % WD] = x1 + WD < NXI ? uc[(size_t)(x1 + WD) * 64] : un[(size_t)(x1 + WD - NXI) * 64];
             // between the MFMAs: the transform of chunk c+1 (double steps 0..5), then the window of chunk c+2 (WINO4_LPS
             // loads per double step; past the last chunk all out of range = 0, written to the idle buffer)
-            if (xp < 3) { if (!(WINO4_ABL & 4)) { column_pass(2 * xp); column_pass(2 * xp + 1); } }
-            else if (xp < 6) { if (!(WINO4_ABL & 4)) { row_pass(2 * (xp - 3), Vn); row_pass(2 * (xp - 3) + 1, Vn); } }
-            else if (xp < 6 + 36 / WINO4_LPS && !(WINO4_ABL & 1)) {      // row-major (column-major issue order measured 5 % slower: worse line locality)
+            if (xp < 3) { column_pass(2 * xp); column_pass(2 * xp + 1); }
+            else if (xp < 6) { row_pass(2 * (xp - 3), Vn); row_pass(2 * (xp - 3) + 1, Vn); }
+            else if (xp < 6 + 36 / WINO4_LPS) {      // row-major (column-major issue order measured 5 % slower: worse line locality)
                 if (xp == 6) gather_begin(c + 2);
 #pragma unroll
                 for (int l = WINO4_LPS * (xp - 6); l < WINO4_LPS * (xp - 5); ++l) gather_load(l);

@@ -20,9 +20,6 @@
 // gather of chunk c+2 ride between the MFMAs of chunk c; one LDS-only barrier per chunk.
 #include "cnm_common.h"
 
-#ifndef ROWS_ABL
-#define ROWS_ABL 0   // ablation bit mask for timing studies (results are wrong when set): 1 no gather, 2 no weight refill, 4 no transform
-#endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -299,11 +296,11 @@ __global__ __launch_bounds__(256, 2) void conv_rows_winograd_f32_kernel(const Ro
             }
 #pragma unroll
             for (int b = 0; b < NB; ++b) acc[x][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw.x, bw[b].x, acc[x][b], 0, 0, 0);
-            if (!(ROWS_ABL & 2)) af[x % WD] = x + WD < NX ? uc[(size_t)(x + WD) * 64] : un[(size_t)(x + WD - NX) * 64];   // WD steps ahead (wraps into the next chunk)
+            af[x % WD] = x + WD < NX ? uc[(size_t)(x + WD) * 64] : un[(size_t)(x + WD - NX) * 64];   // WD steps ahead (wraps into the next chunk)
             // between the MFMAs: one transform group of chunk c+1 per step, then (registers free) the windows of chunk
             // c+2, two loads per step (past the last chunk all out of range = 0, written to the idle buffer)
-            if (!(ROWS_ABL & 4) && x < NG) transform_group(x, Vn);
-            if (!(ROWS_ABL & 1) && x >= NG) {                            // LPS loads per step, spread over the steps after the transform
+            if (x < NG) transform_group(x, Vn);
+            if (x >= NG) {                            // LPS loads per step, spread over the steps after the transform
                 constexpr int LPS = (NX + (NX - NG) - 1) / (NX - NG);
                 if (x == NG) gather_begin();
 #pragma unroll

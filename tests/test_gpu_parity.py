@@ -52,16 +52,20 @@ def test_homography_terms(dev, ops, golden):
 
 
 def test_planesweep_golden(dev, ops, golden):
-    """Reference getVolume output incl. a pair with out-of-frame and behind-camera samples."""
+    """Reference getVolume output: a benign pair and a pair whose samples leave the frame / fall behind the camera.
+    Bars from the measured distances (tools/golden_sweep_errors.py): engine vs reference 6.8e-5 max on the benign pair
+    and ZERO on the other one (every sample of it is outside the image: the zeros padding), and the engine is never
+    farther from the float64 closed form than the reference's own fp32 arithmetic is (3.9e-5 against 5.1e-5)."""
     g = golden("planesweep_32x64.npz")
     vol = ops.plane_sweep_volume(T(g["left"]).to(dev), T(g["right"]).to(dev), T(g["left_cam"]).to(dev),
                                  T(g["right_cam"]).to(dev), 3.0, 64).cpu().numpy()
     assert np.isfinite(vol).all()
-    med, q, mx = _stats(vol, g["volume"])
-    # fp32 coordinate rounding (|u'| up to ~1e3 px on the hard pair) times image gradient
-    assert med < 2e-5 and q < 2e-3 and mx < 5e-2, (med, q, mx)
-    med, q, mx = _stats(vol[0], g["volume"][0])          # the benign pair: 1e-3 everywhere
-    assert mx < 1e-3, (med, q, mx)
+    exact = cf.plane_sweep_volume(g["left"], g["right"], g["left_cam"], g["right_cam"], 3.0, 64)
+    for p, bar in ((0, 2e-4), (1, 1e-5)):
+        med, q, mx = _stats(vol[p], g["volume"][p])
+        assert mx < bar and med < 1e-5, (p, med, q, mx)
+        eng, ref = _stats(vol[p], exact[p]), _stats(g["volume"][p], exact[p])
+        assert eng[2] <= 1.5 * ref[2] + 1e-6 and eng[1] <= 1.5 * ref[1] + 1e-6, (p, eng, ref)
 
 
 def test_reference_call_sequence_getvolume(dev, golden):
