@@ -183,19 +183,39 @@ struct DepthBufs {
     float *hmkt, *TEX, *X0, *A1, *CAT2, *A2, *CAT3, *A3, *CAT4, *A4, *CAT5, *A5, *C5, *U5, *I5, *U4, *I4, *U3, *I3, *U2, *I2, *U1, *CAT1;
 };
 
+// Buffers share memory by liveness (launch order of depthnet_forward, one stream):
+//   X0, A1            sweep .. conv1.3                      the encoder's full-resolution level
+//   A2 .. A5          one encoder level each (after A1 is dead)
+//   U5 .. U2, I5..I3  decoder temporaries: all dead before disp2 / upconv1 write CAT1 / U1
+//   U1, CAT1          upconv1 .. iconv1                     the decoder's full-resolution level
+// so CAT1 lives where X0 was, U1 where A1 was, and the low-resolution temporaries (a level's A, U and I share one
+// slot: A is dead when U is written, U when I is) sit inside the A1 / U1 slot.  Skip tensors (CAT2..CAT5), I2 (read
+// while U1 / CAT1 are written) and the plane sweep's tile queue keep memory of their own: 1.1 GB instead of 2.4 GB
+// for 16 pairs at 192x256.
 template <class E>
 static size_t carve_depth(float* ws, int P, int H, int W, int D, DepthBufs* b) {
     Carver c{ws, 0};
     const size_t q = (size_t)P * H * W * 4;     // floats (= 16 bytes x pixels) of one channel group at full resolution
     auto G = [](int C) { return (size_t)((C + E::GD - 1) / E::GD); };
+    auto up64 = [](size_t n) { return (n + 63) & ~(size_t)63; };
     b->TEX = c.take(4);                         // FIRST and never reused: the plane sweep's tile queue, zero between calls
     b->hmkt = c.take((size_t)P * 12);
-    b->X0 = c.take(q * (G(D) + 1));
-    b->A1 = c.take(q * G(128));        b->U1 = c.take(q * G(128));       b->CAT1 = c.take(q * (G(64) + 1));
-    b->CAT2 = c.take(q / 4 * (2 * G(128) + 1));  b->A2 = c.take(q / 4 * G(256));   b->U2 = c.take(q / 4 * G(256));   b->I2 = c.take(q / 4 * G(128));
-    b->CAT3 = c.take(q / 16 * (2 * G(256) + 1)); b->A3 = c.take(q / 16 * G(512)); b->U3 = c.take(q / 16 * G(512)); b->I3 = c.take(q / 16 * G(256));
-    b->CAT4 = c.take(q / 64 * 2 * G(512)); b->A4 = c.take(q / 64 * G(512)); b->U4 = c.take(q / 64 * G(512)); b->I4 = c.take(q / 64 * G(512));
-    b->CAT5 = c.take(q / 256 * 2 * G(512)); b->A5 = c.take(q / 256 * G(512)); b->U5 = c.take(q / 256 * G(512)); b->I5 = c.take(q / 256 * G(512));
+    const size_t x0 = q * (G(D) + 1), cat1 = q * (G(64) + 1);
+    b->X0 = b->CAT1 = c.take(x0 > cat1 ? x0 : cat1);
+    const size_t lvl[4] = {up64(q / 4 * G(256)), up64(q / 16 * G(512)), up64(q / 64 * G(512)), up64(q / 256 * G(512))};   // A2..A5
+    const size_t a1 = q * G(128), inner = lvl[0] + lvl[1] + lvl[2] + lvl[3];
+    float* slot = c.take(a1 > inner ? a1 : inner);
+    b->A1 = b->U1 = slot;
+    size_t o = 0;
+    b->A2 = b->U2 = slot ? slot + o : nullptr; o += lvl[0];
+    b->A3 = b->U3 = b->I3 = slot ? slot + o : nullptr; o += lvl[1];
+    b->A4 = b->U4 = b->I4 = slot ? slot + o : nullptr; o += lvl[2];
+    b->A5 = b->U5 = b->I5 = slot ? slot + o : nullptr;
+    b->I2 = c.take(q / 4 * G(128));
+    b->CAT2 = c.take(q / 4 * (2 * G(128) + 1));
+    b->CAT3 = c.take(q / 16 * (2 * G(256) + 1));
+    b->CAT4 = c.take(q / 64 * 2 * G(512));
+    b->CAT5 = c.take(q / 256 * 2 * G(512));
     b->C5 = c.take(q / 1024 * G(512));
     return c.used;
 }
@@ -284,6 +304,9 @@ struct RefineBufs { float *X, *A1, *C1, *A2, *C2, *A3, *C3, *U3; DecoderBufs d[2
 
 
 
+// The encoder's buffers are dead when the two decoders start (only the skip tensors C1, C2 and the shared U3 are read
+// by them), so decoder 0's temporaries reuse them: U1 <- A1, UC1 <- X, U2 <- A2, UC3 + I3 <- A3.  Decoder 1 runs
+// concurrently on the side stream and keeps buffers of its own.
 template <class E>
 static size_t carve_refine(float* ws, int N, int H, int W, RefineBufs* b) {
     Carver c{ws, 0};
@@ -292,10 +315,16 @@ static size_t carve_refine(float* ws, int N, int H, int W, RefineBufs* b) {
     b->X = c.take(q * (G(64) + 1)); b->A1 = c.take(q * G(128));
     b->C1 = c.take(q / 4 * G(128)); b->A2 = c.take(q / 4 * G(256));
     b->C2 = c.take(q / 16 * G(256)); b->A3 = c.take(q / 16 * G(512)); b->U3 = c.take(q / 16 * G(512));
-    for (DecoderBufs& d : b->d) {
-        d.U1 = c.take(q * G(128)); d.UC1 = c.take(q * G(64)); d.I1 = c.take(q * G(64));
-        d.U2 = c.take(q / 4 * G(256)); d.UC2 = c.take(q / 4 * G(128)); d.I2 = c.take(q / 4 * G(128));
-        d.UC3 = c.take(q / 16 * G(256)); d.I3 = c.take(q / 16 * G(256));
+    for (int k = 0; k < 2; ++k) {
+        DecoderBufs& d = b->d[k];
+        const bool share = k == 0;
+        d.U1 = share ? b->A1 : c.take(q * G(128));
+        d.UC1 = share ? b->X : c.take(q * G(64));
+        d.I1 = c.take(q * G(64));
+        d.U2 = share ? b->A2 : c.take(q / 4 * G(256));
+        d.UC2 = c.take(q / 4 * G(128)); d.I2 = c.take(q / 4 * G(128));
+        d.UC3 = share ? b->A3 : c.take(q / 16 * G(256));
+        d.I3 = share ? (b->A3 ? b->A3 + ((q / 16 * G(256) + 63) & ~(size_t)63) : nullptr) : c.take(q / 16 * G(256));
     }
     b->C3 = c.take(q / 64 * G(512));
     return c.used;

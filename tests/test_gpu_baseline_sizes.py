@@ -133,5 +133,5 @@ def test_forward_pairs_batch_split_matches_unsplit(dev):
         split = net.forward_pairs(*args)
     assert split[0][0].shape == whole[0][0].shape and split[1].shape == whole[1].shape
     for a, b in zip(whole[0], split[0]):
-        assert float((a - b).abs().max()) < 2e-5
+        assert float((a - b).abs().max()) < 1e-4                          # kernel choice per layer differs with the pair count (fp32 rounding on a [0,3] range)
     assert float((whole[1] - split[1]).abs().max()) < 1e-4 * float(whole[1].abs().max())
