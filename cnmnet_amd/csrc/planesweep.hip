@@ -40,6 +40,12 @@
 #ifndef SWEEP_MINW
 #define SWEEP_MINW 4                // waves per SIMD the register allocation must allow (2 workgroups x 8 waves per CU)
 #endif
+#ifndef SWEEP_TAIL_HALVES
+#define SWEEP_TAIL_HALVES 4         // tiles handed out as two half sweeps, in quarters of the grid size
+#endif
+#ifndef SWEEP_TAIL_QUARTERS
+#define SWEEP_TAIL_QUARTERS 0       // tiles handed out as four quarter sweeps (the last ones), in quarters of the grid size
+#endif
 #ifndef SWEEP_AHEAD
 #define SWEEP_AHEAD 1               // samples whose texel reads are in flight ahead of the blend
 #endif
@@ -284,18 +290,22 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
     const size_t plane = (size_t)HW * (LAYOUT == 0 ? 1 : 4);                 // floats per plane / per 16-byte channel group
     if (tid < CNM_MAX_PLANES) zsh[tid] = tid < D ? sweep_depth(a, tid) : 0.f;
 
-    // Work units: whole tiles first; the last tiles (one per resident workgroup) are cut into two half sweeps, so the
-    // launch does not end with a tile-long tail of half-empty CUs.
-    const int nsplit = noct > 1 ? min(ntiles, (int)gridDim.x) : 0, nfull = ntiles - nsplit, nunits = nfull + 2 * nsplit;
+    // Work units: whole tiles first, then tiles cut into two half sweeps, then tiles cut into quarter sweeps: the
+    // launch ends with small units, not with a tile-long tail of half-empty CUs.  Zone sizes in quarters of the grid.
+    const int nq = noct >= 4 ? min(ntiles, (int)gridDim.x * SWEEP_TAIL_QUARTERS / 4) : 0;
+    const int nh = noct >= 2 ? min(ntiles - nq, (int)gridDim.x * SWEEP_TAIL_HALVES / 4) : 0;
+    const int nfull = ntiles - nh - nq, nunits = nfull + 2 * nh + 4 * nq;
     const float inv_tpp = 1.0f / (float)tiles_per_pair, inv_ntx = 1.0f / (float)ntx;
     struct Unit { int p, tx0, ty0, obeg, ocnt; };
     auto decode = [&](int u) {                                               // unit -> pair, tile origin, octet range
         Unit q; q.obeg = 0; q.ocnt = noct;
         int t = u;
         if (u >= nfull) {
-            const int v = u - nfull, h0 = (noct + 1) >> 1;
-            if (v & 1) { q.obeg = h0; q.ocnt = noct - h0; } else q.ocnt = h0;
-            t = nfull + (v >> 1);
+            int v = u - nfull, parts = 2, part;
+            if (v < 2 * nh) { t = nfull + (v >> 1); part = v & 1; }
+            else { v -= 2 * nh; parts = 4; t = nfull + nh + (v >> 2); part = v & 3; }
+            q.obeg = part * noct / parts;
+            q.ocnt = (part + 1) * noct / parts - q.obeg;
         }
         // fp32 reciprocals (exact for t < 2^20, checked by the launcher); back to SGPRs so the rest is scalar arithmetic
         q.p = __builtin_amdgcn_readfirstlane((int)(((float)t + 0.5f) * inv_tpp));
