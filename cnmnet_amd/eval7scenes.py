@@ -99,7 +99,9 @@ def load_sample(files, height, width):
     depth = np.asarray(Image.open(files["depth"])).astype(np.float64) / 1000.0
     h0, w0 = rgb.shape[:2]
     cam = make_cam(read_pose(files["pose"]), INTRINSICS, width / float(w0), height / float(h0))
-    rgb = resize_linear(rgb, height, width)
+    # cv2.resize on a uint8 image returns uint8 (rounded, saturated) and the reference normalises THAT (eval.py:84-90);
+    # rounding here keeps the network input on the same 8-bit grid (cv2's fixed-point weights can still differ by 1 level)
+    rgb = np.clip(np.rint(resize_linear(rgb, height, width)), 0, 255).astype(np.uint8)
     return np.ascontiguousarray(normalize_image(rgb).transpose(2, 0, 1)), depth.astype(np.float32), cam
 
 
