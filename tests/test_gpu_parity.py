@@ -129,6 +129,72 @@ def test_planesweep_vs_oracle_and_layouts(dev, ops, H, W, D, S):
         assert (xs[:, D // 4, :, :, 3] == 0).all()
 
 
+def test_planesweep_queue_scratch_and_fallback_paths(dev, ops):
+    """The persistent sweep's scratch contract and its slow paths:
+    * the tile-queue words are zero again after every call, a reused workspace gives bit-identical results, and two
+      calls in flight on two streams (each with its own workspace) do not disturb each other;
+    * ws = NULL (fixed tile stride instead of the ticket queue) gives the same bits;
+    * cameras the parallax form is not used for (a2 changes sign inside the image: 80 degree yaw) and footprints that
+      do not fit the LDS box (6x zoom) go through the global-gather path and still match the float64 closed form;
+    * a plane count that is not a multiple of 8 (NCHW layout) and more tiles than resident workgroups."""
+    from cnmnet_amd import _lib
+    lib = _lib.load()
+    B, S, H, W, D = 3, 2, 72, 200, 64
+    img, cams = syn.frames(B, S, H, W, seed=77)
+    ref, src = T(img[:, 0]).to(dev), T(img[:, 1:]).to(dev)
+    hmkt = ops.homography_terms(T(cams[:, 0]).to(dev), T(cams[:, 1:]).to(dev))
+    ws = torch.zeros(lib.cnm_planesweep_workspace_floats(B, S, H, W), device=dev)
+    a = ops.plane_sweep_cat_c4(ref, src, hmkt, 3.0, D, ws=ws).clone()
+    assert not ws.view(torch.int32).any()                                 # rearmed by the last workgroup
+    b = ops.plane_sweep_cat_c4(ref, src, hmkt, 3.0, D, ws=ws).clone()
+    assert torch.equal(a, b) and not ws.view(torch.int32).any()
+    lo, hi = ops.idepth_range(3.0)
+    c = torch.empty_like(a)                                               # no scratch at all
+    _lib.check(lib.cnm_planesweep_cat_c4_f32(ref.data_ptr(), src.data_ptr(), hmkt.data_ptr(), c.data_ptr(), None, 0,
+                                             B, S, H, W, D, lo, hi, torch.cuda.current_stream().cuda_stream))
+    assert torch.equal(a, c)
+    s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)  # two calls in flight, own workspaces
+    ws2 = torch.zeros_like(ws)
+    for st in (s1, s2):
+        st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s1):
+        o1 = [ops.plane_sweep_cat_c4(ref, src, hmkt, 3.0, D, ws=ws) for _ in range(4)][-1]
+    with torch.cuda.stream(s2):
+        o2 = [ops.plane_sweep_cat_c4(ref, src, hmkt, 3.0, D, ws=ws2) for _ in range(4)][-1]
+    s1.synchronize(); s2.synchronize()
+    assert torch.equal(o1, a) and torch.equal(o2, a) and not ws.view(torch.int32).any() and not ws2.view(torch.int32).any()
+    want = cf.plane_sweep_volume(img[:, 0], img[:, 1], cams[:, 0], cams[:, 1], 3.0, D)
+    got = a[0::S, :D // 4].permute(0, 1, 4, 2, 3).reshape(B, D, H, W).cpu().numpy()
+    assert _stats(got, want)[2] < 1e-3
+    # --- cameras outside the fast path
+    K = cams[0, 0, 1, :3, :3].astype(np.float64)
+    def cam_with(R, t, zoom=1.0):
+        c = cams[:1, 0].copy()
+        E = np.eye(4); E[:3, :3] = R; E[:3, 3] = t
+        c[0, 0] = E.astype(np.float32)
+        Kz = K.copy(); Kz[0, 0] *= zoom; Kz[1, 1] *= zoom
+        c[0, 1, :3, :3] = Kz.astype(np.float32)
+        return c
+    yaw = np.deg2rad(80.0)
+    Ry = np.array([[np.cos(yaw), 0, np.sin(yaw)], [0, 1, 0], [-np.sin(yaw), 0, np.cos(yaw)]])
+    for name, rc, bar in (("yaw 80 deg", cam_with(Ry, [0.05, 0.0, 0.02]), 5e-3), ("zoom 6x", cam_with(np.eye(3), [0.1, 0.0, 0.0], 6.0), 5e-3)):
+        lc = cams[:1, 0]
+        vol = ops.plane_sweep_volume(T(img[:1, 0]).to(dev), T(img[:1, 1]).to(dev), T(lc).to(dev), T(rc).to(dev), 3.0, D).cpu().numpy()
+        want = cf.plane_sweep_volume(img[:1, 0], img[:1, 1], lc, rc, 3.0, D)
+        ok = np.isfinite(want) & np.isfinite(vol)
+        assert ok.mean() > 0.999, name
+        med, q, mx = _stats(vol[ok], want[ok])
+        assert med < 2e-5 and q < bar, (name, med, q, mx)                  # coordinates of ~1e3 px: fp32 rounding x image gradient in the tail
+    # --- 20 planes (not a multiple of 8) in the NCHW layout
+    vol = ops.plane_sweep_volume(T(img[:, 0]).to(dev), T(img[:, 1]).to(dev), T(cams[:, 0]).to(dev), T(cams[:, 1]).to(dev), 3.0, 20).cpu().numpy()
+    assert _stats(vol, cf.plane_sweep_volume(img[:, 0], img[:, 1], cams[:, 0], cams[:, 1], 3.0, 20))[2] < 1e-3
+    # --- more tiles than resident workgroups (dynamic tickets really drawn): 1600 tiles of a 320x1280 image pair
+    img2, cams2 = syn.frames(2, 1, 320, 1280, seed=3)
+    vol = ops.plane_sweep_volume(T(img2[:, 0]).to(dev), T(img2[:, 1]).to(dev), T(cams2[:, 0]).to(dev), T(cams2[:, 1]).to(dev), 3.0, 8).cpu().numpy()
+    med, q, mx = _stats(vol, cf.plane_sweep_volume(img2[:, 0], img2[:, 1], cams2[:, 0], cams2[:, 1], 3.0, 8))
+    assert med < 2e-5 and q < 1e-3 and mx < 3e-3, (med, q, mx)           # u' up to 1280 px: one fp32 ulp is 1.2e-4 px, times the image gradient
+
+
 def test_planesweep_full_size_identity_known_answer(dev, ops):
     """BASELINE config 2 size (8 x 2 pairs, 192x256, 64 planes).  Identity relative pose and
     equal intrinsics => u' = x, so every plane is the half-pixel box filter:
