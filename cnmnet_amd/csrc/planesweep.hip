@@ -351,6 +351,11 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
             reinterpret_cast<float*>((unsigned long long)src_lo | ((unsigned long long)src_hi << 32)), 0, 3 * chan_bytes, 0x00020000);
 
+        // ---- footprints, wave 0 only (serial work stays on one wave: the kernel is VALU-throughput bound and the CU's
+        // other workgroup fills the gap).  Lane 8j + c of pass q projects tile corner (c & 3) on the first (c < 4) / last
+        // plane of the unit's octet 8q + j; an 8-lane min / max (DPP) gives the octet's box in all eight lanes.  Merging
+        // with the lanes 8, 16, 32 away and with the other pass gives the boxes of every aligned run of 2, 4, 8, 16
+        // octets; the longest run whose boxes all fit the LDS budget wins.  Results go to LDS (groups, level, ticket).
         if (tid < 64) {
             const int cxi = (lane & 1) ? min(tx0 + SWEEP_TW - 1, W - 1) : tx0;
             const int cyi = (lane & 2) ? min(ty0 + SWEEP_TH - 1, H - 1) : ty0;
