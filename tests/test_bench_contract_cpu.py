@@ -28,6 +28,8 @@ def test_committed_bench_line_contract():
     k1 = d["roofline_planesweep"]
     assert k1["bound"] == "hbm" and abs(k1["frac"] - k1["achieved"] / k1["peak"]) < 1e-9
     assert abs(k1["achieved"] - k1["algorithmic_bytes_per_launch"] / k1["avg_launch_ms"] / 1e6) < 1e-6 * k1["achieved"]
+    assert k1["launch_ms"]["n"] >= 50 and k1["launch_ms"]["p10"] <= k1["launch_ms"]["median"] <= k1["launch_ms"]["p90"]
+    assert k1["burst_frac"] > 0 and abs(k1["burst_frac"] - k1["algorithmic_bytes_per_launch"] / k1["burst_avg_launch_ms"] / 1e6 / k1["peak"]) < 1e-9
     # round 2: per-step HIP-event percentiles, rank spread, secondary workloads (never the headline), CPU model in the sample
     st = d["step_ms"]
     assert st["n"] == d["steps"] >= 50 and st["p10"] <= st["median"] <= st["p90"]
