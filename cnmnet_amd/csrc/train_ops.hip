@@ -128,28 +128,32 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
         }
 }
 
+// One thread per (cout, flat k) of the PADDED partial layout, so the `splits` reads of a wave are contiguous rows (the
+// reads outnumber the one scattered OIHW write per element by the split count); fp64 sum.
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int splits, int Cout, int Cout_pad, int Cin, int ks,
                                     int rot, int Kpad128, float* __restrict__ dw) {
+    const int Cp = 4 * ((Cin + 3) / 4), Kflat = ks * ks * Cp;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long total = (long long)Cout * Cin * ks * ks;
-    if (idx >= total) return;
-    const int tap = (int)(idx % (ks * ks));
-    const int ci = (int)((idx / (ks * ks)) % Cin), co = (int)(idx / ((long long)ks * ks * Cin));
-    const int Cp = 4 * ((Cin + 3) / 4);
-    const int cp = (ci + Cin - rot) % Cin;
-    const int k = tap * Cp + cp;
+    if (idx >= (long long)Cout * Kflat) return;
+    const int co = (int)(idx / Kflat), k = (int)(idx - (long long)co * Kflat);
+    const int tap = k / Cp, cp = k - tap * Cp;
     double s = 0.0;
-    for (int z = 0; z < splits; ++z) s += (double)partial[((size_t)z * Cout_pad + co) * Kpad128 + k];
-    dw[idx] = (float)s;
+    const float* q = partial + (size_t)co * Kpad128 + k;
+    const size_t zstride = (size_t)Cout_pad * Kpad128;
+    for (int z = 0; z < splits; ++z) s += (double)q[(size_t)z * zstride];
+    if (cp < Cin) dw[((size_t)co * Cin + (cp + rot) % Cin) * (ks * ks) + tap] = (float)s;
 }
 
+#ifndef CNM_WGRAD_WORKGROUPS
+#define CNM_WGRAD_WORKGROUPS 2048
+#endif
 static inline int wg_round(int v, int m) { return (v + m - 1) / m * m; }
 
 static void wgrad_plan(int Cout, int Cin, int ksize, int M, int* Cout_pad, int* Kpad128, int* splits, int* pps) {
     *Cout_pad = wg_round(Cout, 128);
     *Kpad128 = wg_round(ksize * ksize * 4 * ((Cin + 3) / 4), 128);
     const int tiles = (*Cout_pad / 128) * (*Kpad128 / 128);
-    int s = (2048 + tiles - 1) / tiles;                       // aim at ~2048 workgroups
+    int s = (CNM_WGRAD_WORKGROUPS + tiles - 1) / tiles;       // aim at that many workgroups (1024 and 512 measured slower)
     const int maxs = (M + 255) / 256;                         // at least 256 pixels per split
     if (s > maxs) s = maxs;
     if (s < 1) s = 1;
@@ -184,7 +188,7 @@ extern "C" int cnm_conv2d_wgrad_c4_f32(const float* x, int Gx_total, int gx0, in
     a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)yb;
     dim3 grid(a.Cout_pad / 128, a.Kpad128 / 128, splits);
     conv_wgrad_kernel<<<grid, 256, 0, cnm_stream(stream)>>>(a);
-    const long long total = (long long)Cout * Cin * ksize * ksize;
+    const long long total = (long long)Cout * a.Kflat;
     wgrad_reduce_kernel<<<(unsigned)cnm_ceil_div_ll(total, 256), 256, 0, cnm_stream(stream)>>>(
         ws, splits, Cout, a.Cout_pad, Cin, ksize, rot, a.Kpad128, dw_oihw);
     CNM_LAUNCH_CHECK();
