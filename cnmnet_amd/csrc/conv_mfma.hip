@@ -60,14 +60,10 @@ __device__ __forceinline__ float4 buffer_load_f4(const float* base, unsigned byt
 // TS = 1: ordinary convolution (any stride, via a.stride).  TS = 2: transposed stride-2 gather used by the
 // data gradient of a stride-2 layer: tap (a,b) of output pixel (y,x) reads source pixel ((y+a-pad)/2, (x+b-pad)/2)
 // when both are even and in range (the zero-upsampled view of dy, never materialised).
-// F16 = true: the same kernel on fp16 data ("c8" activations: 8 channels per 16-byte pixel group, weights packed
-// [nk][Cout][32 halfs]).  Every address, the LDS image and the loader are byte-identical to the fp32 kernel (a k-step
-// is 64 bytes per row either way); only the matrix instruction (v_mfma_f32_32x32x16_f16, fp32 accumulate: the 16-byte
-// fragment a lane reads IS its 8-half operand) and the epilogue (fp32 bias/ReLU, 4 halfs = 8 bytes per lane) differ.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
-template <int TC, int TP, int TS = 1, bool F16 = false>
+template <int TC, int TP, int TS = 1>
 __global__ __launch_bounds__(256, CONV_MINW) void conv_mfma_f32_kernel(const ConvArgs a) {
     constexpr int NT = 256, WP = 2;
     constexpr int CI = TC / 64, PI = TP / 64;          // 32x32 MFMA tiles per wave
@@ -169,11 +165,6 @@ __global__ __launch_bounds__(256, CONV_MINW) void conv_mfma_f32_kernel(const Con
             _Pragma("unroll") for (int j = 0; j < PI; ++j) bf[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDK + kg * 8); \
             _Pragma("unroll") for (int i = 0; i < CI; ++i)                                                         \
                 _Pragma("unroll") for (int j = 0; j < PI; ++j) {                                                   \
-                    if constexpr (F16) {                                                                           \
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(&af[i]), \
-                                                                           *reinterpret_cast<const f16x8*>(&bf[j]), acc[i][j], 0, 0, 0); \
-                        continue;                                                                                  \
-                    }                                                                                              \
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);        \
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);        \
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);        \
@@ -220,13 +211,157 @@ __global__ __launch_bounds__(256, CONV_MINW) void conv_mfma_f32_kernel(const Con
                 float4 v = make_float4(acc[i][j][4 * qd + 0] + b.x, acc[i][j][4 * qd + 1] + b.y,
                                        acc[i][j][4 * qd + 2] + b.z, acc[i][j][4 * qd + 3] + b.w);
                 if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                if constexpr (F16) {     // c8: this lane owns channels c..c+3 = half of the 16-byte group c/8
-                    const f16x4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-                    char* o = reinterpret_cast<char*>(a.out + c4_offset(img, a.Gout_tot, a.gout0 + (c >> 3), HoWo, pix)) + (c & 4) * 2;
-                    *reinterpret_cast<f16x4*>(o) = h;
-                    continue;
-                }
                 *reinterpret_cast<float4*>(a.out + c4_offset(img, a.Gout_tot, a.gout0 + (c >> 2), HoWo, pix)) = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ fp16 implicit GEMM fed by LDS-DMA
+// The fp16 matrix pipe is 16x faster than the fp32 one, so the loader above (global -> registers -> ds_write_b128, one
+// barrier per 32 halfs of depth, 128x128 tiles) is LDS-store bound at ~30 % of the pipe.  This kernel moves both operands
+// with buffer_load_dwordx4 ... lds (no VGPRs, no ds_write; an out-of-range offset -- zero padding, pixel tail, ragged K --
+// lands as zeros in LDS: tools/glds_probe.hip), 64 halfs of depth per barrier, 8 waves of 64 couts x 64 pixels each:
+//   LDS image of a k-step, per operand: [8 channel groups][rows][16 B]  (rows = couts / pixels)
+//     - a DMA piece is one group x 64 consecutive rows = 1 KB, lane-linear, and its (tap, channel group) is wave-uniform:
+//       wave w moves group w of every k-step (all its A and B pieces), the tap walk lives in SGPRs;
+//     - the MFMA fragment of lane (row = l & 31, k-half = l >> 5) for the k16 step s is the 16 bytes at
+//       [(2 s + k-half)][row]: 32 consecutive rows per half wave, conflict-free ds_read_b128.
+//   Weights are packed in exactly that order ([k-step][8 groups][Cout_pad][8 halfs]), so A pieces are contiguous.
+// Three LDS buffers (two for the 64 x 512 tile): the DMA of steps t+1 and t+2 is in flight under the MFMAs of step t,
+// one of them across the barrier (counted s_waitcnt vmcnt + raw s_barrier).
+template <int TC, int TP>
+__global__ __launch_bounds__(512) void conv_f16_glds_kernel(const ConvArgs a) {
+    constexpr int WC = TC / 64, WP = 8 / WC;
+    static_assert(TP == 64 * WP && (WC == 1 || WC == 2 || WC == 4), "8 waves of 64 x 64");
+    constexpr int AB = 8 * TC * 16, BB = 8 * TP * 16, BUF = AB + BB;   // bytes per operand image / per buffer
+    constexpr int NPA = TC / 64, NPB = TP / 64;                         // DMA pieces of one group
+    constexpr int NBUF = 3 * BUF <= 160 * 1024 ? 3 : 2;
+    __shared__ __attribute__((aligned(16))) char smem[NBUF * BUF];      // 144 KB: 3 x 48 KB (128 x 256) / 2 x 72 KB (64 x 512)
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wc = wave / WP, wp = wave % WP;
+    const int tilesC = a.Cout_pad / TC;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int c0 = (tile % tilesC) * TC, m0 = (tile / tilesC) * TP;
+    const int HW = a.H * a.W, HoWo = a.Ho * a.Wo;
+
+    // ---- B pieces: lane = pixel m0 + 64 pb + lane of piece pb
+    int iy0[NPB], ix0[NPB]; unsigned vb1[NPB], vb2[NPB]; bool mval[NPB];
+#pragma unroll
+    for (int pb = 0; pb < NPB; ++pb) {
+        const int m = m0 + 64 * pb + lane;
+        mval[pb] = m < a.M;
+        const int mm = mval[pb] ? m : 0;
+        const int img = mm / HoWo, rem = mm - img * HoWo;
+        const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+        iy0[pb] = oy * a.stride - a.pad; ix0[pb] = ox * a.stride - a.pad;
+        const unsigned pix0 = (unsigned)(iy0[pb] * a.W + ix0[pb]);
+        vb1[pb] = ((unsigned)(img * a.Gin_tot + a.gin0) * (unsigned)HW + pix0) * 16u;
+        vb2[pb] = ((unsigned)(img * a.Gin2_tot + a.gin2_0) * (unsigned)HW + pix0) * 16u;
+    }
+    // (tap, channel group) of this wave's group in the next k-step to load: scalar state
+    int g = wave, ky = 0, kx = 0;
+    auto tap_norm = [&]() { while (g >= a.Gin) { g -= a.Gin; if (++kx == a.ks) { kx = 0; ++ky; } } };
+    tap_norm();
+    const unsigned HW16 = (unsigned)HW * 16u;
+    const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, 0xFFFFFFFFu, 0x00020000);
+    const unsigned wlane = ((unsigned)c0 + (unsigned)lane) * 16u;      // byte offset of this lane's row inside a group of the packed filter
+    const unsigned wgroup = (unsigned)a.Cout_pad * 16u;                  // bytes per (k-step, group)
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    auto issue = [&](int kt, int buf) {                                 // DMA of k-step kt into buffer buf (this wave: group `wave`)
+        char* A = smem + buf * BUF + wave * TC * 16;
+        char* B = smem + buf * BUF + AB + wave * TP * 16;
+        const unsigned wsoff = (unsigned)(kt * 8 + wave) * wgroup;
+#pragma unroll
+        for (int p = 0; p < NPA; ++p)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr)(A + p * 1024), 16, wlane + p * 1024u, wsoff, 0, 0);
+        const bool s1 = g < a.Gsplit, tapok = ky < a.ks;
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s1 ? a.in : a.in2), 0, tapok ? (s1 ? a.in_bytes : a.in2_bytes) : 0u, 0x00020000);
+        const unsigned soff = (unsigned)(s1 ? g : g - a.Gsplit) * HW16, tapoff = (unsigned)(ky * a.W + kx) * 16u;
+#pragma unroll
+        for (int pb = 0; pb < NPB; ++pb) {
+            const int iy = iy0[pb] + ky, ix = ix0[pb] + kx;
+            const bool ok = mval[pb] & ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)a.W);
+            const unsigned voff = ok ? (s1 ? vb1[pb] : vb2[pb]) + tapoff : 0xFFFFFFFFu;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(B + pb * 1024), 16, voff, soff, 0, 0);
+        }
+        g += 8; tap_norm();
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int frow = lane & 31, kh = lane >> 5;
+    auto compute = [&](int buf) {
+        const char* Ab = smem + buf * BUF + (kh * TC + wc * 64 + frow) * 16;
+        const char* Bb = smem + buf * BUF + AB + (kh * TP + wp * 64 + frow) * 16;
+        f16x8 af[2][2], bf[2][2];                                       // fragments of k16 step s + 1 are read under the MFMAs of step s
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { af[0][i] = *reinterpret_cast<const f16x8*>(Ab + 32 * i * 16); bf[0][i] = *reinterpret_cast<const f16x8*>(Bb + 32 * i * 16); }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (s < 3) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    af[(s + 1) & 1][i] = *reinterpret_cast<const f16x8*>(Ab + (2 * (s + 1) * TC + 32 * i) * 16);
+                    bf[(s + 1) & 1][i] = *reinterpret_cast<const f16x8*>(Bb + (2 * (s + 1) * TP + 32 * i) * 16);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s & 1][i], bf[s & 1][j], acc[i][j], 0, 0, 0);
+        }
+        // pin the order: the four fragment reads of step s + 1 are ISSUED before the four MFMAs of step s (left alone, the
+        // scheduler reuses one register set and every step waits out the LDS latency with an idle matrix pipe)
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) { __builtin_amdgcn_sched_group_barrier(0x100, 4, 0); __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    };
+
+    // NBUF LDS buffers: the DMA of k-step kt + NBUF - 1 is issued before the MFMAs of step kt; with three buffers one
+    // k-step stays in flight across the barrier (counted vmcnt: NPW DMA instructions per wave and step, in order)
+    constexpr int NPW = NPA + NPB;
+    auto wait_dma = [&](bool one_in_flight) {
+        if (NBUF == 3 && one_in_flight) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // not __syncthreads(): its fence would drain the DMA left in flight
+    };
+    issue(0, 0);
+    if (NBUF == 3 && a.nk > 1) issue(1, 1);
+    wait_dma(a.nk > 1);
+    int cur = 0, nxt = NBUF - 1;                                        // buffer of step kt / of the step issued in iteration kt
+    for (int kt = 0; kt < a.nk; ++kt) {
+        if (kt + NBUF - 1 < a.nk) issue(kt + NBUF - 1, nxt);
+        compute(cur);
+        wait_dma(kt + 2 < a.nk);
+        cur = cur + 1 == NBUF ? 0 : cur + 1; nxt = nxt + 1 == NBUF ? 0 : nxt + 1;
+    }
+
+    // ---- epilogue: acc row = cout (r&3)+8*(r>>2)+4*(lane>>5), col = pixel lane&31
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int mm = m0 + wp * 64 + j * 32 + (lane & 31);
+        if (mm >= a.M) continue;
+        const int img = mm / HoWo, pix = mm - img * HoWo;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int c = c0 + wc * 64 + i * 32 + 8 * qd + 4 * (lane >> 5);
+                if (c >= a.Cout) continue;
+                const float4 b = a.bias ? *reinterpret_cast<const float4*>(a.bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 v = make_float4(acc[i][j][4 * qd + 0] + b.x, acc[i][j][4 * qd + 1] + b.y,
+                                       acc[i][j][4 * qd + 2] + b.z, acc[i][j][4 * qd + 3] + b.w);
+                if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                const f16x4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};   // c8: channels c..c+3 = half of the 16-byte group c/8
+                char* o = reinterpret_cast<char*>(a.out + c4_offset(img, a.Gout_tot, a.gout0 + (c >> 3), HoWo, pix)) + (c & 4) * 2;
+                *reinterpret_cast<f16x4*>(o) = h;
             }
         }
     }
@@ -293,10 +428,10 @@ extern "C" int cnm_pack_conv_bn_f32(const float* w_oihw, const float* bn_gamma, 
     return CNM_OK;
 }
 
-template <int TC, int TP, int TS = 1, bool F16 = false>
+template <int TC, int TP, int TS = 1>
 static void launch_conv(const ConvArgs& a, hipStream_t s) {
     const int nblocks = (a.Cout_pad / TC) * cnm_ceil_div(a.M, TP);
-    conv_mfma_f32_kernel<TC, TP, TS, F16><<<nblocks, 256, 0, s>>>(a);
+    conv_mfma_f32_kernel<TC, TP, TS><<<nblocks, 256, 0, s>>>(a);
 }
 
 // out_h/out_w > 0 selects the transposed (data-gradient) gather: `in` is then dy [N,.,H,W] and the output is
@@ -335,11 +470,11 @@ static int conv_dispatch(const float* in, int Gin_total, int gin0, int Gin,
     // Tile choice: largest tile that still gives every CU (256) a couple of workgroups.
     const long long t128 = (long long)(a.Cout_pad / 128) * cnm_ceil_div(a.M, 128);
     const long long t64x128 = (long long)(a.Cout_pad / 64) * cnm_ceil_div(a.M, 128);
-    if (f16) {
+    if (f16) {                                                                 // fp16: every layer on the LDS-DMA kernel (measured faster down to 6x8 images)
         CNM_REQUIRE(!transposed, CNM_ERR_BAD_ARG);
-        if (a.Cout_pad % 128 == 0 && t128 >= 512) launch_conv<128, 128, 1, true>(a, s);
-        else if (t64x128 >= 512) launch_conv<64, 128, 1, true>(a, s);
-        else launch_conv<64, 64, 1, true>(a, s);
+        a.nk = (ksize * ksize * 8 * Gin + 63) / 64;                            // k-steps of 64 halfs
+        if (a.Cout_pad % 128 == 0) conv_f16_glds_kernel<128, 256><<<(unsigned)((a.Cout_pad / 128) * cnm_ceil_div(a.M, 256)), 512, 0, s>>>(a);
+        else conv_f16_glds_kernel<64, 512><<<(unsigned)((a.Cout_pad / 64) * cnm_ceil_div(a.M, 512)), 512, 0, s>>>(a);
     } else if (transposed && tstride == 2) {
         if (a.Cout_pad % 128 == 0 && t128 >= 512) launch_conv<128, 128, 2>(a, s);
         else if (t64x128 >= 512) launch_conv<64, 128, 2>(a, s);
@@ -428,10 +563,11 @@ __global__ void pack_conv_f16_kernel(const float* __restrict__ w, const float* _
                                      int Kpad, _Float16* __restrict__ wp) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)Kpad * Cout_pad) return;
-    const int kk = (int)(idx % 32);
-    const int co = (int)((idx / 32) % Cout_pad);
-    const int kstep = (int)((idx / 32) / Cout_pad);
-    const int k = kstep * 32 + kk;
+    // [k-step of 64][8 channel groups][Cout_pad][8 halfs]: the LDS image of conv_f16_glds_kernel, DMA piece by DMA piece
+    const int e = (int)(idx % 8);
+    const int co = (int)((idx / 8) % Cout_pad);
+    const int kgrp = (int)((idx / 8) / Cout_pad);           // kstep * 8 + group
+    const int k = kgrp * 8 + e;
     const int Cp = 8 * ((Cin + 7) / 8);
     const int tap = k / Cp, cp = k - tap * Cp;
     float v = 0.f;
@@ -444,7 +580,7 @@ __global__ void pack_conv_f16_kernel(const float* __restrict__ w, const float* _
     wp[idx] = (_Float16)v;
 }
 
-static inline int conv_kpad_f16(int Cin, int ks) { return ((ks * ks * 8 * ((Cin + 7) / 8) + 31) / 32) * 32; }
+static inline int conv_kpad_f16(int Cin, int ks) { return ((ks * ks * 8 * ((Cin + 7) / 8) + 63) / 64) * 64; }
 
 extern "C" size_t cnm_packed_conv_halfs(int Cout, int Cin, int ksize) {
     if (Cout <= 0 || Cin <= 0 || ksize <= 0) return 0;

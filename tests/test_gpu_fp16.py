@@ -33,6 +33,7 @@ def _load(module, seed):
 @pytest.mark.parametrize("cin,cout,k,stride,rot,N,H,W", [(67, 128, 7, 1, 3, 2, 24, 40), (128, 128, 7, 2, 0, 1, 32, 32),
                                                           (513, 256, 3, 1, 0, 1, 12, 20), (65, 64, 3, 1, 0, 3, 20, 28), (512, 512, 3, 2, 0, 2, 6, 8)])
 def test_conv_f16_vs_fp32_torch(dev, cin, cout, k, stride, rot, N, H, W):
+    """conv_f16_glds_kernel on small shapes: pixel tail, ragged K (9 / 65 channel groups), 64-cout tiles, stride 2, rotation."""
     from cnmnet_amd import ops
     rng = np.random.default_rng(cin + k)
     x = T(rng.standard_normal((N, cin, H, W)).astype(np.float32)); w = T((rng.standard_normal((cout, cin, k, k)) * 0.05).astype(np.float32))
