@@ -74,6 +74,6 @@ if __name__ == "__main__":
             wp, bp = ops.pack_conv_f16(torch.randn(L["Cout"], cin, L["ksize"], L["ksize"], device=dev) * 0.01)
             ms = time_call(lambda: ops.conv2d_c8(x, wp, bp, L["Cout"], L["ksize"], L["stride"], True))
             gflop = 2.0 * L["Cout"] * cin * L["ksize"] ** 2 * (h // L["stride"]) * (w // L["stride"]) * N / 1e9
-            if net == 0 and lv in (0, 2, 4) and L["stride"] == 1: print("f16 %-16s %8.3f ms %7.1f TFLOP/s" % (L["conv_key"], ms, gflop / ms))
+            print("f16 net%d %-18s cin %4d cout %4d k%d s%d %4dx%-4d %8.3f ms %7.1f TFLOP/s" % (net, L["conv_key"], cin, L["Cout"], L["ksize"], L["stride"], h, w, ms, gflop / ms))
             tot_g += gflop; tot_ms += ms
     print("f16 conv total %.1f GFLOP %.2f ms -> %.1f TFLOP/s" % (tot_g, tot_ms, tot_g / tot_ms))
