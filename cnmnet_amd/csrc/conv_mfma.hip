@@ -34,6 +34,7 @@ struct ConvArgs {
     const float* in; float* out; const float* w; const float* bias;
     const float* in2;            // optional second source: channel groups [Gsplit, Gin) (torch.cat without the copy)
     unsigned in_bytes, in2_bytes; // extents for the buffer descriptors (< 4 GB each)
+    unsigned w_bytes;             // packed filter bytes (LDS-DMA kernel: k-steps past the end read zeros)
     int Gin2_tot, gin2_0, Gsplit;
     int N, H, W, Ho, Wo;
     int Gin_tot, gin0, Gin;
@@ -219,25 +220,31 @@ __global__ __launch_bounds__(256, CONV_MINW) void conv_mfma_f32_kernel(const Con
 
 // ------------------------------------------------------------------ fp16 implicit GEMM fed by LDS-DMA
 // The fp16 matrix pipe is 16x faster than the fp32 one, so the loader above (global -> registers -> ds_write_b128, one
-// barrier per 32 halfs of depth, 128x128 tiles) is LDS-store bound at ~30 % of the pipe.  This kernel moves both operands
-// with buffer_load_dwordx4 ... lds (no VGPRs, no ds_write; an out-of-range offset -- zero padding, pixel tail, ragged K --
-// lands as zeros in LDS: tools/glds_probe.hip), 64 halfs of depth per barrier, 8 waves of 64 couts x 64 pixels each:
+// barrier per 64 bytes of depth) would be LDS-store bound at ~30 % of the pipe.  This kernel moves both operands with
+// buffer_load_dwordx4 ... lds (no VGPRs, no ds_write; an out-of-range offset -- zero padding, pixel tail, ragged K --
+// lands as zeros in LDS: tools/glds_probe.hip), 64 halfs of depth per barrier, 8 waves of WTC couts x WTP pixels each:
 //   LDS image of a k-step, per operand: [8 channel groups][rows][16 B]  (rows = couts / pixels)
 //     - a DMA piece is one group x 64 consecutive rows = 1 KB, lane-linear, and its (tap, channel group) is wave-uniform:
 //       wave w moves group w of every k-step (all its A and B pieces), the tap walk lives in SGPRs;
 //     - the MFMA fragment of lane (row = l & 31, k-half = l >> 5) for the k16 step s is the 16 bytes at
-//       [(2 s + k-half)][row]: 32 consecutive rows per half wave, conflict-free ds_read_b128.
+//       [(2 s + k-half)][row]: 32 consecutive rows per half wave, conflict-free ds_read_b128.  The reads are typed
+//       f16x8 on purpose: with float4 reads hipcc orders every first ds_read of a k-step behind s_waitcnt vmcnt(0), i.e.
+//       behind the DMA just issued for the NEXT steps (measured: 25-30 % slower).
 //   Weights are packed in exactly that order ([k-step][8 groups][Cout_pad][8 halfs]), so A pieces are contiguous.
-// Three LDS buffers (two for the 64 x 512 tile): the DMA of steps t+1 and t+2 is in flight under the MFMAs of step t,
-// one of them across the barrier (counted s_waitcnt vmcnt + raw s_barrier).
-template <int TC, int TP>
-__global__ __launch_bounds__(512) void conv_f16_glds_kernel(const ConvArgs a) {
-    constexpr int WC = TC / 64, WP = 8 / WC;
-    static_assert(TP == 64 * WP && (WC == 1 || WC == 2 || WC == 4), "8 waves of 64 x 64");
+// Three LDS buffers when they fit: the DMA of steps t+1 and t+2 is in flight under the MFMAs of step t, one of them
+// across the barrier (counted s_waitcnt vmcnt + raw s_barrier).  Tiles: 128 x 256 and 64 x 512 (waves of 64 x 64) for
+// the large layers, 64 x 128 (waves of 32 x 32, two workgroups per CU) where those would leave CUs without a workgroup.
+// (The same kernel on fp32 data -- four v_mfma_f32_32x32x2_f32 per fragment pair -- was measured on the fp32 engine's
+// implicit-GEMM layers: bit-identical, +21 % on conv4.3, -8 ... -20 % on the larger stride-2 layers, which are
+// matrix-pipe bound with the register-staged loader already; not kept.)
+template <int TC, int TP, int WTC, int WTP>
+__global__ __launch_bounds__(512) void conv_glds_kernel(const ConvArgs a) {
+    constexpr int WC = TC / WTC, WP = TP / WTP, CI = WTC / 32, PI = WTP / 32;
+    static_assert(WC * WP == 8 && TC % 64 == 0 && TP % 64 == 0 && WTC % 32 == 0 && WTP % 32 == 0, "8 waves");
     constexpr int AB = 8 * TC * 16, BB = 8 * TP * 16, BUF = AB + BB;   // bytes per operand image / per buffer
     constexpr int NPA = TC / 64, NPB = TP / 64;                         // DMA pieces of one group
     constexpr int NBUF = 3 * BUF <= 160 * 1024 ? 3 : 2;
-    __shared__ __attribute__((aligned(16))) char smem[NBUF * BUF];      // 144 KB: 3 x 48 KB (128 x 256) / 2 x 72 KB (64 x 512)
+    __shared__ __attribute__((aligned(16))) char smem[NBUF * BUF];      // 144 KB: 3 x 48 KB (128 x 256) / 2 x 72 KB (64 x 512); 72 KB for 64 x 128
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wc = wave / WP, wp = wave % WP;
     const int tilesC = a.Cout_pad / TC;
@@ -264,14 +271,14 @@ __global__ __launch_bounds__(512) void conv_f16_glds_kernel(const ConvArgs a) {
     auto tap_norm = [&]() { while (g >= a.Gin) { g -= a.Gin; if (++kx == a.ks) { kx = 0; ++ky; } } };
     tap_norm();
     const unsigned HW16 = (unsigned)HW * 16u;
-    const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, 0xFFFFFFFFu, 0x00020000);
-    const unsigned wlane = ((unsigned)c0 + (unsigned)lane) * 16u;      // byte offset of this lane's row inside a group of the packed filter
-    const unsigned wgroup = (unsigned)a.Cout_pad * 16u;                  // bytes per (k-step, group)
+    // filter [k-step][8 groups][Cout_pad][16 B]: a piece = 64 consecutive rows of one group
+    const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
+    const unsigned wlane = ((unsigned)c0 + (unsigned)lane) * 16u;
     typedef __attribute__((address_space(3))) void* lds_ptr;
     auto issue = [&](int kt, int buf) {                                 // DMA of k-step kt into buffer buf (this wave: group `wave`)
         char* A = smem + buf * BUF + wave * TC * 16;
         char* B = smem + buf * BUF + AB + wave * TP * 16;
-        const unsigned wsoff = (unsigned)(kt * 8 + wave) * wgroup;
+        const unsigned wsoff = (unsigned)(kt * 8 + wave) * (unsigned)a.Cout_pad * 16u;
 #pragma unroll
         for (int p = 0; p < NPA; ++p)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr)(A + p * 1024), 16, wlane + p * 1024u, wsoff, 0, 0);
@@ -288,40 +295,42 @@ __global__ __launch_bounds__(512) void conv_f16_glds_kernel(const ConvArgs a) {
         g += 8; tap_norm();
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[CI][PI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < CI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < PI; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int frow = lane & 31, kh = lane >> 5;
     auto compute = [&](int buf) {
-        const char* Ab = smem + buf * BUF + (kh * TC + wc * 64 + frow) * 16;
-        const char* Bb = smem + buf * BUF + AB + (kh * TP + wp * 64 + frow) * 16;
-        f16x8 af[2][2], bf[2][2];                                       // fragments of k16 step s + 1 are read under the MFMAs of step s
+        const char* Ab = smem + buf * BUF + (kh * TC + wc * WTC + frow) * 16;
+        const char* Bb = smem + buf * BUF + AB + (kh * TP + wp * WTP + frow) * 16;
+        f16x8 af[2][CI], bf[2][PI];                                     // fragments of group pair s + 1 are read under the MFMAs of pair s
 #pragma unroll
-        for (int i = 0; i < 2; ++i) { af[0][i] = *reinterpret_cast<const f16x8*>(Ab + 32 * i * 16); bf[0][i] = *reinterpret_cast<const f16x8*>(Bb + 32 * i * 16); }
+        for (int i = 0; i < CI; ++i) af[0][i] = *reinterpret_cast<const f16x8*>(Ab + 32 * i * 16);
+#pragma unroll
+        for (int j = 0; j < PI; ++j) bf[0][j] = *reinterpret_cast<const f16x8*>(Bb + 32 * j * 16);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             if (s < 3) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    af[(s + 1) & 1][i] = *reinterpret_cast<const f16x8*>(Ab + (2 * (s + 1) * TC + 32 * i) * 16);
-                    bf[(s + 1) & 1][i] = *reinterpret_cast<const f16x8*>(Bb + (2 * (s + 1) * TP + 32 * i) * 16);
-                }
+                for (int i = 0; i < CI; ++i) af[(s + 1) & 1][i] = *reinterpret_cast<const f16x8*>(Ab + (2 * (s + 1) * TC + 32 * i) * 16);
+#pragma unroll
+                for (int j = 0; j < PI; ++j) bf[(s + 1) & 1][j] = *reinterpret_cast<const f16x8*>(Bb + (2 * (s + 1) * TP + 32 * j) * 16);
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < CI; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s & 1][i], bf[s & 1][j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < PI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s & 1][i], bf[s & 1][j], acc[i][j], 0, 0, 0);
         }
-        // pin the order: the four fragment reads of step s + 1 are ISSUED before the four MFMAs of step s (left alone, the
-        // scheduler reuses one register set and every step waits out the LDS latency with an idle matrix pipe)
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        // pin the order: the fragment reads of pair s + 1 are ISSUED before the MFMAs of pair s (left alone, the scheduler
+        // reuses one register set and every step waits out the LDS latency with an idle matrix pipe)
+        constexpr int NR = CI + PI, NM = CI * PI;
+        __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
 #pragma unroll
-        for (int s = 0; s < 3; ++s) { __builtin_amdgcn_sched_group_barrier(0x100, 4, 0); __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); }
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        for (int s = 0; s < 3; ++s) { __builtin_amdgcn_sched_group_barrier(0x100, NR, 0); __builtin_amdgcn_sched_group_barrier(0x008, NM, 0); }
+        __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
     };
 
     // NBUF LDS buffers: the DMA of k-step kt + NBUF - 1 is issued before the MFMAs of step kt; with three buffers one
@@ -345,15 +354,15 @@ __global__ __launch_bounds__(512) void conv_f16_glds_kernel(const ConvArgs a) {
 
     // ---- epilogue: acc row = cout (r&3)+8*(r>>2)+4*(lane>>5), col = pixel lane&31
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int mm = m0 + wp * 64 + j * 32 + (lane & 31);
+    for (int j = 0; j < PI; ++j) {
+        const int mm = m0 + wp * WTP + j * 32 + (lane & 31);
         if (mm >= a.M) continue;
         const int img = mm / HoWo, pix = mm - img * HoWo;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < CI; ++i) {
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
-                const int c = c0 + wc * 64 + i * 32 + 8 * qd + 4 * (lane >> 5);
+                const int c = c0 + wc * WTC + i * 32 + 8 * qd + 4 * (lane >> 5);
                 if (c >= a.Cout) continue;
                 const float4 b = a.bias ? *reinterpret_cast<const float4*>(a.bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
                 float4 v = make_float4(acc[i][j][4 * qd + 0] + b.x, acc[i][j][4 * qd + 1] + b.y,
@@ -428,6 +437,23 @@ extern "C" int cnm_pack_conv_bn_f32(const float* w_oihw, const float* bn_gamma, 
     return CNM_OK;
 }
 
+// Tile choice of the LDS-DMA kernel (tools/f16_conv_probe.py): 128 x 256 (64 x 512 when Cout is not a multiple of 128)
+// unless it leaves most CUs without a workgroup (< 160 workgroups) or the reduction is so short (<= 12 k-steps, Cout = 64
+// layers) that prologue and epilogue dominate: then 64 x 128 with 32 x 32 wave tiles, two workgroups per CU.  g_glds_tile != 0 forces a tile (tests, probes).
+static int g_glds_tile = 0;
+extern "C" int cnm_tune_glds_tile(int n) { const int old = g_glds_tile; if (n >= 0 && n <= 3) g_glds_tile = n; return old; }
+static void launch_glds(const ConvArgs& a, hipStream_t s) {
+    auto wgs = [&](int tc, int tp) { return (long long)(a.Cout_pad / tc) * cnm_ceil_div(a.M, tp); };
+    const bool c128 = a.Cout_pad % 128 == 0;
+    const long long big = c128 ? wgs(128, 256) : wgs(64, 512);
+    int v = g_glds_tile;
+    if (v == 0) v = (big < 160 || (!c128 && a.nk <= 12)) ? 3 : c128 ? 1 : 2;
+    if (!c128 && v == 1) v = 2;
+    if (v == 1) conv_glds_kernel<128, 256, 64, 64><<<(unsigned)wgs(128, 256), 512, 0, s>>>(a);
+    else if (v == 2) conv_glds_kernel<64, 512, 64, 64><<<(unsigned)wgs(64, 512), 512, 0, s>>>(a);
+    else conv_glds_kernel<64, 128, 32, 32><<<(unsigned)wgs(64, 128), 512, 0, s>>>(a);
+}
+
 template <int TC, int TP, int TS = 1>
 static void launch_conv(const ConvArgs& a, hipStream_t s) {
     const int nblocks = (a.Cout_pad / TC) * cnm_ceil_div(a.M, TP);
@@ -473,8 +499,8 @@ static int conv_dispatch(const float* in, int Gin_total, int gin0, int Gin,
     if (f16) {                                                                 // fp16: every layer on the LDS-DMA kernel (measured faster down to 6x8 images)
         CNM_REQUIRE(!transposed, CNM_ERR_BAD_ARG);
         a.nk = (ksize * ksize * 8 * Gin + 63) / 64;                            // k-steps of 64 halfs
-        if (a.Cout_pad % 128 == 0) conv_f16_glds_kernel<128, 256><<<(unsigned)((a.Cout_pad / 128) * cnm_ceil_div(a.M, 256)), 512, 0, s>>>(a);
-        else conv_f16_glds_kernel<64, 512><<<(unsigned)((a.Cout_pad / 64) * cnm_ceil_div(a.M, 512)), 512, 0, s>>>(a);
+        a.w_bytes = (unsigned)((size_t)a.nk * 64 * a.Cout_pad * 2);
+        launch_glds(a, s);
     } else if (transposed && tstride == 2) {
         if (a.Cout_pad % 128 == 0 && t128 >= 512) launch_conv<128, 128, 2>(a, s);
         else if (t64x128 >= 512) launch_conv<64, 128, 2>(a, s);
@@ -563,7 +589,7 @@ __global__ void pack_conv_f16_kernel(const float* __restrict__ w, const float* _
                                      int Kpad, _Float16* __restrict__ wp) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)Kpad * Cout_pad) return;
-    // [k-step of 64][8 channel groups][Cout_pad][8 halfs]: the LDS image of conv_f16_glds_kernel, DMA piece by DMA piece
+    // [k-step of 64][8 channel groups][Cout_pad][8 halfs]: the LDS image of conv_glds_kernel, DMA piece by DMA piece
     const int e = (int)(idx % 8);
     const int co = (int)((idx / 8) % Cout_pad);
     const int kgrp = (int)((idx / 8) / Cout_pad);           // kstep * 8 + group

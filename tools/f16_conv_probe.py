@@ -1,5 +1,5 @@
-"""fp16 convolution layers at the bench shapes: register-staged kernel against the LDS-DMA kernel (cnm_tune_f16_glds_min_tiles),
-with the result of both checked against each other.  GPU box only."""
+"""fp16 convolution layers at the bench shapes on the LDS-DMA kernel: every tile variant (cnm_tune_glds_tile) against the
+automatic choice; results of the variants are checked against each other.  GPU box only."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,6 +13,7 @@ CASES = [  # (N, Cin, Cout, H, W, ksize, stride)
     (8, 256, 256, 96, 128, 3, 2), (8, 256, 512, 48, 64, 3, 1), (8, 512, 512, 48, 64, 3, 2),
     (8, 67, 128, 192, 256, 3, 1), (8, 128, 128, 192, 256, 3, 2), (8, 512, 256, 48, 64, 3, 1), (8, 256, 128, 96, 128, 3, 1), (8, 64, 64, 192, 256, 3, 1),
 ]
+NAMES = {0: "auto", 1: "128x256", 2: "64x512", 3: "64x128"}
 
 
 def bench(fn, iters=10):
@@ -25,20 +26,23 @@ def bench(fn, iters=10):
 
 
 lib = _lib.load(); dev = "cuda"
-tot = {0: 0.0, 1: 0.0}
+tot_auto = tot_best = 0.0
 for N, Cin, Cout, H, W, k, st in CASES:
     w = torch.randn(Cout, Cin, k, k, device=dev) * 0.02
     x = ops.nchw_to_c8(torch.randn(N, Cin, H, W, device=dev))
     wp, bp = ops.pack_conv_f16(w, None, torch.randn(Cout, device=dev))
     fn = lambda: ops.conv2d_c8(x, wp, bp, Cout, k, st, True)
-    res = {}
-    for mode, thr in ((0, 1 << 30), (1, 1)):
-        lib.cnm_tune_f16_glds_min_tiles(thr)
-        y = fn(); torch.cuda.synchronize()
-        res[mode] = (bench(fn), y.float())
-        tot[mode] += res[mode][0]
-    diff = (res[0][1] - res[1][1]).abs().max().item()
+    res, ref = {}, None
+    for v in ([1, 3, 0] if Cout % 128 == 0 else [2, 3, 0]):
+        lib.cnm_tune_glds_tile(v)
+        y = fn().float(); torch.cuda.synchronize()
+        ref = y if ref is None else ref
+        assert float((y - ref).abs().max()) == 0.0, (v, float((y - ref).abs().max()))
+        res[v] = bench(fn)
+    lib.cnm_tune_glds_tile(0)
     gf = 2.0 * Cout * Cin * k * k * (H // st) * (W // st) * N / 1e9
-    print("N%2d %4d->%4d k%d s%d %3dx%-3d: staged %.3f ms (%4.0f TF)  glds %.3f ms (%4.0f TF)  %+.1f %%  maxdiff %.2e (max %.1f)" % (
-        N, Cin, Cout, k, st, H, W, res[0][0], gf / res[0][0], res[1][0], gf / res[1][0], 100 * (res[0][0] / res[1][0] - 1), diff, res[0][1].abs().max().item()))
-print("total staged %.2f ms, glds %.2f ms" % (tot[0], tot[1]))
+    best = min((t, v) for v, t in res.items() if v)
+    tot_auto += res[0]; tot_best += best[0]
+    print("N%2d %4d->%4d k%d s%d %3dx%-3d: auto %.3f ms (%4.0f TF) | " % (N, Cin, Cout, k, st, H, W, res[0], gf / res[0]) +
+          "  ".join("%s %.3f" % (NAMES[v], t) for v, t in res.items() if v) + " | best %s" % NAMES[best[1]])
+print("total auto %.2f ms, best-of %.2f ms" % (tot_auto, tot_best))
