@@ -25,13 +25,16 @@ struct WgradArgs {
     int ks, stride, pad, Kflat, Kpad128, M, pix_per_split;
 };
 
+// TCO = couts per workgroup: 128 (waves 2 x 2, 64 x 64 each) or 64 (waves 1 x 4, 64 couts x 32 k each) for the 64-cout
+// layers, where a 128-row tile would spend half of its MFMAs on padding rows.
+template <int TCO>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
-    constexpr int LDK = 20;
-    __shared__ __attribute__((aligned(16))) float smem[2 * 256 * LDK];
-    float* As = smem;                 // [2][128 co][LDK pix]
-    float* Bs = smem + 2 * 128 * LDK; // [2][128 k ][LDK pix]
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wc = wave >> 1, wp = wave & 1;
-    const int c0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
+    constexpr int LDK = 20, WK = TCO == 128 ? 2 : 4, PJ = 4 / WK;          // waves along k, 32-column blocks per wave
+    __shared__ __attribute__((aligned(16))) float smem[2 * (TCO + 128) * LDK];
+    float* As = smem;                 // [2][TCO co][LDK pix]
+    float* Bs = smem + 2 * TCO * LDK; // [2][128 k ][LDK pix]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wc = wave / WK, wp = wave % WK;
+    const int c0 = blockIdx.x * TCO, k0 = blockIdx.y * 128;
     const int HW = a.H * a.W, HoWo = a.Ho * a.Wo;
     const int r0 = blockIdx.z * a.pix_per_split, r1 = min(r0 + a.pix_per_split, a.M);
 
@@ -41,7 +44,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int q = (t >> 4) + 16 * i;
-        aq[i] = c0 / 4 + q; aok[i] = (c0 + 4 * q) < a.Cout;
+        aq[i] = c0 / 4 + q; aok[i] = 4 * q < TCO && (c0 + 4 * q) < a.Cout;
         const int kq = k0 / 4 + q;                                  // flat k-quad -> (tap, channel group): fixed per thread
         const int tap = kq / a.Gin;
         bgc[i] = kq - tap * a.Gin; bky[i] = tap / a.ks; bkx[i] = tap - bky[i] * a.ks;
@@ -50,11 +53,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     // running output-pixel coordinate of this thread's pixel lane
     int m = r0 + pl, img = m / HoWo, rem = m - img * HoWo, oy = rem / a.Wo, ox = rem - oy * a.Wo;
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][PJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < PJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -78,8 +81,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = 4 * ((t >> 4) + 16 * i);
-            float* pa = As + ((size_t)buf * 128 + row) * LDK + pl;
-            pa[0] = ra[i].x; pa[LDK] = ra[i].y; pa[2 * LDK] = ra[i].z; pa[3 * LDK] = ra[i].w;
+            if (row < TCO) {
+                float* pa = As + ((size_t)buf * TCO + row) * LDK + pl;
+                pa[0] = ra[i].x; pa[LDK] = ra[i].y; pa[2 * LDK] = ra[i].z; pa[3 * LDK] = ra[i].w;
+            }
             float* pb = Bs + ((size_t)buf * 128 + row) * LDK + pl;
             pb[0] = rb[i].x; pb[LDK] = rb[i].y; pb[2 * LDK] = rb[i].z; pb[3 * LDK] = rb[i].w;
         }
@@ -92,17 +97,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
         for (int st = 0; st < nsteps; ++st) {
             const int buf = st & 1;
             if (st + 1 < nsteps) load();
-            const float* Ab = As + ((size_t)buf * 128 + wc * 64 + frow) * LDK + fk;
-            const float* Bb = Bs + ((size_t)buf * 128 + wp * 64 + frow) * LDK + fk;
+            const float* Ab = As + ((size_t)buf * TCO + wc * 64 + frow) * LDK + fk;
+            const float* Bb = Bs + ((size_t)buf * 128 + wp * 32 * PJ + frow) * LDK + fk;
 #pragma unroll
             for (int kg = 0; kg < 2; ++kg) {
-                float4 af[2], bf[2];
+                float4 af[2], bf[PJ];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) { af[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDK + kg * 8); bf[i] = *reinterpret_cast<const float4*>(Bb + i * 32 * LDK + kg * 8); }
+                for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDK + kg * 8);
+#pragma unroll
+                for (int j = 0; j < PJ; ++j) bf[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDK + kg * 8);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
+                    for (int j = 0; j < PJ; ++j) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
@@ -118,8 +125,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int k = k0 + (wp * 2 + j) * 32 + (lane & 31);
+        for (int j = 0; j < PJ; ++j) {
+            const int k = k0 + (wp * PJ + j) * 32 + (lane & 31);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = c0 + (wc * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -149,10 +156,12 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int split
 #endif
 static inline int wg_round(int v, int m) { return (v + m - 1) / m * m; }
 
+static inline int wgrad_tco(int Cout) { return wg_round(Cout, 64) % 128 ? 64 : 128; }   // couts per workgroup
 static void wgrad_plan(int Cout, int Cin, int ksize, int M, int* Cout_pad, int* Kpad128, int* splits, int* pps) {
-    *Cout_pad = wg_round(Cout, 128);
+    const int tco = wgrad_tco(Cout);
+    *Cout_pad = wg_round(Cout, tco);
     *Kpad128 = wg_round(ksize * ksize * 4 * ((Cin + 3) / 4), 128);
-    const int tiles = (*Cout_pad / 128) * (*Kpad128 / 128);
+    const int tiles = (*Cout_pad / tco) * (*Kpad128 / 128);
     int s = (CNM_WGRAD_WORKGROUPS + tiles - 1) / tiles;       // aim at that many workgroups (1024 and 512 measured slower)
     const int maxs = (M + 255) / 256;                         // at least 256 pixels per split
     if (s > maxs) s = maxs;
@@ -186,8 +195,8 @@ extern "C" int cnm_conv2d_wgrad_c4_f32(const float* x, int Gx_total, int gx0, in
     const unsigned long long xb = (unsigned long long)N * Gx_total * H * W * 16ull, yb = (unsigned long long)N * Gy_total * a.Ho * a.Wo * 16ull;
     CNM_REQUIRE(xb < 0xFFFFFFFFull && yb < 0xFFFFFFFFull, CNM_ERR_BAD_ARG);
     a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)yb;
-    dim3 grid(a.Cout_pad / 128, a.Kpad128 / 128, splits);
-    conv_wgrad_kernel<<<grid, 256, 0, cnm_stream(stream)>>>(a);
+    if (wgrad_tco(Cout) == 128) conv_wgrad_kernel<128><<<dim3(a.Cout_pad / 128, a.Kpad128 / 128, splits), 256, 0, cnm_stream(stream)>>>(a);
+    else conv_wgrad_kernel<64><<<dim3(a.Cout_pad / 64, a.Kpad128 / 128, splits), 256, 0, cnm_stream(stream)>>>(a);
     const long long total = (long long)Cout * a.Kflat;
     wgrad_reduce_kernel<<<(unsigned)cnm_ceil_div_ll(total, 256), 256, 0, cnm_stream(stream)>>>(
         ws, splits, Cout, a.Cout_pad, Cin, ksize, rot, a.Kpad128, dw_oihw);
@@ -334,6 +343,13 @@ __global__ void bn_param_grad_kernel(const double* __restrict__ sums, int C, flo
     dbeta[c] = (float)sums[2 * c]; dgamma[c] = (float)sums[2 * c + 1];
 }
 
+// The fp64 sum buffers are cleared by a kernel, not hipMemsetAsync: captured into a HIP graph (TrainStepWoNormal(graph=True))
+// the memset node took effect on the first replay only -- later replays accumulated onto the previous sums.
+__global__ void bn_zero_kernel(double* __restrict__ p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0.0;
+}
+
 static int bn_grid_y(int N, int HW) { long long t = ((long long)N * HW + 255) / 256; return (int)(t < 64 ? (t < 1 ? 1 : t) : 64); }
 
 extern "C" int cnm_bn_train_forward_c4_f32(const float* x, const float* gamma, const float* beta,
@@ -343,7 +359,7 @@ extern "C" int cnm_bn_train_forward_c4_f32(const float* x, const float* gamma, c
     CNM_REQUIRE(x && gamma && beta && y && save_mean && save_invstd && stats_ws && N > 0 && C > 0 && H > 0 && W > 0, CNM_ERR_BAD_ARG);
     const int G = (C + 3) / 4, HW = H * W;
     hipStream_t s = cnm_stream(stream);
-    if (hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * 4 * G, s) != hipSuccess) return CNM_ERR_LAUNCH;
+    bn_zero_kernel<<<cnm_ceil_div(8 * G, 256), 256, 0, s>>>(stats_ws, 8 * G);
     bn_stats_kernel<<<dim3(G, bn_grid_y(N, HW)), 256, 0, s>>>(x, N, G, HW, stats_ws);
     bn_finalize_kernel<<<cnm_ceil_div(C, 256), 256, 0, s>>>(stats_ws, C, (double)N * HW, eps, momentum, save_mean, save_invstd, running_mean, running_var);
     const long long total = (long long)N * G * HW;
@@ -359,7 +375,7 @@ extern "C" int cnm_bn_train_backward_c4_f32(const float* x, const float* y, cons
     CNM_REQUIRE(x && y && dy && gamma && save_mean && save_invstd && dx && dgamma && dbeta && sums_ws && N > 0 && C > 0, CNM_ERR_BAD_ARG);
     const int G = (C + 3) / 4, HW = H * W;
     hipStream_t s = cnm_stream(stream);
-    if (hipMemsetAsync(sums_ws, 0, sizeof(double) * 2 * 4 * G, s) != hipSuccess) return CNM_ERR_LAUNCH;
+    bn_zero_kernel<<<cnm_ceil_div(8 * G, 256), 256, 0, s>>>(sums_ws, 8 * G);
     bn_bwd_reduce_kernel<<<dim3(G, bn_grid_y(N, HW)), 256, 0, s>>>(x, y, dy, save_mean, save_invstd, C, relu, N, G, HW, sums_ws);
     const long long total = (long long)N * G * HW;
     bn_bwd_apply_kernel<<<(int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384), 256, 0, s>>>(

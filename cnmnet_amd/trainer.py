@@ -91,40 +91,118 @@ class BucketedGradAllReduce:
 
 def _masked_l1(pred, gt, dist=None, weight=None, exact=False):
     """IdepthLoss / IdepthwithProbLoss (reference losses.py:30-73), optionally normalised by the global
-    mask count so that averaging the per-rank gradients equals the gathered-batch loss."""
+    mask count so that averaging the per-rank gradients equals the gathered-batch loss.
+    Static shapes: the reference gathers `pred[mask]` (a device-to-host synchronisation per loss term, which stops the
+    host from enqueueing the backward pass while the forward pass still runs); here masked-out elements are replaced by
+    zeros BEFORE the difference (so a non-finite ground truth never reaches the arithmetic or the gradient) and the sum
+    is divided by the mask count -- the same mean, NaN for an empty mask (0 / 0) as the reference's mean of nothing."""
     m = _valid(pred, gt)
-    diff = (pred[m] - gt[m]).abs()
+    zero = torch.zeros((), dtype=pred.dtype, device=pred.device)
+    diff = (torch.where(m, pred, zero) - torch.where(m, gt, zero)).abs()
     if weight is not None:
-        diff = diff * weight[m]
+        diff = diff * torch.where(m, weight, zero)
+    n = m.sum().to(pred.dtype)
     if exact and dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
-        n = torch.tensor([float(diff.numel())], device=pred.device)
+        n = n.reshape(1).clone()
         dist.all_reduce(n)
         return diff.sum() / (n[0] / dist.get_world_size()).clamp(min=1.0)
-    return diff.mean()
+    return diff.sum() / n
+
+
+def _log_values(logs):
+    """dict of scalar tensors -> dict of floats with ONE device-to-host copy."""
+    keys = list(logs)
+    vals = torch.stack([logs[k].detach().float().reshape(()) for k in keys]).tolist()
+    return dict(zip(keys, vals))
 
 
 class TrainStepWoNormal:
-    """One optimisation step of `train_wo_normal` (reference train.py:509-562)."""
+    """One optimisation step of `train_wo_normal` (reference train.py:509-562).
 
-    def __init__(self, depth_net, refine_net, lr=1e-4, weight_decay=1e-5, dist=None, exact_masked_means=False):
+    graph=True (one GPU, no collective): forward, backward and the Adam update are captured ONCE per input shape into a
+    HIP graph and replayed -- the step's ~2900 kernel launches and ~700 small torch operations no longer pass through
+    Python, which is what bounds the eager step (the GPU waits for the host in the low-resolution layers).  Same
+    arithmetic as the eager step: every loss term has static shapes (`_masked_l1`), the capture's warm-up iterations are
+    undone in place (parameters, BatchNorm statistics, Adam state) before the first replay."""
+
+    def __init__(self, depth_net, refine_net, lr=1e-4, weight_decay=1e-5, dist=None, exact_masked_means=False, graph=False):
         self.depth_net, self.refine_net, self.dist, self.exact = depth_net, refine_net, dist, exact_masked_means
         params = list(refine_net.parameters()) + list(depth_net.parameters())              # train.py:87, :446
-        self.optimizer = torch.optim.Adam(params, lr=lr, weight_decay=weight_decay)       # utils/misc.py:31-33
+        self.optimizer = torch.optim.Adam(params, lr=lr, weight_decay=weight_decay, capturable=bool(graph))   # utils/misc.py:31-33
         self.reducer = None
         if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
             self.reducer = BucketedGradAllReduce(params, dist)
+        if graph and self.reducer is not None:
+            raise ValueError("graph=True captures one GPU's step; the gradient all-reduce stays outside a captured region")
         self.l234 = IdepthLoss_234()
+        self.graph_mode, self._graph, self._graph_key = bool(graph), None, None
 
     def __call__(self, rgbs, cameras, disparities, depths, warmup_epoch=False):
         """rgbs [B,3,3,H,W] (ref, src1, src2), cameras [B,3,2,4,4], disparities / depths [B,V,1,H,W]
         (ground truth of the reference view at index 0).  Returns a dict of detached scalars."""
+        if self.graph_mode:
+            return self._graphed_step((rgbs, cameras, disparities, depths), bool(warmup_epoch))
         loss, logs = self.losses(rgbs, cameras, disparities, depths, warmup_epoch)
         self.optimizer.zero_grad(set_to_none=False)                                          # :562-565
         loss.backward()
         if self.reducer is not None:
             self.reducer.finish()
         self.optimizer.step()
-        return {k: float(v.detach()) for k, v in logs.items()}
+        return _log_values(logs)
+
+    # ---- HIP-graph replay of the step
+    def _graphed_step(self, inputs, warmup_epoch):
+        key = (tuple(tuple(t.shape) for t in inputs), warmup_epoch)
+        if self._graph_key != key:
+            self._capture(inputs, warmup_epoch, key)
+        for dst, src in zip(self._static_in, inputs):
+            dst.copy_(src)
+        self._graph.replay()
+        return _log_values(self._static_logs)
+
+    def _state_tensors(self):
+        """Every tensor one step mutates: parameters, BatchNorm buffers, Adam moments and step counters."""
+        out = [p.data for g in self.optimizer.param_groups for p in g["params"]]
+        out += [b for net in (self.depth_net, self.refine_net) for b in net.buffers()]
+        for st in self.optimizer.state.values():
+            out += [v for v in st.values() if torch.is_tensor(v)]
+        return out
+
+    def _capture(self, inputs, warmup_epoch, key):
+        self._static_in = [t.detach().clone() for t in inputs]
+        had_state = len(self.optimizer.state) > 0
+        saved = [t.clone() for t in self._state_tensors()] if had_state else \
+                [t.clone() for t in [p.data for g in self.optimizer.param_groups for p in g["params"]] +
+                 [b for net in (self.depth_net, self.refine_net) for b in net.buffers()]]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                       # warm-up off the default stream: Adam state and allocator pools exist before capture
+            for _ in range(2):
+                loss, logs = self.losses(*self._static_in, warmup_epoch)
+                self.optimizer.zero_grad(set_to_none=True)
+                loss.backward()
+                self.optimizer.step()
+                del loss, logs                              # no autograd graph of the warm-up may outlive it (its AccumulateGrad nodes carry their stream)
+        torch.cuda.current_stream().wait_stream(side)
+        self.optimizer.zero_grad(set_to_none=True)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            loss, logs = self.losses(*self._static_in, warmup_epoch)
+            loss.backward()
+            self.optimizer.step()
+        self._static_logs = {k: v.detach() for k, v in logs.items()}
+        del loss, logs
+        # undo the warm-up in place (the graph holds these addresses): the first replay is the first real step
+        live = self._state_tensors()
+        if had_state:
+            for t, s0 in zip(live, saved):
+                t.copy_(s0)
+        else:
+            for t, s0 in zip(live[:len(saved)], saved):
+                t.copy_(s0)
+            for t in live[len(saved):]:                     # Adam moments and step counters created by the warm-up
+                t.zero_()
+        self._graph_key = key
 
     def losses(self, rgbs, cameras, disparities, depths, warmup_epoch=False):
         """Train-mode forward of both nets on one batch (shard) and the loss mix of train.py:522-559:
@@ -218,7 +296,7 @@ class TrainStep(TrainStepWoNormal):
         if self.reducer is not None:
             self.reducer.finish()
         self.optimizer.step()
-        return {k: float(v.detach()) for k, v in logs.items()}
+        return _log_values(logs)
 
     def losses(self, rgbs, cameras, disparities, depths, normals):
         """Train-mode forward and the loss mix of train.py:164-304: (loss to back-propagate, dict of logged terms)."""

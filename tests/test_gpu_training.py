@@ -171,6 +171,32 @@ def test_trainer_steps_and_first_loss_vs_oracle(dev):
     assert torch.isfinite(o[0]).all()
 
 
+def test_graphed_train_step_equals_eager(dev):
+    """TrainStepWoNormal(graph=True): the captured step replayed on three different batches (then re-captured for a new
+    shape) against the eager step from the same initial weights -- logged losses, every parameter and the BatchNorm
+    statistics; the capture's warm-up iterations must leave no trace.  Both sides use Adam's capturable arithmetic (the
+    net is sensitive enough that the 1e-7 differences between Adam's two code paths grow to 1e-4 within two steps)."""
+    from cnmnet_amd.depthnet import depthNet, DepthRefineNet
+    from cnmnet_amd.trainer import TrainStepWoNormal, synthetic_training_sample
+    mk = lambda graph: TrainStepWoNormal(_load(depthNet(3.0), 71).to(dev), _load(DepthRefineNet(32, 3.0), 72).to(dev), lr=1e-4, graph=graph)
+    eager, graphed = mk(False), mk(True)
+    eager.optimizer = torch.optim.Adam(list(eager.refine_net.parameters()) + list(eager.depth_net.parameters()), lr=1e-4, weight_decay=1e-5, capturable=True)
+    batches = [synthetic_training_sample(2, 64, 96, seed=s) for s in (3, 4, 5)] + [synthetic_training_sample(1, 64, 64, seed=6)]
+    for b in batches:
+        sd = {k: v.to(dev) for k, v in b.items()}
+        le = eager(sd["rgbs"], sd["cameras"], sd["disparities"], sd["depths"])
+        lg = graphed(sd["rgbs"], sd["cameras"], sd["disparities"], sd["depths"])
+        for k in le:
+            assert np.isfinite(lg[k]) and abs(le[k] - lg[k]) <= 1e-5 * max(1.0, abs(le[k])), (k, le[k], lg[k])
+    for (n, pe), pg in zip(list(eager.depth_net.named_parameters()) + list(eager.refine_net.named_parameters()),
+                           list(graphed.depth_net.parameters()) + list(graphed.refine_net.parameters())):
+        assert float((pe - pg).abs().max()) <= 1e-6, (n, float((pe - pg).abs().max()))          # four Adam steps of 1e-4 each
+    for net_e, net_g in ((eager.depth_net, graphed.depth_net), (eager.refine_net, graphed.refine_net)):
+        be, bg = dict(net_e.named_buffers()), dict(net_g.named_buffers())
+        for n in be:
+            assert torch.allclose(be[n].float(), bg[n].float(), rtol=1e-5, atol=1e-6), n
+
+
 @pytest.mark.parametrize("k", [9, 5])
 def test_depth2normal_backward(dev, golden, k):
     """K6 backward vs torch autograd through the oracle's Unfold formulation in fp64 (same fixture as the

@@ -6,7 +6,8 @@ from cnmnet_amd.depthnet import depthNet, DepthRefineNet
 from cnmnet_amd.trainer import TrainStepWoNormal, synthetic_training_sample
 dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-step = TrainStepWoNormal(depthNet(3.0).to(dev), DepthRefineNet(32, 3.0).to(dev))
+GRAPH = len(sys.argv) > 2 and sys.argv[2] == "graph"
+step = TrainStepWoNormal(depthNet(3.0).to(dev), DepthRefineNet(32, 3.0).to(dev), graph=GRAPH)
 s = {k: v.to(dev) for k, v in synthetic_training_sample(B, 192, 256, seed=1).items()}
 for _ in range(2):
     log = step(s["rgbs"], s["cameras"], s["disparities"], s["depths"])
@@ -15,4 +16,4 @@ n = 5
 for _ in range(n):
     log = step(s["rgbs"], s["cameras"], s["disparities"], s["depths"])
 torch.cuda.synchronize(); dt = (time.perf_counter() - t) / n
-print("train step B=%d: %.1f ms -> %.1f samples/s  (loss %.4f, peak mem %.2f GB)" % (B, dt * 1e3, B / dt, log["loss"], torch.cuda.max_memory_allocated() / 2**30))
+print("train step%s B=%d: %.1f ms -> %.1f samples/s  (loss %.4f, peak mem %.2f GB)" % (" (HIP graph)" if GRAPH else "", B, dt * 1e3, B / dt, log["loss"], torch.cuda.max_memory_allocated() / 2**30))
