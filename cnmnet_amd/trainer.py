@@ -265,9 +265,9 @@ def get_warped_depth_loss(depth_refined, gt_depth_src, pose, intrinsic, intrinsi
         from .depthnet.inverse_warp import inverse_warp
     warped = inverse_warp(gt_depth_src.unsqueeze(1), depth_refined, pose, intrinsic, intrinsic_inv).squeeze(1)
     m = (warped > 0) & torch.isfinite(warped) & torch.isfinite(depth_refined) & (depth_refined > 0)
-    if not bool(m.any()):
-        return depth_refined.sum() * 0.0
-    return (warped[m] - depth_refined[m]).abs().mean()
+    zero = torch.zeros((), dtype=warped.dtype, device=warped.device)
+    diff = (torch.where(m, warped, zero) - torch.where(m, depth_refined, zero)).abs()
+    return diff.sum() / m.sum().to(warped.dtype).clamp(min=1.0)          # empty mask: 0 with a zero gradient; no host synchronisation
 
 
 class TrainStep(TrainStepWoNormal):

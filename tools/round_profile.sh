@@ -24,6 +24,12 @@ python3 tools/pmc_mfma.py "$O/pmc_mfma" "$O/pmc_mfma_util.txt" > /dev/null
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES --output-format csv -d "$O/pmc_valu" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-secondary --no-live-traffic > "$O/pmc_valu.log" 2>&1
 python3 tools/pmc_summary.py "$O/pmc_valu" | grep -i "planesweep" > "$O/pmc_planesweep_valu.txt" || true
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_train" -- python3 tools/train_bench.py > "$O/train_bench.txt" 2> "$O/train_bench.err" || true
+sed -i 's/$/   [under rocprofv3]/' "$O/train_bench.txt"
+timeout 300 python3 tools/train_bench.py 4 2>/dev/null | tail -1 >> "$O/train_bench.txt" || true
+timeout 300 python3 tools/train_bench.py 4 graph 2>/dev/null | tail -1 >> "$O/train_bench.txt" || true
+timeout 600 python3 tools/wgrad_sweep.py > "$O/wgrad_sweep.txt" 2>/dev/null || true
+timeout 600 python3 tools/f16_conv_probe.py > "$O/f16_conv_probe.txt" 2>/dev/null || true
+bash tools/f16_profile.sh > /dev/null 2>&1 || true
 f=$(find "$O/stats_train" -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" "$O/train_kernel_stats.csv"
 rm -rf "$O"/pmc_FETCH_SIZE "$O"/pmc_WRITE_SIZE "$O"/pmc_mfma "$O"/pmc_valu "$O"/stats_train
 ls -la "$O"; head -c 1500 "$O/bench_line.json"; echo; head -6 "$O/bench_kernel_stats_serial.csv" | cut -c1-160; cat "$O/pmc_planesweep_valu.txt"
