@@ -18,6 +18,8 @@ Prints ONE JSON line (rank 0).  Extra objects:
   step_ms            per-step HIP-event times on the launch stream: median, p10, p90 (the headline uses the wall clock)
   f16 / config4      secondary measurements (BASELINE configs[4] precision at the headline shape; configs[3] 640x480x96,
                      1 ref + 4 src, batch 4): frames/s, never the headline value
+  train              one GPU's shard of BASELINE configs[2]: the train_wo_normal optimisation step at batch 4 as a HIP
+                     graph, samples/s (secondary as well)
 """
 import argparse
 import json
@@ -371,12 +373,33 @@ def secondary(dev, precision, B, S, Hh, Ww, D, steps=10, warmup=3):
             "workload": "%d frames, 1 ref + %d src, %dx%d, %d planes" % (B, S, Ww, Hh, D)}
 
 
+def train_secondary(dev, B=4, steps=10):
+    """BASELINE configs[2] per-GPU shard: one `train_wo_normal` optimisation step (forward, backward, Adam) on B samples of
+    192x256 with 64 planes, replayed as a HIP graph; samples/s between synchronisations."""
+    from cnmnet_amd.depthnet import depthNet, DepthRefineNet
+    from cnmnet_amd.trainer import TrainStepWoNormal, synthetic_training_sample
+    step = TrainStepWoNormal(load_weights(depthNet(3.0, PLANES), 1).to(dev), load_weights(DepthRefineNet(32, 3.0), 2).to(dev), graph=True)
+    s = {k: v.to(dev) for k, v in synthetic_training_sample(B, H, W, seed=7).items()}
+    a = (s["rgbs"], s["cameras"], s["disparities"], s["depths"])
+    for _ in range(2):                                   # the first call captures
+        log = step(*a)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        log = step(*a)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    assert log["loss"] == log["loss"], "training loss is NaN"
+    return {"value": B / dt, "unit": "samples/s", "ms_per_step": 1e3 * dt, "dtype": "f32",
+            "workload": "train_wo_normal step (forward + backward + Adam as one HIP graph), batch %d, 1 ref + 2 src, %dx%d, %d planes" % (B, W, H, PLANES)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--no-secondary", action="store_true", help="skip the f16 and config-4 secondary measurements")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the f16, config-4 and training-step secondary measurements")
     ap.add_argument("--frames-per-gpu", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -477,6 +500,8 @@ def main():
             torch.cuda.empty_cache()
             line["config4"] = dict(secondary(dev, "f32", 4, 4, 480, 640, 96, steps=5, warmup=2), dtype="f32",
                                    note="BASELINE configs[3]; plane sweep = 125.3 MB algorithmic per (ref, src) pair")
+            torch.cuda.empty_cache()
+            line["train"] = dict(train_secondary(dev), note="BASELINE configs[2], one GPU's shard of 4 samples; parity: tests/test_gpu_training.py")
             torch.cuda.empty_cache()
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()

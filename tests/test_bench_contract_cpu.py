@@ -36,4 +36,6 @@ def test_committed_bench_line_contract():
     assert d["per_rank_frames_per_s"]["min"] <= d["per_rank_frames_per_s"]["max"]
     for k, dt in (("f16", "f16"), ("config4", "f32")):
         assert d[k]["unit"] == "frames/s" and d[k]["value"] > 0 and dt in d[k]["dtype"] and d[k]["value"] != d["value"]
+    if "train" in d:                                                       # added late in round 2
+        assert d["train"]["unit"] == "samples/s" and d["train"]["value"] > 0 and d["train"]["ms_per_step"] > 0
     assert " on " in c["sample"]                                           # "... threads (...) on <CPU model>"
