@@ -18,8 +18,8 @@ Prints ONE JSON line (rank 0).  Extra objects:
   step_ms            per-step HIP-event times on the launch stream: median, p10, p90 (the headline uses the wall clock)
   f16 / config4      secondary measurements (BASELINE configs[4] precision at the headline shape; configs[3] 640x480x96,
                      1 ref + 4 src, batch 4): frames/s, never the headline value
-  train              one GPU's shard of BASELINE configs[2]: the train_wo_normal optimisation step at batch 4 as a HIP
-                     graph, samples/s (secondary as well)
+  train              one GPU's shard of BASELINE configs[2]: the `train` optimisation step (k = 9 normal losses) at batch 4
+                     as a HIP graph, samples/s (secondary as well)
 """
 import argparse
 import json
@@ -374,14 +374,15 @@ def secondary(dev, precision, B, S, Hh, Ww, D, steps=10, warmup=3):
 
 
 def train_secondary(dev, B=4, steps=10):
-    """BASELINE configs[2] per-GPU shard: one `train_wo_normal` optimisation step (forward, backward, Adam) on B samples of
-    192x256 with 64 planes, replayed as a HIP graph; samples/s between synchronisations."""
+    """BASELINE configs[2] per-GPU shard: one `train` optimisation step (train.py:164-310: forward of both nets, Depth2normal
+    k = 9 normal losses, warped-depth losses, backward, Adam) on B samples of 192x256 with 64 planes, replayed as a HIP
+    graph; samples/s between synchronisations."""
     from cnmnet_amd.depthnet import depthNet, DepthRefineNet
-    from cnmnet_amd.trainer import TrainStepWoNormal, synthetic_training_sample
-    step = TrainStepWoNormal(load_weights(depthNet(3.0, PLANES), 1).to(dev), load_weights(DepthRefineNet(32, 3.0), 2).to(dev), graph=True)
+    from cnmnet_amd.trainer import TrainStep, synthetic_training_sample
+    step = TrainStep(load_weights(depthNet(3.0, PLANES), 1).to(dev), load_weights(DepthRefineNet(32, 3.0), 2).to(dev), k_size=KSIZE, graph=True)
     s = {k: v.to(dev) for k, v in synthetic_training_sample(B, H, W, seed=7).items()}
-    a = (s["rgbs"], s["cameras"], s["disparities"], s["depths"])
-    for _ in range(2):                                   # the first call captures
+    a = (s["rgbs"], s["cameras"], s["disparities"], s["depths"], s["normals"])
+    for _ in range(3):                                   # the first call captures (its warm-up iterations are undone)
         log = step(*a)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -391,7 +392,8 @@ def train_secondary(dev, B=4, steps=10):
     dt = (time.perf_counter() - t0) / steps
     assert log["loss"] == log["loss"], "training loss is NaN"
     return {"value": B / dt, "unit": "samples/s", "ms_per_step": 1e3 * dt, "dtype": "f32",
-            "workload": "train_wo_normal step (forward + backward + Adam as one HIP graph), batch %d, 1 ref + 2 src, %dx%d, %d planes" % (B, W, H, PLANES)}
+            "workload": "`train` step (forward + normal / warped-depth losses with Depth2normal k=%d + backward + Adam, one HIP graph), "
+                        "batch %d, 1 ref + 2 src, %dx%d, %d planes" % (KSIZE, B, W, H, PLANES)}
 
 
 def main():

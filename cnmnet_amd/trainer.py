@@ -141,7 +141,8 @@ class TrainStepWoNormal:
         """rgbs [B,3,3,H,W] (ref, src1, src2), cameras [B,3,2,4,4], disparities / depths [B,V,1,H,W]
         (ground truth of the reference view at index 0).  Returns a dict of detached scalars."""
         if self.graph_mode:
-            return self._graphed_step((rgbs, cameras, disparities, depths), bool(warmup_epoch))
+            return self._graphed_step((rgbs, cameras, disparities, depths), bool(warmup_epoch),
+                                      lambda *a: self.losses(*a, warmup_epoch))
         loss, logs = self.losses(rgbs, cameras, disparities, depths, warmup_epoch)
         self.optimizer.zero_grad(set_to_none=False)                                          # :562-565
         loss.backward()
@@ -151,10 +152,11 @@ class TrainStepWoNormal:
         return _log_values(logs)
 
     # ---- HIP-graph replay of the step
-    def _graphed_step(self, inputs, warmup_epoch):
-        key = (tuple(tuple(t.shape) for t in inputs), warmup_epoch)
+    def _graphed_step(self, inputs, variant, fn):
+        """inputs: tensors copied into the graph's static buffers; fn(*static inputs) -> (loss, logs) is what gets captured."""
+        key = (tuple(tuple(t.shape) for t in inputs), variant)
         if self._graph_key != key:
-            self._capture(inputs, warmup_epoch, key)
+            self._capture(inputs, fn, key)
         for dst, src in zip(self._static_in, inputs):
             dst.copy_(src)
         self._graph.replay()
@@ -168,7 +170,7 @@ class TrainStepWoNormal:
             out += [v for v in st.values() if torch.is_tensor(v)]
         return out
 
-    def _capture(self, inputs, warmup_epoch, key):
+    def _capture(self, inputs, fn, key):
         self._static_in = [t.detach().clone() for t in inputs]
         had_state = len(self.optimizer.state) > 0
         saved = [t.clone() for t in self._state_tensors()] if had_state else \
@@ -178,7 +180,7 @@ class TrainStepWoNormal:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                       # warm-up off the default stream: Adam state and allocator pools exist before capture
             for _ in range(2):
-                loss, logs = self.losses(*self._static_in, warmup_epoch)
+                loss, logs = fn(*self._static_in)
                 self.optimizer.zero_grad(set_to_none=True)
                 loss.backward()
                 self.optimizer.step()
@@ -187,7 +189,7 @@ class TrainStepWoNormal:
         self.optimizer.zero_grad(set_to_none=True)
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
-            loss, logs = self.losses(*self._static_in, warmup_epoch)
+            loss, logs = fn(*self._static_in)
             loss.backward()
             self.optimizer.step()
         self._static_logs = {k: v.detach() for k, v in logs.items()}
@@ -290,6 +292,9 @@ class TrainStep(TrainStepWoNormal):
         self.depth2normal, self.inverse_warp, self.intrinsics_inverse = depth2normal, inverse_warp, intrinsics_inverse
 
     def __call__(self, rgbs, cameras, disparities, depths, normals):
+        if self.graph_mode:                                  # the relative poses (a 4x4 inverse) are computed outside the captured region
+            return self._graphed_step((rgbs, cameras, disparities, depths, normals, self.relative_poses(cameras)), "normals",
+                                      lambda r, c, i, d, n, poses: self.losses(r, c, i, d, n, poses))
         loss, logs = self.losses(rgbs, cameras, disparities, depths, normals)
         self.optimizer.zero_grad(set_to_none=False)                                          # :307-310
         loss.backward()
@@ -298,11 +303,28 @@ class TrainStep(TrainStepWoNormal):
         self.optimizer.step()
         return _log_values(logs)
 
-    def losses(self, rgbs, cameras, disparities, depths, normals):
-        """Train-mode forward and the loss mix of train.py:164-304: (loss to back-propagate, dict of logged terms)."""
-        from .depthnet.losses import surface_normal_loss
+    @staticmethod
+    def relative_poses(cameras):
+        """[B,2,3,4]: reference camera -> source view v = 1, 2 (train.py:284-286); inv_ex: no device-to-host error check."""
+        ref_inv = torch.linalg.inv_ex(cameras[:, 0, 0], check_errors=False)[0]
+        return torch.stack([(cameras[:, v, 0] @ ref_inv)[:, :3, :] for v in (1, 2)], 1).contiguous()
+
+    @staticmethod
+    def _normal_terms(pred, gt, valid):
+        """Per-sample (sum of 1 - cos over the kept pixels, kept-pixel count) of `surface_normal_loss` (losses.py:76-122)."""
+        finite = torch.isfinite(gt.sum(1, keepdim=True)) & torch.isfinite(pred.sum(1, keepdim=True))
+        keep = finite & valid
+        zero = torch.zeros((), dtype=pred.dtype, device=pred.device)
+        sim = torch.nn.functional.cosine_similarity(torch.where(keep, pred, zero), torch.where(keep, gt, zero), dim=1)
+        k = keep.squeeze(1).to(sim.dtype)
+        return ((1 - sim) * k).flatten(1).sum(1), k.flatten(1).sum(1)
+
+    def losses(self, rgbs, cameras, disparities, depths, normals, poses=None):
+        """Train-mode forward and the loss mix of train.py:164-304: (loss to back-propagate, dict of logged terms).
+        Static shapes and no host decision: the reference's NaN guard (:275-280 -- a per-sample normal loss is NaN exactly
+        when a sample keeps no pixel, a mean over nothing) becomes a 0 / 1 factor on the device, with the per-sample means
+        computed on clamped counts so that the dropped terms contribute exact zeros to the gradients as well."""
         self.depth_net.train(); self.refine_net.train()
-        B = rgbs.shape[0]
         gt_id, gt_d, gt_n = disparities[:, 0], depths[:, 0], normals[:, 0]
         gt_n_valid = gt_d > 0.1                                                              # :153
         p01, f01 = self.depth_net(rgbs[:, 0], rgbs[:, 1], cameras[:, 0], cameras[:, 1])     # :164-167
@@ -320,24 +342,20 @@ class TrainStep(TrainStepWoNormal):
         nr, _ = self.depth2normal(dr, k_inv)
         loss_depth_1 = (L(d01.unsqueeze(1), gt_d) + L(d02.unsqueeze(1), gt_d)) * 0.5          # :217-218
         loss_depth_refined = L(dr.unsqueeze(1), gt_d)                                        # :220
-        ln, lnr = 0.0, 0.0
-        for i in range(B):                                                                   # :226-263 per-sample loop
-            a, _ = surface_normal_loss(n01[i:i + 1], gt_n[i:i + 1], gt_n_valid[i:i + 1])
-            b, _ = surface_normal_loss(n02[i:i + 1], gt_n[i:i + 1], gt_n_valid[i:i + 1])
-            c, _ = surface_normal_loss(nr[i:i + 1], gt_n[i:i + 1], gt_n_valid[i:i + 1])
-            ln = ln + (a + b) * 0.5; lnr = lnr + c
-        ln, lnr = ln / B, lnr / B                                                            # :268-269
-        if bool(torch.isnan(ln)) or bool(torch.isnan(lnr)):                                  # :275-280 NaN guard
-            loss = loss_idepth_1 + loss_depth_1 + loss_depth_refined + loss_idepth_refined
-        else:
-            loss = loss_idepth_1 + ln + loss_depth_1 + loss_depth_refined + loss_idepth_refined + lnr + prob_loss
+        (s1, c1), (s2, c2), (sr, cr) = (self._normal_terms(n, gt_n, gt_n_valid) for n in (n01, n02, nr))   # :226-263, per sample
+        ln = ((s1 / c1.clamp(min=1.0) + s2 / c2.clamp(min=1.0)) * 0.5).mean()                # :268-269
+        lnr = (sr / cr.clamp(min=1.0)).mean()
+        ok = (torch.minimum(torch.minimum(c1, c2), cr) > 0).all()                            # :275-280: no per-sample mean over nothing
+        zero = torch.zeros((), dtype=ln.dtype, device=ln.device)
+        loss = loss_idepth_1 + loss_depth_1 + loss_depth_refined + loss_idepth_refined + torch.where(ok, ln + lnr + prob_loss, zero)
         K = cameras[:, 0, 1, :3, :3].contiguous()
-        ref_inv = torch.linalg.inv(cameras[:, 0, 0])
-        for v in (1, 2):                                                                     # :284-293, :304
-            pose = (cameras[:, v, 0] @ ref_inv)[:, :3, :].contiguous()
-            loss = loss + get_warped_depth_loss(dr, depths[:, v, 0], pose, K, k_inv, self.inverse_warp)
-        return loss, {"loss": loss, "loss_normal": ln, "loss_normal_refined": lnr, "loss_depth_refined": loss_depth_refined,
-                      "prob_loss": prob_loss}
+        if poses is None:
+            poses = self.relative_poses(cameras)
+        for v in (0, 1):                                                                     # :284-293, :304
+            loss = loss + get_warped_depth_loss(dr, depths[:, v + 1, 0], poses[:, v].contiguous(), K, k_inv, self.inverse_warp)
+        nan = torch.full((), float("nan"), dtype=ln.dtype, device=ln.device)
+        return loss, {"loss": loss, "loss_normal": torch.where(ok, ln, nan), "loss_normal_refined": torch.where(ok, lnr, nan),
+                      "loss_depth_refined": loss_depth_refined, "prob_loss": prob_loss}
 
 
 # ------------------------------------------------------------------ epoch loop and checkpoints (train.py:59-140, :395-410)

@@ -257,6 +257,38 @@ def test_train_with_normals_step(dev):
             assert p.grad is not None and bool(torch.isfinite(p.grad).all()), k
 
 
+def test_train_with_normals_guard_and_graph(dev):
+    """`train` step: (i) the reference's NaN guard (train.py:275-280) as a device-side factor -- a sample without one valid
+    ground-truth normal drops the normal and probability terms, the loss and every gradient stay finite; (ii) the step
+    replayed as a HIP graph equals the eager step (same Adam arithmetic) on two different batches."""
+    from cnmnet_amd.depthnet import depthNet, DepthRefineNet
+    from cnmnet_amd.trainer import TrainStep, synthetic_training_sample
+    mk = lambda graph: TrainStep(_load(depthNet(3.0), 81).to(dev), _load(DepthRefineNet(32, 3.0), 82).to(dev), lr=1e-4, graph=graph)
+    s = {k: v.to(dev) for k, v in synthetic_training_sample(2, 64, 96, seed=5).items()}
+    bad = {k: v.clone() for k, v in s.items()}
+    bad["depths"][0, 0] = 0.05; bad["disparities"][0, 0] = 20.0                    # sample 0: ground truth closer than 0.1 m everywhere -> no valid normal
+    step = mk(False)
+    loss, logs = step.losses(bad["rgbs"], bad["cameras"], bad["disparities"], bad["depths"], bad["normals"])
+    assert np.isnan(float(logs["loss_normal"])) and np.isfinite(float(loss))
+    good_loss, good_logs = step.losses(s["rgbs"], s["cameras"], s["disparities"], s["depths"], s["normals"])
+    assert np.isfinite(float(good_logs["loss_normal"])) and float(good_logs["loss_normal"]) > 0
+    loss.backward()
+    for net in (step.depth_net, step.refine_net):
+        for k, p in net.named_parameters():
+            assert p.grad is None or bool(torch.isfinite(p.grad).all()), k
+    eager, graphed = mk(False), mk(True)
+    eager.optimizer = torch.optim.Adam(list(eager.refine_net.parameters()) + list(eager.depth_net.parameters()), lr=1e-4, weight_decay=1e-5, capturable=True)
+    for seed in (5, 6):
+        b = {k: v.to(dev) for k, v in synthetic_training_sample(2, 64, 96, seed=seed).items()}
+        a = (b["rgbs"], b["cameras"], b["disparities"], b["depths"], b["normals"])
+        le, lg = eager(*a), graphed(*a)
+        for k in le:
+            assert np.isfinite(lg[k]) and abs(le[k] - lg[k]) <= 1e-5 * max(1.0, abs(le[k])), (k, le[k], lg[k])
+    for pe, pg in zip(list(eager.depth_net.parameters()) + list(eager.refine_net.parameters()),
+                      list(graphed.depth_net.parameters()) + list(graphed.refine_net.parameters())):
+        assert float((pe - pg).abs().max()) <= 1e-6
+
+
 def test_scannet_loader_feeds_train_step(dev, tmp_path):
     """SURVEY 8f rank 3 end to end: ScanNet-shaped files -> cnmnet_amd.scannet loader (Resizer + ToTensor, source-view
     depths) -> the `train` step on the GPU; losses finite and decreasing on a repeated batch."""
