@@ -13,27 +13,46 @@ __device__ __forceinline__ void st8(float* base, size_t chunk_off, f16x8 v) {
 }
 
 // ------------------------------------------------------------------ bilinear x2
+// One thread per LOW-resolution (pixel, channel group): its 2 x 2 output pixels come from the 3 x 3 neighbourhood (9 loads
+// and 72 conversions per 4 outputs instead of 16 and 128; one 32-bit index decomposition per 4 outputs -- the
+// one-thread-per-output version with 64-bit div / mod ran at a third of the HBM rate).  Same expression per output as
+// nn.Upsample(scale_factor=2, mode='bilinear', align_corners=False): src = (dst + 0.5) / 2 - 0.5 clamped at 0, i.e. weights
+// 0.75 / 0.25, and weight 0 on the clamped neighbour at the first row / column.
 __global__ __launch_bounds__(256) void upsample2x_c8h_kernel(const float* __restrict__ in, int Gin_tot, int gin0,
                                                              float* __restrict__ out, int Gout_tot, int gout0,
                                                              int N, int G, int H, int W) {
     const int Wo = 2 * W, Ho = 2 * H;
-    const long long total = (long long)N * G * Ho * Wo;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-        const int ox = (int)(idx % Wo);
-        long long r = idx / Wo;
-        const int oy = (int)(r % Ho); r /= Ho;
-        const int g = (int)(r % G), n = (int)(r / G);
-        const float sy = fmaxf((oy + 0.5f) * 0.5f - 0.5f, 0.f), sx = fmaxf((ox + 0.5f) * 0.5f - 0.5f, 0.f);
-        const int y0 = (int)sy, x0 = (int)sx, y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
-        const float ly = sy - y0, lx = sx - x0, hy = 1.f - ly, hx = 1.f - lx;
+    const unsigned total = (unsigned)N * G * H * W;
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int x = (int)(idx % (unsigned)W);
+        unsigned r = idx / (unsigned)W;
+        const int y = (int)(r % (unsigned)H); r /= (unsigned)H;
+        const int g = (int)(r % (unsigned)G), n = (int)(r / (unsigned)G);
+        const int ym = max(y - 1, 0), yp = min(y + 1, H - 1), xm = max(x - 1, 0), xp = min(x + 1, W - 1);
         const size_t b = c4_offset(n, Gin_tot, gin0 + g, H * W, 0);
-        const f16x8 p00 = ld8(in, b + (size_t)(y0 * W + x0) * 4), p01 = ld8(in, b + (size_t)(y0 * W + x1) * 4);
-        const f16x8 p10 = ld8(in, b + (size_t)(y1 * W + x0) * 4), p11 = ld8(in, b + (size_t)(y1 * W + x1) * 4);
-        f16x8 v;
+        float p[3][3][8];
+        const int ys[3] = {ym, y, yp}, xs[3] = {xm, x, xp};
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            v[j] = (_Float16)(hy * (hx * (float)p00[j] + lx * (float)p01[j]) + ly * (hx * (float)p10[j] + lx * (float)p11[j]));
-        st8(out, c4_offset(n, Gout_tot, gout0 + g, Ho * Wo, oy * Wo + ox), v);
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const f16x8 v = ld8(in, b + (size_t)(ys[i] * W + xs[j]) * 4);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) p[i][j][c] = (float)v[c];
+            }
+        // output row 2y + a reads rows (a, a + 1) of the neighbourhood with ly = 0.75 / 0.25; at y = 0 the reference reads
+        // (row 0, row 1) with ly = 0 -- here (row 0, row 0) with ly = 0: the same value for finite data.  Columns alike.
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                const float ly = a ? 0.25f : (y > 0 ? 0.75f : 0.f), lx = bb ? 0.25f : (x > 0 ? 0.75f : 0.f), hy = 1.f - ly, hx = 1.f - lx;
+                f16x8 v;
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    v[c] = (_Float16)(hy * (hx * p[a][bb][c] + lx * p[a][bb + 1][c]) + ly * (hx * p[a + 1][bb][c] + lx * p[a + 1][bb + 1][c]));
+                st8(out, c4_offset(n, Gout_tot, gout0 + g, Ho * Wo, (2 * y + a) * Wo + 2 * x + bb), v);
+            }
     }
 }
 
@@ -41,7 +60,8 @@ extern "C" int cnm_upsample2x_c8_f16(const void* in, int Gin_total, int gin0, vo
                                      int N, int G, int H, int W, void* stream) {
     CNM_REQUIRE(in && out && N > 0 && G > 0 && H > 0 && W > 0, CNM_ERR_BAD_ARG);
     CNM_REQUIRE(gin0 >= 0 && gin0 + G <= Gin_total && gout0 >= 0 && gout0 + G <= Gout_total, CNM_ERR_BAD_ARG);
-    const long long total = (long long)N * G * 4 * H * W;
+    const long long total = (long long)N * G * H * W;
+    CNM_REQUIRE(total < (1ll << 31), CNM_ERR_BAD_ARG);
     upsample2x_c8h_kernel<<<(int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384), 256, 0, cnm_stream(stream)>>>(
         static_cast<const float*>(in), Gin_total, gin0, static_cast<float*>(out), Gout_total, gout0, N, G, H, W);
     CNM_LAUNCH_CHECK();

@@ -9,29 +9,41 @@
 // ------------------------------------------------------------------ bilinear x2 (c4)
 // src = (dst+0.5)/2 - 0.5 clamped at 0; i0 = floor, i1 = min(i0+1, n-1), lambda = src - i0
 // (torch upsample_bilinear2d, align_corners=False).
+// One thread per LOW-resolution (pixel, channel group): its 2 x 2 output pixels come from the 3 x 3 neighbourhood (9 loads
+// per 4 outputs instead of 16, one 32-bit index decomposition instead of four 64-bit ones).  Per output the expression of
+// nn.Upsample(scale_factor=2, mode='bilinear', align_corners=False): src = (dst + 0.5) / 2 - 0.5 clamped at 0, i.e. weights
+// 0.75 / 0.25; output row 2y + a reads neighbourhood rows (a, a + 1); at y = 0 the weight of the second row is 0 (the
+// reference reads row 1 there, this kernel row 0 again: the same value for finite data).  Columns alike.
 __global__ __launch_bounds__(256) void upsample2x_c4_kernel(const float* __restrict__ in, int Gin_tot, int gin0,
                                                             float* __restrict__ out, int Gout_tot, int gout0,
                                                             int N, int G, int H, int W) {
     const int Wo = 2 * W, Ho = 2 * H;
-    const long long total = (long long)N * G * Ho * Wo;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * blockDim.x) {
-        const int ox = (int)(idx % Wo);
-        long long r = idx / Wo;
-        const int oy = (int)(r % Ho); r /= Ho;
-        const int g = (int)(r % G), n = (int)(r / G);
-        const float sy = fmaxf((oy + 0.5f) * 0.5f - 0.5f, 0.f), sx = fmaxf((ox + 0.5f) * 0.5f - 0.5f, 0.f);
-        const int y0 = (int)sy, x0 = (int)sx;
-        const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
-        const float ly = sy - y0, lx = sx - x0, hy = 1.f - ly, hx = 1.f - lx;
+    const unsigned total = (unsigned)N * G * H * W;
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int x = (int)(idx % (unsigned)W);
+        unsigned r = idx / (unsigned)W;
+        const int y = (int)(r % (unsigned)H); r /= (unsigned)H;
+        const int g = (int)(r % (unsigned)G), n = (int)(r / (unsigned)G);
+        const int ys[3] = {max(y - 1, 0), y, min(y + 1, H - 1)}, xs[3] = {max(x - 1, 0), x, min(x + 1, W - 1)};
         const float4* base = reinterpret_cast<const float4*>(in + c4_offset(n, Gin_tot, gin0 + g, H * W, 0));
-        const float4 p00 = base[y0 * W + x0], p01 = base[y0 * W + x1], p10 = base[y1 * W + x0], p11 = base[y1 * W + x1];
-        float4 v;
-        v.x = hy * (hx * p00.x + lx * p01.x) + ly * (hx * p10.x + lx * p11.x);
-        v.y = hy * (hx * p00.y + lx * p01.y) + ly * (hx * p10.y + lx * p11.y);
-        v.z = hy * (hx * p00.z + lx * p01.z) + ly * (hx * p10.z + lx * p11.z);
-        v.w = hy * (hx * p00.w + lx * p01.w) + ly * (hx * p10.w + lx * p11.w);
-        *reinterpret_cast<float4*>(out + c4_offset(n, Gout_tot, gout0 + g, Ho * Wo, oy * Wo + ox)) = v;
+        float4 p[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) p[i][j] = base[ys[i] * W + xs[j]];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const float ly = a ? 0.25f : (y > 0 ? 0.75f : 0.f), lx = b ? 0.25f : (x > 0 ? 0.75f : 0.f), hy = 1.f - ly, hx = 1.f - lx;
+                const float4 p00 = p[a][b], p01 = p[a][b + 1], p10 = p[a + 1][b], p11 = p[a + 1][b + 1];
+                float4 v;
+                v.x = hy * (hx * p00.x + lx * p01.x) + ly * (hx * p10.x + lx * p11.x);
+                v.y = hy * (hx * p00.y + lx * p01.y) + ly * (hx * p10.y + lx * p11.y);
+                v.z = hy * (hx * p00.z + lx * p01.z) + ly * (hx * p10.z + lx * p11.z);
+                v.w = hy * (hx * p00.w + lx * p01.w) + ly * (hx * p10.w + lx * p11.w);
+                *reinterpret_cast<float4*>(out + c4_offset(n, Gout_tot, gout0 + g, Ho * Wo, (2 * y + a) * Wo + 2 * x + b)) = v;
+            }
     }
 }
 
@@ -40,7 +52,8 @@ extern "C" int cnm_upsample2x_c4_f32(const float* in, int Gin_total, int gin0,
                                      int N, int G, int H, int W, void* stream) {
     CNM_REQUIRE(in && out && N > 0 && G > 0 && H > 0 && W > 0, CNM_ERR_BAD_ARG);
     CNM_REQUIRE(gin0 >= 0 && gin0 + G <= Gin_total && gout0 >= 0 && gout0 + G <= Gout_total, CNM_ERR_BAD_ARG);
-    const long long total = (long long)N * G * 4 * H * W;
+    const long long total = (long long)N * G * H * W;                      // one thread per low-resolution (pixel, group)
+    CNM_REQUIRE(total < (1ll << 31), CNM_ERR_BAD_ARG);
     const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     upsample2x_c4_kernel<<<blocks, 256, 0, cnm_stream(stream)>>>(in, Gin_total, gin0, out, Gout_total, gout0, N, G, H, W);
     CNM_LAUNCH_CHECK();

@@ -370,6 +370,16 @@ def upsample2x_c4(x):
     return out
 
 
+def upsample2x_c8(x):
+    """fp16 c8 [N,G,H,W,8] -> [N,G,2H,2W,8]: nn.Upsample(scale_factor=2, mode='bilinear', align_corners=False)."""
+    x = x.contiguous()
+    N, G, H, W, _ = x.shape
+    out = torch.empty(N, G, 2 * H, 2 * W, 8, device=x.device, dtype=torch.float16)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().cnm_upsample2x_c8_f16(x.data_ptr(), G, 0, out.data_ptr(), G, 0, N, G, H, W, _stream()))
+    return out
+
+
 def head_sigmoid_c4(x, w_head, bias, scale, up_out=None, up_group=0):
     _dev(x, w_head, bias, up_out)
     N, G, H, W, _ = x.shape

@@ -60,6 +60,18 @@ def _conv_f16_case(dev, cin, cout, k, stride, rot, N, H, W):
     assert np.abs(got - want).max() < 1.5e-3 * scale, (np.abs(got - want).max(), scale)     # output rounding to fp16: 2^-11 relative
 
 
+@pytest.mark.parametrize("N,C,H,W", [(2, 24, 12, 20), (1, 8, 1, 1), (1, 16, 5, 7), (3, 40, 6, 1), (1, 8, 1, 9)])
+def test_upsample2x_c8_vs_torch(dev, N, C, H, W):
+    """fp16 bilinear x2 (one thread per low-resolution pixel) against F.interpolate on the fp16-rounded input: odd sizes,
+    single rows / columns (the clamped first and last neighbours)."""
+    from cnmnet_amd import ops
+    rng = np.random.default_rng(N * 100 + H * 10 + W)
+    x = T(rng.standard_normal((N, C, H, W)).astype(np.float32)).half().float()
+    want = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False).numpy()
+    got = ops.c8_to_nchw(ops.upsample2x_c8(ops.nchw_to_c8(x.to(dev))), C).cpu().numpy()
+    assert got.shape == want.shape and np.abs(got - want).max() < 1e-3 * max(1.0, np.abs(want).max())     # fp16 rounding of the output
+
+
 def test_frame_f16_vs_fp32_oracle(dev, golden):
     from cnmnet_amd.depthnet import depthNet, DepthRefineNet
     from cnmnet_amd.pipeline import FramePipeline
