@@ -92,3 +92,22 @@ def test_frame_f16_vs_fp32_oracle(dev, golden):
     assert np.abs(disp.cpu().numpy() - gr["disp_refined"]).max() < 6e-2 and np.abs(prob.cpu().numpy() - gr["prob_map"]).max() < 2e-2
     assert float((out["disp"] - disp).abs().max()) < 1e-6 and float((out["prob"] - prob).abs().max()) < 1e-6   # both routes agree
     assert torch.isfinite(out["normal"]).all()
+
+
+@pytest.mark.parametrize("B,S,H,W,D", [(2, 2, 96, 160, 32), (1, 2, 224, 352, 64)])
+def test_f16_engine_other_sizes_vs_f32_engine(dev, B, S, H, W, D):
+    """fp16 frame pipeline against the fp32 one at sizes whose pyramid levels have odd / non-power-of-two widths (352 ->
+    176, 88, 44, 22, 11) and another plane count: the LDS-DMA kernel's pixel tails and tile choices."""
+    from cnmnet_amd.depthnet import depthNet, DepthRefineNet
+    from cnmnet_amd.pipeline import FramePipeline
+    img, cams = syn.frames(B, S, H, W, seed=11)
+    img, cams = T(img).to(dev), T(cams).to(dev)
+    outs = {}
+    for prec in ("f32", "f16"):
+        pipe = FramePipeline(_load(depthNet(3.0, D, precision=prec), 1).to(dev), _load(DepthRefineNet(32, 3.0, precision=prec), 2).to(dev), k_size=9, normals=True)
+        with torch.no_grad():
+            outs[prec] = pipe(img, cams)
+    d = (outs["f32"]["disp"] - outs["f16"]["disp"]).abs()
+    assert float(d.max()) < 5e-2 and float(d.mean()) < 1e-3, (float(d.max()), float(d.mean()))      # [0, 3] range
+    assert float((outs["f32"]["prob"] - outs["f16"]["prob"]).abs().max()) < 5e-2
+    assert bool(torch.isfinite(outs["f16"]["normal"]).all())
