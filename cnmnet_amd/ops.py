@@ -391,6 +391,18 @@ def head_sigmoid_c4(x, w_head, bias, scale, up_out=None, up_group=0):
     return disp
 
 
+def head_sigmoid_c8(x, w_head, bias, scale, up_out=None, up_group=0):
+    """fp16 twin of head_sigmoid_c4: x [N,G,H,W,8] half, w_head from pack_head (fp32) -> disp [N,1,H,W] fp32."""
+    x = x.contiguous()
+    N, G, H, W, _ = x.shape
+    disp = torch.empty(N, 1, H, W, device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().cnm_head_sigmoid_c8_f16(x.data_ptr(), G, 0, 8 * G, _p(w_head), _p(bias), float(scale), _p(disp),
+                                                       up_out.data_ptr() if up_out is not None else None,
+                                                       up_out.shape[1] if up_out is not None else 0, up_group, N, H, W, _stream()))
+    return disp
+
+
 def depth2normal(depth, intrinsic_inv, k_size=9, input_is_idepth=False):
     """depth [B,H,W], K^-1 [B,3,3] -> (normal [B,3,H,W], points [B,3,H,W])   (depth_util.py:149-203)"""
     _dev(depth, intrinsic_inv)

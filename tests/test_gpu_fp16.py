@@ -72,6 +72,26 @@ def test_upsample2x_c8_vs_torch(dev, N, C, H, W):
     assert got.shape == want.shape and np.abs(got - want).max() < 1e-3 * max(1.0, np.abs(want).max())     # fp16 rounding of the output
 
 
+@pytest.mark.parametrize("N,C,H,W", [(2, 64, 192, 256), (8, 64, 100, 130), (2, 64, 24, 40), (1, 256, 12, 20)])
+def test_head_sigmoid_c8_vs_torch(dev, N, C, H, W):
+    """fp16 disparity head (3x3 conv to one channel + bias + scaled sigmoid) against torch on the fp16-rounded input: the
+    4-slice and the 16-slice kernel, ragged pixel tails; plus the nearest x2 copy into a channel group of a wider tensor.
+    (A port of the fp32 engine's row-walking head was measured on this path: 50 us against 45 us per launch -- half the
+    bytes per texel leave the nine-fold L1 re-read cheaper than the DPP shifts; not kept.)"""
+    from cnmnet_amd import ops
+    rng = np.random.default_rng(C + H)
+    x = T(rng.standard_normal((N, C, H, W)).astype(np.float32)).half().float()
+    w = T((rng.standard_normal((1, C, 3, 3)) * 0.05).astype(np.float32)); b = T(np.array([0.1], np.float32))
+    want = (3.0 * torch.sigmoid(F.conv2d(x, w, b, padding=1))).numpy()
+    up = torch.full((N, 3, 2 * H, 2 * W, 8), 7.0, device=dev, dtype=torch.float16)
+    got = ops.head_sigmoid_c8(ops.nchw_to_c8(x.to(dev)), ops.pack_head(w.to(dev)), b.to(dev), 3.0, up, 1)
+    assert np.abs(got.cpu().numpy() - want).max() < 2e-5 * 3.0
+    upn = up.float().cpu().numpy()
+    assert (upn[:, 0] == 7.0).all() and (upn[:, 2] == 7.0).all() and (upn[:, 1, :, :, 1:] == 0.0).all()
+    near = np.repeat(np.repeat(want[:, 0], 2, axis=1), 2, axis=2)
+    assert np.abs(upn[:, 1, :, :, 0] - near).max() < 2e-3 * 3.0                                        # fp16 rounding of the copy
+
+
 def test_frame_f16_vs_fp32_oracle(dev, golden):
     from cnmnet_amd.depthnet import depthNet, DepthRefineNet
     from cnmnet_amd.pipeline import FramePipeline
