@@ -232,8 +232,9 @@ __global__ __launch_bounds__(256, CONV_MINW) void conv_mfma_f32_kernel(const Con
 //       behind the DMA just issued for the NEXT steps (measured: 25-30 % slower).
 //   Weights are packed in exactly that order ([k-step][8 groups][Cout_pad][8 halfs]), so A pieces are contiguous.
 // Three LDS buffers when they fit: the DMA of steps t+1 and t+2 is in flight under the MFMAs of step t, one of them
-// across the barrier (counted s_waitcnt vmcnt + raw s_barrier).  Tiles: 128 x 256 and 64 x 512 (waves of 64 x 64) for
-// the large layers, 64 x 128 (waves of 32 x 32, two workgroups per CU) where those would leave CUs without a workgroup.
+// across the barrier (counted s_waitcnt vmcnt + raw s_barrier).  Tiles: 128 x 256 and 64 x 512 (waves of 64 x 64), the
+// larger 256 x 256 (waves of 128 x 64) and 128 x 512 (64 x 128) where they fill whole rounds of workgroups, and 64 x 128
+// (waves of 32 x 32, two workgroups per CU) where the others would leave CUs without a workgroup.
 // (The same kernel on fp32 data -- four v_mfma_f32_32x32x2_f32 per fragment pair -- was measured on the fp32 engine's
 // implicit-GEMM layers: bit-identical, +21 % on conv4.3, -8 ... -20 % on the larger stride-2 layers, which are
 // matrix-pipe bound with the register-staged loader already; not kept.)
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(const ConvArgs a) {
     constexpr int AB = 8 * TC * 16, BB = 8 * TP * 16, BUF = AB + BB;   // bytes per operand image / per buffer
     constexpr int NPA = TC / 64, NPB = TP / 64;                         // DMA pieces of one group
     constexpr int NBUF = 3 * BUF <= 160 * 1024 ? 3 : 2;
-    __shared__ __attribute__((aligned(16))) char smem[NBUF * BUF];      // 144 KB: 3 x 48 KB (128 x 256) / 2 x 72 KB (64 x 512); 72 KB for 64 x 128
+    __shared__ __attribute__((aligned(16))) char smem[NBUF * BUF];      // 144 KB: 3 x 48 KB (128 x 256) / 2 x 72 KB (64 x 512); 72 KB for 64 x 128; 2 x 64 KB (256 x 256), 2 x 80 KB (128 x 512)
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wc = wave / WP, wp = wave % WP;
     const int tilesC = a.Cout_pad / TC;
@@ -437,21 +438,36 @@ extern "C" int cnm_pack_conv_bn_f32(const float* w_oihw, const float* bn_gamma, 
     return CNM_OK;
 }
 
-// Tile choice of the LDS-DMA kernel (tools/f16_conv_probe.py): 128 x 256 (64 x 512 when Cout is not a multiple of 128)
-// unless it leaves most CUs without a workgroup (< 160 workgroups) or the reduction is so short (<= 12 k-steps, Cout = 64
-// layers) that prologue and epilogue dominate: then 64 x 128 with 32 x 32 wave tiles, two workgroups per CU.  g_glds_tile != 0 forces a tile (tests, probes).
+// Tile choice of the LDS-DMA kernel (tools/f16_conv_probe.py).  Base tile 128 x 256 (64 x 512 when Cout is not a multiple
+// of 128).  If that leaves most CUs without a workgroup (< 160 workgroups) or the reduction is so short (<= 12 k-steps, Cout =
+// 64 layers) that prologue and epilogue dominate: 64 x 128 with 32 x 32 wave tiles, two workgroups per CU.  Otherwise the
+// larger tiles 256 x 256 (waves of 128 x 64; Cout a multiple of 256) and 128 x 512 (waves of 64 x 128; stride 1) are taken
+// when rounds-of-256-workgroups x tile work / measured efficiency (1.2 and 1.12 against 1.0: fewer operand bytes and
+// fragment reads per MFMA) comes out lower -- i.e. when the larger tile does not end in a mostly empty last round.
+// g_glds_tile != 0 forces a tile (tests, probes): 1 128x256, 2 64x512, 3 64x128, 4 128x512, 5 256x256.
 static int g_glds_tile = 0;
-extern "C" int cnm_tune_glds_tile(int n) { const int old = g_glds_tile; if (n >= 0 && n <= 3) g_glds_tile = n; return old; }
+extern "C" int cnm_tune_glds_tile(int n) { const int old = g_glds_tile; if (n >= 0 && n <= 5) g_glds_tile = n; return old; }
 static void launch_glds(const ConvArgs& a, hipStream_t s) {
     auto wgs = [&](int tc, int tp) { return (long long)(a.Cout_pad / tc) * cnm_ceil_div(a.M, tp); };
-    const bool c128 = a.Cout_pad % 128 == 0;
+    const bool c128 = a.Cout_pad % 128 == 0, c256 = a.Cout_pad % 256 == 0;
     const long long big = c128 ? wgs(128, 256) : wgs(64, 512);
     int v = g_glds_tile;
-    if (v == 0) v = (big < 160 || (!c128 && a.nk <= 12)) ? 3 : c128 ? 1 : 2;
-    if (!c128 && v == 1) v = 2;
+    if (v == 0) {
+        v = (big < 160 || (!c128 && a.nk <= 12)) ? 3 : c128 ? 1 : 2;
+        if (v == 1) {
+            auto cost = [&](int tc, int tp, double work, double eff) { return (double)((wgs(tc, tp) + 255) / 256) * work / eff; };
+            double best = cost(128, 256, 1.0, 1.0);
+            if (c256 && cost(256, 256, 2.0, 1.2) < best) { best = cost(256, 256, 2.0, 1.2); v = 5; }
+            if (a.stride == 1 && cost(128, 512, 2.0, 1.12) < best) v = 4;
+        }
+    }
+    if (!c128 && (v == 1 || v == 4 || v == 5)) v = 2;
+    if (v == 5 && !c256) v = 1;
     if (v == 1) conv_glds_kernel<128, 256, 64, 64><<<(unsigned)wgs(128, 256), 512, 0, s>>>(a);
     else if (v == 2) conv_glds_kernel<64, 512, 64, 64><<<(unsigned)wgs(64, 512), 512, 0, s>>>(a);
-    else conv_glds_kernel<64, 128, 32, 32><<<(unsigned)wgs(64, 128), 512, 0, s>>>(a);
+    else if (v == 3) conv_glds_kernel<64, 128, 32, 32><<<(unsigned)wgs(64, 128), 512, 0, s>>>(a);
+    else if (v == 4) conv_glds_kernel<128, 512, 64, 128><<<(unsigned)wgs(128, 512), 512, 0, s>>>(a);
+    else conv_glds_kernel<256, 256, 128, 64><<<(unsigned)wgs(256, 256), 512, 0, s>>>(a);
 }
 
 template <int TC, int TP, int TS = 1>

@@ -50,8 +50,8 @@ int cnm_tune_refine_side_stream(int on);
  *   tensor's round trip; n <= 0 only queries, INT_MAX switches the fused path off. */
 int cnm_tune_upsampled_min_pixels(int n);
 /* glds_tile: tile (couts x pixels) of the LDS-DMA implicit-GEMM kernel: 0 (default) = chosen per layer from its
- *   workgroup count and reduction depth; 1 / 2 / 3 force 128x256 / 64x512 / 64x128 (1 falls back to 2 when Cout is not a
- *   multiple of 128); any other n only queries. */
+ *   workgroup count, stride and reduction depth; 1 .. 5 force 128x256 / 64x512 / 64x128 / 128x512 / 256x256 (falling back
+ *   to 64x512 when Cout is not a multiple of 128, to 128x256 when 256x256 does not divide it); any other n only queries. */
 int cnm_tune_glds_tile(int n);
 
 typedef enum cnm_status {

@@ -13,7 +13,7 @@ CASES = [  # (N, Cin, Cout, H, W, ksize, stride)
     (8, 256, 256, 96, 128, 3, 2), (8, 256, 512, 48, 64, 3, 1), (8, 512, 512, 48, 64, 3, 2),
     (8, 67, 128, 192, 256, 3, 1), (8, 128, 128, 192, 256, 3, 2), (8, 512, 256, 48, 64, 3, 1), (8, 256, 128, 96, 128, 3, 1), (8, 64, 64, 192, 256, 3, 1),
 ]
-NAMES = {0: "auto", 1: "128x256", 2: "64x512", 3: "64x128"}
+NAMES = {0: "auto", 1: "128x256", 2: "64x512", 3: "64x128", 4: "128x512", 5: "256x256"}
 
 
 def bench(fn, iters=10):
@@ -33,7 +33,7 @@ for N, Cin, Cout, H, W, k, st in CASES:
     wp, bp = ops.pack_conv_f16(w, None, torch.randn(Cout, device=dev))
     fn = lambda: ops.conv2d_c8(x, wp, bp, Cout, k, st, True)
     res, ref = {}, None
-    for v in ([1, 3, 0] if Cout % 128 == 0 else [2, 3, 0]):
+    for v in ([1, 3, 4] + ([5] if Cout % 256 == 0 else []) + [0] if Cout % 128 == 0 else [2, 3, 0]):
         lib.cnm_tune_glds_tile(v)
         y = fn().float(); torch.cuda.synchronize()
         ref = y if ref is None else ref
