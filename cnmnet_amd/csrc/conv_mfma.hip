@@ -445,6 +445,11 @@ extern "C" int cnm_pack_conv_bn_f32(const float* w_oihw, const float* bn_gamma, 
 // when rounds-of-256-workgroups x tile work / measured efficiency (1.2 and 1.12 against 1.0: fewer operand bytes and
 // fragment reads per MFMA) comes out lower -- i.e. when the larger tile does not end in a mostly empty last round.
 // g_glds_tile != 0 forces a tile (tests, probes): 1 128x256, 2 64x512, 3 64x128, 4 128x512, 5 256x256.
+static int lds_per_block() {                                            // bytes of LDS one workgroup may use on the current device
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return v;
+}
 static int g_glds_tile = 0;
 extern "C" int cnm_tune_glds_tile(int n) { const int old = g_glds_tile; if (n >= 0 && n <= 5) g_glds_tile = n; return old; }
 static void launch_glds(const ConvArgs& a, hipStream_t s) {
@@ -458,7 +463,7 @@ static void launch_glds(const ConvArgs& a, hipStream_t s) {
             auto cost = [&](int tc, int tp, double work, double eff) { return (double)((wgs(tc, tp) + 255) / 256) * work / eff; };
             double best = cost(128, 256, 1.0, 1.0);
             if (c256 && cost(256, 256, 2.0, 1.2) < best) { best = cost(256, 256, 2.0, 1.2); v = 5; }
-            if (a.stride == 1 && cost(128, 512, 2.0, 1.12) < best) v = 4;
+            if (a.stride == 1 && lds_per_block() >= 160 * 1024 && cost(128, 512, 2.0, 1.12) < best) v = 4;   // that tile takes all 160 KB
         }
     }
     if (!c128 && (v == 1 || v == 4 || v == 5)) v = 2;
