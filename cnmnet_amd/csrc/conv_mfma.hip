@@ -23,12 +23,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef CONV_MINW
 #define CONV_MINW 1           // __launch_bounds__ min waves per SIMD (register cap)
 #endif
-#ifndef CONV_SETPRIO
-#define CONV_SETPRIO 0
-#endif
-#ifndef CONV_PIN
-#define CONV_PIN 0            // 1: pin load -> MFMA -> LDS-store order inside a k-step (measured slower)
-#endif
 
 struct ConvArgs {
     const float* in; float* out; const float* w; const float* bias;
@@ -159,7 +153,6 @@ __global__ __launch_bounds__(256, CONV_MINW) void conv_mfma_f32_kernel(const Con
     do {                                                                                                           \
         const float* Ab = As + ((size_t)(BUF) * TC + wc * (CI * 32) + frow) * LDK + fk;                            \
         const float* Bb = Bs + ((size_t)(BUF) * TP + wp * (PI * 32) + frow) * LDK + fk;                            \
-        if (CONV_SETPRIO) __builtin_amdgcn_s_setprio(1);                                                           \
         _Pragma("unroll") for (int kg = 0; kg < BK / 8; ++kg) {                                                    \
             float4 af[CI], bf[PI];                                                                                 \
             _Pragma("unroll") for (int i = 0; i < CI; ++i) af[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDK + kg * 8); \
@@ -172,7 +165,6 @@ __global__ __launch_bounds__(256, CONV_MINW) void conv_mfma_f32_kernel(const Con
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);        \
                 }                                                                                                  \
         }                                                                                                          \
-        if (CONV_SETPRIO) __builtin_amdgcn_s_setprio(0);                                                           \
     } while (0)
 
     CONV_LOAD_GLOBAL(0);
@@ -181,13 +173,7 @@ __global__ __launch_bounds__(256, CONV_MINW) void conv_mfma_f32_kernel(const Con
     for (int kt = 0; kt + 1 < a.nk; ++kt) {            // steady state: one basic block per k-step
         const int buf = kt & 1;
         CONV_LOAD_GLOBAL(kt + 1);                      // issue first: a whole k-step of MFMAs hides the latency
-#if CONV_PIN
-        __builtin_amdgcn_sched_barrier(0);
-#endif
         CONV_COMPUTE(buf);
-#if CONV_PIN
-        __builtin_amdgcn_sched_barrier(0);
-#endif
         CONV_STORE_LDS(buf ^ 1);
         __syncthreads();
     }
