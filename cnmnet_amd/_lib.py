@@ -54,6 +54,8 @@ PROTOTYPES = {
     "cnm_packed_upsampled_ring_floats": (c_sz, [c_i, c_i]),
     "cnm_pack_upsampled_ring_f32": (c_i, [c_fp, c_fp, c_fp, c_f, c_i, c_i, c_fp, c_fp]),
     "cnm_conv3x3_upsampled_ring_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp]),
+    "cnm_conv3x3_upsampled_c8_f16": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    "cnm_conv3x3_upsampled_ring_c8_f16": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp]),
     "cnm_pack_winograd5x5_bn_f32": (c_i, [c_fp, c_fp, c_fp, c_f, c_i, c_i, c_i, c_fp, c_fp]),
     "cnm_conv5x5_winograd_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp,
                                           c_i, c_i, c_i, c_i, c_fp]),

@@ -38,6 +38,7 @@ struct ConvArgs {
     int nk;          // Kpad / CONV_BK
     int M;           // N*Ho*Wo
     int relu;
+    int ring;        // fused upsampling (conv_glds_kernel<..., UPS>): 1 = leave the one-pixel output ring without bias / ReLU for the ring pass
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -224,7 +225,11 @@ __global__ __launch_bounds__(256, CONV_MINW) void conv_mfma_f32_kernel(const Con
 // (The same kernel on fp32 data -- four v_mfma_f32_32x32x2_f32 per fragment pair -- was measured on the fp32 engine's
 // implicit-GEMM layers: bit-identical, +21 % on conv4.3, -8 ... -20 % on the larger stride-2 layers, which are
 // matrix-pipe bound with the register-staged loader already; not kept.)
-template <int TC, int TP, int WTC, int WTP>
+// UPS: the fp32 engine's fused up_conv (conv_winograd4.hip) on this kernel -- a 3x3 convolution of the LOW-resolution input
+// with the four composed phase filters as 4 x Cr "virtual" output channels (phase major), window samples outside the image
+// clamped (replicate padding of the composition), the epilogue storing virtual channel (2a+b) Cr + c of low-resolution
+// pixel (y, x) to channel c of (2y+a, 2x+b); the one-pixel output ring is finished by cnm_conv3x3_upsampled_ring_c8_f16.
+template <int TC, int TP, int WTC, int WTP, bool UPS = false>
 __global__ __launch_bounds__(512) void conv_glds_kernel(const ConvArgs a) {
     constexpr int WC = TC / WTC, WP = TP / WTP, CI = WTC / 32, PI = WTP / 32;
     static_assert(WC * WP == 8 && TC % 64 == 0 && TP % 64 == 0 && WTC % 32 == 0 && WTP % 32 == 0, "8 waves");
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(const ConvArgs a) {
         const int img = mm / HoWo, rem = mm - img * HoWo;
         const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
         iy0[pb] = oy * a.stride - a.pad; ix0[pb] = ox * a.stride - a.pad;
-        const unsigned pix0 = (unsigned)(iy0[pb] * a.W + ix0[pb]);
+        const unsigned pix0 = UPS ? 0u : (unsigned)(iy0[pb] * a.W + ix0[pb]);   // UPS: the clamped tap position is added per k-step
         vb1[pb] = ((unsigned)(img * a.Gin_tot + a.gin0) * (unsigned)HW + pix0) * 16u;
         vb2[pb] = ((unsigned)(img * a.Gin2_tot + a.gin2_0) * (unsigned)HW + pix0) * 16u;
     }
@@ -275,8 +280,14 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(const ConvArgs a) {
 #pragma unroll
         for (int pb = 0; pb < NPB; ++pb) {
             const int iy = iy0[pb] + ky, ix = ix0[pb] + kx;
-            const bool ok = mval[pb] & ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)a.W);
-            const unsigned voff = ok ? (s1 ? vb1[pb] : vb2[pb]) + tapoff : 0xFFFFFFFFu;
+            unsigned voff;
+            if constexpr (UPS) {
+                const int cy = min(max(iy, 0), a.H - 1), cx = min(max(ix, 0), a.W - 1);
+                voff = mval[pb] ? vb1[pb] + (unsigned)(cy * a.W + cx) * 16u : 0xFFFFFFFFu;
+            } else {
+                const bool ok = mval[pb] & ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)a.W);
+                voff = ok ? (s1 ? vb1[pb] : vb2[pb]) + tapoff : 0xFFFFFFFFu;
+            }
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(B + pb * 1024), 16, voff, soff, 0, 0);
         }
         g += 8; tap_norm();
@@ -352,11 +363,21 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(const ConvArgs a) {
                 const int c = c0 + wc * WTC + i * 32 + 8 * qd + 4 * (lane >> 5);
                 if (c >= a.Cout) continue;
                 const float4 b = a.bias ? *reinterpret_cast<const float4*>(a.bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-                float4 v = make_float4(acc[i][j][4 * qd + 0] + b.x, acc[i][j][4 * qd + 1] + b.y,
-                                       acc[i][j][4 * qd + 2] + b.z, acc[i][j][4 * qd + 3] + b.w);
-                if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                float4 v = make_float4(acc[i][j][4 * qd + 0], acc[i][j][4 * qd + 1], acc[i][j][4 * qd + 2], acc[i][j][4 * qd + 3]);
+                int ogrp = c >> 3, opix = pix, oHW = HoWo, coff = (c & 4) * 2;
+                bool finish = true;
+                if constexpr (UPS) {                                    // virtual channel -> (phase, real channel); low-resolution pixel -> its phase pixel
+                    const int Cr = a.Cout >> 2, ph = c / Cr, cr = c - ph * Cr, y = pix / a.W, x = pix - y * a.W;
+                    const int Y = 2 * y + (ph >> 1), X = 2 * x + (ph & 1), Ho2 = 2 * a.H, Wo2 = 2 * a.W;
+                    ogrp = cr >> 3; coff = (cr & 4) * 2; opix = Y * Wo2 + X; oHW = 4 * HoWo;
+                    finish = !(a.ring && ((Y == 0) | (Y == Ho2 - 1) | (X == 0) | (X == Wo2 - 1)));   // ring pixels: bias and ReLU belong to the ring pass
+                }
+                if (finish) {
+                    v = make_float4(v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w);
+                    if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                }
                 const f16x4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};   // c8: channels c..c+3 = half of the 16-byte group c/8
-                char* o = reinterpret_cast<char*>(a.out + c4_offset(img, a.Gout_tot, a.gout0 + (c >> 3), HoWo, pix)) + (c & 4) * 2;
+                char* o = reinterpret_cast<char*>(a.out + c4_offset(img, a.Gout_tot, a.gout0 + ogrp, oHW, opix)) + coff;
                 *reinterpret_cast<f16x4*>(o) = h;
             }
         }
@@ -438,6 +459,7 @@ static int lds_per_block() {                                            // bytes
 }
 static int g_glds_tile = 0;
 extern "C" int cnm_tune_glds_tile(int n) { const int old = g_glds_tile; if (n >= 0 && n <= 5) g_glds_tile = n; return old; }
+template <bool UPS = false>
 static void launch_glds(const ConvArgs& a, hipStream_t s) {
     auto wgs = [&](int tc, int tp) { return (long long)(a.Cout_pad / tc) * cnm_ceil_div(a.M, tp); };
     const bool c128 = a.Cout_pad % 128 == 0, c256 = a.Cout_pad % 256 == 0;
@@ -454,11 +476,11 @@ static void launch_glds(const ConvArgs& a, hipStream_t s) {
     }
     if (!c128 && (v == 1 || v == 4 || v == 5)) v = 2;
     if (v == 5 && !c256) v = 1;
-    if (v == 1) conv_glds_kernel<128, 256, 64, 64><<<(unsigned)wgs(128, 256), 512, 0, s>>>(a);
-    else if (v == 2) conv_glds_kernel<64, 512, 64, 64><<<(unsigned)wgs(64, 512), 512, 0, s>>>(a);
-    else if (v == 3) conv_glds_kernel<64, 128, 32, 32><<<(unsigned)wgs(64, 128), 512, 0, s>>>(a);
-    else if (v == 4) conv_glds_kernel<128, 512, 64, 128><<<(unsigned)wgs(128, 512), 512, 0, s>>>(a);
-    else conv_glds_kernel<256, 256, 128, 64><<<(unsigned)wgs(256, 256), 512, 0, s>>>(a);
+    if (v == 1) conv_glds_kernel<128, 256, 64, 64, UPS><<<(unsigned)wgs(128, 256), 512, 0, s>>>(a);
+    else if (v == 2) conv_glds_kernel<64, 512, 64, 64, UPS><<<(unsigned)wgs(64, 512), 512, 0, s>>>(a);
+    else if (v == 3) conv_glds_kernel<64, 128, 32, 32, UPS><<<(unsigned)wgs(64, 128), 512, 0, s>>>(a);
+    else if (v == 4) conv_glds_kernel<128, 512, 64, 128, UPS><<<(unsigned)wgs(128, 512), 512, 0, s>>>(a);
+    else conv_glds_kernel<256, 256, 128, 64, UPS><<<(unsigned)wgs(256, 256), 512, 0, s>>>(a);
 }
 
 template <int TC, int TP, int TS = 1>
@@ -656,4 +678,32 @@ extern "C" int cnm_conv2d_cat2_c8_f16(const void* in_a, int Ga_total, int ga0, i
     return conv_dispatch(static_cast<const float*>(in_a), Ga_total, ga0, Ga + Gb, static_cast<const float*>(in_b), Gb_total, gb0, Ga,
                          static_cast<float*>(out), Gout_total, gout0, Cout, static_cast<const float*>(w_packed_f16), b_packed,
                          N, H, W, ksize, stride, relu, stream, 0, 0, 1, true);
+}
+
+// conv3x3(upsample2x(in)) + bias (+ ReLU) on fp16 c8 data without the upsampled tensor: in [N][Gin_total][H][W][8] ->
+// out [N][Gout_total][2H][2W][8]; w_packed_f16 / b_packed are packed (cnm_pack_conv_bn_f16) from the four composed phase
+// filters as 4 * Cout output channels, phase major (reference up_conv_layer, depthNet_model.py:89-112).  with_ring = 0:
+// complete result with REPLICATE padding of the upsampled image; 1: the one-pixel output ring is left un-biased /
+// un-activated for cnm_conv3x3_upsampled_ring_c8_f16, which turns it into the reference's zero-padding result.
+extern "C" int cnm_conv3x3_upsampled_c8_f16(const void* in, int Gin_total, int gin0, int Gin,
+                                            void* out, int Gout_total, int gout0, int Cout,
+                                            const void* w_packed_f16, const float* b_packed,
+                                            int N, int H, int W, int relu, int with_ring, void* stream) {
+    CNM_REQUIRE(in && out && w_packed_f16 && N > 0 && H > 0 && W > 0 && Gin > 0, CNM_ERR_BAD_ARG);
+    CNM_REQUIRE(Cout > 0 && Cout % 8 == 0 && gout0 >= 0 && gout0 + Cout / 8 <= Gout_total && gin0 >= 0 && gin0 + Gin <= Gin_total, CNM_ERR_BAD_ARG);
+    ConvArgs a;
+    a.in = a.in2 = static_cast<const float*>(in); a.out = static_cast<float*>(out); a.w = static_cast<const float*>(w_packed_f16); a.bias = b_packed;
+    const unsigned long long b1 = (unsigned long long)N * Gin_total * H * W * 16ull;
+    CNM_REQUIRE(b1 < 0xFFFFFFFFull && (unsigned long long)N * Gout_total * 4 * H * W * 16ull < (1ull << 40), CNM_ERR_BAD_ARG);
+    a.in_bytes = a.in2_bytes = (unsigned)b1;
+    a.Gin2_tot = Gin_total; a.gin2_0 = gin0; a.Gsplit = Gin;
+    a.N = N; a.H = H; a.W = W; a.Ho = H; a.Wo = W;
+    a.Gin_tot = Gin_total; a.gin0 = gin0; a.Gin = Gin;
+    a.Gout_tot = Gout_total; a.gout0 = gout0; a.Cout = 4 * Cout; a.Cout_pad = round64(4 * Cout);
+    a.ks = 3; a.stride = 1; a.pad = 1;
+    a.nk = (9 * 8 * Gin + 63) / 64; a.w_bytes = (unsigned)((size_t)a.nk * 64 * a.Cout_pad * 2);
+    a.M = N * H * W; a.relu = relu; a.ring = with_ring;
+    launch_glds<true>(a, cnm_stream(stream));
+    CNM_LAUNCH_CHECK();
+    return CNM_OK;
 }

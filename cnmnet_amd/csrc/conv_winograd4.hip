@@ -376,12 +376,29 @@ struct RingArgs {
     int nrow, ncol;                      // 32-pixel blocks per row side / per column side
 };
 
-__device__ __forceinline__ float4 ring_up_sample(const float4* __restrict__ base, int H, int W, int Y, int X) {   // upsample2x_c4_kernel's arithmetic
+// Four channels (virtual c4 group g4) of one low-resolution pixel: fp32 c4 tensors directly, fp16 c8 tensors (HALF) as one
+// half of the 16-byte group g4 >> 1 widened to fp32 -- the ring pass then runs the same fp32 arithmetic on either.
+typedef _Float16 ring_f16x4 __attribute__((ext_vector_type(4)));
+template <bool HALF>
+__device__ __forceinline__ float4 ring_ld4(const float* __restrict__ in, int img, int G_tot, int g0, int g4, int HW, int pix) {
+    if constexpr (HALF) {
+        const char* p = reinterpret_cast<const char*>(in + c4_offset(img, G_tot, g0 + (g4 >> 1), HW, pix)) + (g4 & 1) * 8;
+        const ring_f16x4 h = *reinterpret_cast<const ring_f16x4*>(p);
+        return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+    } else {
+        return *reinterpret_cast<const float4*>(in + c4_offset(img, G_tot, g0 + g4, HW, pix));
+    }
+}
+
+template <bool HALF>
+__device__ __forceinline__ float4 ring_up_sample(const float* __restrict__ in, int img, int G_tot, int g0, int g4, int H, int W, int Y, int X) {   // upsample2x_c4_kernel's arithmetic
     const float sy = fmaxf((Y + 0.5f) * 0.5f - 0.5f, 0.f), sx = fmaxf((X + 0.5f) * 0.5f - 0.5f, 0.f);
     const int y0 = (int)sy, x0 = (int)sx;
     const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
     const float ly = sy - y0, lx = sx - x0, hy = 1.f - ly, hx = 1.f - lx;
-    const float4 p00 = base[y0 * W + x0], p01 = base[y0 * W + x1], p10 = base[y1 * W + x0], p11 = base[y1 * W + x1];
+    const int HW = H * W;
+    const float4 p00 = ring_ld4<HALF>(in, img, G_tot, g0, g4, HW, y0 * W + x0), p01 = ring_ld4<HALF>(in, img, G_tot, g0, g4, HW, y0 * W + x1);
+    const float4 p10 = ring_ld4<HALF>(in, img, G_tot, g0, g4, HW, y1 * W + x0), p11 = ring_ld4<HALF>(in, img, G_tot, g0, g4, HW, y1 * W + x1);
     float4 v;
     v.x = hy * (hx * p00.x + lx * p01.x) + ly * (hx * p10.x + lx * p11.x);
     v.y = hy * (hx * p00.y + lx * p01.y) + ly * (hx * p10.y + lx * p11.y);
@@ -390,6 +407,7 @@ __device__ __forceinline__ float4 ring_up_sample(const float4* __restrict__ base
     return v;
 }
 
+template <bool HALF>                                                     // HALF: fp16 c8 input / output (a.Gin = virtual c4 groups = 2 x the c8 groups)
 __global__ __launch_bounds__(256) void conv_upsampled_ring_kernel(const RingArgs a) {
     // The reduction is short and latency-bound (a few dozen workgroups, 8-32 chunks each): the four waves split the
     // chunks (wave w takes chunks w, w+4, ...), each staging its own chunk in a private LDS region (no workgroup
@@ -448,8 +466,9 @@ __global__ __launch_bounds__(256) void conv_upsampled_ring_kernel(const RingArgs
             const int y0 = (int)sy, x0 = (int)sx;
             const int y1 = min(y0 + 1, a.H - 1), x1 = min(x0 + 1, a.W - 1);
             lyv[i] = sy - y0; lxv[i] = sx - x0;
-            const float4* base = reinterpret_cast<const float4*>(a.in + c4_offset(img, a.Gin_tot, a.gin0 + min(g, a.Gin - 1), HW, 0));
-            tx[i][0] = base[y0 * a.W + x0]; tx[i][1] = base[y0 * a.W + x1]; tx[i][2] = base[y1 * a.W + x0]; tx[i][3] = base[y1 * a.W + x1];
+            const int gl = min(g, a.Gin - 1);
+            tx[i][0] = ring_ld4<HALF>(a.in, img, a.Gin_tot, a.gin0, gl, HW, y0 * a.W + x0); tx[i][1] = ring_ld4<HALF>(a.in, img, a.Gin_tot, a.gin0, gl, HW, y0 * a.W + x1);
+            tx[i][2] = ring_ld4<HALF>(a.in, img, a.Gin_tot, a.gin0, gl, HW, y1 * a.W + x0); tx[i][3] = ring_ld4<HALF>(a.in, img, a.Gin_tot, a.gin0, gl, HW, y1 * a.W + x1);
         }
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
@@ -469,8 +488,7 @@ __global__ __launch_bounds__(256) void conv_upsampled_ring_kernel(const RingArgs
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             const bool right = e >> 1;
             if (g < a.Gin && (right ? hasR : hasL)) {
-                const float4* base = reinterpret_cast<const float4*>(a.in + c4_offset(img, a.Gin_tot, a.gin0 + g, HW, 0));
-                v = ring_up_sample(base, a.H, a.W, side == 0 ? (e & 1) : Ho - 2 + (e & 1), right ? Wo - 1 : 0);
+                v = ring_up_sample<HALF>(a.in, img, a.Gin_tot, a.gin0, g, a.H, a.W, side == 0 ? (e & 1) : Ho - 2 + (e & 1), right ? Wo - 1 : 0);
             }
             *reinterpret_cast<float4*>(Es + e * 16 + q * 4) = v;
         }
@@ -545,11 +563,20 @@ __global__ __launch_bounds__(256) void conv_upsampled_ring_kernel(const RingArgs
         const int j = p0 + blk * 16 + col;
         if (j >= len) continue;
         const int Y = side == 0 ? 0 : side == 1 ? Ho - 1 : 1 + j, X = side == 2 ? 0 : side == 3 ? Wo - 1 : j;
-        float4* o = reinterpret_cast<float4*>(a.out + c4_offset(img, a.Gout_tot, a.gout0 + (co >> 2), Ho * Wo, Y * Wo + X));
-        float4 v = *o;
+        float4 v;
+        ring_f16x4* oh = nullptr; float4* o = nullptr;
+        if constexpr (HALF) {
+            oh = reinterpret_cast<ring_f16x4*>(reinterpret_cast<char*>(a.out + c4_offset(img, a.Gout_tot, a.gout0 + (co >> 3), Ho * Wo, Y * Wo + X)) + (co & 4) * 2);
+            const ring_f16x4 h = *oh;
+            v = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+        } else {
+            o = reinterpret_cast<float4*>(a.out + c4_offset(img, a.Gout_tot, a.gout0 + (co >> 2), Ho * Wo, Y * Wo + X));
+            v = *o;
+        }
         v.x = v.x - sum[blk][0] + bias.x; v.y = v.y - sum[blk][1] + bias.y; v.z = v.z - sum[blk][2] + bias.z; v.w = v.w - sum[blk][3] + bias.w;
         if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        *o = v;
+        if constexpr (HALF) { const ring_f16x4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w}; *oh = h; }
+        else *o = v;
     }
 }
 
@@ -600,7 +627,26 @@ extern "C" int cnm_conv3x3_upsampled_ring_c4_f32(const float* in, int Gin_total,
     a.nchunks = (4 * Gin + 15) / 16; a.relu = relu;
     a.nrow = cnm_ceil_div(2 * W, 32); a.ncol = cnm_ceil_div(2 * H - 2, 32);              // 32-pixel blocks (conv_upsampled_ring_kernel NPX)
     const int nblocks = N * (2 * a.nrow + 2 * a.ncol) * (Cout / 64);
-    conv_upsampled_ring_kernel<<<nblocks, 256, 0, cnm_stream(stream)>>>(a);
+    conv_upsampled_ring_kernel<false><<<nblocks, 256, 0, cnm_stream(stream)>>>(a);
+    CNM_LAUNCH_CHECK();
+    return CNM_OK;
+}
+
+// fp16 twin for cnm_conv3x3_upsampled_c8_f16: `in` / `out` are c8 half tensors (Gin = 16-byte groups of 8 channels), w_ring and
+// b_packed the same fp32 buffers as above (the ring's arithmetic stays fp32; only the loads and the read-modify-write differ).
+extern "C" int cnm_conv3x3_upsampled_ring_c8_f16(const void* in, int Gin_total, int gin0, int Gin,
+                                                 void* out, int Gout_total, int gout0, int Cout,
+                                                 const float* w_ring, const float* b_packed,
+                                                 int N, int H, int W, int relu, void* stream) {
+    CNM_REQUIRE(in && out && w_ring && N > 0 && H > 1 && W > 1 && Gin > 0, CNM_ERR_BAD_ARG);
+    CNM_REQUIRE(Cout > 0 && Cout % 64 == 0 && gout0 >= 0 && gout0 + Cout / 8 <= Gout_total && gin0 >= 0 && gin0 + Gin <= Gin_total, CNM_ERR_BAD_ARG);
+    RingArgs a;
+    a.in = static_cast<const float*>(in); a.out = static_cast<float*>(out); a.wr = w_ring; a.bias = b_packed;
+    a.N = N; a.H = H; a.W = W; a.Gin_tot = Gin_total; a.gin0 = gin0; a.Gin = 2 * Gin; a.Gout_tot = Gout_total; a.gout0 = gout0; a.Cout = Cout;
+    a.nchunks = (8 * Gin + 15) / 16; a.relu = relu;
+    a.nrow = cnm_ceil_div(2 * W, 32); a.ncol = cnm_ceil_div(2 * H - 2, 32);
+    const int nblocks = N * (2 * a.nrow + 2 * a.ncol) * (Cout / 64);
+    conv_upsampled_ring_kernel<true><<<nblocks, 256, 0, cnm_stream(stream)>>>(a);
     CNM_LAUNCH_CHECK();
     return CNM_OK;
 }

@@ -78,6 +78,8 @@ int cnm_upsample2x_c8_f16(const void*, int, int, void*, int, int, int, int, int,
 int cnm_head_sigmoid_c8_f16(const void*, int, int, int, const float*, const float*, float, float*, void*, int, int, int, int, int, void*);
 int cnm_refine_assemble_multi_c8_f16(const float*, const void*, void*, int, int, int, int, int, void*);
 int cnm_planesweep_cat_c8_f16(const float*, const float*, const float*, void*, float*, size_t, int, int, int, int, int, double, double, void*);
+int cnm_conv3x3_upsampled_c8_f16(const void*, int, int, int, void*, int, int, int, const void*, const float*, int, int, int, int, int, void*);
+int cnm_conv3x3_upsampled_ring_c8_f16(const void*, int, int, int, void*, int, int, int, const float*, const float*, int, int, int, int, void*);
 }
 
 // F(4x4,3x3) workgroups cover 64 couts x 16 tiles of 4x4 outputs: worth it only when they fill the chip twice over
@@ -156,6 +158,10 @@ struct EngF32 {
 struct EngF16 {
     static constexpr int GD = 8;
     static int upconv(const float* in, int G, float* up_tmp, float* out, int Gto, int go0, int Cout, const cnm_layer_weights& w, int N, int H, int W, void* s) {
+        if (w.uu && w.bu && w.wr && G * 8 <= 256 && (long long)N * 4 * H * W >= g_upsampled_min_pixels) {   // one fused pass over the low-resolution input + ring pass
+            const int e = cnm_conv3x3_upsampled_c8_f16(in, G, 0, G, out, Gto, go0, Cout, w.uu, w.bu, N, H, W, 1, 1, s);
+            return e != CNM_OK ? e : cnm_conv3x3_upsampled_ring_c8_f16(in, G, 0, G, out, Gto, go0, Cout, w.wr, w.b, N, H, W, 1, s);
+        }
         const int e = up(in, G, up_tmp, N, H, W, s);
         return e != CNM_OK ? e : conv(up_tmp, G, 0, G, out, Gto, go0, Cout, w, N, 2 * H, 2 * W, 3, 1, s);
     }

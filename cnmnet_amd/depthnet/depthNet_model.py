@@ -114,7 +114,12 @@ class _EngineNet(nn.Module):
                 wino = (self.precision == "f32" and self.winograd and L["Cout"] % 64 == 0 and
                         (L["ksize"] == 3 or L["ksize"] in (5, 7)))            # 3x3 stride 2: F(2x2) filter for the low-resolution layers (nets.hip)
                 if not wino:
-                    packed.append((wp, bp))
+                    # fp16 up_conv layers the executor may run fused with their bilinear upsampling (<= 256 input channels)
+                    if (self.precision == "f16" and L["ksize"] == 3 and L["stride"] == 1 and L["conv_key"].startswith("upconv")
+                            and L["Cin"] <= 256 and L["Cout"] % 64 == 0 and self.fused_upsample):
+                        packed.append((wp, bp, None, None) + tuple(ops.pack_upsampled_f16(w, bnp, eps=bn.eps)))
+                    else:
+                        packed.append((wp, bp))
                 else:
                     up = ops.pack_winograd(w, bnp, rot=L["rot"], eps=bn.eps, stride=L["stride"])
                     # 3x3 / 5x5 stride 1: also the 36-point filter (F(4x4,3x3) / F(2x2,5x5)); the executor picks per call by tile count
@@ -130,7 +135,7 @@ class _EngineNet(nn.Module):
         arr = (_lib.LayerWeights * len(packed))()
         for i, t in enumerate(packed):
             arr[i].w, arr[i].b = t[0].data_ptr(), t[1].data_ptr()
-            arr[i].u = t[2].data_ptr() if len(t) > 2 else None
+            arr[i].u = t[2].data_ptr() if len(t) > 2 and t[2] is not None else None
             arr[i].u4 = t[3].data_ptr() if len(t) > 3 and t[3] is not None else None
             arr[i].uu, arr[i].bu, arr[i].wr = [t[j].data_ptr() if len(t) > 6 and t[j] is not None else None for j in (4, 5, 6)]
         self._packed, self._weights_arr, self._packed_key = packed, arr, key

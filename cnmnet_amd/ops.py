@@ -332,6 +332,37 @@ def conv3x3_upsampled_winograd4_c4(x, u_packed, b_packed, Cout, relu=True, w_rin
     return out
 
 
+def pack_upsampled_f16(weight, bn=None, eps=1e-5):
+    """(w_packed half, b_packed, w_ring) for conv3x3_upsampled_c8: the composed phase filters as 4*Cout output channels on
+    the fp16 kernel, the folded bias four times, and the plain filter in MFMA order (fp32) for the ring pass."""
+    _dev(weight, *(bn or ()))
+    lib = _lib.load()
+    Cout, Cin = weight.shape[:2]
+    rep = tuple(t.repeat(4) for t in bn) if bn else None
+    wr = torch.empty(lib.cnm_packed_upsampled_ring_floats(Cout, Cin), device=weight.device, dtype=torch.float32)
+    g, v = (_c(bn[0]), _c(bn[3])) if bn else (None, None)
+    with torch.cuda.device(weight.device):
+        _lib.check(lib.cnm_pack_upsampled_ring_f32(_p(_c(weight)), _p(g), _p(v), eps, Cout, Cin, _p(wr), _stream()))
+    wp, bp = pack_conv_f16(compose_upsample_filters(weight), rep, None, 0, eps)
+    return wp, bp, wr
+
+
+def conv3x3_upsampled_c8(x, w_packed, b_packed, Cout, relu=True, w_ring=None):
+    """fp16 conv3x3(upsample2x(x)) + bias (+ ReLU): x [N,G,H,W,8] half -> [N,Cout/8,2H,2W,8] half; with w_ring the
+    reference's zero-padded result, without it replicate padding of the upsampled image (differs on the output ring)."""
+    x = x.contiguous()
+    N, G, H, W, _ = x.shape
+    out = torch.empty(N, Cout // 8, 2 * H, 2 * W, 8, device=x.device, dtype=torch.float16)
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        _lib.check(lib.cnm_conv3x3_upsampled_c8_f16(x.data_ptr(), G, 0, G, out.data_ptr(), Cout // 8, 0, Cout, w_packed.data_ptr(), _p(b_packed),
+                                                    N, H, W, int(relu), int(w_ring is not None), _stream()))
+        if w_ring is not None:
+            _lib.check(lib.cnm_conv3x3_upsampled_ring_c8_f16(x.data_ptr(), G, 0, G, out.data_ptr(), Cout // 8, 0, Cout, _p(w_ring), _p(b_packed),
+                                                             N, H, W, int(relu), _stream()))
+    return out
+
+
 def conv_rows_winograd_c4(x, u_packed, b_packed, Cout, ksize, relu=True, x2=None, stride=1, tile=None):
     """Row-wise Winograd twin of conv2d_c4(ksize=5|7, stride=1|2)."""
     _dev(x, u_packed, b_packed, x2)

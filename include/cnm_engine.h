@@ -202,6 +202,19 @@ int cnm_conv3x3_upsampled_ring_c4_f32(const float* in, int Gin_total, int gin0, 
                                       const float* w_ring, const float* b_packed,
                                       int N, int H, int W, int relu, void* stream);
 
+/* fp16 twins (c8 tensors, BASELINE config 5): the composed phase filters packed with cnm_pack_conv_bn_f16 as 4*Cout output
+ * channels (phase major; bias replicated four times) run on the LDS-DMA implicit-GEMM kernel with clamped window samples
+ * and the pixel-shuffling epilogue; the ring pass reads / rewrites half data and keeps its arithmetic, w_ring and b_packed
+ * in fp32.  Gin = 16-byte channel groups (8 channels each). */
+int cnm_conv3x3_upsampled_c8_f16(const void* in, int Gin_total, int gin0, int Gin,
+                                 void* out, int Gout_total, int gout0, int Cout,
+                                 const void* w_packed_f16, const float* b_packed,
+                                 int N, int H, int W, int relu, int with_ring, void* stream);
+int cnm_conv3x3_upsampled_ring_c8_f16(const void* in, int Gin_total, int gin0, int Gin,
+                                      void* out, int Gout_total, int gout0, int Cout,
+                                      const float* w_ring, const float* b_packed,
+                                      int N, int H, int W, int relu, void* stream);
+
 /* Row-wise Winograd twin of cnm_conv2d_cat2_c4_f32 for ksize R = 5 or 7, stride 1 or 2 (the reference's
  * conv1 = nn.Conv2d(3+D, 128, 7, 1, 3) / (128, 128, 7, 2, 3) and conv2 = nn.Conv2d(128, 256, 5, 1, 2) /
  * (256, 256, 5, 2, 2), depthNet_model.py:137-148 via conv_layer :77-86): the transform runs along image rows, the R
@@ -282,8 +295,8 @@ int cnm_net_layer(int net, int index, cnm_layer_info* info);   /* D=64 table */
  * cnm_pack_winograd5x5_bn_f32 (F(2x2,5x5)) for 5x5 stride-1 layers: used instead of u when the layer has enough tiles
  * to fill the chip (>= CNM_WINO4_MIN_WORKGROUPS workgroups of 64 couts x 16 tiles).
  * uu, bu, wr: optional, up_conv layers only -- the four composed upsample-then-3x3 phase filters packed as 4*Cout
- * output channels (cnm_pack_winograd4_bn_f32), the folded bias four times, and the ring-pass filter
- * (cnm_pack_upsampled_ring_f32); all three or none. */
+ * output channels (fp32 engine: cnm_pack_winograd4_bn_f32; fp16 engine: cnm_pack_conv_bn_f16, half data), the folded
+ * bias four times, and the ring-pass filter (cnm_pack_upsampled_ring_f32, fp32 for both engines); all three or none. */
 typedef struct cnm_layer_weights { const float* w; const float* b; const float* u; const float* u4;
                                    const float* uu; const float* bu; const float* wr; } cnm_layer_weights;
 

@@ -61,6 +61,26 @@ def _conv_f16_case(dev, cin, cout, k, stride, rot, N, H, W):
     assert np.abs(got - want).max() < 1.5e-3 * scale, (np.abs(got - want).max(), scale)     # output rounding to fp16: 2^-11 relative
 
 
+@pytest.mark.parametrize("cin,cout,N,H,W", [(128, 64, 2, 24, 40), (256, 128, 1, 13, 21), (64, 64, 3, 8, 8)])
+def test_conv3x3_upsampled_c8_vs_torch(dev, cin, cout, N, H, W):
+    """fp16 fused up_conv (upsample x2 -> conv3x3 -> folded BN -> ReLU on the low-resolution input, composed phase filters +
+    ring pass) against torch on the fp16-rounded input: interior, ring, corners, odd sizes, pixel tails of the tiles."""
+    from cnmnet_amd import ops
+    rng = np.random.default_rng(cin + H)
+    x = T(rng.standard_normal((N, cin, H, W)).astype(np.float32)).half().float()
+    w = T((rng.standard_normal((cout, cin, 3, 3)) * 0.05).astype(np.float32))
+    bn = tuple(T(a.astype(np.float32)) for a in (rng.uniform(0.5, 1.5, cout), rng.normal(0, 0.2, cout), rng.normal(0, 0.2, cout), rng.uniform(0.5, 1.5, cout)))
+    up = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+    want = F.relu(F.batch_norm(F.conv2d(up, w, None, padding=1), bn[2], bn[3], bn[0], bn[1], False, 0.0, 1e-5)).numpy()
+    wp, bp, wr = ops.pack_upsampled_f16(w.to(dev), tuple(t.to(dev) for t in bn))
+    got = ops.c8_to_nchw(ops.conv3x3_upsampled_c8(ops.nchw_to_c8(x.to(dev)), wp, bp, cout, True, wr), cout).cpu().numpy()
+    scale = np.abs(want).max()
+    err = np.abs(got - want)
+    assert err.max() < 6e-3 * scale, (err.max(), scale, np.unravel_index(err.argmax(), err.shape))    # fp16 composed filters + fp16 output
+    ring = np.ones(want.shape[2:], bool); ring[1:-1, 1:-1] = False
+    assert err[:, :, ring].max() < 6e-3 * scale                                                        # the ring pass (zero padding of the upsampled image)
+
+
 @pytest.mark.parametrize("N,C,H,W", [(2, 24, 12, 20), (1, 8, 1, 1), (1, 16, 5, 7), (3, 40, 6, 1), (1, 8, 1, 9)])
 def test_upsample2x_c8_vs_torch(dev, N, C, H, W):
     """fp16 bilinear x2 (one thread per low-resolution pixel) against F.interpolate on the fp16-rounded input: odd sizes,
@@ -132,3 +152,29 @@ def test_f16_engine_other_sizes_vs_f32_engine(dev, B, S, H, W, D):
     assert float(d.max()) < 5e-2 and float(d.mean()) < 1e-3, (float(d.max()), float(d.mean()))      # [0, 3] range
     assert float((outs["f32"]["prob"] - outs["f16"]["prob"]).abs().max()) < 5e-2
     assert bool(torch.isfinite(outs["f16"]["normal"]).all())
+
+
+def test_f16_fused_upsample_networks_agree(dev):
+    """fp16 nets with every eligible up_conv layer fused (threshold lowered to 1 pixel) against the same nets with the fused
+    path off: the two differ only by fp16 roundings (composed filters instead of an upsampled tensor), and the fused path
+    really runs."""
+    from cnmnet_amd import _lib
+    from cnmnet_amd.depthnet import depthNet, DepthRefineNet
+    lib = _lib.load()
+    img, cams = syn.frames(2, 2, 64, 96, seed=31)
+    outs = []
+    old = lib.cnm_tune_upsampled_min_pixels(1)
+    try:
+        for fused in (True, False):
+            net = _load(depthNet(3.0, precision="f16"), 5).to(dev); net.fused_upsample = fused
+            ref = _load(DepthRefineNet(32, 3.0, precision="f16"), 6).to(dev); ref.fused_upsample = fused
+            with torch.no_grad():
+                o1, f1 = net(T(img[:, 0]).to(dev), T(img[:, 1]).to(dev), T(cams[:, 0]).to(dev), T(cams[:, 1]).to(dev))
+                o2, f2 = net(T(img[:, 0]).to(dev), T(img[:, 2]).to(dev), T(cams[:, 0]).to(dev), T(cams[:, 2]).to(dev))
+                d, p = ref(o1[0], o2[0], f1, f2)
+            outs.append([t.float().cpu().numpy() for t in (o1[0], o1[1], d, p)])
+    finally:
+        lib.cnm_tune_upsampled_min_pixels(old)
+    for a, b in zip(*outs):
+        assert np.abs(a - b).max() < 4e-2 and np.abs(a - b).mean() < 3e-3, (np.abs(a - b).max(), np.abs(a - b).mean())   # [0, 3] range; two fp16 evaluation orders (measured 2.4e-2 / 1.2e-3)
+    assert any(np.abs(a - b).max() > 0 for a, b in zip(*outs))           # the fused path really ran
