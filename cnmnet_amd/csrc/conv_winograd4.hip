@@ -36,15 +36,7 @@ __device__ __forceinline__ unsigned sat_add(unsigned a, unsigned b) {    // 0xFF
     return r;
 }
 
-struct Wino4Args {
-    const float* in; const float* in2; float* out; const float* u; const float* bias;
-    unsigned in_bytes, in2_bytes;
-    int N, H, W, TH, TW;                 // TH = ceil(H/4), TW = ceil(W/4) tiles
-    int Gin_tot, gin0, Gin2_tot, gin2_0, Gsplit, Gin;
-    int Gout_tot, gout0, Cout;
-    int nchunks, T, relu;                // T = N*TH*TW tiles
-    int ring;                            // fused upsampling: leave the one-pixel output ring without bias / ReLU for the ring kernel
-};
+#include "wino4_args.h"
 
 // B^T (6 points): rows [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1], in place
 #define WINO4_BT(x0, x1, x2, x3, x4, x5) do {                                                                   \
@@ -314,6 +306,10 @@ static int conv36(const float* in_a, int Ga_total, int ga0, int Ga, const float*
     a.Gin_tot = Ga_total; a.gin0 = ga0; a.Gin2_tot = Gb ? Gb_total : Ga_total; a.gin2_0 = Gb ? gb0 : ga0; a.Gsplit = Ga; a.Gin = Ga + Gb;
     a.Gout_tot = Gout_total; a.gout0 = gout0; a.Cout = ups ? 4 * Cout : Cout;     // fused upsampling: four phases of virtual output channels
     a.nchunks = (4 * a.Gin + 15) / 16; a.T = N * a.TH * a.TW; a.relu = relu; a.ring = ring;
+    {
+        const int e = cnm_wino36s_try_launch(a, m, ups, cnm_stream(stream));   // LDS-staged persistent variant where eligible
+        if (e <= 0) return e;
+    }
     const int nblocks = (a.Cout / 64) * cnm_ceil_div(a.T, 16);
     if (ups) conv_winograd36_f32_kernel<4, 3, true><<<nblocks, 256, 0, cnm_stream(stream)>>>(a);
     else if (ksize == 3) conv_winograd36_f32_kernel<4, 3><<<nblocks, 256, 0, cnm_stream(stream)>>>(a);

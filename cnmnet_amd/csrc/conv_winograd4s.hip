@@ -1,0 +1,344 @@
+// Winograd F(4x4,3x3), LDS-staged and persistent: the successor of conv_winograd36_f32_kernel<4,3> (conv_winograd4.hip)
+// for the layers whose output-channel count is a multiple of 128.  Same arithmetic, same packed filters, bit-identical
+// results; what changes is how the operands reach the matrix cores.
+//
+// Why (profiles/r2_conv_pmc.txt): the gather-fed kernel needs its texture addresser as much as its matrix pipes -- per
+// 16-channel chunk a wave issues 36 one-dword window gathers (16 lines per instruction) and 36 weight fragments for 144
+// MFMAs -- and every VALU instruction of the input transform (180 per 144 MFMAs) takes its cycles out of the fp32 matrix
+// pipe, which shares the SIMD's fp32 lanes (profiles/r1_mfma_valu_probes.txt).  Here
+//   * a workgroup = 8 waves = 128 output channels x 16 tiles: the transformed input of a chunk is shared by twice the
+//     MFMAs, and each thread transforms HALF a window (three of the six frequency rows): 72 instead of 180 VALU
+//     instructions per 144 MFMAs;
+//   * the raw 6 x 66 (2 x 8 tiles: 10 x 34) input patch of the tile block reaches LDS by LDS-DMA (buffer_load_dwordx4 ...
+//     lds: 16-byte pixels, coalesced rows, overlapping window columns fetched once, zero padding = out-of-range offsets)
+//     -- 28 wave-instructions per chunk for the workgroup instead of 288 dword gathers;
+//   * the grid is persistent (one workgroup per CU, 128 KB of LDS): a workgroup walks units (tile block, 128-channel
+//     block) and runs ONE software pipeline across them -- phase p multiplies chunk p, transforms chunk p + 1 and
+//     stages chunk p + 2, whichever unit they belong to -- so only the output transform of a unit is not overlapped.
+//
+// LDS: V[2][36 points][16 tiles][16 ci] (72 KB, the MFMA B operand, slots XOR-swizzled as in the gather-fed kernel) and
+// RAW[2][4 channel groups][plane] (56 KB; plane = patch rows x patch columns x 16 bytes, plane pitch = 16 (mod 128) bytes
+// so that the 32 lanes of a ds_read_b32 group -- 16 channels x 2 neighbouring tiles -- fall on 32 different banks).
+// Roles of wave w (lane l):
+//   multiply   output channels 16 w .. 16 w + 15 of the unit's block, all 16 tiles, all 36 points (144 accumulators);
+//   transform  tiles 4 (w & 3) + (l >> 4), channel l & 15, frequency rows {0,1,2} (w < 4) or {5,3,4} (w >= 4): the
+//              column pass B^T d produces three of six rows with the SAME instruction stream for both halves (one
+//              shifted base address and two constants differ), the row pass is the full 6-point transform on them;
+//   stage      DMA pieces w, w + 8, ... of the chunk's 28; waves 0-3 issue theirs at the start of a phase, waves 4-7
+//              a third of a phase later: vmcnt retires in order, so a weight fragment issued behind a first-touch DMA
+//              waits out its HBM latency, and the two waves of a SIMD must not do that at the same time.
+// The DMA is inline assembly on purpose: beside a DMA it knows about, hipcc orders every loop-carried VGPR load behind
+// s_waitcnt vmcnt(0) (checked in the ISA); hidden from its counters, its counted waits for the weight fragments stay
+// counted and can only over-wait.  DMA completion is guaranteed by a counted wait before the phase barrier.
+#include "wino4_args.h"
+
+#ifndef WINO4S_WD
+#define WINO4S_WD 4       // weight fragments in flight per wave
+#endif
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+#define WINO4S_BT(x0, x1, x2, x3, x4, x5) do {                                                                  \
+        const float t0 = fmaf(4.f, x0, fmaf(-5.f, x2, x4)), t5 = fmaf(4.f, x1, fmaf(-5.f, x3, x5));             \
+        const float e1 = fmaf(-4.f, x2, x4), o1 = fmaf(-4.f, x1, x3);                                           \
+        const float e2 = x4 - x2, o2 = x3 - x1;                                                                 \
+        x0 = t0; x1 = e1 + o1; x2 = e1 - o1; x3 = fmaf(2.f, o2, e2); x4 = fmaf(-2.f, o2, e2); x5 = t5;          \
+    } while (0)
+// A^T of F(4,3) on four channels at once: rows [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+#define WINO4S_AT(y0, y1, y2, y3, m0, m1, m2, m3, m4, m5) do {                                                  \
+        const f32x4 s1 = (m1) + (m2), d1 = (m1) - (m2), s2 = (m3) + (m4), d2 = (m3) - (m4);                     \
+        y0 = (m0) + s1 + s2; y1 = d1 + 2.f * d2; y2 = s1 + 4.f * s2; y3 = d1 + 8.f * d2 + (m5);                 \
+    } while (0)
+
+__device__ __forceinline__ void wino4s_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// one LDS-DMA wave-instruction: 64 lanes x 16 bytes from buffer offset voff + soff to lds_addr + 16 lane (an
+// out-of-range voff lands as zeros).  m0 is saved and restored: the compiler does not model it across the statement.
+__device__ __forceinline__ void wino4s_dma16(unsigned lds_addr, unsigned voff, __amdgpu_buffer_rsrc_t rsrc, unsigned soff) {
+    unsigned keep;
+    asm volatile("s_nop 2\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+
+// ABL (debug builds, -DWINO4S_ABLATE, tools/wino36s_ablate.sh): bit 0 no input transform, 1 no DMA, 2 no weight loads in the
+// loop, 3 no B-fragment reads in the loop, 4 no output transform / stores -- timing experiments, results are wrong.
+template <int TSX, bool UPS, int ABL = 0>                                // tile block = (16 / TSX) x TSX tiles
+__global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino4Args a, const int SH, const int SW, const int tilesC, const int nunits) {
+    constexpr int TSY = 16 / TSX, PR = 4 * TSY + 2, PC = 4 * TSX + 2, NSLOT = PR * PC;
+    constexpr int NPIECE = (NSLOT + 63) / 64, PLANE = (NPIECE * 64 + 1) * 16, RAWBUF = 4 * PLANE;   // bytes
+    constexpr int VBUF = 36 * 16 * 64, RAW0 = 2 * VBUF;                  // bytes
+    constexpr int NDMA = 4 * NPIECE, DPW = (NDMA + 7) / 8;               // DMA pieces per chunk / per wave
+    constexpr int WD = WINO4S_WD, NXI = 36;
+    static_assert(PLANE % 128 == 16 && NXI % WD == 0 && WD % 2 == 0, "layout");
+    __shared__ __attribute__((aligned(16))) char smem[2 * VBUF + 2 * RAWBUF];   // 128 KB (TSX 16) / 120 KB (TSX 8)
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int hi = wave >> 2;
+    const int HW = a.H * a.W, SHW = SH * SW, ncb16 = a.Cout / 16;
+    const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem;
+
+    const int G = gridDim.x, first = xcd_remap(blockIdx.x, G);
+    if (first >= nunits) return;
+    const int nmine = (nunits - first + G - 1) / G;
+    const int P = nmine * a.nchunks;                                     // phases of this workgroup
+
+    // ---- stage role: pieces n = wave + 8 m of the chunk's NDMA (plane q = n / NPIECE, piece k = n % NPIECE)
+    unsigned dvoff[DPW];                                                 // per unit: byte offset of this lane's pixel inside one channel group plane of one image
+    int dq[DPW]; unsigned dlds[DPW];
+#pragma unroll
+    for (int m = 0; m < DPW; ++m) {
+        const int n = wave + 8 * m;
+        dq[m] = n / NPIECE;
+        dlds[m] = lds0 + RAW0 + dq[m] * PLANE + (n - dq[m] * NPIECE) * 1024;
+    }
+    int dk = 0, dc = 0, dimg = 0;                                        // cursor of the stage role: unit ordinal, chunk; image of that unit
+    auto dma_unit = [&]() {                                              // per-lane offsets for unit dk
+        const int uid = first + dk * G;
+        const int strip = uid / tilesC;
+        dimg = strip / SHW;
+        const int rem = strip - dimg * SHW, sy = rem / SW, sx = rem - sy * SW;
+        const int y0 = 4 * TSY * sy - 1, x0 = 4 * TSX * sx - 1;
+#pragma unroll
+        for (int m = 0; m < DPW; ++m) {
+            const int n = wave + 8 * m, k = n - dq[m] * NPIECE;
+            const int slot = 64 * k + lane, r = slot / PC, pc = slot - r * PC;
+            int y = y0 + r, x = x0 + pc;
+            bool ok = slot < NSLOT;
+            if constexpr (UPS) { y = min(max(y, 0), a.H - 1); x = min(max(x, 0), a.W - 1); }
+            else ok = ok & ((unsigned)y < (unsigned)a.H) & ((unsigned)x < (unsigned)a.W);
+            dvoff[m] = ok ? (unsigned)(y * a.W + x) * 16u : 0xFFFFFFFFu;
+        }
+    };
+    auto dma_piece = [&](int m) {                                        // piece m of phase (dk, dc) into the buffer of that phase
+        if ((ABL & 2) || wave + 8 * m >= NDMA || dk >= nmine) return;
+        const int g = dc * 4 + dq[m];
+        const bool s1 = g < a.Gsplit;
+        const unsigned bytes = g < a.Gin ? (s1 ? a.in_bytes : a.in2_bytes) : 0u;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s1 ? a.in : a.in2), 0, bytes, 0x00020000);
+        const unsigned gg = s1 ? (unsigned)(dimg * a.Gin_tot + a.gin0 + g) : (unsigned)(dimg * a.Gin2_tot + a.gin2_0 + g - a.Gsplit);
+        wino4s_dma16(dlds[m] + (unsigned)(((dk * a.nchunks + dc) & 1) * RAWBUF), dvoff[m], rsrc, gg * (unsigned)HW * 16u);
+    };
+    auto dma_advance = [&]() { if (++dc == a.nchunks) { dc = 0; ++dk; if (dk < nmine) dma_unit(); } };
+
+    // ---- transform role
+    const int ttile = 4 * (wave & 3) + (lane >> 4), tci = lane & 15, tcg = tci >> 2;
+    const unsigned rbase = RAW0 + tcg * PLANE + (((ttile / TSX) * 4) * PC + (ttile % TSX) * 4) * 16 + (tci & 3) * 4;
+    const unsigned rbaseT = rbase + hi * PC * 16;
+    const unsigned wbase = ttile * 64 + ((tcg ^ ((ttile >> 1) & 3)) * 4 + (tci & 3)) * 4;
+    const unsigned wT = wbase + hi * 5 * 6144, wR = wbase + 6144 + hi * 2 * 6144;
+    const float beta = hi ? -1.f : -4.f, gamma = hi ? 2.f : 1.f;
+    float q[7], rowT[6], rowP[6], rowM[6];
+    auto ldsf = [&](unsigned off) { return *reinterpret_cast<const float*>(smem + off); };
+    auto tr_read = [&](int j, unsigned rb) {                             // rb = byte offset of the raw buffer being transformed
+        if (ABL & 1) return;
+        q[0] = ldsf(rbaseT + rb + (0 * PC + j) * 16); q[1] = ldsf(rbase + rb + (1 * PC + j) * 16); q[2] = ldsf(rbase + rb + (2 * PC + j) * 16);
+        q[3] = ldsf(rbaseT + rb + (2 * PC + j) * 16); q[4] = ldsf(rbase + rb + (3 * PC + j) * 16); q[5] = ldsf(rbase + rb + (4 * PC + j) * 16);
+        q[6] = ldsf(rbaseT + rb + (4 * PC + j) * 16);
+    };
+    auto tr_col = [&](int j) {                                           // rows {0,1,2} / {5,3,4} of B^T d, column j (the gather-fed kernel's column_pass, half of it)
+        if (ABL & 1) return;
+        rowT[j] = fmaf(4.f, q[0], fmaf(-5.f, q[3], q[6]));
+        const float E = fmaf(beta, q[2], q[5]), O = fmaf(beta, q[1], q[4]);
+        rowP[j] = fmaf(gamma, O, E); rowM[j] = fmaf(-gamma, O, E);
+    };
+    auto tr_row = [&](float* x, unsigned wb) {                           // full row pass + store of the six points of one frequency row
+        if (ABL & 1) return;
+        WINO4S_BT(x[0], x[1], x[2], x[3], x[4], x[5]);
+#pragma unroll
+        for (int l = 0; l < 6; ++l) *reinterpret_cast<float*>(smem + wb + l * 1024) = x[l];
+    };
+
+    // ---- multiply role
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.u), 0, (unsigned)((size_t)a.nchunks * ncb16 * NXI * 1024), 0x00020000);
+    const unsigned lane16 = lane * 16;
+    const int rtile = lane & 15, kg = lane >> 4;
+    const unsigned bvoff = (rtile * 16 + (kg ^ ((rtile >> 1) & 3)) * 4) * 4;
+    auto ldA = [&](unsigned soff) { const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, soff, 0); return *reinterpret_cast<const float4*>(&v); };
+    auto abase = [&](int cblk, int c) {                                  // byte offset of fragment 0 of (128-channel block, chunk c) for this wave
+        return (unsigned)((c * ncb16 + cblk * 8 + wave) * NXI) * 1024u;
+    };
+    f32x4 acc[NXI];
+#pragma unroll
+    for (int x = 0; x < NXI; ++x) acc[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- prologue: stage phases 0 and 1, first weight fragments, transform phase 0
+    dma_unit();
+#pragma unroll
+    for (int m = 0; m < DPW; ++m) dma_piece(m);
+    dma_advance();
+#pragma unroll
+    for (int m = 0; m < DPW; ++m) dma_piece(m);
+    dma_advance();
+    int mk = 0, mc = 0;                                                  // cursor of the multiply role
+    int mcblk = first % tilesC, ncblk = (first + G) % tilesC;            // channel block of unit mk / mk + 1
+    unsigned a_cur = abase(mcblk, 0);
+    float4 af[WD];
+#pragma unroll
+    for (int s = 0; s < WD; ++s) af[s] = ldA(a_cur + s * 1024);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wino4s_lds_barrier();
+#pragma unroll
+    for (int j = 0; j < 6; ++j) { tr_read(j, 0); tr_col(j); }
+    tr_row(rowT, wT); tr_row(rowP, wR); tr_row(rowM, wR + 6144);
+    wino4s_lds_barrier();
+
+    for (int p = 0; p < P; ++p) {
+        const unsigned vc = (p & 1) * VBUF + bvoff, vn = ((p + 1) & 1) * VBUF, rn = ((p + 1) & 1) * RAWBUF;
+        const bool lastc = mc + 1 == a.nchunks;
+        const unsigned a_nxt = p + 1 < P ? (lastc ? abase(ncblk, 0) : abase(mcblk, mc + 1)) : a_cur;
+        float4 bf0 = *reinterpret_cast<const float4*>(smem + vc);
+        float4 bf1 = *reinterpret_cast<const float4*>(smem + vc + 1024);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int xp = 0; xp < NXI / 2; ++xp) {
+            const int x0 = 2 * xp, x1 = x0 + 1;
+            const float4 a0 = af[x0 % WD], a1 = af[x1 % WD];
+            const float4 b0 = bf0, b1 = bf1;
+            if (xp + 1 < NXI / 2 && !(ABL & 8)) {
+                bf0 = *reinterpret_cast<const float4*>(smem + vc + (x0 + 2) * 1024);
+                bf1 = *reinterpret_cast<const float4*>(smem + vc + (x1 + 2) * 1024);
+            }
+            acc[x0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc[x0], 0, 0, 0);
+            acc[x1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, acc[x1], 0, 0, 0);
+            if (ABL & 32) {                                              // every wave reads the same 36 KB: fragments from L1 / L2-hot lines
+                af[x0 % WD] = ldA(((x0 + WD) % NXI) * 1024);
+                af[x1 % WD] = ldA(((x1 + WD) % NXI) * 1024);
+            } else if (ABL & 64) {                                       // half the fragment loads
+                af[x0 % WD] = ldA(x0 + WD < NXI ? a_cur + (x0 + WD) * 1024 : a_nxt + (x0 + WD - NXI) * 1024);
+            } else if (!(ABL & 4)) {
+                af[x0 % WD] = ldA(x0 + WD < NXI ? a_cur + (x0 + WD) * 1024 : a_nxt + (x0 + WD - NXI) * 1024);
+                af[x1 % WD] = ldA(x1 + WD < NXI ? a_cur + (x1 + WD) * 1024 : a_nxt + (x1 + WD - NXI) * 1024);
+            }
+            // between the MFMAs: transform of phase p + 1 (raw reads of column xp, column xp - 1; then the three rows),
+            // DMA of phase p + 2 (waves 0-3: double steps 0.., waves 4-7: double steps 6..)
+            if (xp >= 1 && xp < 7) tr_col(xp - 1);
+            if (xp < 6) tr_read(xp, rn);
+            if (xp == 7) tr_row(rowT, wT + vn);
+            if (xp == 8) tr_row(rowP, wR + vn);
+            if (xp == 9) tr_row(rowM, wR + 6144 + vn);
+            if (xp < DPW) { if (!hi) { dma_piece(xp); if (xp == DPW - 1) dma_advance(); } }
+            else if (xp >= 6 && xp < 6 + DPW) { if (hi) { dma_piece(xp - 6); if (xp - 6 == DPW - 1) dma_advance(); } }
+            acc[x0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc[x0], 0, 0, 0);
+            acc[x1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, acc[x1], 0, 0, 0);
+            acc[x0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc[x0], 0, 0, 0);
+            acc[x1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, acc[x1], 0, 0, 0);
+            acc[x0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc[x0], 0, 0, 0);
+            acc[x1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, acc[x1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // every DMA this wave issued in the phase is older than the WD weight fragments still in flight: vmcnt retires in order
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WD) : "memory");
+        wino4s_lds_barrier();                                            // V / RAW of phase p + 1 complete; the buffers of phase p are free
+        a_cur = a_nxt;
+        if (!lastc) { ++mc; continue; }
+
+        // ---- output transform of unit mk: acc row = cout 4 kg + r (one c4 group), col = tile rtile
+        if (ABL & 16) { if (acc[0][0] == 123.456f) a.out[lane] = acc[7][1] + acc[35][3]; }
+        else {
+            const int uid = first + mk * G;
+            const int cblk = mcblk, strip = uid / tilesC;
+            const int img = strip / SHW, rem = strip - img * SHW, sy = rem / SW, sx = rem - sy * SW;
+            const int oty = sy * TSY + rtile / TSX, otx = sx * TSX + rtile % TSX;
+            const int co = cblk * 128 + wave * 16 + 4 * kg;
+            const float4 bv = a.bias ? *reinterpret_cast<const float4*>(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const f32x4 bb = {bv.x, bv.y, bv.z, bv.w};
+            f32x4 s[4][6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) WINO4S_AT(s[0][j], s[1][j], s[2][j], s[3][j], acc[0 * 6 + j], acc[1 * 6 + j], acc[2 * 6 + j], acc[3 * 6 + j], acc[4 * 6 + j], acc[5 * 6 + j]);
+            const bool tok = oty < a.TH && otx < a.TW;
+            if constexpr (UPS) {
+                const int Cr = a.Cout >> 2, ph = co / Cr, cr = co - ph * Cr, pa = ph >> 1, pb = ph & 1;
+                const int Ho = 2 * a.H, Wo = 2 * a.W;
+                float* obase = a.out + c4_offset(img, a.Gout_tot, a.gout0 + (cr >> 2), 4 * HW, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    f32x4 y[4];
+                    WINO4S_AT(y[0], y[1], y[2], y[3], s[i][0], s[i][1], s[i][2], s[i][3], s[i][4], s[i][5]);
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) {
+                        const int ly = 4 * oty + i, lx = 4 * otx + x;
+                        const int oy = 2 * ly + pa, ox = 2 * lx + pb;
+                        const bool ring = (oy == 0) | (oy == Ho - 1) | (ox == 0) | (ox == Wo - 1);   // finished by the ring kernel
+                        f32x4 v = y[x];
+                        if (!ring || !a.ring) {
+                            v += bb;
+                            if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                        }
+                        if (tok && ly < a.H && lx < a.W) *reinterpret_cast<f32x4*>(obase + (size_t)(oy * Wo + ox) * 4) = v;
+                    }
+                }
+            } else {
+                float* obase = a.out + c4_offset(img, a.Gout_tot, a.gout0 + (co >> 2), HW, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    f32x4 y[4];
+                    WINO4S_AT(y[0], y[1], y[2], y[3], s[i][0], s[i][1], s[i][2], s[i][3], s[i][4], s[i][5]);
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) {
+                        const int oy = 4 * oty + i, ox = 4 * otx + x;
+                        f32x4 v = y[x] + bb;
+                        if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                        if (tok && oy < a.H && ox < a.W) *reinterpret_cast<f32x4*>(obase + (size_t)(oy * a.W + ox) * 4) = v;
+                    }
+                }
+            }
+#pragma unroll
+            for (int x = 0; x < NXI; ++x) acc[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        ++mk; mc = 0; mcblk = ncblk; ncblk = (first + (mk + 1) * G) % tilesC;
+    }
+}
+
+static int g_wino36_staged = 1;                                          // tuning knob (A/B against the gather-fed kernel): 0 off, 1 where it pays, 2 wherever eligible
+extern "C" int cnm_tune_wino36_staged(int on) { const int old = g_wino36_staged; if (on >= 0 && on <= 2) g_wino36_staged = on; return old; }
+
+#ifdef WINO4S_ABLATE
+static int g_wino36s_ablate = 0;
+extern "C" int cnm_tune_wino36s_ablate(int m) { const int old = g_wino36s_ablate; if (m >= 0) g_wino36s_ablate = m; return old; }
+#endif
+
+static int wino4s_cus() {                                                // compute units of the current device, queried once per device
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cus[dev]) { int n = 0; cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256; }
+    return cus[dev];
+}
+
+int cnm_wino36s_try_launch(const Wino4Args& a, int M, int ups, hipStream_t stream) {
+    if (!g_wino36_staged || M != 4 || a.Cout % 128) return 1;
+    int tsx = 0;
+    if (a.TW >= 12) tsx = 16; else if (a.TW >= 6 && a.TH >= 2) tsx = 8;
+    if (!tsx) return 1;
+    const int tsy = 16 / tsx;
+    const int SH = cnm_ceil_div(a.TH, tsy), SW = cnm_ceil_div(a.TW, tsx), tilesC = a.Cout / 128;
+    const long long nunits = (long long)a.N * SH * SW * tilesC;
+    if (nunits <= 0 || nunits > 0x7FFFFFFF || (long long)a.nchunks * (a.Cout / 16) * 36 * 1024 >= 0xFFFFFFFFll) return 1;
+    const int cus = wino4s_cus();
+    const int grid = (int)(nunits < cus ? nunits : cus);
+    // One workgroup per CU walks ceil(units / CUs) units: a mostly empty last round costs more than the kernel gains
+    // (measured 1.09-1.13x on whole rounds, 0.85-0.89x at 1.5 rounds, tools/wino36s_probe.py); the gather-fed kernel, two
+    // independent workgroups per CU, balances those better.  g_wino36_staged == 2 forces the staged kernel (tests).
+    if (g_wino36_staged != 2 && nunits > cus && (double)((nunits + cus - 1) / cus) * cus / (double)nunits > 1.15) return 1;
+#ifdef WINO4S_ABLATE
+    if (g_wino36s_ablate && tsx == 16 && !ups) {
+        switch (g_wino36s_ablate) {
+#define WINO4S_CASE(n) case n: conv_winograd36s_f32_kernel<16, false, n><<<grid, 512, 0, stream>>>(a, SH, SW, tilesC, (int)nunits); break;
+            WINO4S_CASE(1) WINO4S_CASE(2) WINO4S_CASE(3) WINO4S_CASE(4) WINO4S_CASE(7) WINO4S_CASE(8) WINO4S_CASE(15) WINO4S_CASE(32) WINO4S_CASE(64) WINO4S_CASE(35) WINO4S_CASE(67)
+            default: return CNM_ERR_BAD_ARG;
+        }
+        CNM_LAUNCH_CHECK();
+        return CNM_OK;
+    }
+#endif
+    if (tsx == 16) {
+        if (ups) conv_winograd36s_f32_kernel<16, true><<<grid, 512, 0, stream>>>(a, SH, SW, tilesC, (int)nunits);
+        else conv_winograd36s_f32_kernel<16, false><<<grid, 512, 0, stream>>>(a, SH, SW, tilesC, (int)nunits);
+    } else {
+        if (ups) conv_winograd36s_f32_kernel<8, true><<<grid, 512, 0, stream>>>(a, SH, SW, tilesC, (int)nunits);
+        else conv_winograd36s_f32_kernel<8, false><<<grid, 512, 0, stream>>>(a, SH, SW, tilesC, (int)nunits);
+    }
+    CNM_LAUNCH_CHECK();
+    return CNM_OK;
+}

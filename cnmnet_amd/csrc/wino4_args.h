@@ -1,0 +1,17 @@
+// Argument block shared by the two 36-point Winograd kernels (conv_winograd4.hip: gather-fed, conv_winograd4s.hip: LDS-staged).
+#pragma once
+#include "cnm_common.h"
+
+struct Wino4Args {
+    const float* in; const float* in2; float* out; const float* u; const float* bias;
+    unsigned in_bytes, in2_bytes;
+    int N, H, W, TH, TW;                 // TH = ceil(H/4), TW = ceil(W/4) tiles
+    int Gin_tot, gin0, Gin2_tot, gin2_0, Gsplit, Gin;
+    int Gout_tot, gout0, Cout;
+    int nchunks, T, relu;                // T = N*TH*TW tiles
+    int ring;                            // fused upsampling: leave the one-pixel output ring without bias / ReLU for the ring kernel
+};
+
+// LDS-staged variant (conv_winograd4s.hip): returns CNM_OK after launching, 1 when the shape is not eligible (the caller
+// then launches the gather-fed kernel), a negative status on launch failure.
+int cnm_wino36s_try_launch(const Wino4Args& a, int M, int ups, hipStream_t stream);

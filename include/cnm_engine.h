@@ -53,6 +53,12 @@ int cnm_tune_upsampled_min_pixels(int n);
  *   workgroup count, stride and reduction depth; 1 .. 5 force 128x256 / 64x512 / 64x128 / 128x512 / 256x256 (falling back
  *   to 64x512 when Cout is not a multiple of 128, to 128x256 when 256x256 does not divide it); any other n only queries. */
 int cnm_tune_glds_tile(int n);
+/* wino36_staged: 1 (default) lets the F(4x4,3x3) entry points (plain, concatenated input, fused up_conv) run the
+ *   LDS-staged persistent kernel (conv_winograd4s.hip: 128 output channels x 16 tiles per workgroup, input patch by
+ *   LDS-DMA) where the output-channel count is a multiple of 128, the image is at least six tiles wide and the units fill
+ *   whole rounds of one workgroup per CU; 2 runs it wherever the shape is eligible; 0 keeps the gather-fed kernel
+ *   everywhere.  Results are bit-identical in all three settings; any other value only queries. */
+int cnm_tune_wino36_staged(int on);
 
 typedef enum cnm_status {
     CNM_OK = 0,

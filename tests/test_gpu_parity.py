@@ -315,6 +315,78 @@ def test_conv3x3_winograd4(dev, ops, cin, cout, rot, N, H, W):
     assert np.abs(got - want).max() < 2e-4 * max(np.abs(want).max(), 1.0), np.abs(got - want).max()
 
 
+@pytest.mark.parametrize("cin,cin2,cout,rot,N,H,W", [
+    (64, 0, 128, 0, 2, 48, 64),        # one tile block per image row, two units per image row pair
+    (67, 0, 128, 3, 1, 40, 72),        # rotated first layer, ragged tile columns (18 tiles: two blocks, second mostly empty)
+    (32, 0, 256, 0, 3, 24, 32),        # 2 x 8 tile blocks, two channel blocks
+    (128, 129, 128, 0, 2, 32, 64),     # concatenated input: 128 + 129 channels, the second view starts mid-chunk
+    (20, 0, 128, 0, 1, 24, 28),        # seven tile columns (2 x 8 blocks, ragged), ragged channel group
+    (16, 0, 128, 0, 40, 16, 64),       # 160 units > one per CU on a small grid is not guaranteed; many images, one chunk
+    (48, 0, 384, 0, 2, 52, 100)])      # three channel blocks, ragged rows and columns
+def test_conv3x3_winograd4_staged(dev, ops, cin, cin2, cout, rot, N, H, W):
+    """LDS-staged persistent F(4x4,3x3) kernel (conv_winograd4s.hip), forced wherever eligible: against the fp64 torch
+    convolution (the gather-fed kernel's bar, 2e-4 of the output scale) and BIT-EQUAL to the gather-fed kernel -- both run
+    the same fp32 operations in the same order, only the operand paths differ."""
+    from cnmnet_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(cin * 13 + H + cout)
+    cp = 4 * ((cin + 3) // 4)
+    x = T(rng.standard_normal((N, cin, H, W)).astype(np.float32))
+    x2 = T(rng.standard_normal((N, cin2, H, W)).astype(np.float32)) if cin2 else None
+    ct = (cp if cin2 else cin) + cin2
+    w = T((rng.standard_normal((cout, ct, 3, 3)) * (2.0 / (ct * 9)) ** 0.5).astype(np.float32))
+    bnp = [T(a.astype(np.float32)) for a in (rng.uniform(0.5, 1.5, cout), rng.normal(0, 0.2, cout), rng.normal(0, 0.2, cout), rng.uniform(0.5, 1.5, cout))]
+    sc = bnp[0].double() / torch.sqrt(bnp[3].double() + 1e-5)
+    xin = x if not cin2 else torch.cat([x, torch.zeros(N, cp - cin, H, W), x2], 1)
+    want = F.relu(F.conv2d(xin.double(), w.double(), padding=1) * sc[None, :, None, None] + (bnp[1].double() - bnp[2].double() * sc)[None, :, None, None]).numpy()
+    bnd = tuple(t.to(dev) for t in bnp)
+    _, bp = ops.pack_conv(w.to(dev), bnd, rot=rot)
+    up = ops.pack_winograd4(w.to(dev), bnd, rot=rot)
+    xr = torch.cat((x[:, rot:], x[:, :rot]), 1) if rot else x
+    xc = ops.nchw_to_c4(xr.to(dev)); x2c = ops.nchw_to_c4(x2.to(dev)) if cin2 else None
+    outs = []
+    old = lib.cnm_tune_wino36_staged(-1)
+    try:
+        for mode in (0, 2):
+            lib.cnm_tune_wino36_staged(mode)
+            outs.append(ops.conv3x3_winograd4_c4(xc, up, bp, cout, True, x2=x2c).clone())
+    finally:
+        lib.cnm_tune_wino36_staged(old)
+    got = ops.c4_to_nchw(outs[1], cout).cpu().numpy()
+    assert np.abs(got - want).max() < 2e-4 * max(np.abs(want).max(), 1.0), np.abs(got - want).max()
+    assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
+
+
+@pytest.mark.parametrize("cin,cout,N,H,W", [(128, 64, 2, 48, 64), (256, 128, 1, 24, 32), (64, 64, 2, 20, 36)])
+def test_conv3x3_upsampled_staged_equals_gather(dev, ops, cin, cout, N, H, W):
+    """Fused up_conv (bilinear x2 + 3x3) on the LDS-staged kernel: clamped (replicate) patch loads, pixel-shuffled stores and
+    the ring contract are bit-equal to the gather-fed kernel, with and without the ring pass, also into a channel slice."""
+    from cnmnet_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(cin + cout + H)
+    xc = ops.nchw_to_c4(T(rng.standard_normal((N, cin, H, W)).astype(np.float32)).to(dev))
+    w = T((rng.standard_normal((cout, cin, 3, 3)) * (2.0 / (cin * 9)) ** 0.5).astype(np.float32)).to(dev)
+    uu, bu, wr = ops.pack_winograd4_upsampled(w)
+    old = lib.cnm_tune_wino36_staged(-1)
+    try:
+        for ring in (None, wr):
+            outs = []
+            for mode in (0, 2):
+                lib.cnm_tune_wino36_staged(mode)
+                outs.append(ops.conv3x3_upsampled_winograd4_c4(xc, uu, bu, cout, True, ring).clone())
+            assert torch.equal(outs[0], outs[1]), (ring is not None, float((outs[0] - outs[1]).abs().max()))
+        wide = []
+        for mode in (0, 2):                                                # output = channel groups 2 .. of a wider tensor: the neighbours stay untouched
+            lib.cnm_tune_wino36_staged(mode)
+            o = torch.full((N, cout // 4 + 3, 2 * H, 2 * W, 4), 7.0, device=dev)
+            _lib.check(lib.cnm_conv3x3_upsampled_winograd4_c4_f32(xc.data_ptr(), xc.shape[1], 0, xc.shape[1], o.data_ptr(), cout // 4 + 3, 2, cout,
+                                                                  uu.data_ptr(), bu.data_ptr(), N, H, W, 0, 1, torch.cuda.current_stream().cuda_stream))
+            wide.append(o)
+        assert torch.equal(wide[0], wide[1]) and float(wide[1][:, :2].min()) == 7.0 and float(wide[1][:, -1].max()) == 7.0
+    finally:
+        lib.cnm_tune_wino36_staged(old)
+
+
 @pytest.mark.parametrize("cin,cout,rot,N,H,W", [(128, 256, 0, 1, 16, 24), (6, 64, 0, 2, 7, 31), (35, 64, 3, 1, 9, 13), (8, 64, 0, 1, 1, 1), (64, 64, 0, 2, 40, 48)])
 def test_conv5x5_winograd(dev, ops, cin, cout, rot, N, H, W):
     """Winograd F(2x2,5x5) (36-point kernel with 2x2 output tiles) twin of the 5x5 stride-1 conv+BN+ReLU."""
