@@ -52,6 +52,10 @@ PROTOTYPES = {
                                            c_i, c_i, c_i, c_i, c_fp]),
     "cnm_conv3x3_s2_winograd_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp]),
     "cnm_conv3x3_upsampled_winograd4_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    "cnm_wino36_sync_floats": (c_sz, []),
+    "cnm_conv3x3_winograd4_sync_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp,
+                                                c_i, c_i, c_i, c_i, c_fp, c_sz, c_fp]),
+    "cnm_conv3x3_upsampled_winograd4_sync_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_sz, c_fp]),
     "cnm_packed_upsampled_ring_floats": (c_sz, [c_i, c_i]),
     "cnm_pack_upsampled_ring_f32": (c_i, [c_fp, c_fp, c_fp, c_f, c_i, c_i, c_fp, c_fp]),
     "cnm_conv3x3_upsampled_ring_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp]),
@@ -139,6 +143,10 @@ def load():
         fn.restype, fn.argtypes = res, args
     if lib.cnm_abi_version() != 4:
         raise EngineError("libcnm_engine.so ABI version %d, expected 4" % lib.cnm_abi_version())
+    # A/B switches without code changes: CNM_TUNE="wino36_staged=2,refine_side_stream=0" calls cnm_tune_<name>(<value>)
+    for item in filter(None, os.environ.get("CNM_TUNE", "").split(",")):
+        name, _, val = item.partition("=")
+        getattr(lib, "cnm_tune_" + name.strip())(int(val))
     _lib = lib
     return lib
 

@@ -290,7 +290,7 @@ static int pack36(const float* w_oihw, const float* bn_gamma, const float* bn_va
 
 static int conv36(const float* in_a, int Ga_total, int ga0, int Ga, const float* in_b, int Gb_total, int gb0, int Gb,
                   float* out, int Gout_total, int gout0, int Cout, const float* u_packed, const float* b_packed,
-                  int N, int H, int W, int ksize, int relu, void* stream, int ups = 0, int ring = 0) {
+                  int N, int H, int W, int ksize, int relu, void* stream, int ups = 0, int ring = 0, float* sync_ws = nullptr, size_t sync_floats = 0) {
     CNM_REQUIRE(in_a && out && u_packed && N > 0 && H > 0 && W > 0 && Ga > 0 && Gb >= 0, CNM_ERR_BAD_ARG);
     CNM_REQUIRE(Cout > 0 && Cout % 64 == 0 && gout0 >= 0 && gout0 + Cout / 4 <= Gout_total, CNM_ERR_BAD_ARG);
     CNM_REQUIRE(!ups || ksize == 3, CNM_ERR_BAD_ARG);
@@ -306,6 +306,7 @@ static int conv36(const float* in_a, int Ga_total, int ga0, int Ga, const float*
     a.Gin_tot = Ga_total; a.gin0 = ga0; a.Gin2_tot = Gb ? Gb_total : Ga_total; a.gin2_0 = Gb ? gb0 : ga0; a.Gsplit = Ga; a.Gin = Ga + Gb;
     a.Gout_tot = Gout_total; a.gout0 = gout0; a.Cout = ups ? 4 * Cout : Cout;     // fused upsampling: four phases of virtual output channels
     a.nchunks = (4 * a.Gin + 15) / 16; a.T = N * a.TH * a.TW; a.relu = relu; a.ring = ring;
+    a.sync_ws = sync_ws; a.sync_floats = sync_floats;
     {
         const int e = cnm_wino36s_try_launch(a, m, ups, cnm_stream(stream));   // LDS-staged persistent variant where eligible
         if (e <= 0) return e;
@@ -331,6 +332,18 @@ extern "C" int cnm_conv3x3_winograd4_c4_f32(const float* in_a, int Ga_total, int
     return conv36(in_a, Ga_total, ga0, Ga, in_b, Gb_total, gb0, Gb, out, Gout_total, gout0, Cout, u_packed, b_packed, N, H, W, 3, relu, stream);
 }
 
+// The same with a sync workspace (cnm_wino36_sync_floats() floats, its first 4096 bytes zero before the first use and left
+// zero by every call, not shared by launches that may run concurrently): the LDS-staged kernel then splits its work into
+// equal phase ranges, one per CU, and adds the partial outputs of a cut unit in a fixed order (bit-reproducible; not bit-equal
+// to the unsplit evaluation, whose accumulation chain is not cut).
+extern "C" int cnm_conv3x3_winograd4_sync_c4_f32(const float* in_a, int Ga_total, int ga0, int Ga,
+                                                 const float* in_b, int Gb_total, int gb0, int Gb,
+                                                 float* out, int Gout_total, int gout0, int Cout,
+                                                 const float* u_packed, const float* b_packed,
+                                                 int N, int H, int W, int relu, float* sync_ws, size_t sync_floats, void* stream) {
+    return conv36(in_a, Ga_total, ga0, Ga, in_b, Gb_total, gb0, Gb, out, Gout_total, gout0, Cout, u_packed, b_packed, N, H, W, 3, relu, stream, 0, 0, sync_ws, sync_floats);
+}
+
 // 3x3 convolution of the bilinear 2x upsampling of `in` ([N][G][H][W][4] -> out [N][Gout][2H][2W][4]) on the
 // low-resolution input: u_packed / b_packed are packed from the four composed phase filters as 4*Cout output channels
 // (phase major).  with_ring = 0: complete result with REPLICATE padding of the upsampled image (differs from the
@@ -341,6 +354,13 @@ extern "C" int cnm_conv3x3_upsampled_winograd4_c4_f32(const float* in, int Gin_t
                                                       const float* u_packed, const float* b_packed,
                                                       int N, int H, int W, int relu, int with_ring, void* stream) {
     return conv36(in, Gin_total, gin0, Gin, nullptr, 0, 0, 0, out, Gout_total, gout0, Cout, u_packed, b_packed, N, H, W, 3, relu, stream, 1, with_ring);
+}
+
+extern "C" int cnm_conv3x3_upsampled_winograd4_sync_c4_f32(const float* in, int Gin_total, int gin0, int Gin,
+                                                           float* out, int Gout_total, int gout0, int Cout,
+                                                           const float* u_packed, const float* b_packed,
+                                                           int N, int H, int W, int relu, int with_ring, float* sync_ws, size_t sync_floats, void* stream) {
+    return conv36(in, Gin_total, gin0, Gin, nullptr, 0, 0, 0, out, Gout_total, gout0, Cout, u_packed, b_packed, N, H, W, 3, relu, stream, 1, with_ring, sync_ws, sync_floats);
 }
 
 // F(2x2,5x5): the same 36-point machine with 2x2 output tiles (25 -> 9 multiplies per output; the row-wise kernel needs 15)

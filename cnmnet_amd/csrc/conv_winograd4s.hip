@@ -35,6 +35,9 @@
 #ifndef WINO4S_WD
 #define WINO4S_WD 4       // weight fragments in flight per wave
 #endif
+#ifndef WINO4S_HI_STEP
+#define WINO4S_HI_STEP 6  // double step at which waves 4-7 start issuing their DMA pieces (waves 0-3: step 0); >= 4
+#endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -63,83 +66,89 @@ __device__ __forceinline__ void wino4s_dma16(unsigned lds_addr, unsigned voff, _
 }
 
 // ABL (debug builds, -DWINO4S_ABLATE, tools/wino36s_ablate.sh): bit 0 no input transform, 1 no DMA, 2 no weight loads in the
-// loop, 3 no B-fragment reads in the loop, 4 no output transform / stores -- timing experiments, results are wrong.
+// loop, 3 no B-fragment reads in the loop, 5 weights from one L1-hot block, 6 half the weight loads -- timing experiments,
+// results are wrong.
+// Register budget (256 per lane, two waves per SIMD): 144 accumulators + 16 (four weight fragments in flight) + 16 (B
+// fragments of this and the next double step) leave ~80.  Hence: the transform runs as two passes (frequency row T, then
+// rows P / M: at most 16 values live), the per-unit DMA offsets live in LDS, everything the output transform needs is
+// derived inside it from an opaque copy of the lane id (loop-invariant code motion would otherwise park ~20 registers
+// across the phase loop), and the two transform constants are wave-uniform (SGPR operands).
 template <int TSX, bool UPS, int ABL = 0>                                // tile block = (16 / TSX) x TSX tiles
-__global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino4Args a, const int SH, const int SW, const int tilesC, const int nunits) {
+__global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino4Args a, const int SH, const int SW, const int tilesC, const int nunits,
+                                                                       unsigned* __restrict__ sync_flags, float* __restrict__ sync_slots) {
     constexpr int TSY = 16 / TSX, PR = 4 * TSY + 2, PC = 4 * TSX + 2, NSLOT = PR * PC;
     constexpr int NPIECE = (NSLOT + 63) / 64, PLANE = (NPIECE * 64 + 1) * 16, RAWBUF = 4 * PLANE;   // bytes
     constexpr int VBUF = 36 * 16 * 64, RAW0 = 2 * VBUF;                  // bytes
     constexpr int NDMA = 4 * NPIECE, DPW = (NDMA + 7) / 8;               // DMA pieces per chunk / per wave
+    constexpr int DV0 = RAW0 + 2 * RAWBUF;                               // [DPW][512] per-thread DMA offsets of the unit being staged
     constexpr int WD = WINO4S_WD, NXI = 36;
+    constexpr int SLOT_BYTES = 8 * 16 * 64 * 16;                         // one range's partial output: 8 waves x 16 pixels x 64 lanes x float4 = 128 KB
     static_assert(PLANE % 128 == 16 && NXI % WD == 0 && WD % 2 == 0, "layout");
-    __shared__ __attribute__((aligned(16))) char smem[2 * VBUF + 2 * RAWBUF];   // 128 KB (TSX 16) / 120 KB (TSX 8)
+    __shared__ __attribute__((aligned(16))) char smem[DV0 + DPW * 512 * 4];   // 136 KB (TSX 16) / 126 KB (TSX 8)
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int hi = wave >> 2;
     const int HW = a.H * a.W, SHW = SH * SW, ncb16 = a.Cout / 16;
     const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem;
 
-    const int G = gridDim.x, first = xcd_remap(blockIdx.x, G);
-    if (first >= nunits) return;
-    const int nmine = (nunits - first + G - 1) / G;
-    const int P = nmine * a.nchunks;                                     // phases of this workgroup
+    // Work = the flat list of phases (unit, chunk), unit = tile block x 128-channel block (channel block fastest).  Range r
+    // of the G equal contiguous ranges belongs to this workgroup (ranges of one XCD are neighbours).  With a sync
+    // workspace the ranges cut units wherever the arithmetic says (every CU gets the same number of phases, whatever the
+    // unit count); without one they are rounded to unit boundaries.
+    const int G = gridDim.x, rng = xcd_remap(blockIdx.x, G), nch = a.nchunks;
+    const long long T = (long long)nunits * nch;
+    const auto range_begin = [&](int r) { return sync_flags ? (int)(T * r / G) : (int)((long long)nunits * r / G) * nch; };
+    const int ps = range_begin(rng), pe = range_begin(rng + 1);
+    const int P = pe - ps;                                               // phases of this workgroup
+    if (P <= 0) return;
 
     // ---- stage role: pieces n = wave + 8 m of the chunk's NDMA (plane q = n / NPIECE, piece k = n % NPIECE)
-    unsigned dvoff[DPW];                                                 // per unit: byte offset of this lane's pixel inside one channel group plane of one image
-    int dq[DPW]; unsigned dlds[DPW];
-#pragma unroll
-    for (int m = 0; m < DPW; ++m) {
-        const int n = wave + 8 * m;
-        dq[m] = n / NPIECE;
-        dlds[m] = lds0 + RAW0 + dq[m] * PLANE + (n - dq[m] * NPIECE) * 1024;
-    }
-    int dk = 0, dc = 0, dimg = 0;                                        // cursor of the stage role: unit ordinal, chunk; image of that unit
-    auto dma_unit = [&]() {                                              // per-lane offsets for unit dk
-        const int uid = first + dk * G;
-        const int strip = uid / tilesC;
+    int du = ps / nch, dc = ps - du * nch, dgp = ps, dimg = 0;           // cursor of the stage role: unit, chunk, global phase; image of that unit
+    auto dma_unit = [&]() {                                              // per-lane offsets for unit du -> LDS (each thread re-reads only its own words)
+        const int strip = du / tilesC;
         dimg = strip / SHW;
         const int rem = strip - dimg * SHW, sy = rem / SW, sx = rem - sy * SW;
         const int y0 = 4 * TSY * sy - 1, x0 = 4 * TSX * sx - 1;
 #pragma unroll
         for (int m = 0; m < DPW; ++m) {
-            const int n = wave + 8 * m, k = n - dq[m] * NPIECE;
+            const int n = wave + 8 * m, k = n % NPIECE;
             const int slot = 64 * k + lane, r = slot / PC, pc = slot - r * PC;
             int y = y0 + r, x = x0 + pc;
             bool ok = slot < NSLOT;
             if constexpr (UPS) { y = min(max(y, 0), a.H - 1); x = min(max(x, 0), a.W - 1); }
             else ok = ok & ((unsigned)y < (unsigned)a.H) & ((unsigned)x < (unsigned)a.W);
-            dvoff[m] = ok ? (unsigned)(y * a.W + x) * 16u : 0xFFFFFFFFu;
+            *reinterpret_cast<unsigned*>(smem + DV0 + (m * 512 + t) * 4) = ok ? (unsigned)(y * a.W + x) * 16u : 0xFFFFFFFFu;
         }
     };
-    auto dma_piece = [&](int m) {                                        // piece m of phase (dk, dc) into the buffer of that phase
-        if ((ABL & 2) || wave + 8 * m >= NDMA || dk >= nmine) return;
-        const int g = dc * 4 + dq[m];
+    auto dma_piece = [&](int m) {                                        // piece m of phase (du, dc) into the buffer of that phase
+        const int n = wave + 8 * m;
+        if ((ABL & 2) || n >= NDMA || dgp >= pe) return;
+        const int q = n / NPIECE, g = dc * 4 + q;
         const bool s1 = g < a.Gsplit;
         const unsigned bytes = g < a.Gin ? (s1 ? a.in_bytes : a.in2_bytes) : 0u;
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s1 ? a.in : a.in2), 0, bytes, 0x00020000);
         const unsigned gg = s1 ? (unsigned)(dimg * a.Gin_tot + a.gin0 + g) : (unsigned)(dimg * a.Gin2_tot + a.gin2_0 + g - a.Gsplit);
-        wino4s_dma16(dlds[m] + (unsigned)(((dk * a.nchunks + dc) & 1) * RAWBUF), dvoff[m], rsrc, gg * (unsigned)HW * 16u);
+        const unsigned voff = *reinterpret_cast<const unsigned*>(smem + DV0 + (m * 512 + t) * 4);
+        wino4s_dma16(lds0 + RAW0 + (unsigned)(((dgp - ps) & 1) * RAWBUF + q * PLANE + (n - q * NPIECE) * 1024), voff, rsrc, gg * (unsigned)HW * 16u);
     };
-    auto dma_advance = [&]() { if (++dc == a.nchunks) { dc = 0; ++dk; if (dk < nmine) dma_unit(); } };
+    auto dma_advance = [&]() { ++dgp; if (++dc == nch) { dc = 0; ++du; if (dgp < pe) dma_unit(); } };
 
     // ---- transform role
     const int ttile = 4 * (wave & 3) + (lane >> 4), tci = lane & 15, tcg = tci >> 2;
-    const unsigned rbase = RAW0 + tcg * PLANE + (((ttile / TSX) * 4) * PC + (ttile % TSX) * 4) * 16 + (tci & 3) * 4;
-    const unsigned rbaseT = rbase + hi * PC * 16;
-    const unsigned wbase = ttile * 64 + ((tcg ^ ((ttile >> 1) & 3)) * 4 + (tci & 3)) * 4;
-    const unsigned wT = wbase + hi * 5 * 6144, wR = wbase + 6144 + hi * 2 * 6144;
-    const float beta = hi ? -1.f : -4.f, gamma = hi ? 2.f : 1.f;
-    float q[7], rowT[6], rowP[6], rowM[6];
+    const unsigned rbase = RAW0 + tcg * PLANE + (((ttile / TSX) * 4) * PC + (ttile % TSX) * 4) * 16 + (tci & 3) * 4;   // + hi * PC * 16 for the shifted taps
+    const unsigned wbase = ttile * 64 + ((tcg ^ ((ttile >> 1) & 3)) * 4 + (tci & 3)) * 4;   // row T at + hi * 5 * 6144, row P at + 6144 + hi * 2 * 6144, row M 6144 further
+    const float beta = __int_as_float(__builtin_amdgcn_readfirstlane(hi ? 0xbf800000 : 0xc0800000));    // -1 : -4
+    const float gamma = __int_as_float(__builtin_amdgcn_readfirstlane(hi ? 0x40000000 : 0x3f800000));   //  2 :  1
     auto ldsf = [&](unsigned off) { return *reinterpret_cast<const float*>(smem + off); };
-    auto tr_read = [&](int j, unsigned rb) {                             // rb = byte offset of the raw buffer being transformed
+    float tq[6][3], pq[6][4], rowT[6], rowP[6], rowM[6];
+    // rows {0,1,2} (waves 0-3) / {5,3,4} (waves 4-7) of B^T d, column j: the gather-fed kernel's column_pass, half of it.
+    // Row T = 4 d[0+s] - 5 d[2+s] + d[4+s] (s = 0 / 1: the shifted base rT), rows P, M = E +- gamma O with
+    // E = beta d2 + d4, O = beta d1 + d3 (beta, gamma = -4, 1 / -1, 2).
+    auto trT_read = [&](int j, unsigned rT) { if (ABL & 1) return; tq[j][0] = ldsf(rT + (0 * PC + j) * 16); tq[j][1] = ldsf(rT + (2 * PC + j) * 16); tq[j][2] = ldsf(rT + (4 * PC + j) * 16); };
+    auto trT_col = [&](int j) { if (ABL & 1) return; rowT[j] = fmaf(4.f, tq[j][0], fmaf(-5.f, tq[j][1], tq[j][2])); };
+    auto trP_read = [&](int j, unsigned r0) { if (ABL & 1) return; pq[j][0] = ldsf(r0 + (1 * PC + j) * 16); pq[j][1] = ldsf(r0 + (2 * PC + j) * 16); pq[j][2] = ldsf(r0 + (3 * PC + j) * 16); pq[j][3] = ldsf(r0 + (4 * PC + j) * 16); };
+    auto trP_col = [&](int j) {
         if (ABL & 1) return;
-        q[0] = ldsf(rbaseT + rb + (0 * PC + j) * 16); q[1] = ldsf(rbase + rb + (1 * PC + j) * 16); q[2] = ldsf(rbase + rb + (2 * PC + j) * 16);
-        q[3] = ldsf(rbaseT + rb + (2 * PC + j) * 16); q[4] = ldsf(rbase + rb + (3 * PC + j) * 16); q[5] = ldsf(rbase + rb + (4 * PC + j) * 16);
-        q[6] = ldsf(rbaseT + rb + (4 * PC + j) * 16);
-    };
-    auto tr_col = [&](int j) {                                           // rows {0,1,2} / {5,3,4} of B^T d, column j (the gather-fed kernel's column_pass, half of it)
-        if (ABL & 1) return;
-        rowT[j] = fmaf(4.f, q[0], fmaf(-5.f, q[3], q[6]));
-        const float E = fmaf(beta, q[2], q[5]), O = fmaf(beta, q[1], q[4]);
+        const float E = fmaf(beta, pq[j][1], pq[j][3]), O = fmaf(beta, pq[j][0], pq[j][2]);
         rowP[j] = fmaf(gamma, O, E); rowM[j] = fmaf(-gamma, O, E);
     };
     auto tr_row = [&](float* x, unsigned wb) {                           // full row pass + store of the six points of one frequency row
@@ -152,8 +161,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
     // ---- multiply role
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.u), 0, (unsigned)((size_t)a.nchunks * ncb16 * NXI * 1024), 0x00020000);
     const unsigned lane16 = lane * 16;
-    const int rtile = lane & 15, kg = lane >> 4;
-    const unsigned bvoff = (rtile * 16 + (kg ^ ((rtile >> 1) & 3)) * 4) * 4;
+    const unsigned bvoff = ((lane & 15) * 16 + ((lane >> 4) ^ (((lane & 15) >> 1) & 3)) * 4) * 4;
     auto ldA = [&](unsigned soff) { const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, soff, 0); return *reinterpret_cast<const float4*>(&v); };
     auto abase = [&](int cblk, int c) {                                  // byte offset of fragment 0 of (128-channel block, chunk c) for this wave
         return (unsigned)((c * ncb16 + cblk * 8 + wave) * NXI) * 1024u;
@@ -170,22 +178,29 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
 #pragma unroll
     for (int m = 0; m < DPW; ++m) dma_piece(m);
     dma_advance();
-    int mk = 0, mc = 0;                                                  // cursor of the multiply role
-    int mcblk = first % tilesC, ncblk = (first + G) % tilesC;            // channel block of unit mk / mk + 1
-    unsigned a_cur = abase(mcblk, 0);
+    int mu = ps / nch, mc = ps - mu * nch;                               // cursor of the multiply role: unit, chunk
+    int mcblk = mu % tilesC;                                             // channel block of unit mu
+    int part_c0 = mc;                                                    // first chunk of the part of unit mu this workgroup multiplies
+    unsigned a_cur = abase(mcblk, mc);
     float4 af[WD];
 #pragma unroll
     for (int s = 0; s < WD; ++s) af[s] = ldA(a_cur + s * 1024);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wino4s_lds_barrier();
+    {
+        const unsigned r0 = rbase, rT = rbase + hi * PC * 16, w0 = wbase;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) { tr_read(j, 0); tr_col(j); }
-    tr_row(rowT, wT); tr_row(rowP, wR); tr_row(rowM, wR + 6144);
+        for (int j = 0; j < 6; ++j) { trT_read(j, rT); trT_col(j); trP_read(j, r0); trP_col(j); }
+        tr_row(rowT, w0 + hi * 5 * 6144); tr_row(rowP, w0 + 6144 + hi * 2 * 6144); tr_row(rowM, w0 + 2 * 6144 + hi * 2 * 6144);
+    }
     wino4s_lds_barrier();
 
     for (int p = 0; p < P; ++p) {
-        const unsigned vc = (p & 1) * VBUF + bvoff, vn = ((p + 1) & 1) * VBUF, rn = ((p + 1) & 1) * RAWBUF;
-        const bool lastc = mc + 1 == a.nchunks;
+        const unsigned vc = (p & 1) * VBUF + bvoff;
+        const unsigned r0 = rbase + ((p + 1) & 1) * RAWBUF, rT = r0 + hi * PC * 16;      // raw buffer of phase p + 1
+        const unsigned w0 = wbase + ((p + 1) & 1) * VBUF;                                 // V buffer of phase p + 1
+        const bool lastc = mc + 1 == nch;
+        const int ncblk = mcblk + 1 == tilesC ? 0 : mcblk + 1;
         const unsigned a_nxt = p + 1 < P ? (lastc ? abase(ncblk, 0) : abase(mcblk, mc + 1)) : a_cur;
         float4 bf0 = *reinterpret_cast<const float4*>(smem + vc);
         float4 bf1 = *reinterpret_cast<const float4*>(smem + vc + 1024);
@@ -210,15 +225,17 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
                 af[x0 % WD] = ldA(x0 + WD < NXI ? a_cur + (x0 + WD) * 1024 : a_nxt + (x0 + WD - NXI) * 1024);
                 af[x1 % WD] = ldA(x1 + WD < NXI ? a_cur + (x1 + WD) * 1024 : a_nxt + (x1 + WD - NXI) * 1024);
             }
-            // between the MFMAs: transform of phase p + 1 (raw reads of column xp, column xp - 1; then the three rows),
+            // between the MFMAs: the transform of phase p + 1 -- row T (double steps 0-4), rows P and M (3-11) -- and the
             // DMA of phase p + 2 (waves 0-3: double steps 0.., waves 4-7: double steps 6..)
-            if (xp >= 1 && xp < 7) tr_col(xp - 1);
-            if (xp < 6) tr_read(xp, rn);
-            if (xp == 7) tr_row(rowT, wT + vn);
-            if (xp == 8) tr_row(rowP, wR + vn);
-            if (xp == 9) tr_row(rowM, wR + 6144 + vn);
+            if (xp >= 1 && xp <= 3) { trT_col(2 * xp - 2); trT_col(2 * xp - 1); }
+            if (xp <= 2) { trT_read(2 * xp, rT); trT_read(2 * xp + 1, rT); }
+            if (xp == 4) tr_row(rowT, w0 + hi * 5 * 6144);
+            if (xp >= 4 && xp <= 9) trP_col(xp - 4);
+            if (xp >= 3 && xp <= 8) trP_read(xp - 3, r0);
+            if (xp == 10) tr_row(rowP, w0 + 6144 + hi * 2 * 6144);
+            if (xp == 11) tr_row(rowM, w0 + 2 * 6144 + hi * 2 * 6144);
             if (xp < DPW) { if (!hi) { dma_piece(xp); if (xp == DPW - 1) dma_advance(); } }
-            else if (xp >= 6 && xp < 6 + DPW) { if (hi) { dma_piece(xp - 6); if (xp - 6 == DPW - 1) dma_advance(); } }
+            else if (xp >= WINO4S_HI_STEP && xp < WINO4S_HI_STEP + DPW) { if (hi) { dma_piece(xp - WINO4S_HI_STEP); if (xp - WINO4S_HI_STEP == DPW - 1) dma_advance(); } }
             acc[x0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc[x0], 0, 0, 0);
             acc[x1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, acc[x1], 0, 0, 0);
             acc[x0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc[x0], 0, 0, 0);
@@ -231,62 +248,114 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WD) : "memory");
         wino4s_lds_barrier();                                            // V / RAW of phase p + 1 complete; the buffers of phase p are free
         a_cur = a_nxt;
-        if (!lastc) { ++mc; continue; }
+        if (!lastc && p + 1 < P) { ++mc; continue; }
 
-        // ---- output transform of unit mk: acc row = cout 4 kg + r (one c4 group), col = tile rtile
-        if (ABL & 16) { if (acc[0][0] == 123.456f) a.out[lane] = acc[7][1] + acc[35][3]; }
-        else {
-            const int uid = first + mk * G;
-            const int cblk = mcblk, strip = uid / tilesC;
+        // ---- a part of unit mu ends here (chunks part_c0 .. mc).  Whole unit: finish it.  Head part (chunk 0 .. mc <
+        // last): the following ranges hold the rest -- add their published partial outputs in range order, then finish.
+        // Any other part: publish the partial output (no bias / ReLU) in this range's slot.
+        const bool publish = part_c0 != 0;
+        int nsrc = 0;                                                    // partial outputs to add: ranges rng + 1 .. rng + nsrc
+        if (!publish && !lastc) {
+            for (int rem = nch - 1 - mc; rem > 0; ++nsrc) rem -= range_begin(rng + nsrc + 2) - range_begin(rng + nsrc + 1);
+            if (t == 0) {                                                // one lane polls (relaxed), one acquire for the workgroup, flags re-armed for the next launch
+                for (int k = 1; k <= nsrc; ++k) {
+                    unsigned spins = 0;
+                    while (__hip_atomic_load(sync_flags + rng + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++spins < (1u << 24)) __builtin_amdgcn_s_sleep(8);
+                    __hip_atomic_store(sync_flags + rng + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            __syncthreads();
+        }
+        // ---- output transform of the part: acc row = cout 4 kg + r (one c4 group), col = tile rtile
+        if (ABL & 16) {                                                  // timing experiment: no output transform / stores (the accumulators stay live)
+#pragma unroll
+            for (int x = 0; x < NXI; ++x) { asm volatile("" :: "v"(acc[x])); acc[x] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        } else {
+            int le = lane; asm volatile("" : "+v"(le));                  // opaque: nothing below is loop-invariant to the compiler
+            const int rtile = le & 15, kg = le >> 4;
+            const int strip = mu / tilesC;
             const int img = strip / SHW, rem = strip - img * SHW, sy = rem / SW, sx = rem - sy * SW;
             const int oty = sy * TSY + rtile / TSX, otx = sx * TSX + rtile % TSX;
-            const int co = cblk * 128 + wave * 16 + 4 * kg;
+            const int co = mcblk * 128 + wave * 16 + 4 * kg;
             const float4 bv = a.bias ? *reinterpret_cast<const float4*>(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
             const f32x4 bb = {bv.x, bv.y, bv.z, bv.w};
             f32x4 s[4][6];
 #pragma unroll
             for (int j = 0; j < 6; ++j) WINO4S_AT(s[0][j], s[1][j], s[2][j], s[3][j], acc[0 * 6 + j], acc[1 * 6 + j], acc[2 * 6 + j], acc[3 * 6 + j], acc[4 * 6 + j], acc[5 * 6 + j]);
-            const bool tok = oty < a.TH && otx < a.TW;
-            if constexpr (UPS) {
-                const int Cr = a.Cout >> 2, ph = co / Cr, cr = co - ph * Cr, pa = ph >> 1, pb = ph & 1;
-                const int Ho = 2 * a.H, Wo = 2 * a.W;
-                float* obase = a.out + c4_offset(img, a.Gout_tot, a.gout0 + (cr >> 2), 4 * HW, 0);
+            // partial outputs travel as [range][wave][pixel 4 i + x][lane] float4: every lane re-reads exactly what its twin wrote
+            const unsigned slot_lane = (unsigned)(wave * 16 * 64 + le);
+            const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(sync_slots, 0, sync_slots ? (unsigned)G * (unsigned)SLOT_BYTES : 0u, 0x00020000);
+            // Finished rows leave through LDS: a lane owns 4 channels of a 4 x 4 tile, i.e. 16-byte pieces 64 bytes apart --
+            // stored directly, a unit is 8192 partial-line writes, and with every workgroup of the chip reaching its output
+            // transform at the same time that burst costs 10-30 % of a layer (tools/wino36s_ablate.sh).  Row i of the 16
+            // tiles is transposed in a wave-private 4.25 KB corner of the V buffer the multiply role has just released
+            // ([channel group][x][tile], x pitch 272 bytes: conflict-free writes, two-way reads) so that lane = pixel:
+            // one store instruction = 64 consecutive pixels of one channel group = 1 KB (two 512-byte rows for 2 x 8 blocks).
+            const unsigned stg = (unsigned)((p & 1) * VBUF + wave * 4352);
+            const unsigned stw = stg + kg * 1088 + rtile * 16, str_ = stg + (le & 3) * 272 + (le >> 2) * 16;
+            const int qt = le >> 2, qty = sy * TSY + qt / TSX, qtx = sx * TSX + qt % TSX;          // lane = pixel (tile qt, column le & 3) of the row being stored
+            const int qcol = 4 * qtx + (le & 3);
+            const bool qok = qty < a.TH && qtx < a.TW;
+            const int cow = mcblk * 128 + wave * 16;                                                // the wave's 16 output channels
+            const int Cr = a.Cout >> 2, ph = UPS ? cow / Cr : 0, pa = ph >> 1, pb = ph & 1;        // UPS: virtual channels -> (phase, real channels)
+            const int Ho = 2 * a.H, Wo = 2 * a.W;
+            float* obase = UPS ? a.out + c4_offset(img, a.Gout_tot, a.gout0 + ((cow - ph * Cr) >> 2), 4 * HW, 0)
+                               : a.out + c4_offset(img, a.Gout_tot, a.gout0 + (cow >> 2), HW, 0);
+            const size_t gstride = (size_t)(UPS ? 4 * HW : HW) * 4;                                 // floats between channel groups
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    f32x4 y[4];
-                    WINO4S_AT(y[0], y[1], y[2], y[3], s[i][0], s[i][1], s[i][2], s[i][3], s[i][4], s[i][5]);
+            for (int i = 0; i < 4; ++i) {
+                f32x4 y[4];
+                WINO4S_AT(y[0], y[1], y[2], y[3], s[i][0], s[i][1], s[i][2], s[i][3], s[i][4], s[i][5]);
+                if (publish) {                                           // write-through (sc1) stores: no release fence needed before the flag
+#pragma unroll
+                    for (int x = 0; x < 4; ++x)
+                        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&y[x]), srsrc, (slot_lane + (unsigned)(4 * i + x) * 64u) * 16u, (unsigned)rng * (unsigned)SLOT_BYTES, 16);
+                    continue;
+                }
+                for (int k = 1; k <= nsrc; ++k) {                        // fixed order: own part, then the following ranges
+                    // sc1 loads, matching the sc1 stores: with plain loads behind the acquire a few 64-byte pieces per slot
+                    // came back stale on MI355X (tools/wino36s_vis.sh)
 #pragma unroll
                     for (int x = 0; x < 4; ++x) {
-                        const int ly = 4 * oty + i, lx = 4 * otx + x;
-                        const int oy = 2 * ly + pa, ox = 2 * lx + pb;
-                        const bool ring = (oy == 0) | (oy == Ho - 1) | (ox == 0) | (ox == Wo - 1);   // finished by the ring kernel
-                        f32x4 v = y[x];
-                        if (!ring || !a.ring) {
-                            v += bb;
-                            if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-                        }
-                        if (tok && ly < a.H && lx < a.W) *reinterpret_cast<f32x4*>(obase + (size_t)(oy * Wo + ox) * 4) = v;
+                        const u32x4 pv = __builtin_amdgcn_raw_buffer_load_b128(srsrc, (slot_lane + (unsigned)(4 * i + x) * 64u) * 16u, (unsigned)(rng + k) * (unsigned)SLOT_BYTES, 16);
+                        y[x] += *reinterpret_cast<const f32x4*>(&pv);
                     }
                 }
-            } else {
-                float* obase = a.out + c4_offset(img, a.Gout_tot, a.gout0 + (co >> 2), HW, 0);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    f32x4 y[4];
-                    WINO4S_AT(y[0], y[1], y[2], y[3], s[i][0], s[i][1], s[i][2], s[i][3], s[i][4], s[i][5]);
-#pragma unroll
-                    for (int x = 0; x < 4; ++x) {
-                        const int oy = 4 * oty + i, ox = 4 * otx + x;
-                        f32x4 v = y[x] + bb;
+                for (int x = 0; x < 4; ++x) {                            // bias, ReLU (own channels), then into the staging row
+                    f32x4 v = y[x];
+                    bool fin = true;
+                    if constexpr (UPS) {
+                        const int oy = 2 * (4 * oty + i) + pa, ox = 2 * (4 * otx + x) + pb;
+                        fin = !(a.ring && ((oy == 0) | (oy == Ho - 1) | (ox == 0) | (ox == Wo - 1)));   // ring pixels are finished by the ring kernel
+                    }
+                    if (fin) {
+                        v += bb;
                         if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-                        if (tok && oy < a.H && ox < a.W) *reinterpret_cast<f32x4*>(obase + (size_t)(oy * a.W + ox) * 4) = v;
                     }
+                    *reinterpret_cast<f32x4*>(smem + stw + x * 272) = v;
                 }
+                const int qrow = 4 * qty + i;
+                const bool st = qok && qrow < a.H && qcol < a.W;
+                float* orow = UPS ? obase + (size_t)((2 * qrow + pa) * Wo + 2 * qcol + pb) * 4 : obase + (size_t)(qrow * a.W + qcol) * 4;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {                            // LDS operations of one wave complete in order: no wait between the writes above and these reads
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(smem + str_ + g * 1088);
+                    if (st) *reinterpret_cast<f32x4*>(orow + g * gstride) = v;
+                }
+            }
+            if (publish) {                                               // every storing wave drains its stores, then ONE lane raises the flag
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (t == 0) __hip_atomic_store(sync_flags + rng, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
 #pragma unroll
             for (int x = 0; x < NXI; ++x) acc[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+            wino4s_lds_barrier();                                        // every wave is done with its staging corner before the next phase's transform writes that V buffer
         }
-        ++mk; mc = 0; mcblk = ncblk; ncblk = (first + (mk + 1) * G) % tilesC;
+        if (lastc) { ++mu; mcblk = ncblk; }
+        mc = 0; part_c0 = 0;
     }
 }
 
@@ -306,6 +375,11 @@ static int wino4s_cus() {                                                // comp
     return cus[dev];
 }
 
+// Sync workspace of one launch: kSyncFlagBytes of flag words (one per range, zero between launches: every raised flag is
+// lowered by its one consumer) followed by one partial-output slot per range.
+static constexpr size_t kSyncFlagBytes = 4096, kSyncSlotBytes = 8 * 16 * 64 * 16;
+extern "C" size_t cnm_wino36_sync_floats(void) { return (kSyncFlagBytes + (size_t)wino4s_cus() * kSyncSlotBytes) / 4; }
+
 int cnm_wino36s_try_launch(const Wino4Args& a, int M, int ups, hipStream_t stream) {
     if (!g_wino36_staged || M != 4 || a.Cout % 128) return 1;
     int tsx = 0;
@@ -314,18 +388,28 @@ int cnm_wino36s_try_launch(const Wino4Args& a, int M, int ups, hipStream_t strea
     const int tsy = 16 / tsx;
     const int SH = cnm_ceil_div(a.TH, tsy), SW = cnm_ceil_div(a.TW, tsx), tilesC = a.Cout / 128;
     const long long nunits = (long long)a.N * SH * SW * tilesC;
-    if (nunits <= 0 || nunits > 0x7FFFFFFF || (long long)a.nchunks * (a.Cout / 16) * 36 * 1024 >= 0xFFFFFFFFll) return 1;
+    if (nunits <= 0 || nunits * a.nchunks > 0x7FFFFFFF || (long long)a.nchunks * (a.Cout / 16) * 36 * 1024 >= 0xFFFFFFFFll) return 1;
     const int cus = wino4s_cus();
-    const int grid = (int)(nunits < cus ? nunits : cus);
-    // One workgroup per CU walks ceil(units / CUs) units: a mostly empty last round costs more than the kernel gains
-    // (measured 1.09-1.13x on whole rounds, 0.85-0.89x at 1.5 rounds, tools/wino36s_probe.py); the gather-fed kernel, two
-    // independent workgroups per CU, balances those better.  g_wino36_staged == 2 forces the staged kernel (tests).
-    if (g_wino36_staged != 2 && nunits > cus && (double)((nunits + cus - 1) / cus) * cus / (double)nunits > 1.15) return 1;
+    int grid = (int)(nunits < cus ? nunits : cus);
+    unsigned* flags = nullptr; float* slots = nullptr;
+    if (a.sync_ws && cus * 4 <= (int)kSyncFlagBytes && a.sync_floats * 4 >= kSyncFlagBytes + (size_t)cus * kSyncSlotBytes) {
+        // phase ranges may cut units: every CU gets the same number of phases (at least four, or the prologue and the
+        // fix-up of a range cost more than they balance)
+        const long long T = nunits * a.nchunks;
+        grid = (int)(T / 4 < cus ? (T / 4 > 0 ? T / 4 : 1) : cus);
+        flags = reinterpret_cast<unsigned*>(a.sync_ws);
+        slots = a.sync_ws + kSyncFlagBytes / 4;
+    } else if (g_wino36_staged != 2 && nunits > cus && (double)((nunits + cus - 1) / cus) * cus / (double)nunits > 1.15) {
+        // Without a sync workspace ranges end on unit boundaries: one workgroup per CU walks ceil(units / CUs) units, and a
+        // mostly empty last round costs more than the kernel gains (1.09-1.13x on whole rounds, 0.85-0.89x at 1.5 rounds,
+        // tools/wino36s_probe.py); the gather-fed kernel, two independent workgroups per CU, balances those better.
+        return 1;
+    }
 #ifdef WINO4S_ABLATE
     if (g_wino36s_ablate && tsx == 16 && !ups) {
         switch (g_wino36s_ablate) {
-#define WINO4S_CASE(n) case n: conv_winograd36s_f32_kernel<16, false, n><<<grid, 512, 0, stream>>>(a, SH, SW, tilesC, (int)nunits); break;
-            WINO4S_CASE(1) WINO4S_CASE(2) WINO4S_CASE(3) WINO4S_CASE(4) WINO4S_CASE(7) WINO4S_CASE(8) WINO4S_CASE(15) WINO4S_CASE(32) WINO4S_CASE(64) WINO4S_CASE(35) WINO4S_CASE(67)
+#define WINO4S_CASE(n) case n: conv_winograd36s_f32_kernel<16, false, n><<<grid, 512, 0, stream>>>(a, SH, SW, tilesC, (int)nunits, flags, slots); break;
+            WINO4S_CASE(1) WINO4S_CASE(2) WINO4S_CASE(3) WINO4S_CASE(4) WINO4S_CASE(7) WINO4S_CASE(8) WINO4S_CASE(15) WINO4S_CASE(16) WINO4S_CASE(18) WINO4S_CASE(32) WINO4S_CASE(64)
             default: return CNM_ERR_BAD_ARG;
         }
         CNM_LAUNCH_CHECK();
@@ -333,11 +417,11 @@ int cnm_wino36s_try_launch(const Wino4Args& a, int M, int ups, hipStream_t strea
     }
 #endif
     if (tsx == 16) {
-        if (ups) conv_winograd36s_f32_kernel<16, true><<<grid, 512, 0, stream>>>(a, SH, SW, tilesC, (int)nunits);
-        else conv_winograd36s_f32_kernel<16, false><<<grid, 512, 0, stream>>>(a, SH, SW, tilesC, (int)nunits);
+        if (ups) conv_winograd36s_f32_kernel<16, true><<<grid, 512, 0, stream>>>(a, SH, SW, tilesC, (int)nunits, flags, slots);
+        else conv_winograd36s_f32_kernel<16, false><<<grid, 512, 0, stream>>>(a, SH, SW, tilesC, (int)nunits, flags, slots);
     } else {
-        if (ups) conv_winograd36s_f32_kernel<8, true><<<grid, 512, 0, stream>>>(a, SH, SW, tilesC, (int)nunits);
-        else conv_winograd36s_f32_kernel<8, false><<<grid, 512, 0, stream>>>(a, SH, SW, tilesC, (int)nunits);
+        if (ups) conv_winograd36s_f32_kernel<8, true><<<grid, 512, 0, stream>>>(a, SH, SW, tilesC, (int)nunits, flags, slots);
+        else conv_winograd36s_f32_kernel<8, false><<<grid, 512, 0, stream>>>(a, SH, SW, tilesC, (int)nunits, flags, slots);
     }
     CNM_LAUNCH_CHECK();
     return CNM_OK;

@@ -123,17 +123,18 @@ extern "C" int cnm_tune_upsampled_min_pixels(int n) { const int old = g_upsample
 struct EngF32 {
     static constexpr int GD = 4;
     // nn.Upsample(2, bilinear) + conv3x3 + BN + ReLU (up_conv_layer, depthNet_model.py:89-112): in [N][G][H][W] -> out at 2H x 2W
-    static int upconv(const float* in, int G, float* up_tmp, float* out, int Gto, int go0, int Cout, const cnm_layer_weights& w, int N, int H, int W, void* s) {
+    // sync: the stream's sync workspace for the LDS-staged F(4x4,3x3) kernel (cnm_wino36_sync_floats() floats), or null
+    static int upconv(const float* in, int G, float* up_tmp, float* out, int Gto, int go0, int Cout, const cnm_layer_weights& w, int N, int H, int W, float* sync, void* s) {
         if (w.uu && w.bu && w.wr && G * 4 <= 256 && (long long)N * 4 * H * W >= g_upsampled_min_pixels) {
-            const int e = cnm_conv3x3_upsampled_winograd4_c4_f32(in, G, 0, G, out, Gto, go0, Cout, w.uu, w.bu, N, H, W, 1, 1, s);
+            const int e = cnm_conv3x3_upsampled_winograd4_sync_c4_f32(in, G, 0, G, out, Gto, go0, Cout, w.uu, w.bu, N, H, W, 1, 1, sync, sync ? cnm_wino36_sync_floats() : 0, s);
             return e != CNM_OK ? e : cnm_conv3x3_upsampled_ring_c4_f32(in, G, 0, G, out, Gto, go0, Cout, w.wr, w.b, N, H, W, 1, s);
         }
         const int e = up(in, G, up_tmp, N, H, W, s);
-        return e != CNM_OK ? e : conv(up_tmp, G, 0, G, out, Gto, go0, Cout, w, N, 2 * H, 2 * W, 3, 1, s);
+        return e != CNM_OK ? e : conv(up_tmp, G, 0, G, out, Gto, go0, Cout, w, N, 2 * H, 2 * W, 3, 1, sync, s);
     }
-    static int conv(const float* in, int Gt, int g0, int Gin, float* out, int Gto, int go0, int Cout, const cnm_layer_weights& w, int N, int H, int W, int k, int st, void* s) {
+    static int conv(const float* in, int Gt, int g0, int Gin, float* out, int Gto, int go0, int Cout, const cnm_layer_weights& w, int N, int H, int W, int k, int st, float* sync, void* s) {
         if (w.u4 && k == 3 && st == 1 && wino4_fills_chip(Cout, N, H, W))
-            return cnm_conv3x3_winograd4_c4_f32(in, Gt, g0, Gin, nullptr, 0, 0, 0, out, Gto, go0, Cout, w.u4, w.b, N, H, W, 1, s);
+            return cnm_conv3x3_winograd4_sync_c4_f32(in, Gt, g0, Gin, nullptr, 0, 0, 0, out, Gto, go0, Cout, w.u4, w.b, N, H, W, 1, sync, sync ? cnm_wino36_sync_floats() : 0, s);
         if (w.u && k == 3 && st == 2 && (Cout / 64) * (((long long)N * ((H + 1) / 2) * ((W + 1) / 2) + 63) / 64) < 256)   // too few implicit-GEMM tiles
             return cnm_conv3x3_s2_winograd_c4_f32(in, Gt, g0, Gin, out, Gto, go0, Cout, w.u, w.b, N, H, W, 1, s);
         if (w.u4 && k == 3 && st == 2 && (Cout / 64) * (((long long)N * ((H + 1) / 2) * (((W + 1) / 2 + 3) / 4) + 47) / 48) >= 384)   // F(4,2) column phases along rows: 1.2x fewer multiplies; pays from ~1.5 workgroups per CU slot pair
@@ -143,8 +144,8 @@ struct EngF32 {
             return cnm_conv5x5_winograd_c4_f32(in, Gt, g0, Gin, nullptr, 0, 0, 0, out, Gto, go0, Cout, w.u4, w.b, N, H, W, 1, s);
         if (w.u && (k == 5 || k == 7)) return cnm_conv_rows_winograd_c4_f32(in, Gt, g0, Gin, nullptr, 0, 0, 0, out, Gto, go0, Cout, w.u, w.b, N, H, W, k, st, (k == 5 && st == 1) ? 2 : 4, 1, s);
         return cnm_conv2d_c4_f32(in, Gt, g0, Gin, out, Gto, go0, Cout, w.w, w.b, N, H, W, k, st, 1, s); }
-    static int conv2(const float* a, int Ga, const float* b, int Gb, float* out, int Gto, int Cout, const cnm_layer_weights& w, int N, int H, int W, void* s) {
-        if (w.u4 && wino4_fills_chip(Cout, N, H, W)) return cnm_conv3x3_winograd4_c4_f32(a, Ga, 0, Ga, b, Gb, 0, Gb, out, Gto, 0, Cout, w.u4, w.b, N, H, W, 1, s);
+    static int conv2(const float* a, int Ga, const float* b, int Gb, float* out, int Gto, int Cout, const cnm_layer_weights& w, int N, int H, int W, float* sync, void* s) {
+        if (w.u4 && wino4_fills_chip(Cout, N, H, W)) return cnm_conv3x3_winograd4_sync_c4_f32(a, Ga, 0, Ga, b, Gb, 0, Gb, out, Gto, 0, Cout, w.u4, w.b, N, H, W, 1, sync, sync ? cnm_wino36_sync_floats() : 0, s);
         if (w.u) return cnm_conv3x3_winograd_c4_f32(a, Ga, 0, Ga, b, Gb, 0, Gb, out, Gto, 0, Cout, w.u, w.b, N, H, W, 1, s);
         return cnm_conv2d_cat2_c4_f32(a, Ga, 0, Ga, b, Gb, 0, Gb, out, Gto, 0, Cout, w.w, w.b, N, H, W, 3, 1, 1, s); }
     static int up(const float* in, int G, float* out, int N, int H, int W, void* s) { return cnm_upsample2x_c4_f32(in, G, 0, out, G, 0, N, G, H, W, s); }
@@ -157,17 +158,17 @@ struct EngF32 {
 
 struct EngF16 {
     static constexpr int GD = 8;
-    static int upconv(const float* in, int G, float* up_tmp, float* out, int Gto, int go0, int Cout, const cnm_layer_weights& w, int N, int H, int W, void* s) {
+    static int upconv(const float* in, int G, float* up_tmp, float* out, int Gto, int go0, int Cout, const cnm_layer_weights& w, int N, int H, int W, float* sync, void* s) {
         if (w.uu && w.bu && w.wr && G * 8 <= 256 && (long long)N * 4 * H * W >= g_upsampled_min_pixels) {   // one fused pass over the low-resolution input + ring pass
             const int e = cnm_conv3x3_upsampled_c8_f16(in, G, 0, G, out, Gto, go0, Cout, w.uu, w.bu, N, H, W, 1, 1, s);
             return e != CNM_OK ? e : cnm_conv3x3_upsampled_ring_c8_f16(in, G, 0, G, out, Gto, go0, Cout, w.wr, w.b, N, H, W, 1, s);
         }
         const int e = up(in, G, up_tmp, N, H, W, s);
-        return e != CNM_OK ? e : conv(up_tmp, G, 0, G, out, Gto, go0, Cout, w, N, 2 * H, 2 * W, 3, 1, s);
+        return e != CNM_OK ? e : conv(up_tmp, G, 0, G, out, Gto, go0, Cout, w, N, 2 * H, 2 * W, 3, 1, sync, s);
     }
-    static int conv(const float* in, int Gt, int g0, int Gin, float* out, int Gto, int go0, int Cout, const cnm_layer_weights& w, int N, int H, int W, int k, int st, void* s) {
+    static int conv(const float* in, int Gt, int g0, int Gin, float* out, int Gto, int go0, int Cout, const cnm_layer_weights& w, int N, int H, int W, int k, int st, float*, void* s) {
         return cnm_conv2d_c8_f16(in, Gt, g0, Gin, out, Gto, go0, Cout, w.w, w.b, N, H, W, k, st, 1, s); }
-    static int conv2(const float* a, int Ga, const float* b, int Gb, float* out, int Gto, int Cout, const cnm_layer_weights& w, int N, int H, int W, void* s) {
+    static int conv2(const float* a, int Ga, const float* b, int Gb, float* out, int Gto, int Cout, const cnm_layer_weights& w, int N, int H, int W, float*, void* s) {
         return cnm_conv2d_cat2_c8_f16(a, Ga, 0, Ga, b, Gb, 0, Gb, out, Gto, 0, Cout, w.w, w.b, N, H, W, 3, 1, 1, s); }
     static int up(const float* in, int G, float* out, int N, int H, int W, void* s) { return cnm_upsample2x_c8_f16(in, G, 0, out, G, 0, N, G, H, W, s); }
     static int head(const float* in, int G, int C, const cnm_layer_weights& w, float scale, float* disp, float* up, int upG, int upg, int N, int H, int W, void* s) {
@@ -186,7 +187,7 @@ struct Carver {
 };
 
 struct DepthBufs {
-    float *hmkt, *TEX, *X0, *A1, *CAT2, *A2, *CAT3, *A3, *CAT4, *A4, *CAT5, *A5, *C5, *U5, *I5, *U4, *I4, *U3, *I3, *U2, *I2, *U1, *CAT1;
+    float *hmkt, *TEX, *SYNC, *X0, *A1, *CAT2, *A2, *CAT3, *A3, *CAT4, *A4, *CAT5, *A5, *C5, *U5, *I5, *U4, *I4, *U3, *I3, *U2, *I2, *U1, *CAT1;
 };
 
 // Buffers share memory by liveness (launch order of depthnet_forward, one stream):
@@ -205,6 +206,7 @@ static size_t carve_depth(float* ws, int P, int H, int W, int D, DepthBufs* b) {
     auto G = [](int C) { return (size_t)((C + E::GD - 1) / E::GD); };
     auto up64 = [](size_t n) { return (n + 63) & ~(size_t)63; };
     b->TEX = c.take(4);                         // FIRST and never reused: the plane sweep's tile queue, zero between calls
+    b->SYNC = E::GD == 4 ? c.take(cnm_wino36_sync_floats()) : nullptr;   // second, at a fixed offset, never reused: flag words (zero between calls) + partial-output slots of the staged F(4x4,3x3) kernel
     b->hmkt = c.take((size_t)P * 12);
     const size_t x0 = q * (G(D) + 1), cat1 = q * (G(64) + 1);
     b->X0 = b->CAT1 = c.take(x0 > cat1 ? x0 : cat1);
@@ -256,7 +258,7 @@ static int depthnet_forward(const cnm_layer_weights* wt, float idepth_scale, int
     const int G0 = G(D) + 1, g64 = G(64), g128 = G(128), g256 = G(256), g512 = G(512);
     const int H1 = H / 2, W1 = W / 2, H2 = H / 4, W2 = W / 4, H3 = H / 8, W3 = W / 8, H4 = H / 16, W4 = W / 16, H5 = H / 32, W5 = W / 32;
 #define CONV(L, in, Gt, g0, Gin, out, Gto, go0, Cout, HH, WW) \
-    CNM_TRY(E::conv(in, Gt, g0, Gin, out, Gto, go0, Cout, wt[L], P, HH, WW, kDepthLayers[L].ksize, kDepthLayers[L].stride, s))
+    CNM_TRY(E::conv(in, Gt, g0, Gin, out, Gto, go0, Cout, wt[L], P, HH, WW, kDepthLayers[L].ksize, kDepthLayers[L].stride, b.SYNC, s))
     // geometry + cost volume                                                   depthNet_model.py:228-233
     CNM_TRY(cnm_homography_terms_f32(ref_cam, src_cam, b.hmkt, B, S, s));
     CNM_TRY(E::sweep(ref, src, b.hmkt, b.X0, b.TEX, 4, B, S, H, W, D, idmin, idmax, s));
@@ -272,18 +274,18 @@ static int depthnet_forward(const cnm_layer_weights* wt, float idepth_scale, int
     CONV(D_CONV5_0, b.CAT5, 2 * g512, g512, g512, b.A5, g512, 0, 512, H4, W4);
     CONV(D_CONV5_3, b.A5, g512, 0, g512, b.C5, g512, 0, 512, H4, W4);
     // decoder                                                                  :241-261
-    CNM_TRY(E::upconv(b.C5, g512, b.U5, b.CAT5, 2 * g512, 0, 512, wt[D_UPCONV5], P, H5, W5, s));
+    CNM_TRY(E::upconv(b.C5, g512, b.U5, b.CAT5, 2 * g512, 0, 512, wt[D_UPCONV5], P, H5, W5, b.SYNC, s));
     CONV(D_ICONV5, b.CAT5, 2 * g512, 0, 2 * g512, b.I5, g512, 0, 512, H4, W4);
-    CNM_TRY(E::upconv(b.I5, g512, b.U4, b.CAT4, 2 * g512, 0, 512, wt[D_UPCONV4], P, H4, W4, s));
+    CNM_TRY(E::upconv(b.I5, g512, b.U4, b.CAT4, 2 * g512, 0, 512, wt[D_UPCONV4], P, H4, W4, b.SYNC, s));
     CONV(D_ICONV4, b.CAT4, 2 * g512, 0, 2 * g512, b.I4, g512, 0, 512, H3, W3);
     CNM_TRY(E::head(b.I4, g512, 512, wt[D_DISP4], idepth_scale, disp4, b.CAT3, 2 * g256 + 1, 2 * g256, P, H3, W3, s));
-    CNM_TRY(E::upconv(b.I4, g512, b.U3, b.CAT3, 2 * g256 + 1, 0, 256, wt[D_UPCONV3], P, H3, W3, s));
+    CNM_TRY(E::upconv(b.I4, g512, b.U3, b.CAT3, 2 * g256 + 1, 0, 256, wt[D_UPCONV3], P, H3, W3, b.SYNC, s));
     CONV(D_ICONV3, b.CAT3, 2 * g256 + 1, 0, 2 * g256 + 1, b.I3, g256, 0, 256, H2, W2);
     CNM_TRY(E::head(b.I3, g256, 256, wt[D_DISP3], idepth_scale, disp3, b.CAT2, 2 * g128 + 1, 2 * g128, P, H2, W2, s));
-    CNM_TRY(E::upconv(b.I3, g256, b.U2, b.CAT2, 2 * g128 + 1, 0, 128, wt[D_UPCONV2], P, H2, W2, s));
+    CNM_TRY(E::upconv(b.I3, g256, b.U2, b.CAT2, 2 * g128 + 1, 0, 128, wt[D_UPCONV2], P, H2, W2, b.SYNC, s));
     CONV(D_ICONV2, b.CAT2, 2 * g128 + 1, 0, 2 * g128 + 1, b.I2, g128, 0, 128, H1, W1);
     CNM_TRY(E::head(b.I2, g128, 128, wt[D_DISP2], idepth_scale, disp2, b.CAT1, g64 + 1, g64, P, H1, W1, s));
-    CNM_TRY(E::upconv(b.I2, g128, b.U1, b.CAT1, g64 + 1, 0, 64, wt[D_UPCONV1], P, H1, W1, s));
+    CNM_TRY(E::upconv(b.I2, g128, b.U1, b.CAT1, g64 + 1, 0, 64, wt[D_UPCONV1], P, H1, W1, b.SYNC, s));
     CONV(D_ICONV1, b.CAT1, g64 + 1, 0, g64 + 1, iconv1, g64, 0, 64, H, W);
     CNM_TRY(E::head(iconv1, g64, 64, wt[D_DISP1], idepth_scale, disp1, nullptr, 0, 0, P, H, W, s));
 #undef CONV
@@ -306,7 +308,7 @@ extern "C" int cnm_depthnet_forward_f16(const cnm_layer_weights* wt, float idept
 
 // ------------------------------------------------------------------ refine net
 struct DecoderBufs { float *UC3, *I3, *U2, *UC2, *I2, *U1, *UC1, *I1; };     // one set per decoder: the two run concurrently
-struct RefineBufs { float *X, *A1, *C1, *A2, *C2, *A3, *C3, *U3; DecoderBufs d[2]; };
+struct RefineBufs { float *SYNC[2], *X, *A1, *C1, *A2, *C2, *A3, *C3, *U3; DecoderBufs d[2]; };   // SYNC: one sync workspace per stream (encoder + depth decoder, probability decoder)
 
 
 
@@ -318,6 +320,7 @@ static size_t carve_refine(float* ws, int N, int H, int W, RefineBufs* b) {
     Carver c{ws, 0};
     const size_t q = (size_t)N * H * W * 4;
     auto G = [](int C) { return (size_t)((C + E::GD - 1) / E::GD); };
+    for (int k = 0; k < 2; ++k) b->SYNC[k] = E::GD == 4 ? c.take(cnm_wino36_sync_floats()) : nullptr;   // FIRST, fixed offsets, never reused: flag words zero between calls
     b->X = c.take(q * (G(64) + 1)); b->A1 = c.take(q * G(128));
     b->C1 = c.take(q / 4 * G(128)); b->A2 = c.take(q / 4 * G(256));
     b->C2 = c.take(q / 16 * G(256)); b->A3 = c.take(q / 16 * G(512)); b->U3 = c.take(q / 16 * G(512));
@@ -349,7 +352,7 @@ static int refinenet_body(const cnm_layer_weights* wt, float idepth_scale, const
     auto G = [](int C) { return (C + E::GD - 1) / E::GD; };
     const int g64 = G(64), g128 = G(128), g256 = G(256), g512 = G(512);
 #define CONV(L, in, Gin, out, Cout, HH, WW) \
-    CNM_TRY(E::conv(in, Gin, 0, Gin, out, G(Cout), 0, Cout, wt[L], N, HH, WW, 3, kRefineLayers[L].stride, s))
+    CNM_TRY(E::conv(in, Gin, 0, Gin, out, G(Cout), 0, Cout, wt[L], N, HH, WW, 3, kRefineLayers[L].stride, b.SYNC[0], s))
     CONV(R_CONV1_0, b.X, g64 + 1, b.A1, 128, H, W);
     CONV(R_CONV1_3, b.A1, g128, b.C1, 128, H, W);
     CONV(R_CONV2_0, b.C1, g128, b.A2, 256, H1, W1);
@@ -367,20 +370,21 @@ static int refinenet_body(const cnm_layer_weights* wt, float idepth_scale, const
     // joined back in every case (kernels already queued on it must be ordered before the caller's stream goes on, and
     // a stream capture must not be left with an unjoined branch).
 #define CONV(L, in, Gin, out, Cout, HH, WW) \
-    rc = E::conv(in, Gin, 0, Gin, out, G(Cout), 0, Cout, wt[L], N, HH, WW, 3, kRefineLayers[L].stride, q)
+    rc = E::conv(in, Gin, 0, Gin, out, G(Cout), 0, Cout, wt[L], N, HH, WW, 3, kRefineLayers[L].stride, sy, q)
     int rc = CNM_OK;
     for (int step = 0; step < 7 && rc == CNM_OK; ++step) {                             // launches interleaved decoder by decoder
         for (int br = 0; br < 2 && rc == CNM_OK; ++br) {                               // 0: depth (:341-351), 1: prob (:357-365)
             const int L = R_BRANCH0 + 6 * br;
             const DecoderBufs& d = b.d[br];
             void* q = st[br];
+            float* sy = b.SYNC[side ? br : 0];                                         // one sync workspace per stream
             float* feat = (br == 0 && iconv1_depth) ? iconv1_depth : d.I1;
             switch (step) {
                 case 0: CONV(L + 0, b.U3, g512, d.UC3, 256, H2, W2); break;
-                case 1: rc = E::conv2(d.UC3, g256, b.C2, g256, d.I3, g256, 256, wt[L + 1], N, H2, W2, q); break;
-                case 2: rc = E::upconv(d.I3, g256, d.U2, d.UC2, g128, 0, 128, wt[L + 2], N, H2, W2, q); break;
-                case 3: rc = E::conv2(d.UC2, g128, b.C1, g128, d.I2, g128, 128, wt[L + 3], N, H1, W1, q); break;
-                case 4: rc = E::upconv(d.I2, g128, d.U1, d.UC1, g64, 0, 64, wt[L + 4], N, H1, W1, q); break;
+                case 1: rc = E::conv2(d.UC3, g256, b.C2, g256, d.I3, g256, 256, wt[L + 1], N, H2, W2, sy, q); break;
+                case 2: rc = E::upconv(d.I3, g256, d.U2, d.UC2, g128, 0, 128, wt[L + 2], N, H2, W2, sy, q); break;
+                case 3: rc = E::conv2(d.UC2, g128, b.C1, g128, d.I2, g128, 128, wt[L + 3], N, H1, W1, sy, q); break;
+                case 4: rc = E::upconv(d.I2, g128, d.U1, d.UC1, g64, 0, 64, wt[L + 4], N, H1, W1, sy, q); break;
                 case 5: CONV(L + 5, d.UC1, g64, feat, 64, H, W); break;
                 case 6: rc = E::head(feat, g64, 64, wt[R_HEAD0 + br], br == 0 ? idepth_scale : 1.0f, br == 0 ? disp_refined : prob_map,
                                      nullptr, 0, 0, N, H, W, q); break;

@@ -10,6 +10,7 @@ struct Wino4Args {
     int Gout_tot, gout0, Cout;
     int nchunks, T, relu;                // T = N*TH*TW tiles
     int ring;                            // fused upsampling: leave the one-pixel output ring without bias / ReLU for the ring kernel
+    float* sync_ws; size_t sync_floats;  // LDS-staged kernel only: zeroed flag words + partial-output slots (cnm_wino36_sync_floats), or null
 };
 
 // LDS-staged variant (conv_winograd4s.hip): returns CNM_OK after launching, 1 when the shape is not eligible (the caller

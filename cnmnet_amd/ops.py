@@ -271,17 +271,29 @@ def conv3x3_s2_winograd_c4(x, u_packed, b_packed, Cout, relu=True):
     return out
 
 
-def conv3x3_winograd4_c4(x, u_packed, b_packed, Cout, relu=True, x2=None, ksize=3):
-    """36-point Winograd twin of conv2d_c4(stride=1): ksize 3 -> F(4x4,3x3), ksize 5 -> F(2x2,5x5)."""
-    _dev(x, u_packed, b_packed, x2)
+def wino36_sync_workspace(device):
+    """Zeroed sync workspace for the LDS-staged F(4x4,3x3) kernel (flag words + partial-output slots): one per stream of
+    launches; every call leaves the flag words zero again."""
+    return torch.zeros(_lib.load().cnm_wino36_sync_floats(), device=device, dtype=torch.float32)
+
+
+def conv3x3_winograd4_c4(x, u_packed, b_packed, Cout, relu=True, x2=None, ksize=3, sync=None):
+    """36-point Winograd twin of conv2d_c4(stride=1): ksize 3 -> F(4x4,3x3), ksize 5 -> F(2x2,5x5).  sync = a
+    wino36_sync_workspace lets the staged 3x3 kernel split its work evenly over the CUs (cnm_conv3x3_winograd4_sync_c4_f32)."""
+    _dev(x, u_packed, b_packed, x2, sync)
     N, G, H, W, _ = x.shape
     out = torch.empty(N, Cout // 4, H, W, 4, device=x.device, dtype=torch.float32)
     G2 = x2.shape[1] if x2 is not None else 0
-    fn = _lib.load().cnm_conv3x3_winograd4_c4_f32 if ksize == 3 else _lib.load().cnm_conv5x5_winograd_c4_f32
+    lib = _lib.load()
     with torch.cuda.device(x.device):
-        _lib.check(fn(_p(x), G, 0, G, _p(x2) if x2 is not None else None, G2, 0, G2,
-                                                            _p(out), Cout // 4, 0, Cout, _p(u_packed), _p(b_packed),
-                                                            N, H, W, int(relu), _stream()))
+        if sync is not None and ksize == 3:
+            _lib.check(lib.cnm_conv3x3_winograd4_sync_c4_f32(_p(x), G, 0, G, _p(x2) if x2 is not None else None, G2, 0, G2,
+                                                             _p(out), Cout // 4, 0, Cout, _p(u_packed), _p(b_packed),
+                                                             N, H, W, int(relu), _p(sync), sync.numel(), _stream()))
+        else:
+            fn = lib.cnm_conv3x3_winograd4_c4_f32 if ksize == 3 else lib.cnm_conv5x5_winograd_c4_f32
+            _lib.check(fn(_p(x), G, 0, G, _p(x2) if x2 is not None else None, G2, 0, G2,
+                          _p(out), Cout // 4, 0, Cout, _p(u_packed), _p(b_packed), N, H, W, int(relu), _stream()))
     return out
 
 
@@ -314,7 +326,7 @@ def pack_winograd4_upsampled(weight, bn=None, eps=1e-5):
     return pack_winograd4(compose_upsample_filters(weight), rep, 0, eps), pack_conv(weight, bn, eps=eps)[1].repeat(4).contiguous(), wr
 
 
-def conv3x3_upsampled_winograd4_c4(x, u_packed, b_packed, Cout, relu=True, w_ring=None, out=None):
+def conv3x3_upsampled_winograd4_c4(x, u_packed, b_packed, Cout, relu=True, w_ring=None, out=None, sync=None):
     """conv3x3(upsample2x(x)) + bias (+ ReLU) without materialising the upsampled tensor: x [N,G,H,W,4] -> [N,Cout/4,2H,2W,4].
     With w_ring (pack_winograd4_upsampled) the ring pass follows and the result is the reference's zero-padded one;
     without it the upsampled image is replicate-padded (differs on the one-pixel output ring)."""
@@ -324,8 +336,12 @@ def conv3x3_upsampled_winograd4_c4(x, u_packed, b_packed, Cout, relu=True, w_rin
         out = torch.empty(N, Cout // 4, 2 * H, 2 * W, 4, device=x.device, dtype=torch.float32)
     lib = _lib.load()
     with torch.cuda.device(x.device):
-        _lib.check(lib.cnm_conv3x3_upsampled_winograd4_c4_f32(_p(x), G, 0, G, _p(out), Cout // 4, 0, Cout, _p(u_packed), _p(b_packed),
-                                                              N, H, W, int(relu), int(w_ring is not None), _stream()))
+        if sync is not None:
+            _lib.check(lib.cnm_conv3x3_upsampled_winograd4_sync_c4_f32(_p(x), G, 0, G, _p(out), Cout // 4, 0, Cout, _p(u_packed), _p(b_packed),
+                                                                       N, H, W, int(relu), int(w_ring is not None), _p(sync), sync.numel(), _stream()))
+        else:
+            _lib.check(lib.cnm_conv3x3_upsampled_winograd4_c4_f32(_p(x), G, 0, G, _p(out), Cout // 4, 0, Cout, _p(u_packed), _p(b_packed),
+                                                                  N, H, W, int(relu), int(w_ring is not None), _stream()))
         if w_ring is not None:
             _lib.check(lib.cnm_conv3x3_upsampled_ring_c4_f32(_p(x), G, 0, G, _p(out), Cout // 4, 0, Cout, _p(w_ring), _p(b_packed),
                                                              N, H, W, int(relu), _stream()))

@@ -171,6 +171,22 @@ int cnm_conv3x3_winograd4_c4_f32(const float* in_a, int Ga_total, int ga0, int G
                                  float* out, int Gout_total, int gout0, int Cout,
                                  const float* u_packed, const float* b_packed,
                                  int N, int H, int W, int relu, void* stream);
+/* The same convolution with a sync workspace for the LDS-staged persistent kernel (conv_winograd4s.hip: 128 output
+ * channels x 16 tiles per workgroup, one workgroup per CU).  sync_ws = cnm_wino36_sync_floats() floats: 4096 bytes of flag
+ * words -- zero before the first use, left zero by every call -- followed by one 128 KB partial-output slot per CU; it must
+ * not be shared by launches that can run concurrently.  With it the kernel splits the layer's (unit, 16-channel chunk)
+ * phases into equal contiguous ranges, one per CU, whatever the unit count: a unit cut by a range boundary is finished by
+ * the range that holds its first chunk, which adds the other ranges' partial outputs in range order (write-through
+ * stores + flag, agent-scope acquire).  Results are bit-reproducible from run to run; they differ from the unsplit
+ * evaluation in the last bits (the fp32 accumulation chain of a cut unit is summed in two or more pieces).  Shapes the
+ * staged kernel does not take (Cout not a multiple of 128, fewer than six tile columns) run as
+ * cnm_conv3x3_winograd4_c4_f32.  sync_ws = NULL is allowed and means exactly that function. */
+size_t cnm_wino36_sync_floats(void);
+int cnm_conv3x3_winograd4_sync_c4_f32(const float* in_a, int Ga_total, int ga0, int Ga,
+                                      const float* in_b, int Gb_total, int gb0, int Gb,
+                                      float* out, int Gout_total, int gout0, int Cout,
+                                      const float* u_packed, const float* b_packed,
+                                      int N, int H, int W, int relu, float* sync_ws, size_t sync_floats, void* stream);
 
 /* Winograd F(2x2,5x5) for the 5x5 stride-1 layer (conv2.0 = nn.Conv2d(128, 256, 5, 1, 2), depthNet_model.py:141-144):
  * the 36-point machine of the F(4x4,3x3) kernel with 2x2 output tiles; 9 instead of 25 multiplies per output (the
@@ -195,6 +211,12 @@ int cnm_conv3x3_upsampled_winograd4_c4_f32(const float* in, int Gin_total, int g
                                            float* out, int Gout_total, int gout0, int Cout,
                                            const float* u_packed, const float* b_packed,
                                            int N, int H, int W, int relu, int with_ring, void* stream);
+/* ... with the sync workspace of cnm_conv3x3_winograd4_sync_c4_f32 (same contract). */
+int cnm_conv3x3_upsampled_winograd4_sync_c4_f32(const float* in, int Gin_total, int gin0, int Gin,
+                                                float* out, int Gout_total, int gout0, int Cout,
+                                                const float* u_packed, const float* b_packed,
+                                                int N, int H, int W, int relu, int with_ring,
+                                                float* sync_ws, size_t sync_floats, void* stream);
 
 /* Ring pass of the fused upsample + 3x3 convolution: subtracts, on the one-pixel output ring, the filter taps that the
  * replicate-padded composition added beyond the reference's zero padding, then applies bias and ReLU there.

@@ -11,12 +11,17 @@ dev = "cuda"
 lib = _lib.load()
 
 
+SYNC = ops.wino36_sync_workspace(dev)
+
+
 def both(fn):
+    """gather-fed, staged with unit-aligned ranges, staged with the sync workspace (twice: reproducibility)"""
     outs = []
-    for on in (0, 2):
+    for on, sync in ((0, None), (2, None), (2, SYNC), (2, SYNC)):
         lib.cnm_tune_wino36_staged(on)
-        outs.append(fn().clone())
+        outs.append(fn(sync).clone())
     lib.cnm_tune_wino36_staged(1)
+    assert float(SYNC[:1024].abs().max()) == 0.0, "flag words not re-armed"
     return outs
 
 
@@ -32,23 +37,25 @@ def check():
         ct = 4 * ((Cin + 3) // 4) + Cin2
         w = torch.randn(Cout, ct, 3, 3, device=dev) * 0.05
         up = ops.pack_winograd4(w); bp = torch.randn(Cout, device=dev)
-        o0, o1 = both(lambda: ops.conv3x3_winograd4_c4(x, up, bp, Cout, True, x2=x2))
+        o0, o1, o2, o3 = both(lambda sy: ops.conv3x3_winograd4_c4(x, up, bp, Cout, True, x2=x2, sync=sy))
         # independent check of the gather-fed result against torch (fp64) so that "equal" means "equal and right"
         xin = ops.c4_to_nchw(x, 4 * ((Cin + 3) // 4))
         if x2 is not None: xin = torch.cat([xin, ops.c4_to_nchw(x2, Cin2)], 1)
         ref = torch.relu(torch.nn.functional.conv2d(xin.double(), w.double(), bp.double(), padding=1)).float()
         err = (ops.c4_to_nchw(o1, Cout) - ref).abs().max().item()
-        eq = torch.equal(o0, o1)
-        bad += (not eq) or err > 2e-3
-        print("plain  N%d %4d+%-3d->%4d %3dx%-3d  equal=%s  max|staged-torch64|=%.2e  max|diff|=%.2e" % (N, Cin, Cin2, Cout, H, W, eq, err, (o0 - o1).abs().max().item()), flush=True)
+        eq = torch.equal(o0, o1); rep = torch.equal(o2, o3)
+        err2 = (ops.c4_to_nchw(o2, Cout) - ref).abs().max().item()
+        bad += (not eq) or (not rep) or err > 2e-3 or err2 > 2e-3
+        print("plain  N%d %4d+%-3d->%4d %3dx%-3d  aligned==gather %s  |aligned-torch64|=%.2e   split: reproducible %s  |split-torch64|=%.2e  |split-gather|=%.2e" % (
+            N, Cin, Cin2, Cout, H, W, eq, err, rep, err2, (o0 - o2).abs().max().item()), flush=True)
     for N, Cin, Cout, H, W in [(2, 128, 64, 48, 64), (1, 256, 128, 24, 32), (2, 64, 64, 20, 36), (1, 128, 64, 96, 128)]:
         x = ops.nchw_to_c4(torch.randn(N, Cin, H, W, device=dev))
         w = torch.randn(Cout, Cin, 3, 3, device=dev) * 0.05
         uu, bu, wr = ops.pack_winograd4_upsampled(w)
         for ring in (None, wr):
-            o0, o1 = both(lambda: ops.conv3x3_upsampled_winograd4_c4(x, uu, bu, Cout, True, ring))
-            eq = torch.equal(o0, o1); bad += not eq
-            print("upconv N%d %4d->%4d %3dx%-3d ring=%d  equal=%s  max|diff|=%.2e" % (N, Cin, Cout, H, W, ring is not None, eq, (o0 - o1).abs().max().item()), flush=True)
+            o0, o1, o2, o3 = both(lambda sy: ops.conv3x3_upsampled_winograd4_c4(x, uu, bu, Cout, True, ring, sync=sy))
+            eq = torch.equal(o0, o1); rep = torch.equal(o2, o3); d2 = (o0 - o2).abs().max().item(); bad += (not eq) or (not rep) or d2 > 1e-3
+            print("upconv N%d %4d->%4d %3dx%-3d ring=%d  aligned==gather %s   split: reproducible %s  |split-gather|=%.2e" % (N, Cin, Cout, H, W, ring is not None, eq, rep, d2), flush=True)
     print("CHECK", "FAILED" if bad else "OK", flush=True)
     return bad
 
@@ -72,35 +79,35 @@ def ev(fn, iters=20, warm=3):
 
 
 def time_layers():
-    tot = [0.0, 0.0]
+    tot = [0.0, 0.0, 0.0]
     for name, N, Cin, Cout, H, W in LAYERS:
         x = ops.nchw_to_c4(torch.randn(N, Cin, H, W, device=dev)); up = ops.pack_winograd4(torch.randn(Cout, Cin, 3, 3, device=dev) * 0.02); bp = torch.zeros(Cout, device=dev)
         ms = []
         for rnd in range(2):
-            for on in (0, 2):
+            for on, sy in ((0, None), (2, None), (2, SYNC)):
                 lib.cnm_tune_wino36_staged(on)
-                m = ev(lambda: ops.conv3x3_winograd4_c4(x, up, bp, Cout, True))
+                m = ev(lambda: ops.conv3x3_winograd4_c4(x, up, bp, Cout, True, sync=sy))
                 if rnd: ms.append(m)
         gf = 2.0 * Cout * Cin * 9 * H * W * N / 1e9
         mult = 2 if name.endswith("x2") else 1
-        tot[0] += ms[0] * mult; tot[1] += ms[1] * mult
-        print("%-24s %4d->%4d %3dx%-3d N%2d: gather %.3f ms %5.1f TF (%.2f) | staged %.3f ms %5.1f TF (%.2f)  x%.2f" % (
-            name, Cin, Cout, H, W, N, ms[0], gf / ms[0] / 4, gf / ms[0] / 4 / 157.3, ms[1], gf / ms[1] / 4, gf / ms[1] / 4 / 157.3, ms[0] / ms[1]), flush=True)
+        for i in range(3): tot[i] += ms[i] * mult
+        print("%-24s %4d->%4d %3dx%-3d N%2d: gather %.3f ms (%.2f) | staged aligned %.3f ms (%.2f) x%.2f | staged split %.3f ms %5.1f TF (%.2f) x%.2f" % (
+            name, Cin, Cout, H, W, N, ms[0], gf / ms[0] / 4 / 157.3, ms[1], gf / ms[1] / 4 / 157.3, ms[0] / ms[1], ms[2], gf / ms[2] / 4, gf / ms[2] / 4 / 157.3, ms[0] / ms[2]), flush=True)
     for name, N, Cin, Cout, H, W in UPS:
         x = ops.nchw_to_c4(torch.randn(N, Cin, H, W, device=dev)); uu, bu, wr = ops.pack_winograd4_upsampled(torch.randn(Cout, Cin, 3, 3, device=dev) * 0.02)
         ms = []
         for rnd in range(2):
-            for on in (0, 2):
+            for on, sy in ((0, None), (2, None), (2, SYNC)):
                 lib.cnm_tune_wino36_staged(on)
-                m = ev(lambda: ops.conv3x3_upsampled_winograd4_c4(x, uu, bu, Cout, True, wr))
+                m = ev(lambda: ops.conv3x3_upsampled_winograd4_c4(x, uu, bu, Cout, True, wr, sync=sy))
                 if rnd: ms.append(m)
         gf = 2.0 * 4 * Cout * Cin * 9 * H * W * N / 1e9
         mult = 2 if name.endswith("x2") else 1
-        tot[0] += ms[0] * mult; tot[1] += ms[1] * mult
-        print("%-24s %4d->%4d %3dx%-3d N%2d: gather %.3f ms %5.1f TF | staged %.3f ms %5.1f TF  x%.2f   (with ring pass)" % (
-            name, Cin, Cout, H, W, N, ms[0], gf / ms[0] / 4, ms[1], gf / ms[1] / 4, ms[0] / ms[1]), flush=True)
+        for i in range(3): tot[i] += ms[i] * mult
+        print("%-24s %4d->%4d %3dx%-3d N%2d: gather %.3f ms | staged aligned %.3f ms x%.2f | staged split %.3f ms %5.1f TF x%.2f   (with ring pass)" % (
+            name, Cin, Cout, H, W, N, ms[0], ms[1], ms[0] / ms[1], ms[2], gf / ms[2] / 4, ms[0] / ms[2]), flush=True)
     lib.cnm_tune_wino36_staged(1)
-    print("sum over a step's launches: gather %.3f ms, staged %.3f ms" % (tot[0], tot[1]), flush=True)
+    print("sum over a step's launches: gather %.3f ms, staged aligned %.3f ms, staged split %.3f ms" % tuple(tot), flush=True)
 
 
 if __name__ == "__main__":
