@@ -73,6 +73,7 @@ def conv_tile(cout, m):
 
 
 _LIVE_TRAFFIC = None      # kernel name -> HBM bytes per launch, measured by this run's own PMC passes (live_traffic)
+_LIVE_TRAFFIC_WHY = "not attempted"   # why the live passes were not used
 
 
 def live_traffic(timeout_s=240):
@@ -87,7 +88,9 @@ def live_traffic(timeout_s=240):
     import shutil
     import subprocess
     import tempfile
+    global _LIVE_TRAFFIC_WHY
     if shutil.which("rocprofv3") is None:
+        _LIVE_TRAFFIC_WHY = "rocprofv3 not on PATH"
         return None
     per = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -99,13 +102,15 @@ def live_traffic(timeout_s=240):
             r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
             files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
             if r.returncode != 0 or not files:
+                _LIVE_TRAFFIC_WHY = "rocprofv3 --pmc %s pass: exit code %d, %d counter file(s)" % (counter, r.returncode, len(files))
                 return None
             tot, ids = collections.defaultdict(float), collections.defaultdict(set)
             for row in csv.DictReader(open(files[0])):
                 if row["Counter_Name"] == counter:
                     tot[row["Kernel_Name"]] += float(row["Counter_Value"]); ids[row["Kernel_Name"]].add(row["Dispatch_Id"])
             per[counter] = {k: tot[k] * 1024.0 / len(ids[k]) for k in tot}               # the counters are in KB
-        except (OSError, subprocess.SubprocessError, KeyError, ValueError):
+        except (OSError, subprocess.SubprocessError, KeyError, ValueError) as e:
+            _LIVE_TRAFFIC_WHY = "rocprofv3 --pmc %s pass: %s" % (counter, type(e).__name__)
             return None
         finally:
             shutil.rmtree(d, ignore_errors=True)
@@ -115,11 +120,11 @@ def live_traffic(timeout_s=240):
 
 def pmc_traffic(kernel, raw=False):
     """HBM bytes per launch of `kernel` (raw=True: without the x2 read correction): from this run's own PMC passes when they ran (live_traffic), else from the
-    committed pass of the last profiled build (profiles/r2_pmc_traffic.json), else None."""
+    committed pass of the last profiled build (profiles/r3_pmc_traffic.json), else None."""
     table = _LIVE_TRAFFIC
     if table is None:
         try:
-            with open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")) as f:
                 table = {k: (v["fetch_bytes_corrected"] + v["write_bytes"], v["fetch_bytes_corrected"] / 2 + v["write_bytes"])
                          for k, v in json.load(f)["kernels"].items()}
         except (OSError, ValueError, KeyError):
@@ -130,13 +135,24 @@ def pmc_traffic(kernel, raw=False):
     return None
 
 
-def conv_kernel(L, m, m4=0):
+def wino36_kernel(cout, h, w, ups=False):
+    """Mirror of cnm_wino36s_try_launch (cnmnet_amd/csrc/conv_winograd4s.hip): which 36-point F(4x4,3x3) kernel takes a layer
+    with `cout` (virtual, for a fused up_conv: 4 x real) output channels on an h x w (low-resolution, for up_conv) image."""
+    th, tw = -(-h // 4), -(-w // 4)
+    if cout % 128 == 0 and tw >= 12:
+        return "conv_winograd36s_f32_kernel<16, %s, 0>" % ("true" if ups else "false")
+    if cout % 128 == 0 and tw >= 6 and th >= 2:
+        return "conv_winograd36s_f32_kernel<8, %s, 0>" % ("true" if ups else "false")
+    return "conv_winograd36_f32_kernel<4, 3, %s>" % ("true" if ups else "false")
+
+
+def conv_kernel(L, m, m4=0, h=0, w=0):
     """Mirror of the fp32 executors' layer -> kernel choice (cnmnet_amd/csrc/nets.hip EngF32::conv) and the share of
     the direct-convolution flops the kernel really executes on the matrix cores (Winograd executes fewer)."""
     k, s = L["ksize"], L["stride"]
     if s == 1 and k == 3:
         if L["Cout"] // 64 * -(-m4 // 16) >= WINO4_MIN_WORKGROUPS:
-            return "conv_winograd36_f32_kernel<4, 3, false>", 36.0 / 144.0      # F(4x4,3x3): 36 multiplies per 16 outputs instead of 144
+            return wino36_kernel(L["Cout"], h, w), 36.0 / 144.0      # F(4x4,3x3): 36 multiplies per 16 outputs instead of 144
         return "conv3x3_winograd_f32_kernel", 16.0 / 36.0            # F(2x2,3x3): 16 multiplies per 4 outputs instead of 36
     if k == 5 and s == 1 and L["Cout"] // 64 * -(-(m // 4) // 16) >= WINO4_MIN_WORKGROUPS:
         return "conv_winograd36_f32_kernel<2, 5, false>", 36.0 / 100.0          # F(2x2,5x5): 36 multiplies per 4 outputs instead of 100
@@ -160,6 +176,8 @@ def kernel_rooflines(dev, frames):
     `algorithmic` is the direct-convolution-equivalent rate (2*Cout*Cin*k*k per output pixel)."""
     from cnmnet_amd import _lib, ops, synthetic as syn
     per_kernel = {}
+    IT, WARM = 20, 3                                                     # launches averaged per layer shape
+    sync = ops.wino36_sync_workspace(dev)                                # as in nets.hip: the staged F(4x4,3x3) kernel splits its phases evenly over the CUs
     for net, n_img, levels in ((_lib.NET_DEPTH, frames * SRC, DEPTH_LEVEL), (_lib.NET_REFINE, frames, REFINE_LEVEL)):
         layers = [L for L in _lib.net_layers(net) if not L["is_head"]]
         for L, lv in zip(layers, levels):
@@ -168,7 +186,7 @@ def kernel_rooflines(dev, frames):
             x = torch.randn(n_img, (cin + 3) // 4, h, w, 4, device=dev)
             wt = torch.randn(L["Cout"], cin, L["ksize"], L["ksize"], device=dev) * 0.02
             ho, wo = h // L["stride"], w // L["stride"]
-            name, executed = conv_kernel(L, n_img * ho * wo, n_img * -(-ho // 4) * -(-wo // 4))
+            name, executed = conv_kernel(L, n_img * ho * wo, n_img * -(-ho // 4) * -(-wo // 4), ho, wo)
             wp, bp = ops.pack_conv(wt)
             flop = 2.0 * L["Cout"] * cin * L["ksize"] ** 2 * ho * wo * n_img
             if L["conv_key"].startswith("upconv") and cin <= 256 and n_img * ho * wo >= UPSAMPLED_MIN_PIXELS:
@@ -179,17 +197,18 @@ def kernel_rooflines(dev, frames):
                 uu, bu, wr = ops.pack_winograd4_upsampled(wt)
                 out = torch.empty(n_img, L["Cout"] // 4, h, w, 4, device=dev)
                 args = (xl.data_ptr(), cin // 4, 0, cin // 4, out.data_ptr(), L["Cout"] // 4, 0, L["Cout"])
-                ms = event_ms(lambda: lib.cnm_conv3x3_upsampled_winograd4_c4_f32(*args, uu.data_ptr(), bu.data_ptr(), n_img, h // 2, w // 2, 1, 1, st), iters=3, warm=1)
-                k = per_kernel.setdefault("conv_winograd36_f32_kernel<4, 3, true>", [0.0, 0.0, 0, 0.0])
+                ms = event_ms(lambda: lib.cnm_conv3x3_upsampled_winograd4_sync_c4_f32(*args, uu.data_ptr(), bu.data_ptr(), n_img, h // 2, w // 2, 1, 1,
+                                                                                      sync.data_ptr(), sync.numel(), st), iters=IT, warm=WARM)
+                k = per_kernel.setdefault(wino36_kernel(4 * L["Cout"], h // 2, w // 2, ups=True), [0.0, 0.0, 0, 0.0])
                 k[0] += flop; k[1] += ms; k[2] += 1; k[3] += flop * 36.0 / 144.0
-                ms = event_ms(lambda: lib.cnm_conv3x3_upsampled_ring_c4_f32(*args, wr.data_ptr(), bu.data_ptr(), n_img, h // 2, w // 2, 1, st), iters=3, warm=1)
+                ms = event_ms(lambda: lib.cnm_conv3x3_upsampled_ring_c4_f32(*args, wr.data_ptr(), bu.data_ptr(), n_img, h // 2, w // 2, 1, st), iters=IT, warm=WARM)
                 k = per_kernel.setdefault("conv_upsampled_ring_kernel", [0.0, 0.0, 0, 0.0])
                 k[1] += ms; k[2] += 1; k[3] += 2.0 * L["Cout"] * cin * 3 * (2 * (h + w) - 4) * n_img
                 del x, xl, wt, wp, bp, uu, bu, wr, out
                 continue
             if name.startswith("conv3x3_winograd4") or name.startswith("conv_winograd36"):
                 up = ops.pack_winograd4(wt)
-                fn = lambda: ops.conv3x3_winograd4_c4(x, up, bp, L["Cout"], True, ksize=L["ksize"])
+                fn = lambda: ops.conv3x3_winograd4_c4(x, up, bp, L["Cout"], True, ksize=L["ksize"], sync=sync)
             elif name.startswith("conv3x3_winograd"):
                 up = ops.pack_winograd(wt)
                 fn = (lambda: ops.conv3x3_s2_winograd_c4(x, up, bp, L["Cout"], True)) if L["stride"] == 2 else (lambda: ops.conv3x3_winograd_c4(x, up, bp, L["Cout"], True))
@@ -198,7 +217,7 @@ def kernel_rooflines(dev, frames):
                 fn = lambda: ops.conv_rows_winograd_c4(x, up, bp, L["Cout"], L["ksize"], True, stride=L["stride"])
             else:
                 fn = lambda: ops.conv2d_c4(x, wp, bp, L["Cout"], L["ksize"], L["stride"], True)
-            ms = event_ms(fn, iters=3, warm=1)
+            ms = event_ms(fn, iters=IT, warm=WARM)
             k = per_kernel.setdefault(name, [0.0, 0.0, 0, 0.0])
             k[0] += flop; k[1] += ms; k[2] += 1; k[3] += flop * executed
             del x, wt, wp, bp
@@ -208,9 +227,10 @@ def kernel_rooflines(dev, frames):
             "frac": exe / ms / 1e9 / MFMA_F32_PEAK_TF, "traffic": pmc_traffic(name), "traffic_uncorrected": pmc_traffic(name, raw=True),
             "traffic_note": "HBM bytes per average launch, PMC pass committed under profiles/ (not live)", "launches_per_step": launches,
             "avg_launch_ms": ms / launches, "algorithmic": flop / ms / 1e9,
-            "note": "achieved = flops executed on the matrix cores; algorithmic = direct-convolution-equivalent rate; avg_launch_ms times each layer alone -- compare with profiles/r1_bench_kernel_stats_serial.csv (in the default run the two refine decoders overlap on two streams, which stretches rocprof's per-launch durations while shortening the step)",
+            "note": "achieved = flops executed on the matrix cores; algorithmic = direct-convolution-equivalent rate; avg_launch_ms = mean over this kernel's layer shapes of a step, each shape timed alone (%d launches after %d warm-up) -- compare with profiles/r3_bench_kernel_stats_serial.csv (in the default run the two refine decoders overlap on two streams, which stretches rocprof's per-launch durations while shortening the step)" % (IT, WARM),
             "all_conv": {"achieved": sum(v[3] for v in per_kernel.values()) / tot_ms / 1e9,
-                         "algorithmic": sum(v[0] for v in per_kernel.values()) / tot_ms / 1e9, "ms_per_step": tot_ms,
+                         "algorithmic": sum(v[0] for v in per_kernel.values()) / tot_ms / 1e9, "sum_of_isolated_layer_ms": tot_ms,
+                         "sum_note": "sum of the per-layer timings above (every layer alone, caches warm): NOT a share of ms_per_step -- in the step layers run cache-cold and two streams overlap",
                          "per_kernel_ms": {k: round(v[1], 3) for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1][1])}}}
     img, cams = syn.frames(frames, SRC, H, W, seed=99)
     img, cams = torch.from_numpy(img).to(dev), torch.from_numpy(cams).to(dev)
@@ -254,6 +274,7 @@ def kernel_rooflines(dev, frames):
     sweep = {"kernel": "planesweep_kernel<1>", "bound": "hbm", "achieved": byts / ms / 1e6, "peak": HBM_PEAK_GBS,
              "unit": "GB/s", "frac": byts / ms / 1e6 / HBM_PEAK_GBS, "traffic": pmc_traffic("planesweep_kernel<1>"),
              "traffic_uncorrected": pmc_traffic("planesweep_kernel<1>", raw=True),
+             "target": 0.60, "met": bool(byts / ms / 1e6 / HBM_PEAK_GBS >= 0.60),             # BASELINE.json north_star: >= 60 % of the HBM roofline
              "algorithmic_bytes_per_launch": byts, "avg_launch_ms": ms,
              "launch_ms": {"median": per[n_it // 2], "p10": per[n_it // 10], "p90": per[9 * n_it // 10], "n": n_it},
              "burst_avg_launch_ms": burst_ms, "burst_frac": byts / burst_ms / 1e6 / HBM_PEAK_GBS,
@@ -311,10 +332,47 @@ def cpu_baseline(budget_s=20.0):
     torch.set_num_threads(threads)
     n = int(max(2, min(20, budget_s / max(dt, 1e-3))))
     dt = sum(one() for _ in range(n)) / n
+    # the headline's batch of 8 frames as ONE call (BASELINE.md section 3 asks for batch 1 and batch 8): oneDNN sees 8x the pixels per op
+    img8, cams8 = syn.frames(8, SRC, H, W, seed=1234)
+    args8 = (T(img8[:, 0]), T(img8[:, 1]), T(img8[:, 2]), T(cams8[:, 0]), T(cams8[:, 1]), T(cams8[:, 2]))
+
+    def one8():
+        t = time.perf_counter(); ra.frame_forward(dn, rn, *args8, k_size=KSIZE); return time.perf_counter() - t
+
+    one8()
+    n8 = int(max(1, min(3, 0.5 * budget_s / max(8 * dt, 1e-3))))
+    dt8 = sum(one8() for _ in range(n8)) / n8
     return {"value": 1.0 / dt, "unit": "frames/s", "cores": threads, "kind": "port",
+            "batch8": {"value": 8.0 / dt8, "unit": "frames/s", "sample": "%d call(s) of 8 frames" % n8},
             "sample": "%d frames (1 ref + 2 src, 256x192, 64 planes, batch 1) after warm-up; torch %s CPU ops in the "
-                      "reference's arrangement, %d threads (host CPU quota %d of %d logical CPUs) on %s"
+                      "reference's arrangement, %d threads (host CPU quota %d of %d logical CPUs) on %s; batch8 = the same graph on "
+                      "the headline's batch of 8 frames per call"
                       % (n, torch.__version__, threads, quota, os.cpu_count(), cpu_model())}
+
+
+def init_dist(want, dev, world):
+    """Process group(s) of a multi-rank run.  The default group is gloo -- it always comes up and carries the timing reduce
+    and the agreement below; the RCCL group (backend "nccl") is created next to it and tried with one all-reduce, and the
+    ranks then AGREE (MIN over gloo) whether every one of them got it: either all barriers / gradient all-reduces run on
+    RCCL or all on gloo, never a mixture (a per-rank fallback would deadlock at the first barrier)."""
+    import datetime
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    pg, ok = None, 0
+    if want == "nccl":
+        try:
+            pg = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=180))
+            t = torch.ones(1, device=dev)
+            dist.all_reduce(t, group=pg)
+            ok = int(round(float(t.item())) == world)
+        except Exception as e:                                           # noqa: BLE001 -- whatever RCCL raises here means "not available"
+            print("bench.py: RCCL unavailable on this rank (%s)" % str(e)[:200], file=sys.stderr)
+        flag = torch.tensor([ok])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = int(flag.item())
+        if not ok:
+            pg = None
+    return dist, pg, ("nccl" if ok else "gloo")
 
 
 def self_launch(n):
@@ -396,8 +454,69 @@ def train_secondary(dev, B=4, steps=10):
                         "batch %d, 1 ref + 2 src, %dx%d, %d planes" % (KSIZE, B, W, H, PLANES)}
 
 
+def train_mode(a, dev, dist, pg, backend, rank, world):
+    """--mode train: BASELINE configs[2] -- the `train` optimisation step (train.py:164-310: two depthNet forwards, DepthRefineNet,
+    Depth2normal k = 9 normal losses, warped-depth losses, backward, Adam) data-parallel over one process per GPU: every rank
+    steps on ITS shard of 4 samples (global batch 4 N, weak scaling: 32 at N = 8) and the ranks exchange gradients with the
+    bucketed all-reduce of cnmnet_amd/trainer.py (178.7 MB fp32 in ~25 MB buckets, launched from backward hooks).
+    value = global samples / max-over-ranks wall time of K steps between barriers."""
+    from cnmnet_amd.depthnet import depthNet, DepthRefineNet
+    from cnmnet_amd.trainer import TrainStep, synthetic_training_sample
+    from cnmnet_amd import sharding
+    B = a.samples_per_gpu
+    step = TrainStep(load_weights(depthNet(3.0, PLANES), 1).to(dev), load_weights(DepthRefineNet(32, 3.0), 2).to(dev), k_size=KSIZE,
+                     dist=dist, group=pg, graph=bool(a.graph))
+    smp = {k: v.to(dev) for k, v in synthetic_training_sample(B, H, W, seed=7 + rank).items()}
+    args = (smp["rgbs"], smp["cameras"], smp["disparities"], smp["depths"], smp["normals"])
+
+    def barrier():
+        if dist is not None:
+            dist.barrier(group=pg)
+        torch.cuda.synchronize()
+
+    for _ in range(max(a.warmup, 3)):                    # allocator pools, the graph capture (graph mode), Adam state
+        log = step(*args)
+    step.finish_events = [] if step.reducer is not None else None
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        ev[i].record()
+        log = step(*args)
+    ev[a.steps].record()
+    torch.cuda.synchronize()
+    barrier()
+    rank_elapsed = time.perf_counter() - t0
+    assert log["loss"] == log["loss"], "training loss is NaN"
+    elapsed = sharding.job_elapsed(rank_elapsed, dist, "cpu")
+    per = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(a.steps))
+    if rank != 0:
+        return None
+    q = lambda f: per[min(len(per) - 1, int(f * len(per)))]
+    line = {"metric": "training samples/sec (`train` step: ref+2src, 256x192, 64 planes, Depth2normal k=9)", "value": world * B * a.steps / elapsed,
+            "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": max(a.warmup, 3), "ms_per_step": 1e3 * elapsed / a.steps,
+            "step_ms": {"median": q(0.5), "p10": q(0.1), "p90": q(0.9), "n": a.steps}, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "CNMNet `train` step (forward + normal / warped-depth losses + backward + Adam), batch %d per GPU, 1 ref + 2 src, "
+                                   "256x192, 64 planes (BASELINE configs[2]: global batch 32 on 8 GPUs)" % B,
+                       "global_batch": world * B, "parallelism": "dp%d" % world,
+                       "allreduce_backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None,
+                       "launch": ("forward + backward as one HIP graph, exchange + Adam eager" if world > 1 else "one HIP graph") if a.graph else "eager"}}
+    if step.reducer is not None:
+        r = step.reducer
+        exposed = [e0.elapsed_time(e1) for e0, e1 in step.finish_events]
+        line["allreduce"] = {"bytes_per_step": r.bytes_per_step, "buckets": len(r.buckets), "launched_from_backward_hooks": r.hook_launches,
+                             "launched_late": r.late_launches, "exposed_ms": sum(exposed) / max(1, len(exposed)),
+                             "note": "exposed_ms = HIP-event time around the reducer's finish() on the compute stream: what backward did not hide of "
+                                     "the exchange, plus the write-back of the averaged gradients" +
+                                     ("" if backend == "nccl" else "; gloo here (no RCCL run): the exchange goes through the host and says nothing about xGMI")}
+    return line
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--mode", choices=["eval", "train"], default="eval", help="eval = the headline frames/s; train = BASELINE configs[2], the data-parallel `train` step, samples/s")
+    ap.add_argument("--samples-per-gpu", type=int, default=4, help="--mode train: batch shard per GPU (configs[2]: 32 over 8 GPUs)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
@@ -422,20 +541,17 @@ def main():
     backend = os.environ.get("CNM_BENCH_BACKEND", "nccl")
     dev = torch.device("cuda", int(os.environ.get("CNM_BENCH_DEVICE", local)))
     torch.cuda.set_device(dev)
-    dist = None
+    dist, pg = None, None
     if world > 1:
-        import torch.distributed as dist
-        if backend == "nccl":
-            try:
-                dist.init_process_group("nccl", device_id=dev)           # RCCL; eager communicator: a broken setup fails HERE
-            except Exception as e:                                       # the data path has no collective -- only the barrier and the
-                print("bench.py: RCCL init failed (%s); barrier / max-over-ranks on gloo" % str(e)[:200], file=sys.stderr)   # timing reduce use it
-                if dist.is_initialized():
-                    dist.destroy_process_group()
-                backend = "gloo"
-                dist.init_process_group("gloo")
-        else:
-            dist.init_process_group(backend)
+        dist, pg, backend = init_dist(backend, dev, world)
+    if a.mode == "train":
+        line = train_mode(a, dev, dist, pg, backend, rank, world)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        if line is not None:
+            print(json.dumps(line), flush=True)
+        return
 
     from cnmnet_amd import synthetic as syn
     from cnmnet_amd.depthnet import depthNet, DepthRefineNet
@@ -452,7 +568,7 @@ def main():
 
     def barrier():
         if dist is not None:
-            dist.barrier()
+            dist.barrier(group=pg)
         torch.cuda.synchronize()
 
     run = pipe
@@ -464,9 +580,8 @@ def main():
     out, rank_elapsed, step_ms = timed_steps(run, img, cams, a.steps, barrier)   # barrier + synchronize on both sides
     assert bool(torch.isfinite(out["disp"]).all()) and bool(torch.isfinite(out["normal"]).all())
     from cnmnet_amd import sharding
-    red_dev = dev if backend == "nccl" else "cpu"
-    elapsed = sharding.job_elapsed(rank_elapsed, dist, red_dev)                                   # max over ranks
-    fastest = -sharding.job_elapsed(-rank_elapsed, dist, red_dev)                                 # min over ranks
+    elapsed = sharding.job_elapsed(rank_elapsed, dist, "cpu")                                     # max over ranks (default group: gloo)
+    fastest = -sharding.job_elapsed(-rank_elapsed, dist, "cpu")                                   # min over ranks
 
     line = None
     if rank == 0:
@@ -492,7 +607,7 @@ def main():
                 _LIVE_TRAFFIC = live_traffic()
             line["roofline"], line["roofline_planesweep"] = kernel_rooflines(dev, B)
             src = ("PMC passes of this run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE as child processes, FETCH_SIZE x 2)" if _LIVE_TRAFFIC is not None
-                   else "PMC pass committed under profiles/ (not live)")
+                   else "PMC pass committed under profiles/r3_pmc_traffic.json, possibly of an earlier build (live passes: %s)" % _LIVE_TRAFFIC_WHY)
             line["roofline"]["traffic_note"] = line["roofline_planesweep"]["traffic_note"] = "HBM bytes per average launch, " + src
         if world == 1 and not a.no_secondary and a.precision == "f32":
             del pipe, run, out

@@ -115,6 +115,7 @@ PROTOTYPES = {
     "cnm_inverse_warp_backward_depth_f32": (c_i, [c_fp] * 7 + [c_i, c_i, c_i, c_i, c_fp]),
     "cnm_intrinsics_inverse_f32": (c_i, [c_fp, c_ll, c_fp, c_i, c_fp]),
     "cnm_inverse_warp_f32": (c_i, [c_fp] * 6 + [c_i, c_i, c_i, c_i, c_fp]),
+    "cnm_inverse_warp_pad_f32": (c_i, [c_fp] * 6 + [c_i, c_i, c_i, c_i, c_i, c_fp]),
 }
 
 NET_DEPTH, NET_REFINE = 0, 1

@@ -242,6 +242,18 @@ extern "C" int cnm_intrinsics_inverse_f32(const float* cam, long long cam_stride
 }
 
 // ------------------------------------------------------------------ K7
+// PAD: grid_sample's padding_mode, which the reference hands through unchanged (inverse_warp.py:116): 0 'zeros' (with the
+// reference's own out-of-view masking, :71-75), 1 'border' (coordinate clipped to the pixel centres), 2 'reflection'
+// (reflected about the image edges -0.5 / size - 0.5, then clipped) -- align_corners=False in all three.
+__device__ __forceinline__ float iw_reflect(float x, int size) {        // ATen reflect_coordinates(x, -1, 2 size - 1) on half-pixel units, then clip
+    const float span = (float)size;                                      // (2 size - 1 - (-1)) / 2
+    x = fabsf(x + 0.5f);                                                 // distance from the low edge -0.5
+    const float extra = fmodf(x, span);
+    const int flips = (int)floorf(x / span);
+    const float r = (flips & 1) ? span - extra - 0.5f : extra - 0.5f;
+    return fminf(fmaxf(r, 0.f), (float)(size - 1));
+}
+template <int PAD>
 __global__ __launch_bounds__(256) void inverse_warp_kernel(const float* __restrict__ feat, const float* __restrict__ depth,
                                                            const float* __restrict__ pose, const float* __restrict__ K,
                                                            const float* __restrict__ Kinv, float* __restrict__ out,
@@ -265,9 +277,13 @@ __global__ __launch_bounds__(256) void inverse_warp_kernel(const float* __restri
     const float Z = fmaxf(P[8] * cx + P[9] * cy + P[10] * cz + P[11], 1e-3f);   // :67
     float xn = 2.f * (X / Z) / (float)(W - 1) - 1.f;                            // :69
     float yn = 2.f * (Y / Z) / (float)(H - 1) - 1.f;                            // :70
-    if (xn > 1.f || xn < -1.f) xn = 2.f;                                         // :71-75
-    if (yn > 1.f || yn < -1.f) yn = 2.f;
-    const float ix = ((xn + 1.f) * W - 1.f) * 0.5f, iy = ((yn + 1.f) * H - 1.f) * 0.5f;   // grid_sample, align_corners=False
+    if constexpr (PAD == 0) {
+        if (xn > 1.f || xn < -1.f) xn = 2.f;                                     // :71-75
+        if (yn > 1.f || yn < -1.f) yn = 2.f;
+    }
+    float ix = ((xn + 1.f) * W - 1.f) * 0.5f, iy = ((yn + 1.f) * H - 1.f) * 0.5f;         // grid_sample, align_corners=False
+    if constexpr (PAD == 1) { ix = fminf(fmaxf(ix, 0.f), (float)(W - 1)); iy = fminf(fmaxf(iy, 0.f), (float)(H - 1)); }
+    if constexpr (PAD == 2) { if (fabsf(ix) < 1e7f && fabsf(iy) < 1e7f) { ix = iw_reflect(ix, W); iy = iw_reflect(iy, H); } }
     float w00 = 0.f, w01 = 0.f, w10 = 0.f, w11 = 0.f; int xi = 0, yi = 0;
     bool x0in = false, x1in = false, y0in = false, y1in = false;
     if (fabsf(ix) < 1e7f && fabsf(iy) < 1e7f) {
@@ -352,14 +368,24 @@ extern "C" int cnm_inverse_warp_backward_depth_f32(const float* feat, const floa
     return CNM_OK;
 }
 
+extern "C" int cnm_inverse_warp_pad_f32(const float* feat, const float* depth, const float* pose,
+                                        const float* K, const float* K_inv, float* out,
+                                        int B, int C, int H, int W, int padding_mode, void* stream) {
+    CNM_REQUIRE(feat && depth && pose && K && K_inv && out && B > 0 && C > 0 && H > 1 && W > 1, CNM_ERR_BAD_ARG);
+    CNM_REQUIRE(padding_mode >= 0 && padding_mode <= 2, CNM_ERR_BAD_ARG);
+    const long long total = (long long)B * H * W;
+    const unsigned nb = (unsigned)cnm_ceil_div_ll(total, 256);
+    if (padding_mode == 0) inverse_warp_kernel<0><<<nb, 256, 0, cnm_stream(stream)>>>(feat, depth, pose, K, K_inv, out, B, C, H, W);
+    else if (padding_mode == 1) inverse_warp_kernel<1><<<nb, 256, 0, cnm_stream(stream)>>>(feat, depth, pose, K, K_inv, out, B, C, H, W);
+    else inverse_warp_kernel<2><<<nb, 256, 0, cnm_stream(stream)>>>(feat, depth, pose, K, K_inv, out, B, C, H, W);
+    CNM_LAUNCH_CHECK();
+    return CNM_OK;
+}
+
 extern "C" int cnm_inverse_warp_f32(const float* feat, const float* depth, const float* pose,
                                     const float* K, const float* K_inv, float* out,
                                     int B, int C, int H, int W, void* stream) {
-    CNM_REQUIRE(feat && depth && pose && K && K_inv && out && B > 0 && C > 0 && H > 1 && W > 1, CNM_ERR_BAD_ARG);
-    const long long total = (long long)B * H * W;
-    inverse_warp_kernel<<<(unsigned)cnm_ceil_div_ll(total, 256), 256, 0, cnm_stream(stream)>>>(feat, depth, pose, K, K_inv, out, B, C, H, W);
-    CNM_LAUNCH_CHECK();
-    return CNM_OK;
+    return cnm_inverse_warp_pad_f32(feat, depth, pose, K, K_inv, out, B, C, H, W, 0, stream);
 }
 
 // ------------------------------------------------------------------ plane-instance regularisation of a normal map

@@ -26,9 +26,9 @@ def inverse_warp(feat, depth, pose, intrinsics, intrinsics_inv, padding_mode="ze
     check_sizes(intrinsics, "intrinsics", "B33")
     check_sizes(intrinsics_inv, "intrinsics", "B33")
     assert intrinsics_inv.size() == intrinsics.size()
-    if padding_mode != "zeros":
-        raise NotImplementedError("only padding_mode='zeros' (the reference's default and only use) is built")
     if torch.is_grad_enabled() and depth.requires_grad:
+        if padding_mode != "zeros":
+            raise NotImplementedError("the gradient w.r.t. depth is built for padding_mode='zeros' (the reference's default and only use) only")
         from ..autograd import InverseWarpFn
         return InverseWarpFn.apply(feat, depth, pose, intrinsics, intrinsics_inv)
-    return ops.inverse_warp(feat, depth, pose, intrinsics, intrinsics_inv)
+    return ops.inverse_warp(feat, depth, pose, intrinsics, intrinsics_inv, padding_mode)

@@ -494,12 +494,17 @@ def intrinsics_inverse(cam):
     return out
 
 
-def inverse_warp(feat, depth, pose, intrinsics, intrinsics_inv):
+PADDING_MODES = {"zeros": 0, "border": 1, "reflection": 2}           # torch.nn.functional.grid_sample's padding_mode values
+
+
+def inverse_warp(feat, depth, pose, intrinsics, intrinsics_inv, padding_mode="zeros"):
     _dev(feat, depth, pose, intrinsics, intrinsics_inv)
+    if padding_mode not in PADDING_MODES:
+        raise ValueError("padding_mode must be one of %s, got %r" % (sorted(PADDING_MODES), padding_mode))
     feat, depth, pose, intrinsics, intrinsics_inv = map(_c, (feat, depth, pose, intrinsics, intrinsics_inv))
     B, Cc, H, W = feat.shape
     out = torch.empty_like(feat)
     with torch.cuda.device(feat.device):
-        _lib.check(_lib.load().cnm_inverse_warp_f32(_p(feat), _p(depth), _p(pose), _p(intrinsics), _p(intrinsics_inv),
-                                                    _p(out), B, Cc, H, W, _stream()))
+        _lib.check(_lib.load().cnm_inverse_warp_pad_f32(_p(feat), _p(depth), _p(pose), _p(intrinsics), _p(intrinsics_inv),
+                                                        _p(out), B, Cc, H, W, PADDING_MODES[padding_mode], _stream()))
     return out

@@ -28,8 +28,10 @@ class BucketedGradAllReduce:
     exactly as it was (None stays None): the optimizer then skips it as it does on one device and under the
     reference's DataParallel, instead of decaying it towards zero."""
 
-    def __init__(self, params, dist, bucket_bytes=25 * 2**20):
-        self.dist, self.world = dist, dist.get_world_size()
+    def __init__(self, params, dist, bucket_bytes=25 * 2**20, group=None, hooks=True):
+        """group: the process group of the all-reduces (None = the default group); hooks=False: no backward hooks -- the
+        caller reduces every bucket after backward with reduce_all() (the HIP-graph step: hooks do not run in a replay)."""
+        self.dist, self.group, self.world = dist, group, dist.get_world_size(group)
         self.params = [p for p in params if p.requires_grad]
         self.buckets, cur, size = [], [], 0
         for p in reversed(self.params):                    # decoder grads are ready first
@@ -44,7 +46,8 @@ class BucketedGradAllReduce:
         self.fired = set()                                 # ids of the parameters whose gradient arrived this step
         self.hook_launches = self.late_launches = 0        # buckets launched from backward hooks / from finish(), last step
         self._hook_count = 0
-        self.handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
+        self.bytes_per_step = 4 * sum(f.numel() for f in self.flat)         # payload of one step's all-reduces
+        self.handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params] if hooks else []
 
     def _hook(self, p):
         i = self.bucket_of[id(p)]
@@ -63,7 +66,14 @@ class BucketedGradAllReduce:
             else:
                 self.flat[i][off:off + n].zero_()
             off += n
-        self.work[i] = self.dist.all_reduce(self.flat[i], op=self.dist.ReduceOp.SUM, async_op=True)
+        self.work[i] = self.dist.all_reduce(self.flat[i], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def reduce_all(self):
+        """Without hooks: every parameter that has a gradient counts as arrived; launches all buckets, then finish()."""
+        for p in self.params:
+            if p.grad is not None:
+                self.fired.add(id(p))
+        self.finish()
 
     def finish(self):
         """Call after backward(): waits for all buckets and writes the averaged gradients back."""
@@ -125,17 +135,19 @@ class TrainStepWoNormal:
     arithmetic as the eager step: every loss term has static shapes (`_masked_l1`), the capture's warm-up iterations are
     undone in place (parameters, BatchNorm statistics, Adam state) before the first replay."""
 
-    def __init__(self, depth_net, refine_net, lr=1e-4, weight_decay=1e-5, dist=None, exact_masked_means=False, graph=False):
+    def __init__(self, depth_net, refine_net, lr=1e-4, weight_decay=1e-5, dist=None, exact_masked_means=False, graph=False, group=None):
+        """group: process group of the gradient all-reduce (None = default).  graph=True with more than one rank: forward and
+        backward are replayed as ONE HIP graph, the bucketed all-reduce and the Adam update follow eagerly (a collective
+        stays outside the captured region; the backward hooks that overlap buckets with backward do not exist in a replay)."""
         self.depth_net, self.refine_net, self.dist, self.exact = depth_net, refine_net, dist, exact_masked_means
         params = list(refine_net.parameters()) + list(depth_net.parameters())              # train.py:87, :446
         self.optimizer = torch.optim.Adam(params, lr=lr, weight_decay=weight_decay, capturable=bool(graph))   # utils/misc.py:31-33
         self.reducer = None
-        if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
-            self.reducer = BucketedGradAllReduce(params, dist)
-        if graph and self.reducer is not None:
-            raise ValueError("graph=True captures one GPU's step; the gradient all-reduce stays outside a captured region")
+        if dist is not None and dist.is_initialized() and dist.get_world_size(group) > 1:
+            self.reducer = BucketedGradAllReduce(params, dist, group=group, hooks=not graph)
         self.l234 = IdepthLoss_234()
         self.graph_mode, self._graph, self._graph_key = bool(graph), None, None
+        self.finish_events = None                                        # set to [] to collect (start, end) HIP events around the reducer's finish()
 
     def __call__(self, rgbs, cameras, disparities, depths, warmup_epoch=False):
         """rgbs [B,3,3,H,W] (ref, src1, src2), cameras [B,3,2,4,4], disparities / depths [B,V,1,H,W]
@@ -147,9 +159,17 @@ class TrainStepWoNormal:
         self.optimizer.zero_grad(set_to_none=False)                                          # :562-565
         loss.backward()
         if self.reducer is not None:
-            self.reducer.finish()
+            self._finish(self.reducer.finish)
         self.optimizer.step()
         return _log_values(logs)
+
+    def _finish(self, fn):
+        """The part of the gradient exchange that backward did not hide: buckets still in flight + the write-back."""
+        if self.finish_events is None:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record()
+        self.finish_events.append((e0, e1))
 
     # ---- HIP-graph replay of the step
     def _graphed_step(self, inputs, variant, fn):
@@ -160,6 +180,9 @@ class TrainStepWoNormal:
         for dst, src in zip(self._static_in, inputs):
             dst.copy_(src)
         self._graph.replay()
+        if self.reducer is not None:                        # the graph holds forward + backward; exchange and update follow eagerly
+            self._finish(self.reducer.reduce_all)
+            self.optimizer.step()
         return _log_values(self._static_logs)
 
     def _state_tensors(self):
@@ -172,10 +195,7 @@ class TrainStepWoNormal:
 
     def _capture(self, inputs, fn, key):
         self._static_in = [t.detach().clone() for t in inputs]
-        had_state = len(self.optimizer.state) > 0
-        saved = [t.clone() for t in self._state_tensors()] if had_state else \
-                [t.clone() for t in [p.data for g in self.optimizer.param_groups for p in g["params"]] +
-                 [b for net in (self.depth_net, self.refine_net) for b in net.buffers()]]
+        saved = [t.clone() for t in self._state_tensors()]  # parameters, BatchNorm buffers and whatever Adam state exists already
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                       # warm-up off the default stream: Adam state and allocator pools exist before capture
@@ -183,7 +203,8 @@ class TrainStepWoNormal:
                 loss, logs = fn(*self._static_in)
                 self.optimizer.zero_grad(set_to_none=True)
                 loss.backward()
-                self.optimizer.step()
+                if self.reducer is None:
+                    self.optimizer.step()
                 del loss, logs                              # no autograd graph of the warm-up may outlive it (its AccumulateGrad nodes carry their stream)
         torch.cuda.current_stream().wait_stream(side)
         self.optimizer.zero_grad(set_to_none=True)
@@ -191,19 +212,20 @@ class TrainStepWoNormal:
         with torch.cuda.graph(self._graph):
             loss, logs = fn(*self._static_in)
             loss.backward()
-            self.optimizer.step()
+            if self.reducer is None:
+                self.optimizer.step()
         self._static_logs = {k: v.detach() for k, v in logs.items()}
         del loss, logs
-        # undo the warm-up in place (the graph holds these addresses): the first replay is the first real step
+        # undo the warm-up in place (the graph holds these addresses): the first replay is the first real step.  State that
+        # existed before is restored; state the warm-up CREATED (Adam moments and step counters of parameters that had
+        # none -- all of them on the first capture, the probability decoder's when a warm-up-epoch graph is followed by the
+        # full one) starts from zero, exactly as if the optimizer met those parameters for the first time.  Adam appends
+        # new state entries behind the existing ones, so the saved list is a prefix of the live one.
         live = self._state_tensors()
-        if had_state:
-            for t, s0 in zip(live, saved):
-                t.copy_(s0)
-        else:
-            for t, s0 in zip(live[:len(saved)], saved):
-                t.copy_(s0)
-            for t in live[len(saved):]:                     # Adam moments and step counters created by the warm-up
-                t.zero_()
+        for t, s0 in zip(live, saved):
+            t.copy_(s0)
+        for t in live[len(saved):]:
+            t.zero_()
         self._graph_key = key
 
     def losses(self, rgbs, cameras, disparities, depths, warmup_epoch=False):
@@ -299,7 +321,7 @@ class TrainStep(TrainStepWoNormal):
         self.optimizer.zero_grad(set_to_none=False)                                          # :307-310
         loss.backward()
         if self.reducer is not None:
-            self.reducer.finish()
+            self._finish(self.reducer.finish)
         self.optimizer.step()
         return _log_values(logs)
 

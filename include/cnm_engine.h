@@ -470,6 +470,12 @@ int cnm_intrinsics_inverse_f32(const float* cam, long long cam_stride, float* K_
 int cnm_inverse_warp_f32(const float* feat, const float* depth, const float* pose,
                          const float* K, const float* K_inv, float* out,
                          int B, int C, int H, int W, void* stream);
+/* The same with the padding_mode the reference hands through to grid_sample (inverse_warp.py:81,116): 0 'zeros' (the
+ * function above: out-of-view coordinates forced to 2, :71-75), 1 'border', 2 'reflection' (no out-of-view masking in the
+ * reference for these two; align_corners=False).  Forward only -- the training path uses 'zeros'. */
+int cnm_inverse_warp_pad_f32(const float* feat, const float* depth, const float* pose,
+                             const float* K, const float* K_inv, float* out,
+                             int B, int C, int H, int W, int padding_mode, void* stream);
 
 /* Backward of cnm_inverse_warp_f32 w.r.t. the target depth (train.py:284-293 differentiates the sampling
  * position; the sampled map itself carries no gradient there): grad_out [B,C,H,W] -> grad_depth [B,H,W]. */

@@ -39,3 +39,22 @@ def test_two_rank_bench_self_launch():
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-roofline"]
     _check_line(subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600))
+
+
+def test_two_rank_train_mode_line():
+    """bench.py --mode train (BASELINE configs[2]): two ranks on GPU 0 over gloo take the `train` step on a shard each and
+    exchange gradients with the bucketed all-reduce; the line carries samples/s and the exchange's accounting."""
+    env = dict(os.environ, CNM_BENCH_BACKEND="gloo", CNM_BENCH_DEVICE="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "train", "--gpus", "2", "--steps", "2", "--warmup", "1", "--samples-per-gpu", "1"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stderr or "")[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["unit"] == "samples/s" and d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 and d["config"]["parallelism"] == "dp2"
+    assert abs(d["value"] - 2 * 1 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+    ar = d["allreduce"]
+    assert ar["bytes_per_step"] == 4 * 44674566 and ar["buckets"] >= 3                    # 33 898 500 + 10 776 066 parameters (SURVEY 2-K8)
+    assert ar["launched_from_backward_hooks"] + ar["launched_late"] == ar["buckets"] and ar["exposed_ms"] > 0

@@ -21,4 +21,4 @@ def test_two_rank_engine_train_step():
            "--master-port", str(port), os.path.join(ROOT, "tests", "dp_step_worker.py")]
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
-    assert "dp-step OK" in r.stdout, r.stdout[-1500:]
+    assert "dp-step OK" in r.stdout and "dp-graph OK" in r.stdout, r.stdout[-1500:]

@@ -941,8 +941,46 @@ def test_inverse_warp_golden(dev, golden):
     a = [T(g[k]).to(dev) for k in ("depth", "pose", "K", "K_inv")]
     w3 = inverse_warp(T(g["feat"]).to(dev), *a).cpu().numpy()
     w1 = inverse_warp(T(g["feat"][:, :1]).to(dev), *a).cpu().numpy()
-    med, q, mx = _stats(w3, g["warped_c3"])
-    assert med < 1e-6 and q < 1e-3, (med, q, mx)
-    assert _stats(w1, g["warped_c1"])[1] < 1e-3
+    # The warp is continuous except where the reference forces an out-of-view coordinate to 2 (inverse_warp.py:71-75): a
+    # pixel whose normalised coordinate lies within rounding of +-1 may fall on either side.  Those pixels are COUNTED and
+    # bounded; every other pixel must agree with the reference at the maximum, not at a quantile.
+    B, _, Hh, Ww = g["feat"].shape
+    ys, xs = np.mgrid[0:Hh, 0:Ww].astype(np.float64)
+    pix = np.stack([xs.ravel(), ys.ravel(), np.ones(Hh * Ww)])                       # [3, HW]
+    near = np.zeros((B, Hh, Ww), bool)
+    for b in range(B):
+        cam = (g["K_inv"][b].astype(np.float64) @ pix) * g["depth"][b].astype(np.float64).ravel()
+        P = g["K"][b].astype(np.float64) @ g["pose"][b].astype(np.float64)
+        pc = P[:, :3] @ cam + P[:, 3:]
+        Z = np.maximum(pc[2], 1e-3)
+        xn, yn = 2 * (pc[0] / Z) / (Ww - 1) - 1, 2 * (pc[1] / Z) / (Hh - 1) - 1
+        near[b] = ((np.abs(np.abs(xn) - 1) < 1e-5) | (np.abs(np.abs(yn) - 1) < 1e-5)).reshape(Hh, Ww)
+    assert near.sum() <= 8, int(near.sum())                                           # a handful of pixels sit on the boundary in this fixture
+    for got, want in ((w3, g["warped_c3"]), (w1, g["warped_c1"])):
+        err = np.abs(got.astype(np.float64) - want.astype(np.float64))
+        away = err[np.broadcast_to(~near[:, None], err.shape)]
+        assert float(np.median(err)) < 1e-6 and float(away.max()) < 1e-4, (float(np.median(err)), float(away.max()))
+        flipped = int((err[np.broadcast_to(near[:, None], err.shape)] > 1e-4).sum())
+        assert flipped <= 3 * int(near.sum()), (flipped, int(near.sum()))            # each boundary pixel may flip (all its channels), nothing else
     want = ra.backproject(T(g["depth"]), T(g["K_inv"])).numpy()
     np.testing.assert_allclose(pixel2cam(a[0], a[3]).cpu().numpy(), want, atol=2e-6, rtol=1e-6)
+
+
+@pytest.mark.parametrize("mode", ["border", "reflection"])
+def test_inverse_warp_padding_modes(dev, golden, mode):
+    """padding_mode is handed to grid_sample unchanged by the reference (inverse_warp.py:81,116; no out-of-view masking for
+    these modes): K7 against the oracle's torch-CPU evaluation of the same lines, on the golden inputs and on a pose that
+    throws a third of the samples out of the image (several reflections deep)."""
+    from cnmnet_amd.depthnet import inverse_warp
+    g = golden("inverse_warp_32x64.npz")
+    feat, depth, K, K_inv = T(g["feat"]), T(g["depth"]), T(g["K"]), T(g["K_inv"])
+    far = T(g["pose"]).clone()
+    far[:, 0, 3] += 1.5; far[:, 1, 3] -= 0.8                                          # large translation: samples well outside the image
+    for pose in (T(g["pose"]), far):
+        want = ra.inverse_warp(feat, depth, pose, K, K_inv, padding_mode=mode).numpy()
+        got = inverse_warp(feat.to(dev), depth.to(dev), pose.to(dev), K.to(dev), K_inv.to(dev), padding_mode=mode).cpu().numpy()
+        err = np.abs(got.astype(np.float64) - want.astype(np.float64))
+        # continuous in the sampling position (no masking): fp32 coordinate rounding times the feature gradient
+        assert float(np.quantile(err, 0.999)) < 1e-4 and float(err.max()) < 2e-3, (mode, float(np.quantile(err, 0.999)), float(err.max()))
+    with pytest.raises(ValueError):
+        inverse_warp(feat.to(dev), depth.to(dev), far.to(dev), K.to(dev), K_inv.to(dev), padding_mode="circular")

@@ -197,6 +197,37 @@ def test_graphed_train_step_equals_eager(dev):
             assert torch.allclose(be[n].float(), bg[n].float(), rtol=1e-5, atol=1e-6), n
 
 
+def test_graphed_warmup_then_full_graph_equals_eager(dev):
+    """fit()'s own schedule with graph=True: the warm-up-epoch graph (train.py:555-559) never gives the probability decoder a
+    gradient, so Adam holds no state for it; the re-capture for the full loss then CREATES that state during its two warm-up
+    iterations.  Those entries must start from zero like the eager optimizer's (they used to keep the warm-up's moments and
+    step = 2): two warm-up steps + two full steps, graphed against eager, every parameter and Adam moment."""
+    from cnmnet_amd.depthnet import depthNet, DepthRefineNet
+    from cnmnet_amd.trainer import TrainStepWoNormal, synthetic_training_sample
+    mk = lambda graph: TrainStepWoNormal(_load(depthNet(3.0), 81).to(dev), _load(DepthRefineNet(32, 3.0), 82).to(dev), lr=1e-4, graph=graph)
+    eager, graphed = mk(False), mk(True)
+    eager.optimizer = torch.optim.Adam(list(eager.refine_net.parameters()) + list(eager.depth_net.parameters()), lr=1e-4, weight_decay=1e-5, capturable=True)
+    for i, warm in enumerate((True, True, False, False)):
+        sd = {k: v.to(dev) for k, v in synthetic_training_sample(2, 64, 96, seed=20 + i).items()}
+        le = eager(sd["rgbs"], sd["cameras"], sd["disparities"], sd["depths"], warmup_epoch=warm)
+        lg = graphed(sd["rgbs"], sd["cameras"], sd["disparities"], sd["depths"], warmup_epoch=warm)
+        assert abs(le["loss"] - lg["loss"]) <= 1e-5 * max(1.0, abs(le["loss"])), (i, le["loss"], lg["loss"])
+    pe = list(eager.refine_net.named_parameters()) + list(eager.depth_net.named_parameters())
+    pg = list(graphed.refine_net.parameters()) + list(graphed.depth_net.parameters())
+    saw_prob = False
+    for (n, a), b in zip(pe, pg):
+        assert float((a - b).abs().max()) <= 1e-6, (n, float((a - b).abs().max()))
+        sa, sb = eager.optimizer.state[a], graphed.optimizer.state[b]
+        assert float(sa["step"]) == float(sb["step"]), (n, float(sa["step"]), float(sb["step"]))
+        if n.startswith("prob.") or "_prob." in n:
+            saw_prob = True
+            assert float(sa["step"]) == 2.0, n                            # the decoder met the optimizer in the two full steps only
+        for key in ("exp_avg", "exp_avg_sq"):
+            d = float((sa[key] - sb[key]).abs().max())
+            assert d <= 1e-5 * max(float(sa[key].abs().max()), 1e-12) + 1e-12, (n, key, d)
+    assert saw_prob
+
+
 @pytest.mark.parametrize("k", [9, 5])
 def test_depth2normal_backward(dev, golden, k):
     """K6 backward vs torch autograd through the oracle's Unfold formulation in fp64 (same fixture as the
