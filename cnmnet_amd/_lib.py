@@ -55,6 +55,8 @@ PROTOTYPES = {
     "cnm_wino36_sync_floats": (c_sz, []),
     "cnm_conv3x3_winograd4_sync_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp,
                                                 c_i, c_i, c_i, c_i, c_fp, c_sz, c_fp]),
+    "cnm_conv5x5_winograd_sync_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp,
+                                               c_i, c_i, c_i, c_i, c_fp, c_sz, c_fp]),
     "cnm_conv3x3_upsampled_winograd4_sync_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_sz, c_fp]),
     "cnm_packed_upsampled_ring_floats": (c_sz, [c_i, c_i]),
     "cnm_pack_upsampled_ring_f32": (c_i, [c_fp, c_fp, c_fp, c_f, c_i, c_i, c_fp, c_fp]),

@@ -369,6 +369,14 @@ extern "C" int cnm_pack_winograd5x5_bn_f32(const float* w_oihw, const float* bn_
     return pack36(w_oihw, bn_gamma, bn_var, eps, Cout, Cin, 5, rot, u_packed, stream);
 }
 
+extern "C" int cnm_conv5x5_winograd_sync_c4_f32(const float* in_a, int Ga_total, int ga0, int Ga,
+                                                const float* in_b, int Gb_total, int gb0, int Gb,
+                                                float* out, int Gout_total, int gout0, int Cout,
+                                                const float* u_packed, const float* b_packed,
+                                                int N, int H, int W, int relu, float* sync_ws, size_t sync_floats, void* stream) {
+    return conv36(in_a, Ga_total, ga0, Ga, in_b, Gb_total, gb0, Gb, out, Gout_total, gout0, Cout, u_packed, b_packed, N, H, W, 5, relu, stream, 0, 0, sync_ws, sync_floats);
+}
+
 extern "C" int cnm_conv5x5_winograd_c4_f32(const float* in_a, int Ga_total, int ga0, int Ga,
                                            const float* in_b, int Gb_total, int gb0, int Gb,
                                            float* out, int Gout_total, int gout0, int Cout,

@@ -35,6 +35,9 @@
 #ifndef WINO4S_WD
 #define WINO4S_WD 4       // weight fragments in flight per wave
 #endif
+#ifndef WINO4S_CBLK_SLOW
+#define WINO4S_CBLK_SLOW 1 // unit order: 1 = channel block slowest (an XCD's neighbouring ranges stream ONE block's filters: a fragment is fetched from
+#endif                     // beyond L2 once per ~32 workgroups), 0 = channel block fastest (the workgroups of a tile block share its input instead)
 #ifndef WINO4S_HI_STEP
 #define WINO4S_HI_STEP 6  // double step at which waves 4-7 start issuing their DMA pieces (waves 0-3: step 0); >= 4
 #endif
@@ -55,14 +58,28 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
         y0 = (m0) + s1 + s2; y1 = d1 + 2.f * d2; y2 = s1 + 4.f * s2; y3 = d1 + 8.f * d2 + (m5);                 \
     } while (0)
 
+// A^T of F(2,5) (2 outputs from the same 6 points): rows [1 1 1 1 1 0; 0 1 -1 2 -2 1]
+#define WINO2S_AT(y0, y1, m0, m1, m2, m3, m4, m5) do {                                                          \
+        const f32x4 s1 = (m1) + (m2), d1 = (m1) - (m2), s2 = (m3) + (m4), d2 = (m3) - (m4);                     \
+        y0 = (m0) + s1 + s2; y1 = d1 + 2.f * d2 + (m5);                                                         \
+    } while (0)
+
 __device__ __forceinline__ void wino4s_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // one LDS-DMA wave-instruction: 64 lanes x 16 bytes from buffer offset voff + soff to lds_addr + 16 lane (an
 // out-of-range voff lands as zeros).  m0 is saved and restored: the compiler does not model it across the statement.
-__device__ __forceinline__ void wino4s_dma16(unsigned lds_addr, unsigned voff, __amdgpu_buffer_rsrc_t rsrc, unsigned soff) {
+// The descriptor and the two scalar operands are pinned to SGPRs with readfirstlane (under register pressure the compiler
+// may hold wave-uniform values in VGPRs, which the "s" constraints cannot take); the leading s_nop covers the
+// readfirstlane -> buffer-instruction hazard, which hipcc does not pad inside an asm statement.
+__device__ __forceinline__ void wino4s_dma16(unsigned lds_addr, unsigned voff, const float* base, unsigned bytes, unsigned soff) {
+    const unsigned long long b = reinterpret_cast<unsigned long long>(base);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>((unsigned long long)lo | ((unsigned long long)hi << 32)), 0,
+                                                                          __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+    const unsigned la = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr), so = (unsigned)__builtin_amdgcn_readfirstlane((int)soff);
     unsigned keep;
-    asm volatile("s_nop 2\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(la), "v"(voff), "s"(rsrc), "s"(so) : "memory");
 }
 
 // ABL (debug builds, -DWINO4S_ABLATE, tools/wino36s_ablate.sh): bit 0 no input transform, 1 no DMA, 2 no weight loads in the
@@ -73,17 +90,24 @@ __device__ __forceinline__ void wino4s_dma16(unsigned lds_addr, unsigned voff, _
 // rows P / M: at most 16 values live), the per-unit DMA offsets live in LDS, everything the output transform needs is
 // derived inside it from an opaque copy of the lane id (loop-invariant code motion would otherwise park ~20 registers
 // across the phase loop), and the two transform constants are wave-uniform (SGPR operands).
-template <int TSX, bool UPS, int ABL = 0>                                // tile block = (16 / TSX) x TSX tiles
+// M = 4: F(4x4,3x3); M = 2: F(2x2,5x5) -- the same six interpolation points, 6 x 6 window and 36 frequency points; only
+// the tile pitch (M), the filter transform (in the packed filter) and the output transform (2 x 6 instead of 4 x 6) differ.
+template <int TSX, bool UPS, int ABL = 0, int M = 4>                     // tile block = (16 / TSX) x TSX tiles of M x M outputs
 __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino4Args a, const int SH, const int SW, const int tilesC, const int nunits,
                                                                        unsigned* __restrict__ sync_flags, float* __restrict__ sync_slots) {
-    constexpr int TSY = 16 / TSX, PR = 4 * TSY + 2, PC = 4 * TSX + 2, NSLOT = PR * PC;
-    constexpr int NPIECE = (NSLOT + 63) / 64, PLANE = (NPIECE * 64 + 1) * 16, RAWBUF = 4 * PLANE;   // bytes
+    static_assert((M == 4 || M == 2) && !(UPS && M != 4), "F(4x4,3x3) (optionally on a 2x upsampled input) or F(2x2,5x5)");
+    constexpr int TSY = 16 / TSX, PR = M * TSY + 6 - M, PC = M * TSX + 6 - M, NSLOT = PR * PC;
+    // Channel-group planes of the raw patch: NPIECE KB each, at pitch PLANE plus a pad per plane chosen so that the 32 lanes
+    // of a ds_read_b32 group (16 channels x 2 neighbouring tiles, M pixels = 4 M dwords apart) fall on 32 different banks:
+    // M = 4 (tiles 16 dwords apart): planes 4 dwords apart (mod 32); M = 2 (tiles 8 apart): planes at 0, 4, 16, 20.
+    constexpr int NPIECE = (NSLOT + 63) / 64, PLANE = NPIECE * 1024 + 128, RAWBUF = 4 * PLANE;   // bytes
+#define WINO4S_PLANE_OFF(q) ((q) * PLANE + (M == 4 ? (q) * 16 : ((q) & 1) * 16 + ((q) >> 1) * 64))
     constexpr int VBUF = 36 * 16 * 64, RAW0 = 2 * VBUF;                  // bytes
     constexpr int NDMA = 4 * NPIECE, DPW = (NDMA + 7) / 8;               // DMA pieces per chunk / per wave
     constexpr int DV0 = RAW0 + 2 * RAWBUF;                               // [DPW][512] per-thread DMA offsets of the unit being staged
     constexpr int WD = WINO4S_WD, NXI = 36;
     constexpr int SLOT_BYTES = 8 * 16 * 64 * 16;                         // one range's partial output: 8 waves x 16 pixels x 64 lanes x float4 = 128 KB
-    static_assert(PLANE % 128 == 16 && NXI % WD == 0 && WD % 2 == 0, "layout");
+    static_assert(PLANE % 128 == 0 && NXI % WD == 0 && WD % 2 == 0, "layout");
     __shared__ __attribute__((aligned(16))) char smem[DV0 + DPW * 512 * 4];   // 136 KB (TSX 16) / 126 KB (TSX 8)
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int hi = wave >> 2;
@@ -104,10 +128,11 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
     // ---- stage role: pieces n = wave + 8 m of the chunk's NDMA (plane q = n / NPIECE, piece k = n % NPIECE)
     int du = ps / nch, dc = ps - du * nch, dgp = ps, dimg = 0;           // cursor of the stage role: unit, chunk, global phase; image of that unit
     auto dma_unit = [&]() {                                              // per-lane offsets for unit du -> LDS (each thread re-reads only its own words)
-        const int strip = du / tilesC;
+        const int nstrips = nunits / tilesC;
+        const int strip = WINO4S_CBLK_SLOW ? du % nstrips : du / tilesC;
         dimg = strip / SHW;
         const int rem = strip - dimg * SHW, sy = rem / SW, sx = rem - sy * SW;
-        const int y0 = 4 * TSY * sy - 1, x0 = 4 * TSX * sx - 1;
+        const int y0 = M * TSY * sy - (6 - M) / 2, x0 = M * TSX * sx - (6 - M) / 2;   // the window starts R / 2 pixels before the tile
 #pragma unroll
         for (int m = 0; m < DPW; ++m) {
             const int n = wave + 8 * m, k = n % NPIECE;
@@ -125,16 +150,15 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
         const int q = n / NPIECE, g = dc * 4 + q;
         const bool s1 = g < a.Gsplit;
         const unsigned bytes = g < a.Gin ? (s1 ? a.in_bytes : a.in2_bytes) : 0u;
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s1 ? a.in : a.in2), 0, bytes, 0x00020000);
         const unsigned gg = s1 ? (unsigned)(dimg * a.Gin_tot + a.gin0 + g) : (unsigned)(dimg * a.Gin2_tot + a.gin2_0 + g - a.Gsplit);
         const unsigned voff = *reinterpret_cast<const unsigned*>(smem + DV0 + (m * 512 + t) * 4);
-        wino4s_dma16(lds0 + RAW0 + (unsigned)(((dgp - ps) & 1) * RAWBUF + q * PLANE + (n - q * NPIECE) * 1024), voff, rsrc, gg * (unsigned)HW * 16u);
+        wino4s_dma16(lds0 + RAW0 + (unsigned)(((dgp - ps) & 1) * RAWBUF + WINO4S_PLANE_OFF(q) + (n - q * NPIECE) * 1024), voff, s1 ? a.in : a.in2, bytes, gg * (unsigned)HW * 16u);
     };
     auto dma_advance = [&]() { ++dgp; if (++dc == nch) { dc = 0; ++du; if (dgp < pe) dma_unit(); } };
 
     // ---- transform role
     const int ttile = 4 * (wave & 3) + (lane >> 4), tci = lane & 15, tcg = tci >> 2;
-    const unsigned rbase = RAW0 + tcg * PLANE + (((ttile / TSX) * 4) * PC + (ttile % TSX) * 4) * 16 + (tci & 3) * 4;   // + hi * PC * 16 for the shifted taps
+    const unsigned rbase = RAW0 + WINO4S_PLANE_OFF(tcg) + (((ttile / TSX) * M) * PC + (ttile % TSX) * M) * 16 + (tci & 3) * 4;   // + hi * PC * 16 for the shifted taps
     const unsigned wbase = ttile * 64 + ((tcg ^ ((ttile >> 1) & 3)) * 4 + (tci & 3)) * 4;   // row T at + hi * 5 * 6144, row P at + 6144 + hi * 2 * 6144, row M 6144 further
     const float beta = __int_as_float(__builtin_amdgcn_readfirstlane(hi ? 0xbf800000 : 0xc0800000));    // -1 : -4
     const float gamma = __int_as_float(__builtin_amdgcn_readfirstlane(hi ? 0x40000000 : 0x3f800000));   //  2 :  1
@@ -179,7 +203,8 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
     for (int m = 0; m < DPW; ++m) dma_piece(m);
     dma_advance();
     int mu = ps / nch, mc = ps - mu * nch;                               // cursor of the multiply role: unit, chunk
-    int mcblk = mu % tilesC;                                             // channel block of unit mu
+    const int nstrips_m = nunits / tilesC;
+    int mcblk = WINO4S_CBLK_SLOW ? mu / nstrips_m : mu % tilesC;          // channel block of unit mu
     int part_c0 = mc;                                                    // first chunk of the part of unit mu this workgroup multiplies
     unsigned a_cur = abase(mcblk, mc);
     float4 af[WD];
@@ -200,7 +225,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
         const unsigned r0 = rbase + ((p + 1) & 1) * RAWBUF, rT = r0 + hi * PC * 16;      // raw buffer of phase p + 1
         const unsigned w0 = wbase + ((p + 1) & 1) * VBUF;                                 // V buffer of phase p + 1
         const bool lastc = mc + 1 == nch;
-        const int ncblk = mcblk + 1 == tilesC ? 0 : mcblk + 1;
+        const int ncblk = WINO4S_CBLK_SLOW ? (mu + 1) / nstrips_m : (mcblk + 1 == tilesC ? 0 : mcblk + 1);   // channel block of unit mu + 1
         const unsigned a_nxt = p + 1 < P ? (lastc ? abase(ncblk, 0) : abase(mcblk, mc + 1)) : a_cur;
         float4 bf0 = *reinterpret_cast<const float4*>(smem + vc);
         float4 bf1 = *reinterpret_cast<const float4*>(smem + vc + 1024);
@@ -274,28 +299,35 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
         } else {
             int le = lane; asm volatile("" : "+v"(le));                  // opaque: nothing below is loop-invariant to the compiler
             const int rtile = le & 15, kg = le >> 4;
-            const int strip = mu / tilesC;
+            const int strip = WINO4S_CBLK_SLOW ? mu % nstrips_m : mu / tilesC;
             const int img = strip / SHW, rem = strip - img * SHW, sy = rem / SW, sx = rem - sy * SW;
             const int oty = sy * TSY + rtile / TSX, otx = sx * TSX + rtile % TSX;
             const int co = mcblk * 128 + wave * 16 + 4 * kg;
             const float4 bv = a.bias ? *reinterpret_cast<const float4*>(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
             const f32x4 bb = {bv.x, bv.y, bv.z, bv.w};
-            f32x4 s[4][6];
+            f32x4 s[M][6];                                               // A^T M: M rows x 6 columns
 #pragma unroll
-            for (int j = 0; j < 6; ++j) WINO4S_AT(s[0][j], s[1][j], s[2][j], s[3][j], acc[0 * 6 + j], acc[1 * 6 + j], acc[2 * 6 + j], acc[3 * 6 + j], acc[4 * 6 + j], acc[5 * 6 + j]);
-            // partial outputs travel as [range][wave][pixel 4 i + x][lane] float4: every lane re-reads exactly what its twin wrote
+            for (int j = 0; j < 6; ++j) {
+                if constexpr (M == 4) WINO4S_AT(s[0][j], s[1][j], s[2][j], s[3][j], acc[0 * 6 + j], acc[1 * 6 + j], acc[2 * 6 + j], acc[3 * 6 + j], acc[4 * 6 + j], acc[5 * 6 + j]);
+                else WINO2S_AT(s[0][j], s[1][j], acc[0 * 6 + j], acc[1 * 6 + j], acc[2 * 6 + j], acc[3 * 6 + j], acc[4 * 6 + j], acc[5 * 6 + j]);
+            }
+            // partial outputs travel as [range][wave][pixel][lane] float4: every lane re-reads exactly what its twin wrote
             const unsigned slot_lane = (unsigned)(wave * 16 * 64 + le);
             const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(sync_slots, 0, sync_slots ? (unsigned)G * (unsigned)SLOT_BYTES : 0u, 0x00020000);
-            // Finished rows leave through LDS: a lane owns 4 channels of a 4 x 4 tile, i.e. 16-byte pieces 64 bytes apart --
-            // stored directly, a unit is 8192 partial-line writes, and with every workgroup of the chip reaching its output
-            // transform at the same time that burst costs 10-30 % of a layer (tools/wino36s_ablate.sh).  Row i of the 16
-            // tiles is transposed in a wave-private 4.25 KB corner of the V buffer the multiply role has just released
-            // ([channel group][x][tile], x pitch 272 bytes: conflict-free writes, two-way reads) so that lane = pixel:
-            // one store instruction = 64 consecutive pixels of one channel group = 1 KB (two 512-byte rows for 2 x 8 blocks).
+            // Finished rows leave through LDS: a lane owns 4 channels of an M x M tile, i.e. 16-byte pieces 16 M bytes apart --
+            // stored directly, a unit is thousands of partial-line writes, and with every workgroup of the chip reaching its
+            // output transform at the same time that burst costs 10-30 % of a layer (tools/wino36s_ablate.sh).  Four pixels per
+            // lane and step (M = 4: row `st` of the tile; M = 2: the whole tile) are transposed in a wave-private 4.25 KB
+            // corner of the V buffer the multiply role has just released ([channel group][pixel slot][tile], slot pitch 272
+            // bytes: conflict-free writes, two-way reads) so that lane = pixel: one store instruction = 64 (M = 2: 2 x 32)
+            // consecutive pixels of one channel group = 1 KB (two 512-byte rows for 2 x 8 tile blocks).
             const unsigned stg = (unsigned)((p & 1) * VBUF + wave * 4352);
-            const unsigned stw = stg + kg * 1088 + rtile * 16, str_ = stg + (le & 3) * 272 + (le >> 2) * 16;
-            const int qt = le >> 2, qty = sy * TSY + qt / TSX, qtx = sx * TSX + qt % TSX;          // lane = pixel (tile qt, column le & 3) of the row being stored
-            const int qcol = 4 * qtx + (le & 3);
+            const unsigned stw = stg + kg * 1088 + rtile * 16;
+            // reading lane = pixel: tile qt, slot qs (M = 4: column le & 3 of row st; M = 2: row le >> 5, column le & 1)
+            const int qt = M == 4 ? le >> 2 : (le & 31) >> 1, qs = M == 4 ? le & 3 : ((le >> 5) << 1) | (le & 1);
+            const unsigned str_ = stg + qs * 272 + qt * 16;
+            const int qty = sy * TSY + qt / TSX, qtx = sx * TSX + qt % TSX;
+            const int qcol = M * qtx + (M == 4 ? le & 3 : le & 1);
             const bool qok = qty < a.TH && qtx < a.TW;
             const int cow = mcblk * 128 + wave * 16;                                                // the wave's 16 output channels
             const int Cr = a.Cout >> 2, ph = UPS ? cow / Cr : 0, pa = ph >> 1, pb = ph & 1;        // UPS: virtual channels -> (phase, real channels)
@@ -304,13 +336,14 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
                                : a.out + c4_offset(img, a.Gout_tot, a.gout0 + (cow >> 2), HW, 0);
             const size_t gstride = (size_t)(UPS ? 4 * HW : HW) * 4;                                 // floats between channel groups
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                f32x4 y[4];
-                WINO4S_AT(y[0], y[1], y[2], y[3], s[i][0], s[i][1], s[i][2], s[i][3], s[i][4], s[i][5]);
+            for (int st = 0; st < M * M / 4; ++st) {
+                f32x4 y[4];                                              // the step's four pixels: (row, column) = M = 4: (st, sl); M = 2: (sl >> 1, sl & 1)
+                if constexpr (M == 4) WINO4S_AT(y[0], y[1], y[2], y[3], s[st][0], s[st][1], s[st][2], s[st][3], s[st][4], s[st][5]);
+                else { WINO2S_AT(y[0], y[1], s[0][0], s[0][1], s[0][2], s[0][3], s[0][4], s[0][5]); WINO2S_AT(y[2], y[3], s[1][0], s[1][1], s[1][2], s[1][3], s[1][4], s[1][5]); }
                 if (publish) {                                           // write-through (sc1) stores: no release fence needed before the flag
 #pragma unroll
                     for (int x = 0; x < 4; ++x)
-                        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&y[x]), srsrc, (slot_lane + (unsigned)(4 * i + x) * 64u) * 16u, (unsigned)rng * (unsigned)SLOT_BYTES, 16);
+                        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&y[x]), srsrc, (slot_lane + (unsigned)(4 * st + x) * 64u) * 16u, (unsigned)rng * (unsigned)SLOT_BYTES, 16);
                     continue;
                 }
                 for (int k = 1; k <= nsrc; ++k) {                        // fixed order: own part, then the following ranges
@@ -318,7 +351,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
                     // came back stale on MI355X (tools/wino36s_vis.sh)
 #pragma unroll
                     for (int x = 0; x < 4; ++x) {
-                        const u32x4 pv = __builtin_amdgcn_raw_buffer_load_b128(srsrc, (slot_lane + (unsigned)(4 * i + x) * 64u) * 16u, (unsigned)(rng + k) * (unsigned)SLOT_BYTES, 16);
+                        const u32x4 pv = __builtin_amdgcn_raw_buffer_load_b128(srsrc, (slot_lane + (unsigned)(4 * st + x) * 64u) * 16u, (unsigned)(rng + k) * (unsigned)SLOT_BYTES, 16);
                         y[x] += *reinterpret_cast<const f32x4*>(&pv);
                     }
                 }
@@ -327,7 +360,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
                     f32x4 v = y[x];
                     bool fin = true;
                     if constexpr (UPS) {
-                        const int oy = 2 * (4 * oty + i) + pa, ox = 2 * (4 * otx + x) + pb;
+                        const int oy = 2 * (4 * oty + st) + pa, ox = 2 * (4 * otx + x) + pb;
                         fin = !(a.ring && ((oy == 0) | (oy == Ho - 1) | (ox == 0) | (ox == Wo - 1)));   // ring pixels are finished by the ring kernel
                     }
                     if (fin) {
@@ -336,13 +369,13 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
                     }
                     *reinterpret_cast<f32x4*>(smem + stw + x * 272) = v;
                 }
-                const int qrow = 4 * qty + i;
-                const bool st = qok && qrow < a.H && qcol < a.W;
+                const int qrow = M * qty + (M == 4 ? st : le >> 5);
+                const bool stv = qok && qrow < a.H && qcol < a.W;
                 float* orow = UPS ? obase + (size_t)((2 * qrow + pa) * Wo + 2 * qcol + pb) * 4 : obase + (size_t)(qrow * a.W + qcol) * 4;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {                            // LDS operations of one wave complete in order: no wait between the writes above and these reads
                     const f32x4 v = *reinterpret_cast<const f32x4*>(smem + str_ + g * 1088);
-                    if (st) *reinterpret_cast<f32x4*>(orow + g * gstride) = v;
+                    if (stv) *reinterpret_cast<f32x4*>(orow + g * gstride) = v;
                 }
             }
             if (publish) {                                               // every storing wave drains its stores, then ONE lane raises the flag
@@ -381,7 +414,7 @@ static constexpr size_t kSyncFlagBytes = 4096, kSyncSlotBytes = 8 * 16 * 64 * 16
 extern "C" size_t cnm_wino36_sync_floats(void) { return (kSyncFlagBytes + (size_t)wino4s_cus() * kSyncSlotBytes) / 4; }
 
 int cnm_wino36s_try_launch(const Wino4Args& a, int M, int ups, hipStream_t stream) {
-    if (!g_wino36_staged || M != 4 || a.Cout % 128) return 1;
+    if (!g_wino36_staged || (M != 4 && M != 2) || (ups && M != 4) || a.Cout % 128) return 1;
     int tsx = 0;
     if (a.TW >= 12) tsx = 16; else if (a.TW >= 6 && a.TH >= 2) tsx = 8;
     if (!tsx) return 1;
@@ -406,7 +439,7 @@ int cnm_wino36s_try_launch(const Wino4Args& a, int M, int ups, hipStream_t strea
         return 1;
     }
 #ifdef WINO4S_ABLATE
-    if (g_wino36s_ablate && tsx == 16 && !ups) {
+    if (g_wino36s_ablate && tsx == 16 && !ups && M == 4) {
         switch (g_wino36s_ablate) {
 #define WINO4S_CASE(n) case n: conv_winograd36s_f32_kernel<16, false, n><<<grid, 512, 0, stream>>>(a, SH, SW, tilesC, (int)nunits, flags, slots); break;
             WINO4S_CASE(1) WINO4S_CASE(2) WINO4S_CASE(3) WINO4S_CASE(4) WINO4S_CASE(7) WINO4S_CASE(8) WINO4S_CASE(15) WINO4S_CASE(16) WINO4S_CASE(18) WINO4S_CASE(32) WINO4S_CASE(64)
@@ -416,7 +449,10 @@ int cnm_wino36s_try_launch(const Wino4Args& a, int M, int ups, hipStream_t strea
         return CNM_OK;
     }
 #endif
-    if (tsx == 16) {
+    if (M == 2) {
+        if (tsx == 16) conv_winograd36s_f32_kernel<16, false, 0, 2><<<grid, 512, 0, stream>>>(a, SH, SW, tilesC, (int)nunits, flags, slots);
+        else conv_winograd36s_f32_kernel<8, false, 0, 2><<<grid, 512, 0, stream>>>(a, SH, SW, tilesC, (int)nunits, flags, slots);
+    } else if (tsx == 16) {
         if (ups) conv_winograd36s_f32_kernel<16, true><<<grid, 512, 0, stream>>>(a, SH, SW, tilesC, (int)nunits, flags, slots);
         else conv_winograd36s_f32_kernel<16, false><<<grid, 512, 0, stream>>>(a, SH, SW, tilesC, (int)nunits, flags, slots);
     } else {

@@ -286,10 +286,10 @@ def conv3x3_winograd4_c4(x, u_packed, b_packed, Cout, relu=True, x2=None, ksize=
     G2 = x2.shape[1] if x2 is not None else 0
     lib = _lib.load()
     with torch.cuda.device(x.device):
-        if sync is not None and ksize == 3:
-            _lib.check(lib.cnm_conv3x3_winograd4_sync_c4_f32(_p(x), G, 0, G, _p(x2) if x2 is not None else None, G2, 0, G2,
-                                                             _p(out), Cout // 4, 0, Cout, _p(u_packed), _p(b_packed),
-                                                             N, H, W, int(relu), _p(sync), sync.numel(), _stream()))
+        if sync is not None:
+            fn = lib.cnm_conv3x3_winograd4_sync_c4_f32 if ksize == 3 else lib.cnm_conv5x5_winograd_sync_c4_f32
+            _lib.check(fn(_p(x), G, 0, G, _p(x2) if x2 is not None else None, G2, 0, G2,
+                          _p(out), Cout // 4, 0, Cout, _p(u_packed), _p(b_packed), N, H, W, int(relu), _p(sync), sync.numel(), _stream()))
         else:
             fn = lib.cnm_conv3x3_winograd4_c4_f32 if ksize == 3 else lib.cnm_conv5x5_winograd_c4_f32
             _lib.check(fn(_p(x), G, 0, G, _p(x2) if x2 is not None else None, G2, 0, G2,

@@ -198,6 +198,13 @@ int cnm_conv5x5_winograd_c4_f32(const float* in_a, int Ga_total, int ga0, int Ga
                                 float* out, int Gout_total, int gout0, int Cout,
                                 const float* u_packed, const float* b_packed,
                                 int N, int H, int W, int relu, void* stream);
+/* ... with the sync workspace of cnm_conv3x3_winograd4_sync_c4_f32 (same contract): the LDS-staged persistent kernel with
+ * 2 x 2 output tiles. */
+int cnm_conv5x5_winograd_sync_c4_f32(const float* in_a, int Ga_total, int ga0, int Ga,
+                                     const float* in_b, int Gb_total, int gb0, int Gb,
+                                     float* out, int Gout_total, int gout0, int Cout,
+                                     const float* u_packed, const float* b_packed,
+                                     int N, int H, int W, int relu, float* sync_ws, size_t sync_floats, void* stream);
 
 /* nn.Upsample(scale_factor=2, mode='bilinear') followed by Conv2d(3x3, pad 1) + folded BatchNorm + ReLU -- the
  * reference's up_conv_layer (depthNet_model.py:89-112) -- as ONE pass over the LOW-resolution input: upsample-then-3x3

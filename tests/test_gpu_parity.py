@@ -345,16 +345,56 @@ def test_conv3x3_winograd4_staged(dev, ops, cin, cin2, cout, rot, N, H, W):
     xr = torch.cat((x[:, rot:], x[:, :rot]), 1) if rot else x
     xc = ops.nchw_to_c4(xr.to(dev)); x2c = ops.nchw_to_c4(x2.to(dev)) if cin2 else None
     outs = []
+    sync = ops.wino36_sync_workspace(dev)
     old = lib.cnm_tune_wino36_staged(-1)
     try:
-        for mode in (0, 2):
+        for mode, sy in ((0, None), (2, None), (2, sync), (2, sync)):      # gather-fed, staged with unit-aligned ranges, staged with ranges that cut units (twice)
             lib.cnm_tune_wino36_staged(mode)
-            outs.append(ops.conv3x3_winograd4_c4(xc, up, bp, cout, True, x2=x2c).clone())
+            outs.append(ops.conv3x3_winograd4_c4(xc, up, bp, cout, True, x2=x2c, sync=sy).clone())
     finally:
         lib.cnm_tune_wino36_staged(old)
     got = ops.c4_to_nchw(outs[1], cout).cpu().numpy()
     assert np.abs(got - want).max() < 2e-4 * max(np.abs(want).max(), 1.0), np.abs(got - want).max()
     assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
+    # with the sync workspace a unit cut by a range boundary is the sum of its parts' output transforms, added in range
+    # order: bit-reproducible, within the same bar of the fp64 convolution, every flag word lowered again
+    got = ops.c4_to_nchw(outs[2], cout).cpu().numpy()
+    assert np.abs(got - want).max() < 2e-4 * max(np.abs(want).max(), 1.0), np.abs(got - want).max()
+    assert torch.equal(outs[2], outs[3]) and float(sync[:1024].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("cin,cout,rot,N,H,W", [(64, 128, 0, 2, 40, 48), (35, 256, 3, 1, 9, 29), (128, 256, 0, 3, 24, 32), (16, 128, 0, 1, 96, 128)])
+def test_conv5x5_winograd_staged(dev, ops, cin, cout, rot, N, H, W):
+    """F(2x2,5x5) on the LDS-staged persistent kernel (2 x 2 output tiles, 6 x 36 / 8 x 20 input patches): bit-equal to the
+    gather-fed 36-point kernel with unit-aligned ranges; with the sync workspace (phase ranges that cut units, partial outputs
+    added in a fixed order) reproducible from run to run and within the kernel's per-layer bar of the fp64 convolution."""
+    from cnmnet_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(cin * 7 + H + cout)
+    x = T(rng.standard_normal((N, cin, H, W)).astype(np.float32))
+    w = T((rng.standard_normal((cout, cin, 5, 5)) * (2.0 / (cin * 25)) ** 0.5).astype(np.float32))
+    bnp = [T(a.astype(np.float32)) for a in (rng.uniform(0.5, 1.5, cout), rng.normal(0, 0.2, cout), rng.normal(0, 0.2, cout), rng.uniform(0.5, 1.5, cout))]
+    sc = bnp[0].double() / torch.sqrt(bnp[3].double() + 1e-5)
+    want = F.relu(F.conv2d(x.double(), w.double(), padding=2) * sc[None, :, None, None] + (bnp[1].double() - bnp[2].double() * sc)[None, :, None, None]).numpy()
+    bnd = tuple(t.to(dev) for t in bnp)
+    _, bp = ops.pack_conv(w.to(dev), bnd, rot=rot)
+    up = ops.pack_winograd4(w.to(dev), bnd, rot=rot)
+    xr = torch.cat((x[:, rot:], x[:, :rot]), 1) if rot else x
+    xc = ops.nchw_to_c4(xr.to(dev))
+    sync = ops.wino36_sync_workspace(dev)
+    old = lib.cnm_tune_wino36_staged(-1)
+    try:
+        outs = []
+        for mode, sy in ((0, None), (2, None), (2, sync), (2, sync)):
+            lib.cnm_tune_wino36_staged(mode)
+            outs.append(ops.conv3x3_winograd4_c4(xc, up, bp, cout, True, ksize=5, sync=sy).clone())
+    finally:
+        lib.cnm_tune_wino36_staged(old)
+    assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
+    assert torch.equal(outs[2], outs[3]) and float(sync[:1024].abs().max()) == 0.0          # reproducible; flag words re-armed
+    for o in (outs[1], outs[2]):
+        got = ops.c4_to_nchw(o, cout).cpu().numpy()
+        assert np.abs(got - want).max() < 2e-4 * max(np.abs(want).max(), 1.0), np.abs(got - want).max()
 
 
 @pytest.mark.parametrize("cin,cout,N,H,W", [(128, 64, 2, 48, 64), (256, 128, 1, 24, 32), (64, 64, 2, 20, 36)])

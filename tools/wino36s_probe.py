@@ -56,6 +56,16 @@ def check():
             o0, o1, o2, o3 = both(lambda sy: ops.conv3x3_upsampled_winograd4_c4(x, uu, bu, Cout, True, ring, sync=sy))
             eq = torch.equal(o0, o1); rep = torch.equal(o2, o3); d2 = (o0 - o2).abs().max().item(); bad += (not eq) or (not rep) or d2 > 1e-3
             print("upconv N%d %4d->%4d %3dx%-3d ring=%d  aligned==gather %s   split: reproducible %s  |split-gather|=%.2e" % (N, Cin, Cout, H, W, ring is not None, eq, rep, d2), flush=True)
+    for N, Cin, Cout, H, W in [(2, 64, 128, 40, 48), (1, 35, 256, 9, 29), (3, 128, 256, 24, 32), (1, 16, 128, 96, 128)]:     # F(2x2,5x5)
+        x = ops.nchw_to_c4(torch.randn(N, Cin, H, W, device=dev))
+        w = torch.randn(Cout, Cin, 5, 5, device=dev) * 0.03
+        up = ops.pack_winograd4(w); bp = torch.randn(Cout, device=dev)
+        o0, o1, o2, o3 = both(lambda sy: ops.conv3x3_winograd4_c4(x, up, bp, Cout, True, ksize=5, sync=sy))
+        ref = torch.relu(torch.nn.functional.conv2d(ops.c4_to_nchw(x, 4 * ((Cin + 3) // 4))[:, :Cin].double(), w.double(), bp.double(), padding=2)).float()
+        err = (ops.c4_to_nchw(o1, Cout) - ref).abs().max().item(); err2 = (ops.c4_to_nchw(o2, Cout) - ref).abs().max().item()
+        eq = torch.equal(o0, o1); rep = torch.equal(o2, o3)
+        bad += (not eq) or (not rep) or err > 2e-3 or err2 > 2e-3
+        print("5x5    N%d %4d->%4d %3dx%-3d  aligned==gather %s  |aligned-torch64|=%.2e   split: reproducible %s  |split-torch64|=%.2e" % (N, Cin, Cout, H, W, eq, err, rep, err2), flush=True)
     print("CHECK", "FAILED" if bad else "OK", flush=True)
     return bad
 
@@ -106,6 +116,18 @@ def time_layers():
         for i in range(3): tot[i] += ms[i] * mult
         print("%-24s %4d->%4d %3dx%-3d N%2d: gather %.3f ms | staged aligned %.3f ms x%.2f | staged split %.3f ms %5.1f TF x%.2f   (with ring pass)" % (
             name, Cin, Cout, H, W, N, ms[0], ms[1], ms[0] / ms[1], ms[2], gf / ms[2] / 4, ms[0] / ms[2]), flush=True)
+    for name, N, Cin, Cout, H, W in [("depth conv2.0 5x5", 16, 128, 256, 96, 128)]:
+        x = ops.nchw_to_c4(torch.randn(N, Cin, H, W, device=dev)); up = ops.pack_winograd4(torch.randn(Cout, Cin, 5, 5, device=dev) * 0.02); bp = torch.zeros(Cout, device=dev)
+        ms = []
+        for rnd in range(2):
+            for on, sy in ((0, None), (2, None), (2, SYNC)):
+                lib.cnm_tune_wino36_staged(on)
+                m = ev(lambda: ops.conv3x3_winograd4_c4(x, up, bp, Cout, True, ksize=5, sync=sy))
+                if rnd: ms.append(m)
+        gf = 2.0 * Cout * Cin * 25 * H * W * N / 1e9
+        for i in range(3): tot[i] += ms[i]
+        print("%-24s %4d->%4d %3dx%-3d N%2d: gather %.3f ms (%.2f) | staged aligned %.3f ms x%.2f | staged split %.3f ms %5.1f TF (%.2f) x%.2f" % (
+            name, Cin, Cout, H, W, N, ms[0], gf * 0.36 / ms[0] / 157.3, ms[1], ms[0] / ms[1], ms[2], gf * 0.36 / ms[2], gf * 0.36 / ms[2] / 157.3, ms[0] / ms[2]), flush=True)
     lib.cnm_tune_wino36_staged(1)
     print("sum over a step's launches: gather %.3f ms, staged aligned %.3f ms, staged split %.3f ms" % tuple(tot), flush=True)
 
