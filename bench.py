@@ -140,9 +140,9 @@ def wino36_kernel(cout, h, w, ups=False):
     with `cout` (virtual, for a fused up_conv: 4 x real) output channels on an h x w (low-resolution, for up_conv) image."""
     th, tw = -(-h // 4), -(-w // 4)
     if cout % 128 == 0 and tw >= 12:
-        return "conv_winograd36s_f32_kernel<16, %s, 0>" % ("true" if ups else "false")
+        return "conv_winograd36s_f32_kernel<16, %s, 0, 4>" % ("true" if ups else "false")
     if cout % 128 == 0 and tw >= 6 and th >= 2:
-        return "conv_winograd36s_f32_kernel<8, %s, 0>" % ("true" if ups else "false")
+        return "conv_winograd36s_f32_kernel<8, %s, 0, 4>" % ("true" if ups else "false")
     return "conv_winograd36_f32_kernel<4, 3, %s>" % ("true" if ups else "false")
 
 
@@ -155,7 +155,8 @@ def conv_kernel(L, m, m4=0, h=0, w=0):
             return wino36_kernel(L["Cout"], h, w), 36.0 / 144.0      # F(4x4,3x3): 36 multiplies per 16 outputs instead of 144
         return "conv3x3_winograd_f32_kernel", 16.0 / 36.0            # F(2x2,3x3): 16 multiplies per 4 outputs instead of 36
     if k == 5 and s == 1 and L["Cout"] // 64 * -(-(m // 4) // 16) >= WINO4_MIN_WORKGROUPS:
-        return "conv_winograd36_f32_kernel<2, 5, false>", 36.0 / 100.0          # F(2x2,5x5): 36 multiplies per 4 outputs instead of 100
+        staged = L["Cout"] % 128 == 0 and -(-w // 2) >= 12                         # cnm_wino36s_try_launch with 2 x 2 output tiles
+        return ("conv_winograd36s_f32_kernel<16, false, 0, 2>" if staged else "conv_winograd36_f32_kernel<2, 5, false>"), 36.0 / 100.0   # F(2x2,5x5): 36 multiplies per 4 outputs instead of 100
     if k in (5, 7):                                                  # F(2,k) along rows; stride 2: two F(2,ceil(k/2)) column phases
         if k == 7 and s == 1:
             return "conv_rows_winograd_f32_kernel<7, 1, 4>", 10.0 / 28.0      # F(4,7): 10 multiplies per 4 outputs and kernel row instead of 28
@@ -282,6 +283,65 @@ def kernel_rooflines(dev, frames):
                      "launch stream and followed by its consumer (conv1.0) as in the step; burst_avg_launch_ms: 50 launches back to back "
                      "(sustained, clock-throttled state)" % n_it}
     return conv, sweep
+
+
+MFMA_F16_PEAK_TF = 2500.0      # MI355X_MICROARCH.md: dense f16 / bf16 MFMA (AMD's 5 PF figure includes 2:1 sparsity)
+
+
+def glds_tile(cout, m, nk, stride):
+    """Mirror of launch_glds (cnmnet_amd/csrc/conv_mfma.hip): the tile instance of the fp16 LDS-DMA kernel for a layer with `cout`
+    output channels, m output pixels and nk k-steps of 64 halfs."""
+    cp = -(-cout // 64) * 64
+    wgs = lambda tc, tp: (cp // tc) * -(-m // tp)
+    c128, c256 = cp % 128 == 0, cp % 256 == 0
+    big = wgs(128, 256) if c128 else wgs(64, 512)
+    v = 3 if (big < 160 or (not c128 and nk <= 12)) else (1 if c128 else 2)
+    if v == 1:
+        cost = lambda tc, tp, work, eff: -(-wgs(tc, tp) // 256) * work / eff
+        best = cost(128, 256, 1.0, 1.0)
+        if c256 and cost(256, 256, 2.0, 1.2) < best:
+            best, v = cost(256, 256, 2.0, 1.2), 5
+        if stride == 1 and cost(128, 512, 2.0, 1.12) < best:
+            v = 4
+    return {1: "128, 256, 64, 64", 2: "64, 512, 64, 64", 3: "64, 128, 32, 32", 4: "128, 512, 64, 128", 5: "256, 256, 128, 64"}[v]
+
+
+def f16_roofline(dev, frames):
+    """The fp16 engine's convolution layers (conv_glds_kernel, LDS-DMA implicit GEMM on v_mfma_f32_32x32x16_f16) at the shapes
+    of a step, each timed alone with HIP events: executed TFLOP/s of the instance that owns most of the time against the
+    2.5 PF dense f16 MFMA peak (compare with conv_glds_kernel rows of profiles/r3_f16_kernel_stats.csv)."""
+    from cnmnet_amd import _lib, ops
+    per, IT, WARM = {}, 20, 3
+    for net, n_img, levels in ((_lib.NET_DEPTH, frames * SRC, DEPTH_LEVEL), (_lib.NET_REFINE, frames, REFINE_LEVEL)):
+        layers = [L for L in _lib.net_layers(net) if not L["is_head"]]
+        for L, lv in zip(layers, levels):
+            cin = 3 + PLANES if (net == _lib.NET_DEPTH and L["conv_key"] == "conv1.0") else L["Cin"]
+            h, w = H >> lv, W >> lv
+            k, st = L["ksize"], L["stride"]
+            ho, wo = h // st, w // st
+            wt = torch.randn(L["Cout"], cin, k, k, device=dev) * 0.02
+            flop = 2.0 * L["Cout"] * cin * k * k * ho * wo * n_img
+            g8 = (cin + 7) // 8
+            if L["conv_key"].startswith("upconv") and cin <= 256 and n_img * ho * wo >= UPSAMPLED_MIN_PIXELS:
+                xl = ops.nchw_to_c8(torch.randn(n_img, cin, h // 2, w // 2, device=dev))
+                wp, bp, wr = ops.pack_upsampled_f16(wt)
+                ms = event_ms(lambda: ops.conv3x3_upsampled_c8(xl, wp, bp, L["Cout"], True, wr), iters=IT, warm=WARM)
+                name = "conv_glds_kernel<%s, true> + ring" % glds_tile(4 * L["Cout"], n_img * (h // 2) * (w // 2), (9 * 8 * g8 + 63) // 64, 1)
+            else:
+                x = ops.nchw_to_c8(torch.randn(n_img, cin, h, w, device=dev))
+                wp, bp = ops.pack_conv_f16(wt)
+                ms = event_ms(lambda: ops.conv2d_c8(x, wp, bp, L["Cout"], k, st, True), iters=IT, warm=WARM)
+                name = "conv_glds_kernel<%s, false>" % glds_tile(L["Cout"], n_img * ho * wo, (k * k * 8 * g8 + 63) // 64, st)
+            e = per.setdefault(name, [0.0, 0.0, 0])
+            e[0] += flop; e[1] += ms; e[2] += 1
+    name, (flop, ms, n) = max(per.items(), key=lambda kv: kv[1][1])
+    tot_f, tot_ms = sum(v[0] for v in per.values()), sum(v[1] for v in per.values())
+    return {"kernel": name, "bound": "mfma", "achieved": flop / ms / 1e9, "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s", "frac": flop / ms / 1e9 / MFMA_F16_PEAK_TF,
+            "traffic": None, "launches_per_step": n, "avg_launch_ms": ms / n,
+            "all_conv": {"achieved": tot_f / tot_ms / 1e9, "frac": tot_f / tot_ms / 1e9 / MFMA_F16_PEAK_TF, "sum_of_isolated_layer_ms": tot_ms,
+                         "per_kernel_ms": {k: round(v[1], 3) for k, v in sorted(per.items(), key=lambda kv: -kv[1][1])}},
+            "note": "implicit GEMM: executed = direct-convolution flops; every layer alone, %d launches after %d warm-up; the package runs at its "
+                    "1400 W limit under this kernel (profiles/r2_clock_power.txt), so the 2.4 GHz peak is not reachable in a sustained loop" % (IT, WARM)}
 
 
 def host_cpu_quota():
@@ -614,6 +674,8 @@ def main():
             torch.cuda.empty_cache()
             line["f16"] = dict(secondary(dev, "f16", B, SRC, H, W, PLANES, steps=30, warmup=5), dtype="f16 storage / f32 accumulate",
                                tolerance="vs the fp32 engine at this size: inverse depth within 2e-2 (depthNet) / 5e-2 (refined) max, 1e-3 mean, on a [0,3] range; probability within 5e-2 max (tests/test_gpu_baseline_sizes.py)")
+            torch.cuda.empty_cache()
+            line["roofline_f16"] = f16_roofline(dev, B)
             torch.cuda.empty_cache()
             line["config4"] = dict(secondary(dev, "f32", 4, 4, 480, 640, 96, steps=5, warmup=2), dtype="f32",
                                    note="BASELINE configs[3]; plane sweep = 125.3 MB algorithmic per (ref, src) pair")

@@ -21,10 +21,21 @@ def _winograd_ok(k, stride, cout):
     return WINOGRAD and cout % 64 == 0 and ((stride == 1 and k == 3) or (stride in (1, 2) and k in (5, 7)))
 
 
+_SYNC = {}      # (device, stream) -> sync workspace of the LDS-staged F(4x4,3x3) kernel: launches on one stream are ordered, so one per stream is enough
+
+
+def _sync_workspace(device):
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    ws = _SYNC.get(key)
+    if ws is None:                                                       # inside a graph capture this allocates from the graph's pool; the zero fill is replayed with it
+        ws = _SYNC[key] = ops.wino36_sync_workspace(device)
+    return ws
+
+
 def _winograd_conv(x, weight, rot, stride=1):
     Cout, _, k, _ = weight.shape
     if k == 3 and _winograd4_fills_chip(x, Cout):                        # large layers: F(4x4,3x3)
-        return ops.conv3x3_winograd4_c4(x, ops.pack_winograd4(weight, None, rot), None, Cout, relu=False)
+        return ops.conv3x3_winograd4_c4(x, ops.pack_winograd4(weight, None, rot), None, Cout, relu=False, sync=_sync_workspace(x.device))
     up = ops.pack_winograd(weight, None, rot, stride=stride, tile=2)    # training keeps the more accurate F(2,k) rows
     if k == 3:
         return ops.conv3x3_winograd_c4(x, up, None, Cout, relu=False)

@@ -452,9 +452,13 @@ extern "C" int cnm_pack_conv_bn_f32(const float* w_oihw, const float* bn_gamma, 
 // when rounds-of-256-workgroups x tile work / measured efficiency (1.2 and 1.12 against 1.0: fewer operand bytes and
 // fragment reads per MFMA) comes out lower -- i.e. when the larger tile does not end in a mostly empty last round.
 // g_glds_tile != 0 forces a tile (tests, probes): 1 128x256, 2 64x512, 3 64x128, 4 128x512, 5 256x256.
-static int lds_per_block() {                                            // bytes of LDS one workgroup may use on the current device
+static int lds_per_block() {                                            // bytes of LDS one workgroup may use on the current device (queried once per device)
+    static int cache[64] = {0};
     int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (dev >= 0 && dev < 64 && cache[dev]) return cache[dev];
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (dev >= 0 && dev < 64) cache[dev] = v;
     return v;
 }
 static int g_glds_tile = 0;
@@ -465,17 +469,22 @@ static void launch_glds(const ConvArgs& a, hipStream_t s) {
     const bool c128 = a.Cout_pad % 128 == 0, c256 = a.Cout_pad % 256 == 0;
     const long long big = c128 ? wgs(128, 256) : wgs(64, 512);
     int v = g_glds_tile;
+    const int lds = lds_per_block();                                    // static LDS of the tiles: 128x512 160 KB, 128x256 / 64x512 144 KB, 256x256 128 KB, 64x128 72 KB
     if (v == 0) {
         v = (big < 160 || (!c128 && a.nk <= 12)) ? 3 : c128 ? 1 : 2;
         if (v == 1) {
             auto cost = [&](int tc, int tp, double work, double eff) { return (double)((wgs(tc, tp) + 255) / 256) * work / eff; };
             double best = cost(128, 256, 1.0, 1.0);
             if (c256 && cost(256, 256, 2.0, 1.2) < best) { best = cost(256, 256, 2.0, 1.2); v = 5; }
-            if (a.stride == 1 && lds_per_block() >= 160 * 1024 && cost(128, 512, 2.0, 1.12) < best) v = 4;   // that tile takes all 160 KB
+            if (a.stride == 1 && lds >= 160 * 1024 && cost(128, 512, 2.0, 1.12) < best) v = 4;   // that tile takes all 160 KB
         }
     }
     if (!c128 && (v == 1 || v == 4 || v == 5)) v = 2;
     if (v == 5 && !c256) v = 1;
+    // a device (or partition) with less LDS per workgroup: every choice, forced ones included, falls back to a tile that fits
+    if (v == 4 && lds < 160 * 1024) v = 1;
+    if ((v == 1 || v == 2) && lds < 144 * 1024) v = (c256 && lds >= 128 * 1024) ? 5 : 3;
+    if (v == 5 && lds < 128 * 1024) v = 3;
     if (v == 1) conv_glds_kernel<128, 256, 64, 64, UPS><<<(unsigned)wgs(128, 256), 512, 0, s>>>(a);
     else if (v == 2) conv_glds_kernel<64, 512, 64, 64, UPS><<<(unsigned)wgs(64, 512), 512, 0, s>>>(a);
     else if (v == 3) conv_glds_kernel<64, 128, 32, 32, UPS><<<(unsigned)wgs(64, 128), 512, 0, s>>>(a);

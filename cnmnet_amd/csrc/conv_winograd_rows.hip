@@ -134,21 +134,28 @@ struct RowArgs {
     int nchunks, T, relu;                // T = N*Ho*TW tiles
 };
 
-template <int R, int S, int M>
-__global__ __launch_bounds__(256, 2) void conv_rows_winograd_f32_kernel(const RowArgs a) {
+// NW = 4: workgroup = 4 waves = 64 couts, two workgroups per CU.  NW = 8: 8 waves = 128 couts over the SAME transformed
+// tiles, one workgroup per CU: waves 0-3 gather and transform exactly as before (one channel quad each), waves 4-7 only
+// multiply -- the transform's VALU work, which comes out of the fp32 matrix pipe's time (profiles/r1_mfma_valu_probes.txt,
+// 18 % of the kernel in profiles/r2_conv_pmc.txt), and the window gathers are shared by twice the MFMAs, and every SIMD
+// still hosts one transforming and one multiplying wave.
+template <int R, int S, int M, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 2) void conv_rows_winograd_f32_kernel(const RowArgs a) {
     using CF = RowCfg<R, S, M>;
     using WM = RowWino<CF::ID>;
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves");
     constexpr int NX = CF::NX, NB = CF::NB, TT = 16 * NB, NG = (NX + 1) / 2;
     constexpr int VBUF = NX * TT * 16;                                   // V[buf][xi][tile][16 k], slots XOR-swizzled with ((tile >> 1) & 3): conflict-free for the four non-contiguous 16-lane groups of ds_read_b128 and for the writes
     __shared__ __attribute__((aligned(16))) float V[2 * VBUF];           // 64 KB (R = 7) / 48 KB (R = 5) / less for stride 2
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int tilesC = a.Cout / 64;
+    const int tilesC = a.Cout / (16 * NW);
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int cblk = tile % tilesC, t0 = (tile / tilesC) * TT;
     const int HW = a.H * a.W, HWo = a.Ho * a.Wo, THW = a.Ho * a.TW;
+    const bool loader = NW == 4 || wave < 4;                             // wave-uniform
 
     // ---- loader: thread = (tile tl, channel quad qd = wave of the chunk)
-    const int tl = lane, qd = wave;
+    const int tl = lane, qd = wave & 3;
     const int tg = t0 + tl;
     const bool tvalid = (tl < TT) & (tg < a.T);                         // TT = 48: the last 16 lanes of a wave carry no tile
     int img, py, ptx;
@@ -256,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void conv_rows_winograd_f32_kernel(const Ro
         for (int b = 0; b < NB; ++b) acc[x][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // weights in MFMA operand order: [chunk][cout/16][xi][lane][4], lane (i = l&15, kg = l>>4) = U[xi][co 16cb+i][k 16chunk+4kg+e]
-    const int cb16 = cblk * 4 + wave, ncb16 = a.Cout / 16;
+    const int cb16 = cblk * NW + wave, ncb16 = a.Cout / 16;
     const float4* ubase = reinterpret_cast<const float4*>(a.u) + lane + (size_t)cb16 * NX * 64;
     const size_t ustride = (size_t)ncb16 * NX * 64;                      // float4 per chunk
     const int rtile = lane & 15, kg = lane >> 4;
@@ -266,14 +273,16 @@ __global__ __launch_bounds__(256, 2) void conv_rows_winograd_f32_kernel(const Ro
     float4 af[WD];
 #pragma unroll
     for (int x = 0; x < WD; ++x) af[x] = ubase[(size_t)x * 64];
-    gather_begin();                                                      // chunk 0
+    if (loader) {
+        gather_begin();                                                  // chunk 0
 #pragma unroll
-    for (int j = 0; j < NX; ++j) gather_load(j);
+        for (int j = 0; j < NX; ++j) gather_load(j);
 #pragma unroll
-    for (int grp = 0; grp < NG; ++grp) transform_group(grp, V);
-    gather_begin();                                                      // chunk 1
+        for (int grp = 0; grp < NG; ++grp) transform_group(grp, V);
+        gather_begin();                                                  // chunk 1
 #pragma unroll
-    for (int j = 0; j < NX; ++j) gather_load(j);
+        for (int j = 0; j < NX; ++j) gather_load(j);
+    }
     lds_barrier();
     for (int c = 0; c < a.nchunks; ++c) {
         const float* Vc = V + (c & 1) * VBUF;
@@ -299,12 +308,14 @@ __global__ __launch_bounds__(256, 2) void conv_rows_winograd_f32_kernel(const Ro
             af[x % WD] = x + WD < NX ? uc[(size_t)(x + WD) * 64] : un[(size_t)(x + WD - NX) * 64];   // WD steps ahead (wraps into the next chunk)
             // between the MFMAs: one transform group of chunk c+1 per step, then (registers free) the windows of chunk
             // c+2, two loads per step (past the last chunk all out of range = 0, written to the idle buffer)
-            if (x < NG) transform_group(x, Vn);
-            if (x >= NG) {                            // LPS loads per step, spread over the steps after the transform
-                constexpr int LPS = (NX + (NX - NG) - 1) / (NX - NG);
-                if (x == NG) gather_begin();
+            if (loader) {
+                if (x < NG) transform_group(x, Vn);
+                if (x >= NG) {                        // LPS loads per step, spread over the steps after the transform
+                    constexpr int LPS = (NX + (NX - NG) - 1) / (NX - NG);
+                    if (x == NG) gather_begin();
 #pragma unroll
-                for (int l = LPS * (x - NG); l < LPS * (x - NG + 1) && l < NX; ++l) gather_load(l);
+                    for (int l = LPS * (x - NG); l < LPS * (x - NG + 1) && l < NX; ++l) gather_load(l);
+                }
             }
 #pragma unroll
             for (int b = 0; b < NB; ++b) acc[x][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw.y, bw[b].y, acc[x][b], 0, 0, 0);
@@ -318,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void conv_rows_winograd_f32_kernel(const Ro
     }
 
     // ---- epilogue: y_i = sum_k AT[i][k] M_k, i < M; acc row = cout 4*(lane>>4)+r (one c4 group), col = tile lane&15 (+16 tb)
-    const int co = cblk * 64 + wave * 16 + 4 * kg;
+    const int co = cblk * 16 * NW + wave * 16 + 4 * kg;
     const float4 bias = a.bias ? *reinterpret_cast<const float4*>(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
     const float bb[4] = {bias.x, bias.y, bias.z, bias.w};
 #pragma unroll
@@ -382,6 +393,9 @@ __global__ void pack_rows_winograd_kernel(const float* __restrict__ w, const flo
     up[idx] = v;
 }
 
+static int g_rows_wide = 1;                                              // 0: 64-cout workgroups only, 1: 128-cout workgroups where they fill whole rounds, 2: wherever Cout % 128 == 0
+extern "C" int cnm_tune_rows_wide(int on) { const int old = g_rows_wide; if (on >= 0 && on <= 2) g_rows_wide = on; return old; }
+
 static int rows_chunks(int Cin, int ksize, int stride) { return (ksize * stride * ((Cin + 3) / 4) + 3) / 4; }
 static bool rows_ksize_ok(int ksize, int stride, int tile) { return ksize == 5 || ksize == 7 || (ksize == 3 && stride == 2 && tile == 4); }   // 3x3: stride 2 only (stride 1 has the 2-D kernels)
 static bool rows_tile_ok(int ksize, int stride, int tile) { return tile == 2 || (tile == 4 && !(ksize == 5 && stride == 1)); }   // 4 outputs per tile: F(4,7), and the stride-2 phases F(4,4) / F(4,3)
@@ -430,8 +444,25 @@ extern "C" int cnm_conv_rows_winograd_c4_f32(const float* in_a, int Ga_total, in
     a.Gin_tot = Ga_total; a.gin0 = ga0; a.Gin2_tot = Gb ? Gb_total : Ga_total; a.gin2_0 = Gb ? gb0 : ga0; a.Gsplit = Ga; a.Gin = Ga + Gb;
     a.Gout_tot = Gout_total; a.gout0 = gout0; a.Cout = Cout;
     a.nchunks = (ksize * stride * a.Gin + 3) / 4; a.T = N * a.Ho * a.TW; a.relu = relu;
-    const int nblocks = (Cout / 64) * cnm_ceil_div(a.T, ((ksize == 7 && stride == 1 && m == 4) || ksize == 3) ? 48 : 64);
+    const int ntb = cnm_ceil_div(a.T, ((ksize == 7 && stride == 1 && m == 4) || ksize == 3) ? 48 : 64);
+    const int nblocks = (Cout / 64) * ntb;
     hipStream_t st = cnm_stream(stream);
+    if (g_rows_wide && m == 4 && Cout % 128 == 0) {
+        // 128 couts per workgroup, one workgroup per CU (rounds of 256): taken unless the last round would be mostly empty
+        const long long nb8 = (long long)(Cout / 128) * ntb;
+        const double waste = (double)((nb8 + 255) / 256) * 256.0 / (double)nb8;
+        // measured (tools/rows_wide_probe.py, 16 pairs at 192x256): 7x7 stride 2 1.07x; 7x7 stride 1 0.99x, 3x3 stride 2 0.91-0.98x, 5x5
+        // stride 2 0.81x (1.5 rounds) -- with one workgroup per CU nothing overlaps a workgroup's prologue, barriers and output
+        // transform any more, which costs what the shared transform saves; mode 1 therefore takes the 7x7 stride-2 layer only
+        if (g_rows_wide == 2 || (waste <= 1.2 && ksize == 7 && stride == 2)) {
+            if (ksize == 3) conv_rows_winograd_f32_kernel<3, 2, 4, 8><<<(unsigned)nb8, 512, 0, st>>>(a);
+            else if (ksize == 5) conv_rows_winograd_f32_kernel<5, 2, 4, 8><<<(unsigned)nb8, 512, 0, st>>>(a);
+            else if (stride == 1) conv_rows_winograd_f32_kernel<7, 1, 4, 8><<<(unsigned)nb8, 512, 0, st>>>(a);
+            else conv_rows_winograd_f32_kernel<7, 2, 4, 8><<<(unsigned)nb8, 512, 0, st>>>(a);
+            CNM_LAUNCH_CHECK();
+            return CNM_OK;
+        }
+    }
     if (ksize == 3) conv_rows_winograd_f32_kernel<3, 2, 4><<<nblocks, 256, 0, st>>>(a);
     else if (ksize == 5 && stride == 1) conv_rows_winograd_f32_kernel<5, 1, 2><<<nblocks, 256, 0, st>>>(a);
     else if (ksize == 5 && tile == 4) conv_rows_winograd_f32_kernel<5, 2, 4><<<nblocks, 256, 0, st>>>(a);

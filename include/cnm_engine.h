@@ -59,6 +59,12 @@ int cnm_tune_glds_tile(int n);
  *   whole rounds of one workgroup per CU; 2 runs it wherever the shape is eligible; 0 keeps the gather-fed kernel
  *   everywhere.  Results are bit-identical in all three settings; any other value only queries. */
 int cnm_tune_wino36_staged(int on);
+/* rows_wide: the row-wise Winograd kernels with four outputs per tile (conv1.0 F(4,7), the stride-2 column-phase layers) run
+ *   128 output channels per workgroup -- eight waves sharing one set of transformed tiles, one workgroup per CU -- for the
+ *   layer where that was measured faster (7x7 stride 2 with Cout a multiple of 128 and whole rounds of workgroups: 1,
+ *   default), wherever Cout % 128 == 0 (2), or never (0: 64 output channels, two workgroups per CU).  Bit-identical
+ *   results; any other value only queries. */
+int cnm_tune_rows_wide(int on);
 
 typedef enum cnm_status {
     CNM_OK = 0,

@@ -315,6 +315,28 @@ def test_conv3x3_winograd4(dev, ops, cin, cout, rot, N, H, W):
     assert np.abs(got - want).max() < 2e-4 * max(np.abs(want).max(), 1.0), np.abs(got - want).max()
 
 
+@pytest.mark.parametrize("k,stride,cin,cout,N,H,W", [(7, 1, 35, 128, 2, 37, 50), (7, 2, 64, 128, 2, 40, 56), (5, 2, 64, 256, 3, 30, 44), (3, 2, 48, 128, 2, 26, 36)])
+def test_conv_rows_wide_equals_narrow(dev, ops, k, stride, cin, cout, N, H, W):
+    """Row-wise Winograd kernels with 128 output channels per workgroup (8 waves, 4 of them transforming: cnm_tune_rows_wide)
+    are bit-equal to the 64-channel workgroups -- same gathers, transform and MFMA order per output channel."""
+    from cnmnet_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(k * 10 + stride + H)
+    x = ops.nchw_to_c4(T(rng.standard_normal((N, cin, H, W)).astype(np.float32)).to(dev))
+    w = T((rng.standard_normal((cout, cin, k, k)) * (2.0 / (cin * k * k)) ** 0.5).astype(np.float32)).to(dev)
+    up = ops.pack_winograd_rows(w, stride=2, tile=4) if k == 3 else ops.pack_winograd(w, stride=stride, tile=4)
+    bp = T(rng.standard_normal(cout).astype(np.float32)).to(dev)
+    old = lib.cnm_tune_rows_wide(-1)
+    try:
+        outs = []
+        for mode in (0, 2):
+            lib.cnm_tune_rows_wide(mode)
+            outs.append(ops.conv_rows_winograd_c4(x, up, bp, cout, k, True, stride=stride, tile=4).clone())
+    finally:
+        lib.cnm_tune_rows_wide(old)
+    assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
+
+
 @pytest.mark.parametrize("cin,cin2,cout,rot,N,H,W", [
     (64, 0, 128, 0, 2, 48, 64),        # one tile block per image row, two units per image row pair
     (67, 0, 128, 3, 1, 40, 72),        # rotated first layer, ragged tile columns (18 tiles: two blocks, second mostly empty)
