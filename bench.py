@@ -143,6 +143,8 @@ def wino36_kernel(cout, h, w, ups=False):
         return "conv_winograd36s_f32_kernel<16, %s, 0, 4>" % ("true" if ups else "false")
     if cout % 128 == 0 and tw >= 6 and th >= 2:
         return "conv_winograd36s_f32_kernel<8, %s, 0, 4>" % ("true" if ups else "false")
+    if cout % 128 == 0 and not ups and tw >= 3 and th >= 3:
+        return "conv_winograd36s_f32_kernel<4, false, 0, 4>"
     return "conv_winograd36_f32_kernel<4, 3, %s>" % ("true" if ups else "false")
 
 
@@ -151,7 +153,8 @@ def conv_kernel(L, m, m4=0, h=0, w=0):
     the direct-convolution flops the kernel really executes on the matrix cores (Winograd executes fewer)."""
     k, s = L["ksize"], L["stride"]
     if s == 1 and k == 3:
-        if L["Cout"] // 64 * -(-m4 // 16) >= WINO4_MIN_WORKGROUPS:
+        small = L["Cout"] % 128 == 0 and -(-w // 4) >= 3 and -(-h // 4) >= 3      # nets.hip wino4_staged_small: the staged kernel balances any unit count
+        if L["Cout"] // 64 * -(-m4 // 16) >= WINO4_MIN_WORKGROUPS or small:
             return wino36_kernel(L["Cout"], h, w), 36.0 / 144.0      # F(4x4,3x3): 36 multiplies per 16 outputs instead of 144
         return "conv3x3_winograd_f32_kernel", 16.0 / 36.0            # F(2x2,3x3): 16 multiplies per 4 outputs instead of 36
     if k == 5 and s == 1 and L["Cout"] // 64 * -(-(m // 4) // 16) >= WINO4_MIN_WORKGROUPS:

@@ -47,6 +47,7 @@ PROTOTYPES = {
     "cnm_tune_glds_tile": (c_i, [c_i]),
     "cnm_tune_wino36_staged": (c_i, [c_i]),
     "cnm_tune_rows_wide": (c_i, [c_i]),
+    "cnm_tune_wino4_small": (c_i, [c_i]),
     "cnm_packed_winograd4_floats": (c_sz, [c_i, c_i]),
     "cnm_pack_winograd4_bn_f32": (c_i, [c_fp, c_fp, c_fp, c_f, c_i, c_i, c_i, c_fp, c_fp]),
     "cnm_conv3x3_winograd4_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp,

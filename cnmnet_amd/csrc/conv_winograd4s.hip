@@ -416,7 +416,7 @@ extern "C" size_t cnm_wino36_sync_floats(void) { return (kSyncFlagBytes + (size_
 int cnm_wino36s_try_launch(const Wino4Args& a, int M, int ups, hipStream_t stream) {
     if (!g_wino36_staged || (M != 4 && M != 2) || (ups && M != 4) || a.Cout % 128) return 1;
     int tsx = 0;
-    if (a.TW >= 12) tsx = 16; else if (a.TW >= 6 && a.TH >= 2) tsx = 8;
+    if (a.TW >= 12) tsx = 16; else if (a.TW >= 6 && a.TH >= 2) tsx = 8; else if (M == 4 && !ups && a.TW >= 3 && a.TH >= 3) tsx = 4;   // tile block 1 x 16, 2 x 8, 4 x 4
     if (!tsx) return 1;
     const int tsy = 16 / tsx;
     const int SH = cnm_ceil_div(a.TH, tsy), SW = cnm_ceil_div(a.TW, tsx), tilesC = a.Cout / 128;
@@ -452,6 +452,8 @@ int cnm_wino36s_try_launch(const Wino4Args& a, int M, int ups, hipStream_t strea
     if (M == 2) {
         if (tsx == 16) conv_winograd36s_f32_kernel<16, false, 0, 2><<<grid, 512, 0, stream>>>(a, SH, SW, tilesC, (int)nunits, flags, slots);
         else conv_winograd36s_f32_kernel<8, false, 0, 2><<<grid, 512, 0, stream>>>(a, SH, SW, tilesC, (int)nunits, flags, slots);
+    } else if (tsx == 4) {
+        conv_winograd36s_f32_kernel<4, false><<<grid, 512, 0, stream>>>(a, SH, SW, tilesC, (int)nunits, flags, slots);
     } else if (tsx == 16) {
         if (ups) conv_winograd36s_f32_kernel<16, true><<<grid, 512, 0, stream>>>(a, SH, SW, tilesC, (int)nunits, flags, slots);
         else conv_winograd36s_f32_kernel<16, false><<<grid, 512, 0, stream>>>(a, SH, SW, tilesC, (int)nunits, flags, slots);

@@ -90,6 +90,9 @@ static inline bool wino4_fills_chip(int Cout, int N, int H, int W, int m = 4) { 
     return (Cout / 64) * ((tiles + 15) / 16) >= g_wino4_min_workgroups;
 }
 
+static int g_wino4_small = 1;                                            // tuning knob: small layers on the staged F(4x4,3x3) kernel (A/B against F(2x2,3x3))
+extern "C" int cnm_tune_wino4_small(int on) { const int old = g_wino4_small; if (on == 0 || on == 1) g_wino4_small = on; return old; }
+
 // The depth and the probability decoder (depthNet_model.py:341-351 / :357-365) share only their inputs, and their
 // layers launch 384-768 workgroups on 512 slots; run side by side they backfill each other's tail and the bandwidth-
 // bound upsample / head launches hide under the other decoder's MFMA work.  The second decoder runs on a side stream
@@ -132,8 +135,11 @@ struct EngF32 {
         const int e = up(in, G, up_tmp, N, H, W, s);
         return e != CNM_OK ? e : conv(up_tmp, G, 0, G, out, Gto, go0, Cout, w, N, 2 * H, 2 * W, 3, 1, sync, s);
     }
+    // with a sync workspace the staged F(4x4,3x3) kernel spreads ANY number of units evenly over the CUs, so it also takes the
+    // small layers (down to 3 x 3 tiles per image) that the gather-fed kernel could not fill the chip with
+    static bool wino4_staged_small(int Cout, int H, int W, const float* sync) { return sync && g_wino4_small && Cout % 128 == 0 && (W + 3) / 4 >= 3 && (H + 3) / 4 >= 3; }
     static int conv(const float* in, int Gt, int g0, int Gin, float* out, int Gto, int go0, int Cout, const cnm_layer_weights& w, int N, int H, int W, int k, int st, float* sync, void* s) {
-        if (w.u4 && k == 3 && st == 1 && wino4_fills_chip(Cout, N, H, W))
+        if (w.u4 && k == 3 && st == 1 && (wino4_fills_chip(Cout, N, H, W) || wino4_staged_small(Cout, H, W, sync)))
             return cnm_conv3x3_winograd4_sync_c4_f32(in, Gt, g0, Gin, nullptr, 0, 0, 0, out, Gto, go0, Cout, w.u4, w.b, N, H, W, 1, sync, sync ? cnm_wino36_sync_floats() : 0, s);
         if (w.u && k == 3 && st == 2 && (Cout / 64) * (((long long)N * ((H + 1) / 2) * ((W + 1) / 2) + 63) / 64) < 256)   // too few implicit-GEMM tiles
             return cnm_conv3x3_s2_winograd_c4_f32(in, Gt, g0, Gin, out, Gto, go0, Cout, w.u, w.b, N, H, W, 1, s);
@@ -145,7 +151,7 @@ struct EngF32 {
         if (w.u && (k == 5 || k == 7)) return cnm_conv_rows_winograd_c4_f32(in, Gt, g0, Gin, nullptr, 0, 0, 0, out, Gto, go0, Cout, w.u, w.b, N, H, W, k, st, (k == 5 && st == 1) ? 2 : 4, 1, s);
         return cnm_conv2d_c4_f32(in, Gt, g0, Gin, out, Gto, go0, Cout, w.w, w.b, N, H, W, k, st, 1, s); }
     static int conv2(const float* a, int Ga, const float* b, int Gb, float* out, int Gto, int Cout, const cnm_layer_weights& w, int N, int H, int W, float* sync, void* s) {
-        if (w.u4 && wino4_fills_chip(Cout, N, H, W)) return cnm_conv3x3_winograd4_sync_c4_f32(a, Ga, 0, Ga, b, Gb, 0, Gb, out, Gto, 0, Cout, w.u4, w.b, N, H, W, 1, sync, sync ? cnm_wino36_sync_floats() : 0, s);
+        if (w.u4 && (wino4_fills_chip(Cout, N, H, W) || wino4_staged_small(Cout, H, W, sync))) return cnm_conv3x3_winograd4_sync_c4_f32(a, Ga, 0, Ga, b, Gb, 0, Gb, out, Gto, 0, Cout, w.u4, w.b, N, H, W, 1, sync, sync ? cnm_wino36_sync_floats() : 0, s);
         if (w.u) return cnm_conv3x3_winograd_c4_f32(a, Ga, 0, Ga, b, Gb, 0, Gb, out, Gto, 0, Cout, w.u, w.b, N, H, W, 1, s);
         return cnm_conv2d_cat2_c4_f32(a, Ga, 0, Ga, b, Gb, 0, Gb, out, Gto, 0, Cout, w.w, w.b, N, H, W, 3, 1, 1, s); }
     static int up(const float* in, int G, float* out, int N, int H, int W, void* s) { return cnm_upsample2x_c4_f32(in, G, 0, out, G, 0, N, G, H, W, s); }

@@ -65,6 +65,10 @@ int cnm_tune_wino36_staged(int on);
  *   default), wherever Cout % 128 == 0 (2), or never (0: 64 output channels, two workgroups per CU).  Bit-identical
  *   results; any other value only queries. */
 int cnm_tune_rows_wide(int on);
+/* wino4_small: 1 (default) lets the fp32 executors run 3x3 stride-1 layers below the wino4_min_workgroups switch on the
+ *   staged F(4x4,3x3) kernel too (Cout a multiple of 128, at least 3 x 3 tiles per image: 4 x 4 tile blocks) -- with the
+ *   executors' sync workspace it spreads any unit count evenly over the CUs; 0 keeps F(2x2,3x3) there.  Other values query. */
+int cnm_tune_wino4_small(int on);
 
 typedef enum cnm_status {
     CNM_OK = 0,

@@ -344,7 +344,9 @@ def test_conv_rows_wide_equals_narrow(dev, ops, k, stride, cin, cout, N, H, W):
     (128, 129, 128, 0, 2, 32, 64),     # concatenated input: 128 + 129 channels, the second view starts mid-chunk
     (20, 0, 128, 0, 1, 24, 28),        # seven tile columns (2 x 8 blocks, ragged), ragged channel group
     (16, 0, 128, 0, 40, 16, 64),       # 160 units > one per CU on a small grid is not guaranteed; many images, one chunk
-    (48, 0, 384, 0, 2, 52, 100)])      # three channel blocks, ragged rows and columns
+    (48, 0, 384, 0, 2, 52, 100),       # three channel blocks, ragged rows and columns
+    (64, 0, 128, 0, 4, 12, 16),        # 4 x 4 tile blocks: 3 x 4 tiles per image (a quarter of the block idle)
+    (96, 0, 256, 0, 3, 14, 18)])       # 4 x 4 tile blocks, ragged: 4 x 5 tiles per image, two blocks per image row
 def test_conv3x3_winograd4_staged(dev, ops, cin, cin2, cout, rot, N, H, W):
     """LDS-staged persistent F(4x4,3x3) kernel (conv_winograd4s.hip), forced wherever eligible: against the fp64 torch
     convolution (the gather-fed kernel's bar, 2e-4 of the output scale) and BIT-EQUAL to the gather-fed kernel -- both run

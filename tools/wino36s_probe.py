@@ -30,7 +30,8 @@ def check():
     bad = 0
     cases = [  # N, Cin, Cin2, Cout, H, W
         (2, 64, 0, 128, 48, 64), (1, 67, 0, 128, 40, 72), (3, 32, 0, 256, 24, 32), (2, 128, 129, 128, 32, 64), (1, 20, 0, 128, 24, 28),
-        (2, 256, 0, 512, 48, 64), (1, 65, 0, 128, 192, 256), (5, 16, 0, 128, 8, 32), (1, 512, 513 - 512, 256, 16, 64), (2, 48, 0, 384, 52, 100)]
+        (2, 256, 0, 512, 48, 64), (1, 65, 0, 128, 192, 256), (5, 16, 0, 128, 8, 32), (1, 512, 513 - 512, 256, 16, 64), (2, 48, 0, 384, 52, 100),
+        (4, 64, 0, 128, 12, 16), (3, 96, 0, 256, 14, 18), (16, 512, 0, 512, 12, 16)]
     for N, Cin, Cin2, Cout, H, W in cases:
         x = ops.nchw_to_c4(torch.randn(N, Cin, H, W, device=dev))
         x2 = ops.nchw_to_c4(torch.randn(N, Cin2, H, W, device=dev)) if Cin2 else None
@@ -70,6 +71,7 @@ def check():
     return bad
 
 
+SMALL = [("depth conv5.0", 16, 512, 512, 12, 16), ("depth iconv5", 16, 1024, 512, 12, 16), ("depth upconv5 (on 12x16)", 16, 512, 512, 12, 16)]
 LAYERS = [  # (name, N, Cin, Cout, H, W)
     ("depth conv3.0", 16, 256, 512, 48, 64), ("depth conv4.0", 16, 512, 512, 24, 32), ("depth upconv3", 16, 512, 256, 48, 64), ("depth iconv3", 16, 513, 256, 48, 64),
     ("depth iconv2", 16, 257, 128, 96, 128), ("depth iconv1", 16, 65, 64, 192, 256), ("depth iconv4", 16, 1024, 512, 24, 32), ("depth upconv4", 16, 512, 512, 24, 32),
@@ -103,6 +105,12 @@ def time_layers():
         for i in range(3): tot[i] += ms[i] * mult
         print("%-24s %4d->%4d %3dx%-3d N%2d: gather %.3f ms (%.2f) | staged aligned %.3f ms (%.2f) x%.2f | staged split %.3f ms %5.1f TF (%.2f) x%.2f" % (
             name, Cin, Cout, H, W, N, ms[0], gf / ms[0] / 4 / 157.3, ms[1], gf / ms[1] / 4 / 157.3, ms[0] / ms[1], ms[2], gf / ms[2] / 4, gf / ms[2] / 4 / 157.3, ms[0] / ms[2]), flush=True)
+    for name, N, Cin, Cout, H, W in SMALL:                                # F(2x2,3x3) kernel against the staged F(4x4,3x3) kernel with 4 x 4 tile blocks
+        x = ops.nchw_to_c4(torch.randn(N, Cin, H, W, device=dev)); wt = torch.randn(Cout, Cin, 3, 3, device=dev) * 0.02
+        u2, u4, bp = ops.pack_winograd(wt), ops.pack_winograd4(wt), torch.zeros(Cout, device=dev)
+        lib.cnm_tune_wino36_staged(1)
+        m2 = ev(lambda: ops.conv3x3_winograd_c4(x, u2, bp, Cout, True)); m4 = ev(lambda: ops.conv3x3_winograd4_c4(x, u4, bp, Cout, True, sync=SYNC))
+        print("%-28s %4d->%4d %3dx%-3d N%2d: F(2x2) %.3f ms | staged F(4x4), 4x4 blocks %.3f ms  x%.2f" % (name, Cin, Cout, H, W, N, m2, m4, m2 / m4), flush=True)
     for name, N, Cin, Cout, H, W in UPS:
         x = ops.nchw_to_c4(torch.randn(N, Cin, H, W, device=dev)); uu, bu, wr = ops.pack_winograd4_upsampled(torch.randn(Cout, Cin, 3, 3, device=dev) * 0.02)
         ms = []
