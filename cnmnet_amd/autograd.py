@@ -32,17 +32,42 @@ def _sync_workspace(device):
     return ws
 
 
+PACK_CACHE = None   # a dict while a trainer step runs (trainer._step_scope): packed filters shared by the two depthNet passes of a step
+
+
+def _packed(kind, weight, rot, stride, fn):
+    """Packed form of `weight` for one step: the trainer opens a cache per step (forward AND backward: the weights only
+    change in optimizer.step()), so depthNet's two passes (train.py:164-167) pack every filter once per direction instead
+    of twice.  Outside a step scope nothing is cached (a HIP-graph replay updates weights without bumping _version)."""
+    c = PACK_CACHE
+    if c is None:
+        return fn()
+    key = (kind, weight.data_ptr(), weight._version, tuple(weight.shape), rot, stride)
+    v = c.get(key)
+    if v is None:
+        v = c[key] = fn()
+    return v
+
+
+def _dgrad_weight(weight):
+    """w'[ci][co] = w[co][ci] rotated by 180 degrees: the data gradient of a stride-1 convolution is a convolution with w'."""
+    return _packed("flip", weight, 0, 1, lambda: weight.detach().flip(2, 3).transpose(0, 1).contiguous())
+
+
 def _winograd_conv(x, weight, rot, stride=1):
     Cout, _, k, _ = weight.shape
-    if k == 3 and _winograd4_fills_chip(x, Cout):                        # large layers: F(4x4,3x3)
-        return ops.conv3x3_winograd4_c4(x, ops.pack_winograd4(weight, None, rot), None, Cout, relu=False, sync=_sync_workspace(x.device))
-    up = ops.pack_winograd(weight, None, rot, stride=stride, tile=2)    # training keeps the more accurate F(2,k) rows
+    # large layers: F(4x4,3x3); with the sync workspace the staged kernel also balances small unit counts (>= 3 x 3 tiles per image)
+    if k == 3 and (_winograd4_fills_chip(x, Cout) or (WINOGRAD4_SMALL and Cout % 128 == 0 and x.shape[2] >= 9 and x.shape[3] >= 9)):
+        up4 = _packed("u4", weight, rot, 1, lambda: ops.pack_winograd4(weight, None, rot))
+        return ops.conv3x3_winograd4_c4(x, up4, None, Cout, relu=False, sync=_sync_workspace(x.device))
+    up = _packed("u2", weight, rot, stride, lambda: ops.pack_winograd(weight, None, rot, stride=stride, tile=2))    # training keeps the more accurate F(2,k) rows
     if k == 3:
         return ops.conv3x3_winograd_c4(x, up, None, Cout, relu=False)
     return ops.conv_rows_winograd_c4(x, up, None, Cout, k, relu=False, stride=stride, tile=2)
 
 
 WINOGRAD4_MIN_WORKGROUPS = 384   # same switch point as the inference executors (include/cnm_engine.h)
+WINOGRAD4_SMALL = True           # ... and the same extension below it (nets.hip wino4_staged_small)
 
 
 def _winograd4_fills_chip(x, Cout):
@@ -105,13 +130,13 @@ class ConvC4(torch.autograd.Function):
         with torch.cuda.device(dev):
             if ctx.needs_input_grad[0] and ctx.rot == 0 and ctx.stride == 1 and _winograd_ok(k, 1, Cin):
                 # stride 1: dx = conv(dy, w') with w'[ci][co] = w[co][ci] rotated by 180 degrees -- the same Winograd kernels
-                dx = _winograd_conv(dy, weight.detach().flip(2, 3).transpose(0, 1).contiguous(), 0)
+                dx = _winograd_conv(dy, _dgrad_weight(weight), 0)
             elif (ctx.needs_input_grad[0] and ctx.rot == 0 and ctx.stride == 2 and WINOGRAD and Cin % 64 == 0
                   and H % 2 == 0 and W % 2 == 0):
                 # stride 2: four stride-1 Winograd convolutions of dY, one per pixel phase of dX (sub-pixel
                 # decomposition: the zero-upsampled dY with its 3/4 structural zeros never exists)
                 dx = torch.empty_like(x)
-                for a, b, wp in _stride2_dgrad_phases(weight.detach()):
+                for a, b, wp in _packed("s2", weight, 0, 2, lambda: _stride2_dgrad_phases(weight.detach())):
                     dx[:, :, a::2, b::2] = _winograd_conv(dy, wp, 0)
             elif ctx.needs_input_grad[0]:
                 wd = torch.empty(lib.cnm_packed_dgrad_floats(Cout, Cin, k), device=dev, dtype=torch.float32)

@@ -19,6 +19,21 @@ import torch
 from .depthnet.losses import IdepthLoss_234, _valid
 
 
+class _step_scope:
+    """Forward + backward of ONE optimisation step: packed filters are shared inside it (autograd.PACK_CACHE) and dropped at
+    its end -- the weights change right after it, in optimizer.step()."""
+
+    def __enter__(self):
+        from . import autograd
+        autograd.PACK_CACHE = {}
+        return self
+
+    def __exit__(self, *exc):
+        from . import autograd
+        autograd.PACK_CACHE = None
+        return False
+
+
 class BucketedGradAllReduce:
     """Average gradients across ranks with bucketed, backward-overlapped all-reduces.
 
@@ -155,9 +170,10 @@ class TrainStepWoNormal:
         if self.graph_mode:
             return self._graphed_step((rgbs, cameras, disparities, depths), bool(warmup_epoch),
                                       lambda *a: self.losses(*a, warmup_epoch))
-        loss, logs = self.losses(rgbs, cameras, disparities, depths, warmup_epoch)
-        self.optimizer.zero_grad(set_to_none=False)                                          # :562-565
-        loss.backward()
+        with _step_scope():
+            loss, logs = self.losses(rgbs, cameras, disparities, depths, warmup_epoch)
+            self.optimizer.zero_grad(set_to_none=False)                                      # :562-565
+            loss.backward()
         if self.reducer is not None:
             self._finish(self.reducer.finish)
         self.optimizer.step()
@@ -200,16 +216,17 @@ class TrainStepWoNormal:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                       # warm-up off the default stream: Adam state and allocator pools exist before capture
             for _ in range(2):
-                loss, logs = fn(*self._static_in)
-                self.optimizer.zero_grad(set_to_none=True)
-                loss.backward()
+                with _step_scope():
+                    loss, logs = fn(*self._static_in)
+                    self.optimizer.zero_grad(set_to_none=True)
+                    loss.backward()
                 if self.reducer is None:
                     self.optimizer.step()
                 del loss, logs                              # no autograd graph of the warm-up may outlive it (its AccumulateGrad nodes carry their stream)
         torch.cuda.current_stream().wait_stream(side)
         self.optimizer.zero_grad(set_to_none=True)
         self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
+        with torch.cuda.graph(self._graph), _step_scope():
             loss, logs = fn(*self._static_in)
             loss.backward()
             if self.reducer is None:
@@ -317,9 +334,10 @@ class TrainStep(TrainStepWoNormal):
         if self.graph_mode:                                  # the relative poses (a 4x4 inverse) are computed outside the captured region
             return self._graphed_step((rgbs, cameras, disparities, depths, normals, self.relative_poses(cameras)), "normals",
                                       lambda r, c, i, d, n, poses: self.losses(r, c, i, d, n, poses))
-        loss, logs = self.losses(rgbs, cameras, disparities, depths, normals)
-        self.optimizer.zero_grad(set_to_none=False)                                          # :307-310
-        loss.backward()
+        with _step_scope():
+            loss, logs = self.losses(rgbs, cameras, disparities, depths, normals)
+            self.optimizer.zero_grad(set_to_none=False)                                      # :307-310
+            loss.backward()
         if self.reducer is not None:
             self._finish(self.reducer.finish)
         self.optimizer.step()
