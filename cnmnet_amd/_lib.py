@@ -72,6 +72,9 @@ PROTOTYPES = {
     "cnm_pack_winograd_rows_bn_f32": (c_i, [c_fp, c_fp, c_fp, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp]),
     "cnm_conv_rows_winograd_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp,
                                             c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    "cnm_conv_rows_winograd_sync_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp,
+                                                 c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_sz, c_fp]),
+    "cnm_tune_rows7_staged": (c_i, [c_i]),
     "cnm_upsample2x_c4_f32": (c_i, [c_fp, c_i, c_i, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "cnm_pack_head_f32": (c_i, [c_fp, c_i, c_fp, c_fp]),
     "cnm_head_sigmoid_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_fp, c_f, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),

@@ -11,7 +11,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libcnm_engine.so")
-SOURCES = ["planesweep.hip", "conv_mfma.hip", "conv_winograd.hip", "conv_winograd4.hip", "conv_winograd4s.hip", "conv_winograd_rows.hip", "pointwise.hip", "geometry.hip", "nets.hip", "train_ops.hip", "half_ops.hip"]
+SOURCES = ["planesweep.hip", "conv_mfma.hip", "conv_winograd.hip", "conv_winograd4.hip", "conv_winograd4s.hip", "conv_winograd_rows.hip", "conv_rows_staged.hip", "pointwise.hip", "geometry.hip", "nets.hip", "train_ops.hip", "half_ops.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # per-file extras: the plane sweep's blend must stay on full-rate scalar v_fma_f32 (the SLP vectoriser would
@@ -28,7 +28,7 @@ def _stale(target, deps):
 
 def build(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
-    headers = [os.path.join(CSRC, "cnm_common.h"), os.path.join(CSRC, "wino4_args.h"), os.path.join(PKG, "..", "include", "cnm_engine.h")]
+    headers = [os.path.join(CSRC, "cnm_common.h"), os.path.join(CSRC, "wino4_args.h"), os.path.join(CSRC, "rows_args.h"), os.path.join(PKG, "..", "include", "cnm_engine.h")]
     objs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)

@@ -344,6 +344,12 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
 #pragma unroll
                     for (int x = 0; x < 4; ++x)
                         __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&y[x]), srsrc, (slot_lane + (unsigned)(4 * st + x) * 64u) * 16u, (unsigned)rng * (unsigned)SLOT_BYTES, 16);
+                    // the 16-byte-per-lane stores read their data registers over several cycles and hipcc knows no hazard for the
+                    // SGPR-soffset form: with the registers rewritten by the very next instruction the last quarter of each
+                    // 16 lanes of the last store went out with the NEW values on MI355X (tools/rows7s_debug.py)
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
                     continue;
                 }
                 for (int k = 1; k <= nsrc; ++k) {                        // fixed order: own part, then the following ranges

@@ -19,6 +19,7 @@
 // private to the wave) and one ds_read_b128 of V per 16-tile block feed 12-16 MFMAs; the transform of chunk c+1 and the
 // gather of chunk c+2 ride between the MFMAs of chunk c; one LDS-only barrier per chunk.
 #include "cnm_common.h"
+#include "rows_args.h"
 
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -125,14 +126,6 @@ template <int ID, int M> __device__ __forceinline__ constexpr float at_coef(int 
     else return RowWino<ID>::AT[i][k];
 }
 
-struct RowArgs {
-    const float* in; const float* in2; float* out; const float* u; const float* bias;
-    unsigned in_bytes, in2_bytes;
-    int N, H, W, Ho, Wo, TW;             // input H x W, output Ho x Wo, TW = ceil(Wo/2) tiles per row
-    int Gin_tot, gin0, Gin2_tot, gin2_0, Gsplit, Gin;
-    int Gout_tot, gout0, Cout;
-    int nchunks, T, relu;                // T = N*Ho*TW tiles
-};
 
 // NW = 4: workgroup = 4 waves = 64 couts, two workgroups per CU.  NW = 8: 8 waves = 128 couts over the SAME transformed
 // tiles, one workgroup per CU: waves 0-3 gather and transform exactly as before (one channel quad each), waves 4-7 only
@@ -423,11 +416,11 @@ extern "C" int cnm_pack_winograd_rows_bn_f32(const float* w_oihw, const float* b
     return CNM_OK;
 }
 
-extern "C" int cnm_conv_rows_winograd_c4_f32(const float* in_a, int Ga_total, int ga0, int Ga,
-                                             const float* in_b, int Gb_total, int gb0, int Gb,
-                                             float* out, int Gout_total, int gout0, int Cout,
-                                             const float* u_packed, const float* b_packed,
-                                             int N, int H, int W, int ksize, int stride, int tile, int relu, void* stream) {
+static int conv_rows(const float* in_a, int Ga_total, int ga0, int Ga,
+                     const float* in_b, int Gb_total, int gb0, int Gb,
+                     float* out, int Gout_total, int gout0, int Cout,
+                     const float* u_packed, const float* b_packed,
+                     int N, int H, int W, int ksize, int stride, int tile, int relu, float* sync_ws, size_t sync_floats, void* stream) {
     CNM_REQUIRE(in_a && out && u_packed && N > 0 && H > 0 && W > 0 && Ga > 0 && Gb >= 0 && rows_ksize_ok(ksize, stride, tile), CNM_ERR_BAD_ARG);
     CNM_REQUIRE((stride == 1 || stride == 2) && rows_tile_ok(ksize, stride, tile), CNM_ERR_BAD_ARG);
     CNM_REQUIRE(Cout > 0 && Cout % 64 == 0 && gout0 >= 0 && gout0 + Cout / 4 <= Gout_total, CNM_ERR_BAD_ARG);
@@ -447,6 +440,10 @@ extern "C" int cnm_conv_rows_winograd_c4_f32(const float* in_a, int Ga_total, in
     const int ntb = cnm_ceil_div(a.T, ((ksize == 7 && stride == 1 && m == 4) || ksize == 3) ? 48 : 64);
     const int nblocks = (Cout / 64) * ntb;
     hipStream_t st = cnm_stream(stream);
+    if (ksize == 7 && stride == 1 && m == 4) {                           // LDS-staged persistent kernel (conv_rows_staged.hip)
+        const int rc = cnm_rows7s_try_launch(a, sync_ws, sync_floats, st);
+        if (rc <= 0) return rc;
+    }
     if (g_rows_wide && m == 4 && Cout % 128 == 0) {
         // 128 couts per workgroup, one workgroup per CU (rounds of 256): taken unless the last round would be mostly empty
         const long long nb8 = (long long)(Cout / 128) * ntb;
@@ -473,4 +470,23 @@ extern "C" int cnm_conv_rows_winograd_c4_f32(const float* in_a, int Ga_total, in
     else conv_rows_winograd_f32_kernel<7, 2, 2><<<nblocks, 256, 0, st>>>(a);
     CNM_LAUNCH_CHECK();
     return CNM_OK;
+}
+
+extern "C" int cnm_conv_rows_winograd_c4_f32(const float* in_a, int Ga_total, int ga0, int Ga,
+                                             const float* in_b, int Gb_total, int gb0, int Gb,
+                                             float* out, int Gout_total, int gout0, int Cout,
+                                             const float* u_packed, const float* b_packed,
+                                             int N, int H, int W, int ksize, int stride, int tile, int relu, void* stream) {
+    return conv_rows(in_a, Ga_total, ga0, Ga, in_b, Gb_total, gb0, Gb, out, Gout_total, gout0, Cout, u_packed, b_packed, N, H, W, ksize, stride, tile, relu, nullptr, 0, stream);
+}
+
+// The same with a sync workspace (cnm_wino36_sync_floats() floats, zero before the first use, one per stream): the staged
+// 7x7 stride-1 kernel then gives every CU an equal share of the reduction phases.  Other shapes ignore it.
+extern "C" int cnm_conv_rows_winograd_sync_c4_f32(const float* in_a, int Ga_total, int ga0, int Ga,
+                                                  const float* in_b, int Gb_total, int gb0, int Gb,
+                                                  float* out, int Gout_total, int gout0, int Cout,
+                                                  const float* u_packed, const float* b_packed,
+                                                  int N, int H, int W, int ksize, int stride, int tile, int relu,
+                                                  float* sync_ws, size_t sync_floats, void* stream) {
+    return conv_rows(in_a, Ga_total, ga0, Ga, in_b, Gb_total, gb0, Gb, out, Gout_total, gout0, Cout, u_packed, b_packed, N, H, W, ksize, stride, tile, relu, sync_ws, sync_floats, stream);
 }

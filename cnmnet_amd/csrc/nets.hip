@@ -148,7 +148,7 @@ struct EngF32 {
         if (w.u && k == 3 && st == 1) return cnm_conv3x3_winograd_c4_f32(in, Gt, g0, Gin, nullptr, 0, 0, 0, out, Gto, go0, Cout, w.u, w.b, N, H, W, 1, s);
         if (w.u4 && k == 5 && st == 1 && wino4_fills_chip(Cout, N, H, W, 2))
             return cnm_conv5x5_winograd_sync_c4_f32(in, Gt, g0, Gin, nullptr, 0, 0, 0, out, Gto, go0, Cout, w.u4, w.b, N, H, W, 1, sync, sync ? cnm_wino36_sync_floats() : 0, s);
-        if (w.u && (k == 5 || k == 7)) return cnm_conv_rows_winograd_c4_f32(in, Gt, g0, Gin, nullptr, 0, 0, 0, out, Gto, go0, Cout, w.u, w.b, N, H, W, k, st, (k == 5 && st == 1) ? 2 : 4, 1, s);
+        if (w.u && (k == 5 || k == 7)) return cnm_conv_rows_winograd_sync_c4_f32(in, Gt, g0, Gin, nullptr, 0, 0, 0, out, Gto, go0, Cout, w.u, w.b, N, H, W, k, st, (k == 5 && st == 1) ? 2 : 4, 1, sync, sync ? cnm_wino36_sync_floats() : 0, s);
         return cnm_conv2d_c4_f32(in, Gt, g0, Gin, out, Gto, go0, Cout, w.w, w.b, N, H, W, k, st, 1, s); }
     static int conv2(const float* a, int Ga, const float* b, int Gb, float* out, int Gto, int Cout, const cnm_layer_weights& w, int N, int H, int W, float* sync, void* s) {
         if (w.u4 && (wino4_fills_chip(Cout, N, H, W) || wino4_staged_small(Cout, H, W, sync))) return cnm_conv3x3_winograd4_sync_c4_f32(a, Ga, 0, Ga, b, Gb, 0, Gb, out, Gto, 0, Cout, w.u4, w.b, N, H, W, 1, sync, sync ? cnm_wino36_sync_floats() : 0, s);

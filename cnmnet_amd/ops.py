@@ -379,8 +379,9 @@ def conv3x3_upsampled_c8(x, w_packed, b_packed, Cout, relu=True, w_ring=None):
     return out
 
 
-def conv_rows_winograd_c4(x, u_packed, b_packed, Cout, ksize, relu=True, x2=None, stride=1, tile=None):
-    """Row-wise Winograd twin of conv2d_c4(ksize=5|7, stride=1|2)."""
+def conv_rows_winograd_c4(x, u_packed, b_packed, Cout, ksize, relu=True, x2=None, stride=1, tile=None, sync=None):
+    """Row-wise Winograd twin of conv2d_c4(ksize=5|7, stride=1|2).  sync: optional wino36_sync_workspace() for the staged
+    7x7 stride-1 kernel (equal shares of the reduction per CU)."""
     _dev(x, u_packed, b_packed, x2)
     N, G, H, W, _ = x.shape
     pad = ksize // 2
@@ -389,9 +390,10 @@ def conv_rows_winograd_c4(x, u_packed, b_packed, Cout, ksize, relu=True, x2=None
     out = torch.empty(N, Cout // 4, Ho, Wo, 4, device=x.device, dtype=torch.float32)
     G2 = x2.shape[1] if x2 is not None else 0
     with torch.cuda.device(x.device):
-        _lib.check(_lib.load().cnm_conv_rows_winograd_c4_f32(_p(x), G, 0, G, _p(x2) if x2 is not None else None, G2, 0, G2,
-                                                             _p(out), Cout // 4, 0, Cout, _p(u_packed), _p(b_packed),
-                                                             N, H, W, ksize, stride, tile, int(relu), _stream()))
+        _lib.check(_lib.load().cnm_conv_rows_winograd_sync_c4_f32(_p(x), G, 0, G, _p(x2) if x2 is not None else None, G2, 0, G2,
+                                                                  _p(out), Cout // 4, 0, Cout, _p(u_packed), _p(b_packed),
+                                                                  N, H, W, ksize, stride, tile, int(relu),
+                                                                  _p(sync), sync.numel() if sync is not None else 0, _stream()))
     return out
 
 

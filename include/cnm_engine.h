@@ -280,6 +280,17 @@ int cnm_conv_rows_winograd_c4_f32(const float* in_a, int Ga_total, int ga0, int 
                                   float* out, int Gout_total, int gout0, int Cout,
                                   const float* u_packed, const float* b_packed,
                                   int N, int H, int W, int ksize, int stride, int tile, int relu, void* stream);
+/* The same with a sync workspace (cnm_wino36_sync_floats() floats, zero before the first use and left zero, one per
+ * stream): the 7x7 stride-1 four-output shape with Cout % 128 == 0 runs the LDS-staged persistent kernel
+ * (csrc/conv_rows_staged.hip) with equal shares of the reduction per CU; other shapes ignore the workspace.
+ * cnm_tune_rows7_staged(0) routes that shape back to the gather-fed kernel (returns the previous setting). */
+int cnm_conv_rows_winograd_sync_c4_f32(const float* in_a, int Ga_total, int ga0, int Ga,
+                                       const float* in_b, int Gb_total, int gb0, int Gb,
+                                       float* out, int Gout_total, int gout0, int Cout,
+                                       const float* u_packed, const float* b_packed,
+                                       int N, int H, int W, int ksize, int stride, int tile, int relu,
+                                       float* sync_ws, size_t sync_floats, void* stream);
+int cnm_tune_rows7_staged(int on);
 
 /* nn.Upsample(scale_factor=2, mode='bilinear') with align_corners=False
  * (depthNet_model.py:94,105) on a c4 view: [N,G,H,W,4] -> [N,G,2H,2W,4]. */
