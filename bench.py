@@ -162,7 +162,8 @@ def conv_kernel(L, m, m4=0, h=0, w=0):
         return ("conv_winograd36s_f32_kernel<16, false, 0, 2>" if staged else "conv_winograd36_f32_kernel<2, 5, false>"), 36.0 / 100.0   # F(2x2,5x5): 36 multiplies per 4 outputs instead of 100
     if k in (5, 7):                                                  # F(2,k) along rows; stride 2: two F(2,ceil(k/2)) column phases
         if k == 7 and s == 1:
-            return "conv_rows_winograd_f32_kernel<7, 1, 4>", 10.0 / 28.0      # F(4,7): 10 multiplies per 4 outputs and kernel row instead of 28
+            staged = L["Cout"] % 128 == 0 and w >= 32 and h >= 4                  # cnm_rows7s_try_launch (conv_rows_staged.hip)
+            return ("conv_rows7s_f32_kernel<0>" if staged else "conv_rows_winograd_f32_kernel<7, 1, 4>"), 10.0 / 28.0      # F(4,7): 10 multiplies per 4 outputs and kernel row instead of 28
         if s == 2:                                                   # two column phases x F(4,ceil(k/2)): (ceil(k/2)+3)/2 multiplies per output and kernel row
             return "conv_rows_winograd_f32_kernel<%d, 2, 4>" % k, ((k + 1) // 2 + 3) / 2.0 / k
         return "conv_rows_winograd_f32_kernel<%d, %d, 2>" % (k, s), (k + 1) / (2.0 * k)
@@ -216,9 +217,9 @@ def kernel_rooflines(dev, frames):
             elif name.startswith("conv3x3_winograd"):
                 up = ops.pack_winograd(wt)
                 fn = (lambda: ops.conv3x3_s2_winograd_c4(x, up, bp, L["Cout"], True)) if L["stride"] == 2 else (lambda: ops.conv3x3_winograd_c4(x, up, bp, L["Cout"], True))
-            elif name.startswith("conv_rows_winograd"):
+            elif name.startswith("conv_rows"):
                 up = ops.pack_winograd_rows(wt, stride=2, tile=4) if L["ksize"] == 3 else ops.pack_winograd(wt, stride=L["stride"])
-                fn = lambda: ops.conv_rows_winograd_c4(x, up, bp, L["Cout"], L["ksize"], True, stride=L["stride"])
+                fn = lambda: ops.conv_rows_winograd_c4(x, up, bp, L["Cout"], L["ksize"], True, stride=L["stride"], sync=sync)
             else:
                 fn = lambda: ops.conv2d_c4(x, wp, bp, L["Cout"], L["ksize"], L["stride"], True)
             ms = event_ms(fn, iters=IT, warm=WARM)

@@ -48,6 +48,17 @@ constexpr float kAT[4][10] = {{1, 1, 1, 1, 1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 
                               {0, 1, 1, 4, 4, 1. / 4, 1. / 4, 9. / 4, 9. / 4, 0}, {0, 1, -1, 8, -8, 1. / 8, -1. / 8, 27. / 8, -27. / 8, 1}};
 }
 
+#ifdef ROWS7S_DMA_NT
+#define ROWS7S_DMA_AUX " nt"
+#else
+#define ROWS7S_DMA_AUX ""
+#endif
+#ifndef ROWS7S_WD
+#define ROWS7S_WD 2
+#endif
+#ifndef ROWS7S_DMA_X1
+#define ROWS7S_DMA_X1 5
+#endif
 __device__ __forceinline__ void rows7s_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // one LDS-DMA wave-instruction (conv_winograd4s.hip): 64 lanes x 16 bytes from buffer offset voff + soff to lds_addr + 16 lane
@@ -58,10 +69,13 @@ __device__ __forceinline__ void rows7s_dma16(unsigned lds_addr, unsigned voff, c
                                                                           __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
     const unsigned la = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr), so = (unsigned)__builtin_amdgcn_readfirstlane((int)soff);
     unsigned keep;
-    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds" ROWS7S_DMA_AUX "\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "s"(la), "v"(voff), "s"(rsrc), "s"(so) : "memory");
 }
 
+#ifdef ROWS7S_ABLATE
+__device__ unsigned long long g_rows7s_clk[2];                           // shader cycles and 100 MHz ticks of workgroup 0's last launch
+#endif
 // ABL (debug builds, -DROWS7S_ABLATE, tools/rows7s_ablate.sh): bit 0 no input transform, 1 no DMA, 2 weight fragments from one hot
 // KB per wave, 3 no B-fragment reads after the first, 4 no output transform / stores, 5 no MFMAs.  Results are then meaningless.
 template <int ABL = 0>
@@ -71,7 +85,7 @@ __global__ __launch_bounds__(512, 2) void conv_rows7s_f32_kernel(const RowArgs a
     constexpr int NPIECE = (PR * PCP + 63) / 64, PLANE = NPIECE * 1024 + 128;                        // raw plane: 7 KB + pad
     constexpr int TVX = PR * TSX * 16, TVS = NX * TVX + 128;                                         // transformed plane: point pitch 1280, plane pitch 12928 bytes
     constexpr int RAW0 = 0, TV0 = 4 * PLANE, STG0 = TV0 + 4 * TVS, LDS_BYTES = STG0 + 8 * 4352;
-    constexpr int WD = 2;                                                // frequency points of weight fragments in flight (two fragments each)
+    constexpr int WD = ROWS7S_WD;                                                // frequency points of weight fragments in flight (two fragments each)
     constexpr int SLOT_BYTES = 8 * 16 * 64 * 16;                         // partial output of one range (as in conv_winograd4s.hip; half of it used)
     static_assert(NX % WD == 0 && TVS % 256 == 128 && TV0 % 128 == 0 && LDS_BYTES <= 120 * 1024, "layout");
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
@@ -86,39 +100,42 @@ __global__ __launch_bounds__(512, 2) void conv_rows7s_f32_kernel(const RowArgs a
     const int ps = range_begin(rng), pe = range_begin(rng + 1);
     const int P = pe - ps;
     if (P <= 0) return;
+#ifdef ROWS7S_ABLATE
+    const unsigned long long clk0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int nstrips = nunits / tilesC;                                 // unit = cblk * nstrips + strip (channel block slowest)
 
-    // A channel group (u, g) is first multiplied in global phase first_use(u, g); it is transformed one phase and staged two
-    // phases before that.  Its ring slots (raw and transformed) are (u ngrp + g) & 3: at most two groups start per phase.
-    const auto first_use = [&](int u, int g) { return u * nch + (NKY * g) / 8; };
-
-    // ---- stage role: one plane = NPIECE pieces of 64 slots, wave w moves piece w.  Cursor (su, sg) = the next group to stage.
+    // The channel groups whose first quad lies in phase c of a unit ("new groups of c"): g in [(8 c + 6) / 7, min(ngrp, (8 c + 14) / 7)),
+    // at most two.  They are staged two phases and transformed one phase before c; ring slots (raw and transformed) of group
+    // (u, g): (u ngrp + g) & 3.
     int mu = ps / nch, mc = ps - mu * nch;                               // cursor of the multiply role: unit, phase of the unit
-    int su = mu, sg = (8 * mc) / NKY;
-    unsigned svoff = 0; int simg = 0;                                    // this lane's offset inside a channel-group plane of the image; image of unit su
-    auto stage_unit = [&]() {
-        const int strip = su % nstrips;
+
+    // ---- stage role: one plane = NPIECE pieces of 64 slots, wave w moves piece w
+    const int pslot = 64 * wave + lane, prow = pslot / PCP, pcol = pslot - prow * PCP;
+    const bool pok = wave < NPIECE && prow < PR && pcol < PC;
+    unsigned svoff = 0; int simg = 0, su_cur = -1;                       // this lane's offset inside a channel-group plane of the image; image; the unit they belong to
+    auto stage_unit = [&](int u) {
+        const int strip = u % nstrips;
         simg = strip / SHW;
         const int rem = strip - simg * SHW, sy = rem / SW, sx = rem - sy * SW;
-        const int slot = 64 * wave + lane, r = slot / PCP, c = slot - r * PCP;
-        const int y = TSY * sy - 3 + r, x = 4 * TSX * sx - 3 + c;
-        const bool ok = wave < NPIECE && r < PR && c < PC && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
-        svoff = ok ? (unsigned)(y * a.W + x) * 16u : 0xFFFFFFFFu;
+        const int y = TSY * sy - 3 + prow, x = 4 * TSX * sx - 3 + pcol;
+        svoff = pok && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W ? (unsigned)(y * a.W + x) * 16u : 0xFFFFFFFFu;
+        su_cur = u;
     };
-    auto stage_groups = [&](int gp) {                                    // groups first multiplied by phase gp + 2 (and inside this range)
-#pragma unroll 1
-        while (first_use(su, sg) <= gp + 2 && first_use(su, sg) < pe) {
-            if (wave < NPIECE && !(ABL & 2)) {
-                const bool s1 = sg < a.Gsplit;
-                const unsigned gg = s1 ? (unsigned)(simg * a.Gin_tot + a.gin0 + sg) : (unsigned)(simg * a.Gin2_tot + a.gin2_0 + sg - a.Gsplit);
-                rows7s_dma16(lds0 + RAW0 + (unsigned)(((su * ngrp + sg) & 3) * PLANE + wave * 1024), svoff, s1 ? a.in : a.in2, s1 ? a.in_bytes : a.in2_bytes, gg * (unsigned)HW * 16u);
-            }
-            if (++sg == ngrp) { sg = 0; ++su; stage_unit(); }
+    auto stage_groups = [&](int u, int g0, int n) {                      // groups g0 .. g0 + n - 1 of unit u, n <= 2
+        if (n <= 0 || wave >= NPIECE || (ABL & 2)) return;
+        if (u != su_cur) stage_unit(u);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (i >= n) break;
+            const int g = g0 + i;
+            const bool s1 = g < a.Gsplit;
+            const unsigned gg = s1 ? (unsigned)(simg * a.Gin_tot + a.gin0 + g) : (unsigned)(simg * a.Gin2_tot + a.gin2_0 + g - a.Gsplit);
+            rows7s_dma16(lds0 + RAW0 + (unsigned)(((u * ngrp + g) & 3) * PLANE + wave * 1024), svoff, s1 ? a.in : a.in2, s1 ? a.in_bytes : a.in2_bytes, gg * (unsigned)HW * 16u);
         }
     };
 
     // ---- transform role: a wave-task = two patch rows of one group: lane = (channel e, tile x, row): lanes 0-31 tiles 0-3, 32-63 tiles 4-7
-    int tu = mu, tg = sg;                                                // cursor: the next group to transform
     const int te = lane & 3, ttx = ((lane >> 2) & 3) | ((lane >> 5) << 2), trr = (lane >> 4) & 1;
     const unsigned lrd = (unsigned)((trr * PCP + 4 * ttx) * 16 + te * 4), lwr = (unsigned)(trr * 128 + ttx * 16 + te * 4);
     float xw[10], vo[10];
@@ -154,25 +171,21 @@ __global__ __launch_bounds__(512, 2) void conv_rows7s_f32_kernel(const RowArgs a
 #pragma unroll
         for (int x = 0; x < NX; ++x) *reinterpret_cast<float*>(smem + wb + x * TVX) = vo[x];
     };
-    // tasks of phase gp: the groups first multiplied by phase gp + 1, five tasks each, task k to wave (k - 3 gp) & 7: this
-    // wave's tasks are k0 = (wave + 3 gp) & 7 and k0 + 8.  Sets ton[] (task present) and the LDS read / write addresses.
-    unsigned trd[2], twr[2]; bool ton[2];
-    auto tr_plan = [&](int gp) {
-        const int G0 = tu * ngrp + tg;
-        int n = 0;
-#pragma unroll 1
-        while (first_use(tu, tg) <= gp + 1 && first_use(tu, tg) < pe) { ++n; if (++tg == ngrp) { tg = 0; ++tu; } }
+    // tasks of phase gp: n groups from global group number G0 on, five tasks each, task k to wave (k - 3 gp) & 7: this wave's
+    // tasks are k0 = (wave + 3 gp) & 7 and k0 + 8.  Sets on[] (task present) and the LDS read / write addresses.
+    auto tr_plan = [&](int gp, int G0, int n, bool* on, unsigned* rd, unsigned* wr) {
         const int k0 = (wave + 3 * gp) & 7;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int k = k0 + 8 * i, gi = k >= 5 ? 1 : 0, part = k - 5 * gi;
-            const bool on = k < 5 * n;
             const int slot = (G0 + gi) & 3;
-            ton[i] = on;
-            trd[i] = (unsigned)(RAW0 + slot * PLANE + 2 * part * PCP * 16) + lrd;
-            twr[i] = (unsigned)(TV0 + slot * TVS + 2 * part * 128) + (lwr ^ (unsigned)((part & 1) * 64));
+            on[i] = k < 5 * n;
+            rd[i] = (unsigned)(RAW0 + slot * PLANE + 2 * part * PCP * 16) + lrd;
+            wr[i] = (unsigned)(TV0 + slot * TVS + 2 * part * 128) + (lwr ^ (unsigned)((part & 1) * 64));
         }
     };
+    const auto new_first = [&](int c) { return (8 * c + 6) / NKY; };
+    const auto new_count = [&](int c) { return max(0, min(ngrp, (8 * c + 14) / NKY) - (8 * c + 6) / NKY); };
 
     // ---- multiply role
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.u), 0, (unsigned)((size_t)a.nchunks * ncb16 * NX * 1024), 0x00020000);
@@ -197,22 +210,30 @@ __global__ __launch_bounds__(512, 2) void conv_rows7s_f32_kernel(const RowArgs a
 #pragma unroll
     for (int x = 0; x < NX; ++x) { acc[x][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[x][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-    // ---- prologue = the two phases before the range's first, without multiplies
+    // ---- prologue = the two phases before the range's first, without multiplies: every group of the first phase is staged,
+    // then transformed while the new groups of the second phase are staged
     int mcblk = mu / nstrips;
     int part_c0 = mc;
-    stage_unit();
-    stage_groups(ps - 2);
+    const int pgL = (8 * mc) / NKY, pgn = min(ngrp - 1, (8 * mc + 7) / NKY) - pgL + 1;
+    stage_groups(mu, pgL, pgn);
     unsigned a_cur = abase(mcblk, mc);
     float4 af[WD][2];
 #pragma unroll
     for (int s = 0; s < WD; ++s) { af[s][0] = ldA(a_cur + s * 1024); af[s][1] = ldA(min(a_cur + ahalf, amax) + s * 1024); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    stage_groups(ps - 1);
-    tr_plan(ps - 1);
+    bool ton[2]; unsigned trd[2], twr[2];
+    {
+        const bool l1 = mc + 1 == nch;
+        const int u1 = l1 ? mu + 1 : mu, c1 = l1 ? 0 : mc + 1;
+        const int n1 = ps + 1 < pe ? new_count(c1) : 0;
+        stage_groups(u1, new_first(c1), n1);
+        tr_plan(ps - 1, mu * ngrp + pgL, pgn, ton, trd, twr);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-        if (ton[i]) { tr_read(trd[i]); tr_compute(); tr_write(twr[i]); }
+        for (int i = 0; i < 2; ++i)
+            if (ton[i]) { tr_read(trd[i]); tr_compute(); tr_write(twr[i]); }
+        tr_plan(ps, u1 * ngrp + new_first(c1), n1, ton, trd, twr);       // the tasks of the first phase
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     rows7s_lds_barrier();
     unsigned bq[2] = {baddr(mu, mc, 0), baddr(mu, mc, 1)};
@@ -223,7 +244,10 @@ __global__ __launch_bounds__(512, 2) void conv_rows7s_f32_kernel(const RowArgs a
         const int nu = lastc ? mu + 1 : mu, nc = lastc ? 0 : mc + 1;     // the next phase
         const int ncblk = lastc && nu % nstrips == 0 ? mcblk + 1 : mcblk;
         const unsigned a_nxt = p + 1 < P ? abase(ncblk, nc) : a_cur;
-        tr_plan(gp);
+        const bool last2 = nc + 1 == nch;
+        const int u2 = last2 ? nu + 1 : nu, c2 = last2 ? 0 : nc + 1;     // the phase after: its new groups are staged now and transformed in the next phase
+        const int n2 = gp + 2 < pe ? new_count(c2) : 0, g2 = new_first(c2);
+        bool ton_n[2]; unsigned trd_n[2], twr_n[2];
         const unsigned b00 = bq[0], b01 = bq[1], b10 = (bq[0] ^ 64u) + 256u, b11 = (bq[1] ^ 64u) + 256u;   // [tile block][half]: two rows down flips the tile XOR
         float4 bf[2][2];
         bf[0][0] = *reinterpret_cast<const float4*>(smem + b00); bf[0][1] = *reinterpret_cast<const float4*>(smem + b01);
@@ -247,34 +271,49 @@ __global__ __launch_bounds__(512, 2) void conv_rows7s_f32_kernel(const RowArgs a
             }
             // between the MFMAs: staging (the two waves of a SIMD at different points: a wave's next weight-fragment wait also
             // waits for its DMA -- vmcnt counts in order), this wave's transform tasks, the next phase's B addresses
-            if (x == 0 && wave < 4) stage_groups(gp);
-            if (x == 5 && wave >= 4) stage_groups(gp);
+            if (x == 0 && wave < 4) stage_groups(u2, g2, n2);
+            if (x == ROWS7S_DMA_X1 && wave >= 4) stage_groups(u2, g2, n2);
+            if (x == 4) tr_plan(gp + 1, u2 * ngrp + g2, n2, ton_n, trd_n, twr_n);
             if (x == 1 && ton[0]) tr_read(trd[0]);
-            if (x == 2 && ton[0]) tr_compute();
             if (x == 3 && ton[0]) tr_write(twr[0]);
             if (x == 6 && ton[1]) tr_read(trd[1]);
-            if (x == 7 && ton[1]) tr_compute();
             if (x == 8 && ton[1]) tr_write(twr[1]);
             if (x == 9) { bq[0] = baddr(nu, nc, 0); bq[1] = baddr(nu, nc, 1); }
-            acc[x][0] = ROWS7S_MFMA(a0.y, b[0][0].y, acc[x][0], 0, 0, 0);
-            acc[x][1] = ROWS7S_MFMA(a0.y, b[1][0].y, acc[x][1], 0, 0, 0);
-            acc[x][0] = ROWS7S_MFMA(a0.z, b[0][0].z, acc[x][0], 0, 0, 0);
-            acc[x][1] = ROWS7S_MFMA(a0.z, b[1][0].z, acc[x][1], 0, 0, 0);
-            acc[x][0] = ROWS7S_MFMA(a0.w, b[0][0].w, acc[x][0], 0, 0, 0);
-            acc[x][1] = ROWS7S_MFMA(a0.w, b[1][0].w, acc[x][1], 0, 0, 0);
-            acc[x][0] = ROWS7S_MFMA(a1.x, b[0][1].x, acc[x][0], 0, 0, 0);
-            acc[x][1] = ROWS7S_MFMA(a1.x, b[1][1].x, acc[x][1], 0, 0, 0);
-            acc[x][0] = ROWS7S_MFMA(a1.y, b[0][1].y, acc[x][0], 0, 0, 0);
-            acc[x][1] = ROWS7S_MFMA(a1.y, b[1][1].y, acc[x][1], 0, 0, 0);
-            acc[x][0] = ROWS7S_MFMA(a1.z, b[0][1].z, acc[x][0], 0, 0, 0);
-            acc[x][1] = ROWS7S_MFMA(a1.z, b[1][1].z, acc[x][1], 0, 0, 0);
-            acc[x][0] = ROWS7S_MFMA(a1.w, b[0][1].w, acc[x][0], 0, 0, 0);
-            acc[x][1] = ROWS7S_MFMA(a1.w, b[1][1].w, acc[x][1], 0, 0, 0);
+            auto rest = [&]() __attribute__((always_inline)) {           // the other 14 MFMAs of the point
+                acc[x][0] = ROWS7S_MFMA(a0.y, b[0][0].y, acc[x][0], 0, 0, 0);
+                acc[x][1] = ROWS7S_MFMA(a0.y, b[1][0].y, acc[x][1], 0, 0, 0);
+                acc[x][0] = ROWS7S_MFMA(a0.z, b[0][0].z, acc[x][0], 0, 0, 0);
+                acc[x][1] = ROWS7S_MFMA(a0.z, b[1][0].z, acc[x][1], 0, 0, 0);
+                acc[x][0] = ROWS7S_MFMA(a0.w, b[0][0].w, acc[x][0], 0, 0, 0);
+                acc[x][1] = ROWS7S_MFMA(a0.w, b[1][0].w, acc[x][1], 0, 0, 0);
+                acc[x][0] = ROWS7S_MFMA(a1.x, b[0][1].x, acc[x][0], 0, 0, 0);
+                acc[x][1] = ROWS7S_MFMA(a1.x, b[1][1].x, acc[x][1], 0, 0, 0);
+                acc[x][0] = ROWS7S_MFMA(a1.y, b[0][1].y, acc[x][0], 0, 0, 0);
+                acc[x][1] = ROWS7S_MFMA(a1.y, b[1][1].y, acc[x][1], 0, 0, 0);
+                acc[x][0] = ROWS7S_MFMA(a1.z, b[0][1].z, acc[x][0], 0, 0, 0);
+                acc[x][1] = ROWS7S_MFMA(a1.z, b[1][1].z, acc[x][1], 0, 0, 0);
+                acc[x][0] = ROWS7S_MFMA(a1.w, b[0][1].w, acc[x][0], 0, 0, 0);
+                acc[x][1] = ROWS7S_MFMA(a1.w, b[1][1].w, acc[x][1], 0, 0, 0);
+            };
+            if ((x == 2 || x == 7) && ton[x == 2 ? 0 : 1]) {
+                // the task's arithmetic shares the basic block with the MFMAs: four VALU instructions behind each MFMA (a lump
+                // of fifty between two MFMAs leaves the matrix pipe idle unless the SIMD's other wave happens to feed it)
+                tr_compute();
+                rest();
+#pragma unroll
+                for (int k = 0; k < 14; ++k) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0); }
+            } else rest();
             __builtin_amdgcn_sched_barrier(0);
         }
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * WD) : "memory");   // every DMA of the phase is older than the 2 WD fragments still in flight
+#ifdef ROWS7S_NOBARRIER
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // timing experiment: wrong results
+#else
         rows7s_lds_barrier();
+#endif
         a_cur = a_nxt;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { ton[i] = ton_n[i]; trd[i] = trd_n[i]; twr[i] = twr_n[i]; }
         if (!lastc && p + 1 < P) { ++mc; continue; }
 
         // ---- a part of unit mu ends (phases part_c0 .. mc): whole unit -> finish; head part -> add the following ranges'
@@ -378,11 +417,19 @@ __global__ __launch_bounds__(512, 2) void conv_rows7s_f32_kernel(const RowArgs a
         if (lastc) { ++mu; mcblk = ncblk; }
         mc = lastc ? 0 : mc + 1; part_c0 = 0;
     }
+#ifdef ROWS7S_ABLATE
+    if (blockIdx.x == 0 && t == 0) { g_rows7s_clk[0] = __builtin_readcyclecounter() - clk0; g_rows7s_clk[1] = __builtin_amdgcn_s_memrealtime() - rt0; }
+#endif
 }
 
 #ifdef ROWS7S_ABLATE
 static int g_rows7s_abl = 0;
 extern "C" int cnm_tune_rows7s_ablate(int m) { const int old = g_rows7s_abl; g_rows7s_abl = m; return old; }
+extern "C" double cnm_debug_rows7s_mhz() {                                 // average shader clock of workgroup 0 over the last launch
+    unsigned long long c[2] = {0, 0};
+    if (hipMemcpyFromSymbol(c, HIP_SYMBOL(g_rows7s_clk), sizeof(c)) != hipSuccess || !c[1]) return 0.0;
+    return (double)c[0] / (double)c[1] * 100.0;
+}
 #endif
 static int g_rows7_staged = 1;                                           // tuning knob: 0 off, 1 on where eligible
 extern "C" int cnm_tune_rows7_staged(int on) { const int old = g_rows7_staged; if (on == 0 || on == 1) g_rows7_staged = on; return old; }

@@ -337,6 +337,42 @@ def test_conv_rows_wide_equals_narrow(dev, ops, k, stride, cin, cout, N, H, W):
     assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
 
 
+@pytest.mark.parametrize("cin,cin2,cout,N,H,W", [
+    (35, 0, 128, 2, 37, 50),           # ragged rows and columns, ragged channel group, 8 phases per unit cut in two by the sync grid
+    (8, 0, 128, 1, 4, 32),             # one unit, two phases
+    (12, 0, 128, 1, 9, 40),            # odd number of 16-deep chunks: the last phase has one half
+    (52, 12, 256, 2, 21, 70),          # two channel blocks, concatenated input
+    (67, 0, 128, 3, 64, 96)])          # the bench layer's channel count: 15 phases per unit, the padding quad in the last
+def test_conv_rows7_staged(dev, ops, cin, cin2, cout, N, H, W):
+    """LDS-staged 7x7 stride-1 row-wise kernel (conv_rows_staged.hip): bit-equal to the gather-fed kernel without a sync
+    workspace (same reduction order); with one (units cut at range boundaries, partial outputs added in range order) equal to
+    it within fp32 re-association error, bit-reproducible run to run, flag words left zero."""
+    from cnmnet_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(cin * 7 + H)
+    xs = T(rng.standard_normal((N, cin + cin2, H, W)).astype(np.float32)).to(dev)
+    x, x2 = (ops.nchw_to_c4(xs[:, :cin].contiguous()), ops.nchw_to_c4(xs[:, cin:].contiguous())) if cin2 else (ops.nchw_to_c4(xs), None)
+    if cin2:
+        assert cin % 4 == 0
+    w = T((rng.standard_normal((cout, cin + cin2, 7, 7)) * (2.0 / ((cin + cin2) * 49)) ** 0.5).astype(np.float32)).to(dev)
+    up = ops.pack_winograd(w, stride=1, tile=4)
+    bp = T(rng.standard_normal(cout).astype(np.float32)).to(dev)
+    run = lambda s=None: ops.conv_rows_winograd_c4(x, up, bp, cout, 7, True, x2=x2, stride=1, tile=4, sync=s).clone()
+    old = lib.cnm_tune_rows7_staged(0)
+    try:
+        ref = run()
+        lib.cnm_tune_rows7_staged(1)
+        got = run()
+        sync = ops.wino36_sync_workspace(dev)
+        split, split2 = run(sync), run(sync)
+    finally:
+        lib.cnm_tune_rows7_staged(old)
+    assert torch.equal(ref, got), float((ref - got).abs().max())
+    assert torch.allclose(ref, split, rtol=2e-4, atol=2e-4), float((ref - split).abs().max())   # fp32 sums in a different order
+    assert torch.equal(split, split2)
+    assert int(sync[:1024].abs().sum().item()) == 0
+
+
 @pytest.mark.parametrize("cin,cin2,cout,rot,N,H,W", [
     (64, 0, 128, 0, 2, 48, 64),        # one tile block per image row, two units per image row pair
     (67, 0, 128, 3, 1, 40, 72),        # rotated first layer, ragged tile columns (18 tiles: two blocks, second mostly empty)
