@@ -141,11 +141,18 @@ class _EngineNet(nn.Module):
         self._packed, self._weights_arr, self._packed_key = packed, arr, key
 
     def _workspace(self, device, nfloats):
+        """The net's long-lived workspace.  Its head holds state that must be zero when a call starts and is left zero when
+        the call's kernels have run (the plane sweep's tile queue, the sync words of the staged convolutions), so two calls
+        may never overlap in it: a call on a different stream than the previous one first waits for that stream."""
         ws = self._ws.get(str(device))
         if ws is None or ws.numel() < nfloats:
-            # zeros: the head of the workspace is the plane sweep's tile queue (zero on entry, left zero by every call)
             self._ws = {str(device): torch.zeros(nfloats, device=device, dtype=torch.float32)}
             ws = self._ws[str(device)]
+        cur = torch.cuda.current_stream(device)
+        last = getattr(self, "_ws_stream", None)
+        if last is not None and last != cur and not torch.cuda.is_current_stream_capturing():
+            cur.wait_stream(last)
+        self._ws_stream = cur
         return ws
 
     def _require_gpu(self, *tensors):

@@ -109,6 +109,10 @@ int cnm_idepth_range_host(double idepth_scale, double* idepth_min, double* idept
  *     persistent sweep (tickets drawn, workgroups gone).  The words must be ZERO when a call starts; the
  *     call leaves them zero, so a workspace is zeroed once, when it is allocated, and may then be reused by
  *     any number of calls that are ordered on one stream (two calls in flight at once need two workspaces).
+ *     Nothing on the device checks this: with stale words tickets start offset and tiles are skipped, so a
+ *     workspace whose last call did not run to completion (failed launch, abandoned capture) must be zeroed
+ *     again.  The Python modules keep one workspace per net and order calls from different streams on it
+ *     (depthnet/depthNet_model.py _EngineNet._workspace).
  *     ws == NULL is allowed: tiles are then dealt to the workgroups with a fixed stride (no scratch, slower
  *     when tiles differ in cost). */
 size_t cnm_planesweep_workspace_floats(int B, int S, int H, int W);
