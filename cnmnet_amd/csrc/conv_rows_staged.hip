@@ -59,12 +59,21 @@ constexpr float kAT[4][10] = {{1, 1, 1, 1, 1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 
 #ifndef ROWS7S_DMA_X1
 #define ROWS7S_DMA_X1 5
 #endif
+// Instruction arbitration between the two waves of a SIMD: with the other wave streaming MFMAs, a wave's VALU-class instructions
+// (address arithmetic, v_readlane of spilled scalars, the transform) wait for a gap in that stream -- tens of cycles each
+// (tools/rows7s_timeline.py).  ROWS7S_PRIO raises the priority of a wave while it is in such a section.
+#ifdef ROWS7S_PRIO
+#define ROWS7S_PRIO_HI() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(3); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define ROWS7S_PRIO_LO() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define ROWS7S_PRIO_HI()
+#define ROWS7S_PRIO_LO()
+#endif
 __device__ __forceinline__ void rows7s_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // one LDS-DMA wave-instruction (conv_winograd4s.hip): 64 lanes x 16 bytes from buffer offset voff + soff to lds_addr + 16 lane
-__device__ __forceinline__ void rows7s_dma16(unsigned lds_addr, unsigned voff, const float* base, unsigned bytes, unsigned soff) {
-    const unsigned long long b = reinterpret_cast<unsigned long long>(base);
-    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
+__device__ __forceinline__ void rows7s_dma16(unsigned lds_addr, unsigned voff, unsigned base_lo, unsigned base_hi, unsigned bytes, unsigned soff) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)base_lo), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)base_hi);
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>((unsigned long long)lo | ((unsigned long long)hi << 32)), 0,
                                                                           __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
     const unsigned la = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr), so = (unsigned)__builtin_amdgcn_readfirstlane((int)soff);
@@ -73,6 +82,9 @@ __device__ __forceinline__ void rows7s_dma16(unsigned lds_addr, unsigned voff, c
                  : "=&s"(keep) : "s"(la), "v"(voff), "s"(rsrc), "s"(so) : "memory");
 }
 
+#ifdef ROWS7S_TIMELINE
+__device__ unsigned g_rows7s_tl[2][8][12];                               // [wave 0 / wave 4][phase][point starts 0..9, phase end, after barrier]: low word of s_memtime
+#endif
 #ifdef ROWS7S_ABLATE
 __device__ unsigned long long g_rows7s_clk[2];                           // shader cycles and 100 MHz ticks of workgroup 0's last launch
 #endif
@@ -88,11 +100,15 @@ __global__ __launch_bounds__(512, 2) void conv_rows7s_f32_kernel(const RowArgs a
     constexpr int WD = ROWS7S_WD;                                                // frequency points of weight fragments in flight (two fragments each)
     constexpr int SLOT_BYTES = 8 * 16 * 64 * 16;                         // partial output of one range (as in conv_winograd4s.hip; half of it used)
     static_assert(NX % WD == 0 && TVS % 256 == 128 && TV0 % 128 == 0 && LDS_BYTES <= 120 * 1024, "layout");
+#ifdef ROWS7S_TIMELINE
+    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES + 2 * 8 * 12 * 4];
+#else
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+#endif
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int HW = a.H * a.W, SHW = SH * SW, ncb16 = a.Cout / 16;
     const int ngrp = a.Gin, nquad = NKY * ngrp, nch = (nquad + 7) / 8;   // channel groups, quads, phases per unit
-    const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem;
+    [[maybe_unused]] const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem;
 
     const int G = gridDim.x, rng = xcd_remap(blockIdx.x, G);
     const long long T = (long long)nunits * nch;
@@ -113,27 +129,66 @@ __global__ __launch_bounds__(512, 2) void conv_rows7s_f32_kernel(const RowArgs a
     // ---- stage role: one plane = NPIECE pieces of 64 slots, wave w moves piece w
     const int pslot = 64 * wave + lane, prow = pslot / PCP, pcol = pslot - prow * PCP;
     const bool pok = wave < NPIECE && prow < PR && pcol < PC;
-    unsigned svoff = 0; int simg = 0, su_cur = -1;                       // this lane's offset inside a channel-group plane of the image; image; the unit they belong to
+    // Everything the staging needs from the kernel arguments lives in laundered scalars: left to itself the compiler
+    // re-reads the argument block (two dependent s_load + s_waitcnt lgkmcnt(0), which also drains the LDS queue) at every use.
+    unsigned in1_lo = (unsigned)reinterpret_cast<unsigned long long>(a.in), in1_hi = (unsigned)(reinterpret_cast<unsigned long long>(a.in) >> 32), in1_bytes = a.in_bytes;
+    unsigned in2_lo = (unsigned)reinterpret_cast<unsigned long long>(a.in2), in2_hi = (unsigned)(reinterpret_cast<unsigned long long>(a.in2) >> 32), in2_bytes = a.in2_bytes;
+    unsigned hw16 = (unsigned)HW * 16u;
+    int gsplit = a.Gsplit;
+    asm volatile("" : "+s"(in1_lo), "+s"(in1_hi), "+s"(in1_bytes), "+s"(in2_lo), "+s"(in2_hi), "+s"(in2_bytes), "+s"(hw16), "+s"(gsplit));
+    unsigned svoff = 0, sbase1 = 0, sbase2 = 0; int su_cur = -1;         // this lane's offset inside a channel-group plane; byte offsets of group 0 of either view in the unit's image; the unit they belong to
     auto stage_unit = [&](int u) {
         const int strip = u % nstrips;
-        simg = strip / SHW;
+        const int simg = strip / SHW;
         const int rem = strip - simg * SHW, sy = rem / SW, sx = rem - sy * SW;
         const int y = TSY * sy - 3 + prow, x = 4 * TSX * sx - 3 + pcol;
         svoff = pok && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W ? (unsigned)(y * a.W + x) * 16u : 0xFFFFFFFFu;
+        sbase1 = (unsigned)(simg * a.Gin_tot + a.gin0) * hw16;
+        sbase2 = (unsigned)(simg * a.Gin2_tot + a.gin2_0 - a.Gsplit) * hw16;
         su_cur = u;
     };
-    auto stage_groups = [&](int u, int g0, int n) {                      // groups g0 .. g0 + n - 1 of unit u, n <= 2
+#ifdef ROWS7S_STAGE_DMA
+    auto stage_groups = [&](int u, int g0, int n) {                      // groups g0 .. g0 + n - 1 of unit u, n <= 2, by LDS-DMA
         if (n <= 0 || wave >= NPIECE || (ABL & 2)) return;
         if (u != su_cur) stage_unit(u);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             if (i >= n) break;
             const int g = g0 + i;
-            const bool s1 = g < a.Gsplit;
-            const unsigned gg = s1 ? (unsigned)(simg * a.Gin_tot + a.gin0 + g) : (unsigned)(simg * a.Gin2_tot + a.gin2_0 + g - a.Gsplit);
-            rows7s_dma16(lds0 + RAW0 + (unsigned)(((u * ngrp + g) & 3) * PLANE + wave * 1024), svoff, s1 ? a.in : a.in2, s1 ? a.in_bytes : a.in2_bytes, gg * (unsigned)HW * 16u);
+            const bool s1 = g < gsplit;
+            rows7s_dma16(lds0 + RAW0 + (unsigned)(((u * ngrp + g) & 3) * PLANE + wave * 1024), svoff, s1 ? in1_lo : in2_lo, s1 ? in1_hi : in2_hi, s1 ? in1_bytes : in2_bytes,
+                         (s1 ? sbase1 : sbase2) + (unsigned)g * hw16);
         }
     };
+    auto stage_store = [&](int, int, int) {};
+#else
+    // Through registers: the loads of a phase's (at most two) pieces are issued at the start of the phase and written to LDS
+    // seven frequency points later.  (An LDS-DMA instruction held its wave for 500 - 1000 cycles -- one memory latency -- before
+    // the wave's next instruction issued: tools/rows7s_timeline.py, tools/wino36s_timeline.py.)
+    u32x4 sreg[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+    auto stage_groups = [&](int u, int g0, int n) {
+        if (n <= 0 || wave >= NPIECE || (ABL & 2)) return;
+        if (u != su_cur) stage_unit(u);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (i >= n) break;
+            const int g = g0 + i;
+            const bool s1 = g < gsplit;
+            const unsigned lo = s1 ? in1_lo : in2_lo, hi = s1 ? in1_hi : in2_hi;
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>((unsigned long long)lo | ((unsigned long long)hi << 32)), 0,
+                                                                                  s1 ? in1_bytes : in2_bytes, 0x00020000);
+            sreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, svoff, (s1 ? sbase1 : sbase2) + (unsigned)g * hw16, 0);
+        }
+    };
+    auto stage_store = [&](int u, int g0, int n) {
+        if (n <= 0 || wave >= NPIECE || (ABL & 2)) return;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (i >= n) break;
+            *reinterpret_cast<u32x4*>(smem + RAW0 + ((u * ngrp + g0 + i) & 3) * PLANE + wave * 1024 + lane * 16) = sreg[i];
+        }
+    };
+#endif
 
     // ---- transform role: a wave-task = two patch rows of one group: lane = (channel e, tile x, row): lanes 0-31 tiles 0-3, 32-63 tiles 4-7
     const int te = lane & 3, ttx = ((lane >> 2) & 3) | ((lane >> 5) << 2), trr = (lane >> 4) & 1;
@@ -216,6 +271,7 @@ __global__ __launch_bounds__(512, 2) void conv_rows7s_f32_kernel(const RowArgs a
     int part_c0 = mc;
     const int pgL = (8 * mc) / NKY, pgn = min(ngrp - 1, (8 * mc + 7) / NKY) - pgL + 1;
     stage_groups(mu, pgL, pgn);
+    stage_store(mu, pgL, pgn);
     unsigned a_cur = abase(mcblk, mc);
     float4 af[WD][2];
 #pragma unroll
@@ -228,6 +284,7 @@ __global__ __launch_bounds__(512, 2) void conv_rows7s_f32_kernel(const RowArgs a
         const int u1 = l1 ? mu + 1 : mu, c1 = l1 ? 0 : mc + 1;
         const int n1 = ps + 1 < pe ? new_count(c1) : 0;
         stage_groups(u1, new_first(c1), n1);
+        stage_store(u1, new_first(c1), n1);
         tr_plan(ps - 1, mu * ngrp + pgL, pgn, ton, trd, twr);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -253,8 +310,15 @@ __global__ __launch_bounds__(512, 2) void conv_rows7s_f32_kernel(const RowArgs a
         bf[0][0] = *reinterpret_cast<const float4*>(smem + b00); bf[0][1] = *reinterpret_cast<const float4*>(smem + b01);
         bf[1][0] = *reinterpret_cast<const float4*>(smem + b10); bf[1][1] = *reinterpret_cast<const float4*>(smem + b11);
         __builtin_amdgcn_sched_barrier(0);
+#ifdef ROWS7S_TIMELINE
+        unsigned tl[12];
+#endif
 #pragma unroll
         for (int x = 0; x < NX; ++x) {                                   // one frequency point per step: 16 MFMAs
+#ifdef ROWS7S_TIMELINE
+            tl[x] = (unsigned)__builtin_readcyclecounter();
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             const float4 a0 = af[x % WD][0], a1 = af[x % WD][1];
             float4 b[2][2];
 #pragma unroll
@@ -271,14 +335,21 @@ __global__ __launch_bounds__(512, 2) void conv_rows7s_f32_kernel(const RowArgs a
             }
             // between the MFMAs: staging (the two waves of a SIMD at different points: a wave's next weight-fragment wait also
             // waits for its DMA -- vmcnt counts in order), this wave's transform tasks, the next phase's B addresses
+            ROWS7S_PRIO_HI();
+#ifdef ROWS7S_STAGE_DMA
             if (x == 0 && wave < 4) stage_groups(u2, g2, n2);
             if (x == ROWS7S_DMA_X1 && wave >= 4) stage_groups(u2, g2, n2);
+#else
+            if (x == 0) stage_groups(u2, g2, n2);
+            if (x == 7) stage_store(u2, g2, n2);
+#endif
             if (x == 4) tr_plan(gp + 1, u2 * ngrp + g2, n2, ton_n, trd_n, twr_n);
             if (x == 1 && ton[0]) tr_read(trd[0]);
             if (x == 3 && ton[0]) tr_write(twr[0]);
             if (x == 6 && ton[1]) tr_read(trd[1]);
             if (x == 8 && ton[1]) tr_write(twr[1]);
             if (x == 9) { bq[0] = baddr(nu, nc, 0); bq[1] = baddr(nu, nc, 1); }
+            ROWS7S_PRIO_LO();
             auto rest = [&]() __attribute__((always_inline)) {           // the other 14 MFMAs of the point
                 acc[x][0] = ROWS7S_MFMA(a0.y, b[0][0].y, acc[x][0], 0, 0, 0);
                 acc[x][1] = ROWS7S_MFMA(a0.y, b[1][0].y, acc[x][1], 0, 0, 0);
@@ -298,18 +369,33 @@ __global__ __launch_bounds__(512, 2) void conv_rows7s_f32_kernel(const RowArgs a
             if ((x == 2 || x == 7) && ton[x == 2 ? 0 : 1]) {
                 // the task's arithmetic shares the basic block with the MFMAs: four VALU instructions behind each MFMA (a lump
                 // of fifty between two MFMAs leaves the matrix pipe idle unless the SIMD's other wave happens to feed it)
+                ROWS7S_PRIO_HI();
                 tr_compute();
+                ROWS7S_PRIO_LO();
                 rest();
+#ifndef ROWS7S_PRIO
 #pragma unroll
                 for (int k = 0; k < 14; ++k) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0); }
+#endif
             } else rest();
             __builtin_amdgcn_sched_barrier(0);
         }
+#ifdef ROWS7S_TIMELINE
+        tl[10] = (unsigned)__builtin_readcyclecounter();
+#endif
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * WD) : "memory");   // every DMA of the phase is older than the 2 WD fragments still in flight
 #ifdef ROWS7S_NOBARRIER
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // timing experiment: wrong results
 #else
         rows7s_lds_barrier();
+#endif
+        ROWS7S_PRIO_HI();
+#ifdef ROWS7S_TIMELINE
+        tl[11] = (unsigned)__builtin_readcyclecounter();
+        if (blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0 && p >= P / 2 && p < P / 2 + 8) {   // parked in LDS, copied out at the end
+#pragma unroll
+            for (int i = 0; i < 12; ++i) reinterpret_cast<unsigned*>(smem + LDS_BYTES)[((wave >> 2) * 8 + p - P / 2) * 12 + i] = tl[i];
+        }
 #endif
         a_cur = a_nxt;
 #pragma unroll
@@ -417,6 +503,10 @@ __global__ __launch_bounds__(512, 2) void conv_rows7s_f32_kernel(const RowArgs a
         if (lastc) { ++mu; mcblk = ncblk; }
         mc = lastc ? 0 : mc + 1; part_c0 = 0;
     }
+#ifdef ROWS7S_TIMELINE
+    __syncthreads();
+    if (blockIdx.x == 0 && t < 2 * 8 * 12) (&g_rows7s_tl[0][0][0])[t] = reinterpret_cast<unsigned*>(smem + LDS_BYTES)[t];
+#endif
 #ifdef ROWS7S_ABLATE
     if (blockIdx.x == 0 && t == 0) { g_rows7s_clk[0] = __builtin_readcyclecounter() - clk0; g_rows7s_clk[1] = __builtin_amdgcn_s_memrealtime() - rt0; }
 #endif
@@ -429,6 +519,11 @@ extern "C" double cnm_debug_rows7s_mhz() {                                 // av
     unsigned long long c[2] = {0, 0};
     if (hipMemcpyFromSymbol(c, HIP_SYMBOL(g_rows7s_clk), sizeof(c)) != hipSuccess || !c[1]) return 0.0;
     return (double)c[0] / (double)c[1] * 100.0;
+}
+#endif
+#ifdef ROWS7S_TIMELINE
+extern "C" int cnm_debug_rows7s_timeline(unsigned* out) {                  // 2 x 8 x 12 words of the last launch
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rows7s_tl), sizeof(unsigned) * 2 * 8 * 12) == hipSuccess ? 0 : -1;
 }
 #endif
 static int g_rows7_staged = 1;                                           // tuning knob: 0 off, 1 on where eligible

@@ -38,6 +38,12 @@
 #ifndef WINO4S_CBLK_SLOW
 #define WINO4S_CBLK_SLOW 1 // unit order: 1 = channel block slowest (an XCD's neighbouring ranges stream ONE block's filters: a fragment is fetched from
 #endif                     // beyond L2 once per ~32 workgroups), 0 = channel block fastest (the workgroups of a tile block share its input instead)
+#ifndef WINO4S_EARLY_BARRIER
+#define WINO4S_EARLY_BARRIER 0  // 1: the phase barrier before the last double step + prefetch of the next phase's first B fragments behind it: measured 1.5 % slower (two more live registers spill)
+#endif
+#ifndef WINO4S_LO_STEP
+#define WINO4S_LO_STEP 0
+#endif
 #ifndef WINO4S_HI_STEP
 #define WINO4S_HI_STEP 6  // double step at which waves 4-7 start issuing their DMA pieces (waves 0-3: step 0); >= 4
 #endif
@@ -71,9 +77,8 @@ __device__ __forceinline__ void wino4s_lds_barrier() { asm volatile("s_waitcnt l
 // The descriptor and the two scalar operands are pinned to SGPRs with readfirstlane (under register pressure the compiler
 // may hold wave-uniform values in VGPRs, which the "s" constraints cannot take); the leading s_nop covers the
 // readfirstlane -> buffer-instruction hazard, which hipcc does not pad inside an asm statement.
-__device__ __forceinline__ void wino4s_dma16(unsigned lds_addr, unsigned voff, const float* base, unsigned bytes, unsigned soff) {
-    const unsigned long long b = reinterpret_cast<unsigned long long>(base);
-    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
+__device__ __forceinline__ void wino4s_dma16(unsigned lds_addr, unsigned voff, unsigned base_lo, unsigned base_hi, unsigned bytes, unsigned soff) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)base_lo), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)base_hi);
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>((unsigned long long)lo | ((unsigned long long)hi << 32)), 0,
                                                                           __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
     const unsigned la = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr), so = (unsigned)__builtin_amdgcn_readfirstlane((int)soff);
@@ -92,6 +97,9 @@ __device__ __forceinline__ void wino4s_dma16(unsigned lds_addr, unsigned voff, c
 // across the phase loop), and the two transform constants are wave-uniform (SGPR operands).
 // M = 4: F(4x4,3x3); M = 2: F(2x2,5x5) -- the same six interpolation points, 6 x 6 window and 36 frequency points; only
 // the tile pitch (M), the filter transform (in the packed filter) and the output transform (2 x 6 instead of 4 x 6) differ.
+#ifdef WINO4S_TIMELINE
+__device__ unsigned g_wino4s_tl[2 * 8 * 24];                             // [wave 0 / wave 4][phase][double-step starts 0..17, phase end, after barrier]: low word of s_memtime
+#endif
 template <int TSX, bool UPS, int ABL = 0, int M = 4>                     // tile block = (16 / TSX) x TSX tiles of M x M outputs
 __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino4Args a, const int SH, const int SW, const int tilesC, const int nunits,
                                                                        unsigned* __restrict__ sync_flags, float* __restrict__ sync_slots) {
@@ -108,7 +116,12 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
     constexpr int WD = WINO4S_WD, NXI = 36;
     constexpr int SLOT_BYTES = 8 * 16 * 64 * 16;                         // one range's partial output: 8 waves x 16 pixels x 64 lanes x float4 = 128 KB
     static_assert(PLANE % 128 == 0 && NXI % WD == 0 && WD % 2 == 0, "layout");
+#ifdef WINO4S_TIMELINE
+    constexpr int TL0 = DV0 + DPW * 512 * 4;
+    __shared__ __attribute__((aligned(16))) char smem[TL0 + 2 * 8 * 24 * 4];
+#else
     __shared__ __attribute__((aligned(16))) char smem[DV0 + DPW * 512 * 4];   // 136 KB (TSX 16) / 126 KB (TSX 8)
+#endif
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int hi = wave >> 2;
     const int HW = a.H * a.W, SHW = SH * SW, ncb16 = a.Cout / 16;
@@ -126,11 +139,22 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
     if (P <= 0) return;
 
     // ---- stage role: pieces n = wave + 8 m of the chunk's NDMA (plane q = n / NPIECE, piece k = n % NPIECE)
-    int du = ps / nch, dc = ps - du * nch, dgp = ps, dimg = 0;           // cursor of the stage role: unit, chunk, global phase; image of that unit
+    // What a DMA instruction needs from the kernel arguments lives in laundered scalars: left to itself the compiler re-reads the
+    // argument block at every piece -- two dependent s_load + s_waitcnt lgkmcnt(0) (which also drains the LDS queue): with
+    // four pieces that was 2500 - 4000 cycles of a 9200-cycle phase (tools/wino36s_timeline.py)
+    unsigned in1_lo = (unsigned)reinterpret_cast<unsigned long long>(a.in), in1_hi = (unsigned)(reinterpret_cast<unsigned long long>(a.in) >> 32), in1_bytes = a.in_bytes;
+    unsigned in2_lo = (unsigned)reinterpret_cast<unsigned long long>(a.in2), in2_hi = (unsigned)(reinterpret_cast<unsigned long long>(a.in2) >> 32), in2_bytes = a.in2_bytes;
+    unsigned hw16 = (unsigned)HW * 16u;
+    int gsplit = a.Gsplit, gin = a.Gin;
+    asm volatile("" : "+s"(in1_lo), "+s"(in1_hi), "+s"(in1_bytes), "+s"(in2_lo), "+s"(in2_hi), "+s"(in2_bytes), "+s"(hw16), "+s"(gsplit), "+s"(gin));
+    int du = ps / nch, dc = ps - du * nch, dgp = ps;                     // cursor of the stage role: unit, chunk, global phase
+    unsigned dbase1 = 0, dbase2 = 0;                                     // byte offsets of channel group 0 of either view in that unit's image
     auto dma_unit = [&]() {                                              // per-lane offsets for unit du -> LDS (each thread re-reads only its own words)
         const int nstrips = nunits / tilesC;
         const int strip = WINO4S_CBLK_SLOW ? du % nstrips : du / tilesC;
-        dimg = strip / SHW;
+        const int dimg = strip / SHW;
+        dbase1 = (unsigned)(dimg * a.Gin_tot + a.gin0) * hw16;
+        dbase2 = (unsigned)(dimg * a.Gin2_tot + a.gin2_0 - a.Gsplit) * hw16;
         const int rem = strip - dimg * SHW, sy = rem / SW, sx = rem - sy * SW;
         const int y0 = M * TSY * sy - (6 - M) / 2, x0 = M * TSX * sx - (6 - M) / 2;   // the window starts R / 2 pixels before the tile
 #pragma unroll
@@ -148,11 +172,11 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
         const int n = wave + 8 * m;
         if ((ABL & 2) || n >= NDMA || dgp >= pe) return;
         const int q = n / NPIECE, g = dc * 4 + q;
-        const bool s1 = g < a.Gsplit;
-        const unsigned bytes = g < a.Gin ? (s1 ? a.in_bytes : a.in2_bytes) : 0u;
-        const unsigned gg = s1 ? (unsigned)(dimg * a.Gin_tot + a.gin0 + g) : (unsigned)(dimg * a.Gin2_tot + a.gin2_0 + g - a.Gsplit);
+        const bool s1 = g < gsplit;
+        const unsigned bytes = g < gin ? (s1 ? in1_bytes : in2_bytes) : 0u;
         const unsigned voff = *reinterpret_cast<const unsigned*>(smem + DV0 + (m * 512 + t) * 4);
-        wino4s_dma16(lds0 + RAW0 + (unsigned)(((dgp - ps) & 1) * RAWBUF + WINO4S_PLANE_OFF(q) + (n - q * NPIECE) * 1024), voff, s1 ? a.in : a.in2, bytes, gg * (unsigned)HW * 16u);
+        wino4s_dma16(lds0 + RAW0 + (unsigned)(((dgp - ps) & 1) * RAWBUF + WINO4S_PLANE_OFF(q) + (n - q * NPIECE) * 1024), voff, s1 ? in1_lo : in2_lo, s1 ? in1_hi : in2_hi, bytes,
+                     (s1 ? dbase1 : dbase2) + (unsigned)g * hw16);
     };
     auto dma_advance = [&]() { ++dgp; if (++dc == nch) { dc = 0; ++du; if (dgp < pe) dma_unit(); } };
 
@@ -220,24 +244,49 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
     }
     wino4s_lds_barrier();
 
+    // WINO4S_EARLY_BARRIER = 1 (experiment, off): the phase barrier at the start of the LAST double step (every LDS write of the
+    // phase and every read of V(p) has been issued by then) and the first B fragments of phase p + 1 read behind it, under the
+    // step's MFMAs.  The last phase of a part keeps the barrier behind the loop (the output transform wants the registers).
+    float4 bf0, bf1;
+    bool bf_ready = false;
     for (int p = 0; p < P; ++p) {
         const unsigned vc = (p & 1) * VBUF + bvoff;
         const unsigned r0 = rbase + ((p + 1) & 1) * RAWBUF, rT = r0 + hi * PC * 16;      // raw buffer of phase p + 1
         const unsigned w0 = wbase + ((p + 1) & 1) * VBUF;                                 // V buffer of phase p + 1
         const bool lastc = mc + 1 == nch;
-        const int ncblk = WINO4S_CBLK_SLOW ? (mu + 1) / nstrips_m : (mcblk + 1 == tilesC ? 0 : mcblk + 1);   // channel block of unit mu + 1
-        const unsigned a_nxt = p + 1 < P ? (lastc ? abase(ncblk, 0) : abase(mcblk, mc + 1)) : a_cur;
-        float4 bf0 = *reinterpret_cast<const float4*>(smem + vc);
-        float4 bf1 = *reinterpret_cast<const float4*>(smem + vc + 1024);
+        int ncblk = mcblk;                                               // channel block of unit mu + 1 (worked out at unit boundaries only: a division)
+        if (lastc) ncblk = WINO4S_CBLK_SLOW ? (mu + 1) / nstrips_m : (mcblk + 1 == tilesC ? 0 : mcblk + 1);
+        const unsigned a_nxt = p + 1 < P ? (lastc ? abase(ncblk, 0) : a_cur + (unsigned)(ncb16 * NXI) * 1024u) : a_cur;
+        const bool early = WINO4S_EARLY_BARRIER && !lastc && p + 1 < P;   // wave-uniform
+        if (!bf_ready) {
+            bf0 = *reinterpret_cast<const float4*>(smem + vc);
+            bf1 = *reinterpret_cast<const float4*>(smem + vc + 1024);
+        }
         __builtin_amdgcn_sched_barrier(0);
+#ifdef WINO4S_TIMELINE
+        const bool tl_on = blockIdx.x == 0 && (wave == 0 || wave == 4) && p >= P / 2 && p < P / 2 + 8;
+        unsigned* const tl_row = reinterpret_cast<unsigned*>(smem + TL0) + ((wave >> 2) * 8 + (tl_on ? p - P / 2 : 0)) * 24;
+#define WINO4S_TL(i) do { const unsigned tv_ = (unsigned)__builtin_readcyclecounter(); if (tl_on && lane == 0) tl_row[i] = tv_; } while (0)
+#endif
 #pragma unroll
         for (int xp = 0; xp < NXI / 2; ++xp) {
+#ifdef WINO4S_TIMELINE
+            WINO4S_TL(xp);
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             const int x0 = 2 * xp, x1 = x0 + 1;
             const float4 a0 = af[x0 % WD], a1 = af[x1 % WD];
             const float4 b0 = bf0, b1 = bf1;
             if (xp + 1 < NXI / 2 && !(ABL & 8)) {
                 bf0 = *reinterpret_cast<const float4*>(smem + vc + (x0 + 2) * 1024);
                 bf1 = *reinterpret_cast<const float4*>(smem + vc + (x1 + 2) * 1024);
+            }
+            if (xp + 1 == NXI / 2 && early) {
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WD) : "memory");   // the phase's DMA data (older than the WD fragments in flight)
+                wino4s_lds_barrier();
+                const unsigned vn = ((p + 1) & 1) * VBUF + bvoff;
+                bf0 = *reinterpret_cast<const float4*>(smem + vn);
+                bf1 = *reinterpret_cast<const float4*>(smem + vn + 1024);
             }
             acc[x0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc[x0], 0, 0, 0);
             acc[x1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, acc[x1], 0, 0, 0);
@@ -259,8 +308,32 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
             if (xp >= 3 && xp <= 8) trP_read(xp - 3, r0);
             if (xp == 10) tr_row(rowP, w0 + 6144 + hi * 2 * 6144);
             if (xp == 11) tr_row(rowM, w0 + 2 * 6144 + hi * 2 * 6144);
-            if (xp < DPW) { if (!hi) { dma_piece(xp); if (xp == DPW - 1) dma_advance(); } }
-            else if (xp >= WINO4S_HI_STEP && xp < WINO4S_HI_STEP + DPW) { if (hi) { dma_piece(xp - WINO4S_HI_STEP); if (xp - WINO4S_HI_STEP == DPW - 1) dma_advance(); } }
+#if defined(WINO4S_DMA_SPREAD)                                            // one piece every WINO4S_DMA_SPREAD double steps (waves 4-7: half a stride later)
+            {
+                constexpr int SP = WINO4S_DMA_SPREAD;
+                const int xs = xp - (hi ? SP / 2 : 0);
+#pragma unroll
+                for (int m = 0; m < DPW; ++m)
+                    if (xs == SP * m) { dma_piece(m); if (m == DPW - 1) dma_advance(); }
+            }
+#else
+            // all pieces of a wave in ONE step: vmcnt retires in order, so the weight fragments loaded after a DMA instruction wait
+            // for its data -- once per phase instead of once per piece (tools/wino36s_timeline.py)
+            if ((xp == WINO4S_LO_STEP && !hi) || (xp == WINO4S_HI_STEP && hi)) {
+#ifdef WINO4S_TIMELINE
+                __builtin_amdgcn_sched_barrier(0); WINO4S_TL(20); __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+                for (int m = 0; m < DPW; ++m) dma_piece(m);
+#ifdef WINO4S_TIMELINE
+                __builtin_amdgcn_sched_barrier(0); WINO4S_TL(21); __builtin_amdgcn_sched_barrier(0);
+#endif
+                dma_advance();
+#ifdef WINO4S_TIMELINE
+                __builtin_amdgcn_sched_barrier(0); WINO4S_TL(22); __builtin_amdgcn_sched_barrier(0);
+#endif
+            }
+#endif
             acc[x0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc[x0], 0, 0, 0);
             acc[x1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, acc[x1], 0, 0, 0);
             acc[x0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc[x0], 0, 0, 0);
@@ -270,8 +343,17 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
             __builtin_amdgcn_sched_barrier(0);
         }
         // every DMA this wave issued in the phase is older than the WD weight fragments still in flight: vmcnt retires in order
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WD) : "memory");
-        wino4s_lds_barrier();                                            // V / RAW of phase p + 1 complete; the buffers of phase p are free
+#ifdef WINO4S_TIMELINE
+        WINO4S_TL(18);
+#endif
+        if (!early) {
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WD) : "memory");
+            wino4s_lds_barrier();                                        // V / RAW of phase p + 1 complete; the buffers of phase p are free
+        }
+        bf_ready = early;
+#ifdef WINO4S_TIMELINE
+        WINO4S_TL(19);
+#endif
         a_cur = a_nxt;
         if (!lastc && p + 1 < P) { ++mc; continue; }
 
@@ -396,8 +478,15 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
         if (lastc) { ++mu; mcblk = ncblk; }
         mc = 0; part_c0 = 0;
     }
+#ifdef WINO4S_TIMELINE
+    __syncthreads();
+    if (blockIdx.x == 0 && t < 2 * 8 * 24) g_wino4s_tl[t] = reinterpret_cast<unsigned*>(smem + TL0)[t];
+#endif
 }
 
+#ifdef WINO4S_TIMELINE
+extern "C" int cnm_debug_wino4s_timeline(unsigned* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wino4s_tl), sizeof(unsigned) * 2 * 8 * 24) == hipSuccess ? 0 : -1; }
+#endif
 static int g_wino36_staged = 1;                                          // tuning knob (A/B against the gather-fed kernel): 0 off, 1 where it pays, 2 wherever eligible
 extern "C" int cnm_tune_wino36_staged(int on) { const int old = g_wino36_staged; if (on >= 0 && on <= 2) g_wino36_staged = on; return old; }
 
