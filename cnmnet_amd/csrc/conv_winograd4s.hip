@@ -41,6 +41,9 @@
 #ifndef WINO4S_EARLY_BARRIER
 #define WINO4S_EARLY_BARRIER 0  // 1: the phase barrier before the last double step + prefetch of the next phase's first B fragments behind it: measured 1.5 % slower (two more live registers spill)
 #endif
+#ifndef WINO4S_LO_SHARE
+#define WINO4S_LO_SHARE 4           // sevenths of a phase's DMA pieces issued by waves 0-3 (4 = 16 of 28: about even; 5 - 7 measured within 0.5 %)
+#endif
 #ifndef WINO4S_LO_STEP
 #define WINO4S_LO_STEP 0
 #endif
@@ -111,7 +114,11 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
     constexpr int NPIECE = (NSLOT + 63) / 64, PLANE = NPIECE * 1024 + 128, RAWBUF = 4 * PLANE;   // bytes
 #define WINO4S_PLANE_OFF(q) ((q) * PLANE + (M == 4 ? (q) * 16 : ((q) & 1) * 16 + ((q) >> 1) * 64))
     constexpr int VBUF = 36 * 16 * 64, RAW0 = 2 * VBUF;                  // bytes
-    constexpr int NDMA = 4 * NPIECE, DPW = (NDMA + 7) / 8;               // DMA pieces per chunk / per wave
+    // DMA pieces per chunk, and per wave: waves 0-3 take NLO each, waves 4-7 NHI.  The two waves of a SIMD do not share the matrix pipe
+    // evenly -- the older one (0-3) runs ahead and then waits ~2500 cycles at the phase barrier for the other -- and a DMA instruction
+    // holds its wave for ~600 cycles (tools/wino36s_timeline.py); giving the waiting wave more of the pieces (WINO4S_LO_SHARE
+    // sevenths) did not pay, though: 5.63 / 5.60 / 5.62 ms per step's launches for 5 / 6 / 7 against 5.64 for the even split.
+    constexpr int NDMA = 4 * NPIECE, NLO = (NDMA * WINO4S_LO_SHARE / 7 + 3) / 4, NHI = (NDMA - 4 * NLO + 3) / 4 > 0 ? (NDMA - 4 * NLO + 3) / 4 : 0, DPW = NLO > NHI ? NLO : NHI;
     constexpr int DV0 = RAW0 + 2 * RAWBUF;                               // [DPW][512] per-thread DMA offsets of the unit being staged
     constexpr int WD = WINO4S_WD, NXI = 36;
     constexpr int SLOT_BYTES = 8 * 16 * 64 * 16;                         // one range's partial output: 8 waves x 16 pixels x 64 lanes x float4 = 128 KB
@@ -149,6 +156,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
     asm volatile("" : "+s"(in1_lo), "+s"(in1_hi), "+s"(in1_bytes), "+s"(in2_lo), "+s"(in2_hi), "+s"(in2_bytes), "+s"(hw16), "+s"(gsplit), "+s"(gin));
     int du = ps / nch, dc = ps - du * nch, dgp = ps;                     // cursor of the stage role: unit, chunk, global phase
     unsigned dbase1 = 0, dbase2 = 0;                                     // byte offsets of channel group 0 of either view in that unit's image
+    auto dma_n = [&](int m) { return hi ? 4 * NLO + (wave - 4) + 4 * m : wave + 4 * m; };   // piece m of this wave
     auto dma_unit = [&]() {                                              // per-lane offsets for unit du -> LDS (each thread re-reads only its own words)
         const int nstrips = nunits / tilesC;
         const int strip = WINO4S_CBLK_SLOW ? du % nstrips : du / tilesC;
@@ -159,7 +167,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
         const int y0 = M * TSY * sy - (6 - M) / 2, x0 = M * TSX * sx - (6 - M) / 2;   // the window starts R / 2 pixels before the tile
 #pragma unroll
         for (int m = 0; m < DPW; ++m) {
-            const int n = wave + 8 * m, k = n % NPIECE;
+            const int n = dma_n(m), k = n % NPIECE;
             const int slot = 64 * k + lane, r = slot / PC, pc = slot - r * PC;
             int y = y0 + r, x = x0 + pc;
             bool ok = slot < NSLOT;
@@ -169,8 +177,8 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
         }
     };
     auto dma_piece = [&](int m) {                                        // piece m of phase (du, dc) into the buffer of that phase
-        const int n = wave + 8 * m;
-        if ((ABL & 2) || n >= NDMA || dgp >= pe) return;
+        const int n = dma_n(m);
+        if ((ABL & 2) || m >= (hi ? NHI : NLO) || n >= NDMA || dgp >= pe) return;
         const int q = n / NPIECE, g = dc * 4 + q;
         const bool s1 = g < gsplit;
         const unsigned bytes = g < gin ? (s1 ? in1_bytes : in2_bytes) : 0u;
