@@ -233,13 +233,20 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     }
 }
 
-__global__ void bn_finalize_kernel(const double* __restrict__ stats, int C, double count, float eps, float momentum,
+// rezero: the sums are cleared again once read (the "zero on entry, left zero" workspace of the *_z entry points: no clearing
+// launch per layer); tracked: nn.BatchNorm2d.num_batches_tracked, incremented here instead of by a launch of its own
+__global__ void bn_finalize_kernel(double* __restrict__ stats, int C, double count, float eps, float momentum,
                                    float* __restrict__ mean, float* __restrict__ invstd,
-                                   float* __restrict__ running_mean, float* __restrict__ running_var) {
+                                   float* __restrict__ running_mean, float* __restrict__ running_var, int rezero, long long* __restrict__ tracked) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    if (c == 0 && tracked) *tracked += 1;
+    if (c >= C) {
+        if (rezero && c < 4 * ((C + 3) / 4)) { stats[2 * c] = 0.0; stats[2 * c + 1] = 0.0; }   // the padding channels of the last group
+        return;
+    }
     const double mu = stats[2 * c] / count;
     double var = stats[2 * c + 1] / count - mu * mu;
+    if (rezero) { stats[2 * c] = 0.0; stats[2 * c + 1] = 0.0; }
     if (var < 0) var = 0;
     mean[c] = (float)mu; invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
     if (running_mean) {
@@ -337,10 +344,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     }
 }
 
-__global__ void bn_param_grad_kernel(const double* __restrict__ sums, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+__global__ void bn_param_grad_kernel(double* __restrict__ sums, int C, float* __restrict__ dgamma, float* __restrict__ dbeta, int rezero) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    dbeta[c] = (float)sums[2 * c]; dgamma[c] = (float)sums[2 * c + 1];
+    if (c < C) { dbeta[c] = (float)sums[2 * c]; dgamma[c] = (float)sums[2 * c + 1]; }
+    if (rezero && c < 4 * ((C + 3) / 4)) { sums[2 * c] = 0.0; sums[2 * c + 1] = 0.0; }
 }
 
 // The fp64 sum buffers are cleared by a kernel, not hipMemsetAsync: captured into a HIP graph (TrainStepWoNormal(graph=True))
@@ -352,18 +359,50 @@ __global__ void bn_zero_kernel(double* __restrict__ p, int n) {
 
 static int bn_grid_y(int N, int HW) { long long t = ((long long)N * HW + 255) / 256; return (int)(t < 64 ? (t < 1 ? 1 : t) : 64); }
 
+static int bn_forward(const float* x, const float* gamma, const float* beta,
+                      float* running_mean, float* running_var, float momentum, float eps, int relu,
+                      float* y, float* save_mean, float* save_invstd, double* stats_ws, int zeroed, long long* tracked,
+                      int N, int C, int H, int W, void* stream) {
+    CNM_REQUIRE(x && gamma && beta && y && save_mean && save_invstd && stats_ws && N > 0 && C > 0 && H > 0 && W > 0, CNM_ERR_BAD_ARG);
+    const int G = (C + 3) / 4, HW = H * W;
+    hipStream_t s = cnm_stream(stream);
+    if (!zeroed) bn_zero_kernel<<<cnm_ceil_div(8 * G, 256), 256, 0, s>>>(stats_ws, 8 * G);
+    bn_stats_kernel<<<dim3(G, bn_grid_y(N, HW)), 256, 0, s>>>(x, N, G, HW, stats_ws);
+    bn_finalize_kernel<<<cnm_ceil_div(4 * G, 256), 256, 0, s>>>(stats_ws, C, (double)N * HW, eps, momentum, save_mean, save_invstd, running_mean, running_var, zeroed, tracked);
+    const long long total = (long long)N * G * HW;
+    bn_apply_kernel<<<(int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384), 256, 0, s>>>(x, save_mean, save_invstd, gamma, beta, C, relu, y, N, G, HW);
+    CNM_LAUNCH_CHECK();
+    return CNM_OK;
+}
+
 extern "C" int cnm_bn_train_forward_c4_f32(const float* x, const float* gamma, const float* beta,
                                            float* running_mean, float* running_var, float momentum, float eps, int relu,
                                            float* y, float* save_mean, float* save_invstd, double* stats_ws,
                                            int N, int C, int H, int W, void* stream) {
-    CNM_REQUIRE(x && gamma && beta && y && save_mean && save_invstd && stats_ws && N > 0 && C > 0 && H > 0 && W > 0, CNM_ERR_BAD_ARG);
+    return bn_forward(x, gamma, beta, running_mean, running_var, momentum, eps, relu, y, save_mean, save_invstd, stats_ws, 0, nullptr, N, C, H, W, stream);
+}
+// The same with a workspace that is ZERO when the call starts and left zero by it (one per stream, any number of layers), and
+// with num_batches_tracked (int64 scalar on the device, may be NULL) incremented by the call: two launches less per layer.
+extern "C" int cnm_bn_train_forward_z_c4_f32(const float* x, const float* gamma, const float* beta,
+                                             float* running_mean, float* running_var, float momentum, float eps, int relu,
+                                             float* y, float* save_mean, float* save_invstd, double* zero_ws, long long* num_batches_tracked,
+                                             int N, int C, int H, int W, void* stream) {
+    return bn_forward(x, gamma, beta, running_mean, running_var, momentum, eps, relu, y, save_mean, save_invstd, zero_ws, 1, num_batches_tracked, N, C, H, W, stream);
+}
+
+static int bn_backward(const float* x, const float* y, const float* dy, const float* gamma,
+                       const float* save_mean, const float* save_invstd, int relu,
+                       float* dx, float* dgamma, float* dbeta, double* sums_ws, int zeroed,
+                       int N, int C, int H, int W, void* stream) {
+    CNM_REQUIRE(x && y && dy && gamma && save_mean && save_invstd && dx && dgamma && dbeta && sums_ws && N > 0 && C > 0, CNM_ERR_BAD_ARG);
     const int G = (C + 3) / 4, HW = H * W;
     hipStream_t s = cnm_stream(stream);
-    bn_zero_kernel<<<cnm_ceil_div(8 * G, 256), 256, 0, s>>>(stats_ws, 8 * G);
-    bn_stats_kernel<<<dim3(G, bn_grid_y(N, HW)), 256, 0, s>>>(x, N, G, HW, stats_ws);
-    bn_finalize_kernel<<<cnm_ceil_div(C, 256), 256, 0, s>>>(stats_ws, C, (double)N * HW, eps, momentum, save_mean, save_invstd, running_mean, running_var);
+    if (!zeroed) bn_zero_kernel<<<cnm_ceil_div(8 * G, 256), 256, 0, s>>>(sums_ws, 8 * G);
+    bn_bwd_reduce_kernel<<<dim3(G, bn_grid_y(N, HW)), 256, 0, s>>>(x, y, dy, save_mean, save_invstd, C, relu, N, G, HW, sums_ws);
     const long long total = (long long)N * G * HW;
-    bn_apply_kernel<<<(int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384), 256, 0, s>>>(x, save_mean, save_invstd, gamma, beta, C, relu, y, N, G, HW);
+    bn_bwd_apply_kernel<<<(int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384), 256, 0, s>>>(
+        x, y, dy, save_mean, save_invstd, gamma, sums_ws, (double)N * HW, C, relu, dx, N, G, HW);
+    bn_param_grad_kernel<<<cnm_ceil_div(4 * G, 256), 256, 0, s>>>(sums_ws, C, dgamma, dbeta, zeroed);
     CNM_LAUNCH_CHECK();
     return CNM_OK;
 }
@@ -372,17 +411,13 @@ extern "C" int cnm_bn_train_backward_c4_f32(const float* x, const float* y, cons
                                             const float* save_mean, const float* save_invstd, int relu,
                                             float* dx, float* dgamma, float* dbeta, double* sums_ws,
                                             int N, int C, int H, int W, void* stream) {
-    CNM_REQUIRE(x && y && dy && gamma && save_mean && save_invstd && dx && dgamma && dbeta && sums_ws && N > 0 && C > 0, CNM_ERR_BAD_ARG);
-    const int G = (C + 3) / 4, HW = H * W;
-    hipStream_t s = cnm_stream(stream);
-    bn_zero_kernel<<<cnm_ceil_div(8 * G, 256), 256, 0, s>>>(sums_ws, 8 * G);
-    bn_bwd_reduce_kernel<<<dim3(G, bn_grid_y(N, HW)), 256, 0, s>>>(x, y, dy, save_mean, save_invstd, C, relu, N, G, HW, sums_ws);
-    const long long total = (long long)N * G * HW;
-    bn_bwd_apply_kernel<<<(int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384), 256, 0, s>>>(
-        x, y, dy, save_mean, save_invstd, gamma, sums_ws, (double)N * HW, C, relu, dx, N, G, HW);
-    bn_param_grad_kernel<<<cnm_ceil_div(C, 256), 256, 0, s>>>(sums_ws, C, dgamma, dbeta);
-    CNM_LAUNCH_CHECK();
-    return CNM_OK;
+    return bn_backward(x, y, dy, gamma, save_mean, save_invstd, relu, dx, dgamma, dbeta, sums_ws, 0, N, C, H, W, stream);
+}
+extern "C" int cnm_bn_train_backward_z_c4_f32(const float* x, const float* y, const float* dy, const float* gamma,
+                                              const float* save_mean, const float* save_invstd, int relu,
+                                              float* dx, float* dgamma, float* dbeta, double* zero_ws,
+                                              int N, int C, int H, int W, void* stream) {
+    return bn_backward(x, y, dy, gamma, save_mean, save_invstd, relu, dx, dgamma, dbeta, zero_ws, 1, N, C, H, W, stream);
 }
 
 // ------------------------------------------------------------------ adjoint of the bilinear x2 upsample

@@ -464,6 +464,17 @@ int cnm_bn_train_backward_c4_f32(const float* x, const float* y, const float* dy
                                  const float* save_mean, const float* save_invstd, int relu,
                                  float* dx, float* dgamma, float* dbeta, double* sums_ws,
                                  int N, int C, int H, int W, void* stream);
+/* The same two with a workspace of 8*ceil(C/4) doubles that is ZERO when the call starts and left zero by it (allocate and
+ * clear it once, for the widest layer; one per stream), and -- forward -- nn.BatchNorm2d.num_batches_tracked (int64 scalar on
+ * the device, may be NULL) incremented by the call: no clearing launch and no counter launch per layer. */
+int cnm_bn_train_forward_z_c4_f32(const float* x, const float* gamma, const float* beta,
+                                  float* running_mean, float* running_var, float momentum, float eps, int relu,
+                                  float* y, float* save_mean, float* save_invstd, double* zero_ws, long long* num_batches_tracked,
+                                  int N, int C, int H, int W, void* stream);
+int cnm_bn_train_backward_z_c4_f32(const float* x, const float* y, const float* dy, const float* gamma,
+                                   const float* save_mean, const float* save_invstd, int relu,
+                                   float* dx, float* dgamma, float* dbeta, double* zero_ws,
+                                   int N, int C, int H, int W, void* stream);
 
 /* Adjoint of cnm_upsample2x_c4_f32: dy [N,G,2H,2W,4] -> dx [N,G,H,W,4] (contiguous). */
 int cnm_upsample2x_backward_c4_f32(const float* dy, float* dx, int N, int G, int H, int W, void* stream);
