@@ -50,6 +50,7 @@ PROTOTYPES = {
     "cnm_tune_wino4_small": (c_i, [c_i]),
     "cnm_packed_winograd4_floats": (c_sz, [c_i, c_i]),
     "cnm_pack_winograd4_bn_f32": (c_i, [c_fp, c_fp, c_fp, c_f, c_i, c_i, c_i, c_fp, c_fp]),
+    "cnm_pack_winograd4_dgrad_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_fp]),
     "cnm_conv3x3_winograd4_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp,
                                            c_i, c_i, c_i, c_i, c_fp]),
     "cnm_conv3x3_s2_winograd_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp]),

@@ -68,12 +68,21 @@ def _dgrad_weight(weight):
     return _packed("flip", weight, 0, 1, lambda: weight.detach().flip(2, 3).transpose(0, 1).contiguous())
 
 
-def _winograd_conv(x, weight, rot, stride=1):
+def _winograd_conv(x, weight, rot, stride=1, dgrad=False):
+    """conv(x, weight); dgrad: conv(x, w') with w'[ci][co] = w[co][ci] rotated by 180 degrees (the data gradient of a stride-1
+    convolution with `weight`): the 36-point pack reads w' straight from `weight`, the other kernels get the flipped tensor."""
     Cout, _, k, _ = weight.shape
+    if dgrad:
+        Cout = weight.shape[1]
     # large layers: F(4x4,3x3); with the sync workspace the staged kernel also balances small unit counts (>= 3 x 3 tiles per image)
     if k == 3 and (_winograd4_fills_chip(x, Cout) or (WINOGRAD4_SMALL and Cout % 128 == 0 and x.shape[2] >= 9 and x.shape[3] >= 9)):
-        up4 = _packed("u4", weight, rot, 1, lambda: ops.pack_winograd4(weight, None, rot))
+        if dgrad:
+            up4 = _packed("u4d", weight, 0, 1, lambda: ops.pack_winograd4_dgrad(weight))
+        else:
+            up4 = _packed("u4", weight, rot, 1, lambda: ops.pack_winograd4(weight, None, rot))
         return ops.conv3x3_winograd4_c4(x, up4, None, Cout, relu=False, sync=_sync_workspace(x.device))
+    if dgrad:
+        weight = _dgrad_weight(weight)
     up = _packed("u2", weight, rot, stride, lambda: ops.pack_winograd(weight, None, rot, stride=stride, tile=2))    # training keeps the more accurate F(2,k) rows
     if k == 3:
         return ops.conv3x3_winograd_c4(x, up, None, Cout, relu=False)
@@ -144,7 +153,7 @@ class ConvC4(torch.autograd.Function):
         with torch.cuda.device(dev):
             if ctx.needs_input_grad[0] and ctx.rot == 0 and ctx.stride == 1 and _winograd_ok(k, 1, Cin):
                 # stride 1: dx = conv(dy, w') with w'[ci][co] = w[co][ci] rotated by 180 degrees -- the same Winograd kernels
-                dx = _winograd_conv(dy, _dgrad_weight(weight), 0)
+                dx = _winograd_conv(dy, weight.detach(), 0, dgrad=True)
             elif (ctx.needs_input_grad[0] and ctx.rot == 0 and ctx.stride == 2 and WINOGRAD and Cin % 64 == 0
                   and H % 2 == 0 and W % 2 == 0):
                 # stride 2: four stride-1 Winograd convolutions of dY, one per pixel phase of dX (sub-pixel

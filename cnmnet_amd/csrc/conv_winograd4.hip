@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void conv_winograd36_f32_kernel(const Wino4
 // at 1.6 TB/s: the training step re-packs ~90 filters, 2 ms).  Same fp64 expression per point as before: bit-identical output.
 template <int R>
 __global__ __launch_bounds__(256) void pack_winograd36_kernel(const float* __restrict__ w, const float* __restrict__ gamma, const float* __restrict__ var,
-                                                              float eps, int Cout, int Cin, int rot, int nchunks, float* __restrict__ up) {
+                                                              float eps, int Cout, int Cin, int rot, int nchunks, float* __restrict__ up, int dgrad) {
     const int ncb16 = Cout / 16;
     const int cb = blockIdx.x % ncb16, chunk = blockIdx.x / ncb16;
     const int t = threadIdx.x, e = t & 3, lane = t >> 2;
@@ -258,10 +258,11 @@ __global__ __launch_bounds__(256) void pack_winograd36_kernel(const float* __res
         return;
     }
     const int ci = (cp + rot) % Cin;
-    const float* g = w + ((size_t)co * Cin + ci) * R * R;
+    // dgrad: the filter of the data gradient, w'[co][ci] = w[ci][co] rotated by 180 degrees, read straight from w [Cin][Cout][R][R]
+    const float* g = dgrad ? w + ((size_t)ci * Cout + co) * R * R : w + ((size_t)co * Cin + ci) * R * R;
     double gv[R * R];
 #pragma unroll
-    for (int k = 0; k < R * R; ++k) gv[k] = (double)g[k];
+    for (int k = 0; k < R * R; ++k) gv[k] = (double)g[dgrad ? R * R - 1 - k : k];
     const double scale = gamma ? (double)gamma[co] / sqrt((double)var[co] + (double)eps) : 1.0;
     constexpr double G3[6][3] = {{1. / 4, 0, 0}, {-1. / 6, -1. / 6, -1. / 6}, {-1. / 6, 1. / 6, -1. / 6}, {1. / 24, 1. / 12, 1. / 6}, {1. / 24, -1. / 12, 1. / 6}, {0, 0, 1}};
     constexpr double G5[6][5] = {{1. / 4, 0, 0, 0, 0}, {-1. / 6, -1. / 6, -1. / 6, -1. / 6, -1. / 6}, {-1. / 6, 1. / 6, -1. / 6, 1. / 6, -1. / 6},
@@ -286,13 +287,13 @@ extern "C" size_t cnm_packed_winograd4_floats(int Cout, int Cin) {
 }
 
 static int pack36(const float* w_oihw, const float* bn_gamma, const float* bn_var, float eps, int Cout, int Cin, int ksize, int rot,
-                  float* u_packed, void* stream) {
+                  float* u_packed, void* stream, int dgrad = 0) {
     CNM_REQUIRE(w_oihw && u_packed && Cout > 0 && Cout % 64 == 0 && Cin > 0 && rot >= 0 && rot < Cin, CNM_ERR_BAD_ARG);
     CNM_REQUIRE(!bn_gamma == !bn_var, CNM_ERR_BAD_ARG);
     const int nchunks = (4 * ((Cin + 3) / 4) + 15) / 16;
     const unsigned nb = (unsigned)(nchunks * (Cout / 16));
-    if (ksize == 3) pack_winograd36_kernel<3><<<nb, 256, 0, cnm_stream(stream)>>>(w_oihw, bn_gamma, bn_var, eps, Cout, Cin, rot, nchunks, u_packed);
-    else pack_winograd36_kernel<5><<<nb, 256, 0, cnm_stream(stream)>>>(w_oihw, bn_gamma, bn_var, eps, Cout, Cin, rot, nchunks, u_packed);
+    if (ksize == 3) pack_winograd36_kernel<3><<<nb, 256, 0, cnm_stream(stream)>>>(w_oihw, bn_gamma, bn_var, eps, Cout, Cin, rot, nchunks, u_packed, dgrad);
+    else pack_winograd36_kernel<5><<<nb, 256, 0, cnm_stream(stream)>>>(w_oihw, bn_gamma, bn_var, eps, Cout, Cin, rot, nchunks, u_packed, dgrad);
     CNM_LAUNCH_CHECK();
     return CNM_OK;
 }
@@ -331,6 +332,14 @@ static int conv36(const float* in_a, int Ga_total, int ga0, int Ga, const float*
 extern "C" int cnm_pack_winograd4_bn_f32(const float* w_oihw, const float* bn_gamma, const float* bn_var, float eps,
                                          int Cout, int Cin, int rot, float* u_packed, void* stream) {
     return pack36(w_oihw, bn_gamma, bn_var, eps, Cout, Cin, 3, rot, u_packed, stream);
+}
+
+// The packed filter of the DATA GRADIENT of a stride-1 convolution with weight w [Cw_out][Cw_in][k][k] (k = 3 or 5): the filter
+// w'[ci][co] = w[co][ci] rotated by 180 degrees has Cw_in output and Cw_out input channels (Cw_in % 64 == 0); same layout as
+// cnm_pack_winograd4_bn_f32 / cnm_pack_winograd5x5_bn_f32 of the flipped, transposed tensor, without materialising it.
+extern "C" int cnm_pack_winograd4_dgrad_f32(const float* w_oihw, int Cw_out, int Cw_in, int ksize, float* u_packed, void* stream) {
+    CNM_REQUIRE(ksize == 3 || ksize == 5, CNM_ERR_BAD_ARG);
+    return pack36(w_oihw, nullptr, nullptr, 0.f, Cw_in, Cw_out, ksize, 0, u_packed, stream, 1);
 }
 
 extern "C" int cnm_conv3x3_winograd4_c4_f32(const float* in_a, int Ga_total, int ga0, int Ga,

@@ -260,6 +260,19 @@ def pack_winograd4(weight, bn=None, rot=0, eps=1e-5):
     return up
 
 
+def pack_winograd4_dgrad(weight):
+    """pack_winograd4(weight.flip(2, 3).transpose(0, 1)) -- the 36-point filter of the data gradient of a stride-1 3x3 / 5x5
+    convolution -- without materialising the flipped tensor."""
+    _dev(weight)
+    lib = _lib.load()
+    Cout, Cin, k, _ = weight.shape
+    assert k in (3, 5) and Cin % 64 == 0
+    up = torch.empty(lib.cnm_packed_winograd4_floats(Cin, Cout), device=weight.device, dtype=torch.float32)
+    with torch.cuda.device(weight.device):
+        _lib.check(lib.cnm_pack_winograd4_dgrad_f32(_p(_c(weight)), Cout, Cin, k, _p(up), _stream()))
+    return up
+
+
 def conv3x3_s2_winograd_c4(x, u_packed, b_packed, Cout, relu=True):
     """3x3 stride-2 pad-1 conv through the F(2x2,3x3) kernel (element (0,0) of every tile): -> [N,Cout/4,ceil(H/2),ceil(W/2),4]."""
     _dev(x, u_packed, b_packed)

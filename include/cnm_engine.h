@@ -180,6 +180,10 @@ int cnm_conv3x3_s2_winograd_c4_f32(const float* in, int Gin_total, int gin0, int
 size_t cnm_packed_winograd4_floats(int Cout, int Cin);
 int cnm_pack_winograd4_bn_f32(const float* w_oihw, const float* bn_gamma, const float* bn_var, float eps,
                               int Cout, int Cin, int rot, float* u_packed, void* stream);
+/* Packed F(4x4,3x3) / F(2x2,5x5) filter of the DATA GRADIENT of a stride-1 convolution with weight w [Cw_out][Cw_in][k][k]
+ * (training, train.py:307-310 through autograd): w'[ci][co] = w[co][ci] rotated by 180 degrees, i.e. Cw_in output channels
+ * (a multiple of 64) and Cw_out input channels, cnm_packed_winograd4_floats(Cw_in, Cw_out) floats; read straight from w. */
+int cnm_pack_winograd4_dgrad_f32(const float* w_oihw, int Cw_out, int Cw_in, int ksize, float* u_packed, void* stream);
 int cnm_conv3x3_winograd4_c4_f32(const float* in_a, int Ga_total, int ga0, int Ga,
                                  const float* in_b, int Gb_total, int gb0, int Gb,
                                  float* out, int Gout_total, int gout0, int Cout,
