@@ -156,7 +156,9 @@ class TrainStepWoNormal:
         stays outside the captured region; the backward hooks that overlap buckets with backward do not exist in a replay)."""
         self.depth_net, self.refine_net, self.dist, self.exact = depth_net, refine_net, dist, exact_masked_means
         params = list(refine_net.parameters()) + list(depth_net.parameters())              # train.py:87, :446
-        self.optimizer = torch.optim.Adam(params, lr=lr, weight_decay=weight_decay, capturable=bool(graph))   # utils/misc.py:31-33
+        # foreach=True is what torch picks for CUDA parameters anyway; stated, it also makes zero_grad(set_to_none=False) one
+        # multi-tensor launch instead of one fill per parameter (217 launches, 0.9 ms of the step)
+        self.optimizer = torch.optim.Adam(params, lr=lr, weight_decay=weight_decay, capturable=bool(graph), foreach=True)   # utils/misc.py:31-33
         self.reducer = None
         if dist is not None and dist.is_initialized() and dist.get_world_size(group) > 1:
             self.reducer = BucketedGradAllReduce(params, dist, group=group, hooks=not graph)
