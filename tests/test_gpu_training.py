@@ -80,6 +80,39 @@ def test_batchnorm_train_forward_backward(dev, C, N, H, W, relu):
     assert _rel(g.grad.cpu().numpy(), bn.weight.grad.numpy()) < 2e-5 and _rel(b.grad.cpu().numpy(), bn.bias.grad.numpy()) < 2e-5
 
 
+@pytest.mark.parametrize("cout,cin,k", [(128, 64, 3), (64, 192, 3), (256, 128, 5)])
+def test_pack_winograd4_dgrad_equals_flipped_pack(dev, cout, cin, k):
+    """cnm_pack_winograd4_dgrad_f32 reads the data-gradient filter w'[ci][co] = w[co][ci] rotated by 180 degrees straight from the
+    weight: bit-equal to packing the flipped, transposed tensor."""
+    from cnmnet_amd import ops
+    w = T(np.random.default_rng(cout + cin).standard_normal((cout, cin, k, k)).astype(np.float32)).to(dev)
+    a = ops.pack_winograd4_dgrad(w)
+    b = ops.pack_winograd4(w.flip(2, 3).transpose(0, 1).contiguous())
+    assert a.shape == b.shape and torch.equal(a, b)
+
+
+def test_batchnorm_workspace_left_zero_and_counter(dev):
+    """The *_z BatchNorm entry points: the fp64 sum workspace is zero again after forward and after backward, and
+    num_batches_tracked is incremented by the forward kernel."""
+    from cnmnet_amd import ops, autograd as ag
+    rng = np.random.default_rng(3)
+    C = 67
+    x = ops.nchw_to_c4(T(rng.standard_normal((2, C, 8, 12)).astype(np.float32)).to(dev)).requires_grad_(True)
+    g = torch.ones(C, device=dev, requires_grad=True); b = torch.zeros(C, device=dev, requires_grad=True)
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    nbt = torch.zeros((), dtype=torch.long, device=dev)
+    y = ag.BatchNormReLUC4.apply(x, g, b, rm, rv, 0.1, 1e-5, True, nbt)
+    ws = ag._bn_workspace(dev, (C + 3) // 4)
+    torch.cuda.synchronize()
+    assert int(nbt.item()) == 1 and float(ws.abs().sum().item()) == 0.0
+    y.sum().backward()
+    torch.cuda.synchronize()
+    assert float(ws.abs().sum().item()) == 0.0 and x.grad is not None
+    y2 = ag.BatchNormReLUC4.apply(x.detach(), g.detach(), b.detach(), rm, rv, 0.1, 1e-5, True, nbt)   # a second layer on the same workspace
+    torch.cuda.synchronize()
+    assert int(nbt.item()) == 2 and torch.equal(y2, y.detach())
+
+
 def test_upsample_backward(dev):
     from cnmnet_amd import ops, autograd as ag
     rng = np.random.default_rng(5)
