@@ -42,10 +42,10 @@
 #define WINO4S_EARLY_BARRIER 0  // 1: the phase barrier before the last double step + prefetch of the next phase's first B fragments behind it: measured 1.5 % slower (two more live registers spill)
 #endif
 #ifndef WINO4S_LO_SHARE
-#define WINO4S_LO_SHARE 4           // sevenths of a phase's DMA pieces issued by waves 0-3 (4 = 16 of 28: about even; 5 - 7 measured within 0.5 %)
+#define WINO4S_LO_SHARE 7           // sevenths of a phase's DMA pieces issued by waves 0-3: all of them (see NLO / NHI below)
 #endif
 #ifndef WINO4S_LO_STEP
-#define WINO4S_LO_STEP 0
+#define WINO4S_LO_STEP 14          // double step at which waves 0-3 issue their DMA pieces: late, so that the holds fall into their wait at the phase barrier
 #endif
 #ifndef WINO4S_HI_STEP
 #define WINO4S_HI_STEP 6  // double step at which waves 4-7 start issuing their DMA pieces (waves 0-3: step 0); >= 4
@@ -116,8 +116,9 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
     constexpr int VBUF = 36 * 16 * 64, RAW0 = 2 * VBUF;                  // bytes
     // DMA pieces per chunk, and per wave: waves 0-3 take NLO each, waves 4-7 NHI.  The two waves of a SIMD do not share the matrix pipe
     // evenly -- the older one (0-3) runs ahead and then waits ~2500 cycles at the phase barrier for the other -- and a DMA instruction
-    // holds its wave for ~600 cycles (tools/wino36s_timeline.py); giving the waiting wave more of the pieces (WINO4S_LO_SHARE
-    // sevenths) did not pay, though: 5.63 / 5.60 / 5.62 ms per step's launches for 5 / 6 / 7 against 5.64 for the even split.
+    // holds its wave for ~600 cycles (tools/wino36s_timeline.py).  So the waiting waves issue ALL the pieces, late in the phase
+    // (WINO4S_LO_STEP), where the holds eat into that wait and not into the trailing wave's critical path: 5.68 -> 5.60 ms per
+    // step's launches (tools/wino36s_variants.sh; the same split issued at step 0: no gain).
     constexpr int NDMA = 4 * NPIECE, NLO = (NDMA * WINO4S_LO_SHARE / 7 + 3) / 4, NHI = (NDMA - 4 * NLO + 3) / 4 > 0 ? (NDMA - 4 * NLO + 3) / 4 : 0, DPW = NLO > NHI ? NLO : NHI;
     constexpr int DV0 = RAW0 + 2 * RAWBUF;                               // [DPW][512] per-thread DMA offsets of the unit being staged
     constexpr int WD = WINO4S_WD, NXI = 36;
