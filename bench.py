@@ -140,11 +140,11 @@ def wino36_kernel(cout, h, w, ups=False):
     with `cout` (virtual, for a fused up_conv: 4 x real) output channels on an h x w (low-resolution, for up_conv) image."""
     th, tw = -(-h // 4), -(-w // 4)
     if cout % 128 == 0 and tw >= 12:
-        return "conv_winograd36s_f32_kernel<16, %s, 0, 4>" % ("true" if ups else "false")
+        return "conv_winograd36s_f32_kernel<16, %s, 0, 4, false>" % ("true" if ups else "false")
     if cout % 128 == 0 and tw >= 6 and th >= 2:
-        return "conv_winograd36s_f32_kernel<8, %s, 0, 4>" % ("true" if ups else "false")
+        return "conv_winograd36s_f32_kernel<8, %s, 0, 4, false>" % ("true" if ups else "false")
     if cout % 128 == 0 and not ups and tw >= 3 and th >= 3:
-        return "conv_winograd36s_f32_kernel<4, false, 0, 4>"
+        return "conv_winograd36s_f32_kernel<4, false, 0, 4, false>"
     return "conv_winograd36_f32_kernel<4, 3, %s>" % ("true" if ups else "false")
 
 
@@ -159,7 +159,12 @@ def conv_kernel(L, m, m4=0, h=0, w=0):
         return "conv3x3_winograd_f32_kernel", 16.0 / 36.0            # F(2x2,3x3): 16 multiplies per 4 outputs instead of 36
     if k == 5 and s == 1 and L["Cout"] // 64 * -(-(m // 4) // 16) >= WINO4_MIN_WORKGROUPS:
         staged = L["Cout"] % 128 == 0 and -(-w // 2) >= 12                         # cnm_wino36s_try_launch with 2 x 2 output tiles
-        return ("conv_winograd36s_f32_kernel<16, false, 0, 2>" if staged else "conv_winograd36_f32_kernel<2, 5, false>"), 36.0 / 100.0   # F(2x2,5x5): 36 multiplies per 4 outputs instead of 100
+        return ("conv_winograd36s_f32_kernel<16, false, 0, 2, false>" if staged else "conv_winograd36_f32_kernel<2, 5, false>"), 36.0 / 100.0   # F(2x2,5x5): 36 multiplies per 4 outputs instead of 100
+    if k in (5, 7) and s == 2 and L["Cout"] % 128 == 0:              # nets.hip: the four pixel phases of the input on the staged 36-point kernel (cnm_conv_s2_winograd4_ok)
+        mo = 4 if k == 5 else 3                                         # 5x5 -> 3x3 phase filters, F(4x4,3x3); 7x7 -> 4x4 phase filters, F(3x3,4x4)
+        th, tw = -(-h // mo), -(-w // mo)
+        if tw >= 12 or (tw >= 6 and th >= 2):
+            return "conv_winograd36s_f32_kernel<%d, false, 0, %d, true>" % (16 if tw >= 12 else 8, mo), 4 * 36.0 / (mo * mo) / (k * k)
     if k in (5, 7):                                                  # F(2,k) along rows; stride 2: two F(2,ceil(k/2)) column phases
         if k == 7 and s == 1:
             staged = L["Cout"] % 128 == 0 and w >= 32 and h >= 4                  # cnm_rows7s_try_launch (conv_rows_staged.hip)
@@ -211,7 +216,10 @@ def kernel_rooflines(dev, frames):
                 k[1] += ms; k[2] += 1; k[3] += 2.0 * L["Cout"] * cin * 3 * (2 * (h + w) - 4) * n_img
                 del x, xl, wt, wp, bp, uu, bu, wr, out
                 continue
-            if name.startswith("conv3x3_winograd4") or name.startswith("conv_winograd36"):
+            if name.startswith("conv_winograd36s") and name.endswith("true>") and L["stride"] == 2:
+                up = ops.pack_winograd4_s2(wt)
+                fn = lambda: ops.conv_s2_winograd4_c4(x, up, bp, L["Cout"], L["ksize"], True, sync=sync)
+            elif name.startswith("conv3x3_winograd4") or name.startswith("conv_winograd36"):
                 up = ops.pack_winograd4(wt)
                 fn = lambda: ops.conv3x3_winograd4_c4(x, up, bp, L["Cout"], True, ksize=L["ksize"], sync=sync)
             elif name.startswith("conv3x3_winograd"):

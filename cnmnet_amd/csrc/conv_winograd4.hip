@@ -244,13 +244,16 @@ __global__ __launch_bounds__(256, 2) void conv_winograd36_f32_kernel(const Wino4
 // One workgroup per (chunk, 16-cout block): thread = (lane, e) of the fragment reads its R x R filter once and writes the 36
 // frequency points as 36 coalesced 1 KB rows (one thread per output float spent its time in 64-bit index arithmetic and wrote
 // at 1.6 TB/s: the training step re-packs ~90 filters, 2 ms).  Same fp64 expression per point as before: bit-identical output.
-template <int R>
+// S2 (stride-2 convolution on the four pixel phases of its input, conv_winograd4s.hip): w is the (2R - 1) x (2R - 1) stride-2
+// filter, chunk = 4 * (input chunk) + 2 py + px, and the R x R filter of phase (py, px) is tap (jy, jx) -> w[2 jy + py - o][2 jx + px - o]
+// (o = 0 for 5x5, 1 for 7x7: the window starts o + 1 phase pixels before the output pixel), zero where that leaves the filter.
+template <int R, bool S2 = false>
 __global__ __launch_bounds__(256) void pack_winograd36_kernel(const float* __restrict__ w, const float* __restrict__ gamma, const float* __restrict__ var,
                                                               float eps, int Cout, int Cin, int rot, int nchunks, float* __restrict__ up, int dgrad) {
     const int ncb16 = Cout / 16;
     const int cb = blockIdx.x % ncb16, chunk = blockIdx.x / ncb16;
     const int t = threadIdx.x, e = t & 3, lane = t >> 2;
-    const int co = cb * 16 + (lane & 15), cp = chunk * 16 + 4 * (lane >> 4) + e;
+    const int co = cb * 16 + (lane & 15), cp = (S2 ? chunk >> 2 : chunk) * 16 + 4 * (lane >> 4) + e;
     float* out = up + (size_t)blockIdx.x * 36 * 256 + t;
     if (cp >= Cin) {
 #pragma unroll
@@ -261,10 +264,25 @@ __global__ __launch_bounds__(256) void pack_winograd36_kernel(const float* __res
     // dgrad: the filter of the data gradient, w'[co][ci] = w[ci][co] rotated by 180 degrees, read straight from w [Cin][Cout][R][R]
     const float* g = dgrad ? w + ((size_t)ci * Cout + co) * R * R : w + ((size_t)co * Cin + ci) * R * R;
     double gv[R * R];
+    if constexpr (S2) {
+        constexpr int K = 2 * R - 1, O = R == 4 ? 1 : 0;
+        const int py = (chunk >> 1) & 1, px = chunk & 1;
+        const float* g2 = w + ((size_t)co * Cin + ci) * K * K;
 #pragma unroll
-    for (int k = 0; k < R * R; ++k) gv[k] = (double)g[dgrad ? R * R - 1 - k : k];
+        for (int jy = 0; jy < R; ++jy)
+#pragma unroll
+            for (int jx = 0; jx < R; ++jx) {
+                const int ky = 2 * jy + py - O, kx = 2 * jx + px - O;
+                gv[jy * R + jx] = (ky >= 0 && ky < K && kx >= 0 && kx < K) ? (double)g2[ky * K + kx] : 0.0;
+            }
+    } else {
+#pragma unroll
+        for (int k = 0; k < R * R; ++k) gv[k] = (double)g[dgrad ? R * R - 1 - k : k];
+    }
     const double scale = gamma ? (double)gamma[co] / sqrt((double)var[co] + (double)eps) : 1.0;
     constexpr double G3[6][3] = {{1. / 4, 0, 0}, {-1. / 6, -1. / 6, -1. / 6}, {-1. / 6, 1. / 6, -1. / 6}, {1. / 24, 1. / 12, 1. / 6}, {1. / 24, -1. / 12, 1. / 6}, {0, 0, 1}};
+    constexpr double G4[6][4] = {{1. / 4, 0, 0, 0}, {-1. / 6, -1. / 6, -1. / 6, -1. / 6}, {-1. / 6, 1. / 6, -1. / 6, 1. / 6},
+                                 {1. / 24, 1. / 12, 1. / 6, 1. / 3}, {1. / 24, -1. / 12, 1. / 6, -1. / 3}, {0, 0, 0, 1}};
     constexpr double G5[6][5] = {{1. / 4, 0, 0, 0, 0}, {-1. / 6, -1. / 6, -1. / 6, -1. / 6, -1. / 6}, {-1. / 6, 1. / 6, -1. / 6, 1. / 6, -1. / 6},
                                  {1. / 24, 1. / 12, 1. / 6, 1. / 3, 2. / 3}, {1. / 24, -1. / 12, 1. / 6, -1. / 3, 2. / 3}, {0, 0, 0, 0, 1}};
 #pragma unroll
@@ -274,7 +292,7 @@ __global__ __launch_bounds__(256) void pack_winograd36_kernel(const float* __res
 #pragma unroll
         for (int p = 0; p < R; ++p)
 #pragma unroll
-            for (int q = 0; q < R; ++q) s += (R == 3 ? G3[ai][p] * G3[bi][q] : G5[ai][p] * G5[bi][q]) * gv[p * R + q];
+            for (int q = 0; q < R; ++q) s += (R == 3 ? G3[ai][p] * G3[bi][q] : R == 4 ? G4[ai][p] * G4[bi][q] : G5[ai][p] * G5[bi][q]) * gv[p * R + q];
         if (gamma) s *= scale;
         out[xi * 256] = (float)s;
     }
@@ -287,12 +305,14 @@ extern "C" size_t cnm_packed_winograd4_floats(int Cout, int Cin) {
 }
 
 static int pack36(const float* w_oihw, const float* bn_gamma, const float* bn_var, float eps, int Cout, int Cin, int ksize, int rot,
-                  float* u_packed, void* stream, int dgrad = 0) {
+                  float* u_packed, void* stream, int dgrad = 0, int s2 = 0) {
     CNM_REQUIRE(w_oihw && u_packed && Cout > 0 && Cout % 64 == 0 && Cin > 0 && rot >= 0 && rot < Cin, CNM_ERR_BAD_ARG);
     CNM_REQUIRE(!bn_gamma == !bn_var, CNM_ERR_BAD_ARG);
-    const int nchunks = (4 * ((Cin + 3) / 4) + 15) / 16;
+    const int nchunks = (4 * ((Cin + 3) / 4) + 15) / 16 * (s2 ? 4 : 1);
     const unsigned nb = (unsigned)(nchunks * (Cout / 16));
-    if (ksize == 3) pack_winograd36_kernel<3><<<nb, 256, 0, cnm_stream(stream)>>>(w_oihw, bn_gamma, bn_var, eps, Cout, Cin, rot, nchunks, u_packed, dgrad);
+    if (s2 && ksize == 5) pack_winograd36_kernel<3, true><<<nb, 256, 0, cnm_stream(stream)>>>(w_oihw, bn_gamma, bn_var, eps, Cout, Cin, rot, nchunks, u_packed, 0);
+    else if (s2) pack_winograd36_kernel<4, true><<<nb, 256, 0, cnm_stream(stream)>>>(w_oihw, bn_gamma, bn_var, eps, Cout, Cin, rot, nchunks, u_packed, 0);
+    else if (ksize == 3) pack_winograd36_kernel<3><<<nb, 256, 0, cnm_stream(stream)>>>(w_oihw, bn_gamma, bn_var, eps, Cout, Cin, rot, nchunks, u_packed, dgrad);
     else pack_winograd36_kernel<5><<<nb, 256, 0, cnm_stream(stream)>>>(w_oihw, bn_gamma, bn_var, eps, Cout, Cin, rot, nchunks, u_packed, dgrad);
     CNM_LAUNCH_CHECK();
     return CNM_OK;
@@ -300,8 +320,9 @@ static int pack36(const float* w_oihw, const float* bn_gamma, const float* bn_va
 
 static int conv36(const float* in_a, int Ga_total, int ga0, int Ga, const float* in_b, int Gb_total, int gb0, int Gb,
                   float* out, int Gout_total, int gout0, int Cout, const float* u_packed, const float* b_packed,
-                  int N, int H, int W, int ksize, int relu, void* stream, int ups = 0, int ring = 0, float* sync_ws = nullptr, size_t sync_floats = 0) {
+                  int N, int H, int W, int ksize, int relu, void* stream, int ups = 0, int ring = 0, float* sync_ws = nullptr, size_t sync_floats = 0, int s2 = 0) {
     CNM_REQUIRE(in_a && out && u_packed && N > 0 && H > 0 && W > 0 && Ga > 0 && Gb >= 0, CNM_ERR_BAD_ARG);
+    CNM_REQUIRE(!s2 || (!ups && (ksize == 5 || ksize == 7) && H % 2 == 0 && W % 2 == 0 && sync_ws), CNM_ERR_BAD_ARG);
     CNM_REQUIRE(Cout > 0 && Cout % 64 == 0 && gout0 >= 0 && gout0 + Cout / 4 <= Gout_total, CNM_ERR_BAD_ARG);
     CNM_REQUIRE(!ups || ksize == 3, CNM_ERR_BAD_ARG);
     CNM_REQUIRE(ga0 >= 0 && ga0 + Ga <= Ga_total && (Gb == 0 || (in_b && gb0 >= 0 && gb0 + Gb <= Gb_total)), CNM_ERR_BAD_ARG);
@@ -311,15 +332,17 @@ static int conv36(const float* in_a, int Ga_total, int ga0, int Ga, const float*
     const unsigned long long b2 = Gb ? (unsigned long long)N * Gb_total * H * W * 16ull : b1;
     CNM_REQUIRE(b1 < 0xFFFFFFFFull && b2 < 0xFFFFFFFFull, CNM_ERR_BAD_ARG);
     a.in_bytes = (unsigned)b1; a.in2_bytes = (unsigned)b2;
-    const int m = ksize == 3 ? 4 : 2;                                    // outputs per tile side
+    const int m = s2 ? (ksize == 5 ? 4 : 3) : ksize == 3 ? 4 : 2;       // outputs per tile side
+    if (s2) { H /= 2; W /= 2; }                                          // from here on the output (= phase image) size
     a.N = N; a.H = H; a.W = W; a.TH = (H + m - 1) / m; a.TW = (W + m - 1) / m;
     a.Gin_tot = Ga_total; a.gin0 = ga0; a.Gin2_tot = Gb ? Gb_total : Ga_total; a.gin2_0 = Gb ? gb0 : ga0; a.Gsplit = Ga; a.Gin = Ga + Gb;
     a.Gout_tot = Gout_total; a.gout0 = gout0; a.Cout = ups ? 4 * Cout : Cout;     // fused upsampling: four phases of virtual output channels
-    a.nchunks = (4 * a.Gin + 15) / 16; a.T = N * a.TH * a.TW; a.relu = relu; a.ring = ring;
+    a.nchunks = (4 * a.Gin + 15) / 16 * (s2 ? 4 : 1); a.T = N * a.TH * a.TW; a.relu = relu; a.ring = ring;
     a.sync_ws = sync_ws; a.sync_floats = sync_floats;
     {
-        const int e = cnm_wino36s_try_launch(a, m, ups, cnm_stream(stream));   // LDS-staged persistent variant where eligible
+        const int e = cnm_wino36s_try_launch(a, m, ups, cnm_stream(stream), s2);   // LDS-staged persistent variant where eligible
         if (e <= 0) return e;
+        CNM_REQUIRE(!s2, CNM_ERR_BAD_ARG);                               // the stride-2 form exists on the staged kernel only (cnm_conv_s2_winograd4_ok)
     }
     const int nblocks = (a.Cout / 64) * cnm_ceil_div(a.T, 16);
     if (ups) conv_winograd36_f32_kernel<4, 3, true><<<nblocks, 256, 0, cnm_stream(stream)>>>(a);
@@ -401,6 +424,34 @@ extern "C" int cnm_conv5x5_winograd_c4_f32(const float* in_a, int Ga_total, int 
                                            const float* u_packed, const float* b_packed,
                                            int N, int H, int W, int relu, void* stream) {
     return conv36(in_a, Ga_total, ga0, Ga, in_b, Gb_total, gb0, Gb, out, Gout_total, gout0, Cout, u_packed, b_packed, N, H, W, 5, relu, stream);
+}
+
+// Stride-2 5x5 (pad 2) / 7x7 (pad 3) convolution as a stride-1 convolution of the four pixel phases of the input on the
+// LDS-staged 36-point kernel: 5x5 -> four 3x3 phase filters, F(4x4,3x3), 9 multiplies per output instead of 25 (the row-wise
+// phase kernel: 15); 7x7 -> four 4x4 phase filters, F(3x3,4x4), 16 instead of 49 (22.75).  H, W (even) are the INPUT size,
+// the output is [N][Gout][H/2][W/2][4].  Needs the sync workspace of cnm_conv3x3_winograd4_sync_c4_f32 and a shape
+// cnm_conv_s2_winograd4_ok() accepts (there is no gather-fed twin to fall back to): CNM_ERR_BAD_ARG otherwise.
+extern "C" size_t cnm_packed_winograd4_s2_floats(int Cout, int Cin) { return 4 * cnm_packed_winograd4_floats(Cout, Cin); }
+
+extern "C" int cnm_pack_winograd4_s2_bn_f32(const float* w_oihw, const float* bn_gamma, const float* bn_var, float eps,
+                                            int Cout, int Cin, int ksize, int rot, float* u_packed, void* stream) {
+    CNM_REQUIRE(ksize == 5 || ksize == 7, CNM_ERR_BAD_ARG);
+    return pack36(w_oihw, bn_gamma, bn_var, eps, Cout, Cin, ksize, rot, u_packed, stream, 0, 1);
+}
+
+extern "C" int cnm_conv_s2_winograd4_ok(int Cout, int H, int W, int ksize) {
+    if ((ksize != 5 && ksize != 7) || Cout <= 0 || Cout % 128 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return 0;
+    const int m = ksize == 5 ? 4 : 3, th = (H / 2 + m - 1) / m, tw = (W / 2 + m - 1) / m;
+    return tw >= 12 || (tw >= 6 && th >= 2);
+}
+
+extern "C" int cnm_conv_s2_winograd4_sync_c4_f32(const float* in_a, int Ga_total, int ga0, int Ga,
+                                                 const float* in_b, int Gb_total, int gb0, int Gb,
+                                                 float* out, int Gout_total, int gout0, int Cout,
+                                                 const float* u_packed, const float* b_packed,
+                                                 int N, int H, int W, int ksize, int relu, float* sync_ws, size_t sync_floats, void* stream) {
+    CNM_REQUIRE(cnm_conv_s2_winograd4_ok(Cout, H, W, ksize), CNM_ERR_BAD_ARG);
+    return conv36(in_a, Ga_total, ga0, Ga, in_b, Gb_total, gb0, Gb, out, Gout_total, gout0, Cout, u_packed, b_packed, N, H, W, ksize, relu, stream, 0, 0, sync_ws, sync_floats, 1);
 }
 
 // ------------------------------------------------------------------ ring of the fused upsample + 3x3

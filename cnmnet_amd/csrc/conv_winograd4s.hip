@@ -67,6 +67,12 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
         y0 = (m0) + s1 + s2; y1 = d1 + 2.f * d2; y2 = s1 + 4.f * s2; y3 = d1 + 8.f * d2 + (m5);                 \
     } while (0)
 
+// A^T of F(3,4) (3 outputs from the same 6 points): rows [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 1]
+#define WINO3S_AT(y0, y1, y2, m0, m1, m2, m3, m4, m5) do {                                                      \
+        const f32x4 s1 = (m1) + (m2), d1 = (m1) - (m2), s2 = (m3) + (m4), d2 = (m3) - (m4);                     \
+        y0 = (m0) + s1 + s2; y1 = d1 + 2.f * d2; y2 = s1 + 4.f * s2 + (m5);                                     \
+    } while (0)
+
 // A^T of F(2,5) (2 outputs from the same 6 points): rows [1 1 1 1 1 0; 0 1 -1 2 -2 1]
 #define WINO2S_AT(y0, y1, m0, m1, m2, m3, m4, m5) do {                                                          \
         const f32x4 s1 = (m1) + (m2), d1 = (m1) - (m2), s2 = (m3) + (m4), d2 = (m3) - (m4);                     \
@@ -100,19 +106,27 @@ __device__ __forceinline__ void wino4s_dma16(unsigned lds_addr, unsigned voff, u
 // across the phase loop), and the two transform constants are wave-uniform (SGPR operands).
 // M = 4: F(4x4,3x3); M = 2: F(2x2,5x5) -- the same six interpolation points, 6 x 6 window and 36 frequency points; only
 // the tile pitch (M), the filter transform (in the packed filter) and the output transform (2 x 6 instead of 4 x 6) differ.
+// S2: a STRIDE-2 convolution as a stride-1 convolution of the four pixel phases of its input (space to depth, never
+// materialised): a 5x5 stride-2 filter is four 3x3 filters (M = 4), a 7x7 one four 4x4 filters (M = 3: F(3x3,4x4), again the
+// same six points), one per phase image P[py][px](v, u) = in(2 v + py, 2 u + px).  a.H / a.W are the OUTPUT (= phase image)
+// dimensions, chunk c = 4 * (16-channel chunk of the input) + 2 py + px; the four phases of a patch are staged back to back,
+// so the half of every 32-byte sector a phase leaves behind is still in the cache when the next phase asks for it.  Only the
+// DMA addressing knows: lane offsets step two pixels / two rows, the phase is a scalar offset.
 #ifdef WINO4S_TIMELINE
 __device__ unsigned g_wino4s_tl[2 * 8 * 24];                             // [wave 0 / wave 4][phase][double-step starts 0..17, phase end, after barrier]: low word of s_memtime
 #endif
-template <int TSX, bool UPS, int ABL = 0, int M = 4>                     // tile block = (16 / TSX) x TSX tiles of M x M outputs
+template <int TSX, bool UPS, int ABL = 0, int M = 4, bool S2 = false>   // tile block = (16 / TSX) x TSX tiles of M x M outputs
 __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino4Args a, const int SH, const int SW, const int tilesC, const int nunits,
                                                                        unsigned* __restrict__ sync_flags, float* __restrict__ sync_slots) {
-    static_assert((M == 4 || M == 2) && !(UPS && M != 4), "F(4x4,3x3) (optionally on a 2x upsampled input) or F(2x2,5x5)");
+    static_assert((M == 4 || M == 2 || (M == 3 && S2)) && !(UPS && (M != 4 || S2)), "F(4x4,3x3) (optionally on a 2x upsampled input or on the phases of a stride-2 5x5), F(2x2,5x5), F(3x3,4x4) on the phases of a stride-2 7x7");
     constexpr int TSY = 16 / TSX, PR = M * TSY + 6 - M, PC = M * TSX + 6 - M, NSLOT = PR * PC;
+    constexpr int PADW = M == 3 ? 2 : (6 - M) / 2;                       // the window starts PADW pixels before the tile (4-tap phase filters of a 7x7: taps -2 .. 1)
+    constexpr int NPX = M == 3 ? 3 : 4, NST = M == 3 ? 3 : M * M / 4;    // output transform: pixels per step (M = 3: one tile row), steps
     // Channel-group planes of the raw patch: NPIECE KB each, at pitch PLANE plus a pad per plane chosen so that the 32 lanes
     // of a ds_read_b32 group (16 channels x 2 neighbouring tiles, M pixels = 4 M dwords apart) fall on 32 different banks:
-    // M = 4 (tiles 16 dwords apart): planes 4 dwords apart (mod 32); M = 2 (tiles 8 apart): planes at 0, 4, 16, 20.
+    // M = 4 (tiles 16 dwords apart): planes 4 dwords apart (mod 32); M = 2 (tiles 8 apart): planes at 0, 4, 16, 20; M = 3 (tiles 12 apart): 0, 8, 16, 24.
     constexpr int NPIECE = (NSLOT + 63) / 64, PLANE = NPIECE * 1024 + 128, RAWBUF = 4 * PLANE;   // bytes
-#define WINO4S_PLANE_OFF(q) ((q) * PLANE + (M == 4 ? (q) * 16 : ((q) & 1) * 16 + ((q) >> 1) * 64))
+#define WINO4S_PLANE_OFF(q) ((q) * PLANE + (M == 4 ? (q) * 16 : M == 3 ? (q) * 32 : ((q) & 1) * 16 + ((q) >> 1) * 64))
     constexpr int VBUF = 36 * 16 * 64, RAW0 = 2 * VBUF;                  // bytes
     // DMA pieces per chunk, and per wave: waves 0-3 take NLO each, waves 4-7 NHI.  The two waves of a SIMD do not share the matrix pipe
     // evenly -- the older one (0-3) runs ahead and then waits ~2500 cycles at the phase barrier for the other -- and a DMA instruction
@@ -152,9 +166,11 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
     // four pieces that was 2500 - 4000 cycles of a 9200-cycle phase (tools/wino36s_timeline.py)
     unsigned in1_lo = (unsigned)reinterpret_cast<unsigned long long>(a.in), in1_hi = (unsigned)(reinterpret_cast<unsigned long long>(a.in) >> 32), in1_bytes = a.in_bytes;
     unsigned in2_lo = (unsigned)reinterpret_cast<unsigned long long>(a.in2), in2_hi = (unsigned)(reinterpret_cast<unsigned long long>(a.in2) >> 32), in2_bytes = a.in2_bytes;
-    unsigned hw16 = (unsigned)HW * 16u;
+    unsigned hw16 = (unsigned)HW * (S2 ? 64u : 16u);                      // bytes between channel groups of the input image (S2: 2H x 2W pixels)
     int gsplit = a.Gsplit, gin = a.Gin;
+    unsigned row32 = (unsigned)a.W * 32u;                                // S2: bytes of one input row
     asm volatile("" : "+s"(in1_lo), "+s"(in1_hi), "+s"(in1_bytes), "+s"(in2_lo), "+s"(in2_hi), "+s"(in2_bytes), "+s"(hw16), "+s"(gsplit), "+s"(gin));
+    if constexpr (S2) asm volatile("" : "+s"(row32));
     int du = ps / nch, dc = ps - du * nch, dgp = ps;                     // cursor of the stage role: unit, chunk, global phase
     unsigned dbase1 = 0, dbase2 = 0;                                     // byte offsets of channel group 0 of either view in that unit's image
     auto dma_n = [&](int m) { return hi ? 4 * NLO + (wave - 4) + 4 * m : wave + 4 * m; };   // piece m of this wave
@@ -165,7 +181,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
         dbase1 = (unsigned)(dimg * a.Gin_tot + a.gin0) * hw16;
         dbase2 = (unsigned)(dimg * a.Gin2_tot + a.gin2_0 - a.Gsplit) * hw16;
         const int rem = strip - dimg * SHW, sy = rem / SW, sx = rem - sy * SW;
-        const int y0 = M * TSY * sy - (6 - M) / 2, x0 = M * TSX * sx - (6 - M) / 2;   // the window starts R / 2 pixels before the tile
+        const int y0 = M * TSY * sy - PADW, x0 = M * TSX * sx - PADW;     // the window starts PADW pixels before the tile
 #pragma unroll
         for (int m = 0; m < DPW; ++m) {
             const int n = dma_n(m), k = n % NPIECE;
@@ -174,18 +190,19 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
             bool ok = slot < NSLOT;
             if constexpr (UPS) { y = min(max(y, 0), a.H - 1); x = min(max(x, 0), a.W - 1); }
             else ok = ok & ((unsigned)y < (unsigned)a.H) & ((unsigned)x < (unsigned)a.W);
-            *reinterpret_cast<unsigned*>(smem + DV0 + (m * 512 + t) * 4) = ok ? (unsigned)(y * a.W + x) * 16u : 0xFFFFFFFFu;
+            *reinterpret_cast<unsigned*>(smem + DV0 + (m * 512 + t) * 4) = ok ? (unsigned)(S2 ? 4 * y * a.W + 2 * x : y * a.W + x) * 16u : 0xFFFFFFFFu;
         }
     };
     auto dma_piece = [&](int m) {                                        // piece m of phase (du, dc) into the buffer of that phase
         const int n = dma_n(m);
         if ((ABL & 2) || m >= (hi ? NHI : NLO) || n >= NDMA || dgp >= pe) return;
-        const int q = n / NPIECE, g = dc * 4 + q;
+        const int q = n / NPIECE, g = (S2 ? dc >> 2 : dc) * 4 + q;
+        const unsigned phoff = S2 ? ((dc >> 1) & 1) * row32 + (dc & 1) * 16u : 0u;   // S2: the chunk's pixel phase
         const bool s1 = g < gsplit;
         const unsigned bytes = g < gin ? (s1 ? in1_bytes : in2_bytes) : 0u;
         const unsigned voff = *reinterpret_cast<const unsigned*>(smem + DV0 + (m * 512 + t) * 4);
         wino4s_dma16(lds0 + RAW0 + (unsigned)(((dgp - ps) & 1) * RAWBUF + WINO4S_PLANE_OFF(q) + (n - q * NPIECE) * 1024), voff, s1 ? in1_lo : in2_lo, s1 ? in1_hi : in2_hi, bytes,
-                     (s1 ? dbase1 : dbase2) + (unsigned)g * hw16);
+                     (s1 ? dbase1 : dbase2) + (unsigned)g * hw16 + phoff);
     };
     auto dma_advance = [&]() { ++dgp; if (++dc == nch) { dc = 0; ++du; if (dgp < pe) dma_unit(); } };
 
@@ -400,6 +417,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
                 if constexpr (M == 4) WINO4S_AT(s[0][j], s[1][j], s[2][j], s[3][j], acc[0 * 6 + j], acc[1 * 6 + j], acc[2 * 6 + j], acc[3 * 6 + j], acc[4 * 6 + j], acc[5 * 6 + j]);
+                else if constexpr (M == 3) WINO3S_AT(s[0][j], s[1][j], s[2][j], acc[0 * 6 + j], acc[1 * 6 + j], acc[2 * 6 + j], acc[3 * 6 + j], acc[4 * 6 + j], acc[5 * 6 + j]);
                 else WINO2S_AT(s[0][j], s[1][j], acc[0 * 6 + j], acc[1 * 6 + j], acc[2 * 6 + j], acc[3 * 6 + j], acc[4 * 6 + j], acc[5 * 6 + j]);
             }
             // partial outputs travel as [range][wave][pixel][lane] float4: every lane re-reads exactly what its twin wrote
@@ -415,11 +433,12 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
             const unsigned stg = (unsigned)((p & 1) * VBUF + wave * 4352);
             const unsigned stw = stg + kg * 1088 + rtile * 16;
             // reading lane = pixel: tile qt, slot qs (M = 4: column le & 3 of row st; M = 2: row le >> 5, column le & 1)
-            const int qt = M == 4 ? le >> 2 : (le & 31) >> 1, qs = M == 4 ? le & 3 : ((le >> 5) << 1) | (le & 1);
+            // (M = 3: tile le / 3, column le % 3 of row st -- 48 lanes, 768 bytes per store)
+            const int qt = M == 4 ? le >> 2 : M == 3 ? min(le / 3, 15) : (le & 31) >> 1, qs = M == 4 ? le & 3 : M == 3 ? le % 3 : ((le >> 5) << 1) | (le & 1);
             const unsigned str_ = stg + qs * 272 + qt * 16;
             const int qty = sy * TSY + qt / TSX, qtx = sx * TSX + qt % TSX;
-            const int qcol = M * qtx + (M == 4 ? le & 3 : le & 1);
-            const bool qok = qty < a.TH && qtx < a.TW;
+            const int qcol = M * qtx + (M == 4 ? le & 3 : M == 3 ? qs : le & 1);
+            const bool qok = qty < a.TH && qtx < a.TW && (M != 3 || le < 48);
             const int cow = mcblk * 128 + wave * 16;                                                // the wave's 16 output channels
             const int Cr = a.Cout >> 2, ph = UPS ? cow / Cr : 0, pa = ph >> 1, pb = ph & 1;        // UPS: virtual channels -> (phase, real channels)
             const int Ho = 2 * a.H, Wo = 2 * a.W;
@@ -427,13 +446,14 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
                                : a.out + c4_offset(img, a.Gout_tot, a.gout0 + (cow >> 2), HW, 0);
             const size_t gstride = (size_t)(UPS ? 4 * HW : HW) * 4;                                 // floats between channel groups
 #pragma unroll
-            for (int st = 0; st < M * M / 4; ++st) {
-                f32x4 y[4];                                              // the step's four pixels: (row, column) = M = 4: (st, sl); M = 2: (sl >> 1, sl & 1)
+            for (int st = 0; st < NST; ++st) {
+                f32x4 y[4];                                              // the step's four pixels: (row, column) = M = 4: (st, sl); M = 2: (sl >> 1, sl & 1); M = 3: three pixels (st, sl)
                 if constexpr (M == 4) WINO4S_AT(y[0], y[1], y[2], y[3], s[st][0], s[st][1], s[st][2], s[st][3], s[st][4], s[st][5]);
+                else if constexpr (M == 3) WINO3S_AT(y[0], y[1], y[2], s[st][0], s[st][1], s[st][2], s[st][3], s[st][4], s[st][5]);
                 else { WINO2S_AT(y[0], y[1], s[0][0], s[0][1], s[0][2], s[0][3], s[0][4], s[0][5]); WINO2S_AT(y[2], y[3], s[1][0], s[1][1], s[1][2], s[1][3], s[1][4], s[1][5]); }
                 if (publish) {                                           // write-through (sc1) stores: no release fence needed before the flag
 #pragma unroll
-                    for (int x = 0; x < 4; ++x)
+                    for (int x = 0; x < NPX; ++x)
                         __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&y[x]), srsrc, (slot_lane + (unsigned)(4 * st + x) * 64u) * 16u, (unsigned)rng * (unsigned)SLOT_BYTES, 16);
                     // the 16-byte-per-lane stores read their data registers over several cycles and hipcc knows no hazard for the
                     // SGPR-soffset form: with the registers rewritten by the very next instruction the last quarter of each
@@ -447,13 +467,13 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
                     // sc1 loads, matching the sc1 stores: with plain loads behind the acquire a few 64-byte pieces per slot
                     // came back stale on MI355X (tools/wino36s_vis.sh)
 #pragma unroll
-                    for (int x = 0; x < 4; ++x) {
+                    for (int x = 0; x < NPX; ++x) {
                         const u32x4 pv = __builtin_amdgcn_raw_buffer_load_b128(srsrc, (slot_lane + (unsigned)(4 * st + x) * 64u) * 16u, (unsigned)(rng + k) * (unsigned)SLOT_BYTES, 16);
                         y[x] += *reinterpret_cast<const f32x4*>(&pv);
                     }
                 }
 #pragma unroll
-                for (int x = 0; x < 4; ++x) {                            // bias, ReLU (own channels), then into the staging row
+                for (int x = 0; x < NPX; ++x) {                          // bias, ReLU (own channels), then into the staging row
                     f32x4 v = y[x];
                     bool fin = true;
                     if constexpr (UPS) {
@@ -466,7 +486,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
                     }
                     *reinterpret_cast<f32x4*>(smem + stw + x * 272) = v;
                 }
-                const int qrow = M * qty + (M == 4 ? st : le >> 5);
+                const int qrow = M * qty + (M == 2 ? le >> 5 : st);
                 const bool stv = qok && qrow < a.H && qcol < a.W;
                 float* orow = UPS ? obase + (size_t)((2 * qrow + pa) * Wo + 2 * qcol + pb) * 4 : obase + (size_t)(qrow * a.W + qcol) * 4;
 #pragma unroll
@@ -517,10 +537,10 @@ static int wino4s_cus() {                                                // comp
 static constexpr size_t kSyncFlagBytes = 4096, kSyncSlotBytes = 8 * 16 * 64 * 16;
 extern "C" size_t cnm_wino36_sync_floats(void) { return (kSyncFlagBytes + (size_t)wino4s_cus() * kSyncSlotBytes) / 4; }
 
-int cnm_wino36s_try_launch(const Wino4Args& a, int M, int ups, hipStream_t stream) {
-    if (!g_wino36_staged || (M != 4 && M != 2) || (ups && M != 4) || a.Cout % 128) return 1;
+int cnm_wino36s_try_launch(const Wino4Args& a, int M, int ups, hipStream_t stream, int s2) {
+    if (!g_wino36_staged || (M != 4 && M != 2 && !(M == 3 && s2)) || (ups && (M != 4 || s2)) || (s2 && M == 2) || a.Cout % 128) return 1;
     int tsx = 0;
-    if (a.TW >= 12) tsx = 16; else if (a.TW >= 6 && a.TH >= 2) tsx = 8; else if (M == 4 && !ups && a.TW >= 3 && a.TH >= 3) tsx = 4;   // tile block 1 x 16, 2 x 8, 4 x 4
+    if (a.TW >= 12) tsx = 16; else if (a.TW >= 6 && a.TH >= 2) tsx = 8; else if (M == 4 && !ups && !s2 && a.TW >= 3 && a.TH >= 3) tsx = 4;   // tile block 1 x 16, 2 x 8, 4 x 4
     if (!tsx) return 1;
     const int tsy = 16 / tsx;
     const int SH = cnm_ceil_div(a.TH, tsy), SW = cnm_ceil_div(a.TW, tsx), tilesC = a.Cout / 128;
@@ -543,7 +563,7 @@ int cnm_wino36s_try_launch(const Wino4Args& a, int M, int ups, hipStream_t strea
         return 1;
     }
 #ifdef WINO4S_ABLATE
-    if (g_wino36s_ablate && tsx == 16 && !ups && M == 4) {
+    if (g_wino36s_ablate && tsx == 16 && !ups && M == 4 && !s2) {
         switch (g_wino36s_ablate) {
 #define WINO4S_CASE(n) case n: conv_winograd36s_f32_kernel<16, false, n><<<grid, 512, 0, stream>>>(a, SH, SW, tilesC, (int)nunits, flags, slots); break;
             WINO4S_CASE(1) WINO4S_CASE(2) WINO4S_CASE(3) WINO4S_CASE(4) WINO4S_CASE(7) WINO4S_CASE(8) WINO4S_CASE(15) WINO4S_CASE(16) WINO4S_CASE(18) WINO4S_CASE(32) WINO4S_CASE(64)
@@ -553,7 +573,15 @@ int cnm_wino36s_try_launch(const Wino4Args& a, int M, int ups, hipStream_t strea
         return CNM_OK;
     }
 #endif
-    if (M == 2) {
+    if (s2) {                                                            // stride 2 on the four pixel phases: 5x5 -> F(4x4,3x3), 7x7 -> F(3x3,4x4)
+        if (M == 4) {
+            if (tsx == 16) conv_winograd36s_f32_kernel<16, false, 0, 4, true><<<grid, 512, 0, stream>>>(a, SH, SW, tilesC, (int)nunits, flags, slots);
+            else conv_winograd36s_f32_kernel<8, false, 0, 4, true><<<grid, 512, 0, stream>>>(a, SH, SW, tilesC, (int)nunits, flags, slots);
+        } else {
+            if (tsx == 16) conv_winograd36s_f32_kernel<16, false, 0, 3, true><<<grid, 512, 0, stream>>>(a, SH, SW, tilesC, (int)nunits, flags, slots);
+            else conv_winograd36s_f32_kernel<8, false, 0, 3, true><<<grid, 512, 0, stream>>>(a, SH, SW, tilesC, (int)nunits, flags, slots);
+        }
+    } else if (M == 2) {
         if (tsx == 16) conv_winograd36s_f32_kernel<16, false, 0, 2><<<grid, 512, 0, stream>>>(a, SH, SW, tilesC, (int)nunits, flags, slots);
         else conv_winograd36s_f32_kernel<8, false, 0, 2><<<grid, 512, 0, stream>>>(a, SH, SW, tilesC, (int)nunits, flags, slots);
     } else if (tsx == 4) {

@@ -90,6 +90,8 @@ static inline bool wino4_fills_chip(int Cout, int N, int H, int W, int m = 4) { 
     return (Cout / 64) * ((tiles + 15) / 16) >= g_wino4_min_workgroups;
 }
 
+static int g_wino4_s2 = 1;                                               // tuning knob: 5x5 / 7x7 stride-2 layers on the staged 36-point kernel (pixel phases) instead of the row-wise phase kernel
+extern "C" int cnm_tune_wino4_s2(int on) { const int old = g_wino4_s2; if (on == 0 || on == 1) g_wino4_s2 = on; return old; }
 static int g_wino4_small = 1;                                            // tuning knob: small layers on the staged F(4x4,3x3) kernel (A/B against F(2x2,3x3))
 extern "C" int cnm_tune_wino4_small(int on) { const int old = g_wino4_small; if (on == 0 || on == 1) g_wino4_small = on; return old; }
 
@@ -148,6 +150,8 @@ struct EngF32 {
         if (w.u && k == 3 && st == 1) return cnm_conv3x3_winograd_c4_f32(in, Gt, g0, Gin, nullptr, 0, 0, 0, out, Gto, go0, Cout, w.u, w.b, N, H, W, 1, s);
         if (w.u4 && k == 5 && st == 1 && wino4_fills_chip(Cout, N, H, W, 2))
             return cnm_conv5x5_winograd_sync_c4_f32(in, Gt, g0, Gin, nullptr, 0, 0, 0, out, Gto, go0, Cout, w.u4, w.b, N, H, W, 1, sync, sync ? cnm_wino36_sync_floats() : 0, s);
+        if (w.u4 && (k == 5 || k == 7) && st == 2 && sync && g_wino4_s2 && cnm_conv_s2_winograd4_ok(Cout, H, W, k))   // four pixel phases on the staged 36-point kernel
+            return cnm_conv_s2_winograd4_sync_c4_f32(in, Gt, g0, Gin, nullptr, 0, 0, 0, out, Gto, go0, Cout, w.u4, w.b, N, H, W, k, 1, sync, cnm_wino36_sync_floats(), s);
         if (w.u && (k == 5 || k == 7)) return cnm_conv_rows_winograd_sync_c4_f32(in, Gt, g0, Gin, nullptr, 0, 0, 0, out, Gto, go0, Cout, w.u, w.b, N, H, W, k, st, (k == 5 && st == 1) ? 2 : 4, 1, sync, sync ? cnm_wino36_sync_floats() : 0, s);
         return cnm_conv2d_c4_f32(in, Gt, g0, Gin, out, Gto, go0, Cout, w.w, w.b, N, H, W, k, st, 1, s); }
     static int conv2(const float* a, int Ga, const float* b, int Gb, float* out, int Gto, int Cout, const cnm_layer_weights& w, int N, int H, int W, float* sync, void* s) {

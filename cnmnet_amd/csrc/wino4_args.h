@@ -15,4 +15,6 @@ struct Wino4Args {
 
 // LDS-staged variant (conv_winograd4s.hip): returns CNM_OK after launching, 1 when the shape is not eligible (the caller
 // then launches the gather-fed kernel), a negative status on launch failure.
-int cnm_wino36s_try_launch(const Wino4Args& a, int M, int ups, hipStream_t stream);
+// s2: the stride-2 form on the four pixel phases of the input (a.H / a.W = output size, a.nchunks = 4 x the input's chunks,
+// filter packed by cnm_pack_winograd4_s2_bn_f32): M = 4 for a 5x5, M = 3 for a 7x7 filter; there is no gather-fed twin.
+int cnm_wino36s_try_launch(const Wino4Args& a, int M, int ups, hipStream_t stream, int s2 = 0);

@@ -127,6 +127,8 @@ class _EngineNet(nn.Module):
                           if (L["ksize"] in (3, 5) and L["stride"] == 1 and self.winograd4) else None)
                     if L["ksize"] == 3 and L["stride"] == 2 and self.winograd4:      # 3x3 stride 2: u = F(2x2) filter (small layers), u4 = F(4,2) row phases
                         u4 = ops.pack_winograd_rows(w, bnp, rot=L["rot"], eps=bn.eps, stride=2, tile=4)
+                    if L["ksize"] in (5, 7) and L["stride"] == 2 and self.winograd4 and L["Cout"] % 128 == 0:   # stride-2 5x5 / 7x7: the four pixel phases on the 36-point kernel
+                        u4 = ops.pack_winograd4_s2(w, bnp, rot=L["rot"], eps=bn.eps)
                     # up_conv layers the executor may run fused with their bilinear upsampling (<= 256 input channels)
                     fused = (ops.pack_winograd4_upsampled(w, bnp, eps=bn.eps)
                              if (u4 is not None and L["ksize"] == 3 and L["conv_key"].startswith("upconv") and L["Cin"] <= 256

@@ -260,6 +260,34 @@ def pack_winograd4(weight, bn=None, rot=0, eps=1e-5):
     return up
 
 
+def pack_winograd4_s2(weight, bn=None, rot=0, eps=1e-5):
+    """36-point packed filter of a STRIDE-2 5x5 / 7x7 layer as a stride-1 convolution of the four pixel phases of its input:
+    5x5 -> four 3x3 phase filters (F(4x4,3x3)), 7x7 -> four 4x4 phase filters (F(3x3,4x4))."""
+    _dev(weight, *(bn or ()))
+    lib = _lib.load()
+    Cout, Cin, k, _ = weight.shape
+    assert k in (5, 7)
+    up = torch.empty(lib.cnm_packed_winograd4_s2_floats(Cout, Cin), device=weight.device, dtype=torch.float32)
+    g, v = (_c(bn[0]), _c(bn[3])) if bn else (None, None)
+    with torch.cuda.device(weight.device):
+        _lib.check(lib.cnm_pack_winograd4_s2_bn_f32(_p(_c(weight)), _p(g), _p(v), eps, Cout, Cin, k, rot, _p(up), _stream()))
+    return up
+
+
+def conv_s2_winograd4_c4(x, u_packed, b_packed, Cout, ksize, relu=True, x2=None, sync=None):
+    """Stride-2 5x5 (pad 2) / 7x7 (pad 3) convolution on the LDS-staged 36-point kernel (pack_winograd4_s2 filter):
+    x [N,G,H,W,4] (H, W even) -> [N,Cout/4,H/2,W/2,4].  sync = a wino36_sync_workspace (required)."""
+    _dev(x, u_packed, b_packed, x2, sync)
+    N, G, H, W, _ = x.shape
+    out = torch.empty(N, Cout // 4, H // 2, W // 2, 4, device=x.device, dtype=torch.float32)
+    G2 = x2.shape[1] if x2 is not None else 0
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().cnm_conv_s2_winograd4_sync_c4_f32(_p(x), G, 0, G, _p(x2) if x2 is not None else None, G2, 0, G2,
+                                                                 _p(out), Cout // 4, 0, Cout, _p(u_packed), _p(b_packed), N, H, W, ksize, int(relu),
+                                                                 _p(sync) if sync is not None else None, sync.numel() if sync is not None else 0, _stream()))
+    return out
+
+
 def pack_winograd4_dgrad(weight):
     """pack_winograd4(weight.flip(2, 3).transpose(0, 1)) -- the 36-point filter of the data gradient of a stride-1 3x3 / 5x5
     convolution -- without materialising the flipped tensor."""

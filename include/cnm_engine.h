@@ -224,6 +224,26 @@ int cnm_conv5x5_winograd_sync_c4_f32(const float* in_a, int Ga_total, int ga0, i
                                      const float* u_packed, const float* b_packed,
                                      int N, int H, int W, int relu, float* sync_ws, size_t sync_floats, void* stream);
 
+/* The STRIDE-2 5x5 / 7x7 layers (conv2.3 = nn.Conv2d(256, 256, 5, 2, 2), conv1.3 = nn.Conv2d(128, 128, 7, 2, 3),
+ * depthNet_model.py:136-139,145-148 through conv_layer :19-43) as a stride-1 convolution of the four pixel phases of the
+ * input (space to depth, never materialised) on the LDS-staged 36-point kernel: 5x5 -> four 3x3 phase filters,
+ * F(4x4,3x3), 9 multiplies per output instead of 25 (row-wise phase kernel: 15); 7x7 -> four 4x4 phase filters,
+ * F(3x3,4x4) on the same six points, 16 instead of 49 (22.75).  H, W (even) = INPUT size, out = [N][Gout][H/2][W/2][4].
+ * u_packed from cnm_pack_winograd4_s2_bn_f32 (cnm_packed_winograd4_s2_floats floats).  Staged kernel only: needs the
+ * sync workspace of cnm_conv3x3_winograd4_sync_c4_f32 (same contract) and a shape cnm_conv_s2_winograd4_ok() accepts
+ * (Cout % 128 == 0, even H and W, at least six tiles per output row): CNM_ERR_BAD_ARG otherwise.
+ * cnm_tune_wino4_s2(0) makes the fp32 executors keep the row-wise phase kernel for these layers (default 1; other values query). */
+size_t cnm_packed_winograd4_s2_floats(int Cout, int Cin);
+int cnm_pack_winograd4_s2_bn_f32(const float* w_oihw, const float* bn_gamma, const float* bn_var, float eps,
+                                 int Cout, int Cin, int ksize, int rot, float* u_packed, void* stream);
+int cnm_conv_s2_winograd4_ok(int Cout, int H, int W, int ksize);
+int cnm_conv_s2_winograd4_sync_c4_f32(const float* in_a, int Ga_total, int ga0, int Ga,
+                                      const float* in_b, int Gb_total, int gb0, int Gb,
+                                      float* out, int Gout_total, int gout0, int Cout,
+                                      const float* u_packed, const float* b_packed,
+                                      int N, int H, int W, int ksize, int relu, float* sync_ws, size_t sync_floats, void* stream);
+int cnm_tune_wino4_s2(int on);
+
 /* nn.Upsample(scale_factor=2, mode='bilinear') followed by Conv2d(3x3, pad 1) + folded BatchNorm + ReLU -- the
  * reference's up_conv_layer (depthNet_model.py:89-112) -- as ONE pass over the LOW-resolution input: upsample-then-3x3
  * equals, per output row / column parity, a 3x3 filter on the low-resolution image; the four composed filters are packed
@@ -357,7 +377,8 @@ int cnm_net_layer(int net, int index, cnm_layer_info* info);   /* D=64 table */
  * cnm_conv_rows_winograd_c4_f32 (w may then be NULL); ignored by heads, 3x3 stride-2 layers and the fp16 engine.
  * u4: optional 36-point filter -- cnm_pack_winograd4_bn_f32 (F(4x4,3x3)) for 3x3 stride-1 layers,
  * cnm_pack_winograd5x5_bn_f32 (F(2x2,5x5)) for 5x5 stride-1 layers: used instead of u when the layer has enough tiles
- * to fill the chip (>= CNM_WINO4_MIN_WORKGROUPS workgroups of 64 couts x 16 tiles).
+ * to fill the chip (>= CNM_WINO4_MIN_WORKGROUPS workgroups of 64 couts x 16 tiles); cnm_pack_winograd4_s2_bn_f32 for
+ * 5x5 / 7x7 stride-2 layers: used instead of u where cnm_conv_s2_winograd4_ok() accepts the shape.
  * uu, bu, wr: optional, up_conv layers only -- the four composed upsample-then-3x3 phase filters packed as 4*Cout
  * output channels (fp32 engine: cnm_pack_winograd4_bn_f32; fp16 engine: cnm_pack_conv_bn_f16, half data), the folded
  * bias four times, and the ring-pass filter (cnm_pack_upsampled_ring_f32, fp32 for both engines); all three or none. */

@@ -457,6 +457,54 @@ def test_conv5x5_winograd_staged(dev, ops, cin, cout, rot, N, H, W):
         assert np.abs(got - want).max() < 2e-4 * max(np.abs(want).max(), 1.0), np.abs(got - want).max()
 
 
+@pytest.mark.parametrize("k,cin,cin2,cout,rot,N,H,W", [
+    (5, 64, 0, 128, 0, 2, 96, 128),    # conv2.3's geometry at a quarter of the channels: 12 x 16 tiles per image, 1 x 16 tile blocks
+    (5, 35, 0, 256, 3, 1, 36, 100),    # ragged channel group, rotated input, ragged tiles (5 x 13), two channel blocks
+    (5, 32, 20, 128, 0, 3, 24, 56),    # concatenated input, 2 x 8 tile blocks (3 x 7 tiles)
+    (7, 64, 0, 128, 0, 2, 96, 128),    # conv1.3's geometry at half the channels: F(3x3,4x4), 16 x 22 tiles (ragged: 64 = 21.3 x 3)
+    (7, 19, 0, 256, 0, 1, 38, 74),     # ragged everything: 19 rows / 37 columns of outputs = 7 x 13 tiles
+    (7, 16, 16, 128, 0, 2, 20, 40)])   # concatenated input, 2 x 8 tile blocks (4 x 7 tiles)
+def test_conv_s2_winograd4_staged(dev, ops, k, cin, cin2, cout, rot, N, H, W):
+    """Stride-2 5x5 / 7x7 layers as a stride-1 convolution of the four pixel phases of the input on the LDS-staged 36-point
+    kernel (F(4x4,3x3) / F(3x3,4x4)): within the 36-point kernels' per-layer bar of the fp64 torch convolution, next to the
+    row-wise phase kernel it replaces, reproducible run to run, flag words re-armed; ineligible shapes are refused."""
+    from cnmnet_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(cin * 11 + H + cout + k)
+    cp = 4 * ((cin + 3) // 4)
+    x = T(rng.standard_normal((N, cin, H, W)).astype(np.float32))
+    x2 = T(rng.standard_normal((N, cin2, H, W)).astype(np.float32)) if cin2 else None
+    ct = (cp if cin2 else cin) + cin2
+    w = T((rng.standard_normal((cout, ct, k, k)) * (2.0 / (ct * k * k)) ** 0.5).astype(np.float32))
+    bnp = [T(a.astype(np.float32)) for a in (rng.uniform(0.5, 1.5, cout), rng.normal(0, 0.2, cout), rng.normal(0, 0.2, cout), rng.uniform(0.5, 1.5, cout))]
+    sc = bnp[0].double() / torch.sqrt(bnp[3].double() + 1e-5)
+    xin = x if not cin2 else torch.cat([x, torch.zeros(N, cp - cin, H, W), x2], 1)
+    want = F.relu(F.conv2d(xin.double(), w.double(), stride=2, padding=k // 2) * sc[None, :, None, None] + (bnp[1].double() - bnp[2].double() * sc)[None, :, None, None]).numpy()
+    bnd = tuple(t.to(dev) for t in bnp)
+    _, bp = ops.pack_conv(w.to(dev), bnd, rot=rot)
+    up = ops.pack_winograd4_s2(w.to(dev), bnd, rot=rot)
+    xr = torch.cat((x[:, rot:], x[:, :rot]), 1) if rot else x
+    xc = ops.nchw_to_c4(xr.to(dev)); x2c = ops.nchw_to_c4(x2.to(dev)) if cin2 else None
+    sync = ops.wino36_sync_workspace(dev)
+    assert lib.cnm_conv_s2_winograd4_ok(cout, H, W, k) == 1
+    o1 = ops.conv_s2_winograd4_c4(xc, up, bp, cout, k, True, x2=x2c, sync=sync).clone()
+    o2 = ops.conv_s2_winograd4_c4(xc, up, bp, cout, k, True, x2=x2c, sync=sync)
+    got = ops.c4_to_nchw(o1, cout).cpu().numpy()
+    assert got.shape == want.shape
+    err = np.abs(got - want).max()
+    assert err < 2e-4 * max(np.abs(want).max(), 1.0), err
+    assert torch.equal(o1, o2) and float(sync[:1024].abs().max()) == 0.0
+    if not cin2:                                                         # the row-wise phase kernel on the same input: same bar
+        ur = ops.pack_winograd(w.to(dev), bnd, rot=rot, stride=2)
+        rows = ops.c4_to_nchw(ops.conv_rows_winograd_c4(xc, ur, bp, cout, k, True, stride=2), cout).cpu().numpy()
+        assert np.abs(rows - got).max() < 4e-4 * max(np.abs(want).max(), 1.0)
+    # refused: no sync workspace, odd size, Cout not a multiple of 128, too narrow
+    with pytest.raises(_lib.EngineError):
+        ops.conv_s2_winograd4_c4(xc, up, bp, cout, k, True, x2=x2c, sync=None)
+    assert lib.cnm_conv_s2_winograd4_ok(cout, H + 1, W, k) == 0 and lib.cnm_conv_s2_winograd4_ok(64, H, W, k) == 0
+    assert lib.cnm_conv_s2_winograd4_ok(cout, H, 16, k) == 0 and lib.cnm_conv_s2_winograd4_ok(cout, H, W, 3) == 0
+
+
 @pytest.mark.parametrize("cin,cout,N,H,W", [(128, 64, 2, 48, 64), (256, 128, 1, 24, 32), (64, 64, 2, 20, 36)])
 def test_conv3x3_upsampled_staged_equals_gather(dev, ops, cin, cout, N, H, W):
     """Fused up_conv (bilinear x2 + 3x3) on the LDS-staged kernel: clamped (replicate) patch loads, pixel-shuffled stores and
