@@ -163,8 +163,10 @@ def conv_kernel(L, m, m4=0, h=0, w=0):
     if k in (5, 7) and s == 2 and L["Cout"] % 128 == 0:              # nets.hip: the four pixel phases of the input on the staged 36-point kernel (cnm_conv_s2_winograd4_ok)
         mo = 4 if k == 5 else 3                                         # 5x5 -> 3x3 phase filters, F(4x4,3x3); 7x7 -> 4x4 phase filters, F(3x3,4x4)
         th, tw = -(-h // mo), -(-w // mo)
-        if tw >= 12 or (tw >= 6 and th >= 2):
-            return "conv_winograd36s_f32_kernel<%d, false, 0, %d, true>" % (16 if tw >= 12 else 8, mo), 4 * 36.0 / (mo * mo) / (k * k)
+        shapes = [c for c in (16, 8, 4) if (tw >= 12 if c == 16 else (tw >= 6 and th >= 2) if c == 8 else (tw >= 3 and th >= 3))]
+        if shapes:                                                      # the tile block shape that pads the tile grid least (ties: the widest), as cnm_wino36s_try_launch
+            tsx = min(shapes, key=lambda c: (-(-tw // c) * c * -(-th // (16 // c)) * (16 // c), -c))
+            return "conv_winograd36s_f32_kernel<%d, false, 0, %d, true>" % (tsx, mo), 4 * 36.0 / (mo * mo) / (k * k)
     if k in (5, 7):                                                  # F(2,k) along rows; stride 2: two F(2,ceil(k/2)) column phases
         if k == 7 and s == 1:
             staged = L["Cout"] % 128 == 0 and w >= 32 and h >= 4                  # cnm_rows7s_try_launch (conv_rows_staged.hip)

@@ -442,7 +442,7 @@ extern "C" int cnm_pack_winograd4_s2_bn_f32(const float* w_oihw, const float* bn
 extern "C" int cnm_conv_s2_winograd4_ok(int Cout, int H, int W, int ksize) {
     if ((ksize != 5 && ksize != 7) || Cout <= 0 || Cout % 128 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return 0;
     const int m = ksize == 5 ? 4 : 3, th = (H / 2 + m - 1) / m, tw = (W / 2 + m - 1) / m;
-    return tw >= 12 || (tw >= 6 && th >= 2);
+    return tw >= 12 || (tw >= 6 && th >= 2) || (tw >= 3 && th >= 3);
 }
 
 extern "C" int cnm_conv_s2_winograd4_sync_c4_f32(const float* in_a, int Ga_total, int ga0, int Ga,

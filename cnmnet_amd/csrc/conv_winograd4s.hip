@@ -542,6 +542,17 @@ int cnm_wino36s_try_launch(const Wino4Args& a, int M, int ups, hipStream_t strea
     int tsx = 0;
     if (a.TW >= 12) tsx = 16; else if (a.TW >= 6 && a.TH >= 2) tsx = 8; else if (M == 4 && !ups && !s2 && a.TW >= 3 && a.TH >= 3) tsx = 4;   // tile block 1 x 16, 2 x 8, 4 x 4
     if (!tsx) return 1;
+    if (s2) {
+        // stride-2 form: the tile block shape that pads the tile grid least (ties: the widest).  conv1.3 (32 x 43 tiles of 3 x 3
+        // outputs): 4 x 4 blocks cover 32 x 44 tiles, 1 x 16 blocks 32 x 48 -- 0.99 -> 0.90 ms (tools/s2_probe.py)
+        long long best = -1;
+        for (int c = 16; c >= 4; c >>= 1) {
+            const int cy = 16 / c;
+            if (!(c == 16 ? a.TW >= 12 : c == 8 ? (a.TW >= 6 && a.TH >= 2) : (a.TW >= 3 && a.TH >= 3))) continue;
+            const long long cover = (long long)cnm_ceil_div(a.TW, c) * c * cnm_ceil_div(a.TH, cy) * cy;
+            if (best < 0 || cover < best) { best = cover; tsx = c; }
+        }
+    }
     const int tsy = 16 / tsx;
     const int SH = cnm_ceil_div(a.TH, tsy), SW = cnm_ceil_div(a.TW, tsx), tilesC = a.Cout / 128;
     const long long nunits = (long long)a.N * SH * SW * tilesC;
@@ -576,9 +587,11 @@ int cnm_wino36s_try_launch(const Wino4Args& a, int M, int ups, hipStream_t strea
     if (s2) {                                                            // stride 2 on the four pixel phases: 5x5 -> F(4x4,3x3), 7x7 -> F(3x3,4x4)
         if (M == 4) {
             if (tsx == 16) conv_winograd36s_f32_kernel<16, false, 0, 4, true><<<grid, 512, 0, stream>>>(a, SH, SW, tilesC, (int)nunits, flags, slots);
+            else if (tsx == 4) conv_winograd36s_f32_kernel<4, false, 0, 4, true><<<grid, 512, 0, stream>>>(a, SH, SW, tilesC, (int)nunits, flags, slots);
             else conv_winograd36s_f32_kernel<8, false, 0, 4, true><<<grid, 512, 0, stream>>>(a, SH, SW, tilesC, (int)nunits, flags, slots);
         } else {
             if (tsx == 16) conv_winograd36s_f32_kernel<16, false, 0, 3, true><<<grid, 512, 0, stream>>>(a, SH, SW, tilesC, (int)nunits, flags, slots);
+            else if (tsx == 4) conv_winograd36s_f32_kernel<4, false, 0, 3, true><<<grid, 512, 0, stream>>>(a, SH, SW, tilesC, (int)nunits, flags, slots);
             else conv_winograd36s_f32_kernel<8, false, 0, 3, true><<<grid, 512, 0, stream>>>(a, SH, SW, tilesC, (int)nunits, flags, slots);
         }
     } else if (M == 2) {

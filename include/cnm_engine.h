@@ -231,7 +231,7 @@ int cnm_conv5x5_winograd_sync_c4_f32(const float* in_a, int Ga_total, int ga0, i
  * F(3x3,4x4) on the same six points, 16 instead of 49 (22.75).  H, W (even) = INPUT size, out = [N][Gout][H/2][W/2][4].
  * u_packed from cnm_pack_winograd4_s2_bn_f32 (cnm_packed_winograd4_s2_floats floats).  Staged kernel only: needs the
  * sync workspace of cnm_conv3x3_winograd4_sync_c4_f32 (same contract) and a shape cnm_conv_s2_winograd4_ok() accepts
- * (Cout % 128 == 0, even H and W, at least six tiles per output row): CNM_ERR_BAD_ARG otherwise.
+ * (Cout % 128 == 0, even H and W, at least 3 x 3 tiles of 4 x 4 (5x5) / 3 x 3 (7x7) outputs per image): CNM_ERR_BAD_ARG otherwise.
  * cnm_tune_wino4_s2(0) makes the fp32 executors keep the row-wise phase kernel for these layers (default 1; other values query). */
 size_t cnm_packed_winograd4_s2_floats(int Cout, int Cin);
 int cnm_pack_winograd4_s2_bn_f32(const float* w_oihw, const float* bn_gamma, const float* bn_var, float eps,

@@ -463,7 +463,9 @@ def test_conv5x5_winograd_staged(dev, ops, cin, cout, rot, N, H, W):
     (5, 32, 20, 128, 0, 3, 24, 56),    # concatenated input, 2 x 8 tile blocks (3 x 7 tiles)
     (7, 64, 0, 128, 0, 2, 96, 128),    # conv1.3's geometry at half the channels: F(3x3,4x4), 16 x 22 tiles (ragged: 64 = 21.3 x 3)
     (7, 19, 0, 256, 0, 1, 38, 74),     # ragged everything: 19 rows / 37 columns of outputs = 7 x 13 tiles
-    (7, 16, 16, 128, 0, 2, 20, 40)])   # concatenated input, 2 x 8 tile blocks (4 x 7 tiles)
+    (7, 16, 16, 128, 0, 2, 20, 40),    # concatenated input, 2 x 8 tile blocks (4 x 7 tiles)
+    (5, 24, 0, 128, 0, 3, 40, 24),     # 4 x 4 tile blocks: 5 x 3 tiles per image
+    (7, 32, 0, 128, 0, 2, 48, 26)])    # 4 x 4 tile blocks: 8 x 5 tiles per image (13 columns of outputs)
 def test_conv_s2_winograd4_staged(dev, ops, k, cin, cin2, cout, rot, N, H, W):
     """Stride-2 5x5 / 7x7 layers as a stride-1 convolution of the four pixel phases of the input on the LDS-staged 36-point
     kernel (F(4x4,3x3) / F(3x3,4x4)): within the 36-point kernels' per-layer bar of the fp64 torch convolution, next to the
@@ -502,7 +504,8 @@ def test_conv_s2_winograd4_staged(dev, ops, k, cin, cin2, cout, rot, N, H, W):
     with pytest.raises(_lib.EngineError):
         ops.conv_s2_winograd4_c4(xc, up, bp, cout, k, True, x2=x2c, sync=None)
     assert lib.cnm_conv_s2_winograd4_ok(cout, H + 1, W, k) == 0 and lib.cnm_conv_s2_winograd4_ok(64, H, W, k) == 0
-    assert lib.cnm_conv_s2_winograd4_ok(cout, H, 16, k) == 0 and lib.cnm_conv_s2_winograd4_ok(cout, H, W, 3) == 0
+    assert lib.cnm_conv_s2_winograd4_ok(cout, H, 8, k) == 0 and lib.cnm_conv_s2_winograd4_ok(cout, H, W, 3) == 0
+    assert lib.cnm_conv_s2_winograd4_ok(cout, 16, 24, k) == 0 and lib.cnm_conv_s2_winograd4_ok(cout, 24, 24, k) == 1
 
 
 @pytest.mark.parametrize("cin,cout,N,H,W", [(128, 64, 2, 48, 64), (256, 128, 1, 24, 32), (64, 64, 2, 20, 36)])
