@@ -81,6 +81,12 @@ def _winograd_conv(x, weight, rot, stride=1, dgrad=False):
         else:
             up4 = _packed("u4", weight, rot, 1, lambda: ops.pack_winograd4(weight, None, rot))
         return ops.conv3x3_winograd4_c4(x, up4, None, Cout, relu=False, sync=_sync_workspace(x.device))
+    if (not dgrad and stride == 2 and k in S2_PHASE_KSIZES and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
+            and _lib.load().cnm_conv_s2_winograd4_ok(Cout, x.shape[2], x.shape[3], k)):
+        # stride-2 5x5 / 7x7 forward: the four pixel phases of x on the staged 36-point kernel (F(4x4,3x3) / F(3x3,4x4)),
+        # the transforms the 3x3 layers of the step already run with
+        ups = _packed("u4s2", weight, rot, 2, lambda: ops.pack_winograd4_s2(weight, None, rot))
+        return ops.conv_s2_winograd4_c4(x, ups, None, Cout, k, relu=False, sync=_sync_workspace(x.device))
     if dgrad:
         weight = _dgrad_weight(weight)
     up = _packed("u2", weight, rot, stride, lambda: ops.pack_winograd(weight, None, rot, stride=stride, tile=2))    # training keeps the more accurate F(2,k) rows
@@ -90,6 +96,8 @@ def _winograd_conv(x, weight, rot, stride=1, dgrad=False):
 
 
 WINOGRAD4_MIN_WORKGROUPS = 384   # same switch point as the inference executors (include/cnm_engine.h)
+S2_PHASE_KSIZES = (5, 7)         # stride-2 layers whose FORWARD runs on the pixel phases of the input (ops.conv_s2_winograd4_c4); () keeps the F(2,k) row phases
+S2_DGRAD_SCATTER = True          # stride-2 data gradient with 3x3 phase filters: one phase-interleaving launch instead of four convolutions + four strided copies
 WINOGRAD4_SMALL = True           # ... and the same extension below it (nets.hip wino4_staged_small)
 
 
@@ -158,9 +166,16 @@ class ConvC4(torch.autograd.Function):
                   and H % 2 == 0 and W % 2 == 0):
                 # stride 2: four stride-1 Winograd convolutions of dY, one per pixel phase of dX (sub-pixel
                 # decomposition: the zero-upsampled dY with its 3/4 structural zeros never exists)
-                dx = torch.empty_like(x)
-                for a, b, wp in _packed("s2", weight, 0, 2, lambda: _stride2_dgrad_phases(weight.detach())):
-                    dx[:, :, a::2, b::2] = _winograd_conv(dy, wp, 0)
+                phases = _packed("s2", weight, 0, 2, lambda: _stride2_dgrad_phases(weight.detach()))
+                if S2_DGRAD_SCATTER and all(wp.shape[2] == 3 for _, _, wp in phases):
+                    # 3x3 and 5x5 filters: all four phase filters are 3x3 -- ONE F(4x4,3x3) launch with 4*Cin output channels whose
+                    # store path interleaves the phases (the kernel of the fused up_conv layers, zero padding): no scatter copies
+                    up = _packed("s2cat", weight, 0, 2, lambda: ops.pack_winograd4(torch.cat([wp for _, _, wp in phases], 0)))
+                    dx = ops.conv3x3_phase_scatter_c4(dy, up, Cin, sync=_sync_workspace(dev))
+                else:
+                    dx = torch.empty_like(x)
+                    for a, b, wp in phases:
+                        dx[:, :, a::2, b::2] = _winograd_conv(dy, wp, 0)
             elif ctx.needs_input_grad[0]:
                 wd = torch.empty(lib.cnm_packed_dgrad_floats(Cout, Cin, k), device=dev, dtype=torch.float32)
                 _lib.check(lib.cnm_pack_conv_dgrad_f32(weight.detach().contiguous().data_ptr(), Cout, Cin, k, ctx.rot, wd.data_ptr(), _s()))

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256, 2) void conv_winograd36_f32_kernel(const Wino4
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             int iy = py + i, ix = px + i;
-            if constexpr (UPS) { iy = min(max(iy, 0), a.H - 1); ix = min(max(ix, 0), a.W - 1); }
+            if constexpr (UPS) { if (!a.ups_zero) { iy = min(max(iy, 0), a.H - 1); ix = min(max(ix, 0), a.W - 1); } }
             roff[i] = (tvalid & ((unsigned)iy < (unsigned)a.H)) ? imgterm + (unsigned)(iy * a.W) * 16u + cc * 4u : 0xFFFFFFFFu;
             coff[i] = (unsigned)ix < (unsigned)a.W ? (unsigned)ix * 16u : 0xFFFFFFFFu;
         }
@@ -320,7 +320,7 @@ static int pack36(const float* w_oihw, const float* bn_gamma, const float* bn_va
 
 static int conv36(const float* in_a, int Ga_total, int ga0, int Ga, const float* in_b, int Gb_total, int gb0, int Gb,
                   float* out, int Gout_total, int gout0, int Cout, const float* u_packed, const float* b_packed,
-                  int N, int H, int W, int ksize, int relu, void* stream, int ups = 0, int ring = 0, float* sync_ws = nullptr, size_t sync_floats = 0, int s2 = 0) {
+                  int N, int H, int W, int ksize, int relu, void* stream, int ups = 0, int ring = 0, float* sync_ws = nullptr, size_t sync_floats = 0, int s2 = 0, int ups_zero = 0) {
     CNM_REQUIRE(in_a && out && u_packed && N > 0 && H > 0 && W > 0 && Ga > 0 && Gb >= 0, CNM_ERR_BAD_ARG);
     CNM_REQUIRE(!s2 || (!ups && (ksize == 5 || ksize == 7) && H % 2 == 0 && W % 2 == 0 && sync_ws), CNM_ERR_BAD_ARG);
     CNM_REQUIRE(Cout > 0 && Cout % 64 == 0 && gout0 >= 0 && gout0 + Cout / 4 <= Gout_total, CNM_ERR_BAD_ARG);
@@ -337,7 +337,7 @@ static int conv36(const float* in_a, int Ga_total, int ga0, int Ga, const float*
     a.N = N; a.H = H; a.W = W; a.TH = (H + m - 1) / m; a.TW = (W + m - 1) / m;
     a.Gin_tot = Ga_total; a.gin0 = ga0; a.Gin2_tot = Gb ? Gb_total : Ga_total; a.gin2_0 = Gb ? gb0 : ga0; a.Gsplit = Ga; a.Gin = Ga + Gb;
     a.Gout_tot = Gout_total; a.gout0 = gout0; a.Cout = ups ? 4 * Cout : Cout;     // fused upsampling: four phases of virtual output channels
-    a.nchunks = (4 * a.Gin + 15) / 16 * (s2 ? 4 : 1); a.T = N * a.TH * a.TW; a.relu = relu; a.ring = ring;
+    a.nchunks = (4 * a.Gin + 15) / 16 * (s2 ? 4 : 1); a.T = N * a.TH * a.TW; a.relu = relu; a.ring = ring; a.ups_zero = ups_zero;
     a.sync_ws = sync_ws; a.sync_floats = sync_floats;
     {
         const int e = cnm_wino36s_try_launch(a, m, ups, cnm_stream(stream), s2);   // LDS-staged persistent variant where eligible
@@ -402,6 +402,19 @@ extern "C" int cnm_conv3x3_upsampled_winograd4_sync_c4_f32(const float* in, int 
                                                            const float* u_packed, const float* b_packed,
                                                            int N, int H, int W, int relu, int with_ring, float* sync_ws, size_t sync_floats, void* stream) {
     return conv36(in, Gin_total, gin0, Gin, nullptr, 0, 0, 0, out, Gout_total, gout0, Cout, u_packed, b_packed, N, H, W, 3, relu, stream, 1, with_ring, sync_ws, sync_floats);
+}
+
+// Phase-scatter form: four 3x3 stride-1 convolutions of `in` [N][G][H][W][4], one per pixel phase (a, b) of the output
+// [N][Gout][2H][2W][4] -- out[2y + a][2x + b] = conv3x3(in, w_phase[2a + b])[y][x], zero padding -- in ONE launch: the four filters
+// packed as 4*Cout output channels, phase major (cnm_pack_winograd4_bn_f32 of the [4*Cout, Cin, 3, 3] tensor), on the
+// kernel of the fused up_conv layers with its interleaving store path.  This is the data gradient of a stride-2
+// convolution (train.py:164-310 through autograd: dX phases are stride-1 convolutions of dY), written without the four
+// strided scatter copies.  Same sync-workspace contract as cnm_conv3x3_winograd4_sync_c4_f32 (NULL allowed).
+extern "C" int cnm_conv3x3_phase_scatter_winograd4_sync_c4_f32(const float* in, int Gin_total, int gin0, int Gin,
+                                                               float* out, int Gout_total, int gout0, int Cout,
+                                                               const float* u_packed, const float* b_packed,
+                                                               int N, int H, int W, int relu, float* sync_ws, size_t sync_floats, void* stream) {
+    return conv36(in, Gin_total, gin0, Gin, nullptr, 0, 0, 0, out, Gout_total, gout0, Cout, u_packed, b_packed, N, H, W, 3, relu, stream, 1, 0, sync_ws, sync_floats, 0, 1);
 }
 
 // F(2x2,5x5): the same 36-point machine with 2x2 output tiles (25 -> 9 multiplies per output; the row-wise kernel needs 15)

@@ -188,7 +188,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
             const int slot = 64 * k + lane, r = slot / PC, pc = slot - r * PC;
             int y = y0 + r, x = x0 + pc;
             bool ok = slot < NSLOT;
-            if constexpr (UPS) { y = min(max(y, 0), a.H - 1); x = min(max(x, 0), a.W - 1); }
+            if (UPS && !a.ups_zero) { y = min(max(y, 0), a.H - 1); x = min(max(x, 0), a.W - 1); }
             else ok = ok & ((unsigned)y < (unsigned)a.H) & ((unsigned)x < (unsigned)a.W);
             *reinterpret_cast<unsigned*>(smem + DV0 + (m * 512 + t) * 4) = ok ? (unsigned)(S2 ? 4 * y * a.W + 2 * x : y * a.W + x) * 16u : 0xFFFFFFFFu;
         }
@@ -541,7 +541,6 @@ int cnm_wino36s_try_launch(const Wino4Args& a, int M, int ups, hipStream_t strea
     if (!g_wino36_staged || (M != 4 && M != 2 && !(M == 3 && s2)) || (ups && (M != 4 || s2)) || (s2 && M == 2) || a.Cout % 128) return 1;
     int tsx = 0;
     if (a.TW >= 12) tsx = 16; else if (a.TW >= 6 && a.TH >= 2) tsx = 8; else if (M == 4 && !ups && !s2 && a.TW >= 3 && a.TH >= 3) tsx = 4;   // tile block 1 x 16, 2 x 8, 4 x 4
-    if (!tsx) return 1;
     if (s2) {
         // stride-2 form: the tile block shape that pads the tile grid least (ties: the widest).  conv1.3 (32 x 43 tiles of 3 x 3
         // outputs): 4 x 4 blocks cover 32 x 44 tiles, 1 x 16 blocks 32 x 48 -- 0.99 -> 0.90 ms (tools/s2_probe.py)
@@ -553,6 +552,7 @@ int cnm_wino36s_try_launch(const Wino4Args& a, int M, int ups, hipStream_t strea
             if (best < 0 || cover < best) { best = cover; tsx = c; }
         }
     }
+    if (!tsx) return 1;
     const int tsy = 16 / tsx;
     const int SH = cnm_ceil_div(a.TH, tsy), SW = cnm_ceil_div(a.TW, tsx), tilesC = a.Cout / 128;
     const long long nunits = (long long)a.N * SH * SW * tilesC;

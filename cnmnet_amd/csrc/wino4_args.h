@@ -10,6 +10,7 @@ struct Wino4Args {
     int Gout_tot, gout0, Cout;
     int nchunks, T, relu;                // T = N*TH*TW tiles
     int ring;                            // fused upsampling: leave the one-pixel output ring without bias / ReLU for the ring kernel
+    int ups_zero;                        // UPS kernels: zero padding of the low-resolution input instead of edge replication (phase-scatter form)
     float* sync_ws; size_t sync_floats;  // LDS-staged kernel only: zeroed flag words + partial-output slots (cnm_wino36_sync_floats), or null
 };
 

@@ -288,6 +288,20 @@ def conv_s2_winograd4_c4(x, u_packed, b_packed, Cout, ksize, relu=True, x2=None,
     return out
 
 
+def conv3x3_phase_scatter_c4(x, u_packed, Cout, sync=None, out=None):
+    """out[:, :, a::2, b::2] = conv3x3(x, w_phase[2a + b]) (zero padding, no bias) for the four filters packed phase major as
+    4*Cout output channels (pack_winograd4 of the [4*Cout, Cin, 3, 3] tensor): x [N,G,H,W,4] -> [N,Cout/4,2H,2W,4], one launch."""
+    _dev(x, u_packed, sync)
+    N, G, H, W, _ = x.shape
+    if out is None:
+        out = torch.empty(N, Cout // 4, 2 * H, 2 * W, 4, device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().cnm_conv3x3_phase_scatter_winograd4_sync_c4_f32(_p(x), G, 0, G, _p(out), Cout // 4, 0, Cout, _p(u_packed), None,
+                                                                               N, H, W, 0, _p(sync) if sync is not None else None,
+                                                                               sync.numel() if sync is not None else 0, _stream()))
+    return out
+
+
 def pack_winograd4_dgrad(weight):
     """pack_winograd4(weight.flip(2, 3).transpose(0, 1)) -- the 36-point filter of the data gradient of a stride-1 3x3 / 5x5
     convolution -- without materialising the flipped tensor."""

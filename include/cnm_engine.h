@@ -224,6 +224,17 @@ int cnm_conv5x5_winograd_sync_c4_f32(const float* in_a, int Ga_total, int ga0, i
                                      const float* u_packed, const float* b_packed,
                                      int N, int H, int W, int relu, float* sync_ws, size_t sync_floats, void* stream);
 
+/* Phase-scatter form of four 3x3 stride-1 convolutions: out[2y + a][2x + b] = conv3x3(in, w_phase[2a + b])[y][x] (zero
+ * padding), in [N][G][H][W][4] -> out [N][Gout][2H][2W][4], ONE launch on the kernel of the fused up_conv layers with the
+ * four filters packed as 4*Cout output channels, phase major (cnm_pack_winograd4_bn_f32 of the [4*Cout, Cin, 3, 3]
+ * tensor; b_packed: 4*Cout values or NULL).  It is the data gradient of a stride-2 convolution with a 3x3 or 5x5 filter
+ * (reference train.py:164-310 via autograd of depthNet_model.py:19-43 conv_layer): the dX phases are stride-1
+ * convolutions of dY.  Sync workspace as for cnm_conv3x3_winograd4_sync_c4_f32 (NULL / 0 allowed). */
+int cnm_conv3x3_phase_scatter_winograd4_sync_c4_f32(const float* in, int Gin_total, int gin0, int Gin,
+                                                    float* out, int Gout_total, int gout0, int Cout,
+                                                    const float* u_packed, const float* b_packed,
+                                                    int N, int H, int W, int relu, float* sync_ws, size_t sync_floats, void* stream);
+
 /* The STRIDE-2 5x5 / 7x7 layers (conv2.3 = nn.Conv2d(256, 256, 5, 2, 2), conv1.3 = nn.Conv2d(128, 128, 7, 2, 3),
  * depthNet_model.py:136-139,145-148 through conv_layer :19-43) as a stride-1 convolution of the four pixel phases of the
  * input (space to depth, never materialised) on the LDS-staged 36-point kernel: 5x5 -> four 3x3 phase filters,

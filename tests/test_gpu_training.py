@@ -57,6 +57,39 @@ def test_conv_forward_dgrad_wgrad(dev, cin, cout, k, stride, rot, N, H, W):
     assert _rel(wd.grad.cpu().numpy(), w.grad.numpy()) < 5e-5
 
 
+@pytest.mark.parametrize("cin,cout,k,N,Ho,Wo", [(64, 128, 3, 2, 24, 32), (128, 64, 5, 1, 48, 64), (64, 64, 3, 3, 9, 14), (256, 128, 5, 2, 6, 8)])
+def test_stride2_dgrad_phase_scatter(dev, cin, cout, k, N, Ho, Wo):
+    """Data gradient of a stride-2 3x3 / 5x5 convolution as ONE phase-interleaving F(4x4,3x3) launch
+    (cnm_conv3x3_phase_scatter_winograd4_sync_c4_f32: the four 3x3 phase filters as 4*Cin output channels, zero padding, staged
+    and gather-fed kernels) against torch's conv_transpose2d in fp64, and against the four-convolutions-plus-scatter path."""
+    from cnmnet_amd import ops, autograd as ag
+    rng = np.random.default_rng(cin + cout + k)
+    w = T((rng.standard_normal((cout, cin, k, k)) * 0.05).astype(np.float32))
+    dy = T(rng.standard_normal((N, cout, Ho, Wo)).astype(np.float32))
+    want = F.conv_transpose2d(dy.double(), w.double(), stride=2, padding=k // 2, output_padding=1).numpy()
+    phases = ag._stride2_dgrad_phases(w.to(dev))
+    assert all(wp.shape[2] == 3 for _, _, wp in phases)
+    up = ops.pack_winograd4(torch.cat([wp for _, _, wp in phases], 0))
+    dyc = ops.nchw_to_c4(dy.to(dev))
+    sync = ops.wino36_sync_workspace(dev)
+    outs = [ops.conv3x3_phase_scatter_c4(dyc, up, cin, sync=sy).clone() for sy in (None, sync, sync)]
+    for o in outs[:2]:
+        assert _rel(ops.c4_to_nchw(o, cin).cpu().numpy(), want) < 2e-5
+    assert torch.equal(outs[1], outs[2]) and float(sync[:1024].abs().max()) == 0.0
+    old = ag.S2_DGRAD_SCATTER
+    try:
+        res = []
+        for mode in (True, False):
+            ag.S2_DGRAD_SCATTER = mode
+            x = torch.zeros(N, cin // 4, 2 * Ho, 2 * Wo, 4, device=dev, requires_grad=True)
+            y = ag.ConvC4.apply(x, w.to(dev).requires_grad_(True), 2, 0)
+            y.backward(dyc)
+            res.append(x.grad.clone())
+    finally:
+        ag.S2_DGRAD_SCATTER = old
+    assert _rel(res[0].cpu().numpy(), res[1].cpu().numpy()) < 2e-5
+
+
 @pytest.mark.parametrize("C,N,H,W,relu", [(128, 2, 12, 20, True), (67, 3, 8, 8, False), (512, 2, 6, 8, True)])
 def test_batchnorm_train_forward_backward(dev, C, N, H, W, relu):
     from cnmnet_amd import ops, autograd as ag
