@@ -62,6 +62,8 @@ PROTOTYPES = {
                                                c_i, c_i, c_i, c_i, c_fp, c_sz, c_fp]),
     "cnm_conv3x3_upsampled_winograd4_sync_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_sz, c_fp]),
     "cnm_conv3x3_phase_scatter_winograd4_sync_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_sz, c_fp]),
+    "cnm_conv4x4_phase_scatter_winograd_sync_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_sz, c_fp]),
+    "cnm_pack_winograd36_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_fp]),
     "cnm_packed_winograd4_s2_floats": (c_sz, [c_i, c_i]),
     "cnm_pack_winograd4_s2_bn_f32": (c_i, [c_fp, c_fp, c_fp, c_f, c_i, c_i, c_i, c_i, c_fp, c_fp]),
     "cnm_conv_s2_winograd4_ok": (c_i, [c_i, c_i, c_i, c_i]),

@@ -133,6 +133,14 @@ def _stride2_dgrad_phases(weight):
     return out
 
 
+def _taps4(wp):
+    """A phase filter of _stride2_dgrad_phases (3x3: offsets -1 .. 1, 5x5: offsets -2 .. 2 with nothing at -2) as 4x4 taps at
+    offsets -1 .. 2."""
+    if wp.shape[2] == 3:
+        return torch.nn.functional.pad(wp, (0, 1, 0, 1))
+    return wp[:, :, 1:, 1:]
+
+
 class ConvC4(torch.autograd.Function):
     """y = conv2d(x, weight, stride, padding=(k-1)//2) on c4 tensors, no bias.
     x [N,ceil(Cin/4),H,W,4] (channels possibly rotated by `rot`), weight OIHW; Cout % 4 == 0, >= 16."""
@@ -172,6 +180,11 @@ class ConvC4(torch.autograd.Function):
                     # store path interleaves the phases (the kernel of the fused up_conv layers, zero padding): no scatter copies
                     up = _packed("s2cat", weight, 0, 2, lambda: ops.pack_winograd4(torch.cat([wp for _, _, wp in phases], 0)))
                     dx = ops.conv3x3_phase_scatter_c4(dy, up, Cin, sync=_sync_workspace(dev))
+                elif (S2_DGRAD_SCATTER and k == 7 and Cin % 32 == 0 and (dy.shape[3] + 2) // 3 >= 6 and (dy.shape[2] + 2) // 3 >= 2):
+                    # 7x7: phase filters of 3 or 4 taps per axis at offsets -1 .. 1 / -1 .. 2 -- all four as 4x4 filters on F(3x3,4x4),
+                    # again one phase-interleaving launch (staged kernel)
+                    up = _packed("s2cat", weight, 0, 2, lambda: ops.pack_winograd36(torch.cat([_taps4(wp) for _, _, wp in phases], 0)))
+                    dx = ops.conv3x3_phase_scatter_c4(dy, up, Cin, sync=_sync_workspace(dev), ksize=4)
                 else:
                     dx = torch.empty_like(x)
                     for a, b, wp in phases:

@@ -313,6 +313,7 @@ static int pack36(const float* w_oihw, const float* bn_gamma, const float* bn_va
     if (s2 && ksize == 5) pack_winograd36_kernel<3, true><<<nb, 256, 0, cnm_stream(stream)>>>(w_oihw, bn_gamma, bn_var, eps, Cout, Cin, rot, nchunks, u_packed, 0);
     else if (s2) pack_winograd36_kernel<4, true><<<nb, 256, 0, cnm_stream(stream)>>>(w_oihw, bn_gamma, bn_var, eps, Cout, Cin, rot, nchunks, u_packed, 0);
     else if (ksize == 3) pack_winograd36_kernel<3><<<nb, 256, 0, cnm_stream(stream)>>>(w_oihw, bn_gamma, bn_var, eps, Cout, Cin, rot, nchunks, u_packed, dgrad);
+    else if (ksize == 4) pack_winograd36_kernel<4><<<nb, 256, 0, cnm_stream(stream)>>>(w_oihw, bn_gamma, bn_var, eps, Cout, Cin, rot, nchunks, u_packed, dgrad);
     else pack_winograd36_kernel<5><<<nb, 256, 0, cnm_stream(stream)>>>(w_oihw, bn_gamma, bn_var, eps, Cout, Cin, rot, nchunks, u_packed, dgrad);
     CNM_LAUNCH_CHECK();
     return CNM_OK;
@@ -324,7 +325,7 @@ static int conv36(const float* in_a, int Ga_total, int ga0, int Ga, const float*
     CNM_REQUIRE(in_a && out && u_packed && N > 0 && H > 0 && W > 0 && Ga > 0 && Gb >= 0, CNM_ERR_BAD_ARG);
     CNM_REQUIRE(!s2 || (!ups && (ksize == 5 || ksize == 7) && H % 2 == 0 && W % 2 == 0 && sync_ws), CNM_ERR_BAD_ARG);
     CNM_REQUIRE(Cout > 0 && Cout % 64 == 0 && gout0 >= 0 && gout0 + Cout / 4 <= Gout_total, CNM_ERR_BAD_ARG);
-    CNM_REQUIRE(!ups || ksize == 3, CNM_ERR_BAD_ARG);
+    CNM_REQUIRE(!ups || ksize == 3 || (ksize == 4 && ups_zero), CNM_ERR_BAD_ARG);
     CNM_REQUIRE(ga0 >= 0 && ga0 + Ga <= Ga_total && (Gb == 0 || (in_b && gb0 >= 0 && gb0 + Gb <= Gb_total)), CNM_ERR_BAD_ARG);
     Wino4Args a;
     a.in = in_a; a.in2 = Gb ? in_b : in_a; a.out = out; a.u = u_packed; a.bias = b_packed;
@@ -332,7 +333,7 @@ static int conv36(const float* in_a, int Ga_total, int ga0, int Ga, const float*
     const unsigned long long b2 = Gb ? (unsigned long long)N * Gb_total * H * W * 16ull : b1;
     CNM_REQUIRE(b1 < 0xFFFFFFFFull && b2 < 0xFFFFFFFFull, CNM_ERR_BAD_ARG);
     a.in_bytes = (unsigned)b1; a.in2_bytes = (unsigned)b2;
-    const int m = s2 ? (ksize == 5 ? 4 : 3) : ksize == 3 ? 4 : 2;       // outputs per tile side
+    const int m = s2 ? (ksize == 5 ? 4 : 3) : ksize == 3 ? 4 : ksize == 4 ? 3 : 2;   // outputs per tile side
     if (s2) { H /= 2; W /= 2; }                                          // from here on the output (= phase image) size
     a.N = N; a.H = H; a.W = W; a.TH = (H + m - 1) / m; a.TW = (W + m - 1) / m;
     a.Gin_tot = Ga_total; a.gin0 = ga0; a.Gin2_tot = Gb ? Gb_total : Ga_total; a.gin2_0 = Gb ? gb0 : ga0; a.Gsplit = Ga; a.Gin = Ga + Gb;
@@ -342,7 +343,7 @@ static int conv36(const float* in_a, int Ga_total, int ga0, int Ga, const float*
     {
         const int e = cnm_wino36s_try_launch(a, m, ups, cnm_stream(stream), s2);   // LDS-staged persistent variant where eligible
         if (e <= 0) return e;
-        CNM_REQUIRE(!s2, CNM_ERR_BAD_ARG);                               // the stride-2 form exists on the staged kernel only (cnm_conv_s2_winograd4_ok)
+        CNM_REQUIRE(!s2 && m != 3, CNM_ERR_BAD_ARG);                     // the stride-2 form and F(3x3,4x4) exist on the staged kernel only (cnm_conv_s2_winograd4_ok)
     }
     const int nblocks = (a.Cout / 64) * cnm_ceil_div(a.T, 16);
     if (ups) conv_winograd36_f32_kernel<4, 3, true><<<nblocks, 256, 0, cnm_stream(stream)>>>(a);
@@ -415,6 +416,23 @@ extern "C" int cnm_conv3x3_phase_scatter_winograd4_sync_c4_f32(const float* in, 
                                                                const float* u_packed, const float* b_packed,
                                                                int N, int H, int W, int relu, float* sync_ws, size_t sync_floats, void* stream) {
     return conv36(in, Gin_total, gin0, Gin, nullptr, 0, 0, 0, out, Gout_total, gout0, Cout, u_packed, b_packed, N, H, W, 3, relu, stream, 1, 0, sync_ws, sync_floats, 0, 1);
+}
+
+// The same with 4x4 phase filters (taps at offsets -1 .. 2 of either axis) on F(3x3,4x4): the data gradient of a stride-2 7x7
+// convolution.  u_packed: cnm_pack_winograd36_f32(ksize 4) of the [4*Cout, Cin, 4, 4] tensor.  Staged kernel only: 4*Cout % 128
+// == 0 and at least 6 x 2 tiles of 3 x 3 low-resolution pixels per image, else CNM_ERR_BAD_ARG.
+extern "C" int cnm_conv4x4_phase_scatter_winograd_sync_c4_f32(const float* in, int Gin_total, int gin0, int Gin,
+                                                              float* out, int Gout_total, int gout0, int Cout,
+                                                              const float* u_packed, const float* b_packed,
+                                                              int N, int H, int W, int relu, float* sync_ws, size_t sync_floats, void* stream) {
+    CNM_REQUIRE(Cout > 0 && Cout % 32 == 0 && (W + 2) / 3 >= 6 && (H + 2) / 3 >= 2, CNM_ERR_BAD_ARG);
+    return conv36(in, Gin_total, gin0, Gin, nullptr, 0, 0, 0, out, Gout_total, gout0, Cout, u_packed, b_packed, N, H, W, 4, relu, stream, 1, 0, sync_ws, sync_floats, 0, 1);
+}
+
+// Plain 36-point pack of a [Cout, Cin, k, k] filter (k = 3, 4, 5: F(4x4,3x3), F(3x3,4x4), F(2x2,5x5)), no BatchNorm fold, no rotation
+extern "C" int cnm_pack_winograd36_f32(const float* w_oihw, int Cout, int Cin, int ksize, float* u_packed, void* stream) {
+    CNM_REQUIRE(ksize >= 3 && ksize <= 5, CNM_ERR_BAD_ARG);
+    return pack36(w_oihw, nullptr, nullptr, 0.f, Cout, Cin, ksize, 0, u_packed, stream);
 }
 
 // F(2x2,5x5): the same 36-point machine with 2x2 output tiles (25 -> 9 multiplies per output; the row-wise kernel needs 15)

@@ -118,9 +118,9 @@ __device__ unsigned g_wino4s_tl[2 * 8 * 24];                             // [wav
 template <int TSX, bool UPS, int ABL = 0, int M = 4, bool S2 = false>   // tile block = (16 / TSX) x TSX tiles of M x M outputs
 __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino4Args a, const int SH, const int SW, const int tilesC, const int nunits,
                                                                        unsigned* __restrict__ sync_flags, float* __restrict__ sync_slots) {
-    static_assert((M == 4 || M == 2 || (M == 3 && S2)) && !(UPS && (M != 4 || S2)), "F(4x4,3x3) (optionally on a 2x upsampled input or on the phases of a stride-2 5x5), F(2x2,5x5), F(3x3,4x4) on the phases of a stride-2 7x7");
+    static_assert((M == 4 || M == 2 || (M == 3 && (S2 || UPS))) && !(UPS && (M == 2 || S2)), "F(4x4,3x3) (optionally on a 2x upsampled input or on the phases of a stride-2 5x5), F(2x2,5x5), F(3x3,4x4) on the phases of a stride-2 7x7 or as its phase-scattering data gradient");
     constexpr int TSY = 16 / TSX, PR = M * TSY + 6 - M, PC = M * TSX + 6 - M, NSLOT = PR * PC;
-    constexpr int PADW = M == 3 ? 2 : (6 - M) / 2;                       // the window starts PADW pixels before the tile (4-tap phase filters of a 7x7: taps -2 .. 1)
+    constexpr int PADW = M == 3 ? (S2 ? 2 : 1) : (6 - M) / 2;            // the window starts PADW pixels before the tile (4-tap phase filters of a 7x7: taps -2 .. 1; of its data gradient: -1 .. 2)
     constexpr int NPX = M == 3 ? 3 : 4, NST = M == 3 ? 3 : M * M / 4;    // output transform: pixels per step (M = 3: one tile row), steps
     // Channel-group planes of the raw patch: NPIECE KB each, at pitch PLANE plus a pad per plane chosen so that the 32 lanes
     // of a ds_read_b32 group (16 channels x 2 neighbouring tiles, M pixels = 4 M dwords apart) fall on 32 different banks:
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
                     f32x4 v = y[x];
                     bool fin = true;
                     if constexpr (UPS) {
-                        const int oy = 2 * (4 * oty + st) + pa, ox = 2 * (4 * otx + x) + pb;
+                        const int oy = 2 * (M * oty + st) + pa, ox = 2 * (M * otx + x) + pb;
                         fin = !(a.ring && ((oy == 0) | (oy == Ho - 1) | (ox == 0) | (ox == Wo - 1)));   // ring pixels are finished by the ring kernel
                     }
                     if (fin) {
@@ -538,7 +538,7 @@ static constexpr size_t kSyncFlagBytes = 4096, kSyncSlotBytes = 8 * 16 * 64 * 16
 extern "C" size_t cnm_wino36_sync_floats(void) { return (kSyncFlagBytes + (size_t)wino4s_cus() * kSyncSlotBytes) / 4; }
 
 int cnm_wino36s_try_launch(const Wino4Args& a, int M, int ups, hipStream_t stream, int s2) {
-    if (!g_wino36_staged || (M != 4 && M != 2 && !(M == 3 && s2)) || (ups && (M != 4 || s2)) || (s2 && M == 2) || a.Cout % 128) return 1;
+    if (!g_wino36_staged || (M != 4 && M != 2 && !(M == 3 && (s2 || ups))) || (ups && (M == 2 || s2)) || (s2 && M == 2) || a.Cout % 128) return 1;
     int tsx = 0;
     if (a.TW >= 12) tsx = 16; else if (a.TW >= 6 && a.TH >= 2) tsx = 8; else if (M == 4 && !ups && !s2 && a.TW >= 3 && a.TH >= 3) tsx = 4;   // tile block 1 x 16, 2 x 8, 4 x 4
     if (s2) {
@@ -594,6 +594,9 @@ int cnm_wino36s_try_launch(const Wino4Args& a, int M, int ups, hipStream_t strea
             else if (tsx == 4) conv_winograd36s_f32_kernel<4, false, 0, 3, true><<<grid, 512, 0, stream>>>(a, SH, SW, tilesC, (int)nunits, flags, slots);
             else conv_winograd36s_f32_kernel<8, false, 0, 3, true><<<grid, 512, 0, stream>>>(a, SH, SW, tilesC, (int)nunits, flags, slots);
         }
+    } else if (M == 3) {                                                 // F(3x3,4x4) phase scatter: the data gradient of a stride-2 7x7
+        if (tsx == 16) conv_winograd36s_f32_kernel<16, true, 0, 3><<<grid, 512, 0, stream>>>(a, SH, SW, tilesC, (int)nunits, flags, slots);
+        else conv_winograd36s_f32_kernel<8, true, 0, 3><<<grid, 512, 0, stream>>>(a, SH, SW, tilesC, (int)nunits, flags, slots);
     } else if (M == 2) {
         if (tsx == 16) conv_winograd36s_f32_kernel<16, false, 0, 2><<<grid, 512, 0, stream>>>(a, SH, SW, tilesC, (int)nunits, flags, slots);
         else conv_winograd36s_f32_kernel<8, false, 0, 2><<<grid, 512, 0, stream>>>(a, SH, SW, tilesC, (int)nunits, flags, slots);

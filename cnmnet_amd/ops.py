@@ -288,15 +288,28 @@ def conv_s2_winograd4_c4(x, u_packed, b_packed, Cout, ksize, relu=True, x2=None,
     return out
 
 
-def conv3x3_phase_scatter_c4(x, u_packed, Cout, sync=None, out=None):
-    """out[:, :, a::2, b::2] = conv3x3(x, w_phase[2a + b]) (zero padding, no bias) for the four filters packed phase major as
-    4*Cout output channels (pack_winograd4 of the [4*Cout, Cin, 3, 3] tensor): x [N,G,H,W,4] -> [N,Cout/4,2H,2W,4], one launch."""
+def pack_winograd36(weight):
+    """Plain 36-point pack of a [Cout,Cin,k,k] filter, k = 3 / 4 / 5 (F(4x4,3x3) / F(3x3,4x4) / F(2x2,5x5))."""
+    _dev(weight)
+    lib = _lib.load()
+    Cout, Cin, k, _ = weight.shape
+    up = torch.empty(lib.cnm_packed_winograd4_floats(Cout, Cin), device=weight.device, dtype=torch.float32)
+    with torch.cuda.device(weight.device):
+        _lib.check(lib.cnm_pack_winograd36_f32(_p(_c(weight)), Cout, Cin, k, _p(up), _stream()))
+    return up
+
+
+def conv3x3_phase_scatter_c4(x, u_packed, Cout, sync=None, out=None, ksize=3):
+    """out[:, :, a::2, b::2] = conv(x, w_phase[2a + b]) (zero padding, no bias) for the four filters packed phase major as
+    4*Cout output channels: x [N,G,H,W,4] -> [N,Cout/4,2H,2W,4], one launch.  ksize 3: 3x3 phase filters, taps -1 .. 1
+    (pack_winograd4 of the [4*Cout, Cin, 3, 3] tensor); ksize 4: 4x4 phase filters, taps -1 .. 2 (pack_winograd36)."""
     _dev(x, u_packed, sync)
     N, G, H, W, _ = x.shape
     if out is None:
         out = torch.empty(N, Cout // 4, 2 * H, 2 * W, 4, device=x.device, dtype=torch.float32)
+    fn = _lib.load().cnm_conv3x3_phase_scatter_winograd4_sync_c4_f32 if ksize == 3 else _lib.load().cnm_conv4x4_phase_scatter_winograd_sync_c4_f32
     with torch.cuda.device(x.device):
-        _lib.check(_lib.load().cnm_conv3x3_phase_scatter_winograd4_sync_c4_f32(_p(x), G, 0, G, _p(out), Cout // 4, 0, Cout, _p(u_packed), None,
+        _lib.check(fn(_p(x), G, 0, G, _p(out), Cout // 4, 0, Cout, _p(u_packed), None,
                                                                                N, H, W, 0, _p(sync) if sync is not None else None,
                                                                                sync.numel() if sync is not None else 0, _stream()))
     return out

@@ -235,6 +235,16 @@ int cnm_conv3x3_phase_scatter_winograd4_sync_c4_f32(const float* in, int Gin_tot
                                                     const float* u_packed, const float* b_packed,
                                                     int N, int H, int W, int relu, float* sync_ws, size_t sync_floats, void* stream);
 
+/* ... with 4x4 phase filters (taps at offsets -1 .. 2) on F(3x3,4x4): the data gradient of a stride-2 7x7 convolution (conv1.3).
+ * u_packed = cnm_pack_winograd36_f32(ksize 4) of the [4*Cout, Cin, 4, 4] tensor.  Staged kernel only (Cout % 32 == 0, at least
+ * 6 x 2 tiles of 3 x 3 pixels per image): CNM_ERR_BAD_ARG otherwise. */
+int cnm_conv4x4_phase_scatter_winograd_sync_c4_f32(const float* in, int Gin_total, int gin0, int Gin,
+                                                   float* out, int Gout_total, int gout0, int Cout,
+                                                   const float* u_packed, const float* b_packed,
+                                                   int N, int H, int W, int relu, float* sync_ws, size_t sync_floats, void* stream);
+/* 36-point pack of a plain [Cout, Cin, k, k] filter, k = 3 / 4 / 5 (F(4x4,3x3) / F(3x3,4x4) / F(2x2,5x5)); no BatchNorm fold. */
+int cnm_pack_winograd36_f32(const float* w_oihw, int Cout, int Cin, int ksize, float* u_packed, void* stream);
+
 /* The STRIDE-2 5x5 / 7x7 layers (conv2.3 = nn.Conv2d(256, 256, 5, 2, 2), conv1.3 = nn.Conv2d(128, 128, 7, 2, 3),
  * depthNet_model.py:136-139,145-148 through conv_layer :19-43) as a stride-1 convolution of the four pixel phases of the
  * input (space to depth, never materialised) on the LDS-staged 36-point kernel: 5x5 -> four 3x3 phase filters,

@@ -57,7 +57,8 @@ def test_conv_forward_dgrad_wgrad(dev, cin, cout, k, stride, rot, N, H, W):
     assert _rel(wd.grad.cpu().numpy(), w.grad.numpy()) < 5e-5
 
 
-@pytest.mark.parametrize("cin,cout,k,N,Ho,Wo", [(64, 128, 3, 2, 24, 32), (128, 64, 5, 1, 48, 64), (64, 64, 3, 3, 9, 14), (256, 128, 5, 2, 6, 8)])
+@pytest.mark.parametrize("cin,cout,k,N,Ho,Wo", [(64, 128, 3, 2, 24, 32), (128, 64, 5, 1, 48, 64), (64, 64, 3, 3, 9, 14), (256, 128, 5, 2, 6, 8),
+                                                 (128, 128, 7, 2, 48, 64), (64, 32, 7, 1, 10, 31)])
 def test_stride2_dgrad_phase_scatter(dev, cin, cout, k, N, Ho, Wo):
     """Data gradient of a stride-2 3x3 / 5x5 convolution as ONE phase-interleaving F(4x4,3x3) launch
     (cnm_conv3x3_phase_scatter_winograd4_sync_c4_f32: the four 3x3 phase filters as 4*Cin output channels, zero padding, staged
@@ -68,13 +69,16 @@ def test_stride2_dgrad_phase_scatter(dev, cin, cout, k, N, Ho, Wo):
     dy = T(rng.standard_normal((N, cout, Ho, Wo)).astype(np.float32))
     want = F.conv_transpose2d(dy.double(), w.double(), stride=2, padding=k // 2, output_padding=1).numpy()
     phases = ag._stride2_dgrad_phases(w.to(dev))
-    assert all(wp.shape[2] == 3 for _, _, wp in phases)
-    up = ops.pack_winograd4(torch.cat([wp for _, _, wp in phases], 0))
+    if k == 7:                                                           # 3- and 4-tap phase filters as 4x4 taps on F(3x3,4x4)
+        up = ops.pack_winograd36(torch.cat([ag._taps4(wp) for _, _, wp in phases], 0))
+    else:
+        assert all(wp.shape[2] == 3 for _, _, wp in phases)
+        up = ops.pack_winograd4(torch.cat([wp for _, _, wp in phases], 0))
     dyc = ops.nchw_to_c4(dy.to(dev))
     sync = ops.wino36_sync_workspace(dev)
-    outs = [ops.conv3x3_phase_scatter_c4(dyc, up, cin, sync=sy).clone() for sy in (None, sync, sync)]
+    outs = [ops.conv3x3_phase_scatter_c4(dyc, up, cin, sync=sy, ksize=4 if k == 7 else 3).clone() for sy in (None, sync, sync)]
     for o in outs[:2]:
-        assert _rel(ops.c4_to_nchw(o, cin).cpu().numpy(), want) < 2e-5
+        assert _rel(ops.c4_to_nchw(o, cin).cpu().numpy(), want) < 2e-5, _rel(ops.c4_to_nchw(o, cin).cpu().numpy(), want)
     assert torch.equal(outs[1], outs[2]) and float(sync[:1024].abs().max()) == 0.0
     old = ag.S2_DGRAD_SCATTER
     try:
