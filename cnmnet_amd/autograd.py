@@ -74,36 +74,57 @@ def _winograd_conv(x, weight, rot, stride=1, dgrad=False):
     Cout, _, k, _ = weight.shape
     if dgrad:
         Cout = weight.shape[1]
-    # large layers: F(4x4,3x3); with the sync workspace the staged kernel also balances small unit counts (>= 3 x 3 tiles per image)
-    if k == 3 and (_winograd4_fills_chip(x, Cout) or (WINOGRAD4_SMALL and Cout % 128 == 0 and x.shape[2] >= 9 and x.shape[3] >= 9)):
+    # large layers: F(4x4,3x3); with the sync workspace the staged kernel also balances small unit counts (>= 3 x 3 tiles per image).
+    # 5x5 stride 1 (conv2.0) with enough 2 x 2 tiles: F(2x2,5x5) on the same kernel -- relative L2 error against the fp64
+    # convolution 2.0-2.6e-6, as F(4x4,3x3) (tools/rel_err_probe.py; rows F(2,5): 1.6-2.2e-6)
+    if stride == 1 and ((k == 3 and (_winograd4_fills_chip(x, Cout) or (WINOGRAD4_SMALL and Cout % 128 == 0 and x.shape[2] >= 9 and x.shape[3] >= 9)))
+                        or (k == 5 and FAST_FORWARD and _winograd4_fills_chip(x, Cout, 2))):
         if dgrad:
             up4 = _packed("u4d", weight, 0, 1, lambda: ops.pack_winograd4_dgrad(weight))
         else:
             up4 = _packed("u4", weight, rot, 1, lambda: ops.pack_winograd4(weight, None, rot))
-        return ops.conv3x3_winograd4_c4(x, up4, None, Cout, relu=False, sync=_sync_workspace(x.device))
+        return ops.conv3x3_winograd4_c4(x, up4, None, Cout, relu=False, ksize=k, sync=_sync_workspace(x.device))
     if (not dgrad and stride == 2 and k in S2_PHASE_KSIZES and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
             and _lib.load().cnm_conv_s2_winograd4_ok(Cout, x.shape[2], x.shape[3], k)):
         # stride-2 5x5 / 7x7 forward: the four pixel phases of x on the staged 36-point kernel (F(4x4,3x3) / F(3x3,4x4)),
         # the transforms the 3x3 layers of the step already run with
         ups = _packed("u4s2", weight, rot, 2, lambda: ops.pack_winograd4_s2(weight, None, rot))
         return ops.conv_s2_winograd4_c4(x, ups, None, Cout, k, relu=False, sync=_sync_workspace(x.device))
+    if k == 3 and stride == 2:                                           # (only called where _rows3_stride2_ok says so) two F(4,2) column phases along rows
+        up = _packed("u4r", weight, rot, 2, lambda: ops.pack_winograd_rows(weight, None, rot, stride=2, tile=4))
+        return ops.conv_rows_winograd_c4(x, up, None, Cout, 3, relu=False, stride=2, tile=4)
     if dgrad:
         weight = _dgrad_weight(weight)
-    up = _packed("u2", weight, rot, stride, lambda: ops.pack_winograd(weight, None, rot, stride=stride, tile=2))    # training keeps the more accurate F(2,k) rows
+    if k == 7 and stride == 1 and FAST_ROWS7 and Cout % 128 == 0:
+        # conv1.0: F(4,7) along rows on the staged kernel (0.88 -> 0.54 ms for 4 pairs at 192x256, tools/rel_err_probe.py).  OFF:
+        # its relative L2 error is 2.5-4.5e-6 on non-negative inputs (a cost volume) but 2.1e-5 on zero-mean random data, at the
+        # op-level bar of tests/test_gpu_training.py::test_conv_forward_dgrad_wgrad (2e-5); F(2,7) stays a decade below it
+        up = _packed("u4r", weight, rot, 1, lambda: ops.pack_winograd(weight, None, rot, stride=1, tile=4))
+        return ops.conv_rows_winograd_c4(x, up, None, Cout, 7, relu=False, stride=1, tile=4, sync=_sync_workspace(x.device))
+    up = _packed("u2", weight, rot, stride, lambda: ops.pack_winograd(weight, None, rot, stride=stride, tile=2))    # F(2,k) rows
     if k == 3:
         return ops.conv3x3_winograd_c4(x, up, None, Cout, relu=False)
     return ops.conv_rows_winograd_c4(x, up, None, Cout, k, relu=False, stride=stride, tile=2)
 
 
+FAST_FORWARD = True              # the inference kernels' larger tiles where their relative L2 error stays a decade below the op-level bar (2e-5): F(2x2,5x5), F(4,2) stride-2 rows
+FAST_ROWS7 = False               # ... F(4,7) for conv1.0 does not (see _winograd_conv): off
 WINOGRAD4_MIN_WORKGROUPS = 384   # same switch point as the inference executors (include/cnm_engine.h)
 S2_PHASE_KSIZES = (5, 7)         # stride-2 layers whose FORWARD runs on the pixel phases of the input (ops.conv_s2_winograd4_c4); () keeps the F(2,k) row phases
 S2_DGRAD_SCATTER = True          # stride-2 data gradient with 3x3 phase filters: one phase-interleaving launch instead of four convolutions + four strided copies
 WINOGRAD4_SMALL = True           # ... and the same extension below it (nets.hip wino4_staged_small)
 
 
-def _winograd4_fills_chip(x, Cout):
+def _winograd4_fills_chip(x, Cout, m=4):
     N, _, H, W, _ = x.shape
-    return (Cout // 64) * -(-(N * -(-H // 4) * -(-W // 4)) // 16) >= WINOGRAD4_MIN_WORKGROUPS
+    return (Cout // 64) * -(-(N * -(-H // m) * -(-W // m)) // 16) >= WINOGRAD4_MIN_WORKGROUPS
+
+
+def _rows3_stride2_ok(x, Cout):
+    """3x3 stride 2 along rows (two F(4,2) column phases, 7.5 multiplies per output instead of 9): where the inference executor
+    takes it (nets.hip EngF32::conv: at least 384 workgroups of 64 couts x 48 row tiles)."""
+    N, _, H, W, _ = x.shape
+    return FAST_FORWARD and WINOGRAD and Cout % 64 == 0 and (Cout // 64) * -(-(N * -(-H // 2) * -(-(-(-W // 2)) // 4)) // 48) >= 384
 
 
 def _stride2_dgrad_phases(weight):
@@ -149,7 +170,7 @@ class ConvC4(torch.autograd.Function):
     def forward(ctx, x, weight, stride, rot):
         x = x.contiguous()
         Cout, Cin, k, _ = weight.shape
-        if _winograd_ok(k, stride, Cout):
+        if _winograd_ok(k, stride, Cout) or (k == 3 and stride == 2 and _rows3_stride2_ok(x, Cout)):
             y = _winograd_conv(x, weight.detach(), rot, stride)
         else:
             wp, _ = ops.pack_conv(weight.detach(), None, None, rot)

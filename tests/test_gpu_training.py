@@ -36,7 +36,9 @@ def _rel(a, b):
 @pytest.mark.parametrize("cin,cout,k,stride,rot,N,H,W", [
     (67, 128, 7, 1, 3, 2, 16, 24), (128, 128, 7, 2, 0, 1, 32, 32), (256, 256, 5, 2, 0, 2, 16, 16),
     (513, 256, 3, 1, 0, 1, 12, 20), (65, 64, 3, 1, 0, 3, 20, 28), (64, 16, 3, 1, 0, 2, 24, 40),
-    (512, 512, 3, 2, 0, 2, 6, 8), (128, 64, 3, 1, 0, 2, 40, 48)])
+    (512, 512, 3, 2, 0, 2, 6, 8), (128, 64, 3, 1, 0, 2, 40, 48),
+    (128, 256, 5, 1, 0, 2, 48, 64),       # conv2.0's kernels: F(2x2,5x5) forward and data gradient
+    (128, 128, 3, 2, 0, 6, 128, 192)])    # 3x3 stride 2 along rows (F(4,2) column phases), phase-scatter data gradient on the staged kernel
 def test_conv_forward_dgrad_wgrad(dev, cin, cout, k, stride, rot, N, H, W):
     from cnmnet_amd import ops, autograd as ag
     rng = np.random.default_rng(cin + 3 * k + stride)
