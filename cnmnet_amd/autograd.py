@@ -108,6 +108,7 @@ def _winograd_conv(x, weight, rot, stride=1, dgrad=False):
 
 
 FAST_FORWARD = True              # the inference kernels' larger tiles where their relative L2 error stays a decade below the op-level bar (2e-5): F(2x2,5x5), F(4,2) stride-2 rows
+PAD_DGRAD = True                 # 3x3 stride-1 data gradients with ragged input-channel counts on the Winograd kernels (padded), not the direct kernel
 FAST_ROWS7 = False               # ... F(4,7) for conv1.0 does not (see _winograd_conv): off
 WINOGRAD4_MIN_WORKGROUPS = 384   # same switch point as the inference executors (include/cnm_engine.h)
 S2_PHASE_KSIZES = (5, 7)         # stride-2 layers whose FORWARD runs on the pixel phases of the input (ops.conv_s2_winograd4_c4); () keeps the F(2,k) row phases
@@ -191,6 +192,13 @@ class ConvC4(torch.autograd.Function):
             if ctx.needs_input_grad[0] and ctx.rot == 0 and ctx.stride == 1 and _winograd_ok(k, 1, Cin):
                 # stride 1: dx = conv(dy, w') with w'[ci][co] = w[co][ci] rotated by 180 degrees -- the same Winograd kernels
                 dx = _winograd_conv(dy, weight.detach(), 0, dgrad=True)
+            elif (ctx.needs_input_grad[0] and ctx.rot == 0 and ctx.stride == 1 and k == 3 and PAD_DGRAD and _winograd_ok(3, 1, 64) and Cin > 64):
+                # stride 1, input channels not a multiple of 64 (the concatenations with a disparity channel: 65, 257, 513): the same
+                # F(4x4,3x3) data gradient with w' zero-padded to the next 64 output channels -- 1.1-2x the multiplies of a kernel
+                # that needs a quarter of the direct count -- and the padding groups dropped (a view)
+                Cp = 128 if Cin < 128 else 64 * -(-Cin // 64)
+                wpad = _packed("wpad", weight, 0, 1, lambda: torch.nn.functional.pad(weight.detach(), (0, 0, 0, 0, 0, Cp - Cin)))
+                dx = _winograd_conv(dy, wpad, 0, dgrad=True)[:, :G]
             elif (ctx.needs_input_grad[0] and ctx.rot == 0 and ctx.stride == 2 and WINOGRAD and Cin % 64 == 0
                   and H % 2 == 0 and W % 2 == 0):
                 # stride 2: four stride-1 Winograd convolutions of dY, one per pixel phase of dX (sub-pixel
