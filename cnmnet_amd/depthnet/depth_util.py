@@ -50,7 +50,14 @@ class Depth2normal(nn.Module):
 
     def forward(self, depth, intrinsic_inv, instance_segs=None, planes_num=None):
         if planes_num is not None:
-            # plane branch (reference :205-238): -> (normal, loss, points); inference semantics (no autograd through it)
+            # plane branch (reference :205-238): -> (normal, loss, points)
+            if torch.is_grad_enabled() and depth.requires_grad:
+                # differentiable, as the reference's is: normals through the HIP backward kernel, the per-instance means / cosine
+                # loss as the reference's own torch expressions on the device (same values as cnm_plane_normals_f32)
+                from ..autograd import Depth2NormalFn
+                normal, points = Depth2NormalFn.apply(depth, intrinsic_inv, self.k_size, False)
+                normal, loss = _plane_normals_autograd(normal, instance_segs, planes_num)
+                return normal, loss, points
             normal, points = ops.depth2normal(depth.detach(), intrinsic_inv, self.k_size)
             normal, loss = ops.plane_normals(normal, instance_segs, planes_num)
             return normal, loss, points
@@ -58,6 +65,28 @@ class Depth2normal(nn.Module):
             from ..autograd import Depth2NormalFn
             return Depth2NormalFn.apply(depth, intrinsic_inv, self.k_size, False)
         return ops.depth2normal(depth, intrinsic_inv, self.k_size)
+
+
+def _plane_normals_autograd(normal, instance_segs, planes_num):
+    """Reference depth_util.py:205-238 with autograd: plane instances in order, each instance's pixels replaced by the
+    instance's mean normal (:221-236), loss = sum over instances of mean(1 - cos(mean, inside ? n : 0)) (:228-233).
+    normal [B,3,H,W] -> (regularised normal [B,3,H,W], loss)."""
+    n = normal.permute(0, 2, 3, 1)
+    B, H, W, _ = n.shape
+    loss = normal.new_zeros(())
+    rows = []
+    for b in range(B):
+        nb = n[b]
+        for i in range(int(planes_num[b])):
+            m = instance_segs[b, i].to(normal.device).bool().unsqueeze(-1)       # [H,W,1]
+            mf = m.to(nb.dtype)
+            mean = (nb * mf).reshape(-1, 3).sum(0) / mf.sum()                    # :221-225
+            reg = mean.expand(H, W, 3)
+            orig = torch.where(m, nb, torch.zeros_like(nb))                      # :228
+            loss = loss + (1 - torch.nn.functional.cosine_similarity(reg.reshape(-1, 3), orig.reshape(-1, 3), dim=1)).mean()   # :230-233
+            nb = torch.where(m, reg, nb)                                         # :235-236
+        rows.append(nb)
+    return torch.stack(rows, 0).permute(0, 3, 1, 2), loss
 
 
 def get_normal_by_planes(gt_normal, instance_segs, planes_num):

@@ -328,6 +328,34 @@ def test_depth2normal_backward(dev, golden, k):
     assert float(err.max()) < 2e-3 * scale and float(np.linalg.norm((got_n - gd_n).numpy()) / np.linalg.norm(gd_n.numpy())) < 1e-4
 
 
+def test_depth2normal_plane_branch_is_differentiable(dev, golden):
+    """Depth2normal's plane-instance branch (reference depth_util.py:205-238) with a depth that requires grad: the same values
+    as the forward-only HIP kernel (cnm_plane_normals_f32), and d(loss + <normal, g>)/d(depth) against torch autograd through
+    the oracle's fp64 restatement of both stages."""
+    from cnmnet_amd.depthnet import Depth2normal
+    g = golden("depth2normal_48x64.npz")
+    rng = np.random.default_rng(5)
+    B, H, W = 2, 48, 64
+    segs = np.zeros((B, 4, H, W), bool)
+    segs[0, 0, 4:20, 6:30] = True; segs[0, 1, 12:40, 20:60] = True; segs[0, 2, 30:46, 2:18] = True      # overlapping instances: order matters
+    segs[1, 0, 8:44, 10:50] = True
+    planes = [3, 1]
+    gn = T(rng.standard_normal((B, 3, H, W)).astype(np.float32))
+    d64 = T(g["depth"]).double().requires_grad_(True)
+    n64, _ = ra.depth_to_normal(d64, T(g["K_inv"]).double(), 9)
+    r64, l64 = ra.plane_normals(n64, T(segs), planes)
+    ((r64 * gn.double()).sum() + 10.0 * l64).backward()
+    dd = T(g["depth"]).to(dev).requires_grad_(True)
+    nd, ld, pd = Depth2normal(9)(dd, T(g["K_inv"]).to(dev), T(segs).to(dev), planes)
+    ((nd * gn.to(dev)).sum() + 10.0 * ld).backward()
+    with torch.no_grad():                                                # forward-only path: the HIP kernel
+        nk, lk, _ = Depth2normal(9)(dd.detach(), T(g["K_inv"]).to(dev), T(segs).to(dev), planes)
+    assert float((nd - nk).abs().max()) < 2e-6 and abs(float(ld) - float(lk)) < 1e-5 * max(1.0, abs(float(lk)))
+    assert abs(float(ld) - float(l64)) < 1e-4 * max(1.0, abs(float(l64)))
+    got, want = dd.grad.cpu().double(), d64.grad
+    assert float(np.linalg.norm((got - want).numpy()) / np.linalg.norm(want.numpy())) < 1e-3
+
+
 def test_inverse_warp_backward_depth(dev, golden):
     from cnmnet_amd.depthnet import inverse_warp
     g = golden("inverse_warp_32x64.npz")
