@@ -178,6 +178,12 @@ def conv_kernel(L, m, m4=0, h=0, w=0):
         return "conv_rows_winograd_f32_kernel<3, 2, 4>", 10.0 / 12.0       # two F(4,2) column phases: 10 multiplies per 4 outputs and kernel row instead of 12
     if k == 3 and s == 2 and (L["Cout"] // 64) * -(-m // 64) < 256:     # too few implicit-GEMM tiles: F(2x2,3x3) kernel keeping one output per tile
         return "conv3x3_winograd_f32_kernel", 16.0 / 9.0
+    if k == 3 and s == 2 and L["Cout"] % 128 == 0:                      # nets.hip: what is left of the 3x3 stride-2 layers on the pixel phases (staged kernel, direct count)
+        th, tw = -(-h // 4), -(-w // 4)
+        shapes = [c for c in (16, 8, 4) if (tw >= 12 if c == 16 else (tw >= 6 and th >= 2) if c == 8 else (tw >= 3 and th >= 3))]
+        if shapes:
+            tsx = min(shapes, key=lambda c: (-(-tw // c) * c * -(-th // (16 // c)) * (16 // c), -c))
+            return "conv_winograd36s_f32_kernel<%d, false, 0, 4, true>" % tsx, 1.0
     return conv_tile(L["Cout"], m), 1.0
 
 

@@ -244,9 +244,10 @@ __global__ __launch_bounds__(256, 2) void conv_winograd36_f32_kernel(const Wino4
 // One workgroup per (chunk, 16-cout block): thread = (lane, e) of the fragment reads its R x R filter once and writes the 36
 // frequency points as 36 coalesced 1 KB rows (one thread per output float spent its time in 64-bit index arithmetic and wrote
 // at 1.6 TB/s: the training step re-packs ~90 filters, 2 ms).  Same fp64 expression per point as before: bit-identical output.
-// S2 (stride-2 convolution on the four pixel phases of its input, conv_winograd4s.hip): w is the (2R - 1) x (2R - 1) stride-2
-// filter, chunk = 4 * (input chunk) + 2 py + px, and the R x R filter of phase (py, px) is tap (jy, jx) -> w[2 jy + py - o][2 jx + px - o]
-// (o = 0 for 5x5, 1 for 7x7: the window starts o + 1 phase pixels before the output pixel), zero where that leaves the filter.
+// S2 (stride-2 convolution on the four pixel phases of its input, conv_winograd4s.hip): w is the K x K stride-2 filter (dgrad
+// carries K: 7 -> R = 4; 5 or 3 -> R = 3), chunk = 4 * (input chunk) + 2 py + px, and the R x R filter of phase (py, px) is
+// tap (jy, jx) -> w[2 jy + py - o][2 jx + px - o] (o = 0 for 5x5, 1 for 7x7 and 3x3: the window starts (K - 1) / 2 input pixels
+// = 1 or 2 phase pixels before the output pixel), zero where that leaves the filter (a 3x3 filter fills 1 / 2 / 2 / 4 of the 9 taps).
 template <int R, bool S2 = false>
 __global__ __launch_bounds__(256) void pack_winograd36_kernel(const float* __restrict__ w, const float* __restrict__ gamma, const float* __restrict__ var,
                                                               float eps, int Cout, int Cin, int rot, int nchunks, float* __restrict__ up, int dgrad) {
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(256) void pack_winograd36_kernel(const float* __res
     const float* g = dgrad ? w + ((size_t)ci * Cout + co) * R * R : w + ((size_t)co * Cin + ci) * R * R;
     double gv[R * R];
     if constexpr (S2) {
-        constexpr int K = 2 * R - 1, O = R == 4 ? 1 : 0;
+        const int K = dgrad, O = K == 5 ? 0 : 1;                         // S2: the `dgrad` argument carries the source filter size
         const int py = (chunk >> 1) & 1, px = chunk & 1;
         const float* g2 = w + ((size_t)co * Cin + ci) * K * K;
 #pragma unroll
@@ -310,8 +311,8 @@ static int pack36(const float* w_oihw, const float* bn_gamma, const float* bn_va
     CNM_REQUIRE(!bn_gamma == !bn_var, CNM_ERR_BAD_ARG);
     const int nchunks = (4 * ((Cin + 3) / 4) + 15) / 16 * (s2 ? 4 : 1);
     const unsigned nb = (unsigned)(nchunks * (Cout / 16));
-    if (s2 && ksize == 5) pack_winograd36_kernel<3, true><<<nb, 256, 0, cnm_stream(stream)>>>(w_oihw, bn_gamma, bn_var, eps, Cout, Cin, rot, nchunks, u_packed, 0);
-    else if (s2) pack_winograd36_kernel<4, true><<<nb, 256, 0, cnm_stream(stream)>>>(w_oihw, bn_gamma, bn_var, eps, Cout, Cin, rot, nchunks, u_packed, 0);
+    if (s2 && ksize != 7) pack_winograd36_kernel<3, true><<<nb, 256, 0, cnm_stream(stream)>>>(w_oihw, bn_gamma, bn_var, eps, Cout, Cin, rot, nchunks, u_packed, ksize);
+    else if (s2) pack_winograd36_kernel<4, true><<<nb, 256, 0, cnm_stream(stream)>>>(w_oihw, bn_gamma, bn_var, eps, Cout, Cin, rot, nchunks, u_packed, ksize);
     else if (ksize == 3) pack_winograd36_kernel<3><<<nb, 256, 0, cnm_stream(stream)>>>(w_oihw, bn_gamma, bn_var, eps, Cout, Cin, rot, nchunks, u_packed, dgrad);
     else if (ksize == 4) pack_winograd36_kernel<4><<<nb, 256, 0, cnm_stream(stream)>>>(w_oihw, bn_gamma, bn_var, eps, Cout, Cin, rot, nchunks, u_packed, dgrad);
     else pack_winograd36_kernel<5><<<nb, 256, 0, cnm_stream(stream)>>>(w_oihw, bn_gamma, bn_var, eps, Cout, Cin, rot, nchunks, u_packed, dgrad);
@@ -323,7 +324,7 @@ static int conv36(const float* in_a, int Ga_total, int ga0, int Ga, const float*
                   float* out, int Gout_total, int gout0, int Cout, const float* u_packed, const float* b_packed,
                   int N, int H, int W, int ksize, int relu, void* stream, int ups = 0, int ring = 0, float* sync_ws = nullptr, size_t sync_floats = 0, int s2 = 0, int ups_zero = 0) {
     CNM_REQUIRE(in_a && out && u_packed && N > 0 && H > 0 && W > 0 && Ga > 0 && Gb >= 0, CNM_ERR_BAD_ARG);
-    CNM_REQUIRE(!s2 || (!ups && (ksize == 5 || ksize == 7) && H % 2 == 0 && W % 2 == 0 && sync_ws), CNM_ERR_BAD_ARG);
+    CNM_REQUIRE(!s2 || (!ups && (ksize == 3 || ksize == 5 || ksize == 7) && H % 2 == 0 && W % 2 == 0 && sync_ws), CNM_ERR_BAD_ARG);
     CNM_REQUIRE(Cout > 0 && Cout % 64 == 0 && gout0 >= 0 && gout0 + Cout / 4 <= Gout_total, CNM_ERR_BAD_ARG);
     CNM_REQUIRE(!ups || ksize == 3 || (ksize == 4 && ups_zero), CNM_ERR_BAD_ARG);
     CNM_REQUIRE(ga0 >= 0 && ga0 + Ga <= Ga_total && (Gb == 0 || (in_b && gb0 >= 0 && gb0 + Gb <= Gb_total)), CNM_ERR_BAD_ARG);
@@ -333,7 +334,7 @@ static int conv36(const float* in_a, int Ga_total, int ga0, int Ga, const float*
     const unsigned long long b2 = Gb ? (unsigned long long)N * Gb_total * H * W * 16ull : b1;
     CNM_REQUIRE(b1 < 0xFFFFFFFFull && b2 < 0xFFFFFFFFull, CNM_ERR_BAD_ARG);
     a.in_bytes = (unsigned)b1; a.in2_bytes = (unsigned)b2;
-    const int m = s2 ? (ksize == 5 ? 4 : 3) : ksize == 3 ? 4 : ksize == 4 ? 3 : 2;   // outputs per tile side
+    const int m = s2 ? (ksize == 7 ? 3 : 4) : ksize == 3 ? 4 : ksize == 4 ? 3 : 2;   // outputs per tile side
     if (s2) { H /= 2; W /= 2; }                                          // from here on the output (= phase image) size
     a.N = N; a.H = H; a.W = W; a.TH = (H + m - 1) / m; a.TW = (W + m - 1) / m;
     a.Gin_tot = Ga_total; a.gin0 = ga0; a.Gin2_tot = Gb ? Gb_total : Ga_total; a.gin2_0 = Gb ? gb0 : ga0; a.Gsplit = Ga; a.Gin = Ga + Gb;
@@ -466,13 +467,13 @@ extern "C" size_t cnm_packed_winograd4_s2_floats(int Cout, int Cin) { return 4 *
 
 extern "C" int cnm_pack_winograd4_s2_bn_f32(const float* w_oihw, const float* bn_gamma, const float* bn_var, float eps,
                                             int Cout, int Cin, int ksize, int rot, float* u_packed, void* stream) {
-    CNM_REQUIRE(ksize == 5 || ksize == 7, CNM_ERR_BAD_ARG);
+    CNM_REQUIRE(ksize == 3 || ksize == 5 || ksize == 7, CNM_ERR_BAD_ARG);
     return pack36(w_oihw, bn_gamma, bn_var, eps, Cout, Cin, ksize, rot, u_packed, stream, 0, 1);
 }
 
 extern "C" int cnm_conv_s2_winograd4_ok(int Cout, int H, int W, int ksize) {
-    if ((ksize != 5 && ksize != 7) || Cout <= 0 || Cout % 128 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return 0;
-    const int m = ksize == 5 ? 4 : 3, th = (H / 2 + m - 1) / m, tw = (W / 2 + m - 1) / m;
+    if ((ksize != 3 && ksize != 5 && ksize != 7) || Cout <= 0 || Cout % 128 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return 0;
+    const int m = ksize == 7 ? 3 : 4, th = (H / 2 + m - 1) / m, tw = (W / 2 + m - 1) / m;
     return tw >= 12 || (tw >= 6 && th >= 2) || (tw >= 3 && th >= 3);
 }
 

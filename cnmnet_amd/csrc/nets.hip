@@ -147,6 +147,8 @@ struct EngF32 {
             return cnm_conv3x3_s2_winograd_c4_f32(in, Gt, g0, Gin, out, Gto, go0, Cout, w.u, w.b, N, H, W, 1, s);
         if (w.u4 && k == 3 && st == 2 && (Cout / 64) * (((long long)N * ((H + 1) / 2) * (((W + 1) / 2 + 3) / 4) + 47) / 48) >= 384)   // F(4,2) column phases along rows: 1.2x fewer multiplies; pays from ~1.5 workgroups per CU slot pair
             return cnm_conv_rows_winograd_c4_f32(in, Gt, g0, Gin, nullptr, 0, 0, 0, out, Gto, go0, Cout, w.u4, w.b, N, H, W, 3, 2, 4, 1, s);
+        if (w.uu && !w.bu && k == 3 && st == 2 && sync && g_wino4_s2 && cnm_conv_s2_winograd4_ok(Cout, H, W, 3))   // what is left of the 3x3 stride-2 layers: the pixel phases on the staged kernel (the direct count, at its efficiency) instead of the implicit GEMM
+            return cnm_conv_s2_winograd4_sync_c4_f32(in, Gt, g0, Gin, nullptr, 0, 0, 0, out, Gto, go0, Cout, w.uu, w.b, N, H, W, 3, 1, sync, cnm_wino36_sync_floats(), s);
         if (w.u && k == 3 && st == 1) return cnm_conv3x3_winograd_c4_f32(in, Gt, g0, Gin, nullptr, 0, 0, 0, out, Gto, go0, Cout, w.u, w.b, N, H, W, 1, s);
         if (w.u4 && k == 5 && st == 1 && wino4_fills_chip(Cout, N, H, W, 2))
             return cnm_conv5x5_winograd_sync_c4_f32(in, Gt, g0, Gin, nullptr, 0, 0, 0, out, Gto, go0, Cout, w.u4, w.b, N, H, W, 1, sync, sync ? cnm_wino36_sync_floats() : 0, s);

@@ -133,6 +133,10 @@ class _EngineNet(nn.Module):
                     fused = (ops.pack_winograd4_upsampled(w, bnp, eps=bn.eps)
                              if (u4 is not None and L["ksize"] == 3 and L["conv_key"].startswith("upconv") and L["Cin"] <= 256
                                  and self.fused_upsample) else (None, None, None))
+                    if L["ksize"] == 3 and L["stride"] == 2 and self.winograd4 and L["Cout"] % 128 == 0:
+                        # 3x3 stride 2: a third filter, in the uu slot (bu / wr stay empty: not an up_conv) -- the pixel-phase form for the
+                        # shapes that would otherwise run the implicit GEMM (nets.hip)
+                        fused = (ops.pack_winograd4_s2(w, bnp, rot=L["rot"], eps=bn.eps), None, None)
                     packed.append((wp, bp, up, u4) + tuple(fused))
         arr = (_lib.LayerWeights * len(packed))()
         for i, t in enumerate(packed):

@@ -261,12 +261,12 @@ def pack_winograd4(weight, bn=None, rot=0, eps=1e-5):
 
 
 def pack_winograd4_s2(weight, bn=None, rot=0, eps=1e-5):
-    """36-point packed filter of a STRIDE-2 5x5 / 7x7 layer as a stride-1 convolution of the four pixel phases of its input:
-    5x5 -> four 3x3 phase filters (F(4x4,3x3)), 7x7 -> four 4x4 phase filters (F(3x3,4x4))."""
+    """36-point packed filter of a STRIDE-2 3x3 / 5x5 / 7x7 layer as a stride-1 convolution of the four pixel phases of its input:
+    5x5 (3x3) -> four 3x3 phase filters (F(4x4,3x3)), 7x7 -> four 4x4 phase filters (F(3x3,4x4))."""
     _dev(weight, *(bn or ()))
     lib = _lib.load()
     Cout, Cin, k, _ = weight.shape
-    assert k in (5, 7)
+    assert k in (3, 5, 7)
     up = torch.empty(lib.cnm_packed_winograd4_s2_floats(Cout, Cin), device=weight.device, dtype=torch.float32)
     g, v = (_c(bn[0]), _c(bn[3])) if bn else (None, None)
     with torch.cuda.device(weight.device):
@@ -275,7 +275,7 @@ def pack_winograd4_s2(weight, bn=None, rot=0, eps=1e-5):
 
 
 def conv_s2_winograd4_c4(x, u_packed, b_packed, Cout, ksize, relu=True, x2=None, sync=None):
-    """Stride-2 5x5 (pad 2) / 7x7 (pad 3) convolution on the LDS-staged 36-point kernel (pack_winograd4_s2 filter):
+    """Stride-2 3x3 (pad 1) / 5x5 (pad 2) / 7x7 (pad 3) convolution on the LDS-staged 36-point kernel (pack_winograd4_s2 filter):
     x [N,G,H,W,4] (H, W even) -> [N,Cout/4,H/2,W/2,4].  sync = a wino36_sync_workspace (required)."""
     _dev(x, u_packed, b_packed, x2, sync)
     N, G, H, W, _ = x.shape

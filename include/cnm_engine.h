@@ -245,10 +245,11 @@ int cnm_conv4x4_phase_scatter_winograd_sync_c4_f32(const float* in, int Gin_tota
 /* 36-point pack of a plain [Cout, Cin, k, k] filter, k = 3 / 4 / 5 (F(4x4,3x3) / F(3x3,4x4) / F(2x2,5x5)); no BatchNorm fold. */
 int cnm_pack_winograd36_f32(const float* w_oihw, int Cout, int Cin, int ksize, float* u_packed, void* stream);
 
-/* The STRIDE-2 5x5 / 7x7 layers (conv2.3 = nn.Conv2d(256, 256, 5, 2, 2), conv1.3 = nn.Conv2d(128, 128, 7, 2, 3),
+/* The STRIDE-2 5x5 / 7x7 (and, where they would run the implicit GEMM, 3x3) layers (conv2.3 = nn.Conv2d(256, 256, 5, 2, 2), conv1.3 = nn.Conv2d(128, 128, 7, 2, 3),
  * depthNet_model.py:136-139,145-148 through conv_layer :19-43) as a stride-1 convolution of the four pixel phases of the
  * input (space to depth, never materialised) on the LDS-staged 36-point kernel: 5x5 -> four 3x3 phase filters,
- * F(4x4,3x3), 9 multiplies per output instead of 25 (row-wise phase kernel: 15); 7x7 -> four 4x4 phase filters,
+ * F(4x4,3x3), 9 multiplies per output instead of 25 (row-wise phase kernel: 15); 3x3 -> four (at most) 2x2 phase filters in
+ * 3x3 slots, F(4x4,3x3): the direct count of 9, at the staged kernel's efficiency; 7x7 -> four 4x4 phase filters,
  * F(3x3,4x4) on the same six points, 16 instead of 49 (22.75).  H, W (even) = INPUT size, out = [N][Gout][H/2][W/2][4].
  * u_packed from cnm_pack_winograd4_s2_bn_f32 (cnm_packed_winograd4_s2_floats floats).  Staged kernel only: needs the
  * sync workspace of cnm_conv3x3_winograd4_sync_c4_f32 (same contract) and a shape cnm_conv_s2_winograd4_ok() accepts
@@ -400,6 +401,8 @@ int cnm_net_layer(int net, int index, cnm_layer_info* info);   /* D=64 table */
  * cnm_pack_winograd5x5_bn_f32 (F(2x2,5x5)) for 5x5 stride-1 layers: used instead of u when the layer has enough tiles
  * to fill the chip (>= CNM_WINO4_MIN_WORKGROUPS workgroups of 64 couts x 16 tiles); cnm_pack_winograd4_s2_bn_f32 for
  * 5x5 / 7x7 stride-2 layers: used instead of u where cnm_conv_s2_winograd4_ok() accepts the shape.
+ * uu alone (bu = wr = NULL) on a 3x3 stride-2 layer: optional cnm_pack_winograd4_s2_bn_f32(ksize 3) filter -- the layer then runs
+ * on the four pixel phases of its input (staged 36-point kernel) where neither the F(2x2) nor the row kernel is chosen.
  * uu, bu, wr: optional, up_conv layers only -- the four composed upsample-then-3x3 phase filters packed as 4*Cout
  * output channels (fp32 engine: cnm_pack_winograd4_bn_f32; fp16 engine: cnm_pack_conv_bn_f16, half data), the folded
  * bias four times, and the ring-pass filter (cnm_pack_upsampled_ring_f32, fp32 for both engines); all three or none. */
