@@ -84,10 +84,9 @@ def _winograd_conv(x, weight, rot, stride=1, dgrad=False):
         else:
             up4 = _packed("u4", weight, rot, 1, lambda: ops.pack_winograd4(weight, None, rot))
         return ops.conv3x3_winograd4_c4(x, up4, None, Cout, relu=False, ksize=k, sync=_sync_workspace(x.device))
-    if (not dgrad and stride == 2 and k in S2_PHASE_KSIZES and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
-            and _lib.load().cnm_conv_s2_winograd4_ok(Cout, x.shape[2], x.shape[3], k)):
-        # stride-2 5x5 / 7x7 forward: the four pixel phases of x on the staged 36-point kernel (F(4x4,3x3) / F(3x3,4x4)),
-        # the transforms the 3x3 layers of the step already run with
+    if not dgrad and stride == 2 and _s2_phases_ok(x, Cout, k) and not (k == 3 and _rows3_stride2_ok(x, Cout)):
+        # stride-2 5x5 / 7x7 forward (and the 3x3 ones the row kernel does not take): the four pixel phases of x on the staged
+        # 36-point kernel (F(4x4,3x3) / F(3x3,4x4)), the transforms the 3x3 layers of the step already run with
         ups = _packed("u4s2", weight, rot, 2, lambda: ops.pack_winograd4_s2(weight, None, rot))
         return ops.conv_s2_winograd4_c4(x, ups, None, Cout, k, relu=False, sync=_sync_workspace(x.device))
     if k == 3 and stride == 2:                                           # (only called where _rows3_stride2_ok says so) two F(4,2) column phases along rows
@@ -111,7 +110,7 @@ FAST_FORWARD = True              # the inference kernels' larger tiles where the
 PAD_DGRAD = True                 # 3x3 stride-1 data gradients with ragged input-channel counts on the Winograd kernels (padded), not the direct kernel
 FAST_ROWS7 = False               # ... F(4,7) for conv1.0 does not (see _winograd_conv): off
 WINOGRAD4_MIN_WORKGROUPS = 384   # same switch point as the inference executors (include/cnm_engine.h)
-S2_PHASE_KSIZES = (5, 7)         # stride-2 layers whose FORWARD runs on the pixel phases of the input (ops.conv_s2_winograd4_c4); () keeps the F(2,k) row phases
+S2_PHASE_KSIZES = (3, 5, 7)         # stride-2 layers whose FORWARD runs on the pixel phases of the input (ops.conv_s2_winograd4_c4); () keeps the F(2,k) row phases
 S2_DGRAD_SCATTER = True          # stride-2 data gradient with 3x3 phase filters: one phase-interleaving launch instead of four convolutions + four strided copies
 WINOGRAD4_SMALL = True           # ... and the same extension below it (nets.hip wino4_staged_small)
 
@@ -119,6 +118,11 @@ WINOGRAD4_SMALL = True           # ... and the same extension below it (nets.hip
 def _winograd4_fills_chip(x, Cout, m=4):
     N, _, H, W, _ = x.shape
     return (Cout // 64) * -(-(N * -(-H // m) * -(-W // m)) // 16) >= WINOGRAD4_MIN_WORKGROUPS
+
+
+def _s2_phases_ok(x, Cout, k):
+    return (WINOGRAD and k in S2_PHASE_KSIZES and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
+            and bool(_lib.load().cnm_conv_s2_winograd4_ok(Cout, x.shape[2], x.shape[3], k)))
 
 
 def _rows3_stride2_ok(x, Cout):
@@ -171,7 +175,7 @@ class ConvC4(torch.autograd.Function):
     def forward(ctx, x, weight, stride, rot):
         x = x.contiguous()
         Cout, Cin, k, _ = weight.shape
-        if _winograd_ok(k, stride, Cout) or (k == 3 and stride == 2 and _rows3_stride2_ok(x, Cout)):
+        if _winograd_ok(k, stride, Cout) or (k == 3 and stride == 2 and (_rows3_stride2_ok(x, Cout) or _s2_phases_ok(x, Cout, 3))):
             y = _winograd_conv(x, weight.detach(), rot, stride)
         else:
             wp, _ = ops.pack_conv(weight.detach(), None, None, rot)

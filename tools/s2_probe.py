@@ -24,7 +24,7 @@ def event_ms(fn, iters=20, warm=3):
 
 
 torch.manual_seed(0)
-for name, k, Cin, Cout, N, H, W in (("depth conv2.3", 5, 256, 256, 16, 96, 128), ("depth conv1.3", 7, 128, 128, 16, 192, 256), ("refine conv3.3", 3, 512, 512, 8, 48, 64), ("depth conv4.3", 3, 512, 512, 16, 24, 32), ("depth conv3.3", 3, 512, 512, 16, 48, 64)):
+for name, k, Cin, Cout, N, H, W in (("depth conv2.3", 5, 256, 256, 16, 96, 128), ("depth conv1.3", 7, 128, 128, 16, 192, 256), ("refine conv3.3", 3, 512, 512, 8, 48, 64), ("depth conv4.3", 3, 512, 512, 16, 24, 32), ("depth conv3.3", 3, 512, 512, 16, 48, 64), ("refine conv1.3", 3, 128, 128, 8, 192, 256), ("refine conv2.3", 3, 256, 256, 8, 96, 128)):
     w = torch.randn(Cout, Cin, k, k, device=dev) * (2.0 / (Cin * k * k)) ** 0.5
     bp = torch.randn(Cout, device=dev) * 0.1
     us = ops.pack_winograd4_s2(w)
