@@ -23,7 +23,8 @@ struct WgradArgs {
     unsigned x_bytes, dy_bytes;
     int N, H, W, Ho, Wo, Gx_tot, gx0, Gin, Gy_tot, gy0, Cout, Cout_pad;
     int ks, stride, pad, Kflat, Kpad128, M, pix_per_split;
-};
+    int per_image_splits;           // 0: one reduction over all N*Ho*Wo pixels, split by grid.z.  s > 0: grid.z = image * s + split -- every image is a
+};                                  // problem of its own (the 36 frequency points of the Winograd-domain gradient below), M = Ho*Wo
 
 // TCO = couts per workgroup: 128 (waves 2 x 2, 64 x 64 each) or 64 (waves 1 x 4, 64 couts x 32 k each) for the 64-cout
 // layers, where a 128-row tile would spend half of its MFMAs on padding rows.
@@ -36,7 +37,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wc = wave / WK, wp = wave % WK;
     const int c0 = blockIdx.x * TCO, k0 = blockIdx.y * 128;
     const int HW = a.H * a.W, HoWo = a.Ho * a.Wo;
-    const int r0 = blockIdx.z * a.pix_per_split, r1 = min(r0 + a.pix_per_split, a.M);
+    const int zsplit = a.per_image_splits ? (int)blockIdx.z % a.per_image_splits : (int)blockIdx.z;
+    const int zimg = a.per_image_splits ? (int)blockIdx.z / a.per_image_splits : 0;
+    const int r0 = zsplit * a.pix_per_split, r1 = min(r0 + a.pix_per_split, a.M);
 
     // loader mapping: float4 slot f = t + i*256 (i = 0,1): pixel lane pl = f % 16, quad row q = f / 16 (0..31)
     const int pl = t & 15;
@@ -51,7 +54,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
         bok[i] = tap < a.ks * a.ks;
     }
     // running output-pixel coordinate of this thread's pixel lane
-    int m = r0 + pl, img = m / HoWo, rem = m - img * HoWo, oy = rem / a.Wo, ox = rem - oy * a.Wo;
+    int m = r0 + pl, img = a.per_image_splits ? zimg : m / HoWo, rem = a.per_image_splits ? m : m - img * HoWo, oy = rem / a.Wo, ox = rem - oy * a.Wo;
 
     f32x16 acc[2][PJ];
 #pragma unroll
@@ -191,6 +194,7 @@ extern "C" int cnm_conv2d_wgrad_c4_f32(const float* x, int Gx_total, int gx0, in
     a.Kflat = ksize * ksize * 4 * a.Gin; a.M = N * a.Ho * a.Wo;
     int splits;
     wgrad_plan(Cout, Cin, ksize, a.M, &a.Cout_pad, &a.Kpad128, &splits, &a.pix_per_split);
+    a.per_image_splits = 0;
     CNM_REQUIRE((size_t)splits * a.Cout_pad * a.Kpad128 <= ws_floats, CNM_ERR_WORKSPACE);
     const unsigned long long xb = (unsigned long long)N * Gx_total * H * W * 16ull, yb = (unsigned long long)N * Gy_total * a.Ho * a.Wo * 16ull;
     CNM_REQUIRE(xb < 0xFFFFFFFFull && yb < 0xFFFFFFFFull, CNM_ERR_BAD_ARG);
@@ -200,6 +204,177 @@ extern "C" int cnm_conv2d_wgrad_c4_f32(const float* x, int Gx_total, int gx0, in
     const long long total = (long long)Cout * a.Kflat;
     wgrad_reduce_kernel<<<(unsigned)cnm_ceil_div_ll(total, 256), 256, 0, cnm_stream(stream)>>>(
         ws, splits, Cout, a.Cout_pad, Cin, ksize, rot, a.Kpad128, dw_oihw);
+    CNM_LAUNCH_CHECK();
+    return CNM_OK;
+}
+
+// ------------------------------------------------------------------ weight gradient of the 3x3 stride-1 layers in the Winograd domain
+// y = A^T [ (G g G^T) (.) (B^T d B) ] A per 4x4 output tile (F(4x4,3x3), the forward's algorithm)  =>
+//     dg = G^T [ sum_tiles (A dY A^T) (.) (B^T d B) ] G :
+// for each of the 36 frequency points one GEMM  dU[xi][co][ci] = sum_t Yh[xi][co][t] Xh[xi][ci][t]  over the T = N*ceil(H/4)*ceil(W/4)
+// tiles -- a quarter of the direct gradient's multiplies (36 per 16 pixels and tap-free, instead of 9 per pixel).  Unfused on
+// purpose: the transformed tensors (2.25x the size of X and dY) are written once and read once, 0.05-0.1 ms per layer at HBM
+// rates, against 0.3 ms for the direct kernel; the 36 GEMMs are ONE launch of conv_wgrad_kernel (the transformed tensors are
+// laid out as c4 "images" [36][G][1][T][4]: per_image_splits mode, 1x1 taps), and the finishing kernel sums the splits (fp64),
+// applies G^T . G and scatters to OIHW.
+typedef float wg_f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void wg_bt6(wg_f4& x0, wg_f4& x1, wg_f4& x2, wg_f4& x3, wg_f4& x4, wg_f4& x5) {   // B^T of F(4,3), points {0, 1, -1, 2, -2, inf}
+    const wg_f4 t0 = 4.f * x0 - 5.f * x2 + x4, t5 = 4.f * x1 - 5.f * x3 + x5;
+    const wg_f4 e1 = x4 - 4.f * x2, o1 = x3 - 4.f * x1, e2 = x4 - x2, o2 = x3 - x1;
+    x0 = t0; x1 = e1 + o1; x2 = e1 - o1; x3 = e2 + 2.f * o2; x4 = e2 - 2.f * o2; x5 = t5;
+}
+
+// Xh[xi][g][t] = (B^T d B)[xi] of the 6x6 window of tile t (origin 4 ty - 1, 4 tx - 1, zero padding), channel group g.
+// One thread per (tile, group), tiles fastest: the 36 stores of a wave are 36 contiguous 1 KB rows.
+__global__ __launch_bounds__(256) void wino_wgrad_xform_x_kernel(const float* __restrict__ x, int Gx_tot, int gx0, int Gin, int N, int H, int W,
+                                                                 int TH, int TW, float* __restrict__ xh) {
+    const int T = N * TH * TW;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)T * Gin) return;
+    const int t = (int)(idx % T), g = (int)(idx / T);
+    const int n = t / (TH * TW), r = t - n * TH * TW, ty = r / TW, tx = r - ty * TW;
+    const wg_f4* base = reinterpret_cast<const wg_f4*>(x + c4_offset(n, Gx_tot, gx0 + g, H * W, 0));
+    wg_f4 d[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int iy = 4 * ty - 1 + i;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int ix = 4 * tx - 1 + j;
+            d[i][j] = ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? base[iy * W + ix] : wg_f4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) wg_bt6(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) wg_bt6(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5]);
+    wg_f4* out = reinterpret_cast<wg_f4*>(xh) + (size_t)g * T + t;
+    const size_t plane = (size_t)Gin * T;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) out[(size_t)(i * 6 + j) * plane] = d[i][j];
+}
+
+// Yh[xi][g][t] = (A dY A^T)[xi] of the 4x4 output tile t (zero beyond the image), A = (A^T of F(4,3))^T: rows [1 0 0 0], [1 1 1 1],
+// [1 -1 1 -1], [1 2 4 8], [1 -2 4 -8], [0 0 0 1].
+__device__ __forceinline__ void wg_a6(const wg_f4 v0, const wg_f4 v1, const wg_f4 v2, const wg_f4 v3, wg_f4 (&o)[6]) {
+    const wg_f4 s02 = v0 + v2, s13 = v1 + v3, p = v0 + 4.f * v2, q = 2.f * v1 + 8.f * v3;
+    o[0] = v0; o[1] = s02 + s13; o[2] = s02 - s13; o[3] = p + q; o[4] = p - q; o[5] = v3;
+}
+__global__ __launch_bounds__(256) void wino_wgrad_xform_dy_kernel(const float* __restrict__ dy, int Gy_tot, int gy0, int Gout, int N, int H, int W,
+                                                                  int TH, int TW, float* __restrict__ yh) {
+    const int T = N * TH * TW;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)T * Gout) return;
+    const int t = (int)(idx % T), g = (int)(idx / T);
+    const int n = t / (TH * TW), r = t - n * TH * TW, ty = r / TW, tx = r - ty * TW;
+    const wg_f4* base = reinterpret_cast<const wg_f4*>(dy + c4_offset(n, Gy_tot, gy0 + g, H * W, 0));
+    wg_f4 c[4][6];                                                       // columns first: c[i][*] = A applied along x of row i
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int iy = 4 * ty + i;
+        wg_f4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ix = 4 * tx + j;
+            v[j] = (iy < H && ix < W) ? base[iy * W + ix] : wg_f4{0.f, 0.f, 0.f, 0.f};
+        }
+        wg_a6(v[0], v[1], v[2], v[3], c[i]);
+    }
+    wg_f4* out = reinterpret_cast<wg_f4*>(yh) + (size_t)g * T + t;
+    const size_t plane = (size_t)Gout * T;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        wg_f4 o[6];
+        wg_a6(c[0][j], c[1][j], c[2][j], c[3][j], o);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) out[(size_t)(i * 6 + j) * plane] = o[i];
+    }
+}
+
+// dW[co][ci] = G^T dU[.][co][ci] G with dU[xi] = the sum of the `splits` partial tiles of frequency point xi (fp64 throughout).
+// partial: [36 * splits][Cout_pad][Kpad128]; one thread per (cout, packed input channel).
+__global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* __restrict__ partial, int splits, int Cout, int Cout_pad, int Cin, int rot,
+                                                                int Kpad128, float* __restrict__ dw) {
+    const int Cp = 4 * ((Cin + 3) / 4);
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)Cout * Cp) return;
+    const int co = (int)(idx / Cp), cp = (int)(idx - (long long)co * Cp);
+    if (cp >= Cin) return;
+    const float* q = partial + (size_t)co * Kpad128 + cp;
+    const size_t zstride = (size_t)Cout_pad * Kpad128;
+    double u[6][6];
+#pragma unroll
+    for (int xi = 0; xi < 36; ++xi) {
+        double s = 0.0;
+        for (int z = 0; z < splits; ++z) s += (double)q[(size_t)(xi * splits + z) * zstride];
+        u[xi / 6][xi % 6] = s;
+    }
+    constexpr double G3[6][3] = {{1. / 4, 0, 0}, {-1. / 6, -1. / 6, -1. / 6}, {-1. / 6, 1. / 6, -1. / 6}, {1. / 24, 1. / 12, 1. / 6}, {1. / 24, -1. / 12, 1. / 6}, {0, 0, 1}};
+    float* o = dw + ((size_t)co * Cin + (cp + rot) % Cin) * 9;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            double s = 0.0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int b = 0; b < 6; ++b) s += G3[a][p] * u[a][b] * G3[b][r];
+            o[p * 3 + r] = (float)s;
+        }
+}
+
+static void wino_wgrad_plan(int Cout, int Cin, int T, int* Cout_pad, int* Kpad128, int* splits, int* pps) {
+    const int tco = wgrad_tco(Cout);
+    *Cout_pad = wg_round(Cout, tco);
+    *Kpad128 = wg_round(4 * ((Cin + 3) / 4), 128);
+    const int tiles = 36 * (*Cout_pad / tco) * (*Kpad128 / 128);
+    int s = (CNM_WGRAD_WORKGROUPS + tiles - 1) / tiles;
+    const int maxs = (T + 255) / 256;                                    // at least 256 tiles per split
+    if (s > maxs) s = maxs;
+    if (s < 1) s = 1;
+    *pps = wg_round((T + s - 1) / s, 16);
+    *splits = (T + *pps - 1) / *pps;
+}
+
+extern "C" size_t cnm_conv3x3_wgrad_winograd_workspace_floats(int Cout, int Cin, int N, int H, int W) {
+    if (Cout <= 0 || Cin <= 0 || N <= 0 || H <= 0 || W <= 0) return 0;
+    const size_t T = (size_t)N * ((H + 3) / 4) * ((W + 3) / 4);
+    int cp, kp, sp, pps;
+    wino_wgrad_plan(Cout, Cin, (int)T, &cp, &kp, &sp, &pps);
+    return 36 * T * 4 * (size_t)((Cin + 3) / 4) + 36 * T * 4 * (size_t)((Cout + 3) / 4) + (size_t)36 * sp * cp * kp;
+}
+
+extern "C" int cnm_conv3x3_wgrad_winograd_c4_f32(const float* x, int Gx_total, int gx0, int Cin,
+                                                 const float* dy, int Gy_total, int gy0, int Cout,
+                                                 float* dw_oihw, float* ws, size_t ws_floats,
+                                                 int N, int H, int W, int rot, void* stream) {
+    CNM_REQUIRE(x && dy && dw_oihw && ws && N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cout % 4 == 0 && rot >= 0 && rot < Cin, CNM_ERR_BAD_ARG);
+    const int Gin = (Cin + 3) / 4, Gout = Cout / 4, TH = (H + 3) / 4, TW = (W + 3) / 4;
+    const long long Tll = (long long)N * TH * TW;
+    CNM_REQUIRE(gx0 >= 0 && gx0 + Gin <= Gx_total && gy0 >= 0 && gy0 + Gout <= Gy_total && Tll < (1ll << 24), CNM_ERR_BAD_ARG);
+    const int T = (int)Tll;
+    CNM_REQUIRE(cnm_conv3x3_wgrad_winograd_workspace_floats(Cout, Cin, N, H, W) <= ws_floats, CNM_ERR_WORKSPACE);
+    float* xh = ws; float* yh = xh + (size_t)36 * T * 4 * Gin; float* partial = yh + (size_t)36 * T * 4 * Gout;
+    const unsigned long long xb = 36ull * T * Gin * 16ull, yb = 36ull * T * Gout * 16ull;
+    CNM_REQUIRE(xb < 0xFFFFFFFFull && yb < 0xFFFFFFFFull, CNM_ERR_BAD_ARG);
+    hipStream_t s = cnm_stream(stream);
+    wino_wgrad_xform_x_kernel<<<(unsigned)cnm_ceil_div_ll((long long)T * Gin, 256), 256, 0, s>>>(x, Gx_total, gx0, Gin, N, H, W, TH, TW, xh);
+    wino_wgrad_xform_dy_kernel<<<(unsigned)cnm_ceil_div_ll((long long)T * Gout, 256), 256, 0, s>>>(dy, Gy_total, gy0, Gout, N, H, W, TH, TW, yh);
+    WgradArgs a;
+    a.x = xh; a.dy = yh; a.partial = partial; a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)yb;
+    a.N = 36; a.H = 1; a.W = T; a.Ho = 1; a.Wo = T; a.ks = 1; a.stride = 1; a.pad = 0;
+    a.Gx_tot = Gin; a.gx0 = 0; a.Gin = Gin; a.Gy_tot = Gout; a.gy0 = 0; a.Cout = Cout;
+    a.Kflat = 4 * Gin; a.M = T;
+    int splits;
+    wino_wgrad_plan(Cout, Cin, T, &a.Cout_pad, &a.Kpad128, &splits, &a.pix_per_split);
+    a.per_image_splits = splits;
+    if (wgrad_tco(Cout) == 128) conv_wgrad_kernel<128><<<dim3(a.Cout_pad / 128, a.Kpad128 / 128, 36 * splits), 256, 0, s>>>(a);
+    else conv_wgrad_kernel<64><<<dim3(a.Cout_pad / 64, a.Kpad128 / 128, 36 * splits), 256, 0, s>>>(a);
+    wino_wgrad_finish_kernel<<<(unsigned)cnm_ceil_div_ll((long long)Cout * 4 * Gin, 256), 256, 0, s>>>(partial, splits, Cout, a.Cout_pad, Cin, rot, a.Kpad128, dw_oihw);
     CNM_LAUNCH_CHECK();
     return CNM_OK;
 }

@@ -497,6 +497,16 @@ int cnm_conv2d_dgrad_c4_f32(const float* dy, int Gy_total, int gy0, int Cout,
  * the pixels as the reduction dimension, split into partial sums (ws) and reduced in fp64.
  * x [N,.,H,W,4] (forward input view), dy [N,.,Ho,Wo,4] -> dw_oihw [Cout,Cin,k,k] (rotation undone). */
 size_t cnm_conv2d_wgrad_workspace_floats(int Cout, int Cin, int ksize, int N, int Ho, int Wo);
+/* The same gradient for a 3x3 stride-1 pad-1 convolution in the Winograd domain of the forward's F(4x4,3x3):
+ * dW = G^T [ sum_tiles (A dY A^T) (.) (B^T X B) ] G -- two transform kernels, ONE launch of 36 GEMMs over the tiles (a quarter of
+ * the direct gradient's multiplies), a finishing kernel (fp64 split sums, G^T . G, OIHW scatter).  Same arguments as
+ * cnm_conv2d_wgrad_c4_f32 without ksize / stride; ws of cnm_conv3x3_wgrad_winograd_workspace_floats floats (transformed X and
+ * dY + partial tiles). */
+size_t cnm_conv3x3_wgrad_winograd_workspace_floats(int Cout, int Cin, int N, int H, int W);
+int cnm_conv3x3_wgrad_winograd_c4_f32(const float* x, int Gx_total, int gx0, int Cin,
+                                      const float* dy, int Gy_total, int gy0, int Cout,
+                                      float* dw_oihw, float* ws, size_t ws_floats,
+                                      int N, int H, int W, int rot, void* stream);
 int cnm_conv2d_wgrad_c4_f32(const float* x, int Gx_total, int gx0, int Cin,
                             const float* dy, int Gy_total, int gy0, int Cout,
                             float* dw_oihw, float* ws, size_t ws_floats,
