@@ -108,7 +108,7 @@ def _winograd_conv(x, weight, rot, stride=1, dgrad=False):
 
 FAST_FORWARD = True              # the inference kernels' larger tiles where their relative L2 error stays a decade below the op-level bar (2e-5): F(2x2,5x5), F(4,2) stride-2 rows
 WINOGRAD_WGRAD = True            # weight gradient of the 3x3 stride-1 layers in the Winograd domain (transform, 36 GEMMs, inverse transform)
-WINOGRAD_WGRAD_MAX_PIXELS = 65536   # ... up to this many pixels N*H*W (4 x 96 x 128: measured 1.14-1.41x there, 2x at 48x64 and 24x32; 0.45-0.58x at 4 x 192 x 256)
+WINOGRAD_WGRAD_MIN_PIXELS = 512     # ... from this many pixels N*H*W on (4 x 12 x 16 = 768: 1.2-1.4x; 4 x 6 x 8: the direct kernel)
 PAD_DGRAD = True                 # 3x3 stride-1 data gradients with ragged input-channel counts on the Winograd kernels (padded), not the direct kernel
 FAST_ROWS7 = False               # ... F(4,7) for conv1.0 does not (see _winograd_conv): off
 WINOGRAD4_MIN_WORKGROUPS = 384   # same switch point as the inference executors (include/cnm_engine.h)
@@ -230,10 +230,10 @@ class ConvC4(torch.autograd.Function):
                 dx = torch.empty_like(x)
                 _lib.check(lib.cnm_conv2d_dgrad_c4_f32(dy.data_ptr(), dy.shape[1], 0, Cout, dx.data_ptr(), G, 0, Cin,
                                                        wd.data_ptr(), N, H, W, k, ctx.stride, _s()))
-            if ctx.needs_input_grad[1] and WINOGRAD_WGRAD and k == 3 and ctx.stride == 1 and N * H * W <= WINOGRAD_WGRAD_MAX_PIXELS:
-                # 3x3 stride 1 below full resolution: the gradient in the Winograd domain of the forward's F(4x4,3x3) -- 36 GEMMs over
-                # the tiles, a quarter of the direct kernel's multiplies (cnm_conv3x3_wgrad_winograd_c4_f32): 1.1-2.3x
-                # (tools/wgrad_wino_probe.py); at 192x256 the transformed tensors (2.25x X and dY through HBM) cost more than they save
+            if ctx.needs_input_grad[1] and WINOGRAD_WGRAD and k == 3 and ctx.stride == 1 and N * H * W >= WINOGRAD_WGRAD_MIN_PIXELS:
+                # 3x3 stride 1: the gradient in the Winograd domain of the forward's F(4x4,3x3) -- 36 GEMMs over the tiles, a quarter
+                # of the direct kernel's multiplies (cnm_conv3x3_wgrad_winograd_c4_f32): 1.5-2.4x from 4 x 24 x 32 pixels up
+                # (tools/wgrad_wino_probe.py)
                 ws = torch.empty(lib.cnm_conv3x3_wgrad_winograd_workspace_floats(Cout, Cin, N, H, W), device=dev, dtype=torch.float32)
                 dw = torch.empty_like(weight)
                 _lib.check(lib.cnm_conv3x3_wgrad_winograd_c4_f32(x.data_ptr(), G, 0, Cin, dy.data_ptr(), dy.shape[1], 0, Cout,

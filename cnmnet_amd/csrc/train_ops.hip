@@ -215,8 +215,8 @@ extern "C" int cnm_conv2d_wgrad_c4_f32(const float* x, int Gx_total, int gx0, in
 // tiles -- a quarter of the direct gradient's multiplies (36 per 16 pixels and tap-free, instead of 9 per pixel).  Unfused on
 // purpose: the transformed tensors (2.25x the size of X and dY) are written once and read once, 0.05-0.1 ms per layer at HBM
 // rates, against 0.3 ms for the direct kernel; the 36 GEMMs are ONE launch of conv_wgrad_kernel (the transformed tensors are
-// laid out as c4 "images" [36][G][1][T][4]: per_image_splits mode, 1x1 taps), and the finishing kernel sums the splits (fp64),
-// applies G^T . G and scatters to OIHW.
+// laid out as c4 "images" [36][G][1][T][4]: per_image_splits mode, 1x1 taps); a reduction kernel sums the splits (fp64) and the
+// finishing kernel applies G^T . G and scatters to OIHW.
 typedef float wg_f4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void wg_bt6(wg_f4& x0, wg_f4& x1, wg_f4& x2, wg_f4& x3, wg_f4& x4, wg_f4& x5) {   // B^T of F(4,3), points {0, 1, -1, 2, -2, inf}
@@ -294,23 +294,48 @@ __global__ __launch_bounds__(256) void wino_wgrad_xform_dy_kernel(const float* _
     }
 }
 
-// dW[co][ci] = G^T dU[.][co][ci] G with dU[xi] = the sum of the `splits` partial tiles of frequency point xi (fp64 throughout).
-// partial: [36 * splits][Cout_pad][Kpad128]; one thread per (cout, packed input channel).
-__global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* __restrict__ partial, int splits, int Cout, int Cout_pad, int Cin, int rot,
-                                                                int Kpad128, float* __restrict__ dw) {
+// dU[xi][co][cp] = the sum of the `splits` partial tiles of frequency point xi (fp64 sum, one thread per element: 36 x Cout x Cp
+// threads -- a thread per (cout, channel) that walked all 36 x splits partials itself ran 4352 threads for 0.5 ms on the 64-channel
+// full-resolution layers), then dW[co][ci] = G^T dU[.][co][ci] G in fp64, scattered to OIHW.
+// partial: [36 * splits][Cout_pad][Kpad128]; u: [36][Cout][Cp].
+__global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __restrict__ partial, int splits, int Cout, int Cout_pad, int Cp, int Kpad128,
+                                                                float* __restrict__ u) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long per = (long long)Cout * Cp;
+    if (idx >= 36 * per) return;
+    const int xi = (int)(idx / per); const long long r = idx - xi * per;
+    const int co = (int)(r / Cp), cp = (int)(r - (long long)co * Cp);
+    const float* q = partial + (size_t)xi * splits * Cout_pad * Kpad128 + (size_t)co * Kpad128 + cp;
+    const size_t zstride = (size_t)Cout_pad * Kpad128;
+    double s = 0.0;
+    for (int z = 0; z < splits; ++z) s += (double)q[(size_t)z * zstride];
+    u[idx] = (float)s;
+}
+
+// FUSED (few splits: the low-resolution layers): u = the partial tiles themselves, every thread sums its 36 x splits values -- one
+// launch and no 36 x Cout x Cp intermediate.
+template <bool FUSED>
+__global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* __restrict__ u, int splits, int Cout, int Cout_pad, int Kpad128,
+                                                                int Cin, int rot, float* __restrict__ dw) {
     const int Cp = 4 * ((Cin + 3) / 4);
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)Cout * Cp) return;
+    const long long per = (long long)Cout * Cp;
+    if (idx >= per) return;
     const int co = (int)(idx / Cp), cp = (int)(idx - (long long)co * Cp);
     if (cp >= Cin) return;
-    const float* q = partial + (size_t)co * Kpad128 + cp;
-    const size_t zstride = (size_t)Cout_pad * Kpad128;
-    double u[6][6];
+    double uu[6][6];
+    if constexpr (FUSED) {
+        const float* q = u + (size_t)co * Kpad128 + cp;
+        const size_t zstride = (size_t)Cout_pad * Kpad128;
 #pragma unroll
-    for (int xi = 0; xi < 36; ++xi) {
-        double s = 0.0;
-        for (int z = 0; z < splits; ++z) s += (double)q[(size_t)(xi * splits + z) * zstride];
-        u[xi / 6][xi % 6] = s;
+        for (int xi = 0; xi < 36; ++xi) {
+            double s = 0.0;
+            for (int z = 0; z < splits; ++z) s += (double)q[(size_t)(xi * splits + z) * zstride];
+            uu[xi / 6][xi % 6] = s;
+        }
+    } else {
+#pragma unroll
+        for (int xi = 0; xi < 36; ++xi) uu[xi / 6][xi % 6] = (double)u[(size_t)xi * per + idx];
     }
     constexpr double G3[6][3] = {{1. / 4, 0, 0}, {-1. / 6, -1. / 6, -1. / 6}, {-1. / 6, 1. / 6, -1. / 6}, {1. / 24, 1. / 12, 1. / 6}, {1. / 24, -1. / 12, 1. / 6}, {0, 0, 1}};
     float* o = dw + ((size_t)co * Cin + (cp + rot) % Cin) * 9;
@@ -322,7 +347,7 @@ __global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* __r
 #pragma unroll
             for (int a = 0; a < 6; ++a)
 #pragma unroll
-                for (int b = 0; b < 6; ++b) s += G3[a][p] * u[a][b] * G3[b][r];
+                for (int b = 0; b < 6; ++b) s += G3[a][p] * uu[a][b] * G3[b][r];
             o[p * 3 + r] = (float)s;
         }
 }
@@ -345,7 +370,7 @@ extern "C" size_t cnm_conv3x3_wgrad_winograd_workspace_floats(int Cout, int Cin,
     const size_t T = (size_t)N * ((H + 3) / 4) * ((W + 3) / 4);
     int cp, kp, sp, pps;
     wino_wgrad_plan(Cout, Cin, (int)T, &cp, &kp, &sp, &pps);
-    return 36 * T * 4 * (size_t)((Cin + 3) / 4) + 36 * T * 4 * (size_t)((Cout + 3) / 4) + (size_t)36 * sp * cp * kp;
+    return 36 * T * 4 * (size_t)((Cin + 3) / 4) + 36 * T * 4 * (size_t)((Cout + 3) / 4) + (size_t)36 * sp * cp * kp + (size_t)36 * Cout * 4 * ((Cin + 3) / 4);
 }
 
 extern "C" int cnm_conv3x3_wgrad_winograd_c4_f32(const float* x, int Gx_total, int gx0, int Cin,
@@ -374,7 +399,14 @@ extern "C" int cnm_conv3x3_wgrad_winograd_c4_f32(const float* x, int Gx_total, i
     a.per_image_splits = splits;
     if (wgrad_tco(Cout) == 128) conv_wgrad_kernel<128><<<dim3(a.Cout_pad / 128, a.Kpad128 / 128, 36 * splits), 256, 0, s>>>(a);
     else conv_wgrad_kernel<64><<<dim3(a.Cout_pad / 64, a.Kpad128 / 128, 36 * splits), 256, 0, s>>>(a);
-    wino_wgrad_finish_kernel<<<(unsigned)cnm_ceil_div_ll((long long)Cout * 4 * Gin, 256), 256, 0, s>>>(partial, splits, Cout, a.Cout_pad, Cin, rot, a.Kpad128, dw_oihw);
+    const unsigned nfin = (unsigned)cnm_ceil_div_ll((long long)Cout * 4 * Gin, 256);
+    if (splits <= 4) {
+        wino_wgrad_finish_kernel<true><<<nfin, 256, 0, s>>>(partial, splits, Cout, a.Cout_pad, a.Kpad128, Cin, rot, dw_oihw);
+    } else {
+        float* u = partial + (size_t)36 * splits * a.Cout_pad * a.Kpad128;
+        wino_wgrad_reduce_kernel<<<(unsigned)cnm_ceil_div_ll(36ll * Cout * 4 * Gin, 256), 256, 0, s>>>(partial, splits, Cout, a.Cout_pad, 4 * Gin, a.Kpad128, u);
+        wino_wgrad_finish_kernel<false><<<nfin, 256, 0, s>>>(u, splits, Cout, a.Cout_pad, a.Kpad128, Cin, rot, dw_oihw);
+    }
     CNM_LAUNCH_CHECK();
     return CNM_OK;
 }
