@@ -238,6 +238,13 @@ class ConvC4(torch.autograd.Function):
                 dw = torch.empty_like(weight)
                 _lib.check(lib.cnm_conv3x3_wgrad_winograd_c4_f32(x.data_ptr(), G, 0, Cin, dy.data_ptr(), dy.shape[1], 0, Cout,
                                                                  dw.data_ptr(), ws.data_ptr(), ws.numel(), N, H, W, ctx.rot, _s()))
+            elif (ctx.needs_input_grad[1] and WINOGRAD_WGRAD and k in (5, 7) and ctx.stride == 2 and H % 2 == 0 and W % 2 == 0
+                  and N * H * W >= 4 * WINOGRAD_WGRAD_MIN_PIXELS):
+                # 5x5 / 7x7 stride 2: the same on the four pixel phases of x (cnm_conv_s2_wgrad_winograd_c4_f32)
+                ws = torch.empty(lib.cnm_conv_s2_wgrad_winograd_workspace_floats(Cout, Cin, k, N, H, W), device=dev, dtype=torch.float32)
+                dw = torch.empty_like(weight)
+                _lib.check(lib.cnm_conv_s2_wgrad_winograd_c4_f32(x.data_ptr(), G, 0, Cin, dy.data_ptr(), dy.shape[1], 0, Cout,
+                                                                 dw.data_ptr(), ws.data_ptr(), ws.numel(), N, H, W, k, ctx.rot, _s()))
             elif ctx.needs_input_grad[1]:
                 Ho, Wo = dy.shape[2], dy.shape[3]
                 ws = torch.empty(lib.cnm_conv2d_wgrad_workspace_floats(Cout, Cin, k, N, Ho, Wo), device=dev, dtype=torch.float32)

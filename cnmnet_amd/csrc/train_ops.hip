@@ -225,44 +225,58 @@ __device__ __forceinline__ void wg_bt6(wg_f4& x0, wg_f4& x1, wg_f4& x2, wg_f4& x
     x0 = t0; x1 = e1 + o1; x2 = e1 - o1; x3 = e2 + 2.f * o2; x4 = e2 - 2.f * o2; x5 = t5;
 }
 
-// Xh[xi][g][t] = (B^T d B)[xi] of the 6x6 window of tile t (origin 4 ty - 1, 4 tx - 1, zero padding), channel group g.
+// Xh[xi][g][t] = (B^T d B)[xi] of the 6x6 window of tile t (origin M ty - PADW, M tx - PADW, zero padding), channel group g.
 // One thread per (tile, group), tiles fastest: the 36 stores of a wave are 36 contiguous 1 KB rows.
+// S2 (the stride-2 layers, conv_winograd4s.hip): the "image" is one of the four pixel phases of x -- group gg = phase * Gin + g reads
+// x(2 iy + py, 2 ix + px) on the H x W phase grid (= the output size); M = 3 with PADW = 2 for the 4x4 phase filters of a 7x7.
+template <int M, bool S2>
 __global__ __launch_bounds__(256) void wino_wgrad_xform_x_kernel(const float* __restrict__ x, int Gx_tot, int gx0, int Gin, int N, int H, int W,
                                                                  int TH, int TW, float* __restrict__ xh) {
-    const int T = N * TH * TW;
+    constexpr int PADW = (S2 && M == 3) ? 2 : 1;
+    const int T = N * TH * TW, Geff = S2 ? 4 * Gin : Gin;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)T * Gin) return;
-    const int t = (int)(idx % T), g = (int)(idx / T);
+    if (idx >= (long long)T * Geff) return;
+    const int t = (int)(idx % T), gg = (int)(idx / T);
+    const int ph = S2 ? gg / Gin : 0, g = S2 ? gg - ph * Gin : gg, py = ph >> 1, px = ph & 1;
     const int n = t / (TH * TW), r = t - n * TH * TW, ty = r / TW, tx = r - ty * TW;
-    const wg_f4* base = reinterpret_cast<const wg_f4*>(x + c4_offset(n, Gx_tot, gx0 + g, H * W, 0));
+    const int Wi = S2 ? 2 * W : W, HWi = S2 ? 4 * H * W : H * W;         // the stored image
+    const wg_f4* base = reinterpret_cast<const wg_f4*>(x + c4_offset(n, Gx_tot, gx0 + g, HWi, 0));
     wg_f4 d[6][6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-        const int iy = 4 * ty - 1 + i;
+        const int iy = M * ty - PADW + i;
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
-            const int ix = 4 * tx - 1 + j;
-            d[i][j] = ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? base[iy * W + ix] : wg_f4{0.f, 0.f, 0.f, 0.f};
+            const int ix = M * tx - PADW + j;
+            const int off = S2 ? (2 * iy + py) * Wi + 2 * ix + px : iy * W + ix;
+            d[i][j] = ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? base[off] : wg_f4{0.f, 0.f, 0.f, 0.f};
         }
     }
 #pragma unroll
     for (int j = 0; j < 6; ++j) wg_bt6(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]);
 #pragma unroll
     for (int i = 0; i < 6; ++i) wg_bt6(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5]);
-    wg_f4* out = reinterpret_cast<wg_f4*>(xh) + (size_t)g * T + t;
-    const size_t plane = (size_t)Gin * T;
+    wg_f4* out = reinterpret_cast<wg_f4*>(xh) + (size_t)gg * T + t;
+    const size_t plane = (size_t)Geff * T;
 #pragma unroll
     for (int i = 0; i < 6; ++i)
 #pragma unroll
         for (int j = 0; j < 6; ++j) out[(size_t)(i * 6 + j) * plane] = d[i][j];
 }
 
-// Yh[xi][g][t] = (A dY A^T)[xi] of the 4x4 output tile t (zero beyond the image), A = (A^T of F(4,3))^T: rows [1 0 0 0], [1 1 1 1],
-// [1 -1 1 -1], [1 2 4 8], [1 -2 4 -8], [0 0 0 1].
-__device__ __forceinline__ void wg_a6(const wg_f4 v0, const wg_f4 v1, const wg_f4 v2, const wg_f4 v3, wg_f4 (&o)[6]) {
-    const wg_f4 s02 = v0 + v2, s13 = v1 + v3, p = v0 + 4.f * v2, q = 2.f * v1 + 8.f * v3;
-    o[0] = v0; o[1] = s02 + s13; o[2] = s02 - s13; o[3] = p + q; o[4] = p - q; o[5] = v3;
+// Yh[xi][g][t] = (A dY A^T)[xi] of the M x M output tile t (zero beyond the image), A = (A^T of F(M, 7 - M))^T:
+// M = 4: rows [1 0 0 0], [1 1 1 1], [1 -1 1 -1], [1 2 4 8], [1 -2 4 -8], [0 0 0 1];  M = 3: [1 0 0], [1 1 1], [1 -1 1], [1 2 4], [1 -2 4], [0 0 1].
+template <int M>
+__device__ __forceinline__ void wg_a6(const wg_f4 (&v)[M], wg_f4 (&o)[6]) {
+    if constexpr (M == 4) {
+        const wg_f4 s02 = v[0] + v[2], s13 = v[1] + v[3], p = v[0] + 4.f * v[2], q = 2.f * v[1] + 8.f * v[3];
+        o[0] = v[0]; o[1] = s02 + s13; o[2] = s02 - s13; o[3] = p + q; o[4] = p - q; o[5] = v[3];
+    } else {
+        const wg_f4 s02 = v[0] + v[2], p = v[0] + 4.f * v[2], q = 2.f * v[1];
+        o[0] = v[0]; o[1] = s02 + v[1]; o[2] = s02 - v[1]; o[3] = p + q; o[4] = p - q; o[5] = v[2];
+    }
 }
+template <int M>
 __global__ __launch_bounds__(256) void wino_wgrad_xform_dy_kernel(const float* __restrict__ dy, int Gy_tot, int gy0, int Gout, int N, int H, int W,
                                                                   int TH, int TW, float* __restrict__ yh) {
     const int T = N * TH * TW;
@@ -271,24 +285,26 @@ __global__ __launch_bounds__(256) void wino_wgrad_xform_dy_kernel(const float* _
     const int t = (int)(idx % T), g = (int)(idx / T);
     const int n = t / (TH * TW), r = t - n * TH * TW, ty = r / TW, tx = r - ty * TW;
     const wg_f4* base = reinterpret_cast<const wg_f4*>(dy + c4_offset(n, Gy_tot, gy0 + g, H * W, 0));
-    wg_f4 c[4][6];                                                       // columns first: c[i][*] = A applied along x of row i
+    wg_f4 c[M][6];                                                       // along x first: c[i][*] = A applied to row i of the tile
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int iy = 4 * ty + i;
-        wg_f4 v[4];
+    for (int i = 0; i < M; ++i) {
+        const int iy = M * ty + i;
+        wg_f4 v[M];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int ix = 4 * tx + j;
+        for (int j = 0; j < M; ++j) {
+            const int ix = M * tx + j;
             v[j] = (iy < H && ix < W) ? base[iy * W + ix] : wg_f4{0.f, 0.f, 0.f, 0.f};
         }
-        wg_a6(v[0], v[1], v[2], v[3], c[i]);
+        wg_a6<M>(v, c[i]);
     }
     wg_f4* out = reinterpret_cast<wg_f4*>(yh) + (size_t)g * T + t;
     const size_t plane = (size_t)Gout * T;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-        wg_f4 o[6];
-        wg_a6(c[0][j], c[1][j], c[2][j], c[3][j], o);
+        wg_f4 col[M], o[6];
+#pragma unroll
+        for (int i = 0; i < M; ++i) col[i] = c[i][j];
+        wg_a6<M>(col, o);
 #pragma unroll
         for (int i = 0; i < 6; ++i) out[(size_t)(i * 6 + j) * plane] = o[i];
     }
@@ -297,7 +313,7 @@ __global__ __launch_bounds__(256) void wino_wgrad_xform_dy_kernel(const float* _
 // dU[xi][co][cp] = the sum of the `splits` partial tiles of frequency point xi (fp64 sum, one thread per element: 36 x Cout x Cp
 // threads -- a thread per (cout, channel) that walked all 36 x splits partials itself ran 4352 threads for 0.5 ms on the 64-channel
 // full-resolution layers), then dW[co][ci] = G^T dU[.][co][ci] G in fp64, scattered to OIHW.
-// partial: [36 * splits][Cout_pad][Kpad128]; u: [36][Cout][Cp].
+// partial: [36 * splits][Cout_pad][Kpad128]; u: [36][Cout][Cp] (Cp = packed input channels, x 4 phases for the stride-2 form).
 __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __restrict__ partial, int splits, int Cout, int Cout_pad, int Cp, int Kpad128,
                                                                 float* __restrict__ u) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -313,19 +329,22 @@ __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __r
 }
 
 // FUSED (few splits: the low-resolution layers): u = the partial tiles themselves, every thread sums its 36 x splits values -- one
-// launch and no 36 x Cout x Cp intermediate.
-template <bool FUSED>
+// launch and no 36 x Cout x Cp intermediate.  R = taps per axis of the (phase) filter: 3 (G of F(4,3)) or 4 (G of F(3,4)).
+// ks = 0: a 3x3 stride-1 filter.  ks = 5 / 7: the stride-2 form -- packed channel cpe = phase * Cp + cp, tap (jy, jx) of phase (py, px)
+// is w[2 jy + py - o][2 jx + px - o] (o = 0 for 5x5, 1 for 7x7), taps that leave the filter are dropped.
+template <bool FUSED, int R>
 __global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* __restrict__ u, int splits, int Cout, int Cout_pad, int Kpad128,
-                                                                int Cin, int rot, float* __restrict__ dw) {
-    const int Cp = 4 * ((Cin + 3) / 4);
+                                                                int Cin, int rot, int ks, float* __restrict__ dw) {
+    const int Cp = 4 * ((Cin + 3) / 4), Ce = ks ? 4 * Cp : Cp;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long per = (long long)Cout * Cp;
+    const long long per = (long long)Cout * Ce;
     if (idx >= per) return;
-    const int co = (int)(idx / Cp), cp = (int)(idx - (long long)co * Cp);
+    const int co = (int)(idx / Ce), cpe = (int)(idx - (long long)co * Ce);
+    const int ph = cpe / Cp, cp = cpe - ph * Cp;
     if (cp >= Cin) return;
     double uu[6][6];
     if constexpr (FUSED) {
-        const float* q = u + (size_t)co * Kpad128 + cp;
+        const float* q = u + (size_t)co * Kpad128 + cpe;
         const size_t zstride = (size_t)Cout_pad * Kpad128;
 #pragma unroll
         for (int xi = 0; xi < 36; ++xi) {
@@ -338,24 +357,28 @@ __global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* __r
         for (int xi = 0; xi < 36; ++xi) uu[xi / 6][xi % 6] = (double)u[(size_t)xi * per + idx];
     }
     constexpr double G3[6][3] = {{1. / 4, 0, 0}, {-1. / 6, -1. / 6, -1. / 6}, {-1. / 6, 1. / 6, -1. / 6}, {1. / 24, 1. / 12, 1. / 6}, {1. / 24, -1. / 12, 1. / 6}, {0, 0, 1}};
-    float* o = dw + ((size_t)co * Cin + (cp + rot) % Cin) * 9;
+    constexpr double G4[6][4] = {{1. / 4, 0, 0, 0}, {-1. / 6, -1. / 6, -1. / 6, -1. / 6}, {-1. / 6, 1. / 6, -1. / 6, 1. / 6},
+                                 {1. / 24, 1. / 12, 1. / 6, 1. / 3}, {1. / 24, -1. / 12, 1. / 6, -1. / 3}, {0, 0, 0, 1}};
+    const int K = ks ? ks : 3, py = ph >> 1, px = ph & 1, o_ = ks == 7 ? 1 : 0;
+    float* o = dw + ((size_t)co * Cin + (cp + rot) % Cin) * (K * K);
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < R; ++p)
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
+        for (int r = 0; r < R; ++r) {
             double s = 0.0;
 #pragma unroll
             for (int a = 0; a < 6; ++a)
 #pragma unroll
-                for (int b = 0; b < 6; ++b) s += G3[a][p] * uu[a][b] * G3[b][r];
-            o[p * 3 + r] = (float)s;
+                for (int b = 0; b < 6; ++b) s += (R == 3 ? G3[a][p] * G3[b][r] : G4[a][p] * G4[b][r]) * uu[a][b];
+            const int ky = ks ? 2 * p + py - o_ : p, kx = ks ? 2 * r + px - o_ : r;
+            if (ky >= 0 && ky < K && kx >= 0 && kx < K) o[ky * K + kx] = (float)s;
         }
 }
 
-static void wino_wgrad_plan(int Cout, int Cin, int T, int* Cout_pad, int* Kpad128, int* splits, int* pps) {
+static void wino_wgrad_plan(int Cout, int Ceff, int T, int* Cout_pad, int* Kpad128, int* splits, int* pps) {   // Ceff = packed input channels (x 4 phases)
     const int tco = wgrad_tco(Cout);
     *Cout_pad = wg_round(Cout, tco);
-    *Kpad128 = wg_round(4 * ((Cin + 3) / 4), 128);
+    *Kpad128 = wg_round(Ceff, 128);
     const int tiles = 36 * (*Cout_pad / tco) * (*Kpad128 / 128);
     int s = (CNM_WGRAD_WORKGROUPS + tiles - 1) / tiles;
     const int maxs = (T + 255) / 256;                                    // at least 256 tiles per split
@@ -365,50 +388,88 @@ static void wino_wgrad_plan(int Cout, int Cin, int T, int* Cout_pad, int* Kpad12
     *splits = (T + *pps - 1) / *pps;
 }
 
-extern "C" size_t cnm_conv3x3_wgrad_winograd_workspace_floats(int Cout, int Cin, int N, int H, int W) {
+// ks = 3: stride 1 (H, W = image size).  ks = 5 / 7: stride 2 on the pixel phases (H, W = INPUT size, even).
+static size_t wino_wgrad_ws(int Cout, int Cin, int N, int H, int W, int ks) {
     if (Cout <= 0 || Cin <= 0 || N <= 0 || H <= 0 || W <= 0) return 0;
-    const size_t T = (size_t)N * ((H + 3) / 4) * ((W + 3) / 4);
+    const int M = ks == 7 ? 3 : 4, Ho = ks == 3 ? H : H / 2, Wo = ks == 3 ? W : W / 2, ph = ks == 3 ? 1 : 4;
+    const size_t T = (size_t)N * ((Ho + M - 1) / M) * ((Wo + M - 1) / M);
+    const int Ceff = ph * 4 * ((Cin + 3) / 4);
     int cp, kp, sp, pps;
-    wino_wgrad_plan(Cout, Cin, (int)T, &cp, &kp, &sp, &pps);
-    return 36 * T * 4 * (size_t)((Cin + 3) / 4) + 36 * T * 4 * (size_t)((Cout + 3) / 4) + (size_t)36 * sp * cp * kp + (size_t)36 * Cout * 4 * ((Cin + 3) / 4);
+    wino_wgrad_plan(Cout, Ceff, (int)T, &cp, &kp, &sp, &pps);
+    return 36 * T * (size_t)Ceff + 36 * T * 4 * (size_t)((Cout + 3) / 4) + (size_t)36 * sp * cp * kp + (size_t)36 * Cout * Ceff;
 }
+
+static int wino_wgrad(const float* x, int Gx_total, int gx0, int Cin, const float* dy, int Gy_total, int gy0, int Cout,
+                      float* dw_oihw, float* ws, size_t ws_floats, int N, int H, int W, int ks, int rot, void* stream) {
+    CNM_REQUIRE(x && dy && dw_oihw && ws && N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cout % 4 == 0 && rot >= 0 && rot < Cin, CNM_ERR_BAD_ARG);
+    CNM_REQUIRE(ks == 3 || ((ks == 5 || ks == 7) && H % 2 == 0 && W % 2 == 0), CNM_ERR_BAD_ARG);
+    const bool s2 = ks != 3;
+    const int M = ks == 7 ? 3 : 4, Ho = s2 ? H / 2 : H, Wo = s2 ? W / 2 : W;
+    const int Gin = (Cin + 3) / 4, Geff = (s2 ? 4 : 1) * Gin, Gout = Cout / 4, TH = (Ho + M - 1) / M, TW = (Wo + M - 1) / M;
+    const long long Tll = (long long)N * TH * TW;
+    CNM_REQUIRE(gx0 >= 0 && gx0 + Gin <= Gx_total && gy0 >= 0 && gy0 + Gout <= Gy_total && Tll < (1ll << 24), CNM_ERR_BAD_ARG);
+    const int T = (int)Tll;
+    CNM_REQUIRE(wino_wgrad_ws(Cout, Cin, N, H, W, ks) <= ws_floats, CNM_ERR_WORKSPACE);
+    float* xh = ws; float* yh = xh + (size_t)36 * T * 4 * Geff; float* partial = yh + (size_t)36 * T * 4 * Gout;
+    const unsigned long long xb = 36ull * T * Geff * 16ull, yb = 36ull * T * Gout * 16ull;
+    CNM_REQUIRE(xb < 0xFFFFFFFFull && yb < 0xFFFFFFFFull, CNM_ERR_BAD_ARG);
+    hipStream_t s = cnm_stream(stream);
+    const unsigned nbx = (unsigned)cnm_ceil_div_ll((long long)T * Geff, 256), nby = (unsigned)cnm_ceil_div_ll((long long)T * Gout, 256);
+    if (ks == 3) wino_wgrad_xform_x_kernel<4, false><<<nbx, 256, 0, s>>>(x, Gx_total, gx0, Gin, N, Ho, Wo, TH, TW, xh);
+    else if (ks == 5) wino_wgrad_xform_x_kernel<4, true><<<nbx, 256, 0, s>>>(x, Gx_total, gx0, Gin, N, Ho, Wo, TH, TW, xh);
+    else wino_wgrad_xform_x_kernel<3, true><<<nbx, 256, 0, s>>>(x, Gx_total, gx0, Gin, N, Ho, Wo, TH, TW, xh);
+    if (M == 4) wino_wgrad_xform_dy_kernel<4><<<nby, 256, 0, s>>>(dy, Gy_total, gy0, Gout, N, Ho, Wo, TH, TW, yh);
+    else wino_wgrad_xform_dy_kernel<3><<<nby, 256, 0, s>>>(dy, Gy_total, gy0, Gout, N, Ho, Wo, TH, TW, yh);
+    WgradArgs a;
+    a.x = xh; a.dy = yh; a.partial = partial; a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)yb;
+    a.N = 36; a.H = 1; a.W = T; a.Ho = 1; a.Wo = T; a.ks = 1; a.stride = 1; a.pad = 0;
+    a.Gx_tot = Geff; a.gx0 = 0; a.Gin = Geff; a.Gy_tot = Gout; a.gy0 = 0; a.Cout = Cout;
+    a.Kflat = 4 * Geff; a.M = T;
+    int splits;
+    wino_wgrad_plan(Cout, 4 * Geff, T, &a.Cout_pad, &a.Kpad128, &splits, &a.pix_per_split);
+    a.per_image_splits = splits;
+    if (wgrad_tco(Cout) == 128) conv_wgrad_kernel<128><<<dim3(a.Cout_pad / 128, a.Kpad128 / 128, 36 * splits), 256, 0, s>>>(a);
+    else conv_wgrad_kernel<64><<<dim3(a.Cout_pad / 64, a.Kpad128 / 128, 36 * splits), 256, 0, s>>>(a);
+    const unsigned nfin = (unsigned)cnm_ceil_div_ll((long long)Cout * 4 * Geff, 256);
+    const int fks = s2 ? ks : 0;
+    const float* src = partial;
+    if (splits > 4) {
+        float* u = partial + (size_t)36 * splits * a.Cout_pad * a.Kpad128;
+        wino_wgrad_reduce_kernel<<<(unsigned)cnm_ceil_div_ll(36ll * Cout * 4 * Geff, 256), 256, 0, s>>>(partial, splits, Cout, a.Cout_pad, 4 * Geff, a.Kpad128, u);
+        src = u;
+    }
+    if (splits > 4) {
+        if (M == 4) wino_wgrad_finish_kernel<false, 3><<<nfin, 256, 0, s>>>(src, splits, Cout, a.Cout_pad, a.Kpad128, Cin, rot, fks, dw_oihw);
+        else wino_wgrad_finish_kernel<false, 4><<<nfin, 256, 0, s>>>(src, splits, Cout, a.Cout_pad, a.Kpad128, Cin, rot, fks, dw_oihw);
+    } else {
+        if (M == 4) wino_wgrad_finish_kernel<true, 3><<<nfin, 256, 0, s>>>(src, splits, Cout, a.Cout_pad, a.Kpad128, Cin, rot, fks, dw_oihw);
+        else wino_wgrad_finish_kernel<true, 4><<<nfin, 256, 0, s>>>(src, splits, Cout, a.Cout_pad, a.Kpad128, Cin, rot, fks, dw_oihw);
+    }
+    CNM_LAUNCH_CHECK();
+    return CNM_OK;
+}
+
+extern "C" size_t cnm_conv3x3_wgrad_winograd_workspace_floats(int Cout, int Cin, int N, int H, int W) { return wino_wgrad_ws(Cout, Cin, N, H, W, 3); }
 
 extern "C" int cnm_conv3x3_wgrad_winograd_c4_f32(const float* x, int Gx_total, int gx0, int Cin,
                                                  const float* dy, int Gy_total, int gy0, int Cout,
                                                  float* dw_oihw, float* ws, size_t ws_floats,
                                                  int N, int H, int W, int rot, void* stream) {
-    CNM_REQUIRE(x && dy && dw_oihw && ws && N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cout % 4 == 0 && rot >= 0 && rot < Cin, CNM_ERR_BAD_ARG);
-    const int Gin = (Cin + 3) / 4, Gout = Cout / 4, TH = (H + 3) / 4, TW = (W + 3) / 4;
-    const long long Tll = (long long)N * TH * TW;
-    CNM_REQUIRE(gx0 >= 0 && gx0 + Gin <= Gx_total && gy0 >= 0 && gy0 + Gout <= Gy_total && Tll < (1ll << 24), CNM_ERR_BAD_ARG);
-    const int T = (int)Tll;
-    CNM_REQUIRE(cnm_conv3x3_wgrad_winograd_workspace_floats(Cout, Cin, N, H, W) <= ws_floats, CNM_ERR_WORKSPACE);
-    float* xh = ws; float* yh = xh + (size_t)36 * T * 4 * Gin; float* partial = yh + (size_t)36 * T * 4 * Gout;
-    const unsigned long long xb = 36ull * T * Gin * 16ull, yb = 36ull * T * Gout * 16ull;
-    CNM_REQUIRE(xb < 0xFFFFFFFFull && yb < 0xFFFFFFFFull, CNM_ERR_BAD_ARG);
-    hipStream_t s = cnm_stream(stream);
-    wino_wgrad_xform_x_kernel<<<(unsigned)cnm_ceil_div_ll((long long)T * Gin, 256), 256, 0, s>>>(x, Gx_total, gx0, Gin, N, H, W, TH, TW, xh);
-    wino_wgrad_xform_dy_kernel<<<(unsigned)cnm_ceil_div_ll((long long)T * Gout, 256), 256, 0, s>>>(dy, Gy_total, gy0, Gout, N, H, W, TH, TW, yh);
-    WgradArgs a;
-    a.x = xh; a.dy = yh; a.partial = partial; a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)yb;
-    a.N = 36; a.H = 1; a.W = T; a.Ho = 1; a.Wo = T; a.ks = 1; a.stride = 1; a.pad = 0;
-    a.Gx_tot = Gin; a.gx0 = 0; a.Gin = Gin; a.Gy_tot = Gout; a.gy0 = 0; a.Cout = Cout;
-    a.Kflat = 4 * Gin; a.M = T;
-    int splits;
-    wino_wgrad_plan(Cout, Cin, T, &a.Cout_pad, &a.Kpad128, &splits, &a.pix_per_split);
-    a.per_image_splits = splits;
-    if (wgrad_tco(Cout) == 128) conv_wgrad_kernel<128><<<dim3(a.Cout_pad / 128, a.Kpad128 / 128, 36 * splits), 256, 0, s>>>(a);
-    else conv_wgrad_kernel<64><<<dim3(a.Cout_pad / 64, a.Kpad128 / 128, 36 * splits), 256, 0, s>>>(a);
-    const unsigned nfin = (unsigned)cnm_ceil_div_ll((long long)Cout * 4 * Gin, 256);
-    if (splits <= 4) {
-        wino_wgrad_finish_kernel<true><<<nfin, 256, 0, s>>>(partial, splits, Cout, a.Cout_pad, a.Kpad128, Cin, rot, dw_oihw);
-    } else {
-        float* u = partial + (size_t)36 * splits * a.Cout_pad * a.Kpad128;
-        wino_wgrad_reduce_kernel<<<(unsigned)cnm_ceil_div_ll(36ll * Cout * 4 * Gin, 256), 256, 0, s>>>(partial, splits, Cout, a.Cout_pad, 4 * Gin, a.Kpad128, u);
-        wino_wgrad_finish_kernel<false><<<nfin, 256, 0, s>>>(u, splits, Cout, a.Cout_pad, a.Kpad128, Cin, rot, dw_oihw);
-    }
-    CNM_LAUNCH_CHECK();
-    return CNM_OK;
+    return wino_wgrad(x, Gx_total, gx0, Cin, dy, Gy_total, gy0, Cout, dw_oihw, ws, ws_floats, N, H, W, 3, rot, stream);
+}
+
+// The stride-2 5x5 / 7x7 layers: the same on the four pixel phases of x (F(4x4,3x3) / F(3x3,4x4) of the 3x3 / 4x4 phase filters, as the
+// forward of conv_winograd4s.hip): dY is transformed once, X per phase as 4*Cin channels; H, W = INPUT size (even).
+extern "C" size_t cnm_conv_s2_wgrad_winograd_workspace_floats(int Cout, int Cin, int ksize, int N, int H, int W) {
+    return (ksize == 5 || ksize == 7) && H % 2 == 0 && W % 2 == 0 ? wino_wgrad_ws(Cout, Cin, N, H, W, ksize) : 0;
+}
+
+extern "C" int cnm_conv_s2_wgrad_winograd_c4_f32(const float* x, int Gx_total, int gx0, int Cin,
+                                                 const float* dy, int Gy_total, int gy0, int Cout,
+                                                 float* dw_oihw, float* ws, size_t ws_floats,
+                                                 int N, int H, int W, int ksize, int rot, void* stream) {
+    CNM_REQUIRE(ksize == 5 || ksize == 7, CNM_ERR_BAD_ARG);
+    return wino_wgrad(x, Gx_total, gx0, Cin, dy, Gy_total, gy0, Cout, dw_oihw, ws, ws_floats, N, H, W, ksize, rot, stream);
 }
 
 // ------------------------------------------------------------------ BatchNorm2d (train mode) + ReLU on c4

@@ -503,6 +503,13 @@ size_t cnm_conv2d_wgrad_workspace_floats(int Cout, int Cin, int ksize, int N, in
  * cnm_conv2d_wgrad_c4_f32 without ksize / stride; ws of cnm_conv3x3_wgrad_winograd_workspace_floats floats (transformed X and
  * dY + partial tiles). */
 size_t cnm_conv3x3_wgrad_winograd_workspace_floats(int Cout, int Cin, int N, int H, int W);
+/* ... and of the stride-2 5x5 / 7x7 layers on the four pixel phases of x (3x3 / 4x4 phase filters, F(4x4,3x3) / F(3x3,4x4), as
+ * cnm_conv_s2_winograd4_sync_c4_f32 runs the forward): dY transformed once, X per phase as 4*Cin channels.  H, W (even) = INPUT size. */
+size_t cnm_conv_s2_wgrad_winograd_workspace_floats(int Cout, int Cin, int ksize, int N, int H, int W);
+int cnm_conv_s2_wgrad_winograd_c4_f32(const float* x, int Gx_total, int gx0, int Cin,
+                                      const float* dy, int Gy_total, int gy0, int Cout,
+                                      float* dw_oihw, float* ws, size_t ws_floats,
+                                      int N, int H, int W, int ksize, int rot, void* stream);
 int cnm_conv3x3_wgrad_winograd_c4_f32(const float* x, int Gx_total, int gx0, int Cin,
                                       const float* dy, int Gy_total, int gy0, int Cout,
                                       float* dw_oihw, float* ws, size_t ws_floats,

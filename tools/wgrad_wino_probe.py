@@ -42,3 +42,16 @@ for name, cin, cout, N, H, W, mult in (("iconv1", 65, 64, 4, 192, 256, 2), ("upc
     tot_d += td * mult; tot_w += tw * mult
     print("%-15s %4d->%4d %3dx%-3d N%d: direct %.3f ms  winograd %.3f ms  %.2fx   ws %5.0f MB   %s" % (name, cin, cout, H, W, N, td, tw, td / tw, wsw.numel() * 4 / 1e6, err), flush=True)
 print("weighted by launches per step: direct %.2f ms, winograd %.2f ms" % (tot_d, tot_w))
+for name, k, cin, cout, N, H, W in (("conv2.3", 5, 256, 256, 4, 96, 128), ("conv1.3", 7, 128, 128, 4, 192, 256), ("conv2.3 small", 5, 64, 128, 2, 24, 40), ("conv1.3 small", 7, 35, 64, 1, 26, 38)):
+    G = (cin + 3) // 4
+    x = torch.randn(N, cin, H, W, device=dev); dy = torch.randn(N, cout, H // 2, W // 2, device=dev)
+    xc, dyc = ops.nchw_to_c4(x), ops.nchw_to_c4(dy)
+    dwd, dww = torch.empty(cout, cin, k, k, device=dev), torch.full((cout, cin, k, k), 7.0, device=dev)
+    wsd = torch.empty(lib.cnm_conv2d_wgrad_workspace_floats(cout, cin, k, N, H // 2, W // 2), device=dev)
+    wsw = torch.empty(lib.cnm_conv_s2_wgrad_winograd_workspace_floats(cout, cin, k, N, H, W), device=dev)
+    fd = lambda: _lib.check(lib.cnm_conv2d_wgrad_c4_f32(xc.data_ptr(), G, 0, cin, dyc.data_ptr(), cout // 4, 0, cout, dwd.data_ptr(), wsd.data_ptr(), wsd.numel(), N, H, W, k, 2, 0, st()))
+    fw = lambda: _lib.check(lib.cnm_conv_s2_wgrad_winograd_c4_f32(xc.data_ptr(), G, 0, cin, dyc.data_ptr(), cout // 4, 0, cout, dww.data_ptr(), wsw.data_ptr(), wsw.numel(), N, H, W, k, 0, st()))
+    fd(); fw(); torch.cuda.synchronize()
+    ref = torch.nn.grad.conv2d_weight(x.double(), (cout, cin, k, k), dy.double(), stride=2, padding=k // 2)
+    rel = lambda a_: float((a_.double() - ref).norm() / ref.norm())
+    print("%-15s %dx%d s2 %4d->%4d %3dx%-3d N%d: direct %.3f ms  winograd %.3f ms  %.2fx   rel L2: direct %.1e  winograd %.1e" % (name, k, k, cin, cout, H, W, N, ms(fd), ms(fw), ms(fd) / ms(fw), rel(dwd), rel(dww)), flush=True)
