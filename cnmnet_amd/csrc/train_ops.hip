@@ -23,8 +23,10 @@ struct WgradArgs {
     unsigned x_bytes, dy_bytes;
     int N, H, W, Ho, Wo, Gx_tot, gx0, Gin, Gy_tot, gy0, Cout, Cout_pad;
     int ks, stride, pad, Kflat, Kpad128, M, pix_per_split;
-    int per_image_splits;           // 0: one reduction over all N*Ho*Wo pixels, split by grid.z.  s > 0: grid.z = image * s + split -- every image is a
-};                                  // problem of its own (the 36 frequency points of the Winograd-domain gradient below), M = Ho*Wo
+    int per_image_splits;           // 0: one reduction over all N*Ho*Wo pixels, split by grid.z.  s > 0: grid.z = problem * s + split -- every group of
+                                    // `ipp` images is a problem of its own (the frequency points of the Winograd-domain gradients below), M = ipp*Ho*Wo
+    int ipp, ksx, padx;             // images per problem; taps / padding along x (ks, pad: along y) -- the direct gradient has ksx = ks, padx = pad
+};
 
 // TCO = couts per workgroup: 128 (waves 2 x 2, 64 x 64 each) or 64 (waves 1 x 4, 64 couts x 32 k each) for the 64-cout
 // layers, where a 128-row tile would spend half of its MFMAs on padding rows.
@@ -50,11 +52,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
         aq[i] = c0 / 4 + q; aok[i] = 4 * q < TCO && (c0 + 4 * q) < a.Cout;
         const int kq = k0 / 4 + q;                                  // flat k-quad -> (tap, channel group): fixed per thread
         const int tap = kq / a.Gin;
-        bgc[i] = kq - tap * a.Gin; bky[i] = tap / a.ks; bkx[i] = tap - bky[i] * a.ks;
-        bok[i] = tap < a.ks * a.ks;
+        bgc[i] = kq - tap * a.Gin; bky[i] = tap / a.ksx; bkx[i] = tap - bky[i] * a.ksx;
+        bok[i] = tap < a.ks * a.ksx;
     }
     // running output-pixel coordinate of this thread's pixel lane
-    int m = r0 + pl, img = a.per_image_splits ? zimg : m / HoWo, rem = a.per_image_splits ? m : m - img * HoWo, oy = rem / a.Wo, ox = rem - oy * a.Wo;
+    int m = r0 + pl, img = m / HoWo, rem = m - img * HoWo, oy = rem / a.Wo, ox = rem - oy * a.Wo;
+    img += zimg * a.ipp;
 
     f32x16 acc[2][PJ];
 #pragma unroll
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
         for (int i = 0; i < 2; ++i) {
             const unsigned offa = (mok && aok[i]) ? ((unsigned)((img * a.Gy_tot + a.gy0 + aq[i]) * HoWo + rem)) * 16u : 0xFFFFFFFFu;
             ra[i] = tr_buffer_load_f4(a.dy, a.dy_bytes, offa);
-            const int iy = oy * a.stride - a.pad + bky[i], ix = ox * a.stride - a.pad + bkx[i];
+            const int iy = oy * a.stride - a.pad + bky[i], ix = ox * a.stride - a.padx + bkx[i];
             const bool ok = mok && bok[i] && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
             const unsigned offb = ok ? ((unsigned)((img * a.Gx_tot + a.gx0 + bgc[i]) * HW + iy * a.W + ix)) * 16u : 0xFFFFFFFFu;
             rb[i] = tr_buffer_load_f4(a.x, a.x_bytes, offb);
@@ -194,7 +197,7 @@ extern "C" int cnm_conv2d_wgrad_c4_f32(const float* x, int Gx_total, int gx0, in
     a.Kflat = ksize * ksize * 4 * a.Gin; a.M = N * a.Ho * a.Wo;
     int splits;
     wgrad_plan(Cout, Cin, ksize, a.M, &a.Cout_pad, &a.Kpad128, &splits, &a.pix_per_split);
-    a.per_image_splits = 0;
+    a.per_image_splits = 0; a.ipp = 1; a.ksx = a.ks; a.padx = a.pad;
     CNM_REQUIRE((size_t)splits * a.Cout_pad * a.Kpad128 <= ws_floats, CNM_ERR_WORKSPACE);
     const unsigned long long xb = (unsigned long long)N * Gx_total * H * W * 16ull, yb = (unsigned long long)N * Gy_total * a.Ho * a.Wo * 16ull;
     CNM_REQUIRE(xb < 0xFFFFFFFFull && yb < 0xFFFFFFFFull, CNM_ERR_BAD_ARG);
@@ -315,10 +318,10 @@ __global__ __launch_bounds__(256) void wino_wgrad_xform_dy_kernel(const float* _
 // full-resolution layers), then dW[co][ci] = G^T dU[.][co][ci] G in fp64, scattered to OIHW.
 // partial: [36 * splits][Cout_pad][Kpad128]; u: [36][Cout][Cp] (Cp = packed input channels, x 4 phases for the stride-2 form).
 __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __restrict__ partial, int splits, int Cout, int Cout_pad, int Cp, int Kpad128,
-                                                                float* __restrict__ u) {
+                                                                float* __restrict__ u, int npts = 36) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long per = (long long)Cout * Cp;
-    if (idx >= 36 * per) return;
+    if (idx >= npts * per) return;
     const int xi = (int)(idx / per); const long long r = idx - xi * per;
     const int co = (int)(r / Cp), cp = (int)(r - (long long)co * Cp);
     const float* q = partial + (size_t)xi * splits * Cout_pad * Kpad128 + (size_t)co * Kpad128 + cp;
@@ -427,7 +430,7 @@ static int wino_wgrad(const float* x, int Gx_total, int gx0, int Cin, const floa
     a.Kflat = 4 * Geff; a.M = T;
     int splits;
     wino_wgrad_plan(Cout, 4 * Geff, T, &a.Cout_pad, &a.Kpad128, &splits, &a.pix_per_split);
-    a.per_image_splits = splits;
+    a.per_image_splits = splits; a.ipp = 1; a.ksx = 1; a.padx = 0;
     if (wgrad_tco(Cout) == 128) conv_wgrad_kernel<128><<<dim3(a.Cout_pad / 128, a.Kpad128 / 128, 36 * splits), 256, 0, s>>>(a);
     else conv_wgrad_kernel<64><<<dim3(a.Cout_pad / 64, a.Kpad128 / 128, 36 * splits), 256, 0, s>>>(a);
     const unsigned nfin = (unsigned)cnm_ceil_div_ll((long long)Cout * 4 * Geff, 256);
@@ -470,6 +473,136 @@ extern "C" int cnm_conv_s2_wgrad_winograd_c4_f32(const float* x, int Gx_total, i
                                                  int N, int H, int W, int ksize, int rot, void* stream) {
     CNM_REQUIRE(ksize == 5 || ksize == 7, CNM_ERR_BAD_ARG);
     return wino_wgrad(x, Gx_total, gx0, Cin, dy, Gy_total, gy0, Cout, dw_oihw, ws, ws_floats, N, H, W, ksize, rot, stream);
+}
+
+// ------------------------------------------------------------------ ... and of the 7x7 stride-1 layer (conv1.0), row-wise F(4,7)
+// The forward's own algorithm (conv_winograd_rows.hip: Winograd along image rows, the seven kernel rows stay in the reduction):
+//     dW[co][ci][ky][.] = G^T sum_{n, y, t} (A dY[co][n][y][4t .. 4t+3]) (.) (B^T X[ci][n][y + ky - 3][4t - 3 .. 4t + 6])
+// -- ten frequency points, each a weight gradient with 7 x 1 taps on [N][H][W/4] "images": 17.5 multiplies per pixel instead of 49.
+// Tables: RowWino<74> of conv_winograd_rows.hip (tools/wino1d_matrices.py, points 0, +-1, +-2, +-1/2, +-3/2, inf).
+__device__ __constant__ float kWg47BT[10][10] = {
+    {9. / 4, 0, -205. / 16, 0, 273. / 16, 0, -15. / 2, 0, 1, 0},
+    {0, -9. / 4, -9. / 4, 169. / 16, 169. / 16, -13. / 2, -13. / 2, 1, 1, 0}, {0, 9. / 4, -9. / 4, -169. / 16, 169. / 16, 13. / 2, -13. / 2, -1, 1, 0},
+    {0, -9. / 8, -9. / 16, 49. / 8, 49. / 16, -7, -7. / 2, 2, 1, 0}, {0, 9. / 8, -9. / 16, -49. / 8, 49. / 16, 7, -7. / 2, -2, 1, 0},
+    {0, -9. / 2, -9, 61. / 8, 61. / 4, -29. / 8, -29. / 4, 1. / 2, 1, 0}, {0, 9. / 2, -9, -61. / 8, 61. / 4, 29. / 8, -29. / 4, -1. / 2, 1, 0},
+    {0, -3. / 2, -1, 63. / 8, 21. / 4, -63. / 8, -21. / 4, 3. / 2, 1, 0}, {0, 3. / 2, -1, -63. / 8, 21. / 4, 63. / 8, -21. / 4, -3. / 2, 1, 0},
+    {0, 9. / 4, 0, -205. / 16, 0, 273. / 16, 0, -15. / 2, 0, 1}};
+__device__ __constant__ float kWg47A[10][4] = {{1, 0, 0, 0}, {1, 1, 1, 1}, {1, -1, 1, -1}, {1, 2, 4, 8}, {1, -2, 4, -8}, {1, 1. / 2, 1. / 4, 1. / 8},
+                                               {1, -1. / 2, 1. / 4, -1. / 8}, {1, 3. / 2, 9. / 4, 27. / 8}, {1, -3. / 2, 9. / 4, -27. / 8}, {0, 0, 0, 1}};
+__device__ __constant__ double kWg47G[10][7] = {
+    {4. / 9, 0, 0, 0, 0, 0, 0},
+    {8. / 45, 8. / 45, 8. / 45, 8. / 45, 8. / 45, 8. / 45, 8. / 45}, {8. / 45, -8. / 45, 8. / 45, -8. / 45, 8. / 45, -8. / 45, 8. / 45},
+    {2. / 315, 4. / 315, 8. / 315, 16. / 315, 32. / 315, 64. / 315, 128. / 315}, {2. / 315, -4. / 315, 8. / 315, -16. / 315, 32. / 315, -64. / 315, 128. / 315},
+    {-16. / 45, -8. / 45, -4. / 45, -2. / 45, -1. / 45, -1. / 90, -1. / 180}, {-16. / 45, 8. / 45, -4. / 45, 2. / 45, -1. / 45, 1. / 90, -1. / 180},
+    {-16. / 315, -8. / 105, -4. / 35, -6. / 35, -9. / 35, -27. / 70, -81. / 140}, {-16. / 315, 8. / 105, -4. / 35, 6. / 35, -9. / 35, 27. / 70, -81. / 140},
+    {0, 0, 0, 0, 0, 0, 1}};
+
+// out[(xi * N + n)][g][y][t] = sum_j Mx[xi][j] in[n][g][y][4 t - off + j]: DY: Mx = A (4 pixels of the tile), else Mx = B^T (the 10-pixel window, off = 3).
+// One thread per (tile, row, image, group), tiles fastest.
+template <bool DY>
+__global__ __launch_bounds__(256) void wino_wgrad_rows_xform_kernel(const float* __restrict__ in, int G_tot, int g0, int G, int N, int H, int W, int TW,
+                                                                    float* __restrict__ out) {
+    constexpr int NL = DY ? 4 : 10, OFF = DY ? 0 : 3;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)TW * H * N * G;
+    if (idx >= total) return;
+    const int t = (int)(idx % TW); long long r = idx / TW;
+    const int y = (int)(r % H); r /= H;
+    const int n = (int)(r % N), g = (int)(r / N);
+    const wg_f4* row = reinterpret_cast<const wg_f4*>(in + c4_offset(n, G_tot, g0 + g, H * W, y * W));
+    wg_f4 v[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+        const int ix = 4 * t - OFF + j;
+        v[j] = (unsigned)ix < (unsigned)W ? row[ix] : wg_f4{0.f, 0.f, 0.f, 0.f};
+    }
+    const size_t plane = (size_t)N * G * H * TW;                          // float4 elements per frequency point
+    wg_f4* o = reinterpret_cast<wg_f4*>(out) + ((size_t)(n * G + g) * H + y) * TW + t;
+#pragma unroll
+    for (int xi = 0; xi < 10; ++xi) {
+        wg_f4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const float c = DY ? kWg47A[xi][j] : kWg47BT[xi][j];
+            if (c != 0.f) s += c * v[j];
+        }
+        o[(size_t)xi * plane] = s;
+    }
+}
+
+// dW[co][ci][ky][kx] = sum_xi G[xi][kx] dU[xi][co][ky * Cp + cp]   (u: [10][Cout][7 * Cp], split sums done by wino_wgrad_reduce_kernel)
+__global__ __launch_bounds__(256) void wino_wgrad_rows_finish_kernel(const float* __restrict__ u, int Cout, int Cin, int rot, float* __restrict__ dw) {
+    const int Cp = 4 * ((Cin + 3) / 4), K7 = 7 * Cp;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long per = (long long)Cout * K7;
+    if (idx >= per) return;
+    const int co = (int)(idx / K7), k = (int)(idx - (long long)co * K7), ky = k / Cp, cp = k - ky * Cp;
+    if (cp >= Cin) return;
+    double uu[10];
+#pragma unroll
+    for (int xi = 0; xi < 10; ++xi) uu[xi] = (double)u[(size_t)xi * per + idx];
+    float* o = dw + (((size_t)co * Cin + (cp + rot) % Cin) * 7 + ky) * 7;
+#pragma unroll
+    for (int kx = 0; kx < 7; ++kx) {
+        double s = 0.0;
+#pragma unroll
+        for (int xi = 0; xi < 10; ++xi) s += kWg47G[xi][kx] * uu[xi];
+        o[kx] = (float)s;
+    }
+}
+
+static void wino_rows_plan(int Cout, int Cin, long long Mpix, int* Cout_pad, int* Kpad128, int* splits, int* pps) {
+    const int tco = wgrad_tco(Cout);
+    *Cout_pad = wg_round(Cout, tco);
+    *Kpad128 = wg_round(7 * 4 * ((Cin + 3) / 4), 128);
+    const int tiles = 10 * (*Cout_pad / tco) * (*Kpad128 / 128);
+    int s = (CNM_WGRAD_WORKGROUPS + tiles - 1) / tiles;
+    const int maxs = (int)((Mpix + 255) / 256);
+    if (s > maxs) s = maxs;
+    if (s < 1) s = 1;
+    *pps = wg_round((int)((Mpix + s - 1) / s), 16);
+    *splits = (int)((Mpix + *pps - 1) / *pps);
+}
+
+extern "C" size_t cnm_conv7x7_wgrad_winograd_workspace_floats(int Cout, int Cin, int N, int H, int W) {
+    if (Cout <= 0 || Cin <= 0 || N <= 0 || H <= 0 || W <= 0) return 0;
+    const size_t TW = (size_t)(W + 3) / 4, P = (size_t)N * H * TW;
+    int cp, kp, sp, pps;
+    wino_rows_plan(Cout, Cin, (long long)P, &cp, &kp, &sp, &pps);
+    return 10 * P * 4 * (size_t)((Cin + 3) / 4) + 10 * P * 4 * (size_t)((Cout + 3) / 4) + (size_t)10 * sp * cp * kp + (size_t)10 * Cout * 7 * 4 * ((Cin + 3) / 4);
+}
+
+extern "C" int cnm_conv7x7_wgrad_winograd_c4_f32(const float* x, int Gx_total, int gx0, int Cin,
+                                                 const float* dy, int Gy_total, int gy0, int Cout,
+                                                 float* dw_oihw, float* ws, size_t ws_floats,
+                                                 int N, int H, int W, int rot, void* stream) {
+    CNM_REQUIRE(x && dy && dw_oihw && ws && N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cout % 4 == 0 && rot >= 0 && rot < Cin, CNM_ERR_BAD_ARG);
+    const int Gin = (Cin + 3) / 4, Gout = Cout / 4, TW = (W + 3) / 4;
+    const long long P = (long long)N * H * TW;
+    CNM_REQUIRE(gx0 >= 0 && gx0 + Gin <= Gx_total && gy0 >= 0 && gy0 + Gout <= Gy_total && P < (1ll << 24), CNM_ERR_BAD_ARG);
+    CNM_REQUIRE(cnm_conv7x7_wgrad_winograd_workspace_floats(Cout, Cin, N, H, W) <= ws_floats, CNM_ERR_WORKSPACE);
+    float* xh = ws; float* yh = xh + (size_t)10 * P * 4 * Gin; float* partial = yh + (size_t)10 * P * 4 * Gout;
+    const unsigned long long xb = 10ull * P * Gin * 16ull, yb = 10ull * P * Gout * 16ull;
+    CNM_REQUIRE(xb < 0xFFFFFFFFull && yb < 0xFFFFFFFFull, CNM_ERR_BAD_ARG);
+    hipStream_t s = cnm_stream(stream);
+    wino_wgrad_rows_xform_kernel<false><<<(unsigned)cnm_ceil_div_ll(P * Gin, 256), 256, 0, s>>>(x, Gx_total, gx0, Gin, N, H, W, TW, xh);
+    wino_wgrad_rows_xform_kernel<true><<<(unsigned)cnm_ceil_div_ll(P * Gout, 256), 256, 0, s>>>(dy, Gy_total, gy0, Gout, N, H, W, TW, yh);
+    WgradArgs a;
+    a.x = xh; a.dy = yh; a.partial = partial; a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)yb;
+    a.N = 10 * N; a.H = H; a.W = TW; a.Ho = H; a.Wo = TW; a.ks = 7; a.stride = 1; a.pad = 3; a.ksx = 1; a.padx = 0; a.ipp = N;
+    a.Gx_tot = Gin; a.gx0 = 0; a.Gin = Gin; a.Gy_tot = Gout; a.gy0 = 0; a.Cout = Cout;
+    a.Kflat = 7 * 4 * Gin; a.M = (int)P;
+    int splits;
+    wino_rows_plan(Cout, Cin, P, &a.Cout_pad, &a.Kpad128, &splits, &a.pix_per_split);
+    a.per_image_splits = splits;
+    if (wgrad_tco(Cout) == 128) conv_wgrad_kernel<128><<<dim3(a.Cout_pad / 128, a.Kpad128 / 128, 10 * splits), 256, 0, s>>>(a);
+    else conv_wgrad_kernel<64><<<dim3(a.Cout_pad / 64, a.Kpad128 / 128, 10 * splits), 256, 0, s>>>(a);
+    float* u = partial + (size_t)10 * splits * a.Cout_pad * a.Kpad128;
+    const int K7 = 7 * 4 * Gin;
+    wino_wgrad_reduce_kernel<<<(unsigned)cnm_ceil_div_ll(10ll * Cout * K7, 256), 256, 0, s>>>(partial, splits, Cout, a.Cout_pad, K7, a.Kpad128, u, 10);
+    wino_wgrad_rows_finish_kernel<<<(unsigned)cnm_ceil_div_ll((long long)Cout * K7, 256), 256, 0, s>>>(u, Cout, Cin, rot, dw_oihw);
+    CNM_LAUNCH_CHECK();
+    return CNM_OK;
 }
 
 // ------------------------------------------------------------------ BatchNorm2d (train mode) + ReLU on c4

@@ -505,6 +505,13 @@ size_t cnm_conv2d_wgrad_workspace_floats(int Cout, int Cin, int ksize, int N, in
 size_t cnm_conv3x3_wgrad_winograd_workspace_floats(int Cout, int Cin, int N, int H, int W);
 /* ... and of the stride-2 5x5 / 7x7 layers on the four pixel phases of x (3x3 / 4x4 phase filters, F(4x4,3x3) / F(3x3,4x4), as
  * cnm_conv_s2_winograd4_sync_c4_f32 runs the forward): dY transformed once, X per phase as 4*Cin channels.  H, W (even) = INPUT size. */
+/* ... and of the 7x7 stride-1 layer (conv1.0) row-wise, in the domain of the forward's F(4,7): ten frequency points, each a weight
+ * gradient with 7 x 1 taps over [N][H][W/4] images (17.5 multiplies per pixel instead of 49). */
+size_t cnm_conv7x7_wgrad_winograd_workspace_floats(int Cout, int Cin, int N, int H, int W);
+int cnm_conv7x7_wgrad_winograd_c4_f32(const float* x, int Gx_total, int gx0, int Cin,
+                                      const float* dy, int Gy_total, int gy0, int Cout,
+                                      float* dw_oihw, float* ws, size_t ws_floats,
+                                      int N, int H, int W, int rot, void* stream);
 size_t cnm_conv_s2_wgrad_winograd_workspace_floats(int Cout, int Cin, int ksize, int N, int H, int W);
 int cnm_conv_s2_wgrad_winograd_c4_f32(const float* x, int Gx_total, int gx0, int Cin,
                                       const float* dy, int Gy_total, int gy0, int Cout,

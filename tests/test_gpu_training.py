@@ -38,6 +38,7 @@ def _rel(a, b):
     (513, 256, 3, 1, 0, 1, 12, 20), (65, 64, 3, 1, 0, 3, 20, 28), (64, 16, 3, 1, 0, 2, 24, 40),
     (512, 512, 3, 2, 0, 2, 6, 8), (128, 64, 3, 1, 0, 2, 40, 48),
     (128, 256, 5, 1, 0, 2, 48, 64),       # conv2.0's kernels: F(2x2,5x5) forward and data gradient
+    (67, 128, 7, 1, 3, 2, 40, 72),        # conv1.0 with the row-wise Winograd-domain weight gradient (rotated input channels, ragged row tiles)
     (128, 128, 3, 2, 0, 6, 128, 192)])    # 3x3 stride 2 along rows (F(4,2) column phases), phase-scatter data gradient on the staged kernel
 def test_conv_forward_dgrad_wgrad(dev, cin, cout, k, stride, rot, N, H, W):
     from cnmnet_amd import ops, autograd as ag

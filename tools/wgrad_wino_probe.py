@@ -55,3 +55,22 @@ for name, k, cin, cout, N, H, W in (("conv2.3", 5, 256, 256, 4, 96, 128), ("conv
     ref = torch.nn.grad.conv2d_weight(x.double(), (cout, cin, k, k), dy.double(), stride=2, padding=k // 2)
     rel = lambda a_: float((a_.double() - ref).norm() / ref.norm())
     print("%-15s %dx%d s2 %4d->%4d %3dx%-3d N%d: direct %.3f ms  winograd %.3f ms  %.2fx   rel L2: direct %.1e  winograd %.1e" % (name, k, k, cin, cout, H, W, N, ms(fd), ms(fw), ms(fd) / ms(fw), rel(dwd), rel(dww)), flush=True)
+
+for name, cin, cout, N, H, W, signed in (("conv1.0", 67, 128, 4, 192, 256, False), ("conv1.0 zero-mean x", 67, 128, 2, 48, 64, True), ("conv1.0 small", 35, 64, 1, 13, 30, False)):
+    G = (cin + 3) // 4
+    x = torch.randn(N, cin, H, W, device=dev); dy = torch.randn(N, cout, H, W, device=dev)
+    if not signed: x = x.abs()
+    xc, dyc = ops.nchw_to_c4(x), ops.nchw_to_c4(dy)
+    dwd, dww = torch.empty(cout, cin, 7, 7, device=dev), torch.full((cout, cin, 7, 7), 7.0, device=dev)
+    wsd = torch.empty(lib.cnm_conv2d_wgrad_workspace_floats(cout, cin, 7, N, H, W), device=dev)
+    wsw = torch.empty(lib.cnm_conv7x7_wgrad_winograd_workspace_floats(cout, cin, N, H, W), device=dev)
+    fd = lambda: _lib.check(lib.cnm_conv2d_wgrad_c4_f32(xc.data_ptr(), G, 0, cin, dyc.data_ptr(), cout // 4, 0, cout, dwd.data_ptr(), wsd.data_ptr(), wsd.numel(), N, H, W, 7, 1, 0, st()))
+    fw = lambda: _lib.check(lib.cnm_conv7x7_wgrad_winograd_c4_f32(xc.data_ptr(), G, 0, cin, dyc.data_ptr(), cout // 4, 0, cout, dww.data_ptr(), wsw.data_ptr(), wsw.numel(), N, H, W, 0, st()))
+    fd(); fw(); torch.cuda.synchronize()
+    if N * H * W <= 2 * 48 * 64:
+        ref = torch.nn.grad.conv2d_weight(x.double(), (cout, cin, 7, 7), dy.double(), padding=3)
+        rel = lambda a_: float((a_.double() - ref).norm() / ref.norm())
+        err = "rel L2: direct %.1e  winograd rows %.1e" % (rel(dwd), rel(dww))
+    else:
+        err = "rel L2 between them %.1e" % float((dwd - dww).norm() / dwd.norm())
+    print("%-20s 7x7 %4d->%4d %3dx%-3d N%d: direct %.3f ms  winograd rows %.3f ms  %.2fx  ws %4.0f MB  %s" % (name, cin, cout, H, W, N, ms(fd), ms(fw), ms(fd) / ms(fw), wsw.numel() * 4 / 1e6, err), flush=True)
