@@ -125,6 +125,8 @@ PROTOTYPES = {
     "cnm_conv3x3_wgrad_winograd_workspace_floats": (c_sz, [c_i, c_i, c_i, c_i, c_i]),
     "cnm_conv7x7_wgrad_winograd_workspace_floats": (c_sz, [c_i, c_i, c_i, c_i, c_i]),
     "cnm_conv7x7_wgrad_winograd_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_sz, c_i, c_i, c_i, c_i, c_fp]),
+    "cnm_conv5x5_wgrad_winograd_workspace_floats": (c_sz, [c_i, c_i, c_i, c_i, c_i]),
+    "cnm_conv5x5_wgrad_winograd_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_sz, c_i, c_i, c_i, c_i, c_fp]),
     "cnm_conv_s2_wgrad_winograd_workspace_floats": (c_sz, [c_i, c_i, c_i, c_i, c_i, c_i]),
     "cnm_conv_s2_wgrad_winograd_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_sz, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "cnm_conv3x3_wgrad_winograd_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_sz, c_i, c_i, c_i, c_i, c_fp]),

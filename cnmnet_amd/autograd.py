@@ -238,13 +238,15 @@ class ConvC4(torch.autograd.Function):
                 dw = torch.empty_like(weight)
                 _lib.check(lib.cnm_conv3x3_wgrad_winograd_c4_f32(x.data_ptr(), G, 0, Cin, dy.data_ptr(), dy.shape[1], 0, Cout,
                                                                  dw.data_ptr(), ws.data_ptr(), ws.numel(), N, H, W, ctx.rot, _s()))
-            elif ctx.needs_input_grad[1] and WINOGRAD_WGRAD and k == 7 and ctx.stride == 1 and N * H * W >= 8 * WINOGRAD_WGRAD_MIN_PIXELS:
-                # 7x7 stride 1 (conv1.0): row-wise, in the domain of the forward's F(4,7) -- ten weight gradients with 7 x 1 taps on
-                # [N][H][W/4] images, 17.5 multiplies per pixel instead of 49 (cnm_conv7x7_wgrad_winograd_c4_f32): 1.64 -> 0.75 ms
-                ws = torch.empty(lib.cnm_conv7x7_wgrad_winograd_workspace_floats(Cout, Cin, N, H, W), device=dev, dtype=torch.float32)
+            elif ctx.needs_input_grad[1] and WINOGRAD_WGRAD and k in (5, 7) and ctx.stride == 1 and N * H * W >= 8 * WINOGRAD_WGRAD_MIN_PIXELS:
+                # 7x7 / 5x5 stride 1 (conv1.0, conv2.0): row-wise, in the domain of F(4,7) / F(4,5) -- ten / eight weight gradients with
+                # k x 1 taps on [N][H][W/4] images, 17.5 / 10 multiplies per pixel instead of 49 / 25 (cnm_conv7x7_wgrad_winograd_c4_f32,
+                # cnm_conv5x5_wgrad_winograd_c4_f32): conv1.0 1.64 -> 0.75 ms
+                wsf, fn = ((lib.cnm_conv7x7_wgrad_winograd_workspace_floats, lib.cnm_conv7x7_wgrad_winograd_c4_f32) if k == 7 else
+                           (lib.cnm_conv5x5_wgrad_winograd_workspace_floats, lib.cnm_conv5x5_wgrad_winograd_c4_f32))
+                ws = torch.empty(wsf(Cout, Cin, N, H, W), device=dev, dtype=torch.float32)
                 dw = torch.empty_like(weight)
-                _lib.check(lib.cnm_conv7x7_wgrad_winograd_c4_f32(x.data_ptr(), G, 0, Cin, dy.data_ptr(), dy.shape[1], 0, Cout,
-                                                                 dw.data_ptr(), ws.data_ptr(), ws.numel(), N, H, W, ctx.rot, _s()))
+                _lib.check(fn(x.data_ptr(), G, 0, Cin, dy.data_ptr(), dy.shape[1], 0, Cout, dw.data_ptr(), ws.data_ptr(), ws.numel(), N, H, W, ctx.rot, _s()))
             elif (ctx.needs_input_grad[1] and WINOGRAD_WGRAD and k in (5, 7) and ctx.stride == 2 and H % 2 == 0 and W % 2 == 0
                   and N * H * W >= 4 * WINOGRAD_WGRAD_MIN_PIXELS):
                 # 5x5 / 7x7 stride 2: the same on the four pixel phases of x (cnm_conv_s2_wgrad_winograd_c4_f32)

@@ -497,12 +497,21 @@ __device__ __constant__ double kWg47G[10][7] = {
     {-16. / 315, -8. / 105, -4. / 35, -6. / 35, -9. / 35, -27. / 70, -81. / 140}, {-16. / 315, 8. / 105, -4. / 35, 6. / 35, -9. / 35, 27. / 70, -81. / 140},
     {0, 0, 0, 0, 0, 0, 1}};
 
-// out[(xi * N + n)][g][y][t] = sum_j Mx[xi][j] in[n][g][y][4 t - off + j]: DY: Mx = A (4 pixels of the tile), else Mx = B^T (the 10-pixel window, off = 3).
-// One thread per (tile, row, image, group), tiles fastest.
-template <bool DY>
+// F(4,5) (conv2.0, 5x5 stride 1): eight points 0, +-1, +-2, +-1/2, inf -- 10 multiplies per pixel instead of 25.
+__device__ __constant__ float kWg45BT[8][8] = {{-1, 0, 21. / 4, 0, -21. / 4, 0, 1, 0}, {0, 1, 1, -17. / 4, -17. / 4, 1, 1, 0}, {0, -1, 1, 17. / 4, -17. / 4, -1, 1, 0},
+                                               {0, 1. / 2, 1. / 4, -5. / 2, -5. / 4, 2, 1, 0}, {0, -1. / 2, 1. / 4, 5. / 2, -5. / 4, -2, 1, 0},
+                                               {0, 2, 4, -5. / 2, -5, 1. / 2, 1, 0}, {0, -2, 4, 5. / 2, -5, -1. / 2, 1, 0}, {0, -1, 0, 21. / 4, 0, -21. / 4, 0, 1}};
+__device__ __constant__ float kWg45A[8][4] = {{1, 0, 0, 0}, {1, 1, 1, 1}, {1, -1, 1, -1}, {1, 2, 4, 8}, {1, -2, 4, -8}, {1, 1. / 2, 1. / 4, 1. / 8}, {1, -1. / 2, 1. / 4, -1. / 8}, {0, 0, 0, 1}};
+__device__ __constant__ double kWg45G[8][5] = {{-1, 0, 0, 0, 0}, {-2. / 9, -2. / 9, -2. / 9, -2. / 9, -2. / 9}, {-2. / 9, 2. / 9, -2. / 9, 2. / 9, -2. / 9},
+                                               {1. / 90, 1. / 45, 2. / 45, 4. / 45, 8. / 45}, {1. / 90, -1. / 45, 2. / 45, -4. / 45, 8. / 45},
+                                               {32. / 45, 16. / 45, 8. / 45, 4. / 45, 2. / 45}, {32. / 45, -16. / 45, 8. / 45, -4. / 45, 2. / 45}, {0, 0, 0, 0, 1}};
+
+// out[(xi * N + n)][g][y][t] = sum_j Mx[xi][j] in[n][g][y][4 t - off + j]: DY: Mx = A (4 pixels of the tile), else Mx = B^T (the (R + 3)-pixel
+// window, off = R / 2).  One thread per (tile, row, image, group), tiles fastest.  R = 7: F(4,7), 10 points; R = 5: F(4,5), 8 points.
+template <bool DY, int R>
 __global__ __launch_bounds__(256) void wino_wgrad_rows_xform_kernel(const float* __restrict__ in, int G_tot, int g0, int G, int N, int H, int W, int TW,
                                                                     float* __restrict__ out) {
-    constexpr int NL = DY ? 4 : 10, OFF = DY ? 0 : 3;
+    constexpr int NP = R + 3, NL = DY ? 4 : NP, OFF = DY ? 0 : R / 2;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long total = (long long)TW * H * N * G;
     if (idx >= total) return;
@@ -519,43 +528,45 @@ __global__ __launch_bounds__(256) void wino_wgrad_rows_xform_kernel(const float*
     const size_t plane = (size_t)N * G * H * TW;                          // float4 elements per frequency point
     wg_f4* o = reinterpret_cast<wg_f4*>(out) + ((size_t)(n * G + g) * H + y) * TW + t;
 #pragma unroll
-    for (int xi = 0; xi < 10; ++xi) {
+    for (int xi = 0; xi < NP; ++xi) {
         wg_f4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < NL; ++j) {
-            const float c = DY ? kWg47A[xi][j] : kWg47BT[xi][j];
+            const float c = R == 7 ? (DY ? kWg47A[xi][j] : kWg47BT[xi][j]) : (DY ? kWg45A[xi][j] : kWg45BT[xi][j]);
             if (c != 0.f) s += c * v[j];
         }
         o[(size_t)xi * plane] = s;
     }
 }
 
-// dW[co][ci][ky][kx] = sum_xi G[xi][kx] dU[xi][co][ky * Cp + cp]   (u: [10][Cout][7 * Cp], split sums done by wino_wgrad_reduce_kernel)
+// dW[co][ci][ky][kx] = sum_xi G[xi][kx] dU[xi][co][ky * Cp + cp]   (u: [R + 3][Cout][R * Cp], split sums done by wino_wgrad_reduce_kernel)
+template <int R>
 __global__ __launch_bounds__(256) void wino_wgrad_rows_finish_kernel(const float* __restrict__ u, int Cout, int Cin, int rot, float* __restrict__ dw) {
-    const int Cp = 4 * ((Cin + 3) / 4), K7 = 7 * Cp;
+    constexpr int NP = R + 3;
+    const int Cp = 4 * ((Cin + 3) / 4), K7 = R * Cp;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long per = (long long)Cout * K7;
     if (idx >= per) return;
     const int co = (int)(idx / K7), k = (int)(idx - (long long)co * K7), ky = k / Cp, cp = k - ky * Cp;
     if (cp >= Cin) return;
-    double uu[10];
+    double uu[NP];
 #pragma unroll
-    for (int xi = 0; xi < 10; ++xi) uu[xi] = (double)u[(size_t)xi * per + idx];
-    float* o = dw + (((size_t)co * Cin + (cp + rot) % Cin) * 7 + ky) * 7;
+    for (int xi = 0; xi < NP; ++xi) uu[xi] = (double)u[(size_t)xi * per + idx];
+    float* o = dw + (((size_t)co * Cin + (cp + rot) % Cin) * R + ky) * R;
 #pragma unroll
-    for (int kx = 0; kx < 7; ++kx) {
+    for (int kx = 0; kx < R; ++kx) {
         double s = 0.0;
 #pragma unroll
-        for (int xi = 0; xi < 10; ++xi) s += kWg47G[xi][kx] * uu[xi];
+        for (int xi = 0; xi < NP; ++xi) s += (R == 7 ? kWg47G[xi][kx] : kWg45G[xi][kx]) * uu[xi];
         o[kx] = (float)s;
     }
 }
 
-static void wino_rows_plan(int Cout, int Cin, long long Mpix, int* Cout_pad, int* Kpad128, int* splits, int* pps) {
+static void wino_rows_plan(int Cout, int Cin, int R, long long Mpix, int* Cout_pad, int* Kpad128, int* splits, int* pps) {
     const int tco = wgrad_tco(Cout);
     *Cout_pad = wg_round(Cout, tco);
-    *Kpad128 = wg_round(7 * 4 * ((Cin + 3) / 4), 128);
-    const int tiles = 10 * (*Cout_pad / tco) * (*Kpad128 / 128);
+    *Kpad128 = wg_round(R * 4 * ((Cin + 3) / 4), 128);
+    const int tiles = (R + 3) * (*Cout_pad / tco) * (*Kpad128 / 128);
     int s = (CNM_WGRAD_WORKGROUPS + tiles - 1) / tiles;
     const int maxs = (int)((Mpix + 255) / 256);
     if (s > maxs) s = maxs;
@@ -564,45 +575,61 @@ static void wino_rows_plan(int Cout, int Cin, long long Mpix, int* Cout_pad, int
     *splits = (int)((Mpix + *pps - 1) / *pps);
 }
 
-extern "C" size_t cnm_conv7x7_wgrad_winograd_workspace_floats(int Cout, int Cin, int N, int H, int W) {
+static size_t wino_rows_ws(int Cout, int Cin, int R, int N, int H, int W) {
     if (Cout <= 0 || Cin <= 0 || N <= 0 || H <= 0 || W <= 0) return 0;
-    const size_t TW = (size_t)(W + 3) / 4, P = (size_t)N * H * TW;
+    const size_t TW = (size_t)(W + 3) / 4, P = (size_t)N * H * TW, NP = R + 3;
     int cp, kp, sp, pps;
-    wino_rows_plan(Cout, Cin, (long long)P, &cp, &kp, &sp, &pps);
-    return 10 * P * 4 * (size_t)((Cin + 3) / 4) + 10 * P * 4 * (size_t)((Cout + 3) / 4) + (size_t)10 * sp * cp * kp + (size_t)10 * Cout * 7 * 4 * ((Cin + 3) / 4);
+    wino_rows_plan(Cout, Cin, R, (long long)P, &cp, &kp, &sp, &pps);
+    return NP * P * 4 * (size_t)((Cin + 3) / 4) + NP * P * 4 * (size_t)((Cout + 3) / 4) + NP * sp * (size_t)cp * kp + NP * Cout * (size_t)R * 4 * ((Cin + 3) / 4);
 }
 
-extern "C" int cnm_conv7x7_wgrad_winograd_c4_f32(const float* x, int Gx_total, int gx0, int Cin,
-                                                 const float* dy, int Gy_total, int gy0, int Cout,
-                                                 float* dw_oihw, float* ws, size_t ws_floats,
-                                                 int N, int H, int W, int rot, void* stream) {
+template <int R>
+static int wino_rows_wgrad(const float* x, int Gx_total, int gx0, int Cin, const float* dy, int Gy_total, int gy0, int Cout,
+                           float* dw_oihw, float* ws, size_t ws_floats, int N, int H, int W, int rot, void* stream) {
+    constexpr int NP = R + 3;
     CNM_REQUIRE(x && dy && dw_oihw && ws && N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cout % 4 == 0 && rot >= 0 && rot < Cin, CNM_ERR_BAD_ARG);
     const int Gin = (Cin + 3) / 4, Gout = Cout / 4, TW = (W + 3) / 4;
     const long long P = (long long)N * H * TW;
     CNM_REQUIRE(gx0 >= 0 && gx0 + Gin <= Gx_total && gy0 >= 0 && gy0 + Gout <= Gy_total && P < (1ll << 24), CNM_ERR_BAD_ARG);
-    CNM_REQUIRE(cnm_conv7x7_wgrad_winograd_workspace_floats(Cout, Cin, N, H, W) <= ws_floats, CNM_ERR_WORKSPACE);
-    float* xh = ws; float* yh = xh + (size_t)10 * P * 4 * Gin; float* partial = yh + (size_t)10 * P * 4 * Gout;
-    const unsigned long long xb = 10ull * P * Gin * 16ull, yb = 10ull * P * Gout * 16ull;
+    CNM_REQUIRE(wino_rows_ws(Cout, Cin, R, N, H, W) <= ws_floats, CNM_ERR_WORKSPACE);
+    float* xh = ws; float* yh = xh + (size_t)NP * P * 4 * Gin; float* partial = yh + (size_t)NP * P * 4 * Gout;
+    const unsigned long long xb = (unsigned long long)NP * P * Gin * 16ull, yb = (unsigned long long)NP * P * Gout * 16ull;
     CNM_REQUIRE(xb < 0xFFFFFFFFull && yb < 0xFFFFFFFFull, CNM_ERR_BAD_ARG);
     hipStream_t s = cnm_stream(stream);
-    wino_wgrad_rows_xform_kernel<false><<<(unsigned)cnm_ceil_div_ll(P * Gin, 256), 256, 0, s>>>(x, Gx_total, gx0, Gin, N, H, W, TW, xh);
-    wino_wgrad_rows_xform_kernel<true><<<(unsigned)cnm_ceil_div_ll(P * Gout, 256), 256, 0, s>>>(dy, Gy_total, gy0, Gout, N, H, W, TW, yh);
+    wino_wgrad_rows_xform_kernel<false, R><<<(unsigned)cnm_ceil_div_ll(P * Gin, 256), 256, 0, s>>>(x, Gx_total, gx0, Gin, N, H, W, TW, xh);
+    wino_wgrad_rows_xform_kernel<true, R><<<(unsigned)cnm_ceil_div_ll(P * Gout, 256), 256, 0, s>>>(dy, Gy_total, gy0, Gout, N, H, W, TW, yh);
     WgradArgs a;
     a.x = xh; a.dy = yh; a.partial = partial; a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)yb;
-    a.N = 10 * N; a.H = H; a.W = TW; a.Ho = H; a.Wo = TW; a.ks = 7; a.stride = 1; a.pad = 3; a.ksx = 1; a.padx = 0; a.ipp = N;
+    a.N = NP * N; a.H = H; a.W = TW; a.Ho = H; a.Wo = TW; a.ks = R; a.stride = 1; a.pad = R / 2; a.ksx = 1; a.padx = 0; a.ipp = N;
     a.Gx_tot = Gin; a.gx0 = 0; a.Gin = Gin; a.Gy_tot = Gout; a.gy0 = 0; a.Cout = Cout;
-    a.Kflat = 7 * 4 * Gin; a.M = (int)P;
+    a.Kflat = R * 4 * Gin; a.M = (int)P;
     int splits;
-    wino_rows_plan(Cout, Cin, P, &a.Cout_pad, &a.Kpad128, &splits, &a.pix_per_split);
+    wino_rows_plan(Cout, Cin, R, P, &a.Cout_pad, &a.Kpad128, &splits, &a.pix_per_split);
     a.per_image_splits = splits;
-    if (wgrad_tco(Cout) == 128) conv_wgrad_kernel<128><<<dim3(a.Cout_pad / 128, a.Kpad128 / 128, 10 * splits), 256, 0, s>>>(a);
-    else conv_wgrad_kernel<64><<<dim3(a.Cout_pad / 64, a.Kpad128 / 128, 10 * splits), 256, 0, s>>>(a);
-    float* u = partial + (size_t)10 * splits * a.Cout_pad * a.Kpad128;
-    const int K7 = 7 * 4 * Gin;
-    wino_wgrad_reduce_kernel<<<(unsigned)cnm_ceil_div_ll(10ll * Cout * K7, 256), 256, 0, s>>>(partial, splits, Cout, a.Cout_pad, K7, a.Kpad128, u, 10);
-    wino_wgrad_rows_finish_kernel<<<(unsigned)cnm_ceil_div_ll((long long)Cout * K7, 256), 256, 0, s>>>(u, Cout, Cin, rot, dw_oihw);
+    if (wgrad_tco(Cout) == 128) conv_wgrad_kernel<128><<<dim3(a.Cout_pad / 128, a.Kpad128 / 128, NP * splits), 256, 0, s>>>(a);
+    else conv_wgrad_kernel<64><<<dim3(a.Cout_pad / 64, a.Kpad128 / 128, NP * splits), 256, 0, s>>>(a);
+    float* u = partial + (size_t)NP * splits * a.Cout_pad * a.Kpad128;
+    const int KR = R * 4 * Gin;
+    wino_wgrad_reduce_kernel<<<(unsigned)cnm_ceil_div_ll((long long)NP * Cout * KR, 256), 256, 0, s>>>(partial, splits, Cout, a.Cout_pad, KR, a.Kpad128, u, NP);
+    wino_wgrad_rows_finish_kernel<R><<<(unsigned)cnm_ceil_div_ll((long long)Cout * KR, 256), 256, 0, s>>>(u, Cout, Cin, rot, dw_oihw);
     CNM_LAUNCH_CHECK();
     return CNM_OK;
+}
+
+extern "C" size_t cnm_conv7x7_wgrad_winograd_workspace_floats(int Cout, int Cin, int N, int H, int W) { return wino_rows_ws(Cout, Cin, 7, N, H, W); }
+extern "C" int cnm_conv7x7_wgrad_winograd_c4_f32(const float* x, int Gx_total, int gx0, int Cin,
+                                                 const float* dy, int Gy_total, int gy0, int Cout,
+                                                 float* dw_oihw, float* ws, size_t ws_floats,
+                                                 int N, int H, int W, int rot, void* stream) {
+    return wino_rows_wgrad<7>(x, Gx_total, gx0, Cin, dy, Gy_total, gy0, Cout, dw_oihw, ws, ws_floats, N, H, W, rot, stream);
+}
+// ... and of the 5x5 stride-1 layer (conv2.0) on F(4,5): eight gradients with 5 x 1 taps, 10 multiplies per pixel instead of 25
+extern "C" size_t cnm_conv5x5_wgrad_winograd_workspace_floats(int Cout, int Cin, int N, int H, int W) { return wino_rows_ws(Cout, Cin, 5, N, H, W); }
+extern "C" int cnm_conv5x5_wgrad_winograd_c4_f32(const float* x, int Gx_total, int gx0, int Cin,
+                                                 const float* dy, int Gy_total, int gy0, int Cout,
+                                                 float* dw_oihw, float* ws, size_t ws_floats,
+                                                 int N, int H, int W, int rot, void* stream) {
+    return wino_rows_wgrad<5>(x, Gx_total, gx0, Cin, dy, Gy_total, gy0, Cout, dw_oihw, ws, ws_floats, N, H, W, rot, stream);
 }
 
 // ------------------------------------------------------------------ BatchNorm2d (train mode) + ReLU on c4

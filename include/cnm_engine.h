@@ -512,6 +512,12 @@ int cnm_conv7x7_wgrad_winograd_c4_f32(const float* x, int Gx_total, int gx0, int
                                       const float* dy, int Gy_total, int gy0, int Cout,
                                       float* dw_oihw, float* ws, size_t ws_floats,
                                       int N, int H, int W, int rot, void* stream);
+/* ... and of the 5x5 stride-1 layer (conv2.0) row-wise on F(4,5): eight gradients with 5 x 1 taps, 10 multiplies per pixel instead of 25. */
+size_t cnm_conv5x5_wgrad_winograd_workspace_floats(int Cout, int Cin, int N, int H, int W);
+int cnm_conv5x5_wgrad_winograd_c4_f32(const float* x, int Gx_total, int gx0, int Cin,
+                                      const float* dy, int Gy_total, int gy0, int Cout,
+                                      float* dw_oihw, float* ws, size_t ws_floats,
+                                      int N, int H, int W, int rot, void* stream);
 size_t cnm_conv_s2_wgrad_winograd_workspace_floats(int Cout, int Cin, int ksize, int N, int H, int W);
 int cnm_conv_s2_wgrad_winograd_c4_f32(const float* x, int Gx_total, int gx0, int Cin,
                                       const float* dy, int Gy_total, int gy0, int Cout,

@@ -74,3 +74,18 @@ for name, cin, cout, N, H, W, signed in (("conv1.0", 67, 128, 4, 192, 256, False
     else:
         err = "rel L2 between them %.1e" % float((dwd - dww).norm() / dwd.norm())
     print("%-20s 7x7 %4d->%4d %3dx%-3d N%d: direct %.3f ms  winograd rows %.3f ms  %.2fx  ws %4.0f MB  %s" % (name, cin, cout, H, W, N, ms(fd), ms(fw), ms(fd) / ms(fw), wsw.numel() * 4 / 1e6, err), flush=True)
+
+for name, cin, cout, N, H, W in (("conv2.0", 128, 256, 4, 96, 128), ("conv2.0 small", 36, 64, 2, 20, 30)):
+    G = (cin + 3) // 4
+    x = torch.randn(N, cin, H, W, device=dev); dy = torch.randn(N, cout, H, W, device=dev)
+    xc, dyc = ops.nchw_to_c4(x), ops.nchw_to_c4(dy)
+    dwd, dww = torch.empty(cout, cin, 5, 5, device=dev), torch.full((cout, cin, 5, 5), 7.0, device=dev)
+    wsd = torch.empty(lib.cnm_conv2d_wgrad_workspace_floats(cout, cin, 5, N, H, W), device=dev)
+    wsw = torch.empty(lib.cnm_conv5x5_wgrad_winograd_workspace_floats(cout, cin, N, H, W), device=dev)
+    fd = lambda: _lib.check(lib.cnm_conv2d_wgrad_c4_f32(xc.data_ptr(), G, 0, cin, dyc.data_ptr(), cout // 4, 0, cout, dwd.data_ptr(), wsd.data_ptr(), wsd.numel(), N, H, W, 5, 1, 0, st()))
+    fw = lambda: _lib.check(lib.cnm_conv5x5_wgrad_winograd_c4_f32(xc.data_ptr(), G, 0, cin, dyc.data_ptr(), cout // 4, 0, cout, dww.data_ptr(), wsw.data_ptr(), wsw.numel(), N, H, W, 0, st()))
+    fd(); fw(); torch.cuda.synchronize()
+    ref = torch.nn.grad.conv2d_weight(x.double(), (cout, cin, 5, 5), dy.double(), padding=2)
+    rel = lambda a_: float((a_.double() - ref).norm() / ref.norm())
+    print("%-20s 5x5 %4d->%4d %3dx%-3d N%d: direct %.3f ms  winograd rows %.3f ms  %.2fx  ws %4.0f MB  rel L2: direct %.1e  winograd rows %.1e" % (
+        name, cin, cout, H, W, N, ms(fd), ms(fw), ms(fd) / ms(fw), wsw.numel() * 4 / 1e6, rel(dwd), rel(dww)), flush=True)
