@@ -169,6 +169,20 @@ def _taps4(wp):
     return wp[:, :, 1:, 1:]
 
 
+def _wino_wgrad_fits(k, stride, N, H, W, Cin, Cout):
+    """The Winograd-domain weight gradients address their transformed tensors with 32-bit byte offsets and count at most 2^24
+    tiles (the entry points refuse larger problems): then the direct kernel runs."""
+    gin, gout = -(-Cin // 4), Cout // 4
+    if stride == 1 and k == 3:
+        pts, t, geff = 36, N * -(-H // 4) * -(-W // 4), gin
+    elif stride == 1:
+        pts, t, geff = k + 3, N * H * -(-W // 4), gin
+    else:
+        m = 3 if k == 7 else 4
+        pts, t, geff = 36, N * -(-(H // 2) // m) * -(-(W // 2) // m), 4 * gin
+    return t < (1 << 24) and pts * t * max(geff, gout) * 16 < 0xFFFFFFFF
+
+
 class ConvC4(torch.autograd.Function):
     """y = conv2d(x, weight, stride, padding=(k-1)//2) on c4 tensors, no bias.
     x [N,ceil(Cin/4),H,W,4] (channels possibly rotated by `rot`), weight OIHW; Cout % 4 == 0, >= 16."""
@@ -230,7 +244,8 @@ class ConvC4(torch.autograd.Function):
                 dx = torch.empty_like(x)
                 _lib.check(lib.cnm_conv2d_dgrad_c4_f32(dy.data_ptr(), dy.shape[1], 0, Cout, dx.data_ptr(), G, 0, Cin,
                                                        wd.data_ptr(), N, H, W, k, ctx.stride, _s()))
-            if ctx.needs_input_grad[1] and WINOGRAD_WGRAD and k == 3 and ctx.stride == 1 and N * H * W >= WINOGRAD_WGRAD_MIN_PIXELS:
+            wino = WINOGRAD_WGRAD and _wino_wgrad_fits(k, ctx.stride, N, H, W, Cin, Cout)
+            if ctx.needs_input_grad[1] and wino and k == 3 and ctx.stride == 1 and N * H * W >= WINOGRAD_WGRAD_MIN_PIXELS:
                 # 3x3 stride 1: the gradient in the Winograd domain of the forward's F(4x4,3x3) -- 36 GEMMs over the tiles, a quarter
                 # of the direct kernel's multiplies (cnm_conv3x3_wgrad_winograd_c4_f32): 1.5-2.4x from 4 x 24 x 32 pixels up
                 # (tools/wgrad_wino_probe.py)
@@ -238,7 +253,7 @@ class ConvC4(torch.autograd.Function):
                 dw = torch.empty_like(weight)
                 _lib.check(lib.cnm_conv3x3_wgrad_winograd_c4_f32(x.data_ptr(), G, 0, Cin, dy.data_ptr(), dy.shape[1], 0, Cout,
                                                                  dw.data_ptr(), ws.data_ptr(), ws.numel(), N, H, W, ctx.rot, _s()))
-            elif ctx.needs_input_grad[1] and WINOGRAD_WGRAD and k in (5, 7) and ctx.stride == 1 and N * H * W >= 8 * WINOGRAD_WGRAD_MIN_PIXELS:
+            elif ctx.needs_input_grad[1] and wino and k in (5, 7) and ctx.stride == 1 and N * H * W >= 8 * WINOGRAD_WGRAD_MIN_PIXELS:
                 # 7x7 / 5x5 stride 1 (conv1.0, conv2.0): row-wise, in the domain of F(4,7) / F(4,5) -- ten / eight weight gradients with
                 # k x 1 taps on [N][H][W/4] images, 17.5 / 10 multiplies per pixel instead of 49 / 25 (cnm_conv7x7_wgrad_winograd_c4_f32,
                 # cnm_conv5x5_wgrad_winograd_c4_f32): conv1.0 1.64 -> 0.75 ms
@@ -247,7 +262,7 @@ class ConvC4(torch.autograd.Function):
                 ws = torch.empty(wsf(Cout, Cin, N, H, W), device=dev, dtype=torch.float32)
                 dw = torch.empty_like(weight)
                 _lib.check(fn(x.data_ptr(), G, 0, Cin, dy.data_ptr(), dy.shape[1], 0, Cout, dw.data_ptr(), ws.data_ptr(), ws.numel(), N, H, W, ctx.rot, _s()))
-            elif (ctx.needs_input_grad[1] and WINOGRAD_WGRAD and k in (5, 7) and ctx.stride == 2 and H % 2 == 0 and W % 2 == 0
+            elif (ctx.needs_input_grad[1] and wino and k in (5, 7) and ctx.stride == 2 and H % 2 == 0 and W % 2 == 0
                   and N * H * W >= 4 * WINOGRAD_WGRAD_MIN_PIXELS):
                 # 5x5 / 7x7 stride 2: the same on the four pixel phases of x (cnm_conv_s2_wgrad_winograd_c4_f32)
                 ws = torch.empty(lib.cnm_conv_s2_wgrad_winograd_workspace_floats(Cout, Cin, k, N, H, W), device=dev, dtype=torch.float32)
