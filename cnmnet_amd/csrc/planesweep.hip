@@ -7,7 +7,7 @@
 //    64 x ~12 ATen launches per pair, with ONE launch over all pairs, planes and pixels.
 //
 // K1 = ONE launch on the caller's stream (gfx950, 64-lane waves), persistent workgroups:
-//   The grid is sized to the chip (two 8-wave workgroups per CU).  A workgroup sweeps 64 x 8 pixel tiles drawn
+//   The grid is sized to the chip (one 16-wave workgroup per CU; round 2: two of 8 waves).  A workgroup sweeps 64 x 16 pixel tiles drawn
 //   from a ticket counter (the last tiles are handed out as two half sweeps so the launch has no tile-long
 //   tail); one lane per reference pixel walks the planes, with the per-pixel camera terms and the reference RGB
 //   in registers; the next tile's camera terms / reference pixel / ticket travel while the current one is swept.
@@ -32,10 +32,13 @@
 
 #define CNM_MAX_PLANES 128
 #define SWEEP_TW 64                 // tile width  (pixels, lanes along x)
-#define SWEEP_TH 8                  // tile height
+#ifndef SWEEP_TH
+#define SWEEP_TH 16                 // tile height = waves per workgroup.  [r3] 16 (one 1024-thread workgroup and one 155 KB box per CU) instead of 8
+#endif                              // (two workgroups, two 80 KB boxes): a staged texel serves twice the pixels and a box holds twice the plane range, so
+                                    // the staging instructions per sample halve -- 80 -> 69.5 us in tools/k1_bench.hip, although nothing overlaps a staging any more
 #define SWEEP_NT (SWEEP_TW * SWEEP_TH)
 #ifndef SWEEP_CAP
-#define SWEEP_CAP 1672              // texels per LDS box (3 x 16 B each: 80 256 B, two workgroups per CU)
+#define SWEEP_CAP 3300              // texels per LDS box (3 x 16 B each: 158 400 B, one workgroup per CU)
 #endif
 #ifndef SWEEP_MINW
 #define SWEEP_MINW 4                // waves per SIMD the register allocation must allow (2 workgroups x 8 waves per CU)
@@ -237,7 +240,7 @@ __device__ __forceinline__ float sweep_blend(const float4 u0, const float4 u1, c
     return (__builtin_fabsf(er) + __builtin_fabsf(eg)) + __builtin_fabsf(eb);   // :222-223
 }
 
-// Persistent workgroups: the grid is sized to the chip (two 8-wave workgroups per CU) and a workgroup sweeps tile
+// Persistent workgroups: the grid is sized to the chip (one 16-wave workgroup per CU) and a workgroup sweeps tile
 // blockIdx.x, then tiles drawn from a ticket counter in the caller's workspace (ws[0]: tickets, ws[1]: exits; both
 // are zero between launches - the last workgroup to leave resets them).  Per tile: footprints (wave 0) ->
 // [stage box -> sweep its planes]*.  The ticket, the camera terms and the reference pixel of the NEXT tile are
@@ -293,7 +296,8 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
     // Work units: whole tiles first, then tiles cut into two half sweeps, then tiles cut into quarter sweeps: the
     // launch ends with small units, not with a tile-long tail of half-empty CUs.  Zone sizes in quarters of the grid.
     const int nq = noct >= 4 ? min(ntiles, (int)gridDim.x * SWEEP_TAIL_QUARTERS / 4) : 0;
-    const int nh = noct >= 2 ? min(ntiles - nq, (int)gridDim.x * SWEEP_TAIL_HALVES / 4) : 0;
+    // (no half sweeps when the tiles divide evenly among the workgroups: 768 tiles on 256 CUs ran 72 us with them, 69.5 without)
+    const int nh = (noct >= 2 && ntiles % (int)gridDim.x != 0) ? min(ntiles - nq, (int)gridDim.x * SWEEP_TAIL_HALVES / 4) : 0;
     const int nfull = ntiles - nh - nq, nunits = nfull + 2 * nh + 4 * nq;
     const float inv_tpp = 1.0f / (float)tiles_per_pair, inv_ntx = 1.0f / (float)ntx;
     struct Unit { int p, tx0, ty0, obeg, ocnt; };
@@ -427,9 +431,9 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const int rw = bx1[q] - bx0[q] + 1, rh = by1[q] - by0[q] + 1;
-                    // capacity in texels, and in staging items ((rw + 1) rh over four passes of 8 x 63 lanes)
+                    // capacity in texels, and in staging items ((rw + 1) rh over four passes of SWEEP_TH x 63 lanes)
                     const int rwc = min(max(rw, 0), SWEEP_CAP + 1), rhc = min(max(rh, 0), SWEEP_CAP + 1);   // 24-bit products
-                    fits[q] = bok[q] && __mul24(rwc, rhc) <= SWEEP_CAP && __mul24(rwc + 1, rhc) <= 4 * 8 * 63;
+                    fits[q] = bok[q] && __mul24(rwc, rhc) <= SWEEP_CAP && __mul24(rwc + 1, rhc) <= 4 * SWEEP_TH * 63;
                     const bool run_live = ((q * 8 + (lane >> 3)) & ~((1 << L) - 1)) < ocnt;
                     bad |= run_live && !fits[q];
                 }
@@ -499,8 +503,8 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
                 int dst[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    if (k * 8 * 63 >= n) break;                               // wave-uniform: passes the box does not need
-                    const int i = (k * 8 + wave) * 63 + lane;
+                    if (k * SWEEP_TH * 63 >= n) break;                        // wave-uniform: passes the box does not need
+                    const int i = (k * SWEEP_TH + wave) * 63 + lane;
                     const int r = (int)(((float)i + 0.5f) * inv_pitch);      // exact for i < 2^21 / pitch
                     int c, t, d;                                             // 24-bit multiply-adds (v_mul_lo_u32 is quarter rate)
                     asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(c) : "v"(r), "s"(-pitch), "v"(i));        // c = i - r pitch
@@ -520,7 +524,7 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    if (k * 8 * 63 >= n) break;
+                    if (k * SWEEP_TH * 63 >= n) break;
                     float q0[3], q1[3];
 #pragma unroll
                     for (int ch = 0; ch < 3; ++ch) { q0[ch] = sweep_next_lane(p0[k][ch]); q1[ch] = sweep_next_lane(p1[k][ch]); }
