@@ -35,7 +35,7 @@
 #ifndef SWEEP_TH
 #define SWEEP_TH 16                 // tile height = waves per workgroup.  [r3] 16 (one 1024-thread workgroup and one 155 KB box per CU) instead of 8
 #endif                              // (two workgroups, two 80 KB boxes): a staged texel serves twice the pixels and a box holds twice the plane range, so
-                                    // the staging instructions per sample halve -- 80 -> 69.5 us in tools/k1_bench.hip, although nothing overlaps a staging any more
+                                    // a third fewer texels are staged per launch (3.0 M instead of 4.5 M) -- 80 -> 69.5 us in tools/k1_bench.hip, although nothing overlaps a staging any more
 #define SWEEP_NT (SWEEP_TW * SWEEP_TH)
 #ifndef SWEEP_CAP
 #define SWEEP_CAP 3300              // texels per LDS box (3 x 16 B each: 158 400 B, one workgroup per CU)
