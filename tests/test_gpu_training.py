@@ -39,7 +39,10 @@ def _rel(a, b):
     (512, 512, 3, 2, 0, 2, 6, 8), (128, 64, 3, 1, 0, 2, 40, 48),
     (128, 256, 5, 1, 0, 2, 48, 64),       # conv2.0's kernels: F(2x2,5x5) forward and data gradient
     (67, 128, 7, 1, 3, 2, 40, 72),        # conv1.0 with the row-wise Winograd-domain weight gradient (rotated input channels, ragged row tiles)
-    (128, 128, 3, 2, 0, 6, 128, 192)])    # 3x3 stride 2 along rows (F(4,2) column phases), phase-scatter data gradient on the staged kernel
+    (128, 128, 3, 2, 0, 6, 128, 192),     # 3x3 stride 2 along rows (F(4,2) column phases), phase-scatter data gradient on the staged kernel
+    (64, 128, 5, 2, 0, 2, 48, 64),        # 5x5 stride 2: forward and weight gradient on the pixel phases (F(4x4,3x3))
+    (64, 64, 7, 2, 0, 1, 52, 76),         # 7x7 stride 2: the same on F(3x3,4x4), ragged tiles (26 x 38 outputs)
+    (36, 64, 3, 1, 0, 2, 30, 46)])        # 3x3: Winograd-domain weight gradient with ragged tiles and a ragged channel group
 def test_conv_forward_dgrad_wgrad(dev, cin, cout, k, stride, rot, N, H, W):
     from cnmnet_amd import ops, autograd as ag
     rng = np.random.default_rng(cin + 3 * k + stride)
