@@ -100,6 +100,30 @@ def test_stride2_dgrad_phase_scatter(dev, cin, cout, k, N, Ho, Wo):
     assert _rel(res[0].cpu().numpy(), res[1].cpu().numpy()) < 2e-5
 
 
+def test_winograd_wgrad_argument_errors(dev):
+    """The Winograd-domain weight gradients and the phase-scatter convolutions refuse what they cannot run: a short workspace, odd
+    sizes for the stride-2 forms, an unsupported filter size, a 4x4 phase scatter too small for the staged kernel."""
+    from cnmnet_amd import ops, _lib
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    x = torch.zeros(1, 16, 24, 32, 4, device=dev); dy = torch.zeros(1, 16, 24, 32, 4, device=dev); dys = torch.zeros(1, 16, 12, 16, 4, device=dev)
+    dw = torch.zeros(64, 64, 7, 7, device=dev)
+    need = lib.cnm_conv3x3_wgrad_winograd_workspace_floats(64, 64, 1, 24, 32)
+    assert need > 0 and lib.cnm_conv_s2_wgrad_winograd_workspace_floats(64, 64, 3, 1, 24, 32) == 0 and lib.cnm_conv_s2_wgrad_winograd_workspace_floats(64, 64, 5, 1, 23, 32) == 0
+    ws = torch.zeros(need, device=dev)
+    args = (x.data_ptr(), 16, 0, 64, dy.data_ptr(), 16, 0, 64, dw.data_ptr(), ws.data_ptr())
+    assert lib.cnm_conv3x3_wgrad_winograd_c4_f32(*args, need - 1, 1, 24, 32, 0, st) == -5          # CNM_ERR_WORKSPACE
+    assert lib.cnm_conv3x3_wgrad_winograd_c4_f32(*args, need, 1, 24, 32, 64, st) == -1             # rot out of range
+    assert lib.cnm_conv3x3_wgrad_winograd_c4_f32(*args, need, 1, 24, 32, 0, st) == 0
+    args2 = (x.data_ptr(), 16, 0, 64, dys.data_ptr(), 16, 0, 64, dw.data_ptr(), ws.data_ptr(), 1 << 40)
+    assert lib.cnm_conv_s2_wgrad_winograd_c4_f32(*args2, 1, 24, 32, 3, 0, st) == -1                 # 3x3 stride 2 has no Winograd-domain form
+    assert lib.cnm_conv_s2_wgrad_winograd_c4_f32(*args2, 1, 23, 32, 5, 0, st) == -1                 # odd input height
+    up = ops.pack_winograd36(torch.zeros(256, 64, 4, 4, device=dev))
+    with pytest.raises(_lib.EngineError):
+        ops.conv3x3_phase_scatter_c4(torch.zeros(1, 16, 5, 9, 4, device=dev), up, 64, sync=ops.wino36_sync_workspace(dev), ksize=4)   # 2 x 3 tiles
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("C,N,H,W,relu", [(128, 2, 12, 20, True), (67, 3, 8, 8, False), (512, 2, 6, 8, True)])
 def test_batchnorm_train_forward_backward(dev, C, N, H, W, relu):
     from cnmnet_amd import ops, autograd as ag
