@@ -193,6 +193,13 @@ __device__ __forceinline__ SweepTexel sweep_texel_global(__amdgpu_buffer_rsrc_t 
 // [-2, W] x [-2, H]; columns -2 and W (rows -2 and H) hold all-zero texels, so clamping a sample's coordinates
 // into the box reproduces "no contribution" for everything outside the image.
 struct SweepBox { int rx0, ry0, rw, rh; };
+#ifdef SWEEP_TIMELINE
+// debug builds (tools/k1_bench.hip -DSWEEP_TIMELINE): s_memtime of wave 0 / wave 15 of workgroup 0 at the stations of its first tiles
+__device__ unsigned long long sweep_tl[2][64];
+#define SWEEP_TL(i) do { if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == SWEEP_TH - 1) && tlp + (i) < 64) sweep_tl[wave ? 1 : 0][tlp + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SWEEP_TL(i) do { } while (0)
+#endif
 #ifdef SWEEP_STATS
 __device__ unsigned int sweep_stats[4];     // debug builds only: workgroups, staged boxes, octets gathered from global, box texels
 #endif
@@ -332,7 +339,11 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
     Unit cur = decode(min(unit, nunits - 1));
     if (unit < nunits) tile_loads(cur, hkv, refv);
 
+#ifdef SWEEP_TIMELINE
+    int tlp = 0;
+#endif
     for (int parity = 0; unit < nunits; parity ^= 1) {
+        SWEEP_TL(0);                                                        // tile start
         // the ticket of the unit after this one travels while wave 0 works out the footprints
         int ticket = unit + (int)gridDim.x;                                 // without a queue: a fixed stride
         if (tid == 0 && a.queue) ticket = (int)gridDim.x + (int)atomicAdd(a.queue, 1u);
@@ -456,7 +467,9 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
             }
             if (lane == 0) { hdr[2 * parity] = level; hdr[2 * parity + 1] = ticket; }
         }
+        SWEEP_TL(1);                                                        // footprints done (wave 0) / waiting (others)
         __syncthreads();   // groups parked; every wave has left the previous tile (its box is free)
+        SWEEP_TL(2);
         const int level = __builtin_amdgcn_readfirstlane(hdr[2 * parity]);
         const int next_unit = __builtin_amdgcn_readfirstlane(hdr[2 * parity + 1]);
         const int ngroups = (ocnt + (1 << level) - 1) >> level;
@@ -495,6 +508,7 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
                 // ---- stage the box: rh rows of rw texels + one halo column, as items i = r (rw + 1) + c dealt 63 per
                 // wave pass (lane 63 repeats the next pass' first item: it only feeds lane 62).  A lane loads column c of
                 // image rows y and y + 1, column c + 1 comes from the next lane.  All loads of the box are issued first.
+                if (g == 0) SWEEP_TL(3);                                         // first box: staging starts
                 if (g > 0) __syncthreads();                                      // every wave is done with the previous box
                 const int pitch = bx.rw + 1, n = pitch * bx.rh;
                 const float inv_pitch = 1.0f / (float)pitch;
@@ -536,7 +550,9 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
                         tb[0] = t.u0; tb[1] = t.u1; tb[2] = t.u2;
                     }
                 }
+                if (g == 0) SWEEP_TL(4);                                         // first box: texels written
                 __syncthreads();
+                if (g == 0) SWEEP_TL(5);
             } else {                                                             // whole zero-extended image as the "box"
                 bx.rx0 = -2; bx.ry0 = -2; bx.rw = W + 3; bx.rh = H + 3;
             }
@@ -590,6 +606,10 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
             const sw_f16x8 h = {(_Float16)rr, (_Float16)rg, (_Float16)rb, 0, 0, 0, 0, 0};
             *reinterpret_cast<sw_f16x8*>(optr) = h;
         }
+        SWEEP_TL(6);                                                        // tile done
+#ifdef SWEEP_TIMELINE
+        tlp += 8;
+#endif
         unit = next_unit;
     }
     // every workgroup draws exactly one ticket beyond the last unit; the last one to leave rearms the counters

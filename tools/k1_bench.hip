@@ -104,6 +104,12 @@ int main(int argc, char** argv) {
         }
     }
     printf("   check: layouts mismatching %zu | vs float64 closed form (%d pairs): max %.3e  mean %.3e  >1e-3: %zu of %zu\n", nmis, ncheck, emax, esum / (ecnt + 1e-9), nbig, ecnt);
+#ifdef SWEEP_TIMELINE
+    { unsigned long long tl[2][64]; hipMemcpyFromSymbol(tl, HIP_SYMBOL(sweep_tl), sizeof(tl));
+      for (int w = 0; w < 2; ++w) for (int t = 0; t < 3; ++t) { const unsigned long long* q = tl[w] + 8 * t;
+        printf("   timeline wave %2d tile %d (cycles of the 100 MHz counter x 24 ~ shader cycles): footprints %5lld  barrier %5lld  to staging %5lld  stage first box %5lld  barrier %5lld  rest of the tile (sweeps, further boxes) %6lld  | tile %6lld\n",
+               w ? SWEEP_TH - 1 : 0, t, (long long)(q[1] - q[0]), (long long)(q[2] - q[1]), (long long)(q[3] - q[2]), (long long)(q[4] - q[3]), (long long)(q[5] - q[4]), (long long)(q[6] - q[5]), (long long)(q[6] - q[0])); } }
+#endif
 #ifdef SWEEP_STATS
     { unsigned int st[4]; hipMemcpyFromSymbol(st, HIP_SYMBOL(sweep_stats), 16); const double nl = 5 + iters + 1;   // launches so far
       printf("   per launch: workgroups %.0f, boxes staged %.0f, octets gathered from global %.0f, texels per box %.0f\n", st[0] / nl, st[1] / nl, st[2] / nl, (double)st[3] / (st[1] + 1e-9)); }
