@@ -4,6 +4,11 @@
 // Every run compares the c4 output of pair 0 .. NCHECK-1 with a float64 closed-form evaluation on the host
 // (explicit per-corner zero padding), and the NCHW layout with the c4 layout bit for bit.
 #include "../cnmnet_amd/csrc/planesweep.hip"
+#ifdef K1_NO_QUEUE
+#define K1_WS nullptr   // fixed tile stride instead of the ticket queue
+#else
+#define K1_WS dws
+#endif
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
@@ -56,7 +61,7 @@ int main(int argc, char** argv) {
     hipMemset(dout, 0xff, outn * 4); hipMemset(dvol, 0xff, voln * 4);
     int nb = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, planesweep_kernel<1>, SWEEP_NT, 0);
     for (int i = 0; i < 5; ++i) {
-        const int rc = cnm_planesweep_cat_c4_f32(dref, dsrc, dh, dout, dws, wsn, B, S, H, W, D, 0.1, 3.0, nullptr);
+        const int rc = cnm_planesweep_cat_c4_f32(dref, dsrc, dh, dout, K1_WS, wsn, B, S, H, W, D, 0.1, 3.0, nullptr);
         if (rc != 0) { printf("launch failed: %d\n", rc); return 1; }
     }
     if (hipDeviceSynchronize() != hipSuccess) { printf("kernel fault: %s\n", hipGetErrorString(hipGetLastError())); return 1; }
@@ -66,7 +71,7 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int iters = 50;
     hipEventRecord(e0);
-    for (int i = 0; i < iters; ++i) cnm_planesweep_cat_c4_f32(dref, dsrc, dh, dout, dws, wsn, B, S, H, W, D, 0.1, 3.0, nullptr);
+    for (int i = 0; i < iters; ++i) cnm_planesweep_cat_c4_f32(dref, dsrc, dh, dout, K1_WS, wsn, B, S, H, W, D, 0.1, 3.0, nullptr);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= iters;
     cnm_planesweep_volume_nchw_f32(dref, dsrc, dh, dvol, dws, wsn, B, S, H, W, D, 0.1, 3.0, nullptr);
