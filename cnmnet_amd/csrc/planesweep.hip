@@ -509,7 +509,6 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
                 // wave pass (lane 63 repeats the next pass' first item: it only feeds lane 62).  A lane loads column c of
                 // image rows y and y + 1, column c + 1 comes from the next lane.  All loads of the box are issued first.
                 if (g == 0) SWEEP_TL(3);                                         // first box: staging starts
-                if (g > 0) __syncthreads();                                      // every wave is done with the previous box
                 const int pitch = bx.rw + 1, n = pitch * bx.rh;
                 const float inv_pitch = 1.0f / (float)pitch;
                 const int origin4 = (bx.ry0 * W + bx.rx0) * 4;                // byte offset of box texel (0,0) in a channel plane
@@ -536,6 +535,9 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
                         p1[k][ch] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, o1, ch * chan_bytes, 0));
                     }
                 }
+                // the loads of this box travel while the slower waves finish the previous one (the waves of a tile end their sweeps
+                // 2500 - 3000 cycles apart: -DSWEEP_TIMELINE)
+                if (g > 0) __syncthreads();                                      // every wave is done with the previous box
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if (k * SWEEP_TH * 63 >= n) break;
