@@ -33,11 +33,11 @@ def _sync_workspace(device):
 
 
 _BN_WS = {}     # (device, stream) -> fp64 sum workspace of the BatchNorm kernels: zero between calls (the kernels clear what they read)
-_BN_WS_DOUBLES = 8 * 512          # 8 per channel group: up to 2048 channels
+_BN_WS_DOUBLES = 8 * 512 * 4      # 8 per channel group and statistics group: up to 2048 channels x 4 groups
 
 
-def _bn_workspace(device, G):
-    if 8 * G > _BN_WS_DOUBLES:
+def _bn_workspace(device, G, groups=1):
+    if 8 * G * groups > _BN_WS_DOUBLES:
         raise _lib.EngineError("BatchNorm over %d channel groups: workspace too small" % G)
     key = (str(device), torch.cuda.current_stream(device).cuda_stream)
     ws = _BN_WS.get(key)
@@ -282,23 +282,24 @@ class BatchNormReLUC4(torch.autograd.Function):
     """nn.BatchNorm2d in train mode followed (optionally) by ReLU; running stats updated in place."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, relu, num_batches_tracked=None):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, relu, num_batches_tracked=None, groups=1):
+        """groups > 1: sample n takes the batch statistics of the samples n' = n (mod groups) -- `groups` separate calls in one."""
         x = x.contiguous()
         N, G, H, W, _ = x.shape
         C = gamma.numel()
         lib, dev = _lib.load(), x.device
         y = torch.empty_like(x)
-        mean = torch.empty(C, device=dev, dtype=torch.float32)
+        mean = torch.empty(groups * C, device=dev, dtype=torch.float32)
         invstd = torch.empty_like(mean)
         with torch.cuda.device(dev):
-            _lib.check(lib.cnm_bn_train_forward_z_c4_f32(
+            _lib.check(lib.cnm_bn_train_forward_zg_c4_f32(
                 x.data_ptr(), gamma.detach().contiguous().data_ptr(), beta.detach().contiguous().data_ptr(),
                 running_mean.data_ptr() if running_mean is not None else 0,
                 running_var.data_ptr() if running_var is not None else 0, float(momentum), float(eps), int(relu),
-                y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _bn_workspace(dev, G).data_ptr(),
-                num_batches_tracked.data_ptr() if num_batches_tracked is not None else 0, N, C, H, W, _s()))
+                y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _bn_workspace(dev, G, groups).data_ptr(),
+                num_batches_tracked.data_ptr() if num_batches_tracked is not None else 0, N, C, H, W, groups, _s()))
         ctx.save_for_backward(x, y, gamma, mean, invstd)
-        ctx.relu = relu
+        ctx.relu, ctx.groups = relu, groups
         return y
 
     @staticmethod
@@ -311,10 +312,10 @@ class BatchNormReLUC4(torch.autograd.Function):
         dx = torch.empty_like(x)
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
         with torch.cuda.device(dev):
-            _lib.check(lib.cnm_bn_train_backward_z_c4_f32(
+            _lib.check(lib.cnm_bn_train_backward_zg_c4_f32(
                 x.data_ptr(), y.data_ptr(), dy.data_ptr(), gamma.detach().contiguous().data_ptr(), mean.data_ptr(), invstd.data_ptr(),
-                int(ctx.relu), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), _bn_workspace(dev, G).data_ptr(), N, C, H, W, _s()))
-        return dx, dgamma, dbeta, None, None, None, None, None, None
+                int(ctx.relu), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), _bn_workspace(dev, G, ctx.groups).data_ptr(), N, C, H, W, ctx.groups, _s()))
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None
 
 
 class Upsample2xC4(torch.autograd.Function):
@@ -404,12 +405,12 @@ class InverseWarpFn(torch.autograd.Function):
 
 
 # ---------------------------------------------------------------- building blocks used by the modules in train mode
-def conv_bn_relu(x, conv, bn, rot=0):
+def conv_bn_relu(x, conv, bn, rot=0, groups=1):
     """Conv2d(bias=False) -> BatchNorm2d(train) -> ReLU, as the reference's layer builders
-    (depthNet_model.py:19-112) in training mode."""
+    (depthNet_model.py:19-112) in training mode.  groups: statistics groups of the BatchNorm (sample n -> group n % groups)."""
     y = ConvC4.apply(x, conv.weight, conv.stride[0], rot)
     # num_batches_tracked (int64 on the device) is incremented by the forward kernel
-    return BatchNormReLUC4.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, True, bn.num_batches_tracked)
+    return BatchNormReLUC4.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, True, bn.num_batches_tracked, groups)
 
 
 def head(x, conv, scale):

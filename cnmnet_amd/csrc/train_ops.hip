@@ -635,12 +635,15 @@ extern "C" int cnm_conv5x5_wgrad_winograd_c4_f32(const float* x, int Gx_total, i
 // ------------------------------------------------------------------ BatchNorm2d (train mode) + ReLU on c4
 // stats[c] = (sum, sum of squares) in fp64; mean/invstd derived from them (biased variance for the
 // normalisation, unbiased for the running update -- torch.nn.BatchNorm2d defaults).
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int N, int G, int HW, double* __restrict__ stats) {
-    const int g = blockIdx.x;
-    const long long total = (long long)N * HW;
+// S statistics groups (blockIdx.z): sample n belongs to group n % S -- the S sources of a frame processed as ONE batch keep the
+// batch statistics of S separate forward calls (reference train.py:164-167 calls depthNet once per source).  S = 1: plain BatchNorm.
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int N, int G, int HW, double* __restrict__ stats, int S) {
+    const int g = blockIdx.x, grp = blockIdx.z;
+    const long long total = (long long)((N - grp + S - 1) / S) * HW;
+    stats += (size_t)grp * 8 * G;
     double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
     for (long long i = (long long)blockIdx.y * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.y * blockDim.x) {
-        const int n = (int)(i / HW), pix = (int)(i - (long long)n * HW);
+        const int n = (int)(i / HW) * S + grp, pix = (int)(i % HW);
         const float4 v = *reinterpret_cast<const float4*>(x + c4_offset(n, G, g, HW, pix));
         s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
         q[0] += (double)v.x * v.x; q[1] += (double)v.y * v.y; q[2] += (double)v.z * v.z; q[3] += (double)v.w * v.w;
@@ -665,39 +668,48 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
 // launch per layer); tracked: nn.BatchNorm2d.num_batches_tracked, incremented here instead of by a launch of its own
 __global__ void bn_finalize_kernel(double* __restrict__ stats, int C, double count, float eps, float momentum,
                                    float* __restrict__ mean, float* __restrict__ invstd,
-                                   float* __restrict__ running_mean, float* __restrict__ running_var, int rezero, long long* __restrict__ tracked) {
+                                   float* __restrict__ running_mean, float* __restrict__ running_var, int rezero, long long* __restrict__ tracked,
+                                   int S, int N, int HW) {
+    // count: unused with groups (kept for the signature); group grp holds ceil((N - grp) / S) samples.  The running statistics take the
+    // groups' updates one after the other, in source order, as S forward calls would
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && tracked) *tracked += 1;
-    if (c >= C) {
-        if (rezero && c < 4 * ((C + 3) / 4)) { stats[2 * c] = 0.0; stats[2 * c + 1] = 0.0; }   // the padding channels of the last group
-        return;
-    }
-    const double mu = stats[2 * c] / count;
-    double var = stats[2 * c + 1] / count - mu * mu;
-    if (rezero) { stats[2 * c] = 0.0; stats[2 * c + 1] = 0.0; }
-    if (var < 0) var = 0;
-    mean[c] = (float)mu; invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-    if (running_mean) {
-        const double unbiased = count > 1 ? var * count / (count - 1.0) : var;
-        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
-        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+    if (c == 0 && tracked) *tracked += S;
+    const int Cp = 4 * ((C + 3) / 4);
+    for (int grp = 0; grp < S; ++grp) {
+        double* st = stats + (size_t)grp * 2 * Cp;
+        if (c >= C) {
+            if (rezero && c < Cp) { st[2 * c] = 0.0; st[2 * c + 1] = 0.0; }   // the padding channels of the last group
+            continue;
+        }
+        const double cnt = S == 1 ? count : (double)((N - grp + S - 1) / S) * HW;
+        const double mu = st[2 * c] / cnt;
+        double var = st[2 * c + 1] / cnt - mu * mu;
+        if (rezero) { st[2 * c] = 0.0; st[2 * c + 1] = 0.0; }
+        if (var < 0) var = 0;
+        mean[grp * C + c] = (float)mu; invstd[grp * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (running_mean) {
+            const double unbiased = cnt > 1 ? var * cnt / (cnt - 1.0) : var;
+            running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
+            running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+        }
     }
 }
 
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, int C, int relu,
-                                                       float* __restrict__ y, int N, int G, int HW) {
+                                                       float* __restrict__ y, int N, int G, int HW, int S) {
     const long long total = (long long)N * G * HW;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-        const int g = (int)((idx / HW) % G);
+        const long long ng = idx / HW;
+        const int g = (int)(ng % G), so = S == 1 ? 0 : (int)((ng / G) % S) * C;        // statistics of the sample's group
         const float4 v = *reinterpret_cast<const float4*>(x + idx * 4);
         float in[4] = {v.x, v.y, v.z, v.w}, o[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int c = 4 * g + j;
             float r = 0.f;
-            if (c < C) { r = (in[j] - mean[c]) * invstd[c] * gamma[c] + beta[c]; if (relu) r = fmaxf(r, 0.f); }
+            if (c < C) { r = (in[j] - mean[so + c]) * invstd[so + c] * gamma[c] + beta[c]; if (relu) r = fmaxf(r, 0.f); }
             o[j] = r;
         }
         *reinterpret_cast<float4*>(y + idx * 4) = make_float4(o[0], o[1], o[2], o[3]);
@@ -708,15 +720,16 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                             const float* __restrict__ dy, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, int C, int relu,
-                                                            int N, int G, int HW, double* __restrict__ sums) {
-    const int g = blockIdx.x;
-    const long long total = (long long)N * HW;
+                                                            int N, int G, int HW, double* __restrict__ sums, int S) {
+    const int g = blockIdx.x, grp = blockIdx.z;
+    const long long total = (long long)((N - grp + S - 1) / S) * HW;
+    sums += (size_t)grp * 8 * G;
     double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
     float mu[4], is[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { const int c = 4 * g + j; mu[j] = c < C ? mean[c] : 0.f; is[j] = c < C ? invstd[c] : 0.f; }
+    for (int j = 0; j < 4; ++j) { const int c = 4 * g + j; mu[j] = c < C ? mean[grp * C + c] : 0.f; is[j] = c < C ? invstd[grp * C + c] : 0.f; }
     for (long long i = (long long)blockIdx.y * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.y * blockDim.x) {
-        const int n = (int)(i / HW), pix = (int)(i - (long long)n * HW);
+        const int n = (int)(i / HW) * S + grp, pix = (int)(i % HW);
         const size_t o = c4_offset(n, G, g, HW, pix);
         const float4 xv = *reinterpret_cast<const float4*>(x + o), yv = *reinterpret_cast<const float4*>(y + o);
         const float4 dv = *reinterpret_cast<const float4*>(dy + o);
@@ -748,10 +761,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ dy, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                            const double* __restrict__ sums, double count, int C, int relu,
-                                                           float* __restrict__ dx, int N, int G, int HW) {
+                                                           float* __restrict__ dx, int N, int G, int HW, int S) {
     const long long total = (long long)N * G * HW;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-        const int g = (int)((idx / HW) % G);
+        const long long ng = idx / HW;
+        const int g = (int)(ng % G), grp = S == 1 ? 0 : (int)((ng / G) % S), so = grp * C;
+        const double* sg = sums + (size_t)grp * 8 * G;
+        const double cnt = S == 1 ? count : (double)((N - grp + S - 1) / S) * HW;
         const float4 xv = *reinterpret_cast<const float4*>(x + idx * 4), yv = *reinterpret_cast<const float4*>(y + idx * 4);
         const float4 dv = *reinterpret_cast<const float4*>(dy + idx * 4);
         const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ys[4] = {yv.x, yv.y, yv.z, yv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
@@ -762,9 +778,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             float r = 0.f;
             if (c < C) {
                 const float d = (relu && !(ys[j] > 0.f)) ? 0.f : ds[j];
-                const float xh = (xs[j] - mean[c]) * invstd[c];
-                const float sd = (float)(sums[2 * c] / count), sq = (float)(sums[2 * c + 1] / count);
-                r = gamma[c] * invstd[c] * (d - sd - xh * sq);
+                const float xh = (xs[j] - mean[so + c]) * invstd[so + c];
+                const float sd = (float)(sg[2 * c] / cnt), sq = (float)(sg[2 * c + 1] / cnt);
+                r = gamma[c] * invstd[so + c] * (d - sd - xh * sq);
             }
             o[j] = r;
         }
@@ -772,10 +788,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     }
 }
 
-__global__ void bn_param_grad_kernel(double* __restrict__ sums, int C, float* __restrict__ dgamma, float* __restrict__ dbeta, int rezero) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < C) { dbeta[c] = (float)sums[2 * c]; dgamma[c] = (float)sums[2 * c + 1]; }
-    if (rezero && c < 4 * ((C + 3) / 4)) { sums[2 * c] = 0.0; sums[2 * c + 1] = 0.0; }
+__global__ void bn_param_grad_kernel(double* __restrict__ sums, int C, float* __restrict__ dgamma, float* __restrict__ dbeta, int rezero, int S) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, Cp = 4 * ((C + 3) / 4);
+    if (c >= Cp) return;
+    float db = 0.f, dg = 0.f;                                               // the groups' parameter gradients add in source order, in fp32, as S backward passes accumulate them
+    for (int grp = 0; grp < S; ++grp) {
+        double* sg = sums + (size_t)grp * 2 * Cp;
+        db += (float)sg[2 * c]; dg += (float)sg[2 * c + 1];
+        if (rezero) { sg[2 * c] = 0.0; sg[2 * c + 1] = 0.0; }
+    }
+    if (c < C) { dbeta[c] = db; dgamma[c] = dg; }
 }
 
 // The fp64 sum buffers are cleared by a kernel, not hipMemsetAsync: captured into a HIP graph (TrainStepWoNormal(graph=True))
@@ -790,15 +812,15 @@ static int bn_grid_y(int N, int HW) { long long t = ((long long)N * HW + 255) / 
 static int bn_forward(const float* x, const float* gamma, const float* beta,
                       float* running_mean, float* running_var, float momentum, float eps, int relu,
                       float* y, float* save_mean, float* save_invstd, double* stats_ws, int zeroed, long long* tracked,
-                      int N, int C, int H, int W, void* stream) {
-    CNM_REQUIRE(x && gamma && beta && y && save_mean && save_invstd && stats_ws && N > 0 && C > 0 && H > 0 && W > 0, CNM_ERR_BAD_ARG);
+                      int N, int C, int H, int W, void* stream, int S = 1) {
+    CNM_REQUIRE(x && gamma && beta && y && save_mean && save_invstd && stats_ws && N > 0 && C > 0 && H > 0 && W > 0 && S >= 1 && S <= N, CNM_ERR_BAD_ARG);
     const int G = (C + 3) / 4, HW = H * W;
     hipStream_t s = cnm_stream(stream);
-    if (!zeroed) bn_zero_kernel<<<cnm_ceil_div(8 * G, 256), 256, 0, s>>>(stats_ws, 8 * G);
-    bn_stats_kernel<<<dim3(G, bn_grid_y(N, HW)), 256, 0, s>>>(x, N, G, HW, stats_ws);
-    bn_finalize_kernel<<<cnm_ceil_div(4 * G, 256), 256, 0, s>>>(stats_ws, C, (double)N * HW, eps, momentum, save_mean, save_invstd, running_mean, running_var, zeroed, tracked);
+    if (!zeroed) bn_zero_kernel<<<cnm_ceil_div(8 * G * S, 256), 256, 0, s>>>(stats_ws, 8 * G * S);
+    bn_stats_kernel<<<dim3(G, bn_grid_y((N + S - 1) / S, HW), S), 256, 0, s>>>(x, N, G, HW, stats_ws, S);
+    bn_finalize_kernel<<<cnm_ceil_div(4 * G, 256), 256, 0, s>>>(stats_ws, C, (double)N * HW, eps, momentum, save_mean, save_invstd, running_mean, running_var, zeroed, tracked, S, N, HW);
     const long long total = (long long)N * G * HW;
-    bn_apply_kernel<<<(int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384), 256, 0, s>>>(x, save_mean, save_invstd, gamma, beta, C, relu, y, N, G, HW);
+    bn_apply_kernel<<<(int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384), 256, 0, s>>>(x, save_mean, save_invstd, gamma, beta, C, relu, y, N, G, HW, S);
     CNM_LAUNCH_CHECK();
     return CNM_OK;
 }
@@ -821,16 +843,16 @@ extern "C" int cnm_bn_train_forward_z_c4_f32(const float* x, const float* gamma,
 static int bn_backward(const float* x, const float* y, const float* dy, const float* gamma,
                        const float* save_mean, const float* save_invstd, int relu,
                        float* dx, float* dgamma, float* dbeta, double* sums_ws, int zeroed,
-                       int N, int C, int H, int W, void* stream) {
-    CNM_REQUIRE(x && y && dy && gamma && save_mean && save_invstd && dx && dgamma && dbeta && sums_ws && N > 0 && C > 0, CNM_ERR_BAD_ARG);
+                       int N, int C, int H, int W, void* stream, int S = 1) {
+    CNM_REQUIRE(x && y && dy && gamma && save_mean && save_invstd && dx && dgamma && dbeta && sums_ws && N > 0 && C > 0 && S >= 1 && S <= N, CNM_ERR_BAD_ARG);
     const int G = (C + 3) / 4, HW = H * W;
     hipStream_t s = cnm_stream(stream);
-    if (!zeroed) bn_zero_kernel<<<cnm_ceil_div(8 * G, 256), 256, 0, s>>>(sums_ws, 8 * G);
-    bn_bwd_reduce_kernel<<<dim3(G, bn_grid_y(N, HW)), 256, 0, s>>>(x, y, dy, save_mean, save_invstd, C, relu, N, G, HW, sums_ws);
+    if (!zeroed) bn_zero_kernel<<<cnm_ceil_div(8 * G * S, 256), 256, 0, s>>>(sums_ws, 8 * G * S);
+    bn_bwd_reduce_kernel<<<dim3(G, bn_grid_y((N + S - 1) / S, HW), S), 256, 0, s>>>(x, y, dy, save_mean, save_invstd, C, relu, N, G, HW, sums_ws, S);
     const long long total = (long long)N * G * HW;
     bn_bwd_apply_kernel<<<(int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384), 256, 0, s>>>(
-        x, y, dy, save_mean, save_invstd, gamma, sums_ws, (double)N * HW, C, relu, dx, N, G, HW);
-    bn_param_grad_kernel<<<cnm_ceil_div(4 * G, 256), 256, 0, s>>>(sums_ws, C, dgamma, dbeta, zeroed);
+        x, y, dy, save_mean, save_invstd, gamma, sums_ws, (double)N * HW, C, relu, dx, N, G, HW, S);
+    bn_param_grad_kernel<<<cnm_ceil_div(4 * G, 256), 256, 0, s>>>(sums_ws, C, dgamma, dbeta, zeroed, S);
     CNM_LAUNCH_CHECK();
     return CNM_OK;
 }
@@ -846,6 +868,23 @@ extern "C" int cnm_bn_train_backward_z_c4_f32(const float* x, const float* y, co
                                               float* dx, float* dgamma, float* dbeta, double* zero_ws,
                                               int N, int C, int H, int W, void* stream) {
     return bn_backward(x, y, dy, gamma, save_mean, save_invstd, relu, dx, dgamma, dbeta, zero_ws, 1, N, C, H, W, stream);
+}
+
+// The same with `groups` statistics groups: sample n is normalised with the batch statistics of the samples n' = n (mod groups) -- a
+// batch that interleaves the `groups` sources of every frame (pair p = b * groups + s) then computes exactly what `groups` separate
+// calls, one per source, compute (reference train.py:164-167), running statistics and num_batches_tracked updated `groups` times in
+// source order.  save_mean / save_invstd: groups * C floats; zero_ws: 8 * ceil(C / 4) * groups doubles.
+extern "C" int cnm_bn_train_forward_zg_c4_f32(const float* x, const float* gamma, const float* beta,
+                                              float* running_mean, float* running_var, float momentum, float eps, int relu,
+                                              float* y, float* save_mean, float* save_invstd, double* zero_ws, long long* num_batches_tracked,
+                                              int N, int C, int H, int W, int groups, void* stream) {
+    return bn_forward(x, gamma, beta, running_mean, running_var, momentum, eps, relu, y, save_mean, save_invstd, zero_ws, 1, num_batches_tracked, N, C, H, W, stream, groups);
+}
+extern "C" int cnm_bn_train_backward_zg_c4_f32(const float* x, const float* y, const float* dy, const float* gamma,
+                                               const float* save_mean, const float* save_invstd, int relu,
+                                               float* dx, float* dgamma, float* dbeta, double* zero_ws,
+                                               int N, int C, int H, int W, int groups, void* stream) {
+    return bn_backward(x, y, dy, gamma, save_mean, save_invstd, relu, dx, dgamma, dbeta, zero_ws, 1, N, C, H, W, stream, groups);
 }
 
 // ------------------------------------------------------------------ adjoint of the bilinear x2 upsample

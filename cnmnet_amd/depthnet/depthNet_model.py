@@ -168,14 +168,14 @@ class _EngineNet(nn.Module):
             raise _lib.EngineError("module parameters are on %s but inputs are on %s" % (p.device, tensors[0].device))
 
 
-def _down_train(x, seq, rot=0):
+def _down_train(x, seq, rot=0, groups=1):
     """down_conv_layer in train mode: conv s1 -> BN -> ReLU -> conv s2 -> BN -> ReLU (reference :19-39)."""
-    return ag.conv_bn_relu(ag.conv_bn_relu(x, seq[0], seq[1], rot), seq[3], seq[4])
+    return ag.conv_bn_relu(ag.conv_bn_relu(x, seq[0], seq[1], rot, groups), seq[3], seq[4], 0, groups)
 
 
-def _up_train(x, seq):
+def _up_train(x, seq, groups=1):
     """up_conv_layer in train mode: bilinear x2 -> conv -> BN -> ReLU (reference :91-101)."""
-    return ag.conv_bn_relu(ag.Upsample2xC4.apply(x), seq[1], seq[2])
+    return ag.conv_bn_relu(ag.Upsample2xC4.apply(x), seq[1], seq[2], 0, groups)
 
 
 class depthNet(_EngineNet):
@@ -244,29 +244,52 @@ class depthNet(_EngineNet):
                 ws.data_ptr(), ws.numel(), B, S, H, W, torch.cuda.current_stream().cuda_stream))
         return disp, feat
 
-    def _forward_train(self, ref, src, ref_cam, src_cam):
+    def _forward_train(self, ref, src, ref_cam, src_cam, per_source_statistics=False):
         """Train mode (batch-statistics BatchNorm, autograd): the same graph as reference :226-263 built
-        from cnmnet_amd.autograd Functions; the cost volume is a constant of the graph."""
+        from cnmnet_amd.autograd Functions; the cost volume is a constant of the graph.
+        per_source_statistics: every BatchNorm normalises pair p = b * S + s with the statistics of source s over the batch (and updates
+        the running statistics once per source, in order) -- S calls with one source each, as the reference makes them, in one pass."""
         s = float(self.idepth_scale)
+        gr = src.shape[1] if per_source_statistics else 1
         with torch.no_grad():
             hmkt = ops.homography_terms(ref_cam, src_cam)
             x0 = ops.plane_sweep_cat_c4(ref, src, hmkt, s, self.planes)
-        c1 = _down_train(x0, self.conv1, rot=3)
-        c2 = _down_train(c1, self.conv2); c3 = _down_train(c2, self.conv3)
-        c4 = _down_train(c3, self.conv4); c5 = _down_train(c4, self.conv5)
-        i5 = ag.conv_bn_relu(torch.cat((_up_train(c5, self.upconv5), c4), 1), self.iconv5[0], self.iconv5[1])
-        i4 = ag.conv_bn_relu(torch.cat((_up_train(i5, self.upconv4), c3), 1), self.iconv4[0], self.iconv4[1])
+        cbr = lambda x, seq: ag.conv_bn_relu(x, seq[0], seq[1], 0, gr)
+        c1 = _down_train(x0, self.conv1, 3, gr)
+        c2 = _down_train(c1, self.conv2, 0, gr); c3 = _down_train(c2, self.conv3, 0, gr)
+        c4 = _down_train(c3, self.conv4, 0, gr); c5 = _down_train(c4, self.conv5, 0, gr)
+        i5 = cbr(torch.cat((_up_train(c5, self.upconv5, gr), c4), 1), self.iconv5)
+        i4 = cbr(torch.cat((_up_train(i5, self.upconv4, gr), c3), 1), self.iconv4)
         d4 = ag.head(i4, self.disp4[0], s)
         g4 = ag.scalar_maps_to_group(ag.nearest_up2(d4))
-        i3 = ag.conv_bn_relu(torch.cat((_up_train(i4, self.upconv3), c2, g4), 1), self.iconv3[0], self.iconv3[1])
+        i3 = cbr(torch.cat((_up_train(i4, self.upconv3, gr), c2, g4), 1), self.iconv3)
         d3 = ag.head(i3, self.disp3[0], s)
         g3 = ag.scalar_maps_to_group(ag.nearest_up2(d3))
-        i2 = ag.conv_bn_relu(torch.cat((_up_train(i3, self.upconv2), c1, g3), 1), self.iconv2[0], self.iconv2[1])
+        i2 = cbr(torch.cat((_up_train(i3, self.upconv2, gr), c1, g3), 1), self.iconv2)
         d2 = ag.head(i2, self.disp2[0], s)
         g2 = ag.scalar_maps_to_group(ag.nearest_up2(d2))
-        i1 = ag.conv_bn_relu(torch.cat((_up_train(i2, self.upconv1), g2), 1), self.iconv1[0], self.iconv1[1])
+        i1 = cbr(torch.cat((_up_train(i2, self.upconv1, gr), g2), 1), self.iconv1)
         d1 = ag.head(i1, self.disp1[0], s)
         return [d1, d2, d3, d4], i1
+
+    def forward_sources(self, left_image, right_images, left_cam, right_cams):
+        """Train mode: depthNet(left, right_images[:, s], ...) for every source s, as S separate calls would compute them -- same
+        outputs, same BatchNorm running statistics, same gradients -- in ONE pass over B * S pairs (per-source BatchNorm statistics).
+        right_images [B,S,3,H,W], right_cams [B,S,2,4,4] -> [(disp list, iconv1 NCHW) for each source]."""
+        if not self.training or self.precision != "f32":
+            return [self.forward(left_image, right_images[:, s], left_cam, right_cams[:, s]) for s in range(right_images.shape[1])]
+        ops.idepth_range(self.idepth_scale)
+        self._require_gpu(left_image, right_images, left_cam, right_cams)
+        S = right_images.shape[1]
+        disp, feat = self._forward_train(left_image.contiguous(), right_images.contiguous(), left_cam.contiguous(), right_cams.contiguous(),
+                                         per_source_statistics=True)
+        out = []
+        for s in range(S):
+            f4 = feat[s::S]
+            iconv1 = ag.C4ToNCHW.apply(f4, 64)
+            iconv1._cnm_c4 = f4
+            out.append(([d[s::S] for d in disp], iconv1))
+        return out
 
     def getVolume(self, left_image, right_image, KRKiUV_T, KT_T):
         """Reference depthNet_model.py:185-224: plane-sweep L1 cost volume [B,planes,H,W] from what

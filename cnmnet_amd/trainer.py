@@ -34,6 +34,9 @@ class _step_scope:
         return False
 
 
+SOURCES_IN_ONE_PASS = True       # depthNet over both sources of a frame in one pass with per-source BatchNorm statistics (depthNet.forward_sources)
+
+
 class BucketedGradAllReduce:
     """Average gradients across ranks with bucketed, backward-overlapped all-reduces.
 
@@ -252,8 +255,13 @@ class TrainStepWoNormal:
         (loss to back-propagate, dict of logged terms)."""
         self.depth_net.train(); self.refine_net.train()
         gt_id, gt_d = disparities[:, 0], depths[:, 0]
-        p01, f01 = self.depth_net(rgbs[:, 0], rgbs[:, 1], cameras[:, 0], cameras[:, 1])     # :509-512
-        p02, f02 = self.depth_net(rgbs[:, 0], rgbs[:, 2], cameras[:, 0], cameras[:, 2])
+        if SOURCES_IN_ONE_PASS and hasattr(self.depth_net, "forward_sources"):
+            # the two depthNet calls of the reference as ONE pass over 2 B pairs whose BatchNorms keep per-source batch statistics:
+            # same outputs, running statistics and gradients (tests/test_gpu_training.py), convolutions at twice the batch
+            (p01, f01), (p02, f02) = self.depth_net.forward_sources(rgbs[:, 0], rgbs[:, 1:3], cameras[:, 0], cameras[:, 1:3])
+        else:
+            p01, f01 = self.depth_net(rgbs[:, 0], rgbs[:, 1], cameras[:, 0], cameras[:, 1])     # :509-512
+            p02, f02 = self.depth_net(rgbs[:, 0], rgbs[:, 2], cameras[:, 0], cameras[:, 2])
         idr, prob = self.refine_net(idepth01=p01[0], idepth02=p02[0], iconv01=f01, iconv02=f02)   # :517-520
         L = lambda a, b, w=None: _masked_l1(a, b, self.dist, w, self.exact)
         loss_idepth_1 = (L(p01[0], gt_id) + L(p02[0], gt_id)) * 0.5                          # :522-523
@@ -369,8 +377,11 @@ class TrainStep(TrainStepWoNormal):
         self.depth_net.train(); self.refine_net.train()
         gt_id, gt_d, gt_n = disparities[:, 0], depths[:, 0], normals[:, 0]
         gt_n_valid = gt_d > 0.1                                                              # :153
-        p01, f01 = self.depth_net(rgbs[:, 0], rgbs[:, 1], cameras[:, 0], cameras[:, 1])     # :164-167
-        p02, f02 = self.depth_net(rgbs[:, 0], rgbs[:, 2], cameras[:, 0], cameras[:, 2])
+        if SOURCES_IN_ONE_PASS and hasattr(self.depth_net, "forward_sources"):           # as in TrainStepWoNormal.losses
+            (p01, f01), (p02, f02) = self.depth_net.forward_sources(rgbs[:, 0], rgbs[:, 1:3], cameras[:, 0], cameras[:, 1:3])
+        else:
+            p01, f01 = self.depth_net(rgbs[:, 0], rgbs[:, 1], cameras[:, 0], cameras[:, 1])     # :164-167
+            p02, f02 = self.depth_net(rgbs[:, 0], rgbs[:, 2], cameras[:, 0], cameras[:, 2])
         idr, prob = self.refine_net(idepth01=p01[0], idepth02=p02[0], iconv01=f01, iconv02=f02)   # :172-175
         L = lambda a, b, w=None: _masked_l1(a, b, self.dist, w, self.exact)
         loss_idepth_1 = (L(p01[0], gt_id) + L(p02[0], gt_id)) * 0.5                          # :177-178

@@ -555,6 +555,20 @@ int cnm_bn_train_backward_z_c4_f32(const float* x, const float* y, const float* 
                                    float* dx, float* dgamma, float* dbeta, double* zero_ws,
                                    int N, int C, int H, int W, void* stream);
 
+/* ... with `groups` statistics groups: sample n is normalised with the batch statistics of the samples n' = n (mod groups).  A batch that
+ * interleaves the `groups` sources of every frame (pair p = b * groups + s) then computes exactly what `groups` separate calls, one per
+ * source, compute -- the reference calls depthNet once per source (train.py:164-167) -- with the running statistics and
+ * num_batches_tracked updated `groups` times in source order.  save_mean / save_invstd: groups * C floats; zero_ws: 8 * ceil(C/4) *
+ * groups doubles, zero on entry, left zero. */
+int cnm_bn_train_forward_zg_c4_f32(const float* x, const float* gamma, const float* beta,
+                                   float* running_mean, float* running_var, float momentum, float eps, int relu,
+                                   float* y, float* save_mean, float* save_invstd, double* zero_ws, long long* num_batches_tracked,
+                                   int N, int C, int H, int W, int groups, void* stream);
+int cnm_bn_train_backward_zg_c4_f32(const float* x, const float* y, const float* dy, const float* gamma,
+                                    const float* save_mean, const float* save_invstd, int relu,
+                                    float* dx, float* dgamma, float* dbeta, double* zero_ws,
+                                    int N, int C, int H, int W, int groups, void* stream);
+
 /* Adjoint of cnm_upsample2x_c4_f32: dy [N,G,2H,2W,4] -> dx [N,G,H,W,4] (contiguous). */
 int cnm_upsample2x_backward_c4_f32(const float* dy, float* dx, int N, int G, int H, int W, void* stream);
 
