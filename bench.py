@@ -50,6 +50,22 @@ def load_weights(module, seed):
     return module.eval()
 
 
+def training_nets(dev):
+    """The two nets of the training benches: the modules' own reference initialisation (Kaiming fan-out, depthNet_model.py:165-182), the
+    same on every rank, with the one-channel heads scaled down.  Left as initialised, a head (fan_out = 9: weight std 0.47 over 576
+    inputs) puts some inverse depths p = 3 sigmoid(y) near 1e-12, and the reference's loss -- which divides by p without a floor
+    (train.py:185-186) -- starts at 1e11 and overflows to NaN within two Adam steps, with two depthNet calls as with one pass over
+    both sources (tools/train_trace3.py); scaled, the synthetic run stays finite.  The arithmetic of a step does not depend on it."""
+    from cnmnet_amd.depthnet import depthNet, DepthRefineNet
+    torch.manual_seed(1)
+    nets = depthNet(3.0, PLANES), DepthRefineNet(32, 3.0)
+    for net in nets:
+        for m in net.modules():
+            if isinstance(m, torch.nn.Conv2d) and m.out_channels == 1:
+                m.weight.data.mul_(0.02)
+    return nets[0].to(dev), nets[1].to(dev)
+
+
 def event_ms(fn, iters, warm=2):
     """Average duration of fn() measured with HIP events on the current (= launch) stream."""
     for _ in range(warm):
@@ -517,7 +533,7 @@ def train_secondary(dev, B=4, steps=10):
     graph; samples/s between synchronisations."""
     from cnmnet_amd.depthnet import depthNet, DepthRefineNet
     from cnmnet_amd.trainer import TrainStep, synthetic_training_sample
-    step = TrainStep(load_weights(depthNet(3.0, PLANES), 1).to(dev), load_weights(DepthRefineNet(32, 3.0), 2).to(dev), k_size=KSIZE, graph=True)
+    step = TrainStep(*training_nets(dev), k_size=KSIZE, graph=True)
     s = {k: v.to(dev) for k, v in synthetic_training_sample(B, H, W, seed=7).items()}
     a = (s["rgbs"], s["cameras"], s["disparities"], s["depths"], s["normals"])
     for _ in range(3):                                   # the first call captures (its warm-up iterations are undone)
@@ -544,8 +560,7 @@ def train_mode(a, dev, dist, pg, backend, rank, world):
     from cnmnet_amd.trainer import TrainStep, synthetic_training_sample
     from cnmnet_amd import sharding
     B = a.samples_per_gpu
-    step = TrainStep(load_weights(depthNet(3.0, PLANES), 1).to(dev), load_weights(DepthRefineNet(32, 3.0), 2).to(dev), k_size=KSIZE,
-                     dist=dist, group=pg, graph=bool(a.graph))
+    step = TrainStep(*training_nets(dev), k_size=KSIZE, dist=dist, group=pg, graph=bool(a.graph))
     smp = {k: v.to(dev) for k, v in synthetic_training_sample(B, H, W, seed=7 + rank).items()}
     args = (smp["rgbs"], smp["cameras"], smp["disparities"], smp["depths"], smp["normals"])
 

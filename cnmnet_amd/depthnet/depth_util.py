@@ -3,6 +3,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from .losses import total, row_totals, mean_all
 
 
 def get_pixel_coordinates(height, width, device=None):
@@ -80,10 +81,10 @@ def _plane_normals_autograd(normal, instance_segs, planes_num):
         for i in range(int(planes_num[b])):
             m = instance_segs[b, i].to(normal.device).bool().unsqueeze(-1)       # [H,W,1]
             mf = m.to(nb.dtype)
-            mean = (nb * mf).reshape(-1, 3).sum(0) / mf.sum()                    # :221-225
+            mean = row_totals((nb * mf).permute(2, 0, 1)) / total(mf)           # :221-225
             reg = mean.expand(H, W, 3)
             orig = torch.where(m, nb, torch.zeros_like(nb))                      # :228
-            loss = loss + (1 - torch.nn.functional.cosine_similarity(reg.reshape(-1, 3), orig.reshape(-1, 3), dim=1)).mean()   # :230-233
+            loss = loss + mean_all(1 - torch.nn.functional.cosine_similarity(reg.reshape(-1, 3), orig.reshape(-1, 3), dim=1))   # :230-233
             nb = torch.where(m, reg, nb)                                         # :235-236
         rows.append(nb)
     return torch.stack(rows, 0).permute(0, 3, 1, 2), loss

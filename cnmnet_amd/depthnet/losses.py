@@ -17,6 +17,32 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+def total(x):
+    """Sum of all elements (integer for a bool mask) as rows of 256, then the row sums, until at most 1024 values are left.
+    Why not x.sum(): torch splits a reduction to few outputs over several workgroups that meet through a scratch block cleared
+    by cudaMemsetAsync; replayed inside a HIP graph (TrainStep(graph=True)) such reductions returned stale values after a
+    device-wide synchronise between replays (tools/graph_sync_probe.py).  One workgroup per output needs
+    no scratch.  Ragged sizes (not a multiple of 256) are small ones and take the one launch."""
+    x = x.reshape(-1)
+    if x.dtype == torch.bool:
+        x = x.to(torch.int32)
+    while x.numel() > 1024 and x.numel() % 256 == 0:
+        x = x.view(-1, 256).sum(1)
+    return x.sum()
+
+
+def row_totals(x):
+    """[B, ...] -> [B]: per-sample sums, staged as `total` is."""
+    x = x.flatten(1)
+    while x.shape[1] > 1024 and x.shape[1] % 256 == 0:
+        x = x.view(x.shape[0], -1, 256).sum(2)
+    return x.sum(1)
+
+
+def mean_all(x):
+    return total(x) / x.numel()
+
+
 def _valid(pred, gt):
     return (gt > 0.0) & torch.isfinite(gt) & torch.isfinite(pred) & (pred > 0.0)       # losses.py:39-40, :61
 
@@ -25,11 +51,11 @@ class IdepthLoss_234(nn.Module):
     """0.1/3 * sum of unmasked mean-L1 of disp2..4 against nearest-resized ground truth (losses.py:7-27)."""
 
     def forward(self, idepth_preds, idepth_ground_truth):
-        total = 0.0
+        acc = 0.0
         for disp in idepth_preds[1:4]:
             gt = F.interpolate(idepth_ground_truth, size=disp.shape[2:4])                 # nearest (:18-20)
-            total = total + (disp - gt).abs().mean()
-        return 0.1 * total / 3.0
+            acc = acc + mean_all((disp - gt).abs())
+        return 0.1 * acc / 3.0
 
 
 def _masked(m, *tensors):
@@ -44,13 +70,13 @@ class IdepthLoss(nn.Module):
 
     def forward(self, idepth_pred, idepth_groud_truth, log=False):
         m = _valid(idepth_pred, idepth_groud_truth)
-        n = m.sum().to(idepth_pred.dtype)
+        n = total(m).to(idepth_pred.dtype)
         if log:
             one = torch.ones((), dtype=idepth_pred.dtype, device=idepth_pred.device)
             p, g = torch.where(m, idepth_pred, one), torch.where(m, idepth_groud_truth, one)
-            return (torch.log10(p) - torch.log10(g)).abs().sum() / n
+            return total((torch.log10(p) - torch.log10(g)).abs()) / n
         p, g = _masked(m, idepth_pred, idepth_groud_truth)
-        return (p - g).abs().sum() / n
+        return total((p - g).abs()) / n
 
 
 class IdepthwithProbLoss(nn.Module):
@@ -58,7 +84,7 @@ class IdepthwithProbLoss(nn.Module):
 
     def forward(self, idepth_pred, idepth_gt, prob_map, log=False):
         m = _valid(idepth_pred, idepth_gt)
-        n = m.sum().to(idepth_pred.dtype)
+        n = total(m).to(idepth_pred.dtype)
         (w,) = _masked(m, prob_map)
         if log:
             one = torch.ones((), dtype=idepth_pred.dtype, device=idepth_pred.device)
@@ -66,7 +92,7 @@ class IdepthwithProbLoss(nn.Module):
         else:
             p, g = _masked(m, idepth_pred, idepth_gt)
             diff = (p - g).abs()
-        return (w * diff).sum() / n
+        return total(w * diff) / n
 
 
 def surface_normal_loss(prediction, surface_normal, valid_region, probability_map=None):
@@ -77,11 +103,11 @@ def surface_normal_loss(prediction, surface_normal, valid_region, probability_ma
     p, g = _masked(keep, prediction, surface_normal)
     sim = F.cosine_similarity(p, g, dim=1)                                                # [B,h,w]
     k = keep.squeeze(1).to(sim.dtype)
-    n = k.sum()
+    n = total(k)
     if probability_map is None:
-        loss = ((1 - sim) * k).sum() / n
+        loss = total((1 - sim) * k) / n
     else:
         w = _masked(keep, probability_map)[0].squeeze(1)
-        loss = ((1 - sim) * w).sum() / w.sum()
-    angle = (torch.acos(sim.clamp(-1, 1)) * k).sum() / n
+        loss = total((1 - sim) * w) / total(w)
+    angle = total(torch.acos(sim.clamp(-1, 1)) * k) / n
     return loss, angle / math.pi * 180

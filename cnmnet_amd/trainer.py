@@ -14,9 +14,10 @@ data-parallel over one process per GPU.
   DataParallel.  `exact_masked_means=True` divides every masked loss sum by the GLOBAL mask count
   (one tiny all-reduce of counts), which reproduces DataParallel's gathered-batch masked means.
 """
+import os
 import torch
 
-from .depthnet.losses import IdepthLoss_234, _valid
+from .depthnet.losses import IdepthLoss_234, _valid, total, row_totals, mean_all
 
 
 class _step_scope:
@@ -34,7 +35,7 @@ class _step_scope:
         return False
 
 
-SOURCES_IN_ONE_PASS = True       # depthNet over both sources of a frame in one pass with per-source BatchNorm statistics (depthNet.forward_sources)
+SOURCES_IN_ONE_PASS = os.environ.get("CNM_SOURCES_IN_ONE_PASS", "1") != "0"   # depthNet over both sources of a frame in one pass with per-source BatchNorm statistics (depthNet.forward_sources)
 
 
 class BucketedGradAllReduce:
@@ -129,12 +130,12 @@ def _masked_l1(pred, gt, dist=None, weight=None, exact=False):
     diff = (torch.where(m, pred, zero) - torch.where(m, gt, zero)).abs()
     if weight is not None:
         diff = diff * torch.where(m, weight, zero)
-    n = m.sum().to(pred.dtype)
+    n = total(m).to(pred.dtype)                      # `total`: reductions without scratch memory (HIP-graph replay, see losses.total)
     if exact and dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
         n = n.reshape(1).clone()
         dist.all_reduce(n)
-        return diff.sum() / (n[0] / dist.get_world_size()).clamp(min=1.0)
-    return diff.sum() / n
+        return total(diff) / (n[0] / dist.get_world_size()).clamp(min=1.0)
+    return total(diff) / n
 
 
 def _log_values(logs):
@@ -270,7 +271,7 @@ class TrainStepWoNormal:
         eps = 1e-8
         d01, d02, dr = 1.0 / (p01[0] + eps), 1.0 / (p02[0] + eps), 1.0 / (idr + eps)          # :530-534
         prob_loss_depth = L(idr, gt_id, prob) + L(dr, gt_d, prob)                            # :539-540
-        prob_loss = 5 * prob_loss_depth + (1 - prob.mean())                                  # :541, :545
+        prob_loss = 5 * prob_loss_depth + (1 - mean_all(prob))                                  # :541, :545
         loss_depth_1 = (L(d01, gt_d) + L(d02, gt_d)) * 0.5                                    # :550-551
         loss_depth_refined = L(dr, gt_d)                                                     # :553
         if warmup_epoch:                                                                     # :555-559
@@ -318,7 +319,7 @@ def get_warped_depth_loss(depth_refined, gt_depth_src, pose, intrinsic, intrinsi
     m = (warped > 0) & torch.isfinite(warped) & torch.isfinite(depth_refined) & (depth_refined > 0)
     zero = torch.zeros((), dtype=warped.dtype, device=warped.device)
     diff = (torch.where(m, warped, zero) - torch.where(m, depth_refined, zero)).abs()
-    return diff.sum() / m.sum().to(warped.dtype).clamp(min=1.0)          # empty mask: 0 with a zero gradient; no host synchronisation
+    return total(diff) / total(m).to(warped.dtype).clamp(min=1.0)          # empty mask: 0 with a zero gradient; no host synchronisation
 
 
 class TrainStep(TrainStepWoNormal):
@@ -367,7 +368,7 @@ class TrainStep(TrainStepWoNormal):
         zero = torch.zeros((), dtype=pred.dtype, device=pred.device)
         sim = torch.nn.functional.cosine_similarity(torch.where(keep, pred, zero), torch.where(keep, gt, zero), dim=1)
         k = keep.squeeze(1).to(sim.dtype)
-        return ((1 - sim) * k).flatten(1).sum(1), k.flatten(1).sum(1)
+        return row_totals((1 - sim) * k), row_totals(k)
 
     def losses(self, rgbs, cameras, disparities, depths, normals, poses=None):
         """Train-mode forward and the loss mix of train.py:164-304: (loss to back-propagate, dict of logged terms).
@@ -388,7 +389,7 @@ class TrainStep(TrainStepWoNormal):
         loss_idepth_refined = L(idr, gt_id)                                                  # :180
         d01, d02 = 1.0 / p01[0].squeeze(1), 1.0 / p02[0].squeeze(1)                          # :185-186
         dr = 1.0 / (idr.squeeze(1) + 1e-5)                                                   # :188
-        prob_loss = 5 * (L(idr, gt_id, prob) + L(dr.unsqueeze(1), gt_d, prob)) + (1 - prob.mean())   # :193-199
+        prob_loss = 5 * (L(idr, gt_id, prob) + L(dr.unsqueeze(1), gt_d, prob)) + (1 - mean_all(prob))   # :193-199
         k_inv = self.intrinsics_inverse(cameras[:, 0])                                       # :201-202
         n01, _ = self.depth2normal(d01, k_inv)                                               # :204-207
         n02, _ = self.depth2normal(d02, k_inv)

@@ -981,6 +981,24 @@ def test_config4_full_size_properties(dev):
     assert bool((((n - 1).abs() < 1e-4) | (n < 1e-6)).all())
 
 
+def test_graphed_frame_pipeline_survives_device_synchronise(dev):
+    """GraphedFramePipeline (bench.py --graph) at the headline shape: replays on changing frames equal the eager pipeline, also
+    after a device-wide synchronise between replays (memset nodes below 1 MiB stop acting after one on this ROCm --
+    tools/graph_sync_probe.py; the engine clears its workspaces with kernels, and this is what holds it to that)."""
+    from cnmnet_amd.depthnet import depthNet, DepthRefineNet
+    from cnmnet_amd.pipeline import FramePipeline, GraphedFramePipeline
+    pipe = FramePipeline(_load(depthNet(3.0, 64), 3).to(dev), _load(DepthRefineNet(32, 3.0), 4).to(dev), k_size=9)
+    frames = [tuple(T(a).to(dev) for a in syn.frames(4, 2, 192, 256, seed=60 + i)) for i in range(5)]
+    graphed = GraphedFramePipeline(pipe, *frames[0])
+    for i, (img, cams) in enumerate(frames):
+        if i in (2, 3):
+            torch.cuda.synchronize()
+        got = {k: v.clone() for k, v in graphed(img, cams).items() if torch.is_tensor(v)}
+        want = pipe(img, cams)
+        for k in ("disp", "prob", "normal"):
+            assert torch.isfinite(got[k]).all() and float((got[k] - want[k]).abs().max()) < 2e-4, (i, k, float((got[k] - want[k]).abs().max()))
+
+
 @pytest.mark.parametrize("S", [4, 6])
 def test_multi_source_frame_vs_oracle(dev, S):
     """a-8: 4- and 6-source fusion (eval.py:635-663, :885-929) through the frame pipeline."""

@@ -361,6 +361,37 @@ def test_graphed_train_step_equals_eager(dev):
             assert torch.allclose(be[n].float(), bg[n].float(), rtol=1e-5, atol=1e-6), n
 
 
+def test_graph_replays_survive_device_synchronise(dev):
+    """TrainStep(graph=True) at the bench's training shape (4 samples of 192x256, 64 planes): a device-wide synchronise between
+    two replays must not change what the next replay computes.  It did: the masked-mean losses came back stale (torch's
+    split reductions meet through a scratch block cleared by a memset node) until every full reduction of the step became a
+    two-stage one (depthnet/losses.py `total`); bench.py synchronises between its warm-up and its timed replays."""
+    from cnmnet_amd.depthnet import depthNet, DepthRefineNet
+    from cnmnet_amd.trainer import TrainStep, synthetic_training_sample
+
+    def run(sync_at):
+        torch.manual_seed(1)
+        nets = depthNet(3.0, 64), DepthRefineNet(32, 3.0)
+        for net in nets:
+            for m in net.modules():
+                if isinstance(m, torch.nn.Conv2d) and m.out_channels == 1:
+                    m.weight.data.mul_(0.02)                     # depth heads that start near mid-range (no 1/p blow-up)
+        step = TrainStep(nets[0].to(dev), nets[1].to(dev), k_size=9, graph=True)
+        sd = {k: v.to(dev) for k, v in synthetic_training_sample(4, 192, 256, seed=7).items()}
+        out = []
+        for it in range(6):
+            if it == sync_at:
+                torch.cuda.synchronize()
+            out.append(step(sd["rgbs"], sd["cameras"], sd["disparities"], sd["depths"], sd["normals"]))
+        return out
+
+    plain, synced = run(-1), run(3)
+    for it, (a, b) in enumerate(zip(plain, synced)):
+        for k in a:
+            assert np.isfinite(b[k]) and abs(a[k] - b[k]) <= 2e-3 * max(1.0, abs(a[k])), (it, k, a[k], b[k])
+    assert synced[-1]["loss"] < synced[0]["loss"]
+
+
 def test_graphed_warmup_then_full_graph_equals_eager(dev):
     """fit()'s own schedule with graph=True: the warm-up-epoch graph (train.py:555-559) never gives the probability decoder a
     gradient, so Adam holds no state for it; the re-capture for the full loss then CREATES that state during its two warm-up
