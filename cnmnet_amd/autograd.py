@@ -335,6 +335,67 @@ class Upsample2xC4(torch.autograd.Function):
         return dx
 
 
+_ML1_WS = {}    # (device, stream) -> ticket + block partials of cnm_masked_l1_f32 (the ticket is zero between calls)
+
+
+def _ml1_workspace(device):
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    ws = _ML1_WS.get(key)
+    if ws is None:
+        ws = _ML1_WS[key] = torch.zeros(_lib.load().cnm_masked_l1_workspace_doubles(), device=device, dtype=torch.float64)
+    return ws
+
+
+class MaskedL1(torch.autograd.Function):
+    """Masked mean L1 of the training losses (reference losses.py:30-73) as one launch each way: value =
+    sum_m weight |pred - gt| / count(m) with m = gt > 0 & finite(gt) & finite(pred) & pred > 0; gradients for pred and weight.
+    The torch expression of the same thing (trainer._masked_l1) is ~20 elementwise / reduction launches per term."""
+
+    @staticmethod
+    def forward(ctx, pred, gt, weight):
+        pred, gt = pred.contiguous(), gt.contiguous()
+        weight = weight.contiguous() if weight is not None else None
+        assert pred.shape == gt.shape and (weight is None or weight.shape == pred.shape)
+        out = torch.empty(2, device=pred.device, dtype=torch.float32)
+        with torch.cuda.device(pred.device):
+            _lib.check(_lib.load().cnm_masked_l1_f32(ops._p(pred), ops._p(gt), ops._p(weight), pred.numel(), ops._p(_ml1_workspace(pred.device)), ops._p(out), _s()))
+        ctx.save_for_backward(pred, gt, weight, out)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, go):
+        pred, gt, weight, out = ctx.saved_tensors
+        need_p, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[2] and weight is not None
+        if not (need_p or need_w):
+            return None, None, None
+        dp = torch.empty_like(pred) if need_p else None
+        dw = torch.empty_like(weight) if need_w else None
+        go = go.contiguous().float()
+        with torch.cuda.device(pred.device):
+            _lib.check(_lib.load().cnm_masked_l1_backward_f32(ops._p(pred), ops._p(gt), ops._p(weight), ops._p(go), ops._p(out), pred.numel(), ops._p(dp), ops._p(dw), _s()))
+        return dp, None, dw
+
+
+class SplitSources(torch.autograd.Function):
+    """x [B * S, ...] with sample n belonging to source n % S -> S contiguous tensors [B, ...] (depthNet.forward_sources).
+    As strided slices x[s::S] every source would cost autograd a zero fill of the whole tensor, a strided copy and an addition;
+    here the backward pass interleaves the S gradients in one copy."""
+
+    @staticmethod
+    def forward(ctx, x, S):
+        ctx.S, ctx.shape = S, x.shape
+        v = x.view(x.shape[0] // S, S, *x.shape[1:])
+        return tuple(v[:, s].contiguous() for s in range(S))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        if all(g is None for g in grads):
+            return None, None
+        ref = next(g for g in grads if g is not None)
+        grads = [g if g is not None else torch.zeros_like(ref) for g in grads]
+        return torch.stack(grads, 1).reshape(ctx.shape), None
+
+
 class C4ToNCHW(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, channels):

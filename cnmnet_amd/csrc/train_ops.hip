@@ -919,6 +919,81 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_c4_kernel(const float* __r
     }
 }
 
+// ------------------------------------------------------------------ masked mean L1 (IdepthLoss / IdepthwithProbLoss, losses.py:30-73)
+// value = sum_m w |pred - gt| / count(m),  m = gt > 0 && finite(gt) && finite(pred) && pred > 0  (losses.py:39-40, :61).
+// One launch: per-thread fp64 sums over a grid-stride walk, block partials to the workspace, the LAST block (ticket counter)
+// adds the partials in block order -- the same bits whatever the block schedule -- writes (mean, count) and rearms the ticket.
+constexpr int kMl1Blocks = 256;
+__global__ __launch_bounds__(256) void masked_l1_kernel(const float* __restrict__ pred, const float* __restrict__ gt, const float* __restrict__ w,
+                                                        long long n, double* __restrict__ ws, float* __restrict__ out) {
+    __shared__ double sh[2][4];
+    __shared__ bool last;
+    double s = 0.0, c = 0.0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float p = pred[i], g = gt[i];
+        if (g > 0.f && isfinite(g) && isfinite(p) && p > 0.f) { s += (double)(fabsf(p - g) * (w ? w[i] : 1.f)); c += 1.0; }
+    }
+    for (int o = 32; o; o >>= 1) { s += __shfl_down(s, o); c += __shfl_down(c, o); }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[0][wave] = s; sh[1][wave] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ws[2 + 2 * blockIdx.x] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+        ws[3 + 2 * blockIdx.x] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+        __threadfence();
+        last = atomicAdd(reinterpret_cast<unsigned*>(ws), 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    s = 0.0; c = 0.0;
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += 256) { s += __hip_atomic_load(ws + 2 + 2 * b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); c += __hip_atomic_load(ws + 3 + 2 * b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // kMl1Blocks <= 256: one partial per thread
+    for (int o = 32; o; o >>= 1) { s += __shfl_down(s, o); c += __shfl_down(c, o); }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { sh[0][wave] = s; sh[1][wave] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double S = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]), C = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+        out[0] = (float)(S / C);                                         // empty mask: 0 / 0 = NaN, the reference's mean of nothing
+        out[1] = (float)C;
+        *reinterpret_cast<unsigned*>(ws) = 0u;                           // zero on entry, left zero
+    }
+}
+
+// d value / d pred = w sign(pred - gt) / count on the mask, 0 elsewhere;  d value / d w = |pred - gt| / count on the mask.
+// `go` = gradient of the value (device scalar), `stat` = what the forward wrote (mean, count).
+__global__ __launch_bounds__(256) void masked_l1_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ gt, const float* __restrict__ w,
+                                                            const float* __restrict__ go, const float* __restrict__ stat, long long n,
+                                                            float* __restrict__ dpred, float* __restrict__ dw) {
+    const float k = go[0] / stat[1];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float p = pred[i], g = gt[i];
+        const bool m = g > 0.f && isfinite(g) && isfinite(p) && p > 0.f;
+        const float d = p - g;
+        if (dpred) dpred[i] = m ? (d > 0.f ? k : d < 0.f ? -k : 0.f) * (w ? w[i] : 1.f) : 0.f;
+        if (dw) dw[i] = m ? fabsf(d) * k : 0.f;
+    }
+}
+
+extern "C" size_t cnm_masked_l1_workspace_doubles(void) { return 2 + 2 * kMl1Blocks; }
+
+extern "C" int cnm_masked_l1_f32(const float* pred, const float* gt, const float* weight, long long n, double* zero_ws, float* out2, void* stream) {
+    CNM_REQUIRE(pred && gt && zero_ws && out2 && n > 0, CNM_ERR_BAD_ARG);
+    const int blocks = (int)((n + 1023) / 1024 < kMl1Blocks ? (n + 1023) / 1024 : kMl1Blocks);
+    masked_l1_kernel<<<blocks, 256, 0, cnm_stream(stream)>>>(pred, gt, weight, n, zero_ws, out2);
+    CNM_LAUNCH_CHECK();
+    return CNM_OK;
+}
+
+extern "C" int cnm_masked_l1_backward_f32(const float* pred, const float* gt, const float* weight, const float* grad_out, const float* out2,
+                                          long long n, float* dpred, float* dweight, void* stream) {
+    CNM_REQUIRE(pred && gt && grad_out && out2 && n > 0 && (dpred || dweight) && (!dweight || weight), CNM_ERR_BAD_ARG);
+    const int blocks = (int)((n + 1023) / 1024 < 2048 ? (n + 1023) / 1024 : 2048);
+    masked_l1_bwd_kernel<<<blocks, 256, 0, cnm_stream(stream)>>>(pred, gt, weight, grad_out, out2, n, dpred, dweight);
+    CNM_LAUNCH_CHECK();
+    return CNM_OK;
+}
+
 extern "C" int cnm_upsample2x_backward_c4_f32(const float* dy, float* dx, int N, int G, int H, int W, void* stream) {
     CNM_REQUIRE(dy && dx && N > 0 && G > 0 && H > 0 && W > 0, CNM_ERR_BAD_ARG);
     const long long total = (long long)N * G * H * W;

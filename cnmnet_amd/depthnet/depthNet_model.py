@@ -283,12 +283,13 @@ class depthNet(_EngineNet):
         S = right_images.shape[1]
         disp, feat = self._forward_train(left_image.contiguous(), right_images.contiguous(), left_cam.contiguous(), right_cams.contiguous(),
                                          per_source_statistics=True)
+        feats = ag.SplitSources.apply(feat, S)                          # sample n of the pass belongs to source n % S
+        disps = [ag.SplitSources.apply(d, S) for d in disp]
         out = []
         for s in range(S):
-            f4 = feat[s::S]
-            iconv1 = ag.C4ToNCHW.apply(f4, 64)
-            iconv1._cnm_c4 = f4
-            out.append(([d[s::S] for d in disp], iconv1))
+            iconv1 = ag.C4ToNCHW.apply(feats[s], 64)
+            iconv1._cnm_c4 = feats[s]
+            out.append(([d[s] for d in disps], iconv1))
         return out
 
     def getVolume(self, left_image, right_image, KRKiUV_T, KT_T):

@@ -569,6 +569,17 @@ int cnm_bn_train_backward_zg_c4_f32(const float* x, const float* y, const float*
                                     float* dx, float* dgamma, float* dbeta, double* zero_ws,
                                     int N, int C, int H, int W, int groups, void* stream);
 
+/* Masked mean L1 of the training losses -- IdepthLoss / IdepthwithProbLoss (losses.py:30-73) without the `pred[mask]` gather:
+ *   out2[0] = sum_m weight |pred - gt| / count(m),  out2[1] = count(m),  m = gt > 0 && finite(gt) && finite(pred) && pred > 0
+ * (losses.py:39-40, :61; weight may be NULL = 1; an empty mask gives NaN like the reference's mean of an empty selection).  n elements,
+ * any shape.  One launch, fp64 partial sums added in a fixed order (bit-reproducible); zero_ws: cnm_masked_l1_workspace_doubles()
+ * doubles, zero on entry, left zero (one per stream).  Backward: grad_out = d loss / d out2[0] (device scalar), out2 as the forward
+ * wrote it; dpred / dweight [n] (either may be NULL): w sign(pred - gt) grad / count and |pred - gt| grad / count on the mask, 0 off it. */
+size_t cnm_masked_l1_workspace_doubles(void);
+int cnm_masked_l1_f32(const float* pred, const float* gt, const float* weight, long long n, double* zero_ws, float* out2, void* stream);
+int cnm_masked_l1_backward_f32(const float* pred, const float* gt, const float* weight, const float* grad_out, const float* out2,
+                               long long n, float* dpred, float* dweight, void* stream);
+
 /* Adjoint of cnm_upsample2x_c4_f32: dy [N,G,2H,2W,4] -> dx [N,G,H,W,4] (contiguous). */
 int cnm_upsample2x_backward_c4_f32(const float* dy, float* dx, int N, int G, int H, int W, void* stream);
 

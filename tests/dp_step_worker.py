@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from cnmnet_amd import synthetic as syn                              # noqa: E402
 from cnmnet_amd.depthnet import depthNet, DepthRefineNet            # noqa: E402
-from cnmnet_amd.trainer import TrainStepWoNormal, synthetic_training_sample   # noqa: E402
+from cnmnet_amd.trainer import TrainStepWoNormal, synthetic_training_sample, make_adam   # noqa: E402
 
 H, W, B, LR = 64, 96, 4, 1e-4
 
@@ -109,7 +109,7 @@ def main():
         for graph in (False, True):
             dg, rg = nets(dev)
             st = TrainStepWoNormal(dg, rg, lr=LR, dist=dist, graph=graph)
-            st.optimizer = torch.optim.Adam(list(rg.parameters()) + list(dg.parameters()), lr=LR, weight_decay=1e-5, capturable=True)
+            st.optimizer = make_adam(list(rg.parameters()) + list(dg.parameters()), LR, 1e-5, capturable=True)
             if graph:
                 assert st.reducer is not None and not st.reducer.handles
             for sd in (11, 12):

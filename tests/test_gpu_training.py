@@ -341,10 +341,10 @@ def test_graphed_train_step_equals_eager(dev):
     statistics; the capture's warm-up iterations must leave no trace.  Both sides use Adam's capturable arithmetic (the
     net is sensitive enough that the 1e-7 differences between Adam's two code paths grow to 1e-4 within two steps)."""
     from cnmnet_amd.depthnet import depthNet, DepthRefineNet
-    from cnmnet_amd.trainer import TrainStepWoNormal, synthetic_training_sample
+    from cnmnet_amd.trainer import TrainStepWoNormal, synthetic_training_sample, make_adam
     mk = lambda graph: TrainStepWoNormal(_load(depthNet(3.0), 71).to(dev), _load(DepthRefineNet(32, 3.0), 72).to(dev), lr=1e-4, graph=graph)
     eager, graphed = mk(False), mk(True)
-    eager.optimizer = torch.optim.Adam(list(eager.refine_net.parameters()) + list(eager.depth_net.parameters()), lr=1e-4, weight_decay=1e-5, capturable=True)
+    eager.optimizer = make_adam(list(eager.refine_net.parameters()) + list(eager.depth_net.parameters()), 1e-4, 1e-5, capturable=True)
     batches = [synthetic_training_sample(2, 64, 96, seed=s) for s in (3, 4, 5)] + [synthetic_training_sample(1, 64, 64, seed=6)]
     for b in batches:
         sd = {k: v.to(dev) for k, v in b.items()}
@@ -359,6 +359,42 @@ def test_graphed_train_step_equals_eager(dev):
         be, bg = dict(net_e.named_buffers()), dict(net_g.named_buffers())
         for n in be:
             assert torch.allclose(be[n].float(), bg[n].float(), rtol=1e-5, atol=1e-6), n
+
+
+@pytest.mark.parametrize("shape,weighted", [((4, 1, 192, 256), False), ((4, 1, 192, 256), True), ((3, 1, 17, 23), True), ((1, 1, 1, 5), False)])
+def test_masked_l1_kernel_vs_torch_expression(dev, shape, weighted):
+    """cnm_masked_l1_f32 / _backward_f32 (autograd.MaskedL1) against the torch expression of losses.py:30-73 the trainer used before
+    (trainer._masked_l1 with FUSED_MASKED_L1 off): value, d/d pred, d/d weight; zeros, negatives, inf and NaN in both inputs."""
+    from cnmnet_amd import trainer
+    g = torch.Generator().manual_seed(sum(shape))
+    pred = torch.rand(shape, generator=g) * 2 - 0.2                      # some predictions <= 0
+    gt = torch.rand(shape, generator=g) * 3
+    gt.flatten()[::7] = 0.0; gt.flatten()[3::11] = float("nan"); gt.flatten()[5::13] = float("inf")
+    pred.flatten()[2::17] = float("nan")
+    w = torch.rand(shape, generator=g) if weighted else None
+    res = {}
+    for fused in (True, False):
+        trainer.FUSED_MASKED_L1 = fused
+        try:
+            p = pred.to(dev).requires_grad_(True)
+            ww = w.to(dev).requires_grad_(True) if weighted else None
+            v = trainer._masked_l1(p, gt.to(dev), weight=ww)
+            (v * 1.7).backward()
+            res[fused] = (float(v), p.grad.cpu(), ww.grad.cpu() if weighted else None)
+        finally:
+            trainer.FUSED_MASKED_L1 = True
+    (v1, gp1, gw1), (v0, gp0, gw0) = res[True], res[False]
+    assert np.isfinite(v0) and abs(v1 - v0) <= 1e-6 * abs(v0), (v1, v0)
+    assert torch.isfinite(gp1).all() and float((gp1 - gp0).abs().max()) <= 1e-6 * float(gp0.abs().max())
+    if weighted:
+        assert torch.isfinite(gw1).all() and float((gw1 - gw0).abs().max()) <= 1e-6 * float(gw0.abs().max())
+    # empty mask: NaN like the reference's mean of an empty selection, and exact zeros for the gradients
+    p = pred.to(dev).requires_grad_(True)
+    v = trainer._masked_l1(p, torch.zeros(shape, device=dev))
+    v.backward()
+    assert np.isnan(float(v)) and float(p.grad.abs().max()) == 0.0
+    from cnmnet_amd import autograd as ag
+    assert float(ag._ml1_workspace(torch.device(dev))[0]) == 0.0         # ticket rearmed
 
 
 def test_graph_replays_survive_device_synchronise(dev):
@@ -398,10 +434,10 @@ def test_graphed_warmup_then_full_graph_equals_eager(dev):
     iterations.  Those entries must start from zero like the eager optimizer's (they used to keep the warm-up's moments and
     step = 2): two warm-up steps + two full steps, graphed against eager, every parameter and Adam moment."""
     from cnmnet_amd.depthnet import depthNet, DepthRefineNet
-    from cnmnet_amd.trainer import TrainStepWoNormal, synthetic_training_sample
+    from cnmnet_amd.trainer import TrainStepWoNormal, synthetic_training_sample, make_adam
     mk = lambda graph: TrainStepWoNormal(_load(depthNet(3.0), 81).to(dev), _load(DepthRefineNet(32, 3.0), 82).to(dev), lr=1e-4, graph=graph)
     eager, graphed = mk(False), mk(True)
-    eager.optimizer = torch.optim.Adam(list(eager.refine_net.parameters()) + list(eager.depth_net.parameters()), lr=1e-4, weight_decay=1e-5, capturable=True)
+    eager.optimizer = make_adam(list(eager.refine_net.parameters()) + list(eager.depth_net.parameters()), 1e-4, 1e-5, capturable=True)
     for i, warm in enumerate((True, True, False, False)):
         sd = {k: v.to(dev) for k, v in synthetic_training_sample(2, 64, 96, seed=20 + i).items()}
         le = eager(sd["rgbs"], sd["cameras"], sd["disparities"], sd["depths"], warmup_epoch=warm)
@@ -516,7 +552,7 @@ def test_train_with_normals_guard_and_graph(dev):
     ground-truth normal drops the normal and probability terms, the loss and every gradient stay finite; (ii) the step
     replayed as a HIP graph equals the eager step (same Adam arithmetic) on two different batches."""
     from cnmnet_amd.depthnet import depthNet, DepthRefineNet
-    from cnmnet_amd.trainer import TrainStep, synthetic_training_sample
+    from cnmnet_amd.trainer import TrainStep, synthetic_training_sample, make_adam
     mk = lambda graph: TrainStep(_load(depthNet(3.0), 81).to(dev), _load(DepthRefineNet(32, 3.0), 82).to(dev), lr=1e-4, graph=graph)
     s = {k: v.to(dev) for k, v in synthetic_training_sample(2, 64, 96, seed=5).items()}
     bad = {k: v.clone() for k, v in s.items()}
@@ -531,7 +567,7 @@ def test_train_with_normals_guard_and_graph(dev):
         for k, p in net.named_parameters():
             assert p.grad is None or bool(torch.isfinite(p.grad).all()), k
     eager, graphed = mk(False), mk(True)
-    eager.optimizer = torch.optim.Adam(list(eager.refine_net.parameters()) + list(eager.depth_net.parameters()), lr=1e-4, weight_decay=1e-5, capturable=True)
+    eager.optimizer = make_adam(list(eager.refine_net.parameters()) + list(eager.depth_net.parameters()), 1e-4, 1e-5, capturable=True)
     for seed in (5, 6):
         b = {k: v.to(dev) for k, v in synthetic_training_sample(2, 64, 96, seed=seed).items()}
         a = (b["rgbs"], b["cameras"], b["disparities"], b["depths"], b["normals"])
