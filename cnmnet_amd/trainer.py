@@ -35,6 +35,11 @@ class _step_scope:
         return False
 
 
+# _zero_grad_note: on one GPU the eager step drops the gradients (set_to_none=True) instead of zeroing them -- backward then ASSIGNS
+# every gradient where it would otherwise launch one `grad += new` per parameter (217 launches, 1.1 ms of GPU time per step), which is
+# also what the captured step does.  Same update for every parameter that receives a gradient; a parameter that receives none (the
+# probability decoder during the warm-up epochs, train.py:555-559) is skipped by Adam either way until its first gradient.  With a
+# gradient reducer the buffers stay allocated (its buckets copy from / to them).
 FUSED_MASKED_L1 = os.environ.get("CNM_FUSED_MASKED_L1", "1") != "0"   # the masked mean-L1 loss terms as one HIP launch each way (autograd.MaskedL1)
 FUSED_ADAM = os.environ.get("CNM_FUSED_ADAM", "1") != "0"   # torch's single-kernel Adam on GPU parameters (the multi-tensor form otherwise)
 
@@ -193,7 +198,7 @@ class TrainStepWoNormal:
                                       lambda *a: self.losses(*a, warmup_epoch))
         with _step_scope():
             loss, logs = self.losses(rgbs, cameras, disparities, depths, warmup_epoch)
-            self.optimizer.zero_grad(set_to_none=False)                                      # :562-565
+            self.optimizer.zero_grad(set_to_none=self.reducer is None)                       # :562-565 (see _zero_grad_note)
             loss.backward()
         if self.reducer is not None:
             self._finish(self.reducer.finish)
@@ -362,7 +367,7 @@ class TrainStep(TrainStepWoNormal):
                                       lambda r, c, i, d, n, poses: self.losses(r, c, i, d, n, poses))
         with _step_scope():
             loss, logs = self.losses(rgbs, cameras, disparities, depths, normals)
-            self.optimizer.zero_grad(set_to_none=False)                                      # :307-310
+            self.optimizer.zero_grad(set_to_none=self.reducer is None)                       # :307-310 (see _zero_grad_note)
             loss.backward()
         if self.reducer is not None:
             self._finish(self.reducer.finish)
