@@ -981,6 +981,37 @@ def test_config4_full_size_properties(dev):
     assert bool((((n - 1).abs() < 1e-4) | (n < 1e-6)).all())
 
 
+@pytest.mark.parametrize("B,H,W", [(3, 96, 160), (2, 128, 96), (1, 64, 224), (5, 160, 64), (16, 96, 128)])
+def test_frame_other_sizes_vs_oracle(dev, B, H, W):
+    """The frame pipeline at image sizes and batch counts other than the benchmark's (different tile blocks, stream-K ranges,
+    stride-2 forms accepted or refused per layer, fused / unfused up_conv layers, head kernels) against the CPU oracle on one
+    frame of the batch: inverse depth and probability inside the 1e-3 bar (max), normals at the 99th percentile."""
+    from cnmnet_amd.depthnet import depthNet, DepthRefineNet
+    from cnmnet_amd.pipeline import FramePipeline
+    img, cams = syn.frames(B, 2, H, W, seed=B * 1000 + H + W)
+
+    def load(module, seed, head_scale):                                  # scaled heads: outputs mid-range on every pixel (test_bench_configuration_vs_oracle)
+        shapes = {k: tuple(v.shape) for k, v in module.state_dict().items()}
+        w = syn.state_dict_like(shapes, seed=seed, randomize_bn=True)
+        w = {k: (v * head_scale if (v.ndim == 4 and v.shape[0] == 1) else v) for k, v in w.items()}
+        module.load_state_dict(torch_state(w))
+        return module.eval()
+
+    pipe = FramePipeline(load(depthNet(3.0), 51, 0.2).to(dev), load(DepthRefineNet(32, 3.0), 52, 0.05).to(dev), k_size=9)
+    with torch.no_grad():
+        out = pipe(T(img).to(dev), T(cams).to(dev))
+    cpu_d, cpu_r = load(ra.DepthNetCPU(3.0), 51, 0.2), load(ra.DepthRefineNetCPU(32, 3.0), 52, 0.05)
+    b = B - 1
+    with torch.no_grad():
+        want = ra.frame_forward(cpu_d, cpu_r, T(img[b:b + 1, 0]), T(img[b:b + 1, 1]), T(img[b:b + 1, 2]),
+                                T(cams[b:b + 1, 0]), T(cams[b:b + 1, 1]), T(cams[b:b + 1, 2]))
+    errs = {k: float((out[k][b:b + 1].cpu() - want[k]).abs().max()) for k in ("disp", "prob", "disp_a", "disp_b")}
+    nerr = (out["normal"][b:b + 1].cpu() - want["normal"]).abs().amax(1).flatten()
+    print("%dx%d batch %d: max|err| %s, normal q99 %.2e" % (W, H, B, {k: "%.1e" % v for k, v in errs.items()}, float(nerr.quantile(0.99))))
+    assert max(errs.values()) < 1e-3, errs
+    assert float(nerr.quantile(0.99)) < 1e-3
+
+
 def test_graphed_frame_pipeline_survives_device_synchronise(dev):
     """GraphedFramePipeline (bench.py --graph) at the headline shape: replays on changing frames equal the eager pipeline, also
     after a device-wide synchronise between replays (memset nodes below 1 MiB stop acting after one on this ROCm --
