@@ -21,12 +21,14 @@ def total(x):
     """Sum of all elements (integer for a bool mask) as rows of 256, then the row sums, until at most 1024 values are left.
     Why not x.sum(): torch splits a reduction to few outputs over several workgroups that meet through a scratch block cleared
     by cudaMemsetAsync; replayed inside a HIP graph (TrainStep(graph=True)) such reductions returned stale values after a
-    device-wide synchronise between replays (tools/graph_sync_probe.py, DESIGN.md section 5).  One workgroup per output needs
-    no scratch.  Ragged sizes (not a multiple of 256) are small ones and take the one launch."""
+    device-wide synchronise between replays (tools/graph_sync_probe.py, DESIGN.md section 4.4).  One workgroup per output needs
+    no scratch.  A size that is not a multiple of 256 is zero-padded up to one first."""
     x = x.reshape(-1)
     if x.dtype == torch.bool:
         x = x.to(torch.int32)
-    while x.numel() > 1024 and x.numel() % 256 == 0:
+    while x.numel() > 1024:
+        if x.numel() % 256:
+            x = F.pad(x, (0, -x.numel() % 256))
         x = x.view(-1, 256).sum(1)
     return x.sum()
 
@@ -34,7 +36,9 @@ def total(x):
 def row_totals(x):
     """[B, ...] -> [B]: per-sample sums, staged as `total` is."""
     x = x.flatten(1)
-    while x.shape[1] > 1024 and x.shape[1] % 256 == 0:
+    while x.shape[1] > 1024:
+        if x.shape[1] % 256:
+            x = F.pad(x, (0, -x.shape[1] % 256))
         x = x.view(x.shape[0], -1, 256).sum(2)
     return x.sum(1)
 
