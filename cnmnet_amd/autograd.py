@@ -474,9 +474,43 @@ def conv_bn_relu(x, conv, bn, rot=0, groups=1):
     return BatchNormReLUC4.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, True, bn.num_batches_tracked, groups)
 
 
+FUSED_HEAD = True   # the one-channel heads through the head kernels (HeadC4) instead of an MFMA convolution padded to 16 output channels
+
+
+class HeadC4(torch.autograd.Function):
+    """depth_layer (reference depthNet_model.py:82-84, :246): scale * sigmoid(conv3x3(x; weight [1,C,3,3]) + bias) on a c4 tensor
+    -> [N,1,H,W].  Forward is the inference head kernel (cnm_head_sigmoid_c4_f32); backward two streaming kernels
+    (cnm_head_backward_c4_f32): as an MFMA problem padded to 16 output channels the layer moved 16x its data each way."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, scale):
+        x = x.contiguous()
+        d = ops.head_sigmoid_c4(x, ops.pack_head(weight.detach()), bias.detach(), scale)
+        ctx.save_for_backward(x, weight, d)
+        ctx.scale = float(scale)
+        return d
+
+    @staticmethod
+    def backward(ctx, gd):
+        x, weight, d = ctx.saved_tensors
+        N, G, H, W, _ = x.shape
+        lib = _lib.load()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        need_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        dw = torch.empty_like(weight) if need_w else None
+        db = torch.empty(1, device=x.device, dtype=torch.float32) if need_w else None
+        ws = torch.empty(lib.cnm_head_backward_workspace_doubles(4 * G), device=x.device, dtype=torch.float64)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.cnm_head_backward_c4_f32(ops._p(x), G, 0, 4 * G, ops._p(weight.detach().contiguous()), ops._p(gd.contiguous()), ops._p(d),
+                                                    ctx.scale, ops._p(dx), ops._p(dw), ops._p(db), ops._p(ws), N, H, W, _s()))
+        return dx, dw if ctx.needs_input_grad[1] else None, db if ctx.needs_input_grad[2] else None, None
+
+
 def head(x, conv, scale):
     """depth_layer: Conv2d(C,1,3,padding=1) + Sigmoid, times `scale` (depthNet_model.py:82-84,246).
-    The 1-output-channel conv runs through the MFMA kernel padded to 16 output channels (zero rows)."""
+    FUSED_HEAD off: the 1-output-channel conv runs through the MFMA kernel padded to 16 output channels (zero rows)."""
+    if FUSED_HEAD and x.is_cuda and x.shape[1] * 4 == conv.weight.shape[1]:
+        return HeadC4.apply(x, conv.weight, conv.bias, float(scale))
     w = conv.weight
     w16 = torch.cat((w, w.new_zeros(15, *w.shape[1:])), 0)
     y = ConvC4.apply(x, w16, 1, 0)                        # [N,4,H,W,4]; channel 0 is the real one

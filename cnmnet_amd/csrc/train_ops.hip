@@ -994,6 +994,121 @@ extern "C" int cnm_masked_l1_backward_f32(const float* pred, const float* gt, co
     return CNM_OK;
 }
 
+// ------------------------------------------------------------------ backward of the disparity head (depth_layer, depthNet_model.py:82-84)
+// d = scale * sigmoid(s),  s = conv3x3(x; w [1,C,3,3], zero padding) + bias  ->  ds = gd * d * (1 - d / scale),
+//   dx[c](p) = sum_k ds(p - (k - 1)) w[c][k],   dw[c][k] = sum_p ds(p) x[c](p + (k - 1)),   dbias = sum_p ds(p).
+// The 1-channel convolution as an MFMA problem padded to 16 output channels moved 16x the data each way; these are the two
+// streaming kernels it is: every x texel is read once, every dx texel written once, ds (one float per pixel) comes from cache.
+__device__ __forceinline__ float head_ds(const float* __restrict__ gd, const float* __restrict__ d, float inv_scale, long long i) {
+    const float v = d[i];
+    return gd[i] * v * (1.f - v * inv_scale);
+}
+
+__global__ __launch_bounds__(256) void head_bwd_data_kernel(const float* __restrict__ gd, const float* __restrict__ d, const float* __restrict__ w,
+                                                            float inv_scale, float* __restrict__ dx, int N, int G, int H, int W) {
+    const int HW = H * W;
+    const long long total = (long long)N * G * HW;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int pix = (int)(idx % HW);
+        const long long r = idx / HW;
+        const int g = (int)(r % G), n = (int)(r / G);
+        const int y = pix / W, x = pix - y * W;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* wg = w + (size_t)g * 36;                            // w[c][k], c = 4 g .. 4 g + 3
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int sy = y - (ky - 1);                                 // x(y) feeds s(y - (ky - 1)) through kernel row ky
+            if ((unsigned)sy >= (unsigned)H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int sx = x - (kx - 1);
+                if ((unsigned)sx >= (unsigned)W) continue;
+                const float t = head_ds(gd, d, inv_scale, (long long)n * HW + sy * W + sx);
+                const int k = ky * 3 + kx;
+                acc.x = fmaf(t, wg[k], acc.x); acc.y = fmaf(t, wg[9 + k], acc.y); acc.z = fmaf(t, wg[18 + k], acc.z); acc.w = fmaf(t, wg[27 + k], acc.w);
+            }
+        }
+        *reinterpret_cast<float4*>(dx + c4_offset(n, G, g, HW, pix)) = acc;
+    }
+}
+
+// grid (chunks, G): block (j, g) walks its share of the N * H * W pixels, every thread keeps 36 sums (4 channels x 9 taps, +1 for the
+// bias in group 0); block partials [chunk][g][37] in fp64, added in chunk order by the finishing kernel (bit-reproducible).
+constexpr int kHeadChunks = 96;
+__global__ __launch_bounds__(256) void head_bwd_weight_kernel(const float* __restrict__ x, int Gx_tot, int gx0, const float* __restrict__ gd,
+                                                              const float* __restrict__ d, float inv_scale, double* __restrict__ partial,
+                                                              int N, int G, int H, int W) {
+    __shared__ double sh[4][37];
+    const int HW = H * W, g = blockIdx.y;
+    const long long total = (long long)N * HW;
+    float acc[36];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) acc[i] = 0.f;
+    float accb = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int n = (int)(i / HW), pix = (int)(i - (long long)n * HW);
+        const int y = pix / W, xx = pix - y * W;
+        const float4 v = *reinterpret_cast<const float4*>(x + c4_offset(n, Gx_tot, gx0 + g, HW, pix));
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int sy = y - (ky - 1);
+            if ((unsigned)sy >= (unsigned)H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int sx = xx - (kx - 1);
+                if ((unsigned)sx >= (unsigned)W) continue;
+                const float t = head_ds(gd, d, inv_scale, (long long)n * HW + sy * W + sx);
+                const int k = ky * 3 + kx;
+                acc[k] = fmaf(t, v.x, acc[k]); acc[9 + k] = fmaf(t, v.y, acc[9 + k]); acc[18 + k] = fmaf(t, v.z, acc[18 + k]); acc[27 + k] = fmaf(t, v.w, acc[27 + k]);
+                if (k == 4) accb += t;
+            }
+        }
+    }
+    const int wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 37; ++i) {
+        double v = (double)(i < 36 ? acc[i] : accb);
+        for (int o = 32; o; o >>= 1) v += __shfl_down(v, o);
+        if ((threadIdx.x & 63) == 0) sh[wave][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 37) partial[((size_t)blockIdx.x * G + g) * 37 + threadIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(64) void head_bwd_finish_kernel(const double* __restrict__ partial, int chunks, int G, int C, float* __restrict__ dw, float* __restrict__ dbias) {
+    const int i = blockIdx.x * 64 + threadIdx.x;                         // (g, slot)
+    if (i >= G * 37) return;
+    const int g = i / 37, slot = i - g * 37;
+    double s = 0.0;
+    for (int j = 0; j < chunks; ++j) s += partial[((size_t)j * G + g) * 37 + slot];
+    if (slot < 36) { const int c = 4 * g + slot / 9; if (c < C) dw[(size_t)c * 9 + slot % 9] = (float)s; }
+    else if (g == 0 && dbias) dbias[0] = (float)s;
+}
+
+extern "C" size_t cnm_head_backward_workspace_doubles(int C) { return C > 0 ? (size_t)kHeadChunks * ((C + 3) / 4) * 37 : 0; }
+
+extern "C" int cnm_head_backward_c4_f32(const float* x, int Gx_total, int gx0, int C, const float* w_oihw, const float* grad_disp, const float* disp,
+                                        float scale, float* dx, float* dw_oihw, float* dbias, double* ws, int N, int H, int W, void* stream) {
+    CNM_REQUIRE(x && w_oihw && grad_disp && disp && ws && (dx || dw_oihw) && C > 0 && C % 4 == 0 && N > 0 && H > 0 && W > 0 && scale > 0.f, CNM_ERR_BAD_ARG);
+    const int G = C / 4;
+    CNM_REQUIRE(gx0 >= 0 && gx0 + G <= Gx_total && (long long)N * G * H * W < (1ll << 40), CNM_ERR_BAD_ARG);
+    hipStream_t s = cnm_stream(stream);
+    if (dx) {
+        const long long total = (long long)N * G * H * W;
+        head_bwd_data_kernel<<<(unsigned)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536), 256, 0, s>>>(grad_disp, disp, w_oihw, 1.f / scale, dx, N, G, H, W);
+        CNM_LAUNCH_CHECK();
+    }
+    if (dw_oihw) {
+        const long long px = (long long)N * H * W;
+        const int chunks = (int)((px + 255) / 256 < kHeadChunks ? (px + 255) / 256 : kHeadChunks);
+        head_bwd_weight_kernel<<<dim3(chunks, G), 256, 0, s>>>(x, Gx_total, gx0, grad_disp, disp, 1.f / scale, ws, N, G, H, W);
+        CNM_LAUNCH_CHECK();
+        head_bwd_finish_kernel<<<(G * 37 + 63) / 64, 64, 0, s>>>(ws, chunks, G, C, dw_oihw, dbias);
+        CNM_LAUNCH_CHECK();
+    }
+    return CNM_OK;
+}
+
 extern "C" int cnm_upsample2x_backward_c4_f32(const float* dy, float* dx, int N, int G, int H, int W, void* stream) {
     CNM_REQUIRE(dy && dx && N > 0 && G > 0 && H > 0 && W > 0, CNM_ERR_BAD_ARG);
     const long long total = (long long)N * G * H * W;

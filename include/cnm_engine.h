@@ -580,6 +580,16 @@ int cnm_masked_l1_f32(const float* pred, const float* gt, const float* weight, l
 int cnm_masked_l1_backward_f32(const float* pred, const float* gt, const float* weight, const float* grad_out, const float* out2,
                                long long n, float* dpred, float* dweight, void* stream);
 
+/* Backward of cnm_head_sigmoid_c4_f32 -- depth_layer = Conv2d(C, 1, 3, padding = 1) + Sigmoid, times `scale`
+ * (depthNet_model.py:82-84, :246): with ds = grad_disp * disp * (1 - disp / scale),
+ *   dx [N, C/4, H, W, 4] (contiguous) = transposed 3x3 of ds with w,  dw_oihw [1,C,3,3] = sum_p ds(p) x(p + tap),  dbias [1] = sum ds.
+ * x is a channel-group view (Gx_total, gx0) as everywhere; w_oihw is the module's own weight [1,C,3,3]; grad_disp / disp [N,1,H,W].
+ * dx or dw_oihw (with dbias, which may be NULL) may be NULL.  Streaming kernels (x read once, dx written once); the weight
+ * gradient adds fp64 block partials in a fixed order.  ws: cnm_head_backward_workspace_doubles(C) doubles (no entry state). */
+size_t cnm_head_backward_workspace_doubles(int C);
+int cnm_head_backward_c4_f32(const float* x, int Gx_total, int gx0, int C, const float* w_oihw, const float* grad_disp, const float* disp,
+                             float scale, float* dx, float* dw_oihw, float* dbias, double* ws, int N, int H, int W, void* stream);
+
 /* Adjoint of cnm_upsample2x_c4_f32: dy [N,G,2H,2W,4] -> dx [N,G,H,W,4] (contiguous). */
 int cnm_upsample2x_backward_c4_f32(const float* dy, float* dx, int N, int G, int H, int W, void* stream);
 

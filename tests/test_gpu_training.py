@@ -397,6 +397,37 @@ def test_masked_l1_kernel_vs_torch_expression(dev, shape, weighted):
     assert float(ag._ml1_workspace(torch.device(dev))[0]) == 0.0         # ticket rearmed
 
 
+@pytest.mark.parametrize("N,C,H,W", [(2, 64, 24, 40), (1, 16, 7, 9), (2, 512, 12, 16), (4, 64, 192, 256)])
+def test_head_forward_backward_vs_torch(dev, N, C, H, W):
+    """autograd.HeadC4 (depth_layer: 3x3 conv to one channel + bias + scaled sigmoid; cnm_head_sigmoid_c4_f32 forward,
+    cnm_head_backward_c4_f32 backward) against torch autograd in fp64: value, d/dx, d/dweight, d/dbias; the padded-MFMA form it
+    replaces must agree too."""
+    from cnmnet_amd import autograd as ag, ops
+    g = torch.Generator().manual_seed(N * 1000 + C + H)
+    x = torch.randn(N, C, H, W, generator=g)
+    conv = torch.nn.Conv2d(C, 1, 3, padding=1)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(1, C, 3, 3, generator=g) * (1.0 / (9 * C)) ** 0.5); conv.bias.fill_(0.1)
+    go = torch.randn(N, 1, H, W, generator=g)
+    x64 = x.double().requires_grad_(True); c64 = torch.nn.Conv2d(C, 1, 3, padding=1).double(); c64.load_state_dict({k: v.double() for k, v in conv.state_dict().items()})
+    d64 = 3.0 * torch.sigmoid(c64(x64)); (d64 * go.double()).sum().backward()
+    res = {}
+    for fused in (True, False):
+        ag.FUSED_HEAD = fused
+        try:
+            cg = torch.nn.Conv2d(C, 1, 3, padding=1).to(dev); cg.load_state_dict(conv.state_dict())
+            xc = ops.nchw_to_c4(x.to(dev)).requires_grad_(True)
+            d = ag.head(xc, cg, 3.0)
+            (d * go.to(dev)).sum().backward()
+            res[fused] = (d.detach().cpu(), ops.c4_to_nchw(xc.grad, C).cpu(), cg.weight.grad.cpu(), cg.bias.grad.cpu())
+        finally:
+            ag.FUSED_HEAD = True
+    for fused, (d, gx, gw, gb) in res.items():
+        rel = lambda a, b: float((a.double() - b).norm() / (b.norm() + 1e-30))
+        assert float((d.double() - d64.detach()).abs().max()) < 2e-5 * 3.0, fused
+        assert rel(gx, x64.grad) < 2e-5 and rel(gw, c64.weight.grad) < 2e-5 and rel(gb, c64.bias.grad) < 2e-5, (fused, rel(gx, x64.grad), rel(gw, c64.weight.grad), rel(gb, c64.bias.grad))
+
+
 def test_graph_replays_survive_device_synchronise(dev):
     """TrainStep(graph=True) at the bench's training shape (4 samples of 192x256, 64 planes): a device-wide synchronise between
     two replays must not change what the next replay computes.  It did: the masked-mean losses came back stale (torch's
