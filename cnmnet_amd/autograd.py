@@ -209,15 +209,19 @@ class ConvC4(torch.autograd.Function):
         lib, dev = _lib.load(), x.device
         dx = dw = None
         with torch.cuda.device(dev):
-            if ctx.needs_input_grad[0] and ctx.rot == 0 and ctx.stride == 1 and _winograd_ok(k, 1, Cin):
+            rot = ctx.rot
+            # input channels stored rotated (refine conv1.0: 64 features, then the 3 maps): x position j holds weight channel (j + rot) % Cin,
+            # so the data gradient in x's order is the one of the weight with its input channels rolled by rot
+            wdg = weight.detach() if rot == 0 or ctx.stride != 1 else _packed("roll", weight, rot, 1, lambda: torch.cat((weight.detach()[:, rot:], weight.detach()[:, :rot]), 1))
+            if ctx.needs_input_grad[0] and ctx.stride == 1 and _winograd_ok(k, 1, Cin):
                 # stride 1: dx = conv(dy, w') with w'[ci][co] = w[co][ci] rotated by 180 degrees -- the same Winograd kernels
-                dx = _winograd_conv(dy, weight.detach(), 0, dgrad=True)
-            elif (ctx.needs_input_grad[0] and ctx.rot == 0 and ctx.stride == 1 and k == 3 and PAD_DGRAD and _winograd_ok(3, 1, 64) and Cin > 64):
+                dx = _winograd_conv(dy, wdg, 0, dgrad=True)
+            elif (ctx.needs_input_grad[0] and ctx.stride == 1 and k == 3 and PAD_DGRAD and _winograd_ok(3, 1, 64) and Cin > 64):
                 # stride 1, input channels not a multiple of 64 (the concatenations with a disparity channel: 65, 257, 513): the same
                 # F(4x4,3x3) data gradient with w' zero-padded to the next 64 output channels -- 1.1-2x the multiplies of a kernel
                 # that needs a quarter of the direct count -- and the padding groups dropped (a view)
                 Cp = 128 if Cin < 128 else 64 * -(-Cin // 64)
-                wpad = _packed("wpad", weight, 0, 1, lambda: torch.nn.functional.pad(weight.detach(), (0, 0, 0, 0, 0, Cp - Cin)))
+                wpad = _packed("wpad", weight, rot, 1, lambda: torch.nn.functional.pad(wdg, (0, 0, 0, 0, 0, Cp - Cin)))
                 dx = _winograd_conv(dy, wpad, 0, dgrad=True)[:, :G]
             elif (ctx.needs_input_grad[0] and ctx.rot == 0 and ctx.stride == 2 and WINOGRAD and Cin % 64 == 0
                   and H % 2 == 0 and W % 2 == 0):

@@ -42,7 +42,9 @@ def _rel(a, b):
     (128, 128, 3, 2, 0, 6, 128, 192),     # 3x3 stride 2 along rows (F(4,2) column phases), phase-scatter data gradient on the staged kernel
     (64, 128, 5, 2, 0, 2, 48, 64),        # 5x5 stride 2: forward and weight gradient on the pixel phases (F(4x4,3x3))
     (64, 64, 7, 2, 0, 1, 52, 76),         # 7x7 stride 2: the same on F(3x3,4x4), ragged tiles (26 x 38 outputs)
-    (36, 64, 3, 1, 0, 2, 30, 46)])        # 3x3: Winograd-domain weight gradient with ragged tiles and a ragged channel group
+    (36, 64, 3, 1, 0, 2, 30, 46),         # 3x3: Winograd-domain weight gradient with ragged tiles and a ragged channel group
+    (67, 128, 3, 1, 3, 2, 32, 48),        # refine conv1.0: rotated input channels; data gradient on F(4x4,3x3) with the rolled, zero-padded filter
+    (64, 128, 3, 1, 5, 1, 24, 32)])       # rotated input channels, whole groups
 def test_conv_forward_dgrad_wgrad(dev, cin, cout, k, stride, rot, N, H, W):
     from cnmnet_amd import ops, autograd as ag
     rng = np.random.default_rng(cin + 3 * k + stride)
