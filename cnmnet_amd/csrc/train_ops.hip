@@ -1007,11 +1007,11 @@ __device__ __forceinline__ float head_ds(const float* __restrict__ gd, const flo
 __global__ __launch_bounds__(256) void head_bwd_data_kernel(const float* __restrict__ gd, const float* __restrict__ d, const float* __restrict__ w,
                                                             float inv_scale, float* __restrict__ dx, int N, int G, int H, int W) {
     const int HW = H * W;
-    const long long total = (long long)N * G * HW;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-        const int pix = (int)(idx % HW);
-        const long long r = idx / HW;
-        const int g = (int)(r % G), n = (int)(r / G);
+    const unsigned total = (unsigned)N * G * HW;                          // < 2^31 (checked by the entry point)
+    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+        const int pix = (int)(idx % (unsigned)HW);
+        const unsigned r = idx / (unsigned)HW;
+        const int g = (int)(r % (unsigned)G), n = (int)(r / (unsigned)G);
         const int y = pix / W, x = pix - y * W;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         const float* wg = w + (size_t)g * 36;                            // w[c][k], c = 4 g .. 4 g + 3
@@ -1034,19 +1034,20 @@ __global__ __launch_bounds__(256) void head_bwd_data_kernel(const float* __restr
 
 // grid (chunks, G): block (j, g) walks its share of the N * H * W pixels, every thread keeps 36 sums (4 channels x 9 taps, +1 for the
 // bias in group 0); block partials [chunk][g][37] in fp64, added in chunk order by the finishing kernel (bit-reproducible).
-constexpr int kHeadChunks = 96;
+constexpr int kHeadChunks = 128;
 __global__ __launch_bounds__(256) void head_bwd_weight_kernel(const float* __restrict__ x, int Gx_tot, int gx0, const float* __restrict__ gd,
                                                               const float* __restrict__ d, float inv_scale, double* __restrict__ partial,
                                                               int N, int G, int H, int W) {
     __shared__ double sh[4][37];
+    __shared__ float red[256][37];
     const int HW = H * W, g = blockIdx.y;
-    const long long total = (long long)N * HW;
+    const unsigned total = (unsigned)N * HW;
     float acc[36];
 #pragma unroll
     for (int i = 0; i < 36; ++i) acc[i] = 0.f;
     float accb = 0.f;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int n = (int)(i / HW), pix = (int)(i - (long long)n * HW);
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const int n = (int)(i / (unsigned)HW), pix = (int)(i - (unsigned)n * HW);
         const int y = pix / W, xx = pix - y * W;
         const float4 v = *reinterpret_cast<const float4*>(x + c4_offset(n, Gx_tot, gx0 + g, HW, pix));
 #pragma unroll
@@ -1064,23 +1065,30 @@ __global__ __launch_bounds__(256) void head_bwd_weight_kernel(const float* __res
             }
         }
     }
-    const int wave = threadIdx.x >> 6;
+    // block sum of the 37 values through LDS (cross-lane shuffles of 37 doubles cost more than the walk itself): [thread][37] floats,
+    // then thread (quarter q, slot) adds its 64 rows in fp64, thread `slot` the four quarters
 #pragma unroll
-    for (int i = 0; i < 37; ++i) {
-        double v = (double)(i < 36 ? acc[i] : accb);
-        for (int o = 32; o; o >>= 1) v += __shfl_down(v, o);
-        if ((threadIdx.x & 63) == 0) sh[wave][i] = v;
+    for (int i = 0; i < 36; ++i) red[threadIdx.x][i] = acc[i];
+    red[threadIdx.x][36] = accb;
+    __syncthreads();
+    if (threadIdx.x < 148) {
+        const int q = threadIdx.x / 37, slot = threadIdx.x - q * 37;
+        double v = 0.0;
+        for (int r = q * 64; r < q * 64 + 64; ++r) v += (double)red[r][slot];
+        sh[q][slot] = v;
     }
     __syncthreads();
     if (threadIdx.x < 37) partial[((size_t)blockIdx.x * G + g) * 37 + threadIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
 }
 
-__global__ __launch_bounds__(64) void head_bwd_finish_kernel(const double* __restrict__ partial, int chunks, int G, int C, float* __restrict__ dw, float* __restrict__ dbias) {
-    const int i = blockIdx.x * 64 + threadIdx.x;                         // (g, slot)
+__global__ __launch_bounds__(256) void head_bwd_finish_kernel(const double* __restrict__ partial, int chunks, int G, int C, float* __restrict__ dw, float* __restrict__ dbias) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;   // one wave per (g, slot): lane l adds chunks l, l + 64, ..., then the lanes in a fixed tree
     if (i >= G * 37) return;
     const int g = i / 37, slot = i - g * 37;
     double s = 0.0;
-    for (int j = 0; j < chunks; ++j) s += partial[((size_t)j * G + g) * 37 + slot];
+    for (int j = lane; j < chunks; j += 64) s += partial[((size_t)j * G + g) * 37 + slot];
+    for (int o = 32; o; o >>= 1) s += __shfl_down(s, o);
+    if (lane != 0) return;
     if (slot < 36) { const int c = 4 * g + slot / 9; if (c < C) dw[(size_t)c * 9 + slot % 9] = (float)s; }
     else if (g == 0 && dbias) dbias[0] = (float)s;
 }
@@ -1091,7 +1099,7 @@ extern "C" int cnm_head_backward_c4_f32(const float* x, int Gx_total, int gx0, i
                                         float scale, float* dx, float* dw_oihw, float* dbias, double* ws, int N, int H, int W, void* stream) {
     CNM_REQUIRE(x && w_oihw && grad_disp && disp && ws && (dx || dw_oihw) && C > 0 && C % 4 == 0 && N > 0 && H > 0 && W > 0 && scale > 0.f, CNM_ERR_BAD_ARG);
     const int G = C / 4;
-    CNM_REQUIRE(gx0 >= 0 && gx0 + G <= Gx_total && (long long)N * G * H * W < (1ll << 40), CNM_ERR_BAD_ARG);
+    CNM_REQUIRE(gx0 >= 0 && gx0 + G <= Gx_total && (long long)N * G * H * W < (1ll << 31), CNM_ERR_BAD_ARG);
     hipStream_t s = cnm_stream(stream);
     if (dx) {
         const long long total = (long long)N * G * H * W;
@@ -1103,7 +1111,7 @@ extern "C" int cnm_head_backward_c4_f32(const float* x, int Gx_total, int gx0, i
         const int chunks = (int)((px + 255) / 256 < kHeadChunks ? (px + 255) / 256 : kHeadChunks);
         head_bwd_weight_kernel<<<dim3(chunks, G), 256, 0, s>>>(x, Gx_total, gx0, grad_disp, disp, 1.f / scale, ws, N, G, H, W);
         CNM_LAUNCH_CHECK();
-        head_bwd_finish_kernel<<<(G * 37 + 63) / 64, 64, 0, s>>>(ws, chunks, G, C, dw_oihw, dbias);
+        head_bwd_finish_kernel<<<(G * 37 + 3) / 4, 256, 0, s>>>(ws, chunks, G, C, dw_oihw, dbias);
         CNM_LAUNCH_CHECK();
     }
     return CNM_OK;
