@@ -193,6 +193,12 @@ class ConvC4(torch.autograd.Function):
         Cout, Cin, k, _ = weight.shape
         if _winograd_ok(k, stride, Cout) or (k == 3 and stride == 2 and (_rows3_stride2_ok(x, Cout) or _s2_phases_ok(x, Cout, 3))):
             y = _winograd_conv(x, weight.detach(), rot, stride)
+        elif (WINOGRAD and k == 3 and stride == 2 and Cout % 64 == 0
+              and (Cout // 64) * -(-(x.shape[0] * -(-x.shape[2] // 2) * -(-x.shape[3] // 2)) // 64) < 256):
+            # the deepest stride-2 layer (conv5.3: 48 implicit-GEMM tiles with a 4608-deep reduction each): F(2x2,3x3) keeping one output
+            # per tile, as the inference executor does (nets.hip EngF32::conv)
+            up = _packed("u2s2", weight, rot, 2, lambda: ops.pack_winograd(weight.detach(), None, rot, stride=1, tile=2))
+            y = ops.conv3x3_s2_winograd_c4(x, up, None, Cout, relu=False)
         else:
             wp, _ = ops.pack_conv(weight.detach(), None, None, rot)
             y = ops.conv2d_c4(x, wp, None, Cout, k, stride, relu=False)
