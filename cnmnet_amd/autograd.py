@@ -161,6 +161,35 @@ def _stride2_dgrad_phases(weight):
     return out
 
 
+_S2_CAT_INDEX = {}
+
+
+def _stride2_dgrad_cat(weight):
+    """The four phase filters of _stride2_dgrad_phases concatenated along the output channels, [4 * Cin, Cout, T, T] with taps at
+    offsets -1 .. 1 (k = 3, 5: T = 3) or -1 .. 2 (k = 7: T = 4) -- what the phase-interleaving data-gradient launch packs -- built by
+    ONE gather from the weight (index table cached per k) instead of a zero fill, a flip and a strided copy per phase."""
+    Cout, Cin, k, _ = weight.shape
+    T = 4 if k == 7 else 3
+    key = (k, str(weight.device))
+    idx = _S2_CAT_INDEX.get(key)
+    if idx is None:
+        pad, rows = k // 2, []
+        taps = []
+        for ph in (0, 1):
+            r = (ph + pad) % 2
+            taps.append((r, (ph + pad - r) // 2, len(range(r, k, 2))))    # sub-kernel rows r::2, tap u at offset c - u
+        for a in (0, 1):
+            for b in (0, 1):
+                (ra, ca, Ua), (rb, cb, Ub) = taps[a], taps[b]
+                for oy in range(-1, T - 1):
+                    for ox in range(-1, T - 1):
+                        u, v = ca - oy, cb - ox
+                        rows.append((ra + 2 * u) * k + (rb + 2 * v) if 0 <= u < Ua and 0 <= v < Ub else k * k)   # k * k: the zero slot
+        idx = _S2_CAT_INDEX[key] = torch.tensor(rows, device=weight.device, dtype=torch.long)
+    wt = torch.nn.functional.pad(weight.transpose(0, 1).reshape(Cin, Cout, k * k), (0, 1))        # [Cin, Cout, k*k + 1], last slot zero
+    return wt.index_select(2, idx).reshape(Cin, Cout, 4, T, T).permute(2, 0, 1, 3, 4).reshape(4 * Cin, Cout, T, T)
+
+
 def _taps4(wp):
     """A phase filter of _stride2_dgrad_phases (3x3: offsets -1 .. 1, 5x5: offsets -2 .. 2 with nothing at -2) as 4x4 taps at
     offsets -1 .. 2."""
@@ -233,20 +262,19 @@ class ConvC4(torch.autograd.Function):
                   and H % 2 == 0 and W % 2 == 0):
                 # stride 2: four stride-1 Winograd convolutions of dY, one per pixel phase of dX (sub-pixel
                 # decomposition: the zero-upsampled dY with its 3/4 structural zeros never exists)
-                phases = _packed("s2", weight, 0, 2, lambda: _stride2_dgrad_phases(weight.detach()))
-                if S2_DGRAD_SCATTER and all(wp.shape[2] == 3 for _, _, wp in phases):
+                if S2_DGRAD_SCATTER and k in (3, 5):
                     # 3x3 and 5x5 filters: all four phase filters are 3x3 -- ONE F(4x4,3x3) launch with 4*Cin output channels whose
                     # store path interleaves the phases (the kernel of the fused up_conv layers, zero padding): no scatter copies
-                    up = _packed("s2cat", weight, 0, 2, lambda: ops.pack_winograd4(torch.cat([wp for _, _, wp in phases], 0)))
+                    up = _packed("s2cat", weight, 0, 2, lambda: ops.pack_winograd4(_stride2_dgrad_cat(weight.detach())))
                     dx = ops.conv3x3_phase_scatter_c4(dy, up, Cin, sync=_sync_workspace(dev))
                 elif (S2_DGRAD_SCATTER and k == 7 and Cin % 32 == 0 and (dy.shape[3] + 2) // 3 >= 6 and (dy.shape[2] + 2) // 3 >= 2):
                     # 7x7: phase filters of 3 or 4 taps per axis at offsets -1 .. 1 / -1 .. 2 -- all four as 4x4 filters on F(3x3,4x4),
                     # again one phase-interleaving launch (staged kernel)
-                    up = _packed("s2cat", weight, 0, 2, lambda: ops.pack_winograd36(torch.cat([_taps4(wp) for _, _, wp in phases], 0)))
+                    up = _packed("s2cat", weight, 0, 2, lambda: ops.pack_winograd36(_stride2_dgrad_cat(weight.detach())))
                     dx = ops.conv3x3_phase_scatter_c4(dy, up, Cin, sync=_sync_workspace(dev), ksize=4)
                 else:
                     dx = torch.empty_like(x)
-                    for a, b, wp in phases:
+                    for a, b, wp in _packed("s2", weight, 0, 2, lambda: _stride2_dgrad_phases(weight.detach())):
                         dx[:, :, a::2, b::2] = _winograd_conv(dy, wp, 0)
             elif ctx.needs_input_grad[0]:
                 wd = torch.empty(lib.cnm_packed_dgrad_floats(Cout, Cin, k), device=dev, dtype=torch.float32)
