@@ -65,3 +65,54 @@ def test_stride2_data_gradient_is_a_phase_scatter(k):
             assert w4.shape[2:] == (4, 4)
             assert float((F.conv2d(F.pad(dy, (1, 2, 1, 2)), w4) - got[:, :, a::2, b::2]).abs().max()) < 1e-12
     assert float((got - want).abs().max()) < 1e-12
+
+
+@pytest.mark.parametrize("k", [3, 5, 7])
+def test_stride2_phase_filters_by_one_gather(k):
+    """autograd._stride2_dgrad_cat (one gather from the weight) = the four filters of _stride2_dgrad_phases concatenated along the
+    output channels (as 4x4 taps for k = 7), bit for bit; and the concatenation reproduces conv_transpose2d phase by phase."""
+    from cnmnet_amd.autograd import _stride2_dgrad_phases, _stride2_dgrad_cat, _taps4
+    rng = np.random.default_rng(20 + k)
+    N, Cin, Cout, Ho, Wo = 2, 5, 6, 5, 6
+    w = torch.from_numpy(rng.standard_normal((Cout, Cin, k, k)))
+    phases = _stride2_dgrad_phases(w)
+    ref = torch.cat([_taps4(wp) if k == 7 else wp for _, _, wp in phases], 0)
+    got = _stride2_dgrad_cat(w)
+    assert got.shape == ref.shape and torch.equal(got.contiguous(), ref)
+    dy = torch.from_numpy(rng.standard_normal((N, Cout, Ho, Wo)))
+    want = F.conv_transpose2d(dy, w, stride=2, padding=k // 2, output_padding=1)
+    T = got.shape[2]
+    full = F.conv2d(F.pad(dy, (1, T - 2, 1, T - 2)), got)                 # taps at offsets -1 .. T - 2: [N, 4 * Cin, Ho, Wo]
+    for a in (0, 1):
+        for b in (0, 1):
+            p = 2 * a + b
+            assert float((full[:, p * Cin:(p + 1) * Cin] - want[:, :, a::2, b::2]).abs().max()) < 1e-12
+
+
+def test_split_sources_and_staged_totals():
+    """autograd.SplitSources = strided slices with an interleaving backward (unused outputs count as zero gradients);
+    losses.total / row_totals / mean_all = sum / per-sample sums / mean at any size, gradients included."""
+    from cnmnet_amd.autograd import SplitSources
+    from cnmnet_amd.depthnet.losses import total, row_totals, mean_all
+    x = torch.randn(6, 2, 3, dtype=torch.float64, requires_grad=True)
+    a, b, c = SplitSources.apply(x, 3)
+    assert torch.equal(a, x[0::3]) and torch.equal(b, x[1::3]) and torch.equal(c, x[2::3])
+    (a.sum() + (c * 2).sum()).backward()
+    g = torch.zeros_like(x); g[0::3] = 1; g[2::3] = 2
+    assert torch.equal(x.grad, g)
+    for shape in ((4, 1, 192, 256), (3, 1, 177, 233), (1, 1, 1, 5), (2, 3, 1025), (7, 1300)):
+        y = torch.rand(shape, dtype=torch.float64, requires_grad=True)
+        assert abs(float(total(y) - y.sum())) < 1e-9 and abs(float(mean_all(y) - y.mean())) < 1e-12
+        assert float((row_totals(y) - y.flatten(1).sum(1)).abs().max()) < 1e-9
+        m = y > 0.5
+        assert int(total(m)) == int(m.sum())
+        total(y * 2).backward()
+        assert torch.equal(y.grad, torch.full_like(y, 2.0))
+
+
+def test_make_adam_on_cpu_parameters_is_the_foreach_form():
+    from cnmnet_amd.trainer import make_adam
+    p = [torch.nn.Parameter(torch.randn(3, 3)), torch.nn.Parameter(torch.randn(5))]
+    opt = make_adam(p, 1e-3, 1e-5)
+    assert opt.defaults["foreach"] is True and not opt.defaults.get("fused")
+    sum(q.sum() for q in p).backward(); opt.step()
