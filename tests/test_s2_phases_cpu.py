@@ -115,4 +115,3 @@ def test_make_adam_on_cpu_parameters_is_the_foreach_form():
     p = [torch.nn.Parameter(torch.randn(3, 3)), torch.nn.Parameter(torch.randn(5))]
     opt = make_adam(p, 1e-3, 1e-5)
     assert opt.defaults["foreach"] is True and not opt.defaults.get("fused")
-    sum(q.sum() for q in p).backward(); opt.step()
