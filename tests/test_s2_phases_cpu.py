@@ -108,10 +108,3 @@ def test_split_sources_and_staged_totals():
         assert int(total(m)) == int(m.sum())
         total(y * 2).backward()
         assert torch.equal(y.grad, torch.full_like(y, 2.0))
-
-
-def test_make_adam_on_cpu_parameters_is_the_foreach_form():
-    from cnmnet_amd.trainer import make_adam
-    p = [torch.nn.Parameter(torch.randn(3, 3)), torch.nn.Parameter(torch.randn(5))]
-    opt = make_adam(p, 1e-3, 1e-5)
-    assert opt.defaults["foreach"] is True and not opt.defaults.get("fused")
