@@ -482,7 +482,9 @@ def self_launch(n):
         port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, text=True)
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cpu_quota() // n)))   # the ranks share this node's host cores
+    r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, text=True, env=env)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     for l in lines[-1:]:
         print(l, flush=True)
@@ -637,10 +639,17 @@ def main():
     dev = torch.device("cuda", int(os.environ.get("CNM_BENCH_DEVICE", local)))
     torch.cuda.set_device(dev)
     dist, pg = None, None
+    host_threads = None
     if world > 1:
+        # N ranks share this node's host cores: cap each rank's torch / OpenMP pool at its share of the CPU quota (the GPU boxes
+        # grant 16 CPUs; eight ranks with 16 threads each oversubscribe the quota eightfold and the launch threads starve)
+        host_threads = max(1, host_cpu_quota() // world)
+        torch.set_num_threads(host_threads)
         dist, pg, backend = init_dist(backend, dev, world)
     if a.mode == "train":
         line = train_mode(a, dev, dist, pg, backend, rank, world)
+        if line is not None:
+            line["config"]["host_threads_per_rank"] = host_threads
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -695,6 +704,7 @@ def main():
                                        "256x192, 64 planes, batch=%d frames per GPU (BASELINE configs[1])" % B,
                            "frames_per_gpu": B, "sharding": "independent frame shards per GPU, no collective",
                            "barrier_backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None,
+                           "host_threads_per_rank": host_threads,
                            "launch": "hipGraph replay" if a.graph else "per-kernel, asynchronous"}}
         if not a.no_roofline and a.precision == "f32":
             global _LIVE_TRAFFIC

@@ -41,6 +41,8 @@ PROTOTYPES = {
     "cnm_pack_winograd_bn_f32": (c_i, [c_fp, c_fp, c_fp, c_f, c_i, c_i, c_i, c_fp, c_fp]),
     "cnm_conv3x3_winograd_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp,
                                           c_i, c_i, c_i, c_i, c_fp]),
+    "cnm_engine_status": (c_i, [c_i]),
+    "cnm_tune_sync_spin_limit": (C.c_uint, [C.c_uint]),
     "cnm_tune_wino4_min_workgroups": (c_i, [c_i]),
     "cnm_tune_refine_side_stream": (c_i, [c_i]),
     "cnm_tune_upsampled_min_pixels": (c_i, [c_i]),

@@ -57,9 +57,14 @@ def _packed(kind, weight, rot, stride, fn):
     if c is None:
         return fn()
     key = (kind, weight.data_ptr(), weight._version, tuple(weight.shape), rot, stride)
-    v = c.get(key)
-    if v is None:
-        v = c[key] = fn()
+    hit = c.get(key)
+    # the keyed tensor is held next to the value: a temporary used as a weight (a detached view, a derived filter) may be
+    # freed during backward and a later temporary of the same shape can land on its address with version 0 --
+    # while the cache holds the storage that cannot happen, and a hit is verified against the holder's storage anyway
+    if hit is not None and hit[0].untyped_storage().data_ptr() == weight.untyped_storage().data_ptr():
+        return hit[1]
+    v = fn()
+    c[key] = (weight, v)
     return v
 
 

@@ -28,7 +28,7 @@ def _stale(target, deps):
 
 def build(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
-    headers = [os.path.join(CSRC, "cnm_common.h"), os.path.join(CSRC, "wino4_args.h"), os.path.join(CSRC, "rows_args.h"), os.path.join(PKG, "..", "include", "cnm_engine.h")]
+    headers = [os.path.join(CSRC, "cnm_common.h"), os.path.join(CSRC, "wino4_args.h"), os.path.join(CSRC, "rows_args.h"), os.path.join(CSRC, "sync_ws.h"), os.path.join(PKG, "..", "include", "cnm_engine.h")]
     objs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)

@@ -29,6 +29,7 @@
 // eight wave-private staging corners of the output path: 112 KB.
 #include "cnm_common.h"
 #include "rows_args.h"
+#include "sync_ws.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(512, 2) void conv_rows7s_f32_kernel(const RowArgs a
     const auto range_begin = [&](int r) { return sync_flags ? (int)(T * r / G) : (int)((long long)nunits * r / G) * nch; };
     const int ps = range_begin(rng), pe = range_begin(rng + 1);
     const int P = pe - ps;
-    if (P <= 0) return;
+    if (P <= 0) { if (sync_flags && threadIdx.x == 0) sync_leave(sync_flags, G); return; }
 #ifdef ROWS7S_ABLATE
     const unsigned long long clk0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -408,12 +409,9 @@ __global__ __launch_bounds__(512, 2) void conv_rows7s_f32_kernel(const RowArgs a
         int nsrc = 0;
         if (!publish && !lastc) {
             for (int rem = nch - 1 - mc; rem > 0; ++nsrc) rem -= range_begin(rng + nsrc + 2) - range_begin(rng + nsrc + 1);
-            if (t == 0) {
-                for (int k = 1; k <= nsrc; ++k) {
-                    unsigned spins = 0;
-                    while (__hip_atomic_load(sync_flags + rng + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++spins < (1u << 24)) __builtin_amdgcn_s_sleep(8);
-                    __hip_atomic_store(sync_flags + rng + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+            if (t == 0) {                                                // generation-valued flags, loud time-out: sync_ws.h
+                const unsigned gen = sync_generation(sync_flags);
+                for (int k = 1; k <= nsrc; ++k) sync_wait(sync_flags, rng + k, gen);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
             __syncthreads();
@@ -495,7 +493,7 @@ __global__ __launch_bounds__(512, 2) void conv_rows7s_f32_kernel(const RowArgs a
             if (publish) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
-                if (t == 0) __hip_atomic_store(sync_flags + rng, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                if (t == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); sync_publish(sync_flags, rng, sync_generation(sync_flags)); }
             }
 #pragma unroll
             for (int x = 0; x < NX; ++x) { acc[x][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[x][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -503,6 +501,7 @@ __global__ __launch_bounds__(512, 2) void conv_rows7s_f32_kernel(const RowArgs a
         if (lastc) { ++mu; mcblk = ncblk; }
         mc = lastc ? 0 : mc + 1; part_c0 = 0;
     }
+    if (sync_flags && t == 0) sync_leave(sync_flags, G);                 // the last workgroup out advances the workspace's generation
 #ifdef ROWS7S_TIMELINE
     __syncthreads();
     if (blockIdx.x == 0 && t < 2 * 8 * 12) (&g_rows7s_tl[0][0][0])[t] = reinterpret_cast<unsigned*>(smem + LDS_BYTES)[t];
@@ -539,7 +538,6 @@ static int rows7s_cus() {
 
 // CNM_OK after launching, 1 when the shape is not eligible (the caller launches the gather-fed kernel), negative on failure.
 int cnm_rows7s_try_launch(const RowArgs& a, float* sync_ws, size_t sync_floats, hipStream_t stream) {
-    constexpr size_t kSyncFlagBytes = 4096, kSyncSlotBytes = 8 * 16 * 64 * 16;
     if (!g_rows7_staged || a.Cout % 128 || a.W < 32 || a.H < 4 || a.Ho != a.H || a.Wo != a.W) return 1;
     const int SH = cnm_ceil_div(a.H, 4), SW = cnm_ceil_div(a.W, 32), tilesC = a.Cout / 128;
     const long long nunits = (long long)a.N * SH * SW * tilesC;
@@ -548,7 +546,9 @@ int cnm_rows7s_try_launch(const RowArgs& a, float* sync_ws, size_t sync_floats, 
     const int cus = rows7s_cus();
     int grid = (int)(nunits < cus ? nunits : cus);
     unsigned* flags = nullptr; float* slots = nullptr;
-    if (sync_ws && cus * 4 <= (int)kSyncFlagBytes && sync_floats * 4 >= kSyncFlagBytes + (size_t)cus * kSyncSlotBytes) {
+    sync_ctl_upload(stream);
+    if (cnm_sync_failed()) return CNM_ERR_LAUNCH;                        // an earlier hand-off timed out: refuse until cnm_engine_status(1)
+    if (sync_ws && cus <= kSyncMaxRanges && sync_floats * 4 >= kSyncFlagBytes + (size_t)cus * kSyncSlotBytes) {
         const long long T = nunits * nch;
         grid = (int)(T / 4 < cus ? (T / 4 > 0 ? T / 4 : 1) : cus);
         flags = reinterpret_cast<unsigned*>(sync_ws); slots = sync_ws + kSyncFlagBytes / 4;

@@ -31,6 +31,8 @@
 // s_waitcnt vmcnt(0) (checked in the ISA); hidden from its counters, its counted waits for the weight fragments stay
 // counted and can only over-wait.  DMA completion is guaranteed by a counted wait before the phase barrier.
 #include "wino4_args.h"
+#include "sync_ws.h"
+#include <mutex>
 
 #ifndef WINO4S_WD
 #define WINO4S_WD 4       // weight fragments in flight per wave
@@ -46,6 +48,9 @@
 #endif
 #ifndef WINO4S_LO_STEP
 #define WINO4S_LO_STEP 14          // double step at which waves 0-3 issue their DMA pieces: late, so that the holds fall into their wait at the phase barrier
+#endif
+#ifndef WINO4S_PRIO
+#define WINO4S_PRIO 0
 #endif
 #ifndef WINO4S_HI_STEP
 #define WINO4S_HI_STEP 6  // double step at which waves 4-7 start issuing their DMA pieces (waves 0-3: step 0); >= 4
@@ -158,7 +163,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
     const auto range_begin = [&](int r) { return sync_flags ? (int)(T * r / G) : (int)((long long)nunits * r / G) * nch; };
     const int ps = range_begin(rng), pe = range_begin(rng + 1);
     const int P = pe - ps;                                               // phases of this workgroup
-    if (P <= 0) return;
+    if (P <= 0) { if (sync_flags && threadIdx.x == 0) sync_leave(sync_flags, G); return; }
 
     // ---- stage role: pieces n = wave + 8 m of the chunk's NDMA (plane q = n / NPIECE, piece k = n % NPIECE)
     // What a DMA instruction needs from the kernel arguments lives in laundered scalars: left to itself the compiler re-reads the
@@ -275,6 +280,9 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
     // step's MFMAs.  The last phase of a part keeps the barrier behind the loop (the output transform wants the registers).
     float4 bf0, bf1;
     bool bf_ready = false;
+#if WINO4S_PRIO                                                          // static priority for the second-dispatched half (guide: "Two waves per SIMD", item 4); 2 = the first half instead
+    if ((WINO4S_PRIO == 1) == (hi != 0)) __builtin_amdgcn_s_setprio(1);
+#endif
     for (int p = 0; p < P; ++p) {
         const unsigned vc = (p & 1) * VBUF + bvoff;
         const unsigned r0 = rbase + ((p + 1) & 1) * RAWBUF, rT = r0 + hi * PC * 16;      // raw buffer of phase p + 1
@@ -390,12 +398,9 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
         int nsrc = 0;                                                    // partial outputs to add: ranges rng + 1 .. rng + nsrc
         if (!publish && !lastc) {
             for (int rem = nch - 1 - mc; rem > 0; ++nsrc) rem -= range_begin(rng + nsrc + 2) - range_begin(rng + nsrc + 1);
-            if (t == 0) {                                                // one lane polls (relaxed), one acquire for the workgroup, flags re-armed for the next launch
-                for (int k = 1; k <= nsrc; ++k) {
-                    unsigned spins = 0;
-                    while (__hip_atomic_load(sync_flags + rng + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++spins < (1u << 24)) __builtin_amdgcn_s_sleep(8);
-                    __hip_atomic_store(sync_flags + rng + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+            if (t == 0) {                                                // one lane polls (relaxed) for this launch's generation, one acquire for the workgroup; a time-out is reported to the host (sync_ws.h)
+                const unsigned gen = sync_generation(sync_flags);
+                for (int k = 1; k <= nsrc; ++k) sync_wait(sync_flags, rng + k, gen);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
             __syncthreads();
@@ -498,7 +503,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
             if (publish) {                                               // every storing wave drains its stores, then ONE lane raises the flag
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
-                if (t == 0) __hip_atomic_store(sync_flags + rng, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (t == 0) sync_publish(sync_flags, rng, sync_generation(sync_flags));
             }
 #pragma unroll
             for (int x = 0; x < NXI; ++x) acc[x] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -507,6 +512,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
         if (lastc) { ++mu; mcblk = ncblk; }
         mc = 0; part_c0 = 0;
     }
+    if (sync_flags && t == 0) sync_leave(sync_flags, G);                 // the last workgroup out advances the workspace's generation
 #ifdef WINO4S_TIMELINE
     __syncthreads();
     if (blockIdx.x == 0 && t < 2 * 8 * 24) g_wino4s_tl[t] = reinterpret_cast<unsigned*>(smem + TL0)[t];
@@ -532,13 +538,46 @@ static int wino4s_cus() {                                                // comp
     return cus[dev];
 }
 
-// Sync workspace of one launch: kSyncFlagBytes of flag words (one per range, zero between launches: every raised flag is
-// lowered by its one consumer) followed by one partial-output slot per range.
-static constexpr size_t kSyncFlagBytes = 4096, kSyncSlotBytes = 8 * 16 * 64 * 16;
+// Sync workspace of one launch (sync_ws.h): kSyncFlagBytes of flag / generation words followed by one partial-output slot per range.
 extern "C" size_t cnm_wino36_sync_floats(void) { return (kSyncFlagBytes + (size_t)wino4s_cus() * kSyncSlotBytes) / 4; }
 
+// The pinned status word a timed-out poll writes (sync_ws.h).  Allocated on the first staged launch that is not being captured
+// into a graph (allocation is not allowed during capture; launches recorded before it exists run without host reporting).
+static unsigned* g_sync_status = nullptr;                                // host address == device address (mapped, portable)
+static unsigned g_sync_spin_limit = 0, g_sync_version = 0;             // 0 = kSyncDefaultSpins; the version counts changes of either word
+static std::mutex g_sync_mutex;
+SyncCtl cnm_sync_ctl(hipStream_t stream) {
+    if (!g_sync_status) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+        if (cs == hipStreamCaptureStatusNone) {
+            std::lock_guard<std::mutex> lock(g_sync_mutex);
+            if (!g_sync_status) {
+                void* p = nullptr;
+                if (hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess && p) {
+                    *reinterpret_cast<volatile unsigned*>(p) = 0u;
+                    g_sync_status = reinterpret_cast<unsigned*>(p);
+                    ++g_sync_version;
+                } else (void)hipGetLastError();
+            }
+        }
+    }
+    return SyncCtl{g_sync_status, g_sync_spin_limit, g_sync_version};
+}
+bool cnm_sync_failed() { return g_sync_status && *reinterpret_cast<volatile unsigned*>(g_sync_status) != 0u; }
+// CNM_OK, or CNM_ERR_LAUNCH when a stream-K hand-off timed out since the last clear (the outputs of that launch are
+// wrong).  Reads a pinned host word: synchronise the stream first if the launch in question may still be running.
+extern "C" int cnm_engine_status(int clear) {
+    const bool failed = cnm_sync_failed();
+    if (failed && clear) *reinterpret_cast<volatile unsigned*>(g_sync_status) = 0u;
+    return failed ? CNM_ERR_LAUNCH : CNM_OK;
+}
+// Debug / test only: polls before a hand-off gives up (0 = the default, 2^24); bit 31 = fault injection (publishers keep their flags down).
+extern "C" unsigned cnm_tune_sync_spin_limit(unsigned v) { const unsigned old = g_sync_spin_limit; if (v != old) { g_sync_spin_limit = v; ++g_sync_version; } return old ? old : kSyncDefaultSpins; }
+
 int cnm_wino36s_try_launch(const Wino4Args& a, int M, int ups, hipStream_t stream, int s2) {
-    if (!g_wino36_staged || (M != 4 && M != 2 && !(M == 3 && (s2 || ups))) || (ups && (M == 2 || s2)) || (s2 && M == 2) || a.Cout % 128) return 1;
+    const bool only_here = s2 || M == 3;                                 // forms without a gather-fed twin: the A/B knob and the balance heuristic below do not apply
+    if ((!g_wino36_staged && !only_here) || (M != 4 && M != 2 && !(M == 3 && (s2 || ups))) || (ups && (M == 2 || s2)) || (s2 && M == 2) || a.Cout % 128) return 1;
     int tsx = 0;
     if (a.TW >= 12) tsx = 16; else if (a.TW >= 6 && a.TH >= 2) tsx = 8; else if (M == 4 && !ups && !s2 && a.TW >= 3 && a.TH >= 3) tsx = 4;   // tile block 1 x 16, 2 x 8, 4 x 4
     if (s2) {
@@ -560,14 +599,16 @@ int cnm_wino36s_try_launch(const Wino4Args& a, int M, int ups, hipStream_t strea
     const int cus = wino4s_cus();
     int grid = (int)(nunits < cus ? nunits : cus);
     unsigned* flags = nullptr; float* slots = nullptr;
-    if (a.sync_ws && cus * 4 <= (int)kSyncFlagBytes && a.sync_floats * 4 >= kSyncFlagBytes + (size_t)cus * kSyncSlotBytes) {
+    sync_ctl_upload(stream);
+    if (cnm_sync_failed()) return CNM_ERR_LAUNCH;                        // an earlier hand-off timed out: refuse until cnm_engine_status(1) has acknowledged it
+    if (a.sync_ws && cus <= kSyncMaxRanges && a.sync_floats * 4 >= kSyncFlagBytes + (size_t)cus * kSyncSlotBytes) {
         // phase ranges may cut units: every CU gets the same number of phases (at least four, or the prologue and the
         // fix-up of a range cost more than they balance)
         const long long T = nunits * a.nchunks;
         grid = (int)(T / 4 < cus ? (T / 4 > 0 ? T / 4 : 1) : cus);
         flags = reinterpret_cast<unsigned*>(a.sync_ws);
         slots = a.sync_ws + kSyncFlagBytes / 4;
-    } else if (g_wino36_staged != 2 && nunits > cus && (double)((nunits + cus - 1) / cus) * cus / (double)nunits > 1.15) {
+    } else if (g_wino36_staged != 2 && !only_here && nunits > cus && (double)((nunits + cus - 1) / cus) * cus / (double)nunits > 1.15) {
         // Without a sync workspace ranges end on unit boundaries: one workgroup per CU walks ceil(units / CUs) units, and a
         // mostly empty last round costs more than the kernel gains (1.09-1.13x on whole rounds, 0.85-0.89x at 1.5 rounds,
         // tools/wino36s_probe.py); the gather-fed kernel, two independent workgroups per CU, balances those better.

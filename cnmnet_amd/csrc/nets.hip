@@ -50,7 +50,7 @@ extern "C" const char* cnm_status_string(int status) {
         case CNM_ERR_BAD_ARG: return "bad argument (null pointer, non-positive size or unsupported parameter)";
         case CNM_ERR_BAD_SHAPE: return "image height and width must be multiples of 32";
         case CNM_ERR_BAD_SCALE: return "idepth_scale must be 2.0 or 3.0";
-        case CNM_ERR_LAUNCH: return "HIP kernel launch failed";
+        case CNM_ERR_LAUNCH: return "HIP kernel launch failed, or a stream-K hand-off timed out inside an earlier launch (cnm_engine_status)";
         case CNM_ERR_WORKSPACE: return "workspace too small";
         default: return "unknown status";
     }

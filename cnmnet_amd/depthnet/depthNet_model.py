@@ -280,7 +280,13 @@ class depthNet(_EngineNet):
             return [self.forward(left_image, right_images[:, s], left_cam, right_cams[:, s]) for s in range(right_images.shape[1])]
         ops.idepth_range(self.idepth_scale)
         self._require_gpu(left_image, right_images, left_cam, right_cams)
-        S = right_images.shape[1]
+        B, S, _, H, W = right_images.shape
+        if H % 32 or W % 32:
+            raise ValueError("image height and width must be multiples of 32 (got %dx%d)" % (H, W))
+        # every activation of the one-pass form is S times as large as in S calls, and the convolution kernels address a
+        # tensor with 32-bit byte offsets (512 B per pixel and pair at full resolution): past that, make the S calls
+        if S * B * 512 * H * W > self.max_call_bytes:
+            return [self.forward(left_image, right_images[:, s], left_cam, right_cams[:, s]) for s in range(S)]
         disp, feat = self._forward_train(left_image.contiguous(), right_images.contiguous(), left_cam.contiguous(), right_cams.contiguous(),
                                          per_source_statistics=True)
         feats = ag.SplitSources.apply(feat, S)                          # sample n of the pass belongs to source n % S

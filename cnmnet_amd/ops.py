@@ -340,9 +340,22 @@ def conv3x3_s2_winograd_c4(x, u_packed, b_packed, Cout, relu=True):
 
 
 def wino36_sync_workspace(device):
-    """Zeroed sync workspace for the LDS-staged F(4x4,3x3) kernel (flag words + partial-output slots): one per stream of
-    launches; every call leaves the flag words zero again."""
+    """Zeroed sync workspace for the LDS-staged persistent kernels (flag / generation words + partial-output slots,
+    csrc/sync_ws.h): one per stream of launches; zero before the first use, reusable after every call."""
     return torch.zeros(_lib.load().cnm_wino36_sync_floats(), device=device, dtype=torch.float32)
+
+
+def sync_workspace_state(sync):
+    """(generation, workgroups still counted as leaving) of a sync workspace: after n stream-K launches that used it the
+    state is (n, 0) -- the last workgroup out of each launch advanced the generation and reset the exit counter."""
+    words = sync[:1024].view(torch.int32)[1020:1022].tolist()
+    return int(words[0]) & 0xFFFFFFFF, int(words[1])
+
+
+def engine_status(clear=True):
+    """Raise EngineError if a stream-K hand-off has timed out since the last acknowledgement (cnm_engine_status); with
+    clear=True the failure is acknowledged, so later launches are accepted again.  Synchronise first."""
+    _lib.check(_lib.load().cnm_engine_status(int(bool(clear))))
 
 
 def conv3x3_winograd4_c4(x, u_packed, b_packed, Cout, relu=True, x2=None, ksize=3, sync=None):

@@ -137,14 +137,18 @@ class BucketedGradAllReduce:
             h.remove()
 
 
-def _masked_l1(pred, gt, dist=None, weight=None, exact=False):
+def _masked_l1(pred, gt, dist=None, weight=None, exact=False, group=None):
     """IdepthLoss / IdepthwithProbLoss (reference losses.py:30-73), optionally normalised by the global
     mask count so that averaging the per-rank gradients equals the gathered-batch loss.
+    `group`: the process group of the gradient exchange (the trainer's `group`): the mask count is reduced over the SAME
+    ranks the gradients are averaged over, on the same backend (with bench.py's init_dist the default group is gloo and the
+    gradient group RCCL: the default group would move a device scalar through the host in every loss term).
     Static shapes: the reference gathers `pred[mask]` (a device-to-host synchronisation per loss term, which stops the
     host from enqueueing the backward pass while the forward pass still runs); here masked-out elements are replaced by
     zeros BEFORE the difference (so a non-finite ground truth never reaches the arithmetic or the gradient) and the sum
     is divided by the mask count -- the same mean, NaN for an empty mask (0 / 0) as the reference's mean of nothing."""
-    if FUSED_MASKED_L1 and pred.is_cuda and pred.dtype == torch.float32 and not (exact and dist is not None and dist.is_initialized() and dist.get_world_size() > 1):
+    multi = exact and dist is not None and dist.is_initialized() and dist.get_world_size(group) > 1
+    if FUSED_MASKED_L1 and pred.is_cuda and pred.dtype == torch.float32 and not multi:
         from .autograd import MaskedL1
         return MaskedL1.apply(pred, gt.expand_as(pred), weight.expand_as(pred) if weight is not None else None)   # one launch each way
     m = _valid(pred, gt)
@@ -153,10 +157,10 @@ def _masked_l1(pred, gt, dist=None, weight=None, exact=False):
     if weight is not None:
         diff = diff * torch.where(m, weight, zero)
     n = total(m).to(pred.dtype)                      # `total`: reductions without scratch memory (HIP-graph replay, see losses.total)
-    if exact and dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+    if multi:
         n = n.reshape(1).clone()
-        dist.all_reduce(n)
-        return total(diff) / (n[0] / dist.get_world_size()).clamp(min=1.0)
+        dist.all_reduce(n, group=group)
+        return total(diff) / (n[0] / dist.get_world_size(group)).clamp(min=1.0)
     return total(diff) / n
 
 
@@ -180,7 +184,7 @@ class TrainStepWoNormal:
         """group: process group of the gradient all-reduce (None = default).  graph=True with more than one rank: forward and
         backward are replayed as ONE HIP graph, the bucketed all-reduce and the Adam update follow eagerly (a collective
         stays outside the captured region; the backward hooks that overlap buckets with backward do not exist in a replay)."""
-        self.depth_net, self.refine_net, self.dist, self.exact = depth_net, refine_net, dist, exact_masked_means
+        self.depth_net, self.refine_net, self.dist, self.exact, self.group = depth_net, refine_net, dist, exact_masked_means, group
         params = list(refine_net.parameters()) + list(depth_net.parameters())              # train.py:87, :446
         self.optimizer = make_adam(params, lr, weight_decay, capturable=bool(graph))          # utils/misc.py:31-33
         self.reducer = None
@@ -284,7 +288,7 @@ class TrainStepWoNormal:
             p01, f01 = self.depth_net(rgbs[:, 0], rgbs[:, 1], cameras[:, 0], cameras[:, 1])     # :509-512
             p02, f02 = self.depth_net(rgbs[:, 0], rgbs[:, 2], cameras[:, 0], cameras[:, 2])
         idr, prob = self.refine_net(idepth01=p01[0], idepth02=p02[0], iconv01=f01, iconv02=f02)   # :517-520
-        L = lambda a, b, w=None: _masked_l1(a, b, self.dist, w, self.exact)
+        L = lambda a, b, w=None: _masked_l1(a, b, self.dist, w, self.exact, self.group)
         loss_idepth_1 = (L(p01[0], gt_id) + L(p02[0], gt_id)) * 0.5                          # :522-523
         loss_idepth_refined = L(idr, gt_id)                                                  # :525
         loss_idepth_234 = (self.l234(p01, gt_id) + self.l234(p02, gt_id)) * 0.5              # :527-528
@@ -404,7 +408,7 @@ class TrainStep(TrainStepWoNormal):
             p01, f01 = self.depth_net(rgbs[:, 0], rgbs[:, 1], cameras[:, 0], cameras[:, 1])     # :164-167
             p02, f02 = self.depth_net(rgbs[:, 0], rgbs[:, 2], cameras[:, 0], cameras[:, 2])
         idr, prob = self.refine_net(idepth01=p01[0], idepth02=p02[0], iconv01=f01, iconv02=f02)   # :172-175
-        L = lambda a, b, w=None: _masked_l1(a, b, self.dist, w, self.exact)
+        L = lambda a, b, w=None: _masked_l1(a, b, self.dist, w, self.exact, self.group)
         loss_idepth_1 = (L(p01[0], gt_id) + L(p02[0], gt_id)) * 0.5                          # :177-178
         loss_idepth_refined = L(idr, gt_id)                                                  # :180
         d01, d02 = 1.0 / p01[0].squeeze(1), 1.0 / p02[0].squeeze(1)                          # :185-186

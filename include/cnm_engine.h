@@ -14,8 +14,13 @@
  *     enqueued on it, nothing synchronises, nothing allocates;
  *   - the caller owns every buffer, including workspaces (sizes via *_floats());
  *   - return value: CNM_OK (0) or a negative cnm_status; never throws;
- *   - re-entrant: no process-global mutable state (contrast the reference's module
- *     global pixel_coords, depthnet/inverse_warp.py:5).
+ *   - re-entrant: the data path keeps no process-global mutable state (contrast the
+ *     reference's module global pixel_coords, depthnet/inverse_warp.py:5); every buffer,
+ *     workspace and stream comes from the caller, so DataParallel worker threads (one per
+ *     device / stream) may call concurrently.  Two things ARE process-wide, both outside the
+ *     data path: the cnm_tune_* knobs (DEBUG / A-B switches for benches and tests: set them
+ *     before the first forward and not while other threads are inside the engine; the
+ *     defaults are the product) and the engine status word behind cnm_engine_status().
  *
  * Activation layout inside the engine ("c4"): [N][G][H][W][4] floats, channel
  * c = 4*g + j, G = ceil(C/4), padded channels are zero.  A c4 view is described by
@@ -37,7 +42,20 @@ extern "C" {
 #define CNM_ABI_VERSION 4
 #define CNM_WINO4_MIN_WORKGROUPS 384
 #define CNM_UPSAMPLED_MIN_PIXELS 196608      /* 16 images x 96 x 128 */
-/* Tuning knobs (the engine's only process-wide state).  Each returns the previous value.
+/* Engine status.  The persistent stream-K convolution kernels hand partial outputs from one workgroup to another inside a
+ * launch; a hand-off that does not complete within its spin bound (it cannot, unless workgroups of one launch are not
+ * co-resident for seconds) does not hang and does not pass silently: the kernel records it in a pinned host word, the
+ * outputs of that launch are wrong, and EVERY later call of a staged-kernel entry point returns CNM_ERR_LAUNCH without
+ * launching until the failure has been acknowledged.  cnm_engine_status(clear) returns CNM_OK or CNM_ERR_LAUNCH (a
+ * hand-off timed out since the last clear) and, with clear != 0, acknowledges it.  It reads host memory only: synchronise
+ * the stream first when the launch in question may still be running.  The sync workspaces need no repair afterwards
+ * (flags carry a per-launch generation, csrc/sync_ws.h). */
+int cnm_engine_status(int clear);
+/* DEBUG / TEST ONLY: polls before a hand-off gives up (default 2^24, about five seconds); bit 31 injects the fault the
+ * bound exists for (publishing workgroups keep their flag down).  Returns the previous value. */
+unsigned cnm_tune_sync_spin_limit(unsigned polls);
+
+/* Tuning knobs -- DEBUG / A-B switches, process-wide (see "re-entrant" above).  Each returns the previous value.
  * wino4_min_workgroups: workgroup count from which the fp32 executors prefer the F(4x4,3x3) kernel; n <= 0 only queries.
  * refine_side_stream: 1 (default) runs DepthRefineNet's probability decoder on an engine-owned side stream, forked from
  *   and joined back into the caller's stream with events (the two decoders of depthNet_model.py:341-365 are independent);
@@ -75,7 +93,7 @@ typedef enum cnm_status {
     CNM_ERR_BAD_ARG = -1,       /* null pointer, non-positive size, unsupported parameter */
     CNM_ERR_BAD_SHAPE = -2,     /* H/W not a multiple of 32 for the nets (reference: torch.cat fails) */
     CNM_ERR_BAD_SCALE = -3,     /* idepth_scale not 2.0 or 3.0 (reference: UnboundLocalError, depthNet_model.py:186-191) */
-    CNM_ERR_LAUNCH = -4,        /* hipGetLastError() != hipSuccess after a launch */
+    CNM_ERR_LAUNCH = -4,        /* hipGetLastError() != hipSuccess after a launch, or an unacknowledged device-side failure (cnm_engine_status) */
     CNM_ERR_WORKSPACE = -5      /* workspace smaller than *_workspace_floats() */
 } cnm_status;
 
@@ -191,8 +209,9 @@ int cnm_conv3x3_winograd4_c4_f32(const float* in_a, int Ga_total, int ga0, int G
                                  int N, int H, int W, int relu, void* stream);
 /* The same convolution with a sync workspace for the LDS-staged persistent kernel (conv_winograd4s.hip: 128 output
  * channels x 16 tiles per workgroup, one workgroup per CU).  sync_ws = cnm_wino36_sync_floats() floats: 4096 bytes of flag
- * words -- zero before the first use, left zero by every call -- followed by one 128 KB partial-output slot per CU; it must
- * not be shared by launches that can run concurrently.  With it the kernel splits the layer's (unit, 16-channel chunk)
+ * and generation words -- zero before the first use; a call leaves them in a state every later call accepts, also after
+ * a failed hand-off (cnm_engine_status) -- followed by one 128 KB partial-output slot per CU; it must not be shared by
+ * launches that can run concurrently.  With it the kernel splits the layer's (unit, 16-channel chunk)
  * phases into equal contiguous ranges, one per CU, whatever the unit count: a unit cut by a range boundary is finished by
  * the range that holds its first chunk, which adds the other ranges' partial outputs in range order (write-through
  * stores + flag, agent-scope acquire).  Results are bit-reproducible from run to run; they differ from the unsplit
@@ -330,7 +349,7 @@ int cnm_conv_rows_winograd_c4_f32(const float* in_a, int Ga_total, int ga0, int 
                                   float* out, int Gout_total, int gout0, int Cout,
                                   const float* u_packed, const float* b_packed,
                                   int N, int H, int W, int ksize, int stride, int tile, int relu, void* stream);
-/* The same with a sync workspace (cnm_wino36_sync_floats() floats, zero before the first use and left zero, one per
+/* The same with a sync workspace (cnm_wino36_sync_floats() floats, zero before the first use, one per
  * stream): the 7x7 stride-1 four-output shape with Cout % 128 == 0 runs the LDS-staged persistent kernel
  * (csrc/conv_rows_staged.hip) with equal shares of the reduction per CU; other shapes ignore the workspace.
  * cnm_tune_rows7_staged(0) routes that shape back to the gather-fed kernel (returns the previous setting). */

@@ -28,6 +28,24 @@ def torch_state(np_state):
     return {k: torch.from_numpy(np.asarray(v)) for k, v in np_state.items()}
 
 
+def normal_parity(got, want, ref_cam, disp_oracle, k_size=9, trust=5e-4):
+    """North-star bar for normals as a statement about EVERY pixel.  The reference inverts the 81-point
+    normal equations in fp32, so its own output moves by up to 3.5e-3 with the summation order; the engine sums in fp64.
+    With n64 = the same fit evaluated in float64 on the oracle's depth:
+      e_fit  = max |engine - n64| over ALL pixels                                   (asserted < 1e-3 by the callers)
+      e_ref  = max |engine - reference| over the pixels where the reference itself is within `trust` of n64
+      excluded = the fraction of pixels outside that set (where the reference's fp32 solve is the one that is off).
+    got / want [B,3,H,W] torch (cpu), ref_cam [B,2,4,4], disp_oracle [B,1,H,W].  Returns (e_fit, e_ref, excluded, q99)."""
+    from oracle import ref_arrangement as ra
+    n64, _ = ra.depth_to_normal(1.0 / disp_oracle.double().squeeze(1), ref_cam[:, 1, :3, :3].double().inverse(), k_size)
+    ref_off = (want.double() - n64).abs().amax(1)
+    trusted = ref_off < trust
+    d = (got.double() - want.double()).abs().amax(1)
+    e_fit = float((got.double() - n64).abs().max())
+    e_ref = float(d[trusted].max()) if bool(trusted.any()) else 0.0
+    return e_fit, e_ref, float(1.0 - trusted.double().mean()), float(d.flatten().quantile(0.99))
+
+
 @pytest.fixture(scope="session", autouse=True)
 def _engine_library():
     """Build libcnm_engine.so once if the tree has not been built yet (hipcc cross-compiles without a GPU)."""

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from cnmnet_amd import synthetic as syn
-from conftest import torch_state
+from conftest import normal_parity, torch_state
 from oracle import closed_form as cf
 from oracle import ref_arrangement as ra
 
@@ -67,6 +67,44 @@ def test_config4_batch4_four_sources(dev):
     a = pipe(torch.cat((ti[:1, :3], ti[:1, 1:3]), 1), torch.cat((tc[:1, :3], tc[:1, 1:3]), 1))
     b2 = pipe(ti[:1, :3].contiguous(), tc[:1, :3].contiguous())
     assert float((a["disp"] - b2["disp"]).abs().max()) < 2e-4
+
+
+def test_config4_one_frame_vs_oracle(dev):
+    """configs[3] at its full size against the CPU oracle: one frame of 1 ref + 4 src at 640x480 with
+    96 planes through oracle.ref_arrangement (DepthNetCPU(3.0, 96) on the four pairs, even / odd averaging, the refine net,
+    Depth2normal k = 9 -- about a minute of host time) and through the engine as ONE batch entry of a B = 2 call (so the 4 x 4
+    and 2 x 8 tile blocks, the 120x160 ... 15x20 feature maps and their stream-K ranges are the ones a real config-4 call
+    picks).  Inverse depth / probability max < 1e-3; normals as in test_bench_configuration_vs_oracle."""
+    from cnmnet_amd.depthnet import depthNet, DepthRefineNet
+    from cnmnet_amd.pipeline import FramePipeline
+    B, S, H, W, D = 2, 4, 480, 640, 96
+    img, cams = syn.frames(B, S, H, W, seed=23)
+
+    def load(module, seed, head_scale):                                  # heads out of sigmoid saturation (test_bench_configuration_vs_oracle)
+        shapes = {k: tuple(v.shape) for k, v in module.state_dict().items()}
+        w = syn.state_dict_like(shapes, seed=seed, randomize_bn=True)
+        w = {k: (v * head_scale if (v.ndim == 4 and v.shape[0] == 1) else v) for k, v in w.items()}
+        module.load_state_dict(torch_state(w))
+        return module.eval()
+
+    pipe = FramePipeline(load(depthNet(3.0, D), 61, 0.2).to(dev), load(DepthRefineNet(32, 3.0), 62, 0.05).to(dev), k_size=9)
+    with torch.no_grad():
+        out = pipe(T(img).to(dev), T(cams).to(dev))
+    b = 1
+    cd, cr = load(ra.DepthNetCPU(3.0, D), 61, 0.2), load(ra.DepthRefineNetCPU(32, 3.0), 62, 0.05)
+    with torch.no_grad():
+        disp, prob = ra.frame_forward_multi(cd, cr, T(img[b]), T(cams[b]))
+        K_inv = T(cams[b:b + 1, 0])[:, 1, :3, :3].inverse()
+        normal, _ = ra.depth_to_normal(1.0 / disp.squeeze(1), K_inv, 9)                  # eval.py:452-455
+    e_d = float((out["disp"][b:b + 1].cpu() - disp).abs().max())
+    e_p = float((out["prob"][b:b + 1].cpu() - prob).abs().max())
+    e_fit, e_ref, excluded, q99 = normal_parity(out["normal"][b:b + 1].cpu(), normal, T(cams[b:b + 1, 0]), disp)
+    print("config 4 frame vs oracle (640x480, D=96, S=4): inverse depth max %.1e, probability max %.1e, normals q99 %.1e; vs float64 fit max %.1e, "
+          "vs reference max %.1e where it is within 5e-4 of the fit (%.2f %% excluded); oracle inverse depth %.2f .. %.2f"
+          % (e_d, e_p, q99, e_fit, e_ref, 100 * excluded, float(disp.min()), float(disp.max())))
+    assert float(disp.min()) > 0.05 and float(disp.max()) < 2.95            # the comparison sees every pixel (no saturated sigmoid)
+    assert e_d < 1e-3 and e_p < 1e-3, (e_d, e_p)
+    assert q99 < 1e-3 and e_fit < 1e-3 and e_ref < 1e-3 and excluded < 0.10, (q99, e_fit, e_ref, excluded)
 
 
 def test_config3_shard_train_step_first_loss(dev):

@@ -11,13 +11,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _check_line(r):
+def _check_line(r, world=2, frames=8):
     assert r.returncode == 0, (r.stderr or "")[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]                              # rank 0 prints the one line
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["unit"] == "frames/s"
-    assert abs(d["value"] - 2 * 8 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]     # all ranks' frames / slowest rank's time
+    assert d["n_gpus"] == world and d["steps"] == 3 and d["scaling"] == "weak" and d["unit"] == "frames/s"
+    assert abs(d["value"] - world * frames * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]     # all ranks' frames / slowest rank's time
     assert "cpu_baseline" not in d and "f16" not in d                      # N = 1 only
     assert d["step_ms"]["n"] == 3 and d["step_ms"]["p10"] <= d["step_ms"]["median"] <= d["step_ms"]["p90"]
     assert d["per_rank_frames_per_s"]["min"] <= d["per_rank_frames_per_s"]["max"]
@@ -58,3 +58,37 @@ def test_two_rank_train_mode_line():
     ar = d["allreduce"]
     assert ar["bytes_per_step"] == 4 * 44674566 and ar["buckets"] >= 3                    # 33 898 500 + 10 776 066 parameters
     assert ar["launched_from_backward_hooks"] + ar["launched_late"] == ar["buckets"] and ar["exposed_ms"] > 0
+
+
+def _clean_env():
+    env = dict(os.environ, CNM_BENCH_BACKEND="gloo", CNM_BENCH_DEVICE="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "OMP_NUM_THREADS"):
+        env.pop(k, None)
+    return env
+
+
+def test_eight_rank_dry_run_eval():
+    """the driver's 8-GPU form, dry-run on ONE GPU -- eight ranks self-launched by `python bench.py --gpus 8`
+    (rendezvous on 127.0.0.1, LOCAL_RANK -> device mapping overridden to GPU 0, gloo for the barrier and the timing reduce,
+    host threads capped per rank), one frame per rank: the line has the N = 8 shape and the whole-job value."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--frames-per-gpu", "1",
+           "--no-roofline", "--no-secondary"]
+    r = subprocess.run(cmd, cwd=ROOT, env=_clean_env(), capture_output=True, text=True, timeout=1200)
+    _check_line(r, world=8, frames=1)
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["config"]["barrier_backend"] == "gloo" and d["config"]["host_threads_per_rank"] >= 1
+
+
+def test_eight_rank_dry_run_train():
+    """The same for --mode train (BASELINE configs[2]: 8 ranks, data parallel): every bucket of the gradient exchange leaves
+    from a backward hook on every step (the overlapped path), the line carries the global batch of 8 x 1."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "train", "--gpus", "8", "--steps", "2", "--warmup", "1", "--samples-per-gpu", "1"]
+    r = subprocess.run(cmd, cwd=ROOT, env=_clean_env(), capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, (r.stderr or "")[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["unit"] == "samples/s" and d["n_gpus"] == 8 and d["config"]["global_batch"] == 8 and d["config"]["parallelism"] == "dp8"
+    assert abs(d["value"] - 8 * 1 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+    ar = d["allreduce"]
+    assert ar["bytes_per_step"] == 4 * 44674566 and ar["launched_from_backward_hooks"] == ar["buckets"] and ar["launched_late"] == 0

@@ -11,7 +11,7 @@ import torch
 import torch.nn.functional as F
 
 from cnmnet_amd import synthetic as syn
-from conftest import torch_state
+from conftest import normal_parity, torch_state
 from oracle import closed_form as cf
 from oracle import ref_arrangement as ra
 
@@ -346,7 +346,7 @@ def test_conv_rows_wide_equals_narrow(dev, ops, k, stride, cin, cout, N, H, W):
 def test_conv_rows7_staged(dev, ops, cin, cin2, cout, N, H, W):
     """LDS-staged 7x7 stride-1 row-wise kernel (conv_rows_staged.hip): bit-equal to the gather-fed kernel without a sync
     workspace (same reduction order); with one (units cut at range boundaries, partial outputs added in range order) equal to
-    it within fp32 re-association error, bit-reproducible run to run, flag words left zero."""
+    it within fp32 re-association error, bit-reproducible run to run, the workspace left at generation 2."""
     from cnmnet_amd import _lib
     lib = _lib.load()
     rng = np.random.default_rng(cin * 7 + H)
@@ -370,7 +370,7 @@ def test_conv_rows7_staged(dev, ops, cin, cin2, cout, N, H, W):
     assert torch.equal(ref, got), float((ref - got).abs().max())
     assert torch.allclose(ref, split, rtol=2e-4, atol=2e-4), float((ref - split).abs().max())   # fp32 sums in a different order
     assert torch.equal(split, split2)
-    assert int(sync[:1024].abs().sum().item()) == 0
+    assert ops.sync_workspace_state(sync) == (2, 0)                    # two launches completed, nobody left counted
 
 
 @pytest.mark.parametrize("cin,cin2,cout,rot,N,H,W", [
@@ -417,10 +417,57 @@ def test_conv3x3_winograd4_staged(dev, ops, cin, cin2, cout, rot, N, H, W):
     assert np.abs(got - want).max() < 2e-4 * max(np.abs(want).max(), 1.0), np.abs(got - want).max()
     assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
     # with the sync workspace a unit cut by a range boundary is the sum of its parts' output transforms, added in range
-    # order: bit-reproducible, within the same bar of the fp64 convolution, every flag word lowered again
+    # order: bit-reproducible, within the same bar of the fp64 convolution, the workspace left at generation 2
     got = ops.c4_to_nchw(outs[2], cout).cpu().numpy()
     assert np.abs(got - want).max() < 2e-4 * max(np.abs(want).max(), 1.0), np.abs(got - want).max()
-    assert torch.equal(outs[2], outs[3]) and float(sync[:1024].abs().max()) == 0.0
+    assert torch.equal(outs[2], outs[3]) and ops.sync_workspace_state(sync) == (2, 0)
+
+
+@pytest.mark.parametrize("kind", ["wino36", "rows7"])
+def test_stream_k_handoff_timeout_is_loud(dev, ops, kind):
+    """ADVICE r3 / VERDICT r3 item 4c: a stream-K hand-off that does not complete must not pass silently and must not poison
+    the workspace.  Fault injection (bit 31 of cnm_tune_sync_spin_limit: publishing workgroups keep their flags down) makes
+    every head range run into its spin bound: the launch returns, cnm_engine_status() reports CNM_ERR_LAUNCH, the next
+    staged call is refused until the failure is acknowledged -- and then the SAME workspace, unrepaired, gives the
+    bit-identical right result, also with garbage in every flag word (flags carry a per-launch generation, csrc/sync_ws.h)."""
+    from cnmnet_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(77)
+    if kind == "wino36":
+        cin, cout, N, H, W = 48, 384, 2, 52, 100                          # 156 units of 3 chunks on 117 ranges of 4 phases: most units are cut
+        x = ops.nchw_to_c4(T(rng.standard_normal((N, cin, H, W)).astype(np.float32)).to(dev))
+        w = T((rng.standard_normal((cout, cin, 3, 3)) * 0.05).astype(np.float32)).to(dev)
+        up = ops.pack_winograd4(w); bp = T(rng.standard_normal(cout).astype(np.float32)).to(dev)
+        run = lambda s: ops.conv3x3_winograd4_c4(x, up, bp, cout, True, sync=s).clone()
+    else:
+        cin, cout, N, H, W = 35, 128, 2, 37, 50                           # 8 phases per unit, cut in two by the sync grid
+        x = ops.nchw_to_c4(T(rng.standard_normal((N, cin, H, W)).astype(np.float32)).to(dev))
+        w = T((rng.standard_normal((cout, cin, 7, 7)) * 0.02).astype(np.float32)).to(dev)
+        up = ops.pack_winograd(w, stride=1, tile=4); bp = T(rng.standard_normal(cout).astype(np.float32)).to(dev)
+        run = lambda s: ops.conv_rows_winograd_c4(x, up, bp, cout, 7, True, stride=1, tile=4, sync=s).clone()
+    sync = ops.wino36_sync_workspace(dev)
+    good = run(sync)
+    torch.cuda.synchronize()
+    assert lib.cnm_engine_status(0) == 0 and ops.sync_workspace_state(sync) == (1, 0)
+    old = lib.cnm_tune_sync_spin_limit(0x80000000 | 500)
+    try:
+        run(sync)                                                        # hand-offs time out: wrong output, but it returns
+        torch.cuda.synchronize()
+        assert lib.cnm_engine_status(0) == -4                            # CNM_ERR_LAUNCH, sticky
+        with pytest.raises(_lib.EngineError):
+            run(sync)                                                    # refused, nothing launched
+        assert ops.sync_workspace_state(sync) == (2, 0)
+        with pytest.raises(_lib.EngineError):
+            ops.engine_status(clear=True)                                # reports and acknowledges
+        assert lib.cnm_engine_status(0) == 0
+    finally:
+        lib.cnm_tune_sync_spin_limit(old)
+        lib.cnm_engine_status(1)
+    assert torch.equal(run(sync), good)                                  # no repair needed
+    sync[:1020].view(torch.int32).copy_(T(rng.integers(-2**31, 2**31 - 1, 1020, dtype=np.int64).astype(np.int32)).to(dev))
+    assert torch.equal(run(sync), good) and ops.sync_workspace_state(sync) == (4, 0)
+    torch.cuda.synchronize()
+    assert lib.cnm_engine_status(0) == 0
 
 
 @pytest.mark.parametrize("cin,cout,rot,N,H,W", [(64, 128, 0, 2, 40, 48), (35, 256, 3, 1, 9, 29), (128, 256, 0, 3, 24, 32), (16, 128, 0, 1, 96, 128)])
@@ -451,7 +498,7 @@ def test_conv5x5_winograd_staged(dev, ops, cin, cout, rot, N, H, W):
     finally:
         lib.cnm_tune_wino36_staged(old)
     assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
-    assert torch.equal(outs[2], outs[3]) and float(sync[:1024].abs().max()) == 0.0          # reproducible; flag words re-armed
+    assert torch.equal(outs[2], outs[3]) and ops.sync_workspace_state(sync) == (2, 0)        # reproducible; two generations
     for o in (outs[1], outs[2]):
         got = ops.c4_to_nchw(o, cout).cpu().numpy()
         assert np.abs(got - want).max() < 2e-4 * max(np.abs(want).max(), 1.0), np.abs(got - want).max()
@@ -497,7 +544,7 @@ def test_conv_s2_winograd4_staged(dev, ops, k, cin, cin2, cout, rot, N, H, W):
     assert got.shape == want.shape
     err = np.abs(got - want).max()
     assert err < 2e-4 * max(np.abs(want).max(), 1.0), err
-    assert torch.equal(o1, o2) and float(sync[:1024].abs().max()) == 0.0
+    assert torch.equal(o1, o2) and ops.sync_workspace_state(sync) == (2, 0)
     if not cin2 and k != 3:                                              # the row-wise phase kernel on the same input: same bar
         ur = ops.pack_winograd(w.to(dev), bnd, rot=rot, stride=2)
         rows = ops.c4_to_nchw(ops.conv_rows_winograd_c4(xc, ur, bp, cout, k, True, stride=2), cout).cpu().numpy()
@@ -696,12 +743,12 @@ def test_bench_configuration_vs_oracle(dev):
         # The tail of that normal error is the REFERENCE's rounding, not the engine's: the same least-squares fit on the
         # oracle's depth in float64 is met by the fp32 reference arrangement only to q99 9e-4 / max 3.5e-3 (81-point normal
         # equations inverted in fp32), while the engine (fp64 window sums) stays within 1e-3 of it on EVERY pixel even
-        # though its depth input carries the conv stack's own 2e-5.
-        n64, _ = ra.depth_to_normal(1.0 / want["disp"].double().squeeze(1), T(cams[b:b + 1, 0])[:, 1, :3, :3].double().inverse(), 9)
-        e_gpu = float((out["normal"][b:b + 1].cpu().double() - n64).abs().max())
-        e_ref = float((want["normal"].double() - n64).abs().max())
-        print("          normals vs the float64 fit: engine max %.1e, fp32 reference arrangement max %.1e" % (e_gpu, e_ref))
-        assert e_gpu < 1e-3, e_gpu
+        # though its depth input carries the conv stack's own 2e-5.  Stated as a MAX: the engine is within 1e-3 of the
+        # reference on every pixel where the reference is itself within 5e-4 of the float64 fit; the rest is counted.
+        e_fit, e_ref, excluded, _ = normal_parity(out["normal"][b:b + 1].cpu(), want["normal"], T(cams[b:b + 1, 0]), want["disp"])
+        print("          normals: engine vs the float64 fit max %.1e (all pixels); engine vs reference max %.1e on the %.2f %% of pixels where the reference is within 5e-4 of that fit"
+              % (e_fit, e_ref, 100 * (1 - excluded)))
+        assert e_fit < 1e-3 and e_ref < 1e-3 and excluded < 0.10, (e_fit, e_ref, excluded)
 
 
 def test_winograd4_networks_golden(dev, golden):
@@ -1007,9 +1054,12 @@ def test_frame_other_sizes_vs_oracle(dev, B, H, W):
                                 T(cams[b:b + 1, 0]), T(cams[b:b + 1, 1]), T(cams[b:b + 1, 2]))
     errs = {k: float((out[k][b:b + 1].cpu() - want[k]).abs().max()) for k in ("disp", "prob", "disp_a", "disp_b")}
     nerr = (out["normal"][b:b + 1].cpu() - want["normal"]).abs().amax(1).flatten()
-    print("%dx%d batch %d: max|err| %s, normal q99 %.2e" % (W, H, B, {k: "%.1e" % v for k, v in errs.items()}, float(nerr.quantile(0.99))))
+    e_fit, e_ref, excluded, _ = normal_parity(out["normal"][b:b + 1].cpu(), want["normal"], T(cams[b:b + 1, 0]), want["disp"])
+    print("%dx%d batch %d: max|err| %s, normal q99 %.2e; vs float64 fit max %.1e, vs reference max %.1e where it is within 5e-4 of the fit (%.2f %% excluded)"
+          % (W, H, B, {k: "%.1e" % v for k, v in errs.items()}, float(nerr.quantile(0.99)), e_fit, e_ref, 100 * excluded))
     assert max(errs.values()) < 1e-3, errs
     assert float(nerr.quantile(0.99)) < 1e-3
+    assert e_fit < 1e-3 and e_ref < 1e-3 and excluded < 0.10, (e_fit, e_ref, excluded)
 
 
 def test_graphed_frame_pipeline_survives_device_synchronise(dev):
