@@ -152,6 +152,29 @@ PROTOTYPES = {
     "cnm_intrinsics_inverse_f32": (c_i, [c_fp, c_ll, c_fp, c_i, c_fp]),
     "cnm_inverse_warp_f32": (c_i, [c_fp] * 6 + [c_i, c_i, c_i, c_i, c_fp]),
     "cnm_inverse_warp_pad_f32": (c_i, [c_fp] * 6 + [c_i, c_i, c_i, c_i, c_i, c_fp]),
+    # host twins (csrc/host_twins.cpp, EngHost in csrc/nets.hip): HOST pointers, no stream
+    "cnm_homography_terms_cpu": (c_i, [c_fp, c_fp, c_fp, c_i, c_i]),
+    "cnm_planesweep_volume_nchw_cpu": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_d, c_d]),
+    "cnm_planesweep_cat_c4_cpu": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_d, c_d]),
+    "cnm_packed_conv_floats_cpu": (c_sz, [c_i, c_i, c_i]),
+    "cnm_pack_conv_bn_cpu": (c_i, [c_fp] * 6 + [c_f, c_i, c_i, c_i, c_i, c_fp, c_fp]),
+    "cnm_pack_head_cpu": (c_i, [c_fp, c_i, c_fp]),
+    "cnm_conv2d_cat2_c4_cpu": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i]),
+    "cnm_upsample2x_c4_cpu": (c_i, [c_fp, c_i, c_i, c_fp, c_i, c_i, c_i, c_i, c_i, c_i]),
+    "cnm_head_sigmoid_c4_cpu": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_fp, c_f, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i]),
+    "cnm_nchw_to_c4_cpu": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i]),
+    "cnm_c4_to_nchw_cpu": (c_i, [c_fp, c_i, c_i, c_fp, c_i, c_i, c_i, c_i]),
+    "cnm_intrinsics_inverse_cpu": (c_i, [c_fp, c_ll, c_fp, c_i]),
+    "cnm_depth2normal_cpu": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i]),
+    "cnm_inverse_warp_cpu": (c_i, [c_fp] * 6 + [c_i, c_i, c_i, c_i]),
+    "cnm_depthnet_workspace_floats_cpu": (c_sz, [c_i, c_i, c_i, c_i]),
+    "cnm_depthnet_forward_cpu": (c_i, [C.POINTER(LayerWeights), c_f, c_i, c_fp, c_fp, c_fp, c_fp,
+                                       c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_sz, c_i, c_i, c_i, c_i]),
+    "cnm_refinenet_workspace_floats_cpu": (c_sz, [c_i, c_i, c_i]),
+    "cnm_refinenet_forward_cpu": (c_i, [C.POINTER(LayerWeights), c_f, c_fp, c_fp, c_ll, c_fp, c_i, c_i, c_fp, c_i, c_i,
+                                        c_fp, c_fp, c_fp, c_fp, c_sz, c_i, c_i, c_i]),
+    "cnm_refinenet_forward_multi_cpu": (c_i, [C.POINTER(LayerWeights), c_f, c_fp, c_fp, c_i, c_fp, c_fp, c_fp,
+                                              c_fp, c_sz, c_i, c_i, c_i]),
 }
 
 NET_DEPTH, NET_REFINE = 0, 1

@@ -12,7 +12,9 @@ CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libcnm_engine.so")
 SOURCES = ["planesweep.hip", "conv_mfma.hip", "conv_winograd.hip", "conv_winograd4.hip", "conv_winograd4s.hip", "conv_winograd_rows.hip", "conv_rows_staged.hip", "pointwise.hip", "geometry.hip", "nets.hip", "train_ops.hip", "half_ops.hip"]
+HOST_SOURCES = ["host_twins.cpp"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+HOSTCXX = os.environ.get("CXX", "g++")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # per-file extras: the plane sweep's blend must stay on full-rate scalar v_fma_f32 (the SLP vectoriser would
 # pack it into half-rate v_pk_fma_f32 plus the moves that feed them)
@@ -28,7 +30,7 @@ def _stale(target, deps):
 
 def build(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
-    headers = [os.path.join(CSRC, "cnm_common.h"), os.path.join(CSRC, "wino4_args.h"), os.path.join(CSRC, "rows_args.h"), os.path.join(CSRC, "sync_ws.h"), os.path.join(PKG, "..", "include", "cnm_engine.h")]
+    headers = [os.path.join(CSRC, "cnm_common.h"), os.path.join(CSRC, "wino4_args.h"), os.path.join(CSRC, "rows_args.h"), os.path.join(CSRC, "sync_ws.h"), os.path.join(CSRC, "host_ops.h"), os.path.join(PKG, "..", "include", "cnm_engine.h")]
     objs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
@@ -39,8 +41,18 @@ def build(force=False, verbose=True):
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
         objs.append(o)
+    # host twins (plain C++, no HIP): g++ for the AVX2 / FMA function clones, resolved at load time by the CPU that runs them
+    for src in HOST_SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(LIBDIR, src.replace(".cpp", ".o"))
+        if force or _stale(o, [s, os.path.abspath(__file__), os.path.join(CSRC, "host_ops.h"), os.path.join(PKG, "..", "include", "cnm_engine.h")]):
+            cmd = [HOSTCXX, "-O3", "-std=c++17", "-fPIC", "-Wall", "-pthread", "-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        objs.append(o)
     if force or _stale(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread"] + objs + ["-o", LIB]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

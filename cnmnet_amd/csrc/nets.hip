@@ -8,6 +8,7 @@
 // of its consumer's input buffer (CAT* below), or the consumer reads two views (cat2 conv).
 #include <string.h>
 #include "cnm_common.h"
+#include "host_ops.h"
 
 // ------------------------------------------------------------------ layer tables
 static const cnm_layer_info kDepthLayers[] = {
@@ -127,6 +128,10 @@ extern "C" int cnm_tune_upsampled_min_pixels(int n) { const int old = g_upsample
 
 struct EngF32 {
     static constexpr int GD = 4;
+    static constexpr bool HOST = false;
+    static int homography(const float* rc, const float* sc, float* hmkt, int B, int S, void* s) { return cnm_homography_terms_f32(rc, sc, hmkt, B, S, s); }
+    static int assemble(const float* a, const float* b, long long st, const float* f1, int G1, int g1, const float* f2, int G2, int g2, float* x, int N, int H, int W, void* s) {
+        return cnm_refine_assemble_c4_f32(a, b, st, f1, G1, g1, f2, G2, g2, x, N, 64, H, W, s); }
     // nn.Upsample(2, bilinear) + conv3x3 + BN + ReLU (up_conv_layer, depthNet_model.py:89-112): in [N][G][H][W] -> out at 2H x 2W
     // sync: the stream's sync workspace for the LDS-staged F(4x4,3x3) kernel (cnm_wino36_sync_floats() floats), or null
     static int upconv(const float* in, int G, float* up_tmp, float* out, int Gto, int go0, int Cout, const cnm_layer_weights& w, int N, int H, int W, float* sync, void* s) {
@@ -170,6 +175,8 @@ struct EngF32 {
 
 struct EngF16 {
     static constexpr int GD = 8;
+    static constexpr bool HOST = false;
+    static int homography(const float* rc, const float* sc, float* hmkt, int B, int S, void* s) { return cnm_homography_terms_f32(rc, sc, hmkt, B, S, s); }
     static int upconv(const float* in, int G, float* up_tmp, float* out, int Gto, int go0, int Cout, const cnm_layer_weights& w, int N, int H, int W, float* sync, void* s) {
         if (w.uu && w.bu && w.wr && G * 8 <= 256 && (long long)N * 4 * H * W >= g_upsampled_min_pixels) {   // one fused pass over the low-resolution input + ring pass
             const int e = cnm_conv3x3_upsampled_c8_f16(in, G, 0, G, out, Gto, go0, Cout, w.uu, w.bu, N, H, W, 1, 1, s);
@@ -188,6 +195,29 @@ struct EngF16 {
     static int assemble_multi(const float* idp, const float* f, float* x, int B, int S, int H, int W, void* s) { return cnm_refine_assemble_multi_c8_f16(idp, f, x, B, S, 64, H, W, s); }
     static int sweep(const float* ref, const float* src, const float* hmkt, float* x, float* tex, size_t texn, int B, int S, int H, int W, int D, double lo, double hi, void* s) {
         return cnm_planesweep_cat_c8_f16(ref, src, hmkt, x, tex, texn, B, S, H, W, D, lo, hi, s); }
+};
+
+// Host twin of the fp32 engine (host_twins.cpp): the same launch sequences on HOST pointers -- direct convolutions with the
+// BatchNorm-folded filter of cnm_pack_conv_bn_cpu in cnm_layer_weights.w, no Winograd forms, no streams.  BASELINE configs[0].
+struct EngHost {
+    static constexpr int GD = 4;
+    static constexpr bool HOST = true;
+    static int homography(const float* rc, const float* sc, float* hmkt, int B, int S, void*) { return cnmh::homography(rc, sc, hmkt, B, S); }
+    static int up(const float* in, int G, float* out, int N, int H, int W, void*) { return cnmh::upsample2x(in, G, 0, out, G, 0, N, G, H, W); }
+    static int conv(const float* in, int Gt, int g0, int Gin, float* out, int Gto, int go0, int Cout, const cnm_layer_weights& w, int N, int H, int W, int k, int st, float*, void*) {
+        return cnmh::conv(in, Gt, g0, Gin, nullptr, 0, 0, 0, out, Gto, go0, Cout, w.w, w.b, N, H, W, k, st, 1); }
+    static int conv2(const float* a, int Ga, const float* b, int Gb, float* out, int Gto, int Cout, const cnm_layer_weights& w, int N, int H, int W, float*, void*) {
+        return cnmh::conv(a, Ga, 0, Ga, b, Gb, 0, Gb, out, Gto, 0, Cout, w.w, w.b, N, H, W, 3, 1, 1); }
+    static int upconv(const float* in, int G, float* up_tmp, float* out, int Gto, int go0, int Cout, const cnm_layer_weights& w, int N, int H, int W, float*, void* s) {
+        const int e = up(in, G, up_tmp, N, H, W, s);
+        return e != CNM_OK ? e : conv(up_tmp, G, 0, G, out, Gto, go0, Cout, w, N, 2 * H, 2 * W, 3, 1, nullptr, s); }
+    static int head(const float* in, int G, int C, const cnm_layer_weights& w, float scale, float* disp, float* up, int upG, int upg, int N, int H, int W, void*) {
+        return cnmh::head(in, G, 0, C, w.w, w.b, scale, disp, up, upG, upg, N, H, W); }
+    static int assemble(const float* a, const float* b, long long st, const float* f1, int G1, int g1, const float* f2, int G2, int g2, float* x, int N, int H, int W, void*) {
+        return cnmh::assemble(a, b, st, f1, G1, g1, f2, G2, g2, x, N, 64, H, W); }
+    static int assemble_multi(const float* idp, const float* f, float* x, int B, int S, int H, int W, void*) { return cnmh::assemble_multi(idp, f, x, B, S, 64, H, W); }
+    static int sweep(const float* ref, const float* src, const float* hmkt, float* x, float*, size_t, int B, int S, int H, int W, int D, double lo, double hi, void*) {
+        return cnmh::sweep(ref, src, hmkt, x, B, S, H, W, D, lo, hi, 0); }
 };
 
 #define CNM_TRY(expr) do { int _e = (expr); if (_e != CNM_OK) return _e; } while (0)
@@ -218,7 +248,7 @@ static size_t carve_depth(float* ws, int P, int H, int W, int D, DepthBufs* b) {
     auto G = [](int C) { return (size_t)((C + E::GD - 1) / E::GD); };
     auto up64 = [](size_t n) { return (n + 63) & ~(size_t)63; };
     b->TEX = c.take(4);                         // FIRST and never reused: the plane sweep's tile queue, zero between calls
-    b->SYNC = E::GD == 4 ? c.take(cnm_wino36_sync_floats()) : nullptr;   // second, at a fixed offset, never reused: flag words (zero between calls) + partial-output slots of the staged F(4x4,3x3) kernel
+    b->SYNC = (E::GD == 4 && !E::HOST) ? c.take(cnm_wino36_sync_floats()) : nullptr;   // second, at a fixed offset, never reused: flag words (zero between calls) + partial-output slots of the staged F(4x4,3x3) kernel
     b->hmkt = c.take((size_t)P * 12);
     const size_t x0 = q * (G(D) + 1), cat1 = q * (G(64) + 1);
     b->X0 = b->CAT1 = c.take(x0 > cat1 ? x0 : cat1);
@@ -272,7 +302,7 @@ static int depthnet_forward(const cnm_layer_weights* wt, float idepth_scale, int
 #define CONV(L, in, Gt, g0, Gin, out, Gto, go0, Cout, HH, WW) \
     CNM_TRY(E::conv(in, Gt, g0, Gin, out, Gto, go0, Cout, wt[L], P, HH, WW, kDepthLayers[L].ksize, kDepthLayers[L].stride, b.SYNC, s))
     // geometry + cost volume                                                   depthNet_model.py:228-233
-    CNM_TRY(cnm_homography_terms_f32(ref_cam, src_cam, b.hmkt, B, S, s));
+    CNM_TRY(E::homography(ref_cam, src_cam, b.hmkt, B, S, s));
     CNM_TRY(E::sweep(ref, src, b.hmkt, b.X0, b.TEX, 4, B, S, H, W, D, idmin, idmax, s));
     // encoder                                                                  :235-239
     CONV(D_CONV1_0, b.X0, G0, 0, G0, b.A1, g128, 0, 128, H, W);
@@ -332,7 +362,7 @@ static size_t carve_refine(float* ws, int N, int H, int W, RefineBufs* b) {
     Carver c{ws, 0};
     const size_t q = (size_t)N * H * W * 4;
     auto G = [](int C) { return (size_t)((C + E::GD - 1) / E::GD); };
-    for (int k = 0; k < 2; ++k) b->SYNC[k] = E::GD == 4 ? c.take(cnm_wino36_sync_floats()) : nullptr;   // FIRST, fixed offsets, never reused: flag words zero between calls
+    for (int k = 0; k < 2; ++k) b->SYNC[k] = (E::GD == 4 && !E::HOST) ? c.take(cnm_wino36_sync_floats()) : nullptr;   // FIRST, fixed offsets, never reused: flag words zero between calls
     b->X = c.take(q * (G(64) + 1)); b->A1 = c.take(q * G(128));
     b->C1 = c.take(q / 4 * G(128)); b->A2 = c.take(q / 4 * G(256));
     b->C2 = c.take(q / 16 * G(256)); b->A3 = c.take(q / 16 * G(512)); b->U3 = c.take(q / 16 * G(512));
@@ -372,7 +402,7 @@ static int refinenet_body(const cnm_layer_weights* wt, float idepth_scale, const
     CONV(R_CONV3_0, b.C2, g256, b.A3, 512, H2, W2);
     CONV(R_CONV3_3, b.A3, g512, b.C3, 512, H2, W2);
     CNM_TRY(E::up(b.C3, g512, b.U3, N, H3, W3, s));                                    // shared by both decoders
-    SideStream* side = side_stream();
+    SideStream* side = E::HOST ? nullptr : side_stream();
     void* st[2] = {s, side ? (void*)side->stream : s};
     if (side) {
         if (hipEventRecord(side->fork, (hipStream_t)s) != hipSuccess || hipStreamWaitEvent(side->stream, side->fork, 0) != hipSuccess) return CNM_ERR_LAUNCH;
@@ -411,19 +441,29 @@ static int refinenet_body(const cnm_layer_weights* wt, float idepth_scale, const
     return rc;
 }
 
+template <class E>
+static int refinenet_forward(const cnm_layer_weights* wt, float idepth_scale,
+                             const float* idepth01, const float* idepth02, long long idepth_stride,
+                             const float* iconv01, int G1_total, int g1, const float* iconv02, int G2_total, int g2,
+                             float* disp_refined, float* prob_map, float* iconv1_depth_c4,
+                             float* ws, size_t ws_floats, int N, int H, int W, void* stream) {
+    CNM_REQUIRE(wt && idepth01 && idepth02 && iconv01 && iconv02 && disp_refined && prob_map && ws && N > 0, CNM_ERR_BAD_ARG);
+    CNM_REQUIRE(H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0, CNM_ERR_BAD_SHAPE);
+    for (int i = 0; i < R_NUM; ++i) CNM_REQUIRE((wt[i].w || wt[i].u || wt[i].u4) && wt[i].b, CNM_ERR_BAD_ARG);
+    RefineBufs b;
+    CNM_REQUIRE(carve_refine<E>(ws, N, H, W, &b) <= ws_floats, CNM_ERR_WORKSPACE);
+    CNM_TRY(E::assemble(idepth01, idepth02, idepth_stride, iconv01, G1_total, g1, iconv02, G2_total, g2, b.X, N, H, W, stream));  // :332-333
+    return refinenet_body<E>(wt, idepth_scale, b, disp_refined, prob_map, iconv1_depth_c4, N, H, W, stream);
+}
+
 extern "C" int cnm_refinenet_forward_f32(const cnm_layer_weights* wt, float idepth_scale,
                                          const float* idepth01, const float* idepth02, long long idepth_stride,
                                          const float* iconv01, int G1_total, int g1,
                                          const float* iconv02, int G2_total, int g2,
                                          float* disp_refined, float* prob_map, float* iconv1_depth_c4,
                                          float* ws, size_t ws_floats, int N, int H, int W, void* stream) {
-    CNM_REQUIRE(wt && idepth01 && idepth02 && iconv01 && iconv02 && disp_refined && prob_map && ws && N > 0, CNM_ERR_BAD_ARG);
-    CNM_REQUIRE(H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0, CNM_ERR_BAD_SHAPE);
-    for (int i = 0; i < R_NUM; ++i) CNM_REQUIRE((wt[i].w || wt[i].u || wt[i].u4) && wt[i].b, CNM_ERR_BAD_ARG);
-    RefineBufs b;
-    CNM_REQUIRE(carve_refine<EngF32>(ws, N, H, W, &b) <= ws_floats, CNM_ERR_WORKSPACE);
-    CNM_TRY(cnm_refine_assemble_c4_f32(idepth01, idepth02, idepth_stride, iconv01, G1_total, g1, iconv02, G2_total, g2, b.X, N, 64, H, W, stream));  // :332-333
-    return refinenet_body<EngF32>(wt, idepth_scale, b, disp_refined, prob_map, iconv1_depth_c4, N, H, W, stream);
+    return refinenet_forward<EngF32>(wt, idepth_scale, idepth01, idepth02, idepth_stride, iconv01, G1_total, g1, iconv02, G2_total, g2,
+                                     disp_refined, prob_map, iconv1_depth_c4, ws, ws_floats, N, H, W, stream);
 }
 
 template <class E>
@@ -453,4 +493,42 @@ extern "C" int cnm_refinenet_forward_multi_f16(const cnm_layer_weights* wt, floa
                                                float* ws, size_t ws_floats, int B, int H, int W, void* stream) {
     return refinenet_forward_multi<EngF16>(wt, idepth_scale, idepth_pairs, static_cast<const float*>(iconv_pairs_c8), S, disp_refined, prob_map,
                                            static_cast<float*>(iconv1_depth_c8), ws, ws_floats, B, H, W, stream);
+}
+
+// ------------------------------------------------------------------ host twins of the whole-network entry points (EngHost)
+// Same arguments with HOST pointers and no stream; cnm_layer_weights.w / .b = cnm_pack_conv_bn_cpu (heads: cnm_pack_head_cpu + the
+// bias vector) outputs, the other slots unused.  BASELINE configs[0]; depthNet_model.py:226-263, :331-370.
+extern "C" size_t cnm_depthnet_workspace_floats_cpu(int P, int H, int W, int D) {
+    if (P <= 0 || H <= 0 || W <= 0 || D < 4 || (H % 32) || (W % 32) || (D % 4)) return 0;
+    DepthBufs b;
+    return carve_depth<EngHost>(nullptr, P, H, W, D, &b);
+}
+
+extern "C" int cnm_depthnet_forward_cpu(const cnm_layer_weights* wt, float idepth_scale, int D,
+                                        const float* ref, const float* src, const float* ref_cam, const float* src_cam,
+                                        float* disp1, float* disp2, float* disp3, float* disp4, float* iconv1_c4,
+                                        float* ws, size_t ws_floats, int B, int S, int H, int W) {
+    return depthnet_forward<EngHost>(wt, idepth_scale, D, ref, src, ref_cam, src_cam, disp1, disp2, disp3, disp4, iconv1_c4, ws, ws_floats, B, S, H, W, nullptr);
+}
+
+extern "C" size_t cnm_refinenet_workspace_floats_cpu(int N, int H, int W) {
+    if (N <= 0 || H <= 0 || W <= 0 || (H % 8) || (W % 8)) return 0;
+    RefineBufs b;
+    return carve_refine<EngHost>(nullptr, N, H, W, &b);
+}
+
+extern "C" int cnm_refinenet_forward_cpu(const cnm_layer_weights* wt, float idepth_scale,
+                                         const float* idepth01, const float* idepth02, long long idepth_stride,
+                                         const float* iconv01, int G1_total, int g1, const float* iconv02, int G2_total, int g2,
+                                         float* disp_refined, float* prob_map, float* iconv1_depth_c4,
+                                         float* ws, size_t ws_floats, int N, int H, int W) {
+    return refinenet_forward<EngHost>(wt, idepth_scale, idepth01, idepth02, idepth_stride, iconv01, G1_total, g1, iconv02, G2_total, g2,
+                                      disp_refined, prob_map, iconv1_depth_c4, ws, ws_floats, N, H, W, nullptr);
+}
+
+extern "C" int cnm_refinenet_forward_multi_cpu(const cnm_layer_weights* wt, float idepth_scale,
+                                               const float* idepth_pairs, const float* iconv_pairs_c4, int S,
+                                               float* disp_refined, float* prob_map, float* iconv1_depth_c4,
+                                               float* ws, size_t ws_floats, int B, int H, int W) {
+    return refinenet_forward_multi<EngHost>(wt, idepth_scale, idepth_pairs, iconv_pairs_c4, S, disp_refined, prob_map, iconv1_depth_c4, ws, ws_floats, B, H, W, nullptr);
 }

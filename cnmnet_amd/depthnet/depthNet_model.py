@@ -11,8 +11,10 @@ state_dict keys and shapes are identical to the reference's (nn.Sequential indic
 
 The torch modules below only CONTAIN parameters.  forward() folds eval-mode BatchNorm
 into packed weights on the device (cached until a parameter changes) and makes ONE call
-into the C ABI (cnm_depthnet_forward_f32 / cnm_refinenet_forward_f32).  There is no CPU
-or eager-torch fallback.
+into the C ABI (cnm_depthnet_forward_f32 / cnm_refinenet_forward_f32).  There is no
+eager-torch fallback.  A module left on the CPU runs eval-mode fp32 forwards through the
+library's host twins (cnm_depthnet_forward_cpu / cnm_refinenet_forward_cpu: plain C++ in the
+same library, BASELINE configs[0]); training and the f16 engine need the GPU.
 """
 import ctypes
 
@@ -20,7 +22,7 @@ import os
 import torch
 import torch.nn as nn
 
-from .. import _lib, ops
+from .. import _lib, host, ops
 from .. import autograd as ag
 
 
@@ -100,9 +102,17 @@ class _EngineNet(nn.Module):
         if self._layers is None:
             self._layers = _lib.net_layers(self._NET)
         packed = []
+        on_host = not next(self.parameters()).is_cuda
         for i, L in enumerate(self._layers):
             conv = self._sub(L["conv_key"])
             w = conv.weight.detach()
+            if on_host:                                                   # host twins: BatchNorm-folded direct filters only (cnm_pack_conv_bn_cpu)
+                if L["is_head"]:
+                    packed.append((host.pack_head(w.float()), conv.bias.detach().float().contiguous()))
+                else:
+                    bn = self._sub(L["bn_key"])
+                    packed.append(host.pack_conv(w.float(), (bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var), rot=L["rot"], eps=bn.eps))
+                continue
             if L["is_head"]:
                 packed.append((ops.pack_head(w), conv.bias.detach().contiguous()))
             else:
@@ -167,6 +177,15 @@ class _EngineNet(nn.Module):
         if not p.is_cuda or p.device != tensors[0].device:
             raise _lib.EngineError("module parameters are on %s but inputs are on %s" % (p.device, tensors[0].device))
 
+    def _on_host(self, *tensors):
+        """True when this call runs on the host twins: module and every input on the CPU, eval mode, fp32.  A CPU call that
+        cannot (training, f16, mixed devices) fails loudly -- there is no silent fallback in either direction."""
+        if next(self.parameters()).is_cuda or not host.is_host(*tensors):
+            return False
+        if self.training or self.precision != "f32":
+            raise _lib.EngineError("the host twins run eval-mode fp32 inference only; training and the f16 engine need the GPU")
+        return True
+
 
 def _down_train(x, seq, rot=0, groups=1):
     """down_conv_layer in train mode: conv s1 -> BN -> ReLU -> conv s2 -> BN -> ReLU (reference :19-39)."""
@@ -212,8 +231,13 @@ class depthNet(_EngineNet):
         One engine call for all pairs; the reference replicates the ref image instead
         (eval.py:635-657)."""
         ops.idepth_range(self.idepth_scale)
-        self._require_gpu(ref, src, ref_cam, src_cam)
         B, S, _, H, W = src.shape
+        if self._on_host(ref, src, ref_cam, src_cam):
+            if H % 32 or W % 32:
+                raise ValueError("image height and width must be multiples of 32 (got %dx%d)" % (H, W))
+            self._ensure_packed()
+            return host.depthnet_forward(self._weights_arr, self.idepth_scale, self.planes, ref, src, ref_cam, src_cam)
+        self._require_gpu(ref, src, ref_cam, src_cam)
         if H % 32 or W % 32:
             raise ValueError("image height and width must be multiples of 32 (got %dx%d)" % (H, W))
         if self.training:
@@ -304,7 +328,8 @@ class depthNet(_EngineNet):
         along), a plain [B,3,W*H] grid product in the reference's u-major order (the homography is recovered from
         it), or the homography itself [B,3,3]."""
         from .depth_util import homography_from_grid_product
-        self._require_gpu(left_image, right_image, KRKiUV_T, KT_T)
+        if not host.is_host(left_image, right_image, KRKiUV_T, KT_T):
+            self._require_gpu(left_image, right_image, KRKiUV_T, KT_T)
         B, _, H, W = left_image.shape
         hmkt = getattr(KRKiUV_T, "hmkt", None)
         if hmkt is None:
@@ -349,6 +374,9 @@ class DepthRefineNet(_EngineNet):
     def forward_c4(self, idepth01, idepth02, idepth_stride, f1, G1_total, g1, f2, G2_total, g2, N, H, W, return_volume=False):
         """Raw-view entry used by the frame pipeline (no layout conversion)."""
         self._ensure_packed()
+        if self._on_host(idepth01, idepth02, f1, f2):
+            return host.refinenet_forward(self._weights_arr, self.idepth_scale, idepth01, idepth02, idepth_stride, f1, G1_total, g1, f2, G2_total, g2,
+                                          N, H, W, return_volume)
         lib, dev = _lib.load(), idepth01.device
         disp = torch.empty(N, 1, H, W, device=dev, dtype=torch.float32)
         prob = torch.empty_like(disp)
@@ -366,6 +394,9 @@ class DepthRefineNet(_EngineNet):
         """S (even) sources per frame from ONE depthNet.forward_pairs call: disp1 [B*S,1,H,W] and
         iconv1 c4 [B*S,16,H,W,4]; even sources average into side 1, odd into side 2
         (reference eval.py:656-663 for S=4, :917-929 for S=6; S=2 is the plain two-view case)."""
+        if self._on_host(idepth_pairs, feat_pairs_c4):
+            self._ensure_packed()
+            return host.refinenet_forward_multi(self._weights_arr, self.idepth_scale, idepth_pairs, feat_pairs_c4, S, return_volume)
         self._require_gpu(idepth_pairs)
         self._ensure_packed()
         P, _, H, W = idepth_pairs.shape
@@ -412,7 +443,8 @@ class DepthRefineNet(_EngineNet):
         return disp, prob, vol
 
     def forward(self, idepth01, idepth02, iconv01, iconv02, ReturnVolume=False):
-        self._require_gpu(idepth01, idepth02, iconv01, iconv02)
+        if not self._on_host(idepth01, idepth02, iconv01, iconv02):
+            self._require_gpu(idepth01, idepth02, iconv01, iconv02)
         N, _, H, W = idepth01.shape
         if H % 8 or W % 8:
             raise ValueError("image height and width must be multiples of 8 (got %dx%d)" % (H, W))

@@ -1,13 +1,15 @@
 """Operator-level Python API over the C ABI: torch tensors in, torch tensors out.
 
 torch is used for device memory and streams only; every computation is a call into
-libcnm_engine.so on the tensor's device and the current torch stream.  CPU tensors
-are rejected (there is no CPU path in this package -- the CPU restatement lives in
-oracle/ and is test infrastructure).
+libcnm_engine.so on the tensor's device and the current torch stream.  CPU tensors go to
+the library's host twins (cnmnet_amd.host: the `_cpu` entry points, inference only) for the
+operators that have one -- geometry prep, plane sweep, layout converters, depth->normal,
+inverse warp -- and are rejected everywhere else; the CPU restatement in oracle/ is test
+infrastructure and never involved.
 """
 import torch
 
-from . import _lib
+from . import _lib, host
 
 IDEPTH_RANGE = {2.0: (0.02, 2.0), 3.0: (0.1, 3.0)}   # reference depthnet/depthNet_model.py:186-191
 
@@ -44,6 +46,8 @@ def idepth_range(idepth_scale):
 
 def homography_terms(ref_cam, src_cam):
     """ref_cam [B,2,4,4], src_cam [B,S,2,4,4] -> hmkt [B*S,12]   (depth_util.py:24-56)"""
+    if host.is_host(ref_cam, src_cam):
+        return host.homography_terms(ref_cam, src_cam)
     _dev(ref_cam, src_cam)
     ref_cam, src_cam = _c(ref_cam), _c(src_cam)
     B, S = src_cam.shape[0], src_cam.shape[1]
@@ -56,12 +60,16 @@ def homography_terms(ref_cam, src_cam):
 def plane_sweep_volume(left, right, left_cam, right_cam, idepth_scale=3.0, planes=64):
     """Drop-in for depthNet.getVolume fed by process_camera_parameters
     (depthNet_model.py:185-224): left/right [B,3,H,W], cams [B,2,4,4] -> [B,planes,H,W]."""
+    if host.is_host(left, right, left_cam, right_cam):
+        return plane_sweep_volume_hmkt(left, right, homography_terms(left_cam, right_cam.unsqueeze(1)), idepth_scale, planes)
     _dev(left, right, left_cam, right_cam)
     return plane_sweep_volume_hmkt(left, right, homography_terms(left_cam, right_cam.unsqueeze(1)), idepth_scale, planes)
 
 
 def plane_sweep_volume_hmkt(left, right, hmkt, idepth_scale=3.0, planes=64):
     """getVolume from the 12 camera terms per pair: left/right [B,3,H,W], hmkt [B,12] -> [B,planes,H,W]."""
+    if host.is_host(left, right, hmkt):
+        return host.plane_sweep_volume_hmkt(left, right, hmkt, *idepth_range(idepth_scale), planes)
     _dev(left, right, hmkt)
     lo, hi = idepth_range(idepth_scale)
     left, right, hmkt = _c(left), _c(right), _c(hmkt)
@@ -93,6 +101,8 @@ def plane_sweep_cat_c4(ref, src, hmkt, idepth_scale=3.0, planes=64, ws=None, out
 
 
 def nchw_to_c4(x):
+    if host.is_host(x):
+        return host.nchw_to_c4(x)
     _dev(x)
     x = _c(x)
     N, Cc, H, W = x.shape
@@ -104,6 +114,8 @@ def nchw_to_c4(x):
 
 
 def c4_to_nchw(x, channels=None):
+    if host.is_host(x):
+        return host.c4_to_nchw(x, channels)
     _dev(x)
     N, G, H, W, _ = x.shape
     Cc = channels or 4 * G
@@ -535,6 +547,8 @@ def head_sigmoid_c8(x, w_head, bias, scale, up_out=None, up_group=0):
 
 def depth2normal(depth, intrinsic_inv, k_size=9, input_is_idepth=False):
     """depth [B,H,W], K^-1 [B,3,3] -> (normal [B,3,H,W], points [B,3,H,W])   (depth_util.py:149-203)"""
+    if host.is_host(depth, intrinsic_inv):
+        return host.depth2normal(depth, intrinsic_inv, k_size, input_is_idepth)
     _dev(depth, intrinsic_inv)
     depth, intrinsic_inv = _c(depth), _c(intrinsic_inv)
     B, H, W = depth.shape
@@ -567,6 +581,8 @@ def plane_normals(normal, instance_segs, planes_num, with_loss=True):
 
 def intrinsics_inverse(cam):
     """cam [B,2,4,4] (any batch stride) -> K^-1 [B,3,3]   (train.py:201-202, eval.py:271)"""
+    if host.is_host(cam):
+        return host.intrinsics_inverse(cam)
     _dev(cam)
     if cam.stride()[-3:] != (16, 4, 1):
         cam = cam.contiguous()
@@ -581,6 +597,8 @@ PADDING_MODES = {"zeros": 0, "border": 1, "reflection": 2}           # torch.nn.
 
 
 def inverse_warp(feat, depth, pose, intrinsics, intrinsics_inv, padding_mode="zeros"):
+    if host.is_host(feat, depth, pose, intrinsics, intrinsics_inv):
+        return host.inverse_warp(feat, depth, pose, intrinsics, intrinsics_inv, padding_mode)
     _dev(feat, depth, pose, intrinsics, intrinsics_inv)
     if padding_mode not in PADDING_MODES:
         raise ValueError("padding_mode must be one of %s, got %r" % (sorted(PADDING_MODES), padding_mode))

@@ -659,6 +659,54 @@ int cnm_inverse_warp_backward_depth_f32(const float* feat, const float* depth, c
                                         const float* K, const float* K_inv, const float* grad_out,
                                         float* grad_depth, int B, int C, int H, int W, void* stream);
 
+/* ---------------------------------------------------------------- host twins ("_cpu")
+ * every operator of the path with a twin taking HOST pointers; BASELINE configs[0] ("DepthNet eval, 1 ref +
+ * 1 src, 256x192, 32 planes, batch=1 on CPU: plumbing, no GPU").  Plain C++ in the same library (csrc/host_twins.cpp and
+ * the EngHost policy of csrc/nets.hip): same arguments without the stream, same c4 layout, same return codes; direct
+ * convolutions, one thread per core (CNM_CPU_THREADS overrides).  They are the product's CPU path -- cnmnet_amd.depthnet
+ * routes CPU tensors here in eval mode -- and never the measured one; oracle/ is not involved.
+ * Filters: cnm_pack_conv_bn_cpu folds eval-mode BatchNorm exactly as cnm_pack_conv_bn_f32 does and lays the filter out as
+ * w_packed [Cout][k*k][4*ceil(Cin/4)] (channel position (ci + Cin - rot) % Cin), b_packed [Cout]; heads: cnm_pack_head_cpu.
+ * The whole-network twins take cnm_layer_weights whose .w / .b point at those (all other slots unused). */
+int cnm_homography_terms_cpu(const float* ref_cam, const float* src_cam, float* hmkt, int B, int S);             /* depth_util.py:13-56 */
+int cnm_planesweep_volume_nchw_cpu(const float* ref, const float* src, const float* hmkt, float* volume,
+                                   int B, int S, int H, int W, int D, double idepth_min, double idepth_max);     /* depthNet_model.py:185-224 */
+int cnm_planesweep_cat_c4_cpu(const float* ref, const float* src, const float* hmkt, float* x,
+                              int B, int S, int H, int W, int D, double idepth_min, double idepth_max);          /* + :233 */
+size_t cnm_packed_conv_floats_cpu(int Cout, int Cin, int ksize);
+int cnm_pack_conv_bn_cpu(const float* w_oihw, const float* bn_gamma, const float* bn_beta, const float* bn_mean, const float* bn_var,
+                         const float* bias, float eps, int Cout, int Cin, int ksize, int rot, float* w_packed, float* b_packed);
+int cnm_pack_head_cpu(const float* w_oihw, int C, float* w_head);
+int cnm_conv2d_cat2_c4_cpu(const float* in_a, int Ga_total, int ga0, int Ga, const float* in_b, int Gb_total, int gb0, int Gb,
+                           float* out, int Gout_total, int gout0, int Cout, const float* w_packed, const float* b_packed,
+                           int N, int H, int W, int ksize, int stride, int relu);                                 /* depthNet_model.py:19-79 */
+int cnm_upsample2x_c4_cpu(const float* in, int Gin_total, int gin0, float* out, int Gout_total, int gout0,
+                          int N, int G, int H, int W);                                                            /* :94,105 */
+int cnm_head_sigmoid_c4_cpu(const float* in, int Gin_total, int gin0, int C, const float* w_head, const float* bias, float scale,
+                            float* disp, float* up_out, int up_Gtotal, int up_g, int N, int H, int W);            /* :82-84,246-261 */
+int cnm_nchw_to_c4_cpu(const float* nchw, float* c4, int G_total, int g0, int N, int C, int H, int W);
+int cnm_c4_to_nchw_cpu(const float* c4, int G_total, int g0, float* nchw, int N, int C, int H, int W);
+int cnm_intrinsics_inverse_cpu(const float* cam, long long cam_stride, float* K_inv, int B);
+int cnm_depth2normal_cpu(const float* depth, const float* K_inv, float* normal, float* points,
+                         int B, int H, int W, int ksize, int input_is_idepth);                                    /* depth_util.py:149-203 */
+int cnm_inverse_warp_cpu(const float* feat, const float* depth, const float* pose, const float* K, const float* K_inv,
+                         float* out, int B, int C, int H, int W);                                                 /* inverse_warp.py:27-118 */
+size_t cnm_depthnet_workspace_floats_cpu(int P, int H, int W, int D);
+int cnm_depthnet_forward_cpu(const cnm_layer_weights* weights, float idepth_scale, int D,
+                             const float* ref, const float* src, const float* ref_cam, const float* src_cam,
+                             float* disp1, float* disp2, float* disp3, float* disp4, float* iconv1_c4,
+                             float* ws, size_t ws_floats, int B, int S, int H, int W);                            /* depthNet_model.py:226-263 */
+size_t cnm_refinenet_workspace_floats_cpu(int N, int H, int W);
+int cnm_refinenet_forward_cpu(const cnm_layer_weights* weights, float idepth_scale,
+                              const float* idepth01, const float* idepth02, long long idepth_stride,
+                              const float* iconv01, int G1_total, int g1, const float* iconv02, int G2_total, int g2,
+                              float* disp_refined, float* prob_map, float* iconv1_depth_c4,
+                              float* ws, size_t ws_floats, int N, int H, int W);                                  /* :331-370 */
+int cnm_refinenet_forward_multi_cpu(const cnm_layer_weights* weights, float idepth_scale,
+                                    const float* idepth_pairs, const float* iconv_pairs_c4, int S,
+                                    float* disp_refined, float* prob_map, float* iconv1_depth_c4,
+                                    float* ws, size_t ws_floats, int B, int H, int W);                            /* eval.py:635-663,885-929 */
+
 #ifdef __cplusplus
 }
 #endif

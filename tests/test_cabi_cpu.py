@@ -1,6 +1,6 @@
 """CPU: the C-ABI library loads without a GPU and exports every symbol include/cnm_engine.h
 declares; the ctypes table in cnmnet_amd/_lib.py covers exactly that set; host-only entry
-points behave.  No compute call is made here."""
+points behave.  No GPU compute call is made here (the host twins are exercised in test_host_twins_cpu.py)."""
 import ctypes
 import os
 import re
@@ -69,7 +69,7 @@ def test_layer_tables_match_reference_state_dict():
                 assert L["bn_key"] + ".running_var" in sd and sd[L["bn_key"] + ".weight"].shape[0] == L["Cout"]
 
 
-def test_product_modules_share_reference_state_dict_and_refuse_cpu():
+def test_product_modules_share_reference_state_dict_and_cpu_behaviour():
     import torch
     from cnmnet_amd.depthnet import depthNet, DepthRefineNet, Depth2normal
     from oracle import ref_arrangement as ra
@@ -78,9 +78,15 @@ def test_product_modules_share_reference_state_dict_and_refuse_cpu():
         assert list(a) == list(b) and all(a[k].shape == b[k].shape for k in a)
         mine.load_state_dict({"module." + k: v for k, v in b.items()}, strict=False)   # keys only; see eval.py:189-196
         mine.load_state_dict(b)
-    net = depthNet(3.0).eval()
+    # CPU tensors: eval-mode fp32 runs on the library's host twins (tests/test_host_twins_cpu.py); everything else fails loudly --
+    # there is no torch fallback and oracle/ is never involved
+    net = depthNet(3.0)
     x = torch.zeros(1, 3, 32, 32); cam = torch.eye(4).repeat(1, 2, 1, 1)
-    with pytest.raises(_lib.EngineError):          # the product has no CPU path by design
-        net(x, x, cam, cam)
     with pytest.raises(_lib.EngineError):
-        Depth2normal(9)(torch.ones(1, 8, 8), torch.eye(3)[None])
+        net.train()(x, x, cam, cam)
+    with pytest.raises(_lib.EngineError):
+        depthNet(3.0, precision="f16").eval()(x, x, cam, cam)
+    with pytest.raises(_lib.EngineError):
+        Depth2normal(9)(torch.ones(1, 8, 8, dtype=torch.float64), torch.eye(3, dtype=torch.float64)[None])
+    n, p = Depth2normal(9)(torch.ones(1, 8, 8), torch.eye(3)[None])
+    assert n.shape == (1, 3, 8, 8) and p.shape == (1, 3, 8, 8)
