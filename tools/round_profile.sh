@@ -1,10 +1,10 @@
 #!/bin/bash
 # Round profile (GPU box): bench line, rocprofv3 kernel summaries (default and one-stream), PMC passes (HBM traffic,
-# matrix-pipe utilisation, plane-sweep VALU counters), training-step kernel summary.  Output: gpurun_out/r3/.
+# matrix-pipe utilisation, plane-sweep VALU counters), training-step kernel summary.  Output: gpurun_out/r4/.
 set -euo pipefail
 cd "${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 export TMPDIR=/tmp
-O=gpurun_out/r3
+O=gpurun_out/r4
 rm -rf "$O"; mkdir -p "$O"
 timeout 900 python3 bench.py > "$O/bench_line.json" 2> "$O/bench_line.err" || { tail -5 "$O/bench_line.err"; exit 1; }
 prof() {   # prof <tag> <bench args...>: kernel summary of one bench command
