@@ -660,14 +660,16 @@ def train_mode(a, dev, dist, pg, backend, rank, world):
                                    "256x192, 64 planes (BASELINE configs[2]: global batch 32 on 8 GPUs)" % B,
                        "global_batch": world * B, "parallelism": "dp%d" % world,
                        "allreduce_backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None,
-                       "launch": ("forward + backward as one HIP graph, exchange + Adam eager" if world > 1 else "one HIP graph") if a.graph else "eager"}}
+                       "launch": ("two HIP graphs (forward + refine backward | depthNet backward) with the refine net's gradient buckets launched in between, "
+                                  "remaining buckets + Adam eager" if world > 1 else "one HIP graph") if a.graph else "eager"}}
     if step.reducer is not None:
         r = step.reducer
         exposed = [e0.elapsed_time(e1) for e0, e1 in step.finish_events]
         line["allreduce"] = {"bytes_per_step": r.bytes_per_step, "buckets": len(r.buckets), "launched_from_backward_hooks": r.hook_launches,
                              "launched_late": r.late_launches, "exposed_ms": sum(exposed) / max(1, len(exposed)),
                              "note": "exposed_ms = HIP-event time around the reducer's finish() on the compute stream: what backward did not hide of "
-                                     "the exchange, plus the write-back of the averaged gradients" +
+                                     "the exchange, plus the write-back of the averaged gradients; launched_from_backward_hooks counts buckets that left "
+                                     "before the end of backward (eager: from hooks; --graph: between the two graph replays)" +
                                      ("" if backend == "nccl" else "; gloo here (no RCCL run): the exchange goes through the host and says nothing about xGMI")}
     return line
 

@@ -66,13 +66,18 @@ class BucketedGradAllReduce:
     exactly as it was (None stays None): the optimizer then skips it as it does on one device and under the
     reference's DataParallel, instead of decaying it towards zero."""
 
-    def __init__(self, params, dist, bucket_bytes=25 * 2**20, group=None, hooks=True):
+    def __init__(self, params, dist, bucket_bytes=25 * 2**20, group=None, hooks=True, segment_of=None):
         """group: the process group of the all-reduces (None = the default group); hooks=False: no backward hooks -- the
-        caller reduces every bucket after backward with reduce_all() (the HIP-graph step: hooks do not run in a replay)."""
+        caller reduces buckets with launch_ready() / reduce_all() (the HIP-graph step: hooks do not run in a replay).
+        segment_of: optional {id(parameter): segment}; a bucket never mixes segments, so that the buckets of a segment can
+        leave as soon as that segment's part of backward has run (the segmented graph step: refine net, then depthNet)."""
         self.dist, self.group, self.world = dist, group, dist.get_world_size(group)
         self.params = [p for p in params if p.requires_grad]
         self.buckets, cur, size = [], [], 0
+        seg = (lambda p: segment_of.get(id(p))) if segment_of else (lambda p: None)
         for p in reversed(self.params):                    # decoder grads are ready first
+            if cur and seg(p) != seg(cur[-1]):
+                self.buckets.append(cur); cur, size = [], 0
             cur.append(p); size += p.numel() * 4
             if size >= bucket_bytes:
                 self.buckets.append(cur); cur, size = [], 0
@@ -105,6 +110,20 @@ class BucketedGradAllReduce:
                 self.flat[i][off:off + n].zero_()
             off += n
         self.work[i] = self.dist.all_reduce(self.flat[i], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def launch_ready(self, ready):
+        """Without hooks: launch every bucket whose parameters all satisfy ready(p) and that has not left yet (the part of
+        backward that produces them has been enqueued); returns the number launched.  They count as early launches."""
+        n = 0
+        for i, b in enumerate(self.buckets):
+            if self.work[i] is None and all(ready(p) for p in b):
+                for p in b:
+                    if p.grad is not None:
+                        self.fired.add(id(p))
+                self._hook_count += 1
+                self._launch(i)
+                n += 1
+        return n
 
     def reduce_all(self):
         """Without hooks: every parameter that has a gradient counts as arrived; launches all buckets, then finish()."""
@@ -181,17 +200,20 @@ class TrainStepWoNormal:
     undone in place (parameters, BatchNorm statistics, Adam state) before the first replay."""
 
     def __init__(self, depth_net, refine_net, lr=1e-4, weight_decay=1e-5, dist=None, exact_masked_means=False, graph=False, group=None):
-        """group: process group of the gradient all-reduce (None = default).  graph=True with more than one rank: forward and
-        backward are replayed as ONE HIP graph, the bucketed all-reduce and the Adam update follow eagerly (a collective
-        stays outside the captured region; the backward hooks that overlap buckets with backward do not exist in a replay)."""
+        """group: process group of the gradient all-reduce (None = default).  graph=True with more than one rank: the step is
+        replayed as TWO HIP graphs -- forward + the refine net's backward, then depthNet's backward -- with the refine net's
+        gradient buckets handed to the collective in between (a collective stays outside a captured region, and the backward
+        hooks that overlap buckets with backward do not exist in a replay); the remaining buckets and Adam follow eagerly."""
         self.depth_net, self.refine_net, self.dist, self.exact, self.group = depth_net, refine_net, dist, exact_masked_means, group
         params = list(refine_net.parameters()) + list(depth_net.parameters())              # train.py:87, :446
         self.optimizer = make_adam(params, lr, weight_decay, capturable=bool(graph))          # utils/misc.py:31-33
         self.reducer = None
         if dist is not None and dist.is_initialized() and dist.get_world_size(group) > 1:
-            self.reducer = BucketedGradAllReduce(params, dist, group=group, hooks=not graph)
+            seg = {id(p): 0 for p in refine_net.parameters()}
+            seg.update({id(p): 1 for p in depth_net.parameters()})
+            self.reducer = BucketedGradAllReduce(params, dist, group=group, hooks=not graph, segment_of=seg if graph else None)
         self.l234 = IdepthLoss_234()
-        self.graph_mode, self._graph, self._graph_key = bool(graph), None, None
+        self.graph_mode, self._graph, self._graph_b, self._graph_key, self._cut = bool(graph), None, None, None, None
         self.finish_events = None                                        # set to [] to collect (start, end) HIP events around the reducer's finish()
 
     def __call__(self, rgbs, cameras, disparities, depths, warmup_epoch=False):
@@ -226,7 +248,13 @@ class TrainStepWoNormal:
         for dst, src in zip(self._static_in, inputs):
             dst.copy_(src)
         self._graph.replay()
-        if self.reducer is not None:                        # the graph holds forward + backward; exchange and update follow eagerly
+        if self.reducer is not None:
+            # Two graphs (see _capture): forward + the refine net's backward, then depthNet's backward.  The refine net's buckets
+            # leave between the two replays, so their exchange runs under depthNet's backward (the larger half of the step's
+            # backward time); the depthNet buckets and the update follow eagerly.
+            refine_ids = self._refine_ids
+            self.reducer.launch_ready(lambda p: id(p) in refine_ids)
+            self._graph_b.replay()
             self._finish(self.reducer.reduce_all)
             self.optimizer.step()
         return _log_values(self._static_logs)
@@ -244,24 +272,53 @@ class TrainStepWoNormal:
         saved = [t.clone() for t in self._state_tensors()]  # parameters, BatchNorm buffers and whatever Adam state exists already
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
+        segmented = self.reducer is not None
+        refine_params = [p for p in self.refine_net.parameters() if p.requires_grad]
+        self._refine_ids = {id(p) for p in refine_params}
+
+        def backward_refine(loss):
+            """Backward from the loss down to depthNet's outputs (the cut recorded by losses()): the refine net's parameter gradients
+            are final after it; returns what depthNet's backward starts from."""
+            cut = [c for c in self._cut if c.requires_grad]
+            grads = torch.autograd.grad(loss, refine_params + cut, allow_unused=True)
+            for p, g in zip(refine_params, grads):
+                p.grad = g                                  # assigned, as the captured AccumulateGrad of a None gradient does
+            gc = grads[len(refine_params):]
+            return [c for c, g in zip(cut, gc) if g is not None], [g for g in gc if g is not None]
+
         with torch.cuda.stream(side):                       # warm-up off the default stream: Adam state and allocator pools exist before capture
             for _ in range(2):
                 with _step_scope():
                     loss, logs = fn(*self._static_in)
                     self.optimizer.zero_grad(set_to_none=True)
-                    loss.backward()
+                    if segmented:
+                        torch.autograd.backward(*backward_refine(loss))
+                    else:
+                        loss.backward()
                 if self.reducer is None:
                     self.optimizer.step()
                 del loss, logs                              # no autograd graph of the warm-up may outlive it (its AccumulateGrad nodes carry their stream)
         torch.cuda.current_stream().wait_stream(side)
         self.optimizer.zero_grad(set_to_none=True)
-        self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph), _step_scope():
-            loss, logs = fn(*self._static_in)
-            loss.backward()
-            if self.reducer is None:
-                self.optimizer.step()
+        self._graph, self._graph_b = torch.cuda.CUDAGraph(), None
+        if segmented:
+            # graph A: forward + backward through the refine net; graph B (same memory pool): depthNet's backward.  Between their
+            # replays the refine net's gradient buckets are handed to the collective.
+            with torch.cuda.graph(self._graph), _step_scope():
+                loss, logs = fn(*self._static_in)
+                cut, gcut = backward_refine(loss)
+            self._graph_b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph_b, pool=self._graph.pool()), _step_scope():
+                torch.autograd.backward(cut, gcut)
+            del cut, gcut
+        else:
+            with torch.cuda.graph(self._graph), _step_scope():
+                loss, logs = fn(*self._static_in)
+                loss.backward()
+                if self.reducer is None:
+                    self.optimizer.step()
         self._static_logs = {k: v.detach() for k, v in logs.items()}
+        self._cut = None
         del loss, logs
         # undo the warm-up in place (the graph holds these addresses): the first replay is the first real step.  State that
         # existed before is restored; state the warm-up CREATED (Adam moments and step counters of parameters that had
@@ -287,6 +344,7 @@ class TrainStepWoNormal:
         else:
             p01, f01 = self.depth_net(rgbs[:, 0], rgbs[:, 1], cameras[:, 0], cameras[:, 1])     # :509-512
             p02, f02 = self.depth_net(rgbs[:, 0], rgbs[:, 2], cameras[:, 0], cameras[:, 2])
+        self._cut = [*p01, getattr(f01, "_cnm_c4", f01), *p02, getattr(f02, "_cnm_c4", f02)]   # what depthNet hands on: the segmented graph step cuts backward here
         idr, prob = self.refine_net(idepth01=p01[0], idepth02=p02[0], iconv01=f01, iconv02=f02)   # :517-520
         L = lambda a, b, w=None: _masked_l1(a, b, self.dist, w, self.exact, self.group)
         loss_idepth_1 = (L(p01[0], gt_id) + L(p02[0], gt_id)) * 0.5                          # :522-523
@@ -407,6 +465,7 @@ class TrainStep(TrainStepWoNormal):
         else:
             p01, f01 = self.depth_net(rgbs[:, 0], rgbs[:, 1], cameras[:, 0], cameras[:, 1])     # :164-167
             p02, f02 = self.depth_net(rgbs[:, 0], rgbs[:, 2], cameras[:, 0], cameras[:, 2])
+        self._cut = [*p01, getattr(f01, "_cnm_c4", f01), *p02, getattr(f02, "_cnm_c4", f02)]   # see TrainStepWoNormal.losses
         idr, prob = self.refine_net(idepth01=p01[0], idepth02=p02[0], iconv01=f01, iconv02=f02)   # :172-175
         L = lambda a, b, w=None: _masked_l1(a, b, self.dist, w, self.exact, self.group)
         loss_idepth_1 = (L(p01[0], gt_id) + L(p02[0], gt_id)) * 0.5                          # :177-178

@@ -103,8 +103,9 @@ def main():
                 assert e1 < 1e-3 and e2 < 2e-3, ("Adam moments", k, e1, e2)
                 assert float(std["step"]) == float(st1["step"]) == 1.0, k
             print("dp-step OK: worst gradient rel-L2 %.2e, worst Adam-moment rel-L2 %.2e, buckets %d" % (worst_g, worst_u, len(step.reducer.buckets)), flush=True)
-        # ---- graph mode next to the reducer: forward + backward replayed as one HIP graph, exchange and Adam eager (no hooks:
-        # every bucket is launched after the replay), two steps on different shards against the eager data-parallel step
+        # ---- graph mode next to the reducer: the step replayed as two HIP graphs (forward + refine backward | depthNet backward) with
+        # the refine net's buckets launched in between, the rest and Adam eager; two steps on different shards against the eager
+        # data-parallel step
         pair = []
         for graph in (False, True):
             dg, rg = nets(dev)
@@ -116,6 +117,13 @@ def main():
                 smp = synthetic_training_sample(B, H, W, seed=sd, device=dev)
                 lg = st(**{k: smp[k][rank * per:(rank + 1) * per].contiguous() for k in keys})
                 assert np.isfinite(lg["loss"])
+            if graph:
+                # the segmented replay: the refine net's buckets (no bucket mixes the two nets) left between the two graphs, the
+                # depthNet buckets after the second one
+                r = st.reducer
+                n_refine = sum(all(id(p) in st._refine_ids for p in b) for b in r.buckets)
+                assert st._graph_b is not None and n_refine >= 1 and r.hook_launches == n_refine and r.hook_launches + r.late_launches == len(r.buckets), \
+                    (n_refine, r.hook_launches, r.late_launches, len(r.buckets))
             pair.append((lg, {k: p.detach().clone() for k, p in named(dg, rg)}))
         (le, pe), (lgr, pg_) = pair
         assert abs(le["loss"] - lgr["loss"]) <= 1e-5 * max(1.0, abs(le["loss"])), (le["loss"], lgr["loss"])

@@ -92,3 +92,12 @@ def test_eight_rank_dry_run_train():
     assert abs(d["value"] - 8 * 1 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
     ar = d["allreduce"]
     assert ar["bytes_per_step"] == 4 * 44674566 and ar["launched_from_backward_hooks"] == ar["buckets"] and ar["launched_late"] == 0
+
+
+def test_two_rank_f16_line():
+    """BASELINE configs[4] ("fp16 path ... batch=16 on 2xMI355X"): two ranks of 8 frames each through the f16 engine, dry-run on one GPU."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--precision", "f16", "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-roofline", "--no-secondary"]
+    r = subprocess.run(cmd, cwd=ROOT, env=_clean_env(), capture_output=True, text=True, timeout=900)
+    _check_line(r, world=2, frames=8)
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["dtype"].startswith("f16") and d["config"]["frames_per_gpu"] == 8
