@@ -158,12 +158,16 @@ def live_pmc(timeout_s=240):
             if row["Dispatch_Id"] not in ids[k]:
                 ids[k].add(row["Dispatch_Id"]); dur[k] += (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-3
         _LIVE_VALU = {k: dict({c: v / len(ids[k]) for c, v in tot[k].items()}, us=dur[k] / len(ids[k])) for k in tot}
-    rows = _child_pass([], "kernel_trace.csv", timeout_s, ["--side-stream", "0"])
+    rows = _child_pass([], "kernel_trace.csv", timeout_s, ["--side-stream", "0", "--steps", "4"])
     if not isinstance(rows, str):
-        tot, n = collections.defaultdict(float), collections.defaultdict(int)
-        for row in rows:
-            tot[row["Kernel_Name"]] += (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-3; n[row["Kernel_Name"]] += 1
-        _LIVE_TRACE = {k: (tot[k] / n[k], n[k]) for k in tot}
+        # 1 warm-up + 4 timed steps: the first two steps of the process (cold allocator, first-touch weights) are left out
+        per = collections.defaultdict(list)
+        for row in sorted(rows, key=lambda r: int(r["Start_Timestamp"])):
+            per[row["Kernel_Name"]].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-3)
+        _LIVE_TRACE = {}
+        for k, v in per.items():
+            v = v[2 * len(v) // 5:] if len(v) >= 5 else v
+            _LIVE_TRACE[k] = (sum(v) / len(v), len(v))
 
 
 def _by_kernel(table, kernel):
@@ -371,8 +375,8 @@ def kernel_rooflines(dev, frames):
         # Why 0.60 of the HBM roof is out of this formulation's reach, as numbers.  SQ_ACTIVE_INST_VALU counts
         # QUAD-cycles in which a wave has a vector instruction in execution, so "cycles per issue" read from it cannot come out below 4;
         # tools/valu_rate.hip measures 2.35 cycles per v_fma_f32 with four waves per SIMD.  Both roofs are given.
-        n_simd = 1024.0
-        insts, busy4, gui, us = v["SQ_INSTS_VALU"], 4.0 * v.get("SQ_ACTIVE_INST_VALU", 0.0), v["GRBM_GUI_ACTIVE"], v["us"]
+        n_simd, n_xcd = 1024.0, 8.0
+        insts, busy4, gui, us = v["SQ_INSTS_VALU"], 4.0 * v.get("SQ_ACTIVE_INST_VALU", 0.0), v["GRBM_GUI_ACTIVE"] / n_xcd, v["us"]   # GRBM_GUI_ACTIVE: summed over the XCDs
         mhz = gui / us                                                    # shader clock while the kernel ran under the counters
         sweep.update({"valu_wave_instructions": insts, "valu_instructions_per_sample": insts * 64.0 / (pairs * PLANES * H * W),
                       "valu_cycles_per_issue": busy4 / insts, "valu_issue_frac": busy4 / (n_simd * gui),
