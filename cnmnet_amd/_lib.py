@@ -139,6 +139,7 @@ PROTOTYPES = {
     "cnm_bn_train_backward_z_c4_f32": (c_i, [c_fp] * 6 + [c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp]),
     "cnm_bn_train_forward_zg_c4_f32": (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_f, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "cnm_bn_train_backward_zg_c4_f32": (c_i, [c_fp] * 6 + [c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    "cnm_bn_train_backward_zgb_c4_f32": (c_i, [c_fp] * 6 + [c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "cnm_head_backward_workspace_doubles": (c_sz, [c_i]),
     "cnm_head_backward_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_f, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp]),
     "cnm_masked_l1_workspace_doubles": (c_sz, []),

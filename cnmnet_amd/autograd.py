@@ -5,6 +5,8 @@ torch supplies the tape, the optimizer and the elementwise glue (concatenation a
 sigmoid of the 1-channel heads, losses); every convolution, BatchNorm and resampling -- forward and
 backward -- is a HIP kernel.  The plane sweep is a leaf without gradient.
 """
+import os
+
 import torch
 
 from . import _lib, ops
@@ -111,6 +113,7 @@ def _winograd_conv(x, weight, rot, stride=1, dgrad=False):
     return ops.conv_rows_winograd_c4(x, up, None, Cout, k, relu=False, stride=stride, tile=2)
 
 
+BN_RECOMPUTE_MASK = os.environ.get("CNM_BN_RECOMPUTE_MASK", "1") != "0"   # BatchNorm backward without the saved output (mask from x): 5 tensor passes instead of 7
 FAST_FORWARD = True              # the inference kernels' larger tiles where their relative L2 error stays a decade below the op-level bar (2e-5): F(2x2,5x5), F(4,2) stride-2 rows
 WINOGRAD_WGRAD = True            # weight gradient of the 3x3 stride-1 layers in the Winograd domain (transform, 36 GEMMs, inverse transform)
 WINOGRAD_WGRAD_MIN_PIXELS = 512     # ... from this many pixels N*H*W on (4 x 12 x 16 = 768: 1.2-1.4x; 4 x 6 x 8: the direct kernel)
@@ -341,8 +344,13 @@ class BatchNormReLUC4(torch.autograd.Function):
                 running_var.data_ptr() if running_var is not None else 0, float(momentum), float(eps), int(relu),
                 y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _bn_workspace(dev, G, groups).data_ptr(),
                 num_batches_tracked.data_ptr() if num_batches_tracked is not None else 0, N, C, H, W, groups, _s()))
-        ctx.save_for_backward(x, y, gamma, mean, invstd)
-        ctx.relu, ctx.groups = relu, groups
+        # the backward recomputes the ReLU mask from x (cnm_bn_train_backward_zgb_c4_f32): y is not kept on the tape for BatchNorm's
+        # sake, and the backward kernels read 5 tensors instead of 7
+        if BN_RECOMPUTE_MASK:
+            ctx.save_for_backward(x, beta, gamma, mean, invstd)
+        else:
+            ctx.save_for_backward(x, y, gamma, mean, invstd)
+        ctx.relu, ctx.groups, ctx.recompute = relu, groups, BN_RECOMPUTE_MASK
         return y
 
     @staticmethod
@@ -355,9 +363,14 @@ class BatchNormReLUC4(torch.autograd.Function):
         dx = torch.empty_like(x)
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
         with torch.cuda.device(dev):
-            _lib.check(lib.cnm_bn_train_backward_zg_c4_f32(
-                x.data_ptr(), y.data_ptr(), dy.data_ptr(), gamma.detach().contiguous().data_ptr(), mean.data_ptr(), invstd.data_ptr(),
-                int(ctx.relu), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), _bn_workspace(dev, G, ctx.groups).data_ptr(), N, C, H, W, ctx.groups, _s()))
+            if ctx.recompute:                               # `y` holds beta here (see forward)
+                _lib.check(lib.cnm_bn_train_backward_zgb_c4_f32(
+                    x.data_ptr(), dy.data_ptr(), gamma.detach().contiguous().data_ptr(), y.detach().contiguous().data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                    int(ctx.relu), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), _bn_workspace(dev, G, ctx.groups).data_ptr(), N, C, H, W, ctx.groups, _s()))
+            else:
+                _lib.check(lib.cnm_bn_train_backward_zg_c4_f32(
+                    x.data_ptr(), y.data_ptr(), dy.data_ptr(), gamma.detach().contiguous().data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                    int(ctx.relu), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), _bn_workspace(dev, G, ctx.groups).data_ptr(), N, C, H, W, ctx.groups, _s()))
         return dx, dgamma, dbeta, None, None, None, None, None, None, None
 
 

@@ -695,6 +695,14 @@ __global__ void bn_finalize_kernel(double* __restrict__ stats, int C, double cou
     }
 }
 
+// y before the ReLU, in ONE pinned operation order: the backward kernels recompute the ReLU mask from x with the same function
+// (r > 0 <=> y > 0 bit for bit), so they need not read y -- two of the seven tensor passes of a BatchNorm backward
+__device__ __forceinline__ float bn_affine(float x, float mean, float invstd, float gamma, float beta) {
+#pragma clang fp contract(off)
+    const float xh = (x - mean) * invstd;
+    return __builtin_fmaf(xh, gamma, beta);
+}
+
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, int C, int relu,
@@ -709,7 +717,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
         for (int j = 0; j < 4; ++j) {
             const int c = 4 * g + j;
             float r = 0.f;
-            if (c < C) { r = (in[j] - mean[so + c]) * invstd[so + c] * gamma[c] + beta[c]; if (relu) r = fmaxf(r, 0.f); }
+            if (c < C) { r = bn_affine(in[j], mean[so + c], invstd[so + c], gamma[c], beta[c]); if (relu) r = fmaxf(r, 0.f); }
             o[j] = r;
         }
         *reinterpret_cast<float4*>(y + idx * 4) = make_float4(o[0], o[1], o[2], o[3]);
@@ -717,26 +725,35 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 }
 
 // backward pass 1: sum_dy[c], sum_dy_xhat[c] (dy masked by the ReLU of the forward output y)
+// RECOMP: the ReLU mask from x (bn_affine(x) > 0) instead of from the saved output y (y == nullptr then)
+template <bool RECOMP>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                             const float* __restrict__ dy, const float* __restrict__ mean,
-                                                            const float* __restrict__ invstd, int C, int relu,
+                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int C, int relu,
                                                             int N, int G, int HW, double* __restrict__ sums, int S) {
     const int g = blockIdx.x, grp = blockIdx.z;
     const long long total = (long long)((N - grp + S - 1) / S) * HW;
     sums += (size_t)grp * 8 * G;
     double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
-    float mu[4], is[4];
+    float mu[4], is[4], ga[4], be[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { const int c = 4 * g + j; mu[j] = c < C ? mean[grp * C + c] : 0.f; is[j] = c < C ? invstd[grp * C + c] : 0.f; }
+    for (int j = 0; j < 4; ++j) {
+        const int c = 4 * g + j; mu[j] = c < C ? mean[grp * C + c] : 0.f; is[j] = c < C ? invstd[grp * C + c] : 0.f;
+        ga[j] = (RECOMP && c < C) ? gamma[c] : 0.f; be[j] = (RECOMP && c < C) ? beta[c] : 0.f;
+    }
     for (long long i = (long long)blockIdx.y * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.y * blockDim.x) {
         const int n = (int)(i / HW) * S + grp, pix = (int)(i % HW);
         const size_t o = c4_offset(n, G, g, HW, pix);
-        const float4 xv = *reinterpret_cast<const float4*>(x + o), yv = *reinterpret_cast<const float4*>(y + o);
+        const float4 xv = *reinterpret_cast<const float4*>(x + o);
+        float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (!RECOMP) yv = *reinterpret_cast<const float4*>(y + o);
         const float4 dv = *reinterpret_cast<const float4*>(dy + o);
         const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ys[4] = {yv.x, yv.y, yv.z, yv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float d = (relu && !(ys[j] > 0.f)) ? 0.f : ds[j];
+            const float pre = RECOMP ? bn_affine(xs[j], mu[j], is[j], ga[j], be[j]) : ys[j];
+            const float d = (relu && !(pre > 0.f)) ? 0.f : ds[j];
             s[j] += d; q[j] += (double)d * ((xs[j] - mu[j]) * is[j]);
         }
     }
@@ -757,9 +774,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 }
 
 // backward pass 2: dx = gamma*invstd*(dy - sum_dy/m - xhat*sum_dy_xhat/m); dgamma = sum_dy_xhat; dbeta = sum_dy
+template <bool RECOMP>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                            const float* __restrict__ dy, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta,
                                                            const double* __restrict__ sums, double count, int C, int relu,
                                                            float* __restrict__ dx, int N, int G, int HW, int S) {
     const long long total = (long long)N * G * HW;
@@ -768,7 +787,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         const int g = (int)(ng % G), grp = S == 1 ? 0 : (int)((ng / G) % S), so = grp * C;
         const double* sg = sums + (size_t)grp * 8 * G;
         const double cnt = S == 1 ? count : (double)((N - grp + S - 1) / S) * HW;
-        const float4 xv = *reinterpret_cast<const float4*>(x + idx * 4), yv = *reinterpret_cast<const float4*>(y + idx * 4);
+        const float4 xv = *reinterpret_cast<const float4*>(x + idx * 4);
+        float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (!RECOMP) yv = *reinterpret_cast<const float4*>(y + idx * 4);
         const float4 dv = *reinterpret_cast<const float4*>(dy + idx * 4);
         const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ys[4] = {yv.x, yv.y, yv.z, yv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
         float o[4];
@@ -777,7 +798,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             const int c = 4 * g + j;
             float r = 0.f;
             if (c < C) {
-                const float d = (relu && !(ys[j] > 0.f)) ? 0.f : ds[j];
+                const float pre = RECOMP ? bn_affine(xs[j], mean[so + c], invstd[so + c], gamma[c], beta[c]) : ys[j];
+                const float d = (relu && !(pre > 0.f)) ? 0.f : ds[j];
                 const float xh = (xs[j] - mean[so + c]) * invstd[so + c];
                 const float sd = (float)(sg[2 * c] / cnt), sq = (float)(sg[2 * c + 1] / cnt);
                 r = gamma[c] * invstd[so + c] * (d - sd - xh * sq);
@@ -840,18 +862,23 @@ extern "C" int cnm_bn_train_forward_z_c4_f32(const float* x, const float* gamma,
     return bn_forward(x, gamma, beta, running_mean, running_var, momentum, eps, relu, y, save_mean, save_invstd, zero_ws, 1, num_batches_tracked, N, C, H, W, stream);
 }
 
+// y == nullptr (with beta): the ReLU mask is recomputed from x -- y is then neither read nor needed by the caller's tape
 static int bn_backward(const float* x, const float* y, const float* dy, const float* gamma,
                        const float* save_mean, const float* save_invstd, int relu,
                        float* dx, float* dgamma, float* dbeta, double* sums_ws, int zeroed,
-                       int N, int C, int H, int W, void* stream, int S = 1) {
-    CNM_REQUIRE(x && y && dy && gamma && save_mean && save_invstd && dx && dgamma && dbeta && sums_ws && N > 0 && C > 0 && S >= 1 && S <= N, CNM_ERR_BAD_ARG);
+                       int N, int C, int H, int W, void* stream, int S = 1, const float* beta = nullptr) {
+    CNM_REQUIRE(x && (y || beta || !relu) && dy && gamma && save_mean && save_invstd && dx && dgamma && dbeta && sums_ws && N > 0 && C > 0 && S >= 1 && S <= N, CNM_ERR_BAD_ARG);
     const int G = (C + 3) / 4, HW = H * W;
     hipStream_t s = cnm_stream(stream);
     if (!zeroed) bn_zero_kernel<<<cnm_ceil_div(8 * G * S, 256), 256, 0, s>>>(sums_ws, 8 * G * S);
-    bn_bwd_reduce_kernel<<<dim3(G, bn_grid_y((N + S - 1) / S, HW), S), 256, 0, s>>>(x, y, dy, save_mean, save_invstd, C, relu, N, G, HW, sums_ws, S);
+    const bool recomp = !y && relu;
+    const dim3 rg(G, bn_grid_y((N + S - 1) / S, HW), S);
+    if (recomp) bn_bwd_reduce_kernel<true><<<rg, 256, 0, s>>>(x, nullptr, dy, save_mean, save_invstd, gamma, beta, C, relu, N, G, HW, sums_ws, S);
+    else bn_bwd_reduce_kernel<false><<<rg, 256, 0, s>>>(x, y ? y : x, dy, save_mean, save_invstd, gamma, beta, C, relu, N, G, HW, sums_ws, S);
     const long long total = (long long)N * G * HW;
-    bn_bwd_apply_kernel<<<(int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384), 256, 0, s>>>(
-        x, y, dy, save_mean, save_invstd, gamma, sums_ws, (double)N * HW, C, relu, dx, N, G, HW, S);
+    const int ag = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    if (recomp) bn_bwd_apply_kernel<true><<<ag, 256, 0, s>>>(x, nullptr, dy, save_mean, save_invstd, gamma, beta, sums_ws, (double)N * HW, C, relu, dx, N, G, HW, S);
+    else bn_bwd_apply_kernel<false><<<ag, 256, 0, s>>>(x, y ? y : x, dy, save_mean, save_invstd, gamma, beta, sums_ws, (double)N * HW, C, relu, dx, N, G, HW, S);
     bn_param_grad_kernel<<<cnm_ceil_div(4 * G, 256), 256, 0, s>>>(sums_ws, C, dgamma, dbeta, zeroed, S);
     CNM_LAUNCH_CHECK();
     return CNM_OK;
@@ -885,6 +912,16 @@ extern "C" int cnm_bn_train_backward_zg_c4_f32(const float* x, const float* y, c
                                                float* dx, float* dgamma, float* dbeta, double* zero_ws,
                                                int N, int C, int H, int W, int groups, void* stream) {
     return bn_backward(x, y, dy, gamma, save_mean, save_invstd, relu, dx, dgamma, dbeta, zero_ws, 1, N, C, H, W, stream, groups);
+}
+
+// The grouped backward WITHOUT the saved output: the ReLU mask is recomputed from x, gamma, beta and the saved statistics with
+// the forward's own operation order (bit-identical to the y-reading form); the tape then keeps x only.
+extern "C" int cnm_bn_train_backward_zgb_c4_f32(const float* x, const float* dy, const float* gamma, const float* beta,
+                                                const float* save_mean, const float* save_invstd, int relu,
+                                                float* dx, float* dgamma, float* dbeta, double* zero_ws,
+                                                int N, int C, int H, int W, int groups, void* stream) {
+    CNM_REQUIRE(beta, CNM_ERR_BAD_ARG);
+    return bn_backward(x, nullptr, dy, gamma, save_mean, save_invstd, relu, dx, dgamma, dbeta, zero_ws, 1, N, C, H, W, stream, groups, beta);
 }
 
 // ------------------------------------------------------------------ adjoint of the bilinear x2 upsample

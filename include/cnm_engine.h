@@ -588,6 +588,14 @@ int cnm_bn_train_backward_zg_c4_f32(const float* x, const float* y, const float*
                                     float* dx, float* dgamma, float* dbeta, double* zero_ws,
                                     int N, int C, int H, int W, int groups, void* stream);
 
+/* The grouped backward without the saved output y: the ReLU mask is recomputed from x, gamma, beta and the saved statistics in
+ * the forward's own operation order (bit-identical results); two of the seven tensor passes of a BatchNorm backward less, and
+ * the autograd tape keeps x only. */
+int cnm_bn_train_backward_zgb_c4_f32(const float* x, const float* dy, const float* gamma, const float* beta,
+                                     const float* save_mean, const float* save_invstd, int relu,
+                                     float* dx, float* dgamma, float* dbeta, double* zero_ws,
+                                     int N, int C, int H, int W, int groups, void* stream);
+
 /* Masked mean L1 of the training losses -- IdepthLoss / IdepthwithProbLoss (losses.py:30-73) without the `pred[mask]` gather:
  *   out2[0] = sum_m weight |pred - gt| / count(m),  out2[1] = count(m),  m = gt > 0 && finite(gt) && finite(pred) && pred > 0
  * (losses.py:39-40, :61; weight may be NULL = 1; an empty mask gives NaN like the reference's mean of an empty selection).  n elements,
