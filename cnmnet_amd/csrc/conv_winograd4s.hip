@@ -143,11 +143,12 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
     constexpr int WD = WINO4S_WD, NXI = 36;
     constexpr int SLOT_BYTES = 8 * 16 * 64 * 16;                         // one range's partial output: 8 waves x 16 pixels x 64 lanes x float4 = 128 KB
     static_assert(PLANE % 128 == 0 && NXI % WD == 0 && WD % 2 == 0, "layout");
+    constexpr int GEN0 = DV0 + DPW * 512 * 4;                            // the launch's hand-off generation (sync_ws.h), read at unit ends only
 #ifdef WINO4S_TIMELINE
-    constexpr int TL0 = DV0 + DPW * 512 * 4;
+    constexpr int TL0 = GEN0 + 16;
     __shared__ __attribute__((aligned(16))) char smem[TL0 + 2 * 8 * 24 * 4];
 #else
-    __shared__ __attribute__((aligned(16))) char smem[DV0 + DPW * 512 * 4];   // 136 KB (TSX 16) / 126 KB (TSX 8)
+    __shared__ __attribute__((aligned(16))) char smem[GEN0 + 16];       // 136 KB (TSX 16) / 126 KB (TSX 8)
 #endif
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int hi = wave >> 2;
@@ -163,7 +164,8 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
     const auto range_begin = [&](int r) { return sync_flags ? (int)(T * r / G) : (int)((long long)nunits * r / G) * nch; };
     const int ps = range_begin(rng), pe = range_begin(rng + 1);
     const int P = pe - ps;                                               // phases of this workgroup
-    if (P <= 0) { if (sync_flags && threadIdx.x == 0) sync_leave(sync_flags, G); return; }
+    if (P <= 0) { if (sync_flags && threadIdx.x == 0) sync_leave(sync_flags); return; }
+    if (sync_flags && t == 0) *reinterpret_cast<unsigned*>(smem + GEN0) = sync_generation(sync_flags);   // ordered before its readers by the prologue's barriers
 
     // ---- stage role: pieces n = wave + 8 m of the chunk's NDMA (plane q = n / NPIECE, piece k = n % NPIECE)
     // What a DMA instruction needs from the kernel arguments lives in laundered scalars: left to itself the compiler re-reads the
@@ -398,8 +400,8 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
         int nsrc = 0;                                                    // partial outputs to add: ranges rng + 1 .. rng + nsrc
         if (!publish && !lastc) {
             for (int rem = nch - 1 - mc; rem > 0; ++nsrc) rem -= range_begin(rng + nsrc + 2) - range_begin(rng + nsrc + 1);
-            if (t == 0) {                                                // one lane polls (relaxed) for this launch's generation, one acquire for the workgroup; a time-out is reported to the host (sync_ws.h)
-                const unsigned gen = sync_generation(sync_flags);
+            if (t == 0) {                                                // one lane polls (relaxed) for this launch's generation and re-arms what it saw, one acquire for the workgroup; a time-out is reported to the host (sync_ws.h)
+                const unsigned gen = *reinterpret_cast<const unsigned*>(smem + GEN0);
                 for (int k = 1; k <= nsrc; ++k) sync_wait(sync_flags, rng + k, gen);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
@@ -503,7 +505,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
             if (publish) {                                               // every storing wave drains its stores, then ONE lane raises the flag
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
-                if (t == 0) sync_publish(sync_flags, rng, sync_generation(sync_flags));
+                if (t == 0) sync_publish(sync_flags, rng, *reinterpret_cast<const unsigned*>(smem + GEN0));
             }
 #pragma unroll
             for (int x = 0; x < NXI; ++x) acc[x] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -512,7 +514,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
         if (lastc) { ++mu; mcblk = ncblk; }
         mc = 0; part_c0 = 0;
     }
-    if (sync_flags && t == 0) sync_leave(sync_flags, G);                 // the last workgroup out advances the workspace's generation
+    if (sync_flags && t == 0) sync_leave(sync_flags);                    // exit count: the next launch's generation
 #ifdef WINO4S_TIMELINE
     __syncthreads();
     if (blockIdx.x == 0 && t < 2 * 8 * 24) g_wino4s_tl[t] = reinterpret_cast<unsigned*>(smem + TL0)[t];

@@ -11,6 +11,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -31,10 +32,19 @@ namespace {
 
 inline size_t c4off(int n, int Gt, int g, int HW, int pix) { return (((size_t)n * Gt + g) * (size_t)HW + pix) * 4; }
 
+// threads = CNM_CPU_THREADS, else min(hardware threads, cgroup v2 CPU quota): a container that shows 256 CPUs under a quota of
+// 16 must not get 256 runnable threads
 int host_threads() {
     static int n = [] {
         const char* e = std::getenv("CNM_CPU_THREADS");
-        int v = e ? std::atoi(e) : (int)std::thread::hardware_concurrency();
+        if (e) return std::max(1, std::min(std::atoi(e), 256));
+        int v = (int)std::thread::hardware_concurrency();
+        if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[32] = {0}; long long period = 0;
+            if (std::fscanf(f, "%31s %lld", q, &period) == 2 && std::strcmp(q, "max") != 0 && period > 0)
+                v = std::min<long long>(v, std::max<long long>(1, std::atoll(q) / period));
+            std::fclose(f);
+        }
         return std::max(1, std::min(v, 256));
     }();
     return n;

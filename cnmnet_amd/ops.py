@@ -358,10 +358,11 @@ def wino36_sync_workspace(device):
 
 
 def sync_workspace_state(sync):
-    """(generation, workgroups still counted as leaving) of a sync workspace: after n stream-K launches that used it the
-    state is (n, 0) -- the last workgroup out of each launch advanced the generation and reset the exit counter."""
-    words = sync[:1024].view(torch.int32)[1020:1022].tolist()
-    return int(words[0]) & 0xFFFFFFFF, int(words[1])
+    """(flag words that are not zero, exit count) of a sync workspace (csrc/sync_ws.h): between launches every flag has been
+    re-armed by the range that consumed it -- 0 -- unless a hand-off timed out; the exit count (one per workgroup that has left,
+    never reset) is what the next launch takes its generation from, so it grows with every stream-K launch."""
+    words = sync[:1024].view(torch.int32)
+    return int((words[:1020] != 0).sum().item()), int(words[1020].item()) & 0xFFFFFFFF
 
 
 def engine_status(clear=True):

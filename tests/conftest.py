@@ -46,6 +46,30 @@ def normal_parity(got, want, ref_cam, disp_oracle, k_size=9, trust=5e-4):
     return e_fit, e_ref, float(1.0 - trusted.double().mean()), float(d.flatten().quantile(0.99))
 
 
+def _cpu_quota():
+    """CPUs this process may actually use: min(affinity, cgroup v2 cpu.max quota)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _oracle_threads():
+    """The CPU oracle (torch ops) sizes its thread pool by the logical CPU count; the GPU boxes show 256 CPUs under a quota of
+    16, and 256 runnable threads on 16 CPUs' worth of time made one 640x480 oracle frame take 7 minutes instead of 20 s."""
+    try:
+        import torch
+        torch.set_num_threads(max(1, min(torch.get_num_threads(), _cpu_quota())))
+    except ImportError:
+        pass
+    yield
+
+
 @pytest.fixture(scope="session", autouse=True)
 def _engine_library():
     """Build libcnm_engine.so once if the tree has not been built yet (hipcc cross-compiles without a GPU)."""
