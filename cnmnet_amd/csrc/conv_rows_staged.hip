@@ -97,7 +97,7 @@ __global__ __launch_bounds__(512, 2) void conv_rows7s_f32_kernel(const RowArgs a
     constexpr int NX = 10, NKY = 7, TSY = 4, TSX = 8, PR = TSY + 6, PC = 4 * TSX + 6, PCP = 41;   // patch 10 x 38 pixels, rows of 41 slots
     constexpr int NPIECE = (PR * PCP + 63) / 64, PLANE = NPIECE * 1024 + 128;                        // raw plane: 7 KB + pad
     constexpr int TVX = PR * TSX * 16, TVS = NX * TVX + 128;                                         // transformed plane: point pitch 1280, plane pitch 12928 bytes
-    constexpr int RAW0 = 0, TV0 = 4 * PLANE, STG0 = TV0 + 4 * TVS, GEN0 = STG0 + 8 * 4352, LDS_BYTES = GEN0 + 16;   // GEN0: the launch's hand-off generation (sync_ws.h)
+    constexpr int RAW0 = 0, TV0 = 4 * PLANE, STG0 = TV0 + 4 * TVS, LDS_BYTES = STG0 + 8 * 4352;
     constexpr int WD = ROWS7S_WD;                                                // frequency points of weight fragments in flight (two fragments each)
     constexpr int SLOT_BYTES = 8 * 16 * 64 * 16;                         // partial output of one range (as in conv_winograd4s.hip; half of it used)
     static_assert(NX % WD == 0 && TVS % 256 == 128 && TV0 % 128 == 0 && LDS_BYTES <= 120 * 1024, "layout");
@@ -116,8 +116,7 @@ __global__ __launch_bounds__(512, 2) void conv_rows7s_f32_kernel(const RowArgs a
     const auto range_begin = [&](int r) { return sync_flags ? (int)(T * r / G) : (int)((long long)nunits * r / G) * nch; };
     const int ps = range_begin(rng), pe = range_begin(rng + 1);
     const int P = pe - ps;
-    if (P <= 0) { if (sync_flags && threadIdx.x == 0) sync_leave(sync_flags); return; }
-    if (sync_flags && threadIdx.x == 0) *reinterpret_cast<unsigned*>(smem + GEN0) = sync_generation(sync_flags);   // ordered before its readers by the prologue's barriers
+    if (P <= 0) return;
 #ifdef ROWS7S_ABLATE
     const unsigned long long clk0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -411,7 +410,7 @@ __global__ __launch_bounds__(512, 2) void conv_rows7s_f32_kernel(const RowArgs a
         if (!publish && !lastc) {
             for (int rem = nch - 1 - mc; rem > 0; ++nsrc) rem -= range_begin(rng + nsrc + 2) - range_begin(rng + nsrc + 1);
             if (t == 0) {                                                // generation-valued flags, loud time-out: sync_ws.h
-                const unsigned gen = *reinterpret_cast<const unsigned*>(smem + GEN0);
+                const unsigned gen = sync_generation();
                 for (int k = 1; k <= nsrc; ++k) sync_wait(sync_flags, rng + k, gen);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
@@ -494,7 +493,7 @@ __global__ __launch_bounds__(512, 2) void conv_rows7s_f32_kernel(const RowArgs a
             if (publish) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
-                if (t == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); sync_publish(sync_flags, rng, *reinterpret_cast<const unsigned*>(smem + GEN0)); }
+                if (t == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); sync_publish(sync_flags, rng, sync_generation()); }
             }
 #pragma unroll
             for (int x = 0; x < NX; ++x) { acc[x][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[x][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -502,7 +501,6 @@ __global__ __launch_bounds__(512, 2) void conv_rows7s_f32_kernel(const RowArgs a
         if (lastc) { ++mu; mcblk = ncblk; }
         mc = lastc ? 0 : mc + 1; part_c0 = 0;
     }
-    if (sync_flags && t == 0) sync_leave(sync_flags);                    // exit count: the next launch's generation
 #ifdef ROWS7S_TIMELINE
     __syncthreads();
     if (blockIdx.x == 0 && t < 2 * 8 * 12) (&g_rows7s_tl[0][0][0])[t] = reinterpret_cast<unsigned*>(smem + LDS_BYTES)[t];

@@ -143,12 +143,11 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
     constexpr int WD = WINO4S_WD, NXI = 36;
     constexpr int SLOT_BYTES = 8 * 16 * 64 * 16;                         // one range's partial output: 8 waves x 16 pixels x 64 lanes x float4 = 128 KB
     static_assert(PLANE % 128 == 0 && NXI % WD == 0 && WD % 2 == 0, "layout");
-    constexpr int GEN0 = DV0 + DPW * 512 * 4;                            // the launch's hand-off generation (sync_ws.h), read at unit ends only
 #ifdef WINO4S_TIMELINE
-    constexpr int TL0 = GEN0 + 16;
+    constexpr int TL0 = DV0 + DPW * 512 * 4;
     __shared__ __attribute__((aligned(16))) char smem[TL0 + 2 * 8 * 24 * 4];
 #else
-    __shared__ __attribute__((aligned(16))) char smem[GEN0 + 16];       // 136 KB (TSX 16) / 126 KB (TSX 8)
+    __shared__ __attribute__((aligned(16))) char smem[DV0 + DPW * 512 * 4];   // 136 KB (TSX 16) / 126 KB (TSX 8)
 #endif
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int hi = wave >> 2;
@@ -164,8 +163,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
     const auto range_begin = [&](int r) { return sync_flags ? (int)(T * r / G) : (int)((long long)nunits * r / G) * nch; };
     const int ps = range_begin(rng), pe = range_begin(rng + 1);
     const int P = pe - ps;                                               // phases of this workgroup
-    if (P <= 0) { if (sync_flags && threadIdx.x == 0) sync_leave(sync_flags); return; }
-    if (sync_flags && t == 0) *reinterpret_cast<unsigned*>(smem + GEN0) = sync_generation(sync_flags);   // ordered before its readers by the prologue's barriers
+    if (P <= 0) return;
 
     // ---- stage role: pieces n = wave + 8 m of the chunk's NDMA (plane q = n / NPIECE, piece k = n % NPIECE)
     // What a DMA instruction needs from the kernel arguments lives in laundered scalars: left to itself the compiler re-reads the
@@ -401,7 +399,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
         if (!publish && !lastc) {
             for (int rem = nch - 1 - mc; rem > 0; ++nsrc) rem -= range_begin(rng + nsrc + 2) - range_begin(rng + nsrc + 1);
             if (t == 0) {                                                // one lane polls (relaxed) for this launch's generation and re-arms what it saw, one acquire for the workgroup; a time-out is reported to the host (sync_ws.h)
-                const unsigned gen = *reinterpret_cast<const unsigned*>(smem + GEN0);
+                const unsigned gen = sync_generation();
                 for (int k = 1; k <= nsrc; ++k) sync_wait(sync_flags, rng + k, gen);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
@@ -505,7 +503,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
             if (publish) {                                               // every storing wave drains its stores, then ONE lane raises the flag
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
-                if (t == 0) sync_publish(sync_flags, rng, *reinterpret_cast<const unsigned*>(smem + GEN0));
+                if (t == 0) sync_publish(sync_flags, rng, sync_generation());
             }
 #pragma unroll
             for (int x = 0; x < NXI; ++x) acc[x] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -514,7 +512,6 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
         if (lastc) { ++mu; mcblk = ncblk; }
         mc = 0; part_c0 = 0;
     }
-    if (sync_flags && t == 0) sync_leave(sync_flags);                    // exit count: the next launch's generation
 #ifdef WINO4S_TIMELINE
     __syncthreads();
     if (blockIdx.x == 0 && t < 2 * 8 * 24) g_wino4s_tl[t] = reinterpret_cast<unsigned*>(smem + TL0)[t];
@@ -524,6 +521,9 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
 #ifdef WINO4S_TIMELINE
 extern "C" int cnm_debug_wino4s_timeline(unsigned* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wino4s_tl), sizeof(unsigned) * 2 * 8 * 24) == hipSuccess ? 0 : -1; }
 #endif
+#ifdef WINO4S_ONE_INSTANCE   // codegen probes (tools/hotloop_proxy.sh): only the dominant instance, no host code
+template __global__ void conv_winograd36s_f32_kernel<16, false, 0, 4, false>(const Wino4Args, const int, const int, const int, const int, unsigned* __restrict__, float* __restrict__);
+#else
 static int g_wino36_staged = 1;                                          // tuning knob (A/B against the gather-fed kernel): 0 off, 1 where it pays, 2 wherever eligible
 extern "C" int cnm_tune_wino36_staged(int on) { const int old = g_wino36_staged; if (on >= 0 && on <= 2) g_wino36_staged = on; return old; }
 
@@ -567,6 +567,16 @@ SyncCtl cnm_sync_ctl(hipStream_t stream) {
     return SyncCtl{g_sync_status, g_sync_spin_limit, g_sync_version};
 }
 bool cnm_sync_failed() { return g_sync_status && *reinterpret_cast<volatile unsigned*>(g_sync_status) != 0u; }
+// Test hook (not in the header): the generation the kernels of one launch see -- tests/test_gpu_parity.py checks that it differs
+// from launch to launch, eager and in HIP-graph replays.
+__global__ void sync_generation_probe_kernel(unsigned* out) { if (threadIdx.x == 0) out[blockIdx.x] = sync_generation(); }
+extern "C" int cnm_debug_sync_generation(unsigned* out, int nblocks, void* stream) {
+    CNM_REQUIRE(out && nblocks > 0, CNM_ERR_BAD_ARG);
+    sync_generation_probe_kernel<<<nblocks, 64, 0, cnm_stream(stream)>>>(out);
+    CNM_LAUNCH_CHECK();
+    return CNM_OK;
+}
+
 // CNM_OK, or CNM_ERR_LAUNCH when a stream-K hand-off timed out since the last clear (the outputs of that launch are
 // wrong).  Reads a pinned host word: synchronise the stream first if the launch in question may still be running.
 extern "C" int cnm_engine_status(int clear) {
@@ -655,3 +665,4 @@ int cnm_wino36s_try_launch(const Wino4Args& a, int M, int ups, hipStream_t strea
     CNM_LAUNCH_CHECK();
     return CNM_OK;
 }
+#endif   // WINO4S_ONE_INSTANCE

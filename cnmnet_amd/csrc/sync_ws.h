@@ -3,21 +3,21 @@
 //
 // Layout (cnm_wino36_sync_floats() floats, zero before the FIRST use, one workspace per stream):
 //   words 0 .. 1019   one flag per range (= workgroup) of a launch; zero between launches
-//   word  1020        exit count: every workgroup adds 1 when it leaves (never reset: it only grows)
 //   bytes 4096 ..     one 128 KB partial-output slot per range
 //
-// A launch's GENERATION is the exit count its workgroups read when they start (+1): launches on a stream are ordered, so
-// every workgroup of a launch reads the same value, and every launch -- eager or a HIP-graph replay -- reads a different
-// one.  A range that publishes a partial output stores the generation in its flag; the range that finishes the unit polls
-// for exactly that value and, having SEEN it, re-arms the flag to zero.  A consumer that gives up writes nothing, so a
-// flag raised after its consumer timed out is merely a stale non-zero word: it carries an old generation, can never
-// satisfy a later launch's poll, and is overwritten the next time that range publishes -- the workspace needs no repair
-// (a flag lowered without having been seen raised used to poison every later launch on the stream).
-// Cost against the 0 / 1 flags of round 3: one load at kernel start (consumed much later) and one fire-and-forget
-// atomic at exit.  (A first version advanced the generation with a returning exit atomic + last-leaver logic: 3-4 us per
-// launch, 1.3 % of the bench step -- tools/r4_sync_ab.sh.)  If workgroups of one launch are so far apart that one leaves
-// before another starts, the late one reads a different generation and the hand-off times out: a loud failure, not a
-// wrong result.
+// A launch's GENERATION is its dispatch id -- the per-queue dispatch counter the command processor hands every wave in a user
+// SGPR (llvm.amdgcn.dispatch.id): the same for all workgroups of a launch, different for every launch on the queue, eager or
+// HIP-graph replay -- made odd so that it is never 0.  No memory traffic, no live register (it is re-read where needed).
+// A range that publishes a partial output stores the generation in its flag; the range that finishes the unit polls for
+// exactly that value and, having SEEN it, re-arms the flag to zero.  A consumer that gives up writes nothing, so a flag raised
+// after its consumer timed out is merely a stale non-zero word carrying an old generation: it cannot satisfy a later launch's
+// poll and is overwritten the next time that range publishes -- the workspace needs no repair (a flag lowered
+// without having been seen raised used to poison every later launch on the stream).
+// Two earlier forms of this round kept the generation in the workspace (advanced by the last workgroup out, found with a
+// returning exit atomic; then: an exit count read at kernel start and parked in LDS).  Both were correct and both cost the bench
+// step 0.7-1.3 % (tools/r4_sync_ab.sh, alternating builds on one box): 3-4 us of atomics per launch, and a dozen more
+// spilled SGPRs that pushed the phase loop's spill lanes into a second VGPR.  This form compiles to the round-3 register
+// allocation (tools/hotloop_proxy.sh: 63 spilled SGPRs, the same scratch reloads in the hot path).
 //
 // Failure is loud: a poll that exceeds its spin bound writes a non-zero word to a pinned host status word (system-scope
 // store, no host synchronisation), and every staged-kernel entry point refuses to launch -- CNM_ERR_LAUNCH -- while that
@@ -26,8 +26,8 @@
 #include "cnm_common.h"
 
 constexpr size_t kSyncFlagBytes = 4096, kSyncSlotBytes = 8 * 16 * 64 * 16;
-constexpr int kSyncMaxRanges = 1020, kSyncExitWord = 1020;
-constexpr unsigned kSyncFaultBit = 0x80000000u;                          // test-only fault injection: publishers keep their flag down
+constexpr int kSyncMaxRanges = 1020;
+constexpr unsigned kSyncFaultBit = 0x80000000u;                          // test-only fault injection: every wait fails as if its publisher had never come
 
 struct SyncCtl {
     unsigned* status;                                                    // pinned host word (device-visible), or null
@@ -58,31 +58,32 @@ static inline void sync_ctl_upload(hipStream_t stream) {
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_sync_ctl_dev), &c, sizeof(c)) == hipSuccess) uploaded[dev] = c.version + 1u; else (void)hipGetLastError();
 }
 
-// ONE lane, at kernel start: the generation of this launch (never 0).  The caller parks it in LDS; it is needed at unit ends only.
-__device__ static inline unsigned sync_generation(const unsigned* flags) {
-    const unsigned g = __hip_atomic_load(flags + kSyncExitWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-    return g ? g : 1u;
-}
+// The generation of this launch: the queue's dispatch id (a user SGPR the command processor fills in: the same for every
+// workgroup of a launch, different for every launch on the queue, eager or graph replay), made odd so that it is never 0.
+extern "C" __device__ unsigned long long cnm_llvm_dispatch_id() __asm("llvm.amdgcn.dispatch.id");   // no clang builtin for this intrinsic
+__device__ static inline unsigned sync_generation() { return ((unsigned)cnm_llvm_dispatch_id() << 1) | 1u; }
 // ONE lane: wait until range `idx` has published in this launch, then re-arm its flag.  A flag that was not seen is not written.
-__device__ static inline void sync_wait(unsigned* flags, int idx, unsigned gen) {
+// The bound and the status pointer live in a device global and are looked at every 4096 polls only -- and once up front for the
+// test-only fault bit, which makes the wait fail at once, as if its publisher had never come.
+__device__ static inline void sync_give_up(int idx) {                    // loud: the result of this unit is wrong and the host is told
     unsigned* const status = *reinterpret_cast<unsigned* volatile*>(&g_sync_ctl_dev.status);
-    unsigned limit = *reinterpret_cast<volatile unsigned*>(&g_sync_ctl_dev.spin_limit) & ~kSyncFaultBit;
-    if (!limit) limit = kSyncDefaultSpins;
+    if (status) __hip_atomic_store(status, 0x40000000u | (unsigned)idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ static inline void sync_wait(unsigned* flags, int idx, unsigned gen) {
     unsigned spins = 0;
-    while (__hip_atomic_load(flags + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gen) {
-        if (++spins > limit) {                                           // give up loudly: the result of this unit is wrong and the host is told
-            if (status) __hip_atomic_store(status, 0x40000000u | (unsigned)idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            return;
+    for (;;) {
+        if ((spins & 0xFFFu) == 0u) {                                    // first poll and every 4096th: the bound (and the test-only fault bit = bound 0)
+            const unsigned ctl = *reinterpret_cast<volatile unsigned*>(&g_sync_ctl_dev.spin_limit);
+            const unsigned limit = (ctl & kSyncFaultBit) ? 0u : (ctl ? ctl : kSyncDefaultSpins);
+            if (spins >= limit) { sync_give_up(idx); return; }
         }
+        if (__hip_atomic_load(flags + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) break;
+        ++spins;
         __builtin_amdgcn_s_sleep(8);
     }
     __hip_atomic_store(flags + idx, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ static inline void sync_publish(unsigned* flags, int idx, unsigned gen) {   // ONE lane, after the workgroup's stores have drained
-    if (!(*reinterpret_cast<volatile unsigned*>(&g_sync_ctl_dev.spin_limit) & kSyncFaultBit)) __hip_atomic_store(flags + idx, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// ONE lane per workgroup, as its last action: fire and forget (the result is not used, nothing waits for it)
-__device__ static inline void sync_leave(unsigned* flags) {
-    (void)__hip_atomic_fetch_add(flags + kSyncExitWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(flags + idx, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 #endif

@@ -358,11 +358,9 @@ def wino36_sync_workspace(device):
 
 
 def sync_workspace_state(sync):
-    """(flag words that are not zero, exit count) of a sync workspace (csrc/sync_ws.h): between launches every flag has been
-    re-armed by the range that consumed it -- 0 -- unless a hand-off timed out; the exit count (one per workgroup that has left,
-    never reset) is what the next launch takes its generation from, so it grows with every stream-K launch."""
-    words = sync[:1024].view(torch.int32)
-    return int((words[:1020] != 0).sum().item()), int(words[1020].item()) & 0xFFFFFFFF
+    """Number of flag words of a sync workspace that are not zero (csrc/sync_ws.h): between launches every flag has been re-armed
+    by the range that consumed it -- 0 -- unless a hand-off timed out and its publisher came late."""
+    return int((sync[:1024].view(torch.int32)[:1020] != 0).sum().item())
 
 
 def engine_status(clear=True):

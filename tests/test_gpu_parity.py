@@ -370,8 +370,7 @@ def test_conv_rows7_staged(dev, ops, cin, cin2, cout, N, H, W):
     assert torch.equal(ref, got), float((ref - got).abs().max())
     assert torch.allclose(ref, split, rtol=2e-4, atol=2e-4), float((ref - split).abs().max())   # fp32 sums in a different order
     assert torch.equal(split, split2)
-    nz, exits = ops.sync_workspace_state(sync)
-    assert nz == 0 and exits > 0                                         # every flag re-armed; the workgroups of both launches counted out
+    assert ops.sync_workspace_state(sync) == 0                          # every flag re-armed by its consumer
 
 
 @pytest.mark.parametrize("cin,cin2,cout,rot,N,H,W", [
@@ -421,14 +420,42 @@ def test_conv3x3_winograd4_staged(dev, ops, cin, cin2, cout, rot, N, H, W):
     # order: bit-reproducible, within the same bar of the fp64 convolution, every flag re-armed
     got = ops.c4_to_nchw(outs[2], cout).cpu().numpy()
     assert np.abs(got - want).max() < 2e-4 * max(np.abs(want).max(), 1.0), np.abs(got - want).max()
-    assert torch.equal(outs[2], outs[3]) and ops.sync_workspace_state(sync)[0] == 0
+    assert torch.equal(outs[2], outs[3]) and ops.sync_workspace_state(sync) == 0
+
+
+def test_sync_generation_differs_from_launch_to_launch(dev):
+    """The hand-off generation is the queue's dispatch id (csrc/sync_ws.h): the same for every workgroup of a launch, different for
+    every launch -- eager launches and replays of one captured HIP graph alike (a constant would make a stale flag of a failed
+    replay look fresh to the next one)."""
+    from cnmnet_amd import _lib
+    lib = _lib.load()
+    out = torch.zeros(8, 64, dtype=torch.int32, device=dev)
+    st = lambda: torch.cuda.current_stream().cuda_stream
+    for i in range(4):
+        assert lib.cnm_debug_sync_generation(ctypes.c_void_p(out[i].data_ptr()), 64, ctypes.c_void_p(st())) == 0
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            assert lib.cnm_debug_sync_generation(ctypes.c_void_p(out[4].data_ptr()), 64, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+        gens = []
+        for i in range(3):
+            g.replay(); torch.cuda.synchronize()
+            gens.append(out[4].clone())
+    torch.cuda.synchronize()
+    rows = [out[i] for i in range(4)] + gens
+    for r in rows:
+        assert int(r.min()) == int(r.max()) and int(r[0]) & 1 == 1, r[:4]         # one value per launch, odd (never 0)
+    eager, replays = [int(r[0]) for r in rows[:4]], [int(r[0]) for r in gens]
+    assert len(set(eager)) == 4 and len(set(replays)) == 3, (eager, replays)
 
 
 @pytest.mark.parametrize("kind", ["wino36", "rows7"])
 def test_stream_k_handoff_timeout_is_loud(dev, ops, kind):
     """ADVICE r3 / VERDICT r3 item 4c: a stream-K hand-off that does not complete must not pass silently and must not poison
-    the workspace.  Fault injection (bit 31 of cnm_tune_sync_spin_limit: publishing workgroups keep their flags down) makes
-    every head range run into its spin bound: the launch returns, cnm_engine_status() reports CNM_ERR_LAUNCH, the next
+    the workspace.  Fault injection (bit 31 of cnm_tune_sync_spin_limit: every wait fails as if its publisher had never come --
+    the publishers do come, so their flags are left raised, stale, exactly as after a real time-out) makes every head range give up: the launch returns, cnm_engine_status() reports CNM_ERR_LAUNCH, the next
     staged call is refused until the failure is acknowledged -- and then the SAME workspace, unrepaired, gives the
     bit-identical right result, also with garbage in every flag word (a flag counts only if it carries THIS launch's generation,
     csrc/sync_ws.h)."""
@@ -450,8 +477,7 @@ def test_stream_k_handoff_timeout_is_loud(dev, ops, kind):
     sync = ops.wino36_sync_workspace(dev)
     good = run(sync)
     torch.cuda.synchronize()
-    nz, exits1 = ops.sync_workspace_state(sync)
-    assert lib.cnm_engine_status(0) == 0 and nz == 0 and exits1 > 0
+    assert lib.cnm_engine_status(0) == 0 and ops.sync_workspace_state(sync) == 0
     old = lib.cnm_tune_sync_spin_limit(0x80000000 | 500)
     try:
         run(sync)                                                        # hand-offs time out: wrong output, but it returns
@@ -459,7 +485,7 @@ def test_stream_k_handoff_timeout_is_loud(dev, ops, kind):
         assert lib.cnm_engine_status(0) == -4                            # CNM_ERR_LAUNCH, sticky
         with pytest.raises(_lib.EngineError):
             run(sync)                                                    # refused, nothing launched
-        assert ops.sync_workspace_state(sync) == (0, 2 * exits1)          # the failed launch re-armed nothing it had not seen, and counted out
+        assert ops.sync_workspace_state(sync) > 0                          # the publishers did raise their flags; the consumers, not having polled them, re-armed none
         with pytest.raises(_lib.EngineError):
             ops.engine_status(clear=True)                                # reports and acknowledges
         assert lib.cnm_engine_status(0) == 0
@@ -468,7 +494,7 @@ def test_stream_k_handoff_timeout_is_loud(dev, ops, kind):
         lib.cnm_engine_status(1)
     assert torch.equal(run(sync), good)                                  # no repair needed
     sync[:1020].view(torch.int32).copy_(T(rng.integers(-2**31, 2**31 - 1, 1020, dtype=np.int64).astype(np.int32)).to(dev))
-    assert torch.equal(run(sync), good) and ops.sync_workspace_state(sync)[1] == 4 * exits1
+    assert torch.equal(run(sync), good)
     torch.cuda.synchronize()
     assert lib.cnm_engine_status(0) == 0
 
@@ -501,7 +527,7 @@ def test_conv5x5_winograd_staged(dev, ops, cin, cout, rot, N, H, W):
     finally:
         lib.cnm_tune_wino36_staged(old)
     assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
-    assert torch.equal(outs[2], outs[3]) and ops.sync_workspace_state(sync)[0] == 0          # reproducible; flags re-armed
+    assert torch.equal(outs[2], outs[3]) and ops.sync_workspace_state(sync) == 0          # reproducible; flags re-armed
     for o in (outs[1], outs[2]):
         got = ops.c4_to_nchw(o, cout).cpu().numpy()
         assert np.abs(got - want).max() < 2e-4 * max(np.abs(want).max(), 1.0), np.abs(got - want).max()
@@ -547,7 +573,7 @@ def test_conv_s2_winograd4_staged(dev, ops, k, cin, cin2, cout, rot, N, H, W):
     assert got.shape == want.shape
     err = np.abs(got - want).max()
     assert err < 2e-4 * max(np.abs(want).max(), 1.0), err
-    assert torch.equal(o1, o2) and ops.sync_workspace_state(sync)[0] == 0
+    assert torch.equal(o1, o2) and ops.sync_workspace_state(sync) == 0
     if not cin2 and k != 3:                                              # the row-wise phase kernel on the same input: same bar
         ur = ops.pack_winograd(w.to(dev), bnd, rot=rot, stride=2)
         rows = ops.c4_to_nchw(ops.conv_rows_winograd_c4(xc, ur, bp, cout, k, True, stride=2), cout).cpu().numpy()

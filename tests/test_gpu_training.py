@@ -87,7 +87,7 @@ def test_stride2_dgrad_phase_scatter(dev, cin, cout, k, N, Ho, Wo):
     outs = [ops.conv3x3_phase_scatter_c4(dyc, up, cin, sync=sy, ksize=4 if k == 7 else 3).clone() for sy in (None, sync, sync)]
     for o in outs[:2]:
         assert _rel(ops.c4_to_nchw(o, cin).cpu().numpy(), want) < 2e-5, _rel(ops.c4_to_nchw(o, cin).cpu().numpy(), want)
-    assert torch.equal(outs[1], outs[2]) and ops.sync_workspace_state(sync)[0] == 0
+    assert torch.equal(outs[1], outs[2]) and ops.sync_workspace_state(sync) == 0
     old = ag.S2_DGRAD_SCATTER
     try:
         res = []

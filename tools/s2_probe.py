@@ -56,4 +56,4 @@ for name, k, Cin, Cout, N, H, W in (("depth conv2.3", 5, 256, 256, 16, 96, 128),
             extra = "   implicit GEMM %.3f ms (%.1f TF = %.2f of peak)" % (t_d, flop / t_d / 1e9, flop / t_d / 1e9 / 157.3)
         print("   N%d: rows %.3f ms (executed %.1f TF = %.2f of peak)   staged phases %.3f ms (executed %.1f TF = %.2f of peak)   %.2fx%s" % (
             N, t_r, flop * ex_r / t_r / 1e9, flop * ex_r / t_r / 1e9 / 157.3, t_s, flop * ex_s / t_s / 1e9, flop * ex_s / t_s / 1e9 / 157.3, t_r / t_s, extra), flush=True)
-assert ops.sync_workspace_state(SYNC)[0] == 0
+assert ops.sync_workspace_state(SYNC) == 0

@@ -21,7 +21,7 @@ def both(fn):
         lib.cnm_tune_wino36_staged(on)
         outs.append(fn(sync).clone())
     lib.cnm_tune_wino36_staged(1)
-    assert ops.sync_workspace_state(SYNC)[0] == 0, "workgroups left counted"
+    assert ops.sync_workspace_state(SYNC) == 0, "workgroups left counted"
     return outs
 
 
