@@ -5,6 +5,8 @@ the C ABI (cnmnet_amd -> ctypes -> libcnm_engine.so), against
   (3) size-independent properties at the full BASELINE sizes.
 Tolerance: BASELINE.json north_star asks for 1e-3 on depth/normal outputs; stated per test.
 """
+import ctypes
+
 import numpy as np
 import pytest
 import torch
