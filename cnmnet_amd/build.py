@@ -18,7 +18,14 @@ HOSTCXX = os.environ.get("CXX", "g++")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # per-file extras: the plane sweep's blend must stay on full-rate scalar v_fma_f32 (the SLP vectoriser would
 # pack it into half-rate v_pk_fma_f32 plus the moves that feed them)
-FILE_FLAGS = {"planesweep.hip": ["-fno-slp-vectorize"]}
+# the staged 36-point kernel lives at the register limit (256 VGPRs, 106 SGPRs + spill lanes): the greedy allocator's class-priority
+# order leaves the dominant instance without VGPR spills, and without machine LICM fewer scalars are kept live across the phase loop
+# (67 instead of 71 v_readlane reloads per phase, tools/hotloop_proxy.sh; 5.52 vs 5.57 ms over a step's launches, tools/r4_wino_variants.sh).
+# CNM_NO_FILE_FLAGS=1 builds without them (A/B).
+FILE_FLAGS = {"planesweep.hip": ["-fno-slp-vectorize"],
+              "conv_winograd4s.hip": ["-mllvm", "-greedy-regclass-priority-trumps-globalness=1", "-mllvm", "-disable-machine-licm"]}
+if os.environ.get("CNM_NO_FILE_FLAGS") == "1":
+    FILE_FLAGS = {"planesweep.hip": ["-fno-slp-vectorize"]}
 
 
 def _stale(target, deps):

@@ -199,7 +199,8 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
         }
     };
     auto dma_piece = [&](int m) {                                        // piece m of phase (du, dc) into the buffer of that phase
-        const int n = dma_n(m);
+        int wv = wave; asm volatile("" : "+s"(wv));                      // opaque here: what follows is recomputed on the scalar unit every phase (free) instead of hoisted, spilled and read back with v_readlane (VALU cycles = matrix-pipe cycles)
+        const int n = hi ? 4 * NLO + (wv - 4) + 4 * m : wv + 4 * m;
         if ((ABL & 2) || m >= (hi ? NHI : NLO) || n >= NDMA || dgp >= pe) return;
         const int q = n / NPIECE, g = (S2 ? dc >> 2 : dc) * 4 + q;
         const unsigned phoff = S2 ? ((dc >> 1) & 1) * row32 + (dc & 1) * 16u : 0u;   // S2: the chunk's pixel phase
@@ -353,7 +354,9 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
 #else
             // all pieces of a wave in ONE step: vmcnt retires in order, so the weight fragments loaded after a DMA instruction wait
             // for its data -- once per phase instead of once per piece (tools/wino36s_timeline.py)
-            if ((xp == WINO4S_LO_STEP && !hi) || (xp == WINO4S_HI_STEP && hi)) {
+            // (with every piece on waves 0-3 -- NHI == 0, the shipped split -- waves 4-7 carry no stage role at all: they are the trailing
+            // waves of their SIMDs, i.e. the phase's critical path, and the cursor bookkeeping alone was 25 spill reloads per phase)
+            if ((xp == WINO4S_LO_STEP && !hi) || (NHI > 0 && xp == WINO4S_HI_STEP && hi)) {
 #ifdef WINO4S_TIMELINE
                 __builtin_amdgcn_sched_barrier(0); WINO4S_TL(20); __builtin_amdgcn_sched_barrier(0);
 #endif

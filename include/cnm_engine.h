@@ -49,10 +49,10 @@ extern "C" {
  * launching until the failure has been acknowledged.  cnm_engine_status(clear) returns CNM_OK or CNM_ERR_LAUNCH (a
  * hand-off timed out since the last clear) and, with clear != 0, acknowledges it.  It reads host memory only: synchronise
  * the stream first when the launch in question may still be running.  The sync workspaces need no repair afterwards
- * (flags carry a per-launch generation, csrc/sync_ws.h). */
+ * (a flag counts only if it carries the generation -- the dispatch id -- of the launch that polls it, csrc/sync_ws.h). */
 int cnm_engine_status(int clear);
-/* DEBUG / TEST ONLY: polls before a hand-off gives up (default 2^24, about five seconds); bit 31 injects the fault the
- * bound exists for (publishing workgroups keep their flag down).  Returns the previous value. */
+/* DEBUG / TEST ONLY: polls before a hand-off gives up (0 = the default, 2^24: about five seconds; looked at every 4096 polls);
+ * bit 31 injects the fault the bound exists for (every wait fails at once).  Returns the previous value. */
 unsigned cnm_tune_sync_spin_limit(unsigned polls);
 
 /* Tuning knobs -- DEBUG / A-B switches, process-wide (see "re-entrant" above).  Each returns the previous value.
@@ -209,8 +209,8 @@ int cnm_conv3x3_winograd4_c4_f32(const float* in_a, int Ga_total, int ga0, int G
                                  int N, int H, int W, int relu, void* stream);
 /* The same convolution with a sync workspace for the LDS-staged persistent kernel (conv_winograd4s.hip: 128 output
  * channels x 16 tiles per workgroup, one workgroup per CU).  sync_ws = cnm_wino36_sync_floats() floats: 4096 bytes of flag
- * and generation words -- zero before the first use; a call leaves them in a state every later call accepts, also after
- * a failed hand-off (cnm_engine_status) -- followed by one 128 KB partial-output slot per CU; it must not be shared by
+ * words -- zero before the first use and re-armed by every completed hand-off; a failed one (cnm_engine_status) leaves nothing
+ * a later call could mistake for its own -- followed by one 128 KB partial-output slot per CU; it must not be shared by
  * launches that can run concurrently.  With it the kernel splits the layer's (unit, 16-channel chunk)
  * phases into equal contiguous ranges, one per CU, whatever the unit count: a unit cut by a range boundary is finished by
  * the range that holds its first chunk, which adds the other ranges' partial outputs in range order (write-through
