@@ -23,7 +23,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 # (67 instead of 71 v_readlane reloads per phase, tools/hotloop_proxy.sh; 5.52 vs 5.57 ms over a step's launches, tools/r4_wino_variants.sh).
 # CNM_NO_FILE_FLAGS=1 builds without them (A/B).
 FILE_FLAGS = {"planesweep.hip": ["-fno-slp-vectorize"],
-              "conv_winograd4s.hip": ["-mllvm", "-greedy-regclass-priority-trumps-globalness=1", "-mllvm", "-disable-machine-licm"]}
+              "conv_winograd4s.hip": ["-mllvm", "-greedy-regclass-priority-trumps-globalness=1", "-mllvm", "-disable-machine-licm"],
+              "conv_rows_staged.hip": ["-mllvm", "-greedy-regclass-priority-trumps-globalness=1", "-mllvm", "-disable-machine-licm"]}   # 37 instead of 60 spilled SGPRs
 if os.environ.get("CNM_NO_FILE_FLAGS") == "1":
     FILE_FLAGS = {"planesweep.hip": ["-fno-slp-vectorize"]}
 

@@ -8,6 +8,7 @@ import torch
 from cnmnet_amd import host, ops, synthetic as syn
 from conftest import torch_state
 from oracle import closed_form as cf
+from oracle import ref_arrangement as ra
 
 T = torch.from_numpy
 
@@ -136,3 +137,31 @@ def test_inverse_warp_golden_on_the_host(golden):
         err = np.abs(inverse_warp(T(np.ascontiguousarray(feat)), *a).numpy().astype(np.float64) - want.astype(np.float64))
         # continuous except on the +-1 boundary of the reference's out-of-view test (inverse_warp.py:71-75): a handful of pixels there
         assert float(np.median(err)) < 1e-6 and int((err > 1e-4).sum()) <= 24, (float(np.median(err)), int((err > 1e-4).sum()))
+
+
+def test_config0_depthnet_on_the_host_vs_oracle():
+    """BASELINE configs[0] literally: "DepthNet eval, 1 ref + 1 src, 256x192, 32 depth planes, batch=1 on CPU" -- through the product's host
+    twins, against the CPU oracle with the same weights (the reference itself cannot run 32 planes: depthNet_model.py:194,199,208 hard-code 64;
+    the oracle restatement is proven equal to it at 64).  Inverse depth at all four scales within the north-star's 1e-3."""
+    from cnmnet_amd.depthnet import depthNet
+    img, cams = syn.frames(1, 2, 192, 256, seed=77)
+    net, ref = _load(depthNet(3.0, 32), 21), _load(ra.DepthNetCPU(3.0, 32), 21)
+    a = (T(img[:, 0]), T(img[:, 1]), T(cams[:, 0]), T(cams[:, 1]))
+    with torch.no_grad():
+        outs, feat = net(*a)
+        want, wfeat = ref(*a)
+    for o, w in zip(outs, want):
+        assert o.shape == w.shape and _max(o.numpy(), w.numpy()) < 1e-3
+    assert _max(feat.numpy(), wfeat.numpy()) < 1e-4 * float(wfeat.abs().max())
+
+
+@pytest.mark.parametrize("S", [4, 6])
+def test_multi_source_frame_on_the_host_vs_oracle(S):
+    """a-8 on the host: 4- and 6-source fusion (eval.py:635-663, :885-929) through FramePipeline with CPU modules."""
+    from cnmnet_amd.depthnet import depthNet, DepthRefineNet
+    from cnmnet_amd.pipeline import FramePipeline
+    img, cams = syn.frames(1, S, 32, 64, seed=90 + S)
+    pipe = FramePipeline(_load(depthNet(3.0), 31), _load(DepthRefineNet(32, 3.0), 32), normals=False)
+    out = pipe(T(img), T(cams))
+    disp, prob = ra.frame_forward_multi(_load(ra.DepthNetCPU(3.0), 31), _load(ra.DepthRefineNetCPU(32, 3.0), 32), T(img[0]), T(cams[0]))
+    assert _max(out["disp"].numpy(), disp.numpy()) < 1e-3 and _max(out["prob"].numpy(), prob.numpy()) < 1e-3
