@@ -271,10 +271,20 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(const ConvArgs a) {
         char* A = smem + buf * BUF + wave * TC * 16;
         char* B = smem + buf * BUF + AB + wave * TP * 16;
         const unsigned wsoff = (unsigned)(kt * 8 + wave) * (unsigned)a.Cout_pad * 16u;
+#ifdef GLDS_PROBE
+        const auto wrsrc_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, ((GLDS_PROBE & 2) && kt > 0) ? 0u : a.w_bytes, 0x00020000);
+#define wrsrc wrsrc_p
+#endif
 #pragma unroll
         for (int p = 0; p < NPA; ++p)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr)(A + p * 1024), 16, wlane + p * 1024u, wsoff, 0, 0);
-        const bool s1 = g < a.Gsplit, tapok = ky < a.ks;
+#ifdef GLDS_PROBE
+#undef wrsrc
+#endif
+        bool s1 = g < a.Gsplit, tapok = ky < a.ks;
+#ifdef GLDS_PROBE   // traffic experiment (tools/f16_traffic_probe.sh; wrong results): 1 = pixel pieces fetched for the first tap only, 2 = filter pieces for the first k-step only, 3 = both
+        if ((GLDS_PROBE & 1) && (ky | kx)) tapok = false;
+#endif
         const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s1 ? a.in : a.in2), 0, tapok ? (s1 ? a.in_bytes : a.in2_bytes) : 0u, 0x00020000);
         const unsigned soff = (unsigned)(s1 ? g : g - a.Gsplit) * HW16, tapoff = (unsigned)(ky * a.W + kx) * 16u;
 #pragma unroll
