@@ -20,6 +20,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef CONV_BK
 #define CONV_BK 16            // k-depth of one LDS tile (16 or 32)
 #endif
+#ifndef GLDS_PINGPONG
+#define GLDS_PINGPONG 0       // conv_glds_kernel: two wave groups half a k-step apart (experiment; see the kernel)
+#endif
 #ifndef CONV_MINW
 #define CONV_MINW 1           // __launch_bounds__ min waves per SIMD (register cap)
 #endif
@@ -267,6 +270,9 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(const ConvArgs a) {
     const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
     const unsigned wlane = ((unsigned)c0 + (unsigned)lane) * 16u;
     typedef __attribute__((address_space(3))) void* lds_ptr;
+#ifdef GLDS_PROBE
+    int probe_last = 0;                                                 // DMA instructions of this wave's latest issue()
+#endif
     auto issue = [&](int kt, int buf) {                                 // DMA of k-step kt into buffer buf (this wave: group `wave`)
         char* A = smem + buf * BUF + wave * TC * 16;
         char* B = smem + buf * BUF + AB + wave * TP * 16;
@@ -287,6 +293,11 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(const ConvArgs a) {
 #endif
         const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s1 ? a.in : a.in2), 0, tapok ? (s1 ? a.in_bytes : a.in2_bytes) : 0u, 0x00020000);
         const unsigned soff = (unsigned)(s1 ? g : g - a.Gsplit) * HW16, tapoff = (unsigned)(ky * a.W + kx) * 16u;
+#ifdef GLDS_PROBE
+        probe_last = NPA + NPB;
+        if ((GLDS_PROBE & 4) && (ky | kx)) probe_last = NPA;            // 4: NO pixel-piece instructions past the first tap (the DMA issue count of a halo-staged kernel)
+        if (probe_last == NPA + NPB)
+#endif
 #pragma unroll
         for (int pb = 0; pb < NPB; ++pb) {
             const int iy = iy0[pb] + ky, ix = ix0[pb] + kx;
@@ -345,7 +356,12 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(const ConvArgs a) {
     // k-step stays in flight across the barrier (counted vmcnt: NPW DMA instructions per wave and step, in order)
     constexpr int NPW = NPA + NPB;
     auto wait_dma = [&](bool one_in_flight) {
-        if (NBUF == 3 && one_in_flight) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPW) : "memory");
+        if (NBUF == 3 && one_in_flight) {
+#ifdef GLDS_PROBE
+            if (probe_last == NPA) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPA) : "memory"); else
+#endif
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPW) : "memory");
+        }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // not __syncthreads(): its fence would drain the DMA left in flight
     };
@@ -353,11 +369,66 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(const ConvArgs a) {
     if (NBUF == 3 && a.nk > 1) issue(1, 1);
     wait_dma(a.nk > 1);
     int cur = 0, nxt = NBUF - 1;                                        // buffer of step kt / of the step issued in iteration kt
+#if GLDS_PINGPONG
+    // Two wave groups one segment apart (waves 0-3 / 4-7: one wave of each on every SIMD).  A k-step is 4 / SK sub-steps of SK k16 slices
+    // (16 MFMAs per wave); per sub-step a group has a memory segment (fragment reads of the sub-step, and the step's DMA in the first
+    // one) and a matrix segment (its MFMAs out of registers), and the groups swap roles at every barrier -- every SIMD has one wave in a
+    // matrix segment and one in a memory segment instead of two waves in the same phase.
+    constexpr bool PP = CI * PI >= 4;
+    constexpr int SK = CI * PI >= 8 ? 2 : 4, NS = 4 / SK;
+    f16x8 af[SK][CI], bf[SK][PI];
+    auto load_frags = [&](int buf, int ss) {
+        const char* Ab = smem + buf * BUF + (kh * TC + wc * WTC + frow) * 16;
+        const char* Bb = smem + buf * BUF + AB + (kh * TP + wp * WTP + frow) * 16;
+#pragma unroll
+        for (int s = 0; s < SK; ++s) {
+#pragma unroll
+            for (int i = 0; i < CI; ++i) af[s][i] = *reinterpret_cast<const f16x8*>(Ab + (2 * (ss * SK + s) * TC + 32 * i) * 16);
+#pragma unroll
+            for (int j = 0; j < PI; ++j) bf[s][j] = *reinterpret_cast<const f16x8*>(Bb + (2 * (ss * SK + s) * TP + 32 * j) * 16);
+        }
+    };
+    auto mfma_cluster = [&]() {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < SK; ++s)
+#pragma unroll
+            for (int i = 0; i < CI; ++i)
+#pragma unroll
+                for (int j = 0; j < PI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s][i], bf[s][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    if constexpr (PP) {
+        // both groups run the SAME code; waves 4-7 run it one barrier late (and waves 0-3 pass one more at the end), so the accumulators
+        // live in one set of registers.  Buffer of step kt: last read in the trailing group's memory segment of the last sub-step, whose
+        // barrier is the leading group's last matrix barrier of the step -- only behind it does the leading group issue DMA into that
+        // buffer again.  Both barriers of the last sub-step carry the DMA wait (one of them is the "data of step kt + 1 has landed"
+        // barrier for either group).
+        const bool lead = wave < 4;
+        if (!lead) asm volatile("s_barrier" ::: "memory");
+        for (int kt = 0; kt < a.nk; ++kt) {
+#pragma unroll
+            for (int ss = 0; ss < NS; ++ss) {
+                if (ss == 0 && kt + NBUF - 1 < a.nk) issue(kt + NBUF - 1, nxt);
+                load_frags(cur, ss);
+                if (ss == NS - 1) wait_dma(kt + 2 < a.nk);
+                else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                mfma_cluster();
+                if (ss == NS - 1) wait_dma(kt + 2 < a.nk);
+                else asm volatile("s_barrier" ::: "memory");
+            }
+            cur = cur + 1 == NBUF ? 0 : cur + 1; nxt = nxt + 1 == NBUF ? 0 : nxt + 1;
+        }
+        if (lead) asm volatile("s_barrier" ::: "memory");
+    } else
+#endif
+    {
     for (int kt = 0; kt < a.nk; ++kt) {
         if (kt + NBUF - 1 < a.nk) issue(kt + NBUF - 1, nxt);
         compute(cur);
         wait_dma(kt + 2 < a.nk);
         cur = cur + 1 == NBUF ? 0 : cur + 1; nxt = nxt + 1 == NBUF ? 0 : nxt + 1;
+    }
     }
 
     // ---- epilogue: acc row = cout (r&3)+8*(r>>2)+4*(lane>>5), col = pixel lane&31
