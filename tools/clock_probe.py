@@ -1,5 +1,5 @@
 """Shader clock and power while one kernel family runs back to back (rocm-smi sampled from a child process):
-python tools/clock_probe.py f16|f32|sweep"""
+python tools/clock_probe.py f16|f32|f32s|sweep"""
 import os, subprocess, sys, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,6 +12,10 @@ if kind == "f16":
 elif kind == "f32":
     x = ops.nchw_to_c4(torch.randn(16, 256, 48, 64, device=dev)); up = ops.pack_winograd4(torch.randn(512, 256, 3, 3, device=dev) * 0.02); bp = torch.zeros(512, device=dev)
     fn = lambda: ops.conv3x3_winograd4_c4(x, up, bp, 512, True)
+elif kind == "f32s":                                                     # the staged persistent kernel (round 3+), stream-K ranges
+    x = ops.nchw_to_c4(torch.randn(16, 256, 48, 64, device=dev)); up = ops.pack_winograd4(torch.randn(512, 256, 3, 3, device=dev) * 0.02); bp = torch.zeros(512, device=dev)
+    sync = ops.wino36_sync_workspace(dev)
+    fn = lambda: ops.conv3x3_winograd4_c4(x, up, bp, 512, True, sync=sync)
 else:
     from cnmnet_amd import synthetic as syn
     img, cams = syn.frames(8, 2, 192, 256); img, cams = torch.from_numpy(img).to(dev), torch.from_numpy(cams).to(dev)
