@@ -200,6 +200,11 @@ __device__ unsigned long long sweep_tl[2][64];
 #else
 #define SWEEP_TL(i) do { } while (0)
 #endif
+#ifdef SWEEP_SPAN
+// debug builds (tools/k1_bench.hip -DSWEEP_SPAN): per workgroup, s_memtime when its first tile starts and when its last tile ends (wave 0), tiles done
+__device__ unsigned int sweep_unit_ticks[4096];   // duration of every unit (tile), 100 MHz ticks
+__device__ unsigned long long sweep_span[1024][4];   // s_memrealtime (100 MHz, one base for the device): kernel entry, first tile start, last tile end; tiles
+#endif
 #ifdef SWEEP_STATS
 __device__ unsigned int sweep_stats[4];     // debug builds only: workgroups, staged boxes, octets gathered from global, box texels
 #endif
@@ -291,6 +296,9 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
     int (*const grp)[8] = reinterpret_cast<int (*)[8]>(smem + 3 * SWEEP_CAP + CNM_MAX_PLANES / 4);
     int* const hdr = reinterpret_cast<int*>(smem + 3 * SWEEP_CAP + CNM_MAX_PLANES / 4 + 4 * SWEEP_MAX_OCT);
 
+#ifdef SWEEP_SPAN
+    const unsigned long long span_entry = __builtin_amdgcn_s_memrealtime();
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = a.H, W = a.W, HW = H * W, D = a.D;
     const int noct = (D + 7) >> 3;
@@ -342,8 +350,14 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
 #ifdef SWEEP_TIMELINE
     int tlp = 0;
 #endif
+#ifdef SWEEP_SPAN
+    if (tid == 0 && blockIdx.x < 1024) { sweep_span[blockIdx.x][0] = span_entry; sweep_span[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime(); sweep_span[blockIdx.x][3] = 0; }
+#endif
     for (int parity = 0; unit < nunits; parity ^= 1) {
         SWEEP_TL(0);                                                        // tile start
+#ifdef SWEEP_SPAN
+        const unsigned long long span_u0 = __builtin_amdgcn_s_memrealtime();
+#endif
         // the ticket of the unit after this one travels while wave 0 works out the footprints
         int ticket = unit + (int)gridDim.x;                                 // without a queue: a fixed stride
         if (tid == 0 && a.queue) ticket = (int)gridDim.x + (int)atomicAdd(a.queue, 1u);
@@ -609,6 +623,10 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
             *reinterpret_cast<sw_f16x8*>(optr) = h;
         }
         SWEEP_TL(6);                                                        // tile done
+#ifdef SWEEP_SPAN
+        if (tid == 0 && blockIdx.x < 1024) { sweep_span[blockIdx.x][2] = __builtin_amdgcn_s_memrealtime(); sweep_span[blockIdx.x][3] += 1;
+                                             if (unit < 4096) sweep_unit_ticks[unit] = (unsigned)(sweep_span[blockIdx.x][2] - span_u0); }
+#endif
 #ifdef SWEEP_TIMELINE
         tlp += 8;
 #endif

@@ -115,6 +115,33 @@ int main(int argc, char** argv) {
         printf("   timeline wave %2d tile %d (cycles of the 100 MHz counter x 24 ~ shader cycles): footprints %5lld  barrier %5lld  to staging %5lld  stage first box %5lld  barrier %5lld  rest of the tile (sweeps, further boxes) %6lld  | tile %6lld\n",
                w ? SWEEP_TH - 1 : 0, t, (long long)(q[1] - q[0]), (long long)(q[2] - q[1]), (long long)(q[3] - q[2]), (long long)(q[4] - q[3]), (long long)(q[5] - q[4]), (long long)(q[6] - q[5]), (long long)(q[6] - q[0])); } }
 #endif
+#ifdef SWEEP_SPAN
+    { static unsigned long long sp[1024][4];
+      cnm_planesweep_cat_c4_f32(dref, dsrc, dh, dout, K1_WS, wsn, B, S, H, W, D, 0.1, 3.0, nullptr); hipDeviceSynchronize();   // spans of ONE c4 launch
+      hipMemcpyFromSymbol(sp, HIP_SYMBOL(sweep_span), sizeof(sp));
+      // s_memrealtime: 100 MHz, one base for the device.  Times in us relative to the earliest kernel entry of any workgroup.
+      unsigned long long t0 = ~0ull, t1 = 0; int nwg = 0, hist[16] = {0};
+      for (int i = 0; i < 1024; ++i) if (sp[i][3]) { ++nwg; t0 = std::min(t0, sp[i][0]); t1 = std::max(t1, sp[i][2]); }
+      std::vector<double> ent, st, en, du;
+      for (int i = 0; i < 1024; ++i) if (sp[i][3]) { ent.push_back((sp[i][0] - t0) / 100.0); st.push_back((sp[i][1] - sp[i][0]) / 100.0); en.push_back((t1 - sp[i][2]) / 100.0); du.push_back((sp[i][2] - sp[i][1]) / 100.0); hist[std::min<unsigned long long>(sp[i][3], 15)]++; }
+      std::sort(ent.begin(), ent.end()); std::sort(st.begin(), st.end()); std::sort(en.begin(), en.end()); std::sort(du.begin(), du.end());
+      auto q = [&](std::vector<double>& v, double f) { return v[(size_t)(f * (v.size() - 1))]; };
+      printf("   span (us): %d workgroups, earliest entry -> last tile end %.1f | entry after the earliest: median %.1f p90 %.1f max %.1f | entry -> first tile: median %.1f max %.1f | tiles (busy): min %.1f median %.1f p90 %.1f max %.1f | idle after the last tile until the last workgroup ends: median %.1f p90 %.1f max %.1f | units per workgroup:",
+             nwg, (t1 - t0) / 100.0, q(ent, .5), q(ent, .9), q(ent, 1.), q(st, .5), q(st, 1.), q(du, 0.), q(du, .5), q(du, .9), q(du, 1.), q(en, .5), q(en, .9), q(en, 1.));
+      for (int i = 0; i < 16; ++i) if (hist[i]) printf(" %dx%d", hist[i], i);
+      printf("\n");
+      static unsigned int ut[4096]; hipMemcpyFromSymbol(ut, HIP_SYMBOL(sweep_unit_ticks), sizeof(ut));
+      const int ntx = (W + 63) / 64, nty = (H + SWEEP_TH - 1) / SWEEP_TH, tpp = ntx * nty;
+      if (P * tpp <= 4096) {
+          printf("   tile us by pair (mean min max):");
+          for (int p = 0; p < P; ++p) { double m = 0, lo = 1e9, hi = 0; for (int t = 0; t < tpp; ++t) { const double v = ut[p * tpp + t] / 100.0; m += v; lo = std::min(lo, v); hi = std::max(hi, v); } printf(" %d: %.1f %.1f %.1f |", p, m / tpp, lo, hi); }
+          printf("\n   tile us by tile row (mean over pairs and columns):");
+          for (int ty = 0; ty < nty; ++ty) { double m = 0; for (int p = 0; p < P; ++p) for (int tx = 0; tx < ntx; ++tx) m += ut[p * tpp + ty * ntx + tx] / 100.0; printf(" %.1f", m / (P * ntx)); }
+          printf("\n   tile us by tile column:");
+          for (int tx = 0; tx < ntx; ++tx) { double m = 0; for (int p = 0; p < P; ++p) for (int ty = 0; ty < nty; ++ty) m += ut[p * tpp + ty * ntx + tx] / 100.0; printf(" %.1f", m / (P * nty)); }
+          printf("\n");
+      } }
+#endif
 #ifdef SWEEP_STATS
     { unsigned int st[4]; hipMemcpyFromSymbol(st, HIP_SYMBOL(sweep_stats), 16); const double nl = 5 + iters + 1;   // launches so far
       printf("   per launch: workgroups %.0f, boxes staged %.0f, octets gathered from global %.0f, texels per box %.0f\n", st[0] / nl, st[1] / nl, st[2] / nl, (double)st[3] / (st[1] + 1e-9)); }
