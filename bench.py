@@ -751,6 +751,8 @@ def main():
         out = run(img, cams)
     out, rank_elapsed, step_ms = timed_steps(run, img, cams, a.steps, barrier)   # barrier + synchronize on both sides
     assert bool(torch.isfinite(out["disp"]).all()) and bool(torch.isfinite(out["normal"]).all())
+    from cnmnet_amd import ops as _ops
+    _ops.engine_status(clear=False)             # a stream-K hand-off that timed out inside the timed region (graph replays run no entry point that could refuse): loud, the line is void
     from cnmnet_amd import sharding
     elapsed = sharding.job_elapsed(rank_elapsed, dist, "cpu")                                     # max over ranks (default group: gloo)
     fastest = -sharding.job_elapsed(-rank_elapsed, dist, "cpu")                                   # min over ranks

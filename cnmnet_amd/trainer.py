@@ -187,6 +187,11 @@ def _log_values(logs):
     """dict of scalar tensors -> dict of floats with ONE device-to-host copy."""
     keys = list(logs)
     vals = torch.stack([logs[k].detach().float().reshape(()) for k in keys]).tolist()
+    # the copy above waited for the step: if a stream-K hand-off of a staged kernel timed out inside it, say so here -- in a graph
+    # replay no entry point runs that could refuse, this is the only place the failure surfaces (include/cnm_engine.h, cnm_engine_status)
+    if vals and logs[keys[0]].is_cuda:
+        from . import ops
+        ops.engine_status(clear=False)
     return dict(zip(keys, vals))
 
 

@@ -390,6 +390,43 @@ def test_graphed_train_step_equals_eager(dev):
             assert torch.allclose(be[n].float(), bg[n].float(), rtol=1e-5, atol=1e-6), n
 
 
+def test_graph_replay_reports_a_handoff_timeout(dev):
+    """A stream-K hand-off that times out INSIDE a graph replay: no entry point runs that could refuse the next launch, so the step
+    itself must say so -- the trainer checks cnm_engine_status() where it waits for the step's losses.  Fault injection as in
+    test_gpu_parity.py::test_stream_k_handoff_timeout_is_loud; after the acknowledgement the same graph steps on."""
+    from cnmnet_amd import _lib, ops
+    from cnmnet_amd.depthnet import depthNet, DepthRefineNet
+    from cnmnet_amd.trainer import TrainStepWoNormal, synthetic_training_sample
+    lib = _lib.load()
+    step = TrainStepWoNormal(_load(depthNet(3.0), 71).to(dev), _load(DepthRefineNet(32, 3.0), 72).to(dev), lr=1e-4, graph=True)
+    sd = {k: v.to(dev) for k, v in synthetic_training_sample(1, 192, 256, seed=9).items()}
+    args = (sd["rgbs"], sd["cameras"], sd["disparities"], sd["depths"])
+    first = step(*args)
+    assert np.isfinite(first["loss"]) and lib.cnm_engine_status(0) == 0
+    # the kernels read the spin limit from a device-side control block that a host entry point refreshes at its next launch: one
+    # small eager staged convolution carries a changed knob to the device (a replay runs no host code of the library)
+    x = ops.nchw_to_c4(torch.randn(1, 16, 16, 64, device=dev)); up = ops.pack_winograd4(torch.randn(128, 16, 3, 3, device=dev) * 0.1)
+    bp = torch.zeros(128, device=dev); sync = ops.wino36_sync_workspace(dev)
+    def poke():
+        try:
+            ops.conv3x3_winograd4_c4(x, up, bp, 128, True, sync=sync)
+        except _lib.EngineError:
+            pass
+        torch.cuda.synchronize(); lib.cnm_engine_status(1)
+    old = lib.cnm_tune_sync_spin_limit(0x80000000 | 500)
+    try:
+        poke()
+        assert lib.cnm_engine_status(0) == 0
+        with pytest.raises(_lib.EngineError):
+            step(*args)                                                  # replayed; some staged launch had a cut unit: reported
+        assert lib.cnm_engine_status(0) == -4
+    finally:
+        lib.cnm_tune_sync_spin_limit(old)
+        lib.cnm_engine_status(1)
+        poke()
+    assert np.isfinite(step(*args)["loss"]) and lib.cnm_engine_status(0) == 0
+
+
 @pytest.mark.parametrize("shape,weighted", [((4, 1, 192, 256), False), ((4, 1, 192, 256), True), ((3, 1, 17, 23), True), ((1, 1, 1, 5), False)])
 def test_masked_l1_kernel_vs_torch_expression(dev, shape, weighted):
     """cnm_masked_l1_f32 / _backward_f32 (autograd.MaskedL1) against the torch expression of losses.py:30-73 the trainer used before
