@@ -79,6 +79,50 @@ def event_ms(fn, iters, warm=2):
     return e0.elapsed_time(e1) / iters
 
 
+SCLK_PEAK_MHZ = 2400.0           # the clock the datasheet peaks are quoted at
+
+
+def sustained_clock(fn, launches=20):
+    """Shader clock (MHz) and socket power (W) rocm-smi reports while fn() runs back to back (two samples ~0.4 s apart, after 0.4 s of
+    load): the datasheet peaks assume 2.4 GHz, a matrix-bound kernel at the package power limit does not hold it.  None without rocm-smi."""
+    import re
+    import subprocess
+    import threading
+    got = []
+
+    def sample():
+        time.sleep(0.4)
+        for _ in range(2):
+            try:
+                o = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=15).stdout
+            except Exception:
+                return
+            m, pw = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", o), re.search(r"Power \(W\): ([\d.]+)", o)
+            if m:
+                got.append((float(m.group(1)), float(pw.group(1)) if pw else None))
+
+    th = threading.Thread(target=sample)
+    th.start()
+    while th.is_alive():
+        for _ in range(launches):
+            fn()
+        torch.cuda.synchronize()
+    th.join()
+    if not got:
+        return None
+    return {"sclk_mhz": sum(g[0] for g in got) / len(got), "socket_w": None if got[0][1] is None else sum(g[1] for g in got) / len(got)}
+
+
+def with_clock(roof, clk):
+    """frac against the peak at the clock the package sustained under this kernel, next to the datasheet frac."""
+    if clk:
+        roof["sclk_mhz_sustained"], roof["socket_w"] = clk["sclk_mhz"], clk["socket_w"]
+        roof["frac_at_sustained_clock"] = roof["frac"] * SCLK_PEAK_MHZ / clk["sclk_mhz"]
+    else:
+        roof["sclk_mhz_sustained"] = roof["frac_at_sustained_clock"] = None
+    return roof
+
+
 def conv_tile(cout, m):
     """Mirror of the tile heuristic in cnmnet_amd/csrc/conv_mfma.hip (conv_dispatch)."""
     if cout % 128 == 0 and (cout // 128) * -(-m // 128) >= 512:
@@ -312,6 +356,11 @@ def kernel_rooflines(dev, frames):
                          "algorithmic": sum(v[0] for v in per_kernel.values()) / tot_ms / 1e9, "sum_of_isolated_layer_ms": tot_ms,
                          "sum_note": "sum of the per-layer timings above (every layer alone, caches warm): NOT a share of ms_per_step -- in the step layers run cache-cold and two streams overlap",
                          "per_kernel_ms": {k: round(v[1], 3) for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1][1])}}}
+    if name.startswith("conv_winograd36s"):
+        xs = torch.randn(frames * SRC, 64, H >> 2, W >> 2, 4, device=dev)                          # depthNet conv3.0: 256 -> 512, 3x3, on this kernel
+        us, bs = ops.pack_winograd4(torch.randn(512, 256, 3, 3, device=dev) * 0.02), torch.zeros(512, device=dev)
+        with_clock(conv, sustained_clock(lambda: ops.conv3x3_winograd4_c4(xs, us, bs, 512, True, sync=sync)))
+        del xs, us, bs
     tr = _by_kernel(_LIVE_TRACE, name)
     if tr is not None:
         # the same kernel INSIDE the step (cache-cold inputs, neighbours on the stream), as rocprofv3 --kernel-trace sees it with the refine
@@ -438,12 +487,17 @@ def f16_roofline(dev, frames):
             e[0] += flop; e[1] += ms; e[2] += 1
     name, (flop, ms, n) = max(per.items(), key=lambda kv: kv[1][1])
     tot_f, tot_ms = sum(v[0] for v in per.values()), sum(v[1] for v in per.values())
-    return {"kernel": name, "bound": "mfma", "achieved": flop / ms / 1e9, "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s", "frac": flop / ms / 1e9 / MFMA_F16_PEAK_TF,
+    xs = ops.nchw_to_c8(torch.randn(frames * SRC, 257, H >> 1, W >> 1, device=dev))                # depthNet iconv2: 257 -> 128, 3x3, on the 128 x 256 tile
+    ws, bs = ops.pack_conv_f16(torch.randn(128, 257, 3, 3, device=dev) * 0.02)
+    clk = sustained_clock(lambda: ops.conv2d_c8(xs, ws, bs, 128, 3, 1, True))
+    del xs, ws, bs
+    return with_clock({"kernel": name, "bound": "mfma", "achieved": flop / ms / 1e9, "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s", "frac": flop / ms / 1e9 / MFMA_F16_PEAK_TF,
             "traffic": None, "launches_per_step": n, "avg_launch_ms": ms / n,
             "all_conv": {"achieved": tot_f / tot_ms / 1e9, "frac": tot_f / tot_ms / 1e9 / MFMA_F16_PEAK_TF, "sum_of_isolated_layer_ms": tot_ms,
                          "per_kernel_ms": {k: round(v[1], 3) for k, v in sorted(per.items(), key=lambda kv: -kv[1][1])}},
             "note": "implicit GEMM: executed = direct-convolution flops; every layer alone, %d launches after %d warm-up; the package runs at its "
-                    "1400 W limit under this kernel (profiles/r2_clock_power.txt), so the 2.4 GHz peak is not reachable in a sustained loop" % (IT, WARM)}
+                    "power limit under this kernel: sclk_mhz_sustained / socket_w = rocm-smi while one 128 x 256-tile layer runs back to back; "
+                    "frac_at_sustained_clock = frac x 2400 / sclk" % (IT, WARM)}, clk)
 
 
 def host_cpu_quota():
