@@ -49,7 +49,9 @@ extern "C" {
  * launching until the failure has been acknowledged.  cnm_engine_status(clear) returns CNM_OK or CNM_ERR_LAUNCH (a
  * hand-off timed out since the last clear) and, with clear != 0, acknowledges it.  It reads host memory only: synchronise
  * the stream first when the launch in question may still be running.  The sync workspaces need no repair afterwards
- * (a flag counts only if it carries the generation -- the dispatch id -- of the launch that polls it, csrc/sync_ws.h). */
+ * (a flag counts only if it carries the generation -- the dispatch id -- of the launch that polls it, csrc/sync_ws.h).
+ * Replaying a captured hipGraph runs none of these entry points, so nothing refuses there: call cnm_engine_status() after
+ * synchronising a replay (cnmnet_amd/trainer.py does at the step's loss read-back, bench.py after its timed region). */
 int cnm_engine_status(int clear);
 /* DEBUG / TEST ONLY: polls before a hand-off gives up (0 = the default, 2^24: about five seconds; looked at every 4096 polls);
  * bit 31 injects the fault the bound exists for (every wait fails at once).  Returns the previous value. */
