@@ -112,7 +112,7 @@ int homography(const float* ref_cam, const float* src_cam, float* hmkt, int B, i
 // depthNet_model.py:185-224 (getVolume) + :233 (cat): cost[p,d,y,x] = sum_c | bilinear_zero(src[p,c], u'-0.5, v'-0.5) - ref[b,c,y,x] |,
 // (u',v') = (t0,t1)/(t2+1e-6), t = Hm (x,y,1) z_d + KT in fp32 as the reference computes it; z_d from python doubles (:193-194,209)
 int sweep(const float* ref, const float* src, const float* hmkt, float* out, int B, int S, int H, int W, int D, double idmin, double idmax, int nchw) {
-    CNMH_REQUIRE(ref && src && hmkt && out && B > 0 && S > 0 && H > 0 && W > 0 && D >= 4 && D % 4 == 0, CNM_ERR_BAD_ARG);
+    CNMH_REQUIRE(ref && src && hmkt && out && B > 0 && S > 0 && H > 0 && W > 0 && D >= 2 && D <= 128 && (nchw || D % 4 == 0), CNM_ERR_BAD_ARG);   // as sweep_launch (planesweep.hip): 2 .. CNM_MAX_PLANES planes, the c4 layout in groups of four
     const int HW = H * W, G = D / 4 + 1;
     std::vector<float> zd(D);
     const double step = (idmax - idmin) / (D - 1.0);

@@ -131,6 +131,33 @@ def test_planesweep_vs_oracle_and_layouts(dev, ops, H, W, D, S):
         assert (xs[:, D // 4, :, :, 3] == 0).all()
 
 
+@pytest.mark.parametrize("H,W,D", [(48, 80, 128), (24, 40, 2), (17, 33, 5), (1, 1, 8), (3, 200, 12)])
+def test_planesweep_plane_count_and_size_limits(dev, ops, H, W, D):
+    """The ends of the supported range: 128 planes (CNM_MAX_PLANES: sixteen octets, both footprint passes), 2 planes (the minimum;
+    the reference's linspace needs two), a plane count that is no multiple of 4 (NCHW layout only), a one-pixel image and a
+    3-row strip -- against the closed-form oracle; the c4 layout where it exists equals the NCHW volume bit for bit."""
+    img, cams = syn.frames(2, 1, max(H, 8), max(W, 8), seed=500 + D)
+    img = np.ascontiguousarray(img[..., :H, :W])
+    ref, src = T(img[:, 0]).to(dev), T(img[:, 1:]).to(dev)
+    vol = ops.plane_sweep_volume(ref, src[:, 0], T(cams[:, 0]).to(dev), T(cams[:, 1]).to(dev), 3.0, D).cpu().numpy()
+    want = cf.plane_sweep_volume(img[:, 0], img[:, 1], cams[:, 0], cams[:, 1], 3.0, D)
+    med, q, mx = _stats(vol, want)
+    assert vol.shape == (2, D, H, W) and med < 2e-5 and mx < 1e-3, (med, q, mx)
+    if D % 4 == 0:
+        hmkt = ops.homography_terms(T(cams[:, 0]).to(dev), T(cams[:, 1:]).to(dev))
+        x = ops.plane_sweep_cat_c4(ref, src, hmkt, 3.0, D).cpu()
+        np.testing.assert_array_equal(x[:, :D // 4].permute(0, 1, 4, 2, 3).reshape(2, D, H, W).numpy(), vol)
+
+
+def test_planesweep_plane_count_errors(dev, ops):
+    from cnmnet_amd import _lib
+    img, cams = syn.frames(1, 1, 32, 64, seed=1)
+    a = (T(img[:, 0]).to(dev), T(img[:, 1]).to(dev), T(cams[:, 0]).to(dev), T(cams[:, 1]).to(dev), 3.0)
+    for D in (1, 129, 0):
+        with pytest.raises((_lib.EngineError, ValueError)):
+            ops.plane_sweep_volume(*a, D)
+
+
 def test_planesweep_queue_scratch_and_fallback_paths(dev, ops):
     """The persistent sweep's scratch contract and its slow paths:
     * the tile-queue words are zero again after every call, a reused workspace gives bit-identical results, and two

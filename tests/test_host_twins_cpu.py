@@ -41,6 +41,21 @@ def test_geometry_and_plane_sweep_golden(golden):
     assert _max(v32[0], cf.plane_sweep_volume(g["left"], g["right"], g["left_cam"], g["right_cam"], 3.0, 32)[0]) < 3e-4
 
 
+@pytest.mark.parametrize("H,W,D", [(24, 40, 128), (12, 20, 2), (9, 17, 5), (1, 1, 8)])
+def test_plane_sweep_limits_on_the_host(H, W, D):
+    """The ends of the plane sweep's range on the host twin, as tests/test_gpu_parity.py::test_planesweep_plane_count_and_size_limits
+    has them for the HIP kernel: 128 and 2 planes, a count that is no multiple of 4, a one-pixel image -- vs the closed form."""
+    img, cams = syn.frames(2, 1, max(H, 8), max(W, 8), seed=500 + D)
+    img = np.ascontiguousarray(img[..., :H, :W])
+    vol = ops.plane_sweep_volume(T(img[:, 0]), T(img[:, 1]), T(cams[:, 0]), T(cams[:, 1]), 3.0, D).numpy()
+    want = cf.plane_sweep_volume(img[:, 0], img[:, 1], cams[:, 0], cams[:, 1], 3.0, D)
+    assert vol.shape == (2, D, H, W) and _max(vol, want) < 1e-3
+    from cnmnet_amd import _lib
+    for bad in (1, 129):
+        with pytest.raises(_lib.EngineError):
+            ops.plane_sweep_volume(T(img[:, 0]), T(img[:, 1]), T(cams[:, 0]), T(cams[:, 1]), 3.0, bad)
+
+
 @pytest.mark.parametrize("cin,cin2,cout,k,stride,rot,N,H,W", [(7, 0, 8, 3, 1, 0, 2, 9, 13), (67, 0, 16, 7, 1, 3, 1, 12, 20), (12, 9, 20, 5, 2, 0, 2, 11, 14),
                                                                (16, 0, 8, 3, 2, 0, 1, 8, 8), (8, 5, 12, 7, 2, 0, 1, 10, 17)])
 def test_conv_bn_relu_vs_torch(cin, cin2, cout, k, stride, rot, N, H, W):
