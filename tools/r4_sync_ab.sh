@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 4 A/B (GPU box): the staged kernels with the round-3 hand-off protocol (0 / 1 flags re-armed by the consumer, sources under
-# tools/ab_r3/, not committed) against the generation protocol of this round, same box, alternating builds: sum line of the probe.
+# tools/ab_r3/, not committed: `mkdir tools/ab_r3 && for f in conv_winograd4s conv_rows_staged; do git show f5a2a92:cnmnet_amd/csrc/$f.hip > tools/ab_r3/$f.hip; done`) against the generation protocol of this round, same box, alternating builds: sum line of the probe.
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 mkdir -p /tmp/ab_new && cp cnmnet_amd/csrc/conv_winograd4s.hip cnmnet_amd/csrc/conv_rows_staged.hip /tmp/ab_new/
