@@ -50,16 +50,28 @@ int host_threads() {
     return n;
 }
 
-// fn(i) for i in [0, n): work items are handed out one at a time (they are rows or row blocks: coarse enough)
+// fn(i) for i in [0, n): work items are handed out one at a time (they are rows or row blocks: coarse enough).  Nothing may leave the
+// library as a C++ exception (include/cnm_engine.h: "never throws"): a worker that throws (std::bad_alloc in a row buffer) or a thread
+// that cannot be created is recorded, the remaining items run on the threads that exist, and the entry point returns CNM_ERR_LAUNCH.
+thread_local bool g_pf_failed = false;
+int pf_result() { const bool f = g_pf_failed; g_pf_failed = false; return f ? CNM_ERR_LAUNCH : CNM_OK; }
 void parallel_for(long long n, const std::function<void(long long)>& fn) {
     const int nt = (int)std::min<long long>(host_threads(), n);
-    if (nt <= 1) { for (long long i = 0; i < n; ++i) fn(i); return; }
     std::atomic<long long> next{0};
+    std::atomic<bool> failed{false};
+    auto work = [&] {
+        for (long long i; (i = next.fetch_add(1)) < n;) {
+            try { fn(i); } catch (...) { failed.store(true); }
+        }
+    };
     std::vector<std::thread> th;
-    th.reserve(nt);
-    for (int t = 0; t < nt; ++t)
-        th.emplace_back([&] { for (long long i; (i = next.fetch_add(1)) < n;) fn(i); });
+    try {
+        th.reserve(nt > 1 ? nt - 1 : 0);
+        for (int t = 1; t < nt; ++t) th.emplace_back(work);
+    } catch (...) { failed.store(true); }
+    work();                                                              // the calling thread is one of the workers
     for (auto& t : th) t.join();
+    if (failed.load()) g_pf_failed = true;
 }
 
 bool inv_nxn(double* A, double* Ai, int n) {                             // Gauss-Jordan, partial pivoting (as K0 on the device)
@@ -106,7 +118,7 @@ int homography(const float* ref_cam, const float* src_cam, float* hmkt, int B, i
             hmkt[(size_t)p * 12 + 9 + i] = (float)s;
         }
     }
-    return CNM_OK;
+    return pf_result();
 }
 
 // depthNet_model.py:185-224 (getVolume) + :233 (cat): cost[p,d,y,x] = sum_c | bilinear_zero(src[p,c], u'-0.5, v'-0.5) - ref[b,c,y,x] |,
@@ -154,7 +166,7 @@ int sweep(const float* ref, const float* src, const float* hmkt, float* out, int
             if (!nchw) { float* o = out + c4off(p, G, D / 4, HW, y * W + x); o[0] = rr; o[1] = rg; o[2] = rb; o[3] = 0.f; }
         }
     });
-    return CNM_OK;
+    return pf_result();
 }
 
 // Conv2d(k, stride, padding = k/2, BatchNorm folded) + ReLU on c4 views (depthNet_model.py:19-79).  w [Cout][k*k][4*(Ga+Gb)].
@@ -194,7 +206,7 @@ int conv(const float* in_a, int Ga_total, int ga0, int Ga, const float* in_b, in
             for (int x = 0; x < Wo; ++x) o[4 * x] = relu ? std::max(a[x], 0.f) : a[x];
         }
     });
-    return CNM_OK;
+    return pf_result();
 }
 
 // nn.Upsample(scale_factor=2, mode='bilinear'), align_corners=False (depthNet_model.py:94,105)
@@ -220,7 +232,7 @@ int upsample2x(const float* in, int Gin_total, int gin0, float* out, int Gout_to
             }
         }
     });
-    return CNM_OK;
+    return pf_result();
 }
 
 // depth_layer + scale + F.upsample(nearest) (depthNet_model.py:82-84,246-261,351,365)
@@ -257,7 +269,7 @@ int head(const float* in, int Gin_total, int gin0, int C, const float* w_head, c
                 }
         }
     });
-    return CNM_OK;
+    return pf_result();
 }
 
 // depthNet_model.py:332-333 (channels rotated: 64 features first): x = [f1 + f2, (id1, id2, |id1 - id2|, 0)]
@@ -275,7 +287,7 @@ int assemble(const float* id1, const float* id2, long long ids, const float* f1,
             for (int p = 0; p < HW; ++p) { const float a = id1[(size_t)n * ids + p], b = id2[(size_t)n * ids + p]; o[4 * p] = a; o[4 * p + 1] = b; o[4 * p + 2] = std::fabs(a - b); o[4 * p + 3] = 0.f; }
         }
     });
-    return CNM_OK;
+    return pf_result();
 }
 
 // eval.py:656-663 (S = 4), :917-929 (S = 6): even sources -> side 1, odd -> side 2, averaged, then assembled
@@ -301,7 +313,7 @@ int assemble_multi(const float* idp, const float* f, float* x, int B, int S, int
             }
         }
     });
-    return CNM_OK;
+    return pf_result();
 }
 
 }  // namespace cnmh
@@ -338,13 +350,13 @@ int cnm_pack_conv_bn_cpu(const float* w_oihw, const float* bn_gamma, const float
         }
         b_packed[co] = bn_gamma ? (float)((double)bn_beta[co] - (double)bn_mean[co] * sc) : (bias ? bias[co] : 0.f);
     }
-    return CNM_OK;
+    return pf_result();
 }
 
 int cnm_pack_head_cpu(const float* w_oihw, int C, float* w_head) {
     CNMH_REQUIRE(w_oihw && w_head && C > 0 && C % 4 == 0, CNM_ERR_BAD_ARG);
     for (int t = 0; t < 9; ++t) for (int c = 0; c < C; ++c) w_head[t * C + c] = w_oihw[c * 9 + t];
-    return CNM_OK;
+    return pf_result();
 }
 
 int cnm_conv2d_cat2_c4_cpu(const float* in_a, int Ga_total, int ga0, int Ga, const float* in_b, int Gb_total, int gb0, int Gb,
@@ -374,7 +386,7 @@ int cnm_nchw_to_c4_cpu(const float* nchw, float* c4, int G_total, int g0, int N,
             for (int p = 0; p < HW; ++p) o[4 * p + j] = s ? s[p] : 0.f;
         }
     });
-    return CNM_OK;
+    return pf_result();
 }
 
 int cnm_c4_to_nchw_cpu(const float* c4, int G_total, int g0, float* nchw, int N, int C, int H, int W) {
@@ -386,7 +398,7 @@ int cnm_c4_to_nchw_cpu(const float* c4, int G_total, int g0, float* nchw, int N,
         float* o = nchw + ((size_t)n * C + c) * HW;
         for (int p = 0; p < HW; ++p) o[p] = s[4 * p];
     });
-    return CNM_OK;
+    return pf_result();
 }
 
 int cnm_intrinsics_inverse_cpu(const float* cam, long long cam_stride, float* K_inv, int B) {
@@ -397,7 +409,7 @@ int cnm_intrinsics_inverse_cpu(const float* cam, long long cam_stride, float* K_
         inv_nxn(K, Ki, 3);
         for (int i = 0; i < 9; ++i) K_inv[(size_t)b * 9 + i] = (float)Ki[i];
     }
-    return CNM_OK;
+    return pf_result();
 }
 
 // Depth2normal.forward without the plane branch (depth_util.py:149-203): window sums and solve in double
@@ -445,7 +457,7 @@ int cnm_depth2normal_cpu(const float* depth, const float* K_inv, float* normal, 
             normal[o] = (float)(gx * inv); normal[o + HW] = (float)(gy * inv); normal[o + 2 * (size_t)HW] = (float)(gz * inv);
         }
     });
-    return CNM_OK;
+    return pf_result();
 }
 
 // inverse_warp / pixel2cam / cam2pixel, padding_mode = 'zeros' (inverse_warp.py:27-118)
@@ -485,7 +497,7 @@ int cnm_inverse_warp_cpu(const float* feat, const float* depth, const float* pos
             }
         }
     });
-    return CNM_OK;
+    return pf_result();
 }
 
 }  // extern "C"
