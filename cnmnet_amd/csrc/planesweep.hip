@@ -200,6 +200,15 @@ __device__ unsigned long long sweep_tl[2][64];
 #else
 #define SWEEP_TL(i) do { } while (0)
 #endif
+#ifdef SWEEP_EMU
+// experiment builds (tools/k1_bench.hip -DSWEEP_EMU -DSWEEP_SPAN): what a footprint PRE-PASS and a cost-ordered queue would buy, emulated -- a
+// recording launch stores every tile's box groups; replaying launches read them back instead of working them out (mode bit 0) and / or
+// draw the tiles in a given order, e.g. longest first from the recorded durations (mode bit 1).  Whole tiles only.
+__device__ int sweep_emu_grp[4096][SWEEP_MAX_OCT][8];
+__device__ int sweep_emu_level[4096];
+__device__ int sweep_emu_order[4096];
+__device__ int sweep_emu_mode;
+#endif
 #ifdef SWEEP_SPAN
 // debug builds (tools/k1_bench.hip -DSWEEP_SPAN): per workgroup, s_memtime when its first tile starts and when its last tile ends (wave 0), tiles done
 __device__ unsigned int sweep_unit_ticks[4096];   // duration of every unit (tile), 100 MHz ticks
@@ -315,7 +324,11 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
     const int nh = (noct >= 2 && ntiles % (int)gridDim.x != 0) ? min(ntiles - nq, (int)gridDim.x * SWEEP_TAIL_HALVES / 4) : 0;
     const int nfull = ntiles - nh - nq, nunits = nfull + 2 * nh + 4 * nq;
     const float inv_tpp = 1.0f / (float)tiles_per_pair, inv_ntx = 1.0f / (float)ntx;
+#if defined(SWEEP_EMU) || defined(SWEEP_SPAN)
+    struct Unit { int p, tx0, ty0, obeg, ocnt, tile; };
+#else
     struct Unit { int p, tx0, ty0, obeg, ocnt; };
+#endif
     auto decode = [&](int u) {                                               // unit -> pair, tile origin, octet range
         Unit q; q.obeg = 0; q.ocnt = noct;
         int t = u;
@@ -326,6 +339,12 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
             q.obeg = part * noct / parts;
             q.ocnt = (part + 1) * noct / parts - q.obeg;
         }
+#ifdef SWEEP_EMU
+        if ((sweep_emu_mode & 2) && t < 4096) t = sweep_emu_order[t];
+#endif
+#if defined(SWEEP_EMU) || defined(SWEEP_SPAN)
+        q.tile = t;
+#endif
         // fp32 reciprocals (exact for t < 2^20, checked by the launcher); back to SGPRs so the rest is scalar arithmetic
         q.p = __builtin_amdgcn_readfirstlane((int)(((float)t + 0.5f) * inv_tpp));
         const int rem = t - q.p * tiles_per_pair, tyi = __builtin_amdgcn_readfirstlane((int)(((float)rem + 0.5f) * inv_ntx));
@@ -357,6 +376,7 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
         SWEEP_TL(0);                                                        // tile start
 #ifdef SWEEP_SPAN
         const unsigned long long span_u0 = __builtin_amdgcn_s_memrealtime();
+        const int cur_tile_span = cur.tile;
 #endif
         // the ticket of the unit after this one travels while wave 0 works out the footprints
         int ticket = unit + (int)gridDim.x;                                 // without a queue: a fixed stride
@@ -385,7 +405,17 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
         // plane of the unit's octet 8q + j; an 8-lane min / max (DPP) gives the octet's box in all eight lanes.  Merging
         // with the lanes 8, 16, 32 away and with the other pass gives the boxes of every aligned run of 2, 4, 8, 16
         // octets; the longest run whose boxes all fit the LDS budget wins.  Results go to LDS (groups, level, ticket).
+#ifdef SWEEP_EMU
+        const bool emu_replay = (sweep_emu_mode & 1) && cur.tile < 4096;
+        if (tid < 64 && emu_replay) {                                        // the groups come from the table
+            const int lv = sweep_emu_level[cur.tile];
+            for (int i = lane; i < SWEEP_MAX_OCT * 8; i += 64) grp[parity * SWEEP_MAX_OCT + (i >> 3)][i & 7] = sweep_emu_grp[cur.tile][i >> 3][i & 7];
+            if (lane == 0) { hdr[2 * parity] = lv; hdr[2 * parity + 1] = ticket; }
+        }
+        if (tid < 64 && !emu_replay) {
+#else
         if (tid < 64) {
+#endif
             const int cxi = (lane & 1) ? min(tx0 + SWEEP_TW - 1, W - 1) : tx0;
             const int cyi = (lane & 2) ? min(ty0 + SWEEP_TH - 1, H - 1) : ty0;
             const float cxf = (float)cxi, cyf = (float)cyi;
@@ -477,8 +507,14 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
                     int* gq = grp[parity * SWEEP_MAX_OCT + (oct >> level)];
                     gq[0] = gx0[q]; gq[1] = gy0[q]; gq[2] = gx1[q] - gx0[q] + 1; gq[3] = gy1[q] - gy0[q] + 1;
                     gq[4] = gst[q] && parallax_ok; gq[5] = gcl[q];
+#ifdef SWEEP_EMU
+                    if (cur.tile < 4096) for (int i = 0; i < 6; ++i) sweep_emu_grp[cur.tile][oct >> level][i] = gq[i];
+#endif
                 }
             }
+#ifdef SWEEP_EMU
+            if (lane == 0 && cur.tile < 4096) sweep_emu_level[cur.tile] = level;
+#endif
             if (lane == 0) { hdr[2 * parity] = level; hdr[2 * parity + 1] = ticket; }
         }
         SWEEP_TL(1);                                                        // footprints done (wave 0) / waiting (others)
@@ -625,7 +661,7 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
         SWEEP_TL(6);                                                        // tile done
 #ifdef SWEEP_SPAN
         if (tid == 0 && blockIdx.x < 1024) { sweep_span[blockIdx.x][2] = __builtin_amdgcn_s_memrealtime(); sweep_span[blockIdx.x][3] += 1;
-                                             if (unit < 4096) sweep_unit_ticks[unit] = (unsigned)(sweep_span[blockIdx.x][2] - span_u0); }
+                                             if (cur_tile_span < 4096) sweep_unit_ticks[cur_tile_span] = (unsigned)(sweep_span[blockIdx.x][2] - span_u0); }
 #endif
 #ifdef SWEEP_TIMELINE
         tlp += 8;

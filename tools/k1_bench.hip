@@ -142,6 +142,34 @@ int main(int argc, char** argv) {
           printf("\n");
       } }
 #endif
+#ifdef SWEEP_EMU
+    {   // what a footprint pre-pass and a cost-ordered queue would buy (emulated; see planesweep.hip): the launches above recorded the groups
+        const int ntx = (W + 63) / 64, nty = (H + SWEEP_TH - 1) / SWEEP_TH, ntl = P * ntx * nty;
+        if (ntl <= 4096) {
+            static unsigned int ut[4096]; std::vector<int> order(4096);
+            auto run = [&](int mode, const char* what) {
+                hipMemcpyToSymbol(HIP_SYMBOL(sweep_emu_mode), &mode, sizeof(int));
+                for (int i = 0; i < 5; ++i) cnm_planesweep_cat_c4_f32(dref, dsrc, dh, dout, K1_WS, wsn, B, S, H, W, D, 0.1, 3.0, nullptr);
+                hipEventRecord(e0);
+                for (int i = 0; i < iters; ++i) cnm_planesweep_cat_c4_f32(dref, dsrc, dh, dout, K1_WS, wsn, B, S, H, W, D, 0.1, 3.0, nullptr);
+                hipEventRecord(e1); hipEventSynchronize(e1);
+                float t; hipEventElapsedTime(&t, e0, e1);
+                std::vector<float> o2(outn); hipMemcpy(o2.data(), dout, outn * 4, hipMemcpyDeviceToHost);
+                size_t bad = 0; for (size_t i = 0; i < outn; ++i) if (!(o2[i] == out[i])) ++bad;
+                printf("   emu %-58s %6.1f us   (output differs from the plain launch in %zu values)\n", what, t / iters * 1e3, bad);
+            };
+            run(0, "plain (footprints worked out per tile, queue in tile order)");
+            hipMemcpyFromSymbol(ut, HIP_SYMBOL(sweep_unit_ticks), sizeof(ut));
+            for (int i = 0; i < 4096; ++i) order[i] = i;
+            std::stable_sort(order.begin(), order.begin() + ntl, [&](int a, int b) { return ut[a] > ut[b]; });
+            hipMemcpyToSymbol(HIP_SYMBOL(sweep_emu_order), order.data(), 4096 * sizeof(int));
+            run(1, "groups read from a table (a pre-pass would have written it)");
+            run(2, "footprints per tile, tiles drawn longest first (recorded durations)");
+            run(3, "table + longest first");
+            run(0, "plain again");
+        }
+    }
+#endif
 #ifdef SWEEP_STATS
     { unsigned int st[4]; hipMemcpyFromSymbol(st, HIP_SYMBOL(sweep_stats), 16); const double nl = 5 + iters + 1;   // launches so far
       printf("   per launch: workgroups %.0f, boxes staged %.0f, octets gathered from global %.0f, texels per box %.0f\n", st[0] / nl, st[1] / nl, st[2] / nl, (double)st[3] / (st[1] + 1e-9)); }
