@@ -555,6 +555,9 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
             }
 #endif
             if (staged) {
+#ifdef SWEEP_EMU
+              if (!(sweep_emu_mode & 4)) {                                       // mode bit 2: the box is NOT staged (timing of a launch whose staging is free; wrong output)
+#endif
                 // ---- stage the box: rh rows of rw texels + one halo column, as items i = r (rw + 1) + c dealt 63 per
                 // wave pass (lane 63 repeats the next pass' first item: it only feeds lane 62).  A lane loads column c of
                 // image rows y and y + 1, column c + 1 comes from the next lane.  All loads of the box are issued first.
@@ -603,6 +606,9 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
                     }
                 }
                 if (g == 0) SWEEP_TL(4);                                         // first box: texels written
+#ifdef SWEEP_EMU
+              }
+#endif
                 __syncthreads();
                 if (g == 0) SWEEP_TL(5);
             } else {                                                             // whole zero-extended image as the "box"

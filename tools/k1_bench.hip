@@ -166,6 +166,8 @@ int main(int argc, char** argv) {
             run(1, "groups read from a table (a pre-pass would have written it)");
             run(2, "footprints per tile, tiles drawn longest first (recorded durations)");
             run(3, "table + longest first");
+            run(4, "box staging skipped (wrong output): a launch whose staging is free");
+            run(5, "table + staging skipped (wrong output)");
             run(0, "plain again");
         }
     }
