@@ -1086,7 +1086,7 @@ def test_config4_full_size_properties(dev):
     assert bool((((n - 1).abs() < 1e-4) | (n < 1e-6)).all())
 
 
-@pytest.mark.parametrize("B,H,W", [(3, 96, 160), (2, 128, 96), (1, 64, 224), (5, 160, 64), (16, 96, 128)])
+@pytest.mark.parametrize("B,H,W", [(3, 96, 160), (2, 128, 96), (1, 64, 224), (5, 160, 64), (16, 96, 128), (2, 32, 32), (1, 32, 96)])   # the last two: the smallest legal image (1 x 1 feature maps at 1/32)
 def test_frame_other_sizes_vs_oracle(dev, B, H, W):
     """The frame pipeline at image sizes and batch counts other than the benchmark's (different tile blocks, stream-K ranges,
     stride-2 forms accepted or refused per layer, fused / unfused up_conv layers, head kernels) against the CPU oracle on one
