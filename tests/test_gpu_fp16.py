@@ -135,7 +135,7 @@ def test_frame_f16_vs_fp32_oracle(dev, golden):
     assert torch.isfinite(out["normal"]).all()
 
 
-@pytest.mark.parametrize("B,S,H,W,D", [(2, 2, 96, 160, 32), (1, 2, 224, 352, 64)])
+@pytest.mark.parametrize("B,S,H,W,D", [(2, 2, 96, 160, 32), (1, 2, 224, 352, 64), (1, 2, 32, 32, 64), (3, 4, 32, 64, 32)])   # the last two: the smallest legal images
 def test_f16_engine_other_sizes_vs_f32_engine(dev, B, S, H, W, D):
     """fp16 frame pipeline against the fp32 one at sizes whose pyramid levels have odd / non-power-of-two widths (352 ->
     176, 88, 44, 22, 11) and another plane count: the LDS-DMA kernel's pixel tails and tile choices."""
