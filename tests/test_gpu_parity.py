@@ -1168,6 +1168,23 @@ def test_error_behaviour(dev):
         inverse_warp(x, x[:, 0], torch.zeros(1, 4, 4, device=dev), cam[:, 1, :3, :3], cam[:, 1, :3, :3])
 
 
+def test_views_beyond_32bit_offsets_are_refused(dev):
+    """The convolution kernels address a view through 32-bit byte offsets: a call whose view would pass 4 GB is refused with
+    CNM_ERR_BAD_ARG before anything is launched or read (depthNet.forward_pairs splits its batch so that this never happens,
+    tests/test_gpu_baseline_sizes.py) -- argument check only, the buffers here are tiny."""
+    from cnmnet_amd import _lib
+    lib = _lib.load()
+    buf = torch.zeros(1 << 20, device=dev)                                # 4 MB: holds the packed filter (0.6 MB) and the small call's views
+    st = torch.cuda.current_stream().cuda_stream
+    N, G, H, W = 70000, 32, 64, 64                                       # 147 GB of input view
+    assert N * G * H * W * 16 > 2**32
+    rc = lib.cnm_conv2d_c4_f32(buf.data_ptr(), G, 0, G, buf.data_ptr(), 32, 0, 128, buf.data_ptr(), buf.data_ptr(), N, H, W, 3, 1, 1, st)
+    assert rc == -1
+    rc = lib.cnm_conv2d_c4_f32(buf.data_ptr(), G, 0, G, buf.data_ptr(), 32, 0, 128, buf.data_ptr(), buf.data_ptr(), 1, 8, 8, 3, 1, 1, st)
+    assert rc == 0                                                       # the same call at a size the buffers hold
+    torch.cuda.synchronize()
+
+
 def test_winograd_api_argument_errors(dev):
     """The Winograd entry points reject what they cannot run (negative status, nothing launched)."""
     from cnmnet_amd import _lib
