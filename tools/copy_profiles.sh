@@ -13,6 +13,7 @@ cp $S/pmc_traffic.json $D/r4_pmc_traffic.json
 cp $S/train_bench.txt $D/r4_train_bench.txt
 cp $S/train_kernel_stats.csv $D/r4_train_kernel_stats.csv
 [ -f gpurun_out/f16_kernel_stats.csv ] && cp gpurun_out/f16_kernel_stats.csv $D/r4_f16_kernel_stats.csv
+[ -f $S/config4_kernel_stats.csv ] && cp $S/config4_kernel_stats.csv $D/r4_config4_kernel_stats.csv
 [ -f $S/wgrad_sweep.txt ] && cp $S/wgrad_sweep.txt $D/r4_wgrad_sweep.txt
 [ -f $S/f16_conv_probe.txt ] && cp $S/f16_conv_probe.txt $D/r4_f16_conv_probe.txt
 git status --short $D
