@@ -84,10 +84,13 @@ SCLK_PEAK_MHZ = 2400.0           # the clock the datasheet peaks are quoted at
 
 def sustained_clock(fn, launches=20):
     """Shader clock (MHz) and socket power (W) rocm-smi reports while fn() runs back to back (two samples ~0.4 s apart, after 0.4 s of
-    load): the datasheet peaks assume 2.4 GHz, a matrix-bound kernel at the package power limit does not hold it.  None without rocm-smi."""
+    load): the datasheet peaks assume 2.4 GHz, a matrix-bound kernel at the package power limit does not hold it.  None without rocm-smi
+    and when the process runs under rocprofv3 (the kernel summaries committed under profiles/ stay those of the step and the layer timings)."""
     import re
     import subprocess
     import threading
+    if "rocprofiler" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None            # under rocprofv3 the second of back-to-back launches that feeds rocm-smi would swamp the per-kernel statistics of the run
     got = []
 
     def sample():
