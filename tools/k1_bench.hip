@@ -74,6 +74,16 @@ int main(int argc, char** argv) {
     for (int i = 0; i < iters; ++i) cnm_planesweep_cat_c4_f32(dref, dsrc, dh, dout, K1_WS, wsn, B, S, H, W, D, 0.1, 3.0, nullptr);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= iters;
+    float iso_med = 0.f;
+    {   // launches ONE AT A TIME (events around each, the device drained in between): what a launch costs between other kernels of a step
+        std::vector<float> t;
+        for (int i = 0; i < 25; ++i) {
+            hipDeviceSynchronize();
+            hipEventRecord(e0); cnm_planesweep_cat_c4_f32(dref, dsrc, dh, dout, K1_WS, wsn, B, S, H, W, D, 0.1, 3.0, nullptr); hipEventRecord(e1); hipEventSynchronize(e1);
+            float v; hipEventElapsedTime(&v, e0, e1); t.push_back(v);
+        }
+        std::sort(t.begin(), t.end()); iso_med = t[t.size() / 2];
+    }
     cnm_planesweep_volume_nchw_f32(dref, dsrc, dh, dvol, dws, wsn, B, S, H, W, D, 0.1, 3.0, nullptr);
     std::vector<float> out(outn), vol(voln);
     hipMemcpy(out.data(), dout, outn * 4, hipMemcpyDeviceToHost); hipMemcpy(vol.data(), dvol, voln * 4, hipMemcpyDeviceToHost);
@@ -172,6 +182,22 @@ int main(int argc, char** argv) {
         }
     }
 #endif
+#ifdef SWEEP_TRACE
+    {   // one traced launch -> gpurun_out/k1_trace.txt: workgroup unit hw_id xcc t0 t_foot(ticks) t_end   (100 MHz ticks)
+        unsigned int zero = 0; hipMemcpyToSymbol(HIP_SYMBOL(sweep_trace_n), &zero, 4);
+        cnm_planesweep_cat_c4_f32(dref, dsrc, dh, dout, K1_WS, wsn, B, S, H, W, D, 0.1, 3.0, nullptr); hipDeviceSynchronize();
+        static unsigned long long tr[8192][4]; unsigned int n = 0;
+        hipMemcpyFromSymbol(tr, HIP_SYMBOL(sweep_trace), sizeof(tr)); hipMemcpyFromSymbol(&n, HIP_SYMBOL(sweep_trace_n), 4);
+        FILE* f = fopen("gpurun_out/k1_trace.txt", "w");
+        if (f) { for (unsigned i = 0; i < n && i < 8192; ++i) fprintf(f, "%u %u %u %u %llu %llu %llu\n", (unsigned)(tr[i][0] >> 32), (unsigned)tr[i][0], (unsigned)(tr[i][1] >> 32), (unsigned)tr[i][1], tr[i][2], tr[i][3] & 0xFFFFF, tr[i][3] >> 20); fclose(f); }
+        printf("   trace: %u units -> gpurun_out/k1_trace.txt\n", n);
+        static unsigned long long tf[1024][6]; hipMemcpyFromSymbol(tf, HIP_SYMBOL(sweep_trace_first), sizeof(tf));
+        unsigned long long e0 = ~0ull; for (int i = 0; i < 512; ++i) if (tf[i][0]) e0 = std::min(e0, tf[i][0]);
+        for (int st = 1; st < 6; ++st) { std::vector<double> v; for (int i = 0; i < 512; ++i) if (tf[i][0]) v.push_back((double)(long long)(tf[i][st] - tf[i][st - 1]) / 100.0); std::sort(v.begin(), v.end());
+            static const char* nm[] = {"", "entry -> loop top", "-> footprints done (wave 0)", "-> barrier passed", "-> first box staged", "-> first octet done"};
+            if (!v.empty()) printf("   first unit, %-30s min %.2f median %.2f max %.2f us\n", nm[st], v.front(), v[v.size() / 2], v.back()); }
+    }
+#endif
 #ifdef SWEEP_STATS
     { unsigned int st[4]; hipMemcpyFromSymbol(st, HIP_SYMBOL(sweep_stats), 16); const double nl = 5 + iters + 1;   // launches so far
       printf("   per launch: workgroups %.0f, boxes staged %.0f, octets gathered from global %.0f, texels per box %.0f\n", st[0] / nl, st[1] / nl, st[2] / nl, (double)st[3] / (st[1] + 1e-9)); }
@@ -184,6 +210,7 @@ int main(int argc, char** argv) {
         float t; hipEventElapsedTime(&t, e0, e1); printf("   (pure c4 store stream, same output: %.1f us = %.0f GB/s)\n", t / iters * 1e3, (double)P * (D + 4) * HW * 4 / (t / iters) / 1e6);
     }
     const double bytes = (double)B * 3 * HW * 4 + (double)P * 3 * HW * 4 + (double)P * (D + 3) * HW * 4;
-    printf("%-44s %8.1f us  %7.1f GB/s (%.1f%% of 8 TB/s)  blocks/CU %d  checksum %.6e\n", tag, ms * 1e3, bytes / ms / 1e6, bytes / ms / 1e6 / 80.0, nb, cs);
+    printf("%-44s %8.1f us  %7.1f GB/s (%.1f%% of 8 TB/s)  | one at a time: %.1f us (%.1f%%)  blocks/CU %d  checksum %.6e\n", tag, ms * 1e3, bytes / ms / 1e6, bytes / ms / 1e6 / 80.0,
+           iso_med * 1e3, bytes / iso_med / 1e6 / 80.0, nb, cs);
     return 0;
 }
