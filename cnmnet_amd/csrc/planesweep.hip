@@ -29,6 +29,8 @@
 // HBM-bound by design: algorithmic bytes per pair = 3HW*4 (ref) + 3HW*4 (src) + D*HW*4 (volume)
 // (+ 4HW*4 for the ref group when emitting the concatenated conv input).
 #include "cnm_common.h"
+#include <algorithm>
+#include <cstddef>
 
 // ------------------------------------------------------------------ K0
 __device__ static bool inv_nxn(double* A, double* Ai, int n) {   // Gauss-Jordan, partial pivoting
@@ -112,10 +114,10 @@ extern "C" int cnm_idepth_range_host(double idepth_scale, double* idepth_min, do
 // The queue ends with small units (guided self-scheduling): the last tiles are handed out as 2, 4, 8 partial sweeps of
 // their plane range.  Zone sizes in SIXTEENTHS of the grid size (tiles, not units).
 #ifndef SWEEP_TAIL_HALVES
-#define SWEEP_TAIL_HALVES 8
+#define SWEEP_TAIL_HALVES 6
 #endif
 #ifndef SWEEP_TAIL_QUARTERS
-#define SWEEP_TAIL_QUARTERS 0
+#define SWEEP_TAIL_QUARTERS 2
 #endif
 #ifndef SWEEP_TAIL_EIGHTHS
 #define SWEEP_TAIL_EIGHTHS 0
@@ -123,8 +125,11 @@ extern "C" int cnm_idepth_range_host(double idepth_scale, double* idepth_min, do
 #ifndef SWEEP_AHEAD
 #define SWEEP_AHEAD 1               // 1: two samples' texels in registers (24), reads one sample ahead of the blend; 0: one sample's (12)
 #endif
+#ifndef SWEEP_ROLL_QUADS
+#define SWEEP_ROLL_QUADS 0          // 1: the two quads of an octet as a loop (half the code of the sample loops; not for the fp16 layout, which packs eight planes)
+#endif
 #ifndef SWEEP_STORE_AUX
-#define SWEEP_STORE_AUX 0           // cache policy of the output stores (gfx950: 1 sc0, 2 nt, 16 sc1)
+#define SWEEP_STORE_AUX 2           // cache policy of the output stores (gfx950: 1 sc0, 2 nt, 16 sc1): nt - the volume is 13 MB per pair written once; in the step 57 us against 60 us with the default policy
 #endif
 #define SWEEP_MAX_OCT (CNM_MAX_PLANES / 8)
 #define SWEEP_PASSES ((SWEEP_CAP + SWEEP_NT - 1) / SWEEP_NT)   // staging passes a full box needs
@@ -133,7 +138,13 @@ struct SweepArgs {
     const float* ref; const float* src; const float* hmkt; float* out;
     unsigned int* queue;            // [0] tile tickets, [1] workgroups that have left; zero between launches
     int B, S, H, W, D;
+    // launch constants worked out on the host (sweep_launch): 512 workgroups x 16 waves need not each derive them
+    int noct, ntx, tiles_per_pair, nfull, nh, nq, ne, nunits;                // work units: whole tiles, then halves / quarters / eighths
+    float inv_tpp, inv_ntx, idmin_f, idstep_f;
     double idmin, idstep;           // plane d lies at depth 1 / (idmin + d * idstep)
+#ifdef SWEEP_Z_ARGS
+    float z[CNM_MAX_PLANES];        // experiment: the depths as 512 bytes of kernel arguments (measured: the launches get SLOWER in the step)
+#endif
 };
 
 typedef _Float16 sw_f16x2 __attribute__((ext_vector_type(2)));
@@ -141,10 +152,10 @@ typedef unsigned sw_u32x4 __attribute__((ext_vector_type(4)));
 
 // depth of plane d exactly as depthNet_model.py:193-194,209: python doubles, then one rounding to fp32
 // (separately rounded multiply / add / divide: no contraction)
-__device__ __forceinline__ float sweep_depth(const SweepArgs& a, int d) {
+__host__ __device__ __forceinline__ float sweep_depth(double idmin, double idstep, int d) {
 #pragma clang fp contract(off)
-    const double m = (double)d * a.idstep;
-    const double s = a.idmin + m;
+    const double m = (double)d * idstep;
+    const double s = idmin + m;
     return (float)(1.0 / s);
 }
 
@@ -336,13 +347,15 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t sweep_rsrc(unsigned lo, unsign
 // behind the wave's own output stores - vmcnt counts loads and stores in one in-order counter on gfx9 - and a tile would start
 // by waiting for the previous tile's stores to be acknowledged by a memory system that is busy with exactly those.
 typedef float sw_f32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void sweep_load_terms(const float* hmkt_pair, float (&hq)[12]) {
-    sw_f32x4 q0, q1, q2;
+struct SweepTerms { sw_f32x4 q0, q1, q2; };                       // h00 h01 h02 h10 | h11 h12 h20 h21 | h22 k0 k1 k2
+__device__ __forceinline__ SweepTerms sweep_load_terms(const float* hmkt_pair) {
+    SweepTerms t;
     asm volatile("s_load_dwordx4 %0, %3, 0x0\n\ts_load_dwordx4 %1, %3, 0x10\n\ts_load_dwordx4 %2, %3, 0x20\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&s"(q0), "=&s"(q1), "=&s"(q2) : "s"(hmkt_pair) : "memory");
-    hq[0] = q0.x; hq[1] = q0.y; hq[2] = q0.z; hq[3] = q0.w; hq[4] = q1.x; hq[5] = q1.y; hq[6] = q1.z; hq[7] = q1.w;
-    hq[8] = q2.x; hq[9] = q2.y; hq[10] = q2.z; hq[11] = q2.w;
+                 : "=&s"(t.q0), "=&s"(t.q1), "=&s"(t.q2) : "s"(hmkt_pair) : "memory");
+    return t;
 }
+#define SWEEP_TERMS(t) const float h00 = t.q0.x, h01 = t.q0.y, h02 = t.q0.z, h10 = t.q0.w, h11 = t.q1.x, h12 = t.q1.y, h20 = t.q1.z, h21 = t.q1.w, \
+                                   h22 = t.q2.x, k0 = t.q2.y, k1 = t.q2.z, k2 = t.q2.w
 __device__ __forceinline__ const float* sweep_uniform_ptr(const float* p) {
     const unsigned long long v = reinterpret_cast<unsigned long long>(p);
     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
@@ -354,31 +367,30 @@ __device__ __forceinline__ const float* sweep_uniform_ptr(const float* p) {
 // 8-lane min / max (DPP) gives the octet's box in all eight lanes.  Merging with the lanes 8, 16, 32 away and with the
 // other pass gives the boxes of every aligned run of 2, 4, 8, 16 octets; the longest run whose boxes all fit the LDS
 // budget wins.  Results go to LDS (groups, level).
-__device__ __attribute__((noinline)) void sweep_footprints(const float* hmkt_pair, int tx0_, int ty0_, int obeg_, int ocnt_, int W_, int H_, int D_,
-                                                           float idmin_, float idstep_, int parity_) {
+// NQ = passes of eight octets: 1 for units of up to 64 planes (half the merging work), 2 up to 128.
+template <int NQ>
+__device__ __forceinline__ void sweep_footprints_body(const float* hmkt_pair, int tx0_, int ty0_, int obeg_, int ocnt_, int W_, int H_, int D_,
+                                                      float idmin_, float idstep_, int parity_) {
     const int tx0 = sweep_sgpr(tx0_), ty0 = sweep_sgpr(ty0_), obeg = sweep_sgpr(obeg_), ocnt = sweep_sgpr(ocnt_);
     const int W = sweep_sgpr(W_), H = sweep_sgpr(H_), D = sweep_sgpr(D_), parity = sweep_sgpr(parity_);
     const float idmin = sweep_uniform(idmin_), idstep = sweep_uniform(idstep_);
     int (*const grp)[8] = SWEEP_LDS_GRP;
     int* const hdr = SWEEP_LDS_HDR;
     const int lane = threadIdx.x & 63;
-    float hq[12];
-    sweep_load_terms(sweep_uniform_ptr(hmkt_pair), hq);
-    const float k0 = hq[9], k1 = hq[10], k2 = hq[11];
+    const SweepTerms terms = sweep_load_terms(sweep_uniform_ptr(hmkt_pair));
+    SWEEP_TERMS(terms);
     const int cxi = (lane & 1) ? min(tx0 + SWEEP_TW - 1, W - 1) : tx0;
     const int cyi = (lane & 2) ? min(ty0 + SWEEP_TH - 1, H - 1) : ty0;
     const float cxf = (float)cxi, cyf = (float)cyi;
-    const float ca0 = fmaf(hq[0], cxf, fmaf(hq[1], cyf, hq[2]));
-    const float ca1 = fmaf(hq[3], cxf, fmaf(hq[4], cyf, hq[5]));
-    const float ca2 = fmaf(hq[6], cxf, fmaf(hq[7], cyf, hq[8]));
+    const float ca0 = fmaf(h00, cxf, fmaf(h01, cyf, h02));
+    const float ca1 = fmaf(h10, cxf, fmaf(h11, cyf, h12));
+    const float ca2 = fmaf(h20, cxf, fmaf(h21, cyf, h22));
     // the parallax form needs a2 (linear over the tile: extremes at the corners) away from zero, one sign
     const bool parallax_ok = __ballot(!(fabsf(ca2) >= 0.25f)) == 0 && (__ballot(ca2 < 0.f) == 0 || __ballot(ca2 > 0.f) == 0);
-    int bx0[2], by0[2], bx1[2], by1[2], bok[2], bcl[2];              // box, footprint usable, box clipped by the image
-    bool live[2];
-    bx0[1] = by0[1] = 1 << 28; bx1[1] = by1[1] = -(1 << 28); bok[1] = 1; bcl[1] = 0; live[1] = false;   // neutral second pass
+    int bx0[NQ], by0[NQ], bx1[NQ], by1[NQ], bok[NQ], bcl[NQ];        // box, footprint usable, box clipped by the image
+    bool live[NQ];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        if (q == 1 && ocnt <= 8) break;
+    for (int q = 0; q < NQ; ++q) {
         const int oct = q * 8 + (lane >> 3);                         // octet of this unit
         live[q] = oct < ocnt;
         const int o = obeg + min(oct, ocnt - 1);
@@ -406,12 +418,12 @@ __device__ __attribute__((noinline)) void sweep_footprints(const float* hmkt_pai
                    floorf(vmin - 0.5f) - 1.f >= -2.f && floorf(vmax - 0.5f) + 1.f <= (float)H);
         if (!live[q]) { bx0[q] = 1 << 28; by0[q] = 1 << 28; bx1[q] = -(1 << 28); by1[q] = -(1 << 28); bok[q] = 1; bcl[q] = 0; }   // neutral
     }
-    int level = 0, gx0[2], gy0[2], gx1[2], gy1[2], gst[2], gcl[2];
+    int level = 0, gx0[NQ], gy0[NQ], gx1[NQ], gy1[NQ], gst[NQ], gcl[NQ];
 #pragma unroll
-    for (int L = 0; L < 5; ++L) {
+    for (int L = 0; L < 3 + NQ; ++L) {
         if (L == 1) {
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
+            for (int q = 0; q < NQ; ++q) {
                 bx0[q] = min(bx0[q], sweep_dpp<SWEEP_DPP_ROR8>(bx0[q])); by0[q] = min(by0[q], sweep_dpp<SWEEP_DPP_ROR8>(by0[q]));
                 bx1[q] = max(bx1[q], sweep_dpp<SWEEP_DPP_ROR8>(bx1[q])); by1[q] = max(by1[q], sweep_dpp<SWEEP_DPP_ROR8>(by1[q]));
                 bok[q] &= sweep_dpp<SWEEP_DPP_ROR8>(bok[q]); bcl[q] |= sweep_dpp<SWEEP_DPP_ROR8>(bcl[q]);
@@ -419,20 +431,20 @@ __device__ __attribute__((noinline)) void sweep_footprints(const float* hmkt_pai
         } else if (L == 2 || L == 3) {
             const int m = L == 2 ? 16 : 32;
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
+            for (int q = 0; q < NQ; ++q) {
                 bx0[q] = min(bx0[q], __shfl_xor(bx0[q], m)); by0[q] = min(by0[q], __shfl_xor(by0[q], m));
                 bx1[q] = max(bx1[q], __shfl_xor(bx1[q], m)); by1[q] = max(by1[q], __shfl_xor(by1[q], m));
                 bok[q] &= __shfl_xor(bok[q], m); bcl[q] |= __shfl_xor(bcl[q], m);
             }
         } else if (L == 4) {
-            bx0[0] = bx0[1] = min(bx0[0], bx0[1]); by0[0] = by0[1] = min(by0[0], by0[1]);
-            bx1[0] = bx1[1] = max(bx1[0], bx1[1]); by1[0] = by1[1] = max(by1[0], by1[1]);
-            bok[0] = bok[1] = bok[0] & bok[1]; bcl[0] = bcl[1] = bcl[0] | bcl[1];
+            bx0[0] = bx0[NQ - 1] = min(bx0[0], bx0[NQ - 1]); by0[0] = by0[NQ - 1] = min(by0[0], by0[NQ - 1]);
+            bx1[0] = bx1[NQ - 1] = max(bx1[0], bx1[NQ - 1]); by1[0] = by1[NQ - 1] = max(by1[0], by1[NQ - 1]);
+            bok[0] = bok[NQ - 1] = bok[0] & bok[NQ - 1]; bcl[0] = bcl[NQ - 1] = bcl[0] | bcl[NQ - 1];
         }
         bool bad = false;
-        int fits[2];
+        int fits[NQ];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             // capacity in texels: (footprint width + the R column) x height
             const int rw = bx1[q] - bx0[q] + 2, rh = by1[q] - by0[q] + 1;
             const int rwc = min(max(rw, 0), SWEEP_CAP + 1), rhc = min(max(rh, 0), SWEEP_CAP + 1);   // 24-bit products
@@ -444,12 +456,12 @@ __device__ __attribute__((noinline)) void sweep_footprints(const float* hmkt_pai
         if (L == 0 || all_fit) {                                          // monotone: a run that fits implies its halves fit
             level = L;
 #pragma unroll
-            for (int q = 0; q < 2; ++q) { gx0[q] = bx0[q]; gy0[q] = by0[q]; gx1[q] = bx1[q]; gy1[q] = by1[q]; gst[q] = fits[q]; gcl[q] = bcl[q]; }
+            for (int q = 0; q < NQ; ++q) { gx0[q] = bx0[q]; gy0[q] = by0[q]; gx1[q] = bx1[q]; gy1[q] = by1[q]; gst[q] = fits[q]; gcl[q] = bcl[q]; }
         }
     }
     level = __builtin_amdgcn_readfirstlane(level);
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < NQ; ++q) {
         const int oct = q * 8 + (lane >> 3);
         if ((lane & 7) == 0 && oct < ocnt && (oct & ((1 << level) - 1)) == 0) {
             int* gq = grp[parity * SWEEP_MAX_OCT + (oct >> level)];
@@ -458,6 +470,13 @@ __device__ __attribute__((noinline)) void sweep_footprints(const float* hmkt_pai
         }
     }
     if (lane == 0) hdr[2 * parity] = level;
+}
+
+__device__ __attribute__((noinline)) void sweep_footprints8(const float* hmkt_pair, int tx0, int ty0, int obeg, int ocnt, int W, int H, int D, float idmin, float idstep, int parity) {
+    sweep_footprints_body<1>(hmkt_pair, tx0, ty0, obeg, ocnt, W, H, D, idmin, idstep, parity);
+}
+__device__ __attribute__((noinline)) void sweep_footprints16(const float* hmkt_pair, int tx0, int ty0, int obeg, int ocnt, int W, int H, int D, float idmin, float idstep, int parity) {
+    sweep_footprints_body<2>(hmkt_pair, tx0, ty0, obeg, ocnt, W, H, D, idmin, idstep, parity);
 }
 
 // ---- stage a box: rh rows of rw column texels, item i = r rw + c, SWEEP_NT items per pass.  A lane loads its column of
@@ -520,11 +539,11 @@ __device__ __attribute__((noinline)) float4 sweep_quad_global(unsigned src_lo_, 
     const int W = sweep_sgpr(W_), H = sweep_sgpr(H_), d0 = sweep_sgpr(d0_);
     const unsigned chan_bytes = (unsigned)(H * W) * 4u;
     const __amdgpu_buffer_rsrc_t rsrc = sweep_rsrc(src_lo, src_hi, 3 * chan_bytes);
-    float hq[12];
-    sweep_load_terms(sweep_uniform_ptr(hmkt_pair), hq);
+    const SweepTerms terms = sweep_load_terms(sweep_uniform_ptr(hmkt_pair));
+    SWEEP_TERMS(terms);
     const float fx = (float)x, fy = (float)y;
-    const float a0 = fmaf(hq[0], fx, fmaf(hq[1], fy, hq[2])), a1 = fmaf(hq[3], fx, fmaf(hq[4], fy, hq[5])), a2 = fmaf(hq[6], fx, fmaf(hq[7], fy, hq[8]));
-    const float k0 = hq[9], k1 = hq[10], k2e = hq[11] + 1e-6f;
+    const float a0 = fmaf(h00, fx, fmaf(h01, fy, h02)), a1 = fmaf(h10, fx, fmaf(h11, fy, h12)), a2 = fmaf(h20, fx, fmaf(h21, fy, h22));
+    const float k2e = k2 + 1e-6f;
     const float umax = (float)(W + 2), vmax = (float)(H + 2);              // box = columns -2 .. W + 1, rows -2 .. H
     float cost[4];
 #pragma unroll 1
@@ -563,22 +582,21 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
     bool trace_first = true;
 #endif
     const int H = a.H, W = a.W, HW = H * W, D = a.D;
-    const int noct = (D + 7) >> 3;
-    const int ntx = (W + SWEEP_TW - 1) / SWEEP_TW, nty = (H + SWEEP_TH - 1) / SWEEP_TH, tiles_per_pair = ntx * nty;
-    const int ntiles = a.B * a.S * tiles_per_pair;
-    {   // plane depths (fp64 divisions): not on wave 0, whose footprint pass everybody waits for
+    const int noct = a.noct, ntx = a.ntx, tiles_per_pair = a.tiles_per_pair;
+    {   // plane depths: kernel arguments -> LDS (not by wave 0, whose footprint pass everybody waits for)
         const int zt = tid - (SWEEP_NT >= 2 * CNM_MAX_PLANES ? CNM_MAX_PLANES : 0);
-        if (zt >= 0 && zt < CNM_MAX_PLANES) zsh[zt] = zt < D ? sweep_depth(a, zt) : 0.f;
+#ifdef SWEEP_Z_ARGS
+        // (read through the kernarg segment pointer: indexing the by-value struct leaves a dead 48-byte stack object behind, and with it a scratch set-up per launch)
+        const float* const zarg = reinterpret_cast<const float*>(static_cast<const char*>((const void*)__builtin_amdgcn_kernarg_segment_ptr()) + offsetof(SweepArgs, z));
+        if (zt >= 0 && zt < CNM_MAX_PLANES) zsh[zt] = zarg[zt];
+#else
+        if (zt >= 0 && zt < CNM_MAX_PLANES) zsh[zt] = zt < D ? sweep_depth(a.idmin, a.idstep, zt) : 0.f;
+#endif
     }
-
     // Work units: whole tiles first, then tiles cut into 2, 4, 8 partial sweeps: the launch ends with small units, not
     // with a tile-long tail of half-empty CUs.
-    const int ne = noct >= 8 ? min(ntiles, (int)gridDim.x * SWEEP_TAIL_EIGHTHS / 16) : 0;
-    const int nq = noct >= 4 ? min(ntiles - ne, (int)gridDim.x * SWEEP_TAIL_QUARTERS / 16) : 0;
-    const int nh = noct >= 2 ? min(ntiles - ne - nq, (int)gridDim.x * SWEEP_TAIL_HALVES / 16) : 0;
-    const int nfull = ntiles - nh - nq - ne, nunits = nfull + 2 * nh + 4 * nq + 8 * ne;
-    const float inv_tpp = sweep_uniform(__builtin_amdgcn_rcpf((float)tiles_per_pair)), inv_ntx = sweep_uniform(__builtin_amdgcn_rcpf((float)ntx));
-    const float idmin_f = sweep_uniform((float)a.idmin), idstep_f = sweep_uniform((float)a.idstep);
+    const int nh = a.nh, nq = a.nq, nfull = a.nfull, nunits = a.nunits;
+    const float inv_tpp = a.inv_tpp, inv_ntx = a.inv_ntx, idmin_f = a.idmin_f, idstep_f = a.idstep_f;
 #if defined(SWEEP_SPAN)
     struct Unit { int p, tx0, ty0, obeg, ocnt, tile; };
 #else
@@ -657,7 +675,10 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
 #ifdef SWEEP_TRACE
         if (trace_first && tid == 0 && blockIdx.x < 1024) sweep_trace_first[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
 #endif
-        if (tid < 64) sweep_footprints(hmkt_pair, tx0, ty0, obeg, ocnt, W, H, D, idmin_f, idstep_f, parity);
+        if (tid < 64) {
+            if (ocnt <= 8) sweep_footprints8(hmkt_pair, tx0, ty0, obeg, ocnt, W, H, D, idmin_f, idstep_f, parity);
+            else sweep_footprints16(hmkt_pair, tx0, ty0, obeg, ocnt, W, H, D, idmin_f, idstep_f, parity);
+        }
 #ifdef SWEEP_TRACE
         if (trace_first && tid == 0 && blockIdx.x < 1024) sweep_trace_first[blockIdx.x][2] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -670,9 +691,9 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
 #endif
         const int level = __builtin_amdgcn_readfirstlane(hdr[2 * parity]);
         const int ngroups = (ocnt + (1 << level) - 1) >> level;
-        float hq[12];                                                        // this tile's camera terms: SGPRs
-        sweep_load_terms(hmkt_pair, hq);
-        const float k2e = sweep_uniform(hq[11] + 1e-6f);
+        const SweepTerms terms = sweep_load_terms(hmkt_pair);              // this tile's camera terms: SGPRs
+        SWEEP_TERMS(terms);
+        const float k2e = sweep_uniform(k2 + 1e-6f);
 
         // output: a raw-buffer descriptor over this pair's slice; per lane ONE byte offset (out of range for lanes outside
         // the image: their stores are dropped), the plane / channel-group stride advances in an SGPR
@@ -708,17 +729,17 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
             int xv = x, yv = y;
             asm volatile("" : "+v"(xv), "+v"(yv));
             const float fx_ = (float)xv, fy_ = (float)yv;
-            float a2 = fmaf(hq[6], fx_, fmaf(hq[7], fy_, hq[8]));
+            float a2 = fmaf(h20, fx_, fmaf(h21, fy_, h22));
             const float a2s = fabsf(a2) >= 0.125f ? a2 : 1.f;
             float ra = __builtin_amdgcn_rcpf(a2s);
             ra = fmaf(fmaf(-a2s, ra, 1.0f), ra, ra);
             float pu, pv;
             {
-                const float a0 = fmaf(hq[0], fx_, fmaf(hq[1], fy_, hq[2])), a1 = fmaf(hq[3], fx_, fmaf(hq[4], fy_, hq[5]));
+                const float a0 = fmaf(h00, fx_, fmaf(h01, fy_, h02)), a1 = fmaf(h10, fx_, fmaf(h11, fy_, h12));
                 pu = a0 * ra; pv = a1 * ra;
                 pu = fmaf(fmaf(-a2s, pu, a0), ra, pu); pv = fmaf(fmaf(-a2s, pv, a1), ra, pv);   // correctly rounded quotients but for rare ties
             }
-            const float pa = fmaf(-pu, k2e, hq[9]), pb = fmaf(-pv, k2e, hq[10]);
+            const float pa = fmaf(-pu, k2e, k0), pb = fmaf(-pv, k2e, k1);
             float k2v = k2e;
             asm("" : "+v"(k2v));                                             // VALU operands from VGPRs: an SGPR source
             asm("" : "+v"(a2));                                              // costs the FMA its full issue rate on gfx950
@@ -730,7 +751,11 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
             for (int o = obeg + (g << level); o < o_end; ++o) {
                 const int d0 = o * 8;
                 sw_f16x2 hh[4];
+#if SWEEP_ROLL_QUADS
+#pragma unroll 1
+#else
 #pragma unroll
+#endif
                 for (int q = 0; q < 2; ++q) {
                     float cost[4];
                     if (staged) {
@@ -752,7 +777,11 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
 #endif
                         if (d0 + 4 * q < D) {
                             const sw_u32x4 v = {__float_as_uint(cost[0]), __float_as_uint(cost[1]), __float_as_uint(cost[2]), __float_as_uint(cost[3])};
+#ifdef SWEEP_STORE_LOCAL
+                            __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, ovoff, 0, SWEEP_STORE_AUX);   // debug builds: every store lands in the pair's first channel group (cache-resident)
+#else
                             __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, ovoff, osoff, SWEEP_STORE_AUX);
+#endif
                             osoff += ostride;
                         }
                     } else {
@@ -840,11 +869,26 @@ static int sweep_launch(int layout, const float* ref, const float* src, const fl
     a.ref = ref; a.src = src; a.hmkt = hmkt; a.out = out;
     a.queue = reinterpret_cast<unsigned int*>(ws);
     a.B = B; a.S = S; a.H = H; a.W = W; a.D = D;
-    a.idmin = idepth_min;
-    a.idstep = (idepth_max - idepth_min) / (D - 1.0);                        // depthNet_model.py:194
+    const double idstep = (idepth_max - idepth_min) / (D - 1.0);             // depthNet_model.py:194
+    a.idmin = idepth_min; a.idstep = idstep;
+#ifdef SWEEP_Z_ARGS
+    for (int d = 0; d < CNM_MAX_PLANES; ++d) a.z[d] = d < D ? sweep_depth(idepth_min, idstep, d) : 0.f;
+#endif
+    a.idmin_f = (float)idepth_min; a.idstep_f = (float)idstep;              // fp32 depths are enough for a box with margins
     const int slots = sweep_resident_workgroups();
     CNM_REQUIRE(slots > 0, CNM_ERR_LAUNCH);
     const dim3 grid((unsigned)(ntiles < slots ? ntiles : slots));
+    // the queue ends with small units (zone sizes in sixteenths of the grid; a part never has less than one octet) - when there
+    // is a queue to speak of: a launch that fits the chip at once sweeps whole tiles only (partial units get boxes of their own,
+    // i.e. other box origins and last-bit differences in the sample coordinates: small launches stay independent of how the
+    // caller batches its pairs, which the fp16 engine's tests ask for)
+    const int nt = (int)ntiles, g = ntiles > slots ? (int)grid.x : 0;
+    a.noct = (D + 7) >> 3; a.ntx = cnm_ceil_div(W, SWEEP_TW); a.tiles_per_pair = a.ntx * cnm_ceil_div(H, SWEEP_TH);
+    a.ne = a.noct >= 8 ? std::min(nt, g * SWEEP_TAIL_EIGHTHS / 16) : 0;
+    a.nq = a.noct >= 4 ? std::min(nt - a.ne, g * SWEEP_TAIL_QUARTERS / 16) : 0;
+    a.nh = a.noct >= 2 ? std::min(nt - a.ne - a.nq, g * SWEEP_TAIL_HALVES / 16) : 0;
+    a.nfull = nt - a.nh - a.nq - a.ne; a.nunits = a.nfull + 2 * a.nh + 4 * a.nq + 8 * a.ne;
+    a.inv_tpp = 1.0f / (float)a.tiles_per_pair; a.inv_ntx = 1.0f / (float)a.ntx;
     if (layout == 0) planesweep_kernel<0><<<grid, SWEEP_NT, 0, cnm_stream(stream)>>>(a);
     else if (layout == 1) planesweep_kernel<1><<<grid, SWEEP_NT, 0, cnm_stream(stream)>>>(a);
     else planesweep_kernel<2><<<grid, SWEEP_NT, 0, cnm_stream(stream)>>>(a);

@@ -7,7 +7,10 @@ rm -rf /tmp/k1is; timeout 600 rocprofv3 --kernel-trace --output-format csv -d /t
 python3 - <<'PY'
 import csv, glob
 f = glob.glob("/tmp/k1is/**/*kernel_trace.csv", recursive=True)[0]
-d = sorted((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(f)) if "planesweep_kernel<1>" in r["Kernel_Name"])
+rows = sorted(((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3) for r in csv.DictReader(open(f)) if "planesweep_kernel<1>" in r["Kernel_Name"]))
+import os
+if os.environ.get("K1_SERIES"): print("in launch order:", " ".join("%.0f" % v for _, v in rows))
+d = sorted(v for _, v in rows)
 n = len(d)
 print("plane sweep inside the step: %d launches, min %.1f  p10 %.1f  median %.1f  mean %.1f  p90 %.1f  max %.1f us -> 224.9 MB / median = %.0f GB/s = %.3f of 8 TB/s" % (
     n, d[0], d[n // 10], d[n // 2], sum(d) / n, d[9 * n // 10], d[-1], 224.919552 / d[n // 2] * 1e3, 224.919552 / d[n // 2] / 8.0))
