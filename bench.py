@@ -143,7 +143,7 @@ _LIVE_TRACE = None        # kernel name -> (average in-step duration in us, laun
 VALU_COUNTERS = ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE")
 
 
-def _child_pass(extra, pattern, timeout_s, bench_args=()):
+def _child_pass(extra, pattern, timeout_s, bench_args=(), env=None):
     """One `rocprofv3 <extra> -- python3 bench.py --steps 2 ...` child run (the interpreter directly behind `--`); returns the rows of
     the CSV matching `pattern`, or a string saying why not."""
     import csv
@@ -156,7 +156,7 @@ def _child_pass(extra, pattern, timeout_s, bench_args=()):
         cmd = ["rocprofv3", "--kernel-trace"] + list(extra) + ["--output-format", "csv", "-d", d, "--",
                sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline",
                "--no-secondary", "--no-live-traffic"] + list(bench_args)
-        r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+        r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, TMPDIR="/tmp", **(env or {})), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
         files = glob.glob(d + "/**/*" + pattern, recursive=True)
         if r.returncode != 0 or not files:
             return "exit code %d, %d file(s)" % (r.returncode, len(files))
@@ -177,25 +177,41 @@ def live_pmc(timeout_s=240):
     Sets the module tables; any pass that fails leaves its table None (the committed profiles are cited then)."""
     import collections
     import shutil
-    global _LIVE_TRAFFIC, _LIVE_TRAFFIC_WHY, _LIVE_VALU, _LIVE_TRACE
+    global _LIVE_TRAFFIC, _LIVE_TRAFFIC_WHY, _LIVE_VALU, _LIVE_TRACE, _LIVE_TRAFFIC_F16, _LIVE_FETCH_CBLK0
     if shutil.which("rocprofv3") is None:
         _LIVE_TRAFFIC_WHY = "rocprofv3 not on PATH"
         return
-    per = {}
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-        rows = _child_pass(["--pmc", counter], "counter_collection.csv", timeout_s)
+
+    def counter_pass(counter, bench_args=(), env=None):
+        """bytes per launch and kernel of one counter (KB in the CSV), or the reason it failed"""
+        rows = _child_pass(["--pmc", counter], "counter_collection.csv", timeout_s, bench_args, env)
         if isinstance(rows, str):
-            _LIVE_TRAFFIC_WHY = "rocprofv3 --pmc %s pass: %s" % (counter, rows)
-            per = None
-            break
+            return "rocprofv3 --pmc %s pass: %s" % (counter, rows)
         tot, ids = collections.defaultdict(float), collections.defaultdict(set)
         for row in rows:
             if row["Counter_Name"] == counter:
                 tot[row["Kernel_Name"]] += float(row["Counter_Value"]); ids[row["Kernel_Name"]].add(row["Dispatch_Id"])
-        per[counter] = {k: tot[k] * 1024.0 / len(ids[k]) for k in tot}               # the counters are in KB
-    if per is not None:
+        return {k: tot[k] * 1024.0 / len(ids[k]) for k in tot}
+
+    def traffic_table(bench_args=()):
+        f, w = counter_pass("FETCH_SIZE", bench_args), None
+        if not isinstance(f, str):
+            w = counter_pass("WRITE_SIZE", bench_args)
+        if isinstance(f, str) or isinstance(w, str):
+            return None, (f if isinstance(f, str) else w)
         # (corrected, raw): the x2 applies to wide (16 B per lane) coalesced reads; dword gathers are uncalibrated (guide, HBM section)
-        _LIVE_TRAFFIC = {k: (2.0 * v + per["WRITE_SIZE"].get(k, 0.0), v + per["WRITE_SIZE"].get(k, 0.0)) for k, v in per["FETCH_SIZE"].items()}
+        return {k: (2.0 * v + w.get(k, 0.0), v + w.get(k, 0.0)) for k, v in f.items()}, None
+
+    _LIVE_TRAFFIC, why = traffic_table()
+    if why:
+        _LIVE_TRAFFIC_WHY = why
+    _LIVE_TRAFFIC_F16, _ = traffic_table(["--precision", "f16"])                   # the fp16 engine's step: roofline_f16.traffic
+    # the dominant fp32 instance's reads with the OTHER unit order (channel block fastest, -DWINO4S_CBLK_SLOW=0: round 4 timed it and
+    # never read its bytes): the same pass against the second library cnmnet_amd/build.py links for exactly this
+    alt = os.path.join(ROOT, "cnmnet_amd", "lib", "libcnm_engine_cblk0.so")
+    if os.path.exists(alt):
+        f = counter_pass("FETCH_SIZE", env={"CNM_ENGINE_LIB": alt})
+        _LIVE_FETCH_CBLK0 = None if isinstance(f, str) else f
     rows = _child_pass(["--pmc"] + list(VALU_COUNTERS), "counter_collection.csv", timeout_s)
     if not isinstance(rows, str):
         tot, ids, dur = collections.defaultdict(lambda: collections.defaultdict(float)), collections.defaultdict(set), collections.defaultdict(float)
@@ -215,6 +231,10 @@ def live_pmc(timeout_s=240):
         for k, v in per.items():
             v = v[2 * len(v) // 5:] if len(v) >= 5 else v
             _LIVE_TRACE[k] = (sum(v) / len(v), len(v))
+
+
+_LIVE_TRAFFIC_F16 = None
+_LIVE_FETCH_CBLK0 = None
 
 
 def _by_kernel(table, kernel):
@@ -352,6 +372,11 @@ def kernel_rooflines(dev, frames):
     tot_ms = sum(v[1] for v in per_kernel.values())
     conv = {"kernel": name, "bound": "mfma", "achieved": exe / ms / 1e9, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
             "frac": exe / ms / 1e9 / MFMA_F32_PEAK_TF, "traffic": pmc_traffic(name), "traffic_uncorrected": pmc_traffic(name, raw=True),
+            "fetch_bytes": (2.0 * (pmc_traffic(name) - pmc_traffic(name, raw=True))) if (pmc_traffic(name) is not None and _LIVE_TRAFFIC is not None) else None,
+            "fetch_bytes_unit_order_channel_block_fastest": (2.0 * _by_kernel(_LIVE_FETCH_CBLK0, name)) if _by_kernel(_LIVE_FETCH_CBLK0, name) is not None else None,
+            "fetch_note": "HBM read bytes per average launch (FETCH_SIZE x 2): the shipped unit order (channel block slowest: an XCD's neighbouring ranges stream one block's "
+                          "filters) against -DWINO4S_CBLK_SLOW=0 (channel block fastest: the workgroups of a tile block share its input), the latter from a child pass on "
+                          "cnmnet_amd/lib/libcnm_engine_cblk0.so -- round 4 timed that order (5.70 vs 5.62 ms per step's launches) without reading its bytes",
             "traffic_note": "HBM bytes per average launch, PMC pass committed under profiles/ (not live)", "launches_per_step": launches,
             "avg_launch_ms": ms / launches, "algorithmic": flop / ms / 1e9,
             "note": "achieved = flops executed on the matrix cores; algorithmic = direct-convolution-equivalent rate; avg_launch_ms = mean over this kernel's layer shapes of a step, each shape timed alone (%d launches after %d warm-up) -- compare with profiles/r3_bench_kernel_stats_serial.csv (in the default run the two refine decoders overlap on two streams, which stretches rocprof's per-launch durations while shortening the step)" % (IT, WARM),
@@ -495,7 +520,10 @@ def f16_roofline(dev, frames):
     clk = sustained_clock(lambda: ops.conv2d_c8(xs, ws, bs, 128, 3, 1, True))
     del xs, ws, bs
     return with_clock({"kernel": name, "bound": "mfma", "achieved": flop / ms / 1e9, "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s", "frac": flop / ms / 1e9 / MFMA_F16_PEAK_TF,
-            "traffic": None, "launches_per_step": n, "avg_launch_ms": ms / n,
+            "traffic": (_by_kernel(_LIVE_TRAFFIC_F16, name.split(" + ")[0]) or (None, None))[0],
+            "traffic_uncorrected": (_by_kernel(_LIVE_TRAFFIC_F16, name.split(" + ")[0]) or (None, None))[1],
+            "traffic_note": "HBM bytes per average launch of this instance in the fp16 step: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this run (FETCH_SIZE x 2 = the gfx950 wide-read correction)",
+            "launches_per_step": n, "avg_launch_ms": ms / n,
             "all_conv": {"achieved": tot_f / tot_ms / 1e9, "frac": tot_f / tot_ms / 1e9 / MFMA_F16_PEAK_TF, "sum_of_isolated_layer_ms": tot_ms,
                          "per_kernel_ms": {k: round(v[1], 3) for k, v in sorted(per.items(), key=lambda kv: -kv[1][1])}},
             "note": "implicit GEMM: executed = direct-convolution flops; every layer alone, %d launches after %d warm-up; the package runs at its "
@@ -633,6 +661,41 @@ def timed_steps(run, img, cams, steps, sync):
     per = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(steps))
     q = lambda f: per[min(len(per) - 1, int(f * len(per)))]
     return out, elapsed, {"median": q(0.5), "p10": q(0.1), "p90": q(0.9), "n": steps}
+
+
+def planesweep_alone(dev, B, S, Hh, Ww, D, n_it=12):
+    """The plane-sweep launch of a secondary configuration on its own, as kernel_rooflines() times the headline's: every launch
+    between its own pair of HIP events on the launch stream and followed by its consumer (conv1.0) as in the step."""
+    from cnmnet_amd import _lib, ops, synthetic as syn
+    img, cams = syn.frames(B, S, Hh, Ww, seed=77)
+    img, cams = torch.from_numpy(img).to(dev), torch.from_numpy(cams).to(dev)
+    ref, src = img[:, 0].contiguous(), img[:, 1:].contiguous()
+    hmkt = ops.homography_terms(cams[:, 0], cams[:, 1:])
+    lib = _lib.load()
+    ws = torch.zeros(lib.cnm_planesweep_workspace_floats(B, S, Hh, Ww), device=dev)
+    out = ops.plane_sweep_cat_c4(ref, src, hmkt, 3.0, D, ws=ws)
+    lo, hi = ops.idepth_range(3.0)
+    args = (ref.data_ptr(), src.data_ptr(), hmkt.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), B, S, Hh, Ww, D, lo, hi,
+            torch.cuda.current_stream().cuda_stream)
+    wt = torch.randn(128, 3 + D, 7, 7, device=dev) * 0.02
+    up, (_, bp) = ops.pack_winograd(wt, stride=1), ops.pack_conv(wt)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_it)]
+    for i in range(-2, n_it):
+        if i >= 0:
+            ev[i][0].record()
+        _lib.check(lib.cnm_planesweep_cat_c4_f32(*args))
+        if i >= 0:
+            ev[i][1].record()
+        ops.conv_rows_winograd_c4(out, up, bp, 128, 7, True, stride=1)
+    torch.cuda.synchronize()
+    per = sorted(a.elapsed_time(b) for a, b in ev)
+    ms = sum(per) / n_it
+    pairs = B * S
+    byts = B * 3 * Hh * Ww * 4 + pairs * 3 * Hh * Ww * 4 + pairs * (D + 3) * Hh * Ww * 4
+    return {"kernel": "planesweep_kernel<1>", "bound": "hbm", "achieved": byts / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": byts / ms / 1e6 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": byts, "avg_launch_ms": ms,
+            "launch_ms": {"median": per[n_it // 2], "min": per[0], "max": per[-1], "n": n_it},
+            "note": "ONE launch over the %d pairs of this configuration, timed as roofline_planesweep times the headline's" % pairs}
 
 
 def secondary(dev, precision, B, S, Hh, Ww, D, steps=10, warmup=3):
@@ -848,7 +911,9 @@ def main():
             torch.cuda.empty_cache()
             line["roofline_f16"] = f16_roofline(dev, B)
             torch.cuda.empty_cache()
-            line["config4"] = dict(secondary(dev, "f32", 4, 4, 480, 640, 96, steps=5, warmup=2), dtype="f32",
+            c4_sweep = planesweep_alone(dev, 4, 4, 480, 640, 96)
+            torch.cuda.empty_cache()
+            line["config4"] = dict(secondary(dev, "f32", 4, 4, 480, 640, 96, steps=5, warmup=2), dtype="f32", roofline_planesweep=c4_sweep,
                                    note="BASELINE configs[3]; plane sweep = 125.3 MB algorithmic per (ref, src) pair")
             torch.cuda.empty_cache()
             line["train"] = dict(train_secondary(dev), note="BASELINE configs[2], one GPU's shard of 4 samples; parity: tests/test_gpu_training.py")
@@ -863,7 +928,7 @@ def main():
         print(json.dumps(compact(line)), flush=True)
 
 
-NOTE_KEYS = ("note", "sum_note", "traffic_note", "parity_note", "tolerance")
+NOTE_KEYS = ("note", "sum_note", "traffic_note", "fetch_note", "parity_note", "tolerance")
 TAIL_KEYS = ("config", "roofline", "roofline_planesweep", "cpu_baseline", "speedup_vs_cpu_baseline", "metric", "value", "unit", "n_gpus", "steps", "warmup",
              "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
 

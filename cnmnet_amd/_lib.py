@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcnm_engine.so")
+LIB_PATH = os.environ.get("CNM_ENGINE_LIB") or os.path.join(_HERE, "lib", "libcnm_engine.so")   # CNM_ENGINE_LIB: an A/B build of the same ABI (bench.py's unit-order pass)
 
 c_fp = C.c_void_p          # device pointers travel as integers
 c_i, c_f, c_d, c_ll, c_sz = C.c_int, C.c_float, C.c_double, C.c_longlong, C.c_size_t
@@ -202,8 +202,8 @@ def load():
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch
         fn.restype, fn.argtypes = res, args
-    if lib.cnm_abi_version() != 4:
-        raise EngineError("libcnm_engine.so ABI version %d, expected 4" % lib.cnm_abi_version())
+    if lib.cnm_abi_version() != 5:
+        raise EngineError("libcnm_engine.so ABI version %d, expected 5" % lib.cnm_abi_version())
     # A/B switches without code changes: CNM_TUNE="wino36_staged=2,refine_side_stream=0" calls cnm_tune_<name>(<value>)
     for item in filter(None, os.environ.get("CNM_TUNE", "").split(",")):
         name, _, val = item.partition("=")

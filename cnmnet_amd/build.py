@@ -64,6 +64,22 @@ def build(force=False, verbose=True):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    # A/B twin for bench.py's counter pass: the same library with the staged 36-point kernel's units ordered channel
+    # block FASTEST (-DWINO4S_CBLK_SLOW=0).  Never loaded by the product (cnmnet_amd/_lib.py loads it only when CNM_ENGINE_LIB names it).
+    s = os.path.join(CSRC, "conv_winograd4s.hip")
+    o = os.path.join(LIBDIR, "conv_winograd4s_cblk0.o")
+    alt = os.path.join(LIBDIR, "libcnm_engine_cblk0.so")
+    if force or _stale(o, [s, os.path.abspath(__file__)] + headers):
+        cmd = [HIPCC] + FLAGS + FILE_FLAGS.get("conv_winograd4s.hip", []) + ["-DWINO4S_CBLK_SLOW=0", "-c", s, "-o", o]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    alt_objs = [o if x.endswith("conv_winograd4s.o") else x for x in objs]
+    if force or _stale(alt, alt_objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread"] + alt_objs + ["-o", alt]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
     return LIB
 
 

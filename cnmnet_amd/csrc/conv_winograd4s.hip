@@ -546,30 +546,40 @@ static int wino4s_cus() {                                                // comp
 // Sync workspace of one launch (sync_ws.h): kSyncFlagBytes of flag / generation words followed by one partial-output slot per range.
 extern "C" size_t cnm_wino36_sync_floats(void) { return (kSyncFlagBytes + (size_t)wino4s_cus() * kSyncSlotBytes) / 4; }
 
-// The pinned status word a timed-out poll writes (sync_ws.h).  Allocated on the first staged launch that is not being captured
-// into a graph (allocation is not allowed during capture; launches recorded before it exists run without host reporting).
-static unsigned* g_sync_status = nullptr;                                // host address == device address (mapped, portable)
-static unsigned g_sync_spin_limit = 0, g_sync_version = 0;             // 0 = kSyncDefaultSpins; the version counts changes of either word
+// The pinned status words a timed-out poll writes (sync_ws.h): ONE PER DEVICE [r5] -- a time-out on one device makes the staged
+// entry points refuse on THAT device only (the header promises per-call state for DataParallel-style callers with one thread
+// per device).  A device's word is allocated on its first staged launch that is not being captured into a graph (allocation is
+// not allowed during capture; launches recorded before it exists run without host reporting: cnm_engine_status() allocates it
+// too, so a caller that checks the status once before capturing has it).
+static unsigned* g_sync_status[64] = {nullptr};                          // per device; host address == device address (mapped, portable)
+static unsigned g_sync_spin_limit = 0, g_sync_version[64] = {0}, g_sync_knob_version = 0;   // 0 = kSyncDefaultSpins; the versions count changes
 static std::mutex g_sync_mutex;
-SyncCtl cnm_sync_ctl(hipStream_t stream) {
-    if (!g_sync_status) {
+static int sync_device() { int dev = 0; return (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) ? dev : -1; }
+static unsigned* sync_status_word(int dev, hipStream_t stream, bool may_allocate) {
+    if (dev < 0) return nullptr;
+    if (!g_sync_status[dev] && may_allocate) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(stream, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+        if (stream && hipStreamIsCapturing(stream, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
         if (cs == hipStreamCaptureStatusNone) {
             std::lock_guard<std::mutex> lock(g_sync_mutex);
-            if (!g_sync_status) {
+            if (!g_sync_status[dev]) {
                 void* p = nullptr;
                 if (hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess && p) {
                     *reinterpret_cast<volatile unsigned*>(p) = 0u;
-                    g_sync_status = reinterpret_cast<unsigned*>(p);
-                    ++g_sync_version;
+                    g_sync_status[dev] = reinterpret_cast<unsigned*>(p);
+                    ++g_sync_version[dev];
                 } else (void)hipGetLastError();
             }
         }
     }
-    return SyncCtl{g_sync_status, g_sync_spin_limit, g_sync_version};
+    return g_sync_status[dev];
 }
-bool cnm_sync_failed() { return g_sync_status && *reinterpret_cast<volatile unsigned*>(g_sync_status) != 0u; }
+SyncCtl cnm_sync_ctl(hipStream_t stream) {
+    const int dev = sync_device();
+    unsigned* const w = sync_status_word(dev, stream, true);
+    return SyncCtl{w, g_sync_spin_limit, (dev >= 0 ? g_sync_version[dev] : 0u) + 64u * g_sync_knob_version};
+}
+bool cnm_sync_failed() { const int dev = sync_device(); return dev >= 0 && g_sync_status[dev] && *reinterpret_cast<volatile unsigned*>(g_sync_status[dev]) != 0u; }
 // Test hook (not in the header): the generation the kernels of one launch see -- tests/test_gpu_parity.py checks that it differs
 // from launch to launch, eager and in HIP-graph replays.
 __global__ void sync_generation_probe_kernel(unsigned* out) { if (threadIdx.x == 0) out[blockIdx.x] = sync_generation(); }
@@ -583,12 +593,14 @@ extern "C" int cnm_debug_sync_generation(unsigned* out, int nblocks, void* strea
 // CNM_OK, or CNM_ERR_LAUNCH when a stream-K hand-off timed out since the last clear (the outputs of that launch are
 // wrong).  Reads a pinned host word: synchronise the stream first if the launch in question may still be running.
 extern "C" int cnm_engine_status(int clear) {
+    const int dev = sync_device();
+    (void)sync_status_word(dev, nullptr, true);                          // the current device's word exists from the first status query on
     const bool failed = cnm_sync_failed();
-    if (failed && clear) *reinterpret_cast<volatile unsigned*>(g_sync_status) = 0u;
+    if (failed && clear) *reinterpret_cast<volatile unsigned*>(g_sync_status[dev]) = 0u;
     return failed ? CNM_ERR_LAUNCH : CNM_OK;
 }
 // Debug / test only: polls before a hand-off gives up (0 = the default, 2^24); bit 31 = fault injection (publishers keep their flags down).
-extern "C" unsigned cnm_tune_sync_spin_limit(unsigned v) { const unsigned old = g_sync_spin_limit; if (v != old) { g_sync_spin_limit = v; ++g_sync_version; } return old ? old : kSyncDefaultSpins; }
+extern "C" unsigned cnm_tune_sync_spin_limit(unsigned v) { const unsigned old = g_sync_spin_limit; if (v != old) { g_sync_spin_limit = v; ++g_sync_knob_version; } return old ? old : kSyncDefaultSpins; }
 
 int cnm_wino36s_try_launch(const Wino4Args& a, int M, int ups, hipStream_t stream, int s2) {
     const bool only_here = s2 || M == 3;                                 // forms without a gather-fed twin: the A/B knob and the balance heuristic below do not apply

@@ -782,6 +782,11 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
 #else
                             __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, ovoff, osoff, SWEEP_STORE_AUX);
 #endif
+                            // (a 16-byte store with an SGPR offset reads its data registers over several cycles and hipcc pads no hazard
+                            // for that form -- conv_winograd4s.hip found the tail of such a store leaving with the NEXT values when the
+                            // registers were rewritten at once; here the next write to them is a sample away, and the wait states cost
+                            // this wave nothing that the other seven on its SIMD do not fill)
+                            asm volatile("s_nop 7" ::: "memory");
                             osoff += ostride;
                         }
                     } else {

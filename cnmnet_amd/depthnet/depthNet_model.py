@@ -162,8 +162,11 @@ class _EngineNet(nn.Module):
         may never overlap in it: a call on a different stream than the previous one first waits for that stream."""
         ws = self._ws.get(str(device))
         if ws is None or ws.numel() < nfloats:
-            self._ws = {str(device): torch.zeros(nfloats, device=device, dtype=torch.float32)}
+            self._ws = {str(device): ops.register_sync_owner(torch.zeros(nfloats, device=device, dtype=torch.float32))}
             ws = self._ws[str(device)]
+            if not torch.cuda.is_current_stream_capturing():
+                with torch.cuda.device(device):
+                    ops.engine_status(clear=False)                      # allocates this device's status word before anybody captures a graph over this net
         cur = torch.cuda.current_stream(device)
         last = getattr(self, "_ws_stream", None)
         if last is not None and last != cur and not torch.cuda.is_current_stream_capturing():

@@ -7,6 +7,8 @@ operators that have one -- geometry prep, plane sweep, layout converters, depth-
 inverse warp -- and are rejected everywhere else; the CPU restatement in oracle/ is test
 infrastructure and never involved.
 """
+import weakref
+
 import torch
 
 from . import _lib, host
@@ -354,7 +356,18 @@ def conv3x3_s2_winograd_c4(x, u_packed, b_packed, Cout, relu=True):
 def wino36_sync_workspace(device):
     """Zeroed sync workspace for the LDS-staged persistent kernels (flag / generation words + partial-output slots,
     csrc/sync_ws.h): one per stream of launches; zero before the first use, reusable after every call."""
-    return torch.zeros(_lib.load().cnm_wino36_sync_floats(), device=device, dtype=torch.float32)
+    ws = torch.zeros(_lib.load().cnm_wino36_sync_floats(), device=device, dtype=torch.float32)
+    register_sync_owner(ws)
+    return ws
+
+
+_SYNC_OWNERS = weakref.WeakSet()    # tensors that hold sync words of the staged kernels (sync workspaces, the nets' workspaces)
+
+
+def register_sync_owner(t):
+    """Remember a tensor whose contents include stream-K flag words, so that engine_status(clear=True) can scrub it after a time-out."""
+    _SYNC_OWNERS.add(t)
+    return t
 
 
 def sync_workspace_state(sync):
@@ -364,9 +377,20 @@ def sync_workspace_state(sync):
 
 
 def engine_status(clear=True):
-    """Raise EngineError if a stream-K hand-off has timed out since the last acknowledgement (cnm_engine_status); with
-    clear=True the failure is acknowledged, so later launches are accepted again.  Synchronise first."""
-    _lib.check(_lib.load().cnm_engine_status(int(bool(clear))))
+    """Raise EngineError if a stream-K hand-off has timed out on the current device since the last acknowledgement
+    (cnm_engine_status); with clear=True the failure is acknowledged, so later launches are accepted again, and every registered
+    workspace on that device is zeroed: a timed-out hand-off leaves stale generation words behind, which the queue that wrote
+    them can never mistake for its own, but a workspace may next be used from another stream, i.e. another hardware queue whose
+    dispatch counter runs through the same small numbers.  Synchronise first."""
+    rc = _lib.load().cnm_engine_status(int(bool(clear)))
+    if rc != 0 and clear and torch.cuda.is_available():
+        cur = torch.cuda.current_device()
+        torch.cuda.synchronize()
+        for t in list(_SYNC_OWNERS):
+            if t.is_cuda and t.device.index == cur:
+                t.zero_()
+        torch.cuda.synchronize()
+    _lib.check(rc)
 
 
 def conv3x3_winograd4_c4(x, u_packed, b_packed, Cout, relu=True, x2=None, ksize=3, sync=None):

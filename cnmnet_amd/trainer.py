@@ -337,6 +337,32 @@ class TrainStepWoNormal:
             t.zero_()
         self._graph_key = key
 
+    def _cut_here(self, p01, f01, p02, f02):
+        """A TRUE cut between depthNet and everything behind it: every tensor depthNet hands on goes through an
+        identity autograd node (`view_as`), the refine net and the loss terms see only those, and the nodes are what the
+        segmented graph step differentiates to and restarts from.  depthNet's own outputs are nested -- disp1 = head(iconv1),
+        iconv1 is handed on as well -- so cutting at THEM would make `autograd.grad(loss, refine_params + cut)` walk through
+        depthNet's decoder (freeing its saved tensors) and the second backward count the head paths twice; the identity
+        nodes sit strictly behind depthNet and are ancestors of nothing but the refine net and the losses."""
+        cut = []
+
+        def node(t):
+            v = t.view_as(t)
+            cut.append(v)
+            return v
+
+        def feature(f):
+            c4 = getattr(f, "_cnm_c4", None)
+            if c4 is None:
+                return node(f)
+            g = f.detach()                                   # the NCHW twin only carries the c4 tensor the refine net reads
+            g._cnm_c4 = node(c4)
+            return g
+
+        out = ([node(t) for t in p01], feature(f01), [node(t) for t in p02], feature(f02))
+        self._cut = cut
+        return out
+
     def losses(self, rgbs, cameras, disparities, depths, warmup_epoch=False):
         """Train-mode forward of both nets on one batch (shard) and the loss mix of train.py:522-559:
         (loss to back-propagate, dict of logged terms)."""
@@ -349,7 +375,7 @@ class TrainStepWoNormal:
         else:
             p01, f01 = self.depth_net(rgbs[:, 0], rgbs[:, 1], cameras[:, 0], cameras[:, 1])     # :509-512
             p02, f02 = self.depth_net(rgbs[:, 0], rgbs[:, 2], cameras[:, 0], cameras[:, 2])
-        self._cut = [*p01, getattr(f01, "_cnm_c4", f01), *p02, getattr(f02, "_cnm_c4", f02)]   # what depthNet hands on: the segmented graph step cuts backward here
+        p01, f01, p02, f02 = self._cut_here(p01, f01, p02, f02)               # what depthNet hands on: the segmented graph step cuts backward here
         idr, prob = self.refine_net(idepth01=p01[0], idepth02=p02[0], iconv01=f01, iconv02=f02)   # :517-520
         L = lambda a, b, w=None: _masked_l1(a, b, self.dist, w, self.exact, self.group)
         loss_idepth_1 = (L(p01[0], gt_id) + L(p02[0], gt_id)) * 0.5                          # :522-523
@@ -470,7 +496,7 @@ class TrainStep(TrainStepWoNormal):
         else:
             p01, f01 = self.depth_net(rgbs[:, 0], rgbs[:, 1], cameras[:, 0], cameras[:, 1])     # :164-167
             p02, f02 = self.depth_net(rgbs[:, 0], rgbs[:, 2], cameras[:, 0], cameras[:, 2])
-        self._cut = [*p01, getattr(f01, "_cnm_c4", f01), *p02, getattr(f02, "_cnm_c4", f02)]   # see TrainStepWoNormal.losses
+        p01, f01, p02, f02 = self._cut_here(p01, f01, p02, f02)               # see TrainStepWoNormal.losses
         idr, prob = self.refine_net(idepth01=p01[0], idepth02=p02[0], iconv01=f01, iconv02=f02)   # :172-175
         L = lambda a, b, w=None: _masked_l1(a, b, self.dist, w, self.exact, self.group)
         loss_idepth_1 = (L(p01[0], gt_id) + L(p02[0], gt_id)) * 0.5                          # :177-178

@@ -39,15 +39,20 @@
 extern "C" {
 #endif
 
-#define CNM_ABI_VERSION 4
+#define CNM_ABI_VERSION 5                    /* 5 [r5]: engine status per device; CNM_ERR_LAUNCH is sticky per device after a hand-off time-out; sync-workspace flag
+                                               words are no longer guaranteed zero after a FAILED call (stale generations, harmless to later launches on the
+                                               same queue; callers that acknowledge a failure should zero their sync workspaces, as cnmnet_amd.ops.engine_status
+                                               does); _cpu host twins, cnm_engine_status, cnm_tune_sync_spin_limit exported since 4 */
 #define CNM_WINO4_MIN_WORKGROUPS 384
 #define CNM_UPSAMPLED_MIN_PIXELS 196608      /* 16 images x 96 x 128 */
 /* Engine status.  The persistent stream-K convolution kernels hand partial outputs from one workgroup to another inside a
  * launch; a hand-off that does not complete within its spin bound (it cannot, unless workgroups of one launch are not
  * co-resident for seconds) does not hang and does not pass silently: the kernel records it in a pinned host word, the
- * outputs of that launch are wrong, and EVERY later call of a staged-kernel entry point returns CNM_ERR_LAUNCH without
- * launching until the failure has been acknowledged.  cnm_engine_status(clear) returns CNM_OK or CNM_ERR_LAUNCH (a
- * hand-off timed out since the last clear) and, with clear != 0, acknowledges it.  It reads host memory only: synchronise
+ * outputs of that launch are wrong, and every later call of a staged-kernel entry point ON THAT DEVICE returns CNM_ERR_LAUNCH
+ * without launching until the failure has been acknowledged (one status word per device [r5]: other devices of the process keep
+ * working).  cnm_engine_status(clear) speaks for the CURRENT device: CNM_OK or CNM_ERR_LAUNCH (a hand-off timed out there since
+ * the last clear) and, with clear != 0, acknowledges it; it also allocates the device's status word if no launch has yet, so a
+ * caller that queries the status once before capturing a hipGraph gets time-outs inside replays reported.  It reads host memory only: synchronise
  * the stream first when the launch in question may still be running.  The sync workspaces need no repair afterwards
  * (a flag counts only if it carries the generation -- the dispatch id -- of the launch that polls it, csrc/sync_ws.h).
  * Replaying a captured hipGraph runs none of these entry points, so nothing refuses there: call cnm_engine_status() after

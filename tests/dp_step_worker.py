@@ -13,6 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from cnmnet_amd import synthetic as syn                              # noqa: E402
 from cnmnet_amd.depthnet import depthNet, DepthRefineNet            # noqa: E402
+from cnmnet_amd import trainer as trainer_mod                        # noqa: E402
 from cnmnet_amd.trainer import TrainStepWoNormal, synthetic_training_sample, make_adam   # noqa: E402
 
 H, W, B, LR = 64, 96, 4, 1e-4
@@ -106,31 +107,37 @@ def main():
         # ---- graph mode next to the reducer: the step replayed as two HIP graphs (forward + refine backward | depthNet backward) with
         # the refine net's buckets launched in between, the rest and Adam eager; two steps on different shards against the eager
         # data-parallel step
-        pair = []
-        for graph in (False, True):
-            dg, rg = nets(dev)
-            st = TrainStepWoNormal(dg, rg, lr=LR, dist=dist, graph=graph)
-            st.optimizer = make_adam(list(rg.parameters()) + list(dg.parameters()), LR, 1e-5, capturable=True)
-            if graph:
-                assert st.reducer is not None and not st.reducer.handles
-            for sd in (11, 12):
-                smp = synthetic_training_sample(B, H, W, seed=sd, device=dev)
-                lg = st(**{k: smp[k][rank * per:(rank + 1) * per].contiguous() for k in keys})
-                assert np.isfinite(lg["loss"])
-            if graph:
-                # the segmented replay: the refine net's buckets (no bucket mixes the two nets) left between the two graphs, the
-                # depthNet buckets after the second one
-                r = st.reducer
-                n_refine = sum(all(id(p) in st._refine_ids for p in b) for b in r.buckets)
-                assert st._graph_b is not None and n_refine >= 1 and r.hook_launches == n_refine and r.hook_launches + r.late_launches == len(r.buckets), \
-                    (n_refine, r.hook_launches, r.late_launches, len(r.buckets))
-            pair.append((lg, {k: p.detach().clone() for k, p in named(dg, rg)}))
-        (le, pe), (lgr, pg_) = pair
-        assert abs(le["loss"] - lgr["loss"]) <= 1e-5 * max(1.0, abs(le["loss"])), (le["loss"], lgr["loss"])
-        worst = max(float((pe[k] - pg_[k]).abs().max()) for k in pe)
-        assert worst <= 2e-6, worst                                             # two Adam steps of 1e-4
-        if rank == 0:
-            print("dp-graph OK: eager vs graphed data-parallel step, worst parameter difference %.2e" % worst, flush=True)
+        # Both forms of the forward: depthNet over the two sources in one pass (SplitSources outputs), and the reference's two calls,
+        # whose outputs are NESTED (disp1 = head(iconv1), both handed on): the cut between the two graphs must be a true cut there
+        # too (cutting at depthNet's own outputs double-counted the head paths / raised "backward through the graph a second time").
+        for one_pass in (True, False):
+            trainer_mod.SOURCES_IN_ONE_PASS = one_pass
+            pair = []
+            for graph in (False, True):
+                dg, rg = nets(dev)
+                st = TrainStepWoNormal(dg, rg, lr=LR, dist=dist, graph=graph)
+                st.optimizer = make_adam(list(rg.parameters()) + list(dg.parameters()), LR, 1e-5, capturable=True)
+                if graph:
+                    assert st.reducer is not None and not st.reducer.handles
+                for sd in (11, 12):
+                    smp = synthetic_training_sample(B, H, W, seed=sd, device=dev)
+                    lg = st(**{k: smp[k][rank * per:(rank + 1) * per].contiguous() for k in keys})
+                    assert np.isfinite(lg["loss"])
+                if graph:
+                    # the segmented replay: the refine net's buckets (no bucket mixes the two nets) left between the two graphs, the
+                    # depthNet buckets after the second one
+                    r = st.reducer
+                    n_refine = sum(all(id(p) in st._refine_ids for p in b) for b in r.buckets)
+                    assert st._graph_b is not None and n_refine >= 1 and r.hook_launches == n_refine and r.hook_launches + r.late_launches == len(r.buckets), \
+                        (n_refine, r.hook_launches, r.late_launches, len(r.buckets))
+                pair.append((lg, {k: p.detach().clone() for k, p in named(dg, rg)}))
+            (le, pe), (lgr, pg_) = pair
+            assert abs(le["loss"] - lgr["loss"]) <= 1e-5 * max(1.0, abs(le["loss"])), (one_pass, le["loss"], lgr["loss"])
+            worst = max(float((pe[k] - pg_[k]).abs().max()) for k in pe)
+            assert worst <= 2e-6, (one_pass, worst)                                 # two Adam steps of 1e-4
+            if rank == 0:
+                print("dp-graph OK: eager vs graphed data-parallel step (%s), worst parameter difference %.2e" % ("both sources in one pass" if one_pass else "two depthNet calls, nested outputs", worst), flush=True)
+        trainer_mod.SOURCES_IN_ONE_PASS = True
         dist.barrier()
     finally:
         dist.destroy_process_group()

@@ -12,14 +12,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _launch(cmd, env, timeout):
-    """Run a multi-rank bench command.  Eight processes on ONE GPU is not a supported layout, only a dry run of the launch path: once in
-    about twenty suite runs a rank was killed by a signal (SIGABRT, no Python error; 24 repeats of the command alone: none).  A rank lost
-    to a SIGNAL is retried once, with the first attempt's error lines printed; any other failure is final."""
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
-    if r.returncode != 0 and "Signal" in (r.stderr or ""):
-        print("first attempt lost a rank to a signal:\n" + _why(r))
-        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
-    return r
+    """Run a multi-rank bench command, ONCE (no retry: a rank lost to a signal fails the test -- with its Python and C++ stacks on
+    stderr: faulthandler, TORCH_SHOW_CPP_STACKTRACES)."""
+    env = dict(env, PYTHONFAULTHANDLER="1", TORCH_SHOW_CPP_STACKTRACES="1")
+    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
 
 
 def _check_line(r, world=2, frames=8):
