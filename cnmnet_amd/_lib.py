@@ -109,6 +109,7 @@ PROTOTYPES = {
     "cnm_conv2d_c8_f16": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "cnm_conv2d_cat2_c8_f16": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp,
                                      c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    "cnm_tune_gldsx": (c_i, [c_i]),
     "cnm_planesweep_cat_c8_f16": (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_sz, c_i, c_i, c_i, c_i, c_i, c_d, c_d, c_fp]),
     "cnm_upsample2x_c8_f16": (c_i, [c_fp, c_i, c_i, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "cnm_head_sigmoid_c8_f16": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_fp, c_f, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),

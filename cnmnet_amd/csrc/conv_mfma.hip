@@ -14,6 +14,7 @@
 // 20 floats so the ds_read_b128 fragment reads are bank-conflict free; global->register
 // prefetch of k-step t+1 overlaps the 32..128 MFMAs of k-step t.
 #include "cnm_common.h"
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -208,6 +209,30 @@ __global__ __launch_bounds__(256, CONV_MINW) void conv_mfma_f32_kernel(const Con
     }
 }
 
+// ------------------------------------------------------------------ fp16 path: the order of the reduction [r5]
+// A k-step is 64 halfs = 8 slots of one 16-byte (8-channel) group each.  G = channel groups of the input, NGB = G / 8 full
+// blocks of 8 groups, r = G % 8 left-over groups.  k-steps run
+//   main:      for ky: for gb < NGB: for kx:   slot w = group 8 gb + w at tap (ky, kx)
+//   left-over: for ky: for c < spk:            slot w = group 8 NGB + w % r at tap (ky, c tps + w / r),  tps = 8 / r taps per step,
+//                                              spk = ceil(ks / tps) steps per filter row (slots past the row's taps: zeros)
+// i.e. kx is the FASTEST index of a group block: the ks k-steps of one (ky, gb) read the SAME input rows shifted by one pixel
+// per step -- conv_gldsx_kernel stages that row block once and shifts its fragment addresses, conv_glds_kernel (stride 2, fused
+// upsampling, images narrower than 32 pixels) walks the same order tap by tap.  Packed filters follow it: [k-step][8 slots][Cout_pad][8 halfs].
+struct F16Walk {
+    int ks, NGB, r, tps, spk, nmain, nk;
+    __host__ __device__ F16Walk(int G, int ks_) : ks(ks_), NGB(G >> 3), r(G & 7) {
+        tps = r ? 8 / r : 0; spk = r ? (ks + tps - 1) / tps : 0;
+        nmain = ks * NGB * ks; nk = nmain + ks * spk;
+    }
+    // slot w of k-step kt -> tap (ky, kx), group g; false: the slot is padding (zero filter rows, no pixels)
+    __host__ __device__ bool slot(int kt, int w, int& ky, int& kx, int& g) const {
+        if (kt < nmain) { ky = kt / (NGB * ks); const int rem = kt - ky * NGB * ks, gb = rem / ks; kx = rem - gb * ks; g = 8 * gb + w; return true; }
+        const int q = kt - nmain; ky = q / spk; const int c = q - ky * spk, t = w / r;
+        kx = c * tps + t; g = 8 * NGB + w % r;
+        return t < tps && kx < ks && ky < ks;
+    }
+};
+
 // ------------------------------------------------------------------ fp16 implicit GEMM fed by LDS-DMA
 // The fp16 matrix pipe is 16x faster than the fp32 one, so the loader above (global -> registers -> ds_write_b128, one
 // barrier per 64 bytes of depth) would be LDS-store bound at ~30 % of the pipe.  This kernel moves both operands with
@@ -261,10 +286,8 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(const ConvArgs a) {
         vb1[pb] = ((unsigned)(img * a.Gin_tot + a.gin0) * (unsigned)HW + pix0) * 16u;
         vb2[pb] = ((unsigned)(img * a.Gin2_tot + a.gin2_0) * (unsigned)HW + pix0) * 16u;
     }
-    // (tap, channel group) of this wave's group in the next k-step to load: scalar state
-    int g = wave, ky = 0, kx = 0;
-    auto tap_norm = [&]() { while (g >= a.Gin) { g -= a.Gin; if (++kx == a.ks) { kx = 0; ++ky; } } };
-    tap_norm();
+    // (tap, channel group) of this wave's slot in a k-step: the walk above, scalar arithmetic per issue
+    const F16Walk walkk(a.Gin, a.ks);
     const unsigned HW16 = (unsigned)HW * 16u;
     // filter [k-step][8 groups][Cout_pad][16 B]: a piece = 64 consecutive rows of one group
     const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
@@ -287,7 +310,9 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(const ConvArgs a) {
 #ifdef GLDS_PROBE
 #undef wrsrc
 #endif
-        bool s1 = g < a.Gsplit, tapok = ky < a.ks;
+        int g, ky, kx;
+        bool tapok = walkk.slot(kt, wave, ky, kx, g);
+        const bool s1 = g < a.Gsplit;
 #ifdef GLDS_PROBE   // traffic experiment (tools/f16_traffic_probe.sh; wrong results): 1 = pixel pieces fetched for the first tap only, 2 = filter pieces for the first k-step only, 3 = both
         if ((GLDS_PROBE & 1) && (ky | kx)) tapok = false;
 #endif
@@ -311,7 +336,6 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(const ConvArgs a) {
             }
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(B + pb * 1024), 16, voff, soff, 0, 0);
         }
-        g += 8; tap_norm();
     };
 
     f32x16 acc[CI][PI];
@@ -465,6 +489,187 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(const ConvArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ fp16 implicit GEMM, row-extended pixel operand [r5]
+// conv_glds_kernel fetches the pixel operand of EVERY k-step from L2 -- for a k x k filter the same input rows k times per
+// filter row, shifted by one pixel.  profiles/r4_f16_traffic_probe.txt measured what that costs: with the pixel pieces of
+// all taps but the first not fetched, the 7x7 / 5x5 layers run 22-30 % faster, the 3x3 layers 3-9 %.  This kernel does not
+// fetch them: a tile is TP consecutive output pixels in raster order (whole image rows, or an aligned fraction of one), and for
+// one filter row ky and one block of 8 channel groups the input rows it needs are staged ONCE as a row-extended image
+//   [8 groups][segment = tile row][seglen + 8 slots of 16 B]   (slot j of a segment = input pixel x0 - pad + j; out-of-image = DMA zeros)
+// which the ks k-steps (ky, gb, kx = 0 .. ks-1) of the walk above all read -- the MFMA B fragment of k-step kx is the same
+// 32-consecutive-rows ds_read_b128 as in conv_glds_kernel, its base moved by kx * 16 bytes.  Filters arrive per k-step as
+// before (three LDS buffers); the pixel images are double-buffered per (ky, gb) block and in flight a whole block early.
+// A single left-over group (Cin = 8 n + 1 .. 8: the cost volume's RGB group, the decoder's disparity channel) takes one
+// k-step per filter row: its 8 slots are the taps kx = 0 .. 7 of that ONE group, i.e. the same one-group image read at
+// plane pitch 16 bytes -- slot s is the image moved by s pixels.
+// Scope: stride 1, W a multiple of 32 and (H W) a multiple of TP, at most one left-over group; everything else (stride 2,
+// the fused up_conv, the 12 x 16 and 6 x 8 levels) stays on conv_glds_kernel, which walks the same filter order.
+template <int TC, int TP, int WTC, int WTP>
+__global__ __launch_bounds__(512) void conv_gldsx_kernel(const ConvArgs a) {
+    constexpr int WC = TC / WTC, WP = TP / WTP, CI = WTC / 32, PI = WTP / 32;
+    static_assert(WC * WP == 8 && TC % 64 == 0 && TP % 64 == 0 && WTC % 32 == 0 && WTP % 32 == 0, "8 waves");
+    constexpr int AB = 8 * TC * 16, NPA = TC / 64;                      // filter image of a k-step; its DMA pieces per group
+    constexpr int NSL = TP + 64, NPX = NSL / 64;                        // slots of one group's row-extended image (8 halo slots per segment, <= 8 segments); its DMA pieces
+    constexpr int BXG = NSL * 16, BX = 8 * BXG;                         // bytes of one group's image / of a block of 8 groups
+    constexpr int NBUF = (3 * AB + 2 * BX + 2 * BXG) <= 160 * 1024 ? 3 : 2;
+    __shared__ __attribute__((aligned(16))) char smem[NBUF * AB + 2 * BX + 2 * BXG];   // 128 x 256: 48 + 80 + 10 KB; 256 x 256: 64 + 80 + 10 KB
+    char* const Abuf = smem;
+    char* const Xbuf = smem + NBUF * AB;
+    char* const Lbuf = smem + NBUF * AB + 2 * BX;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wc = wave / WP, wp = wave % WP;
+    const int tilesC = a.Cout_pad / TC;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int c0 = (tile % tilesC) * TC, m0 = (tile / tilesC) * TP;
+    const int HW = a.H * a.W, W = a.W, H = a.H;
+    const F16Walk walkk(a.Gin, a.ks);
+    const int ks = a.ks, pad = a.pad, NGB = walkk.NGB, nmain = walkk.nmain, nk = walkk.nk;
+
+    // ---- the tile: TP consecutive pixels of ONE image (HW % TP == 0), segments = image rows (or one aligned row fraction)
+    const int img = m0 / HW, rem0 = m0 - img * HW, oy0 = rem0 / W, ox0 = rem0 - oy0 * W;
+    const int seglen = TP < W ? TP : W, nseg = TP / seglen, SEGW = seglen + 8;
+    const int lgseg = 31 - __builtin_clz(seglen);                       // seglen is a power of two (W % 32 == 0 and TP | W or W | TP, checked by the launcher)
+    // staging: lane = slot 64 p + lane of piece p of this wave's group
+    int vbx[NPX], ybx[NPX]; bool xok[NPX];   // (vbx as int: with an unsigned array read inside the staging lambda hipcc silently emits no host stub for this template)
+    const unsigned base1 = (unsigned)(img * a.Gin_tot + a.gin0) * (unsigned)HW, base2 = (unsigned)(img * a.Gin2_tot + a.gin2_0) * (unsigned)HW;
+    {
+        const float inv_segw = 1.0f / (float)SEGW;
+#pragma unroll
+        for (int p = 0; p < NPX; ++p) {
+            const int slot = 64 * p + lane;
+            const int seg = (int)(((float)slot + 0.5f) * inv_segw), j = slot - seg * SEGW;
+            const int x = ox0 + j - pad;
+            ybx[p] = oy0 + seg;
+            xok[p] = seg < nseg && (unsigned)x < (unsigned)W;
+            vbx[p] = (ybx[p] * W + x) * 16;
+        }
+    }
+    const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
+    const unsigned wlane = ((unsigned)c0 + (unsigned)lane) * 16u;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+
+    auto issue_a = [&](int kt, int buf) {                               // filters of k-step kt (this wave: slot `wave`)
+        char* A = Abuf + buf * AB + wave * TC * 16;
+        const unsigned wsoff = (unsigned)(kt * 8 + wave) * (unsigned)a.Cout_pad * 16u;
+#pragma unroll
+        for (int p = 0; p < NPA; ++p)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr)(A + p * 1024), 16, wlane + p * 1024u, wsoff, 0, 0);
+    };
+    // one group's row-extended image for filter row ky: pieces [p0, p1) into `dst`
+    auto issue_rows = [&](int g, int ky, char* dst, int p0, int p1) {
+        const bool s1 = g < a.Gsplit;
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s1 ? a.in : a.in2), 0, s1 ? a.in_bytes : a.in2_bytes, 0x00020000);
+        const unsigned soff = ((s1 ? base1 : base2) + (unsigned)(s1 ? g : g - a.Gsplit) * (unsigned)HW) * 16u;
+        const int dy = ky - pad;
+        const unsigned tapoff = (unsigned)(dy * W) * 16u;
+#pragma unroll
+        for (int p = 0; p < NPX; ++p) {
+            if (p < p0 || p >= p1) continue;
+            const bool ok = xok[p] & ((unsigned)(ybx[p] + dy) < (unsigned)H);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(dst + p * 1024), 16, ok ? (unsigned)vbx[p] + tapoff : 0xFFFFFFFFu, soff, 0, 0);
+        }
+    };
+    // block bi = (ky, gb): this wave stages group 8 gb + wave; left-over image of filter row q: wave w < NPX stages piece w
+#define GLDSX_ISSUE_BLOCK(bi_) do { const int b_ = (bi_), ky_ = b_ / NGB, gb_ = b_ - ky_ * NGB; issue_rows(8 * gb_ + wave, ky_, Xbuf + (b_ & 1) * BX + wave * BXG, 0, NPX); } while (0)
+#define GLDSX_ISSUE_LEFT(q_) do { const int l_ = (q_); if (wave < NPX) issue_rows(8 * NGB, l_, Lbuf + (l_ & 1) * BXG, wave, wave + 1); } while (0)
+
+    f32x16 acc[CI][PI];
+#pragma unroll
+    for (int i = 0; i < CI; ++i)
+#pragma unroll
+        for (int j = 0; j < PI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int frow = lane & 31, kh = lane >> 5;
+    unsigned rowoff[PI];
+#pragma unroll
+    for (int j = 0; j < PI; ++j) {
+        const int R = wp * WTP + 32 * j + frow, seg = R >> lgseg, within = R & (seglen - 1);
+        rowoff[j] = (unsigned)(seg * SEGW + within) * 16u;
+    }
+    // B fragments of slot pair s: bbase + (2 s + kh) * pitch + rowoff[j]
+    // (two lambdas from one macro, not a generic lambda: hipcc emits no host stub for a __global__ template whose body holds one)
+#define GLDSX_COMPUTE(NAME, PITCH)                                                                                                   \
+    auto NAME = [&](int abuf, const char* bbase) {     /* PITCH: a compile-time constant, so that every fragment address is one register + an immediate */ \
+        constexpr unsigned pitch = (PITCH);                                                                                          \
+        const char* Ab = Abuf + abuf * AB + (kh * TC + wc * WTC + frow) * 16;                                                        \
+        const char* Bb = bbase + kh * pitch;                                                                                         \
+        f16x8 af[2][CI], bf[2][PI];                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < CI; ++i) af[0][i] = *reinterpret_cast<const f16x8*>(Ab + 32 * i * 16);                 \
+        _Pragma("unroll") for (int j = 0; j < PI; ++j) bf[0][j] = *reinterpret_cast<const f16x8*>(Bb + rowoff[j]);                   \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                                              \
+            if (s < 3) {                                                                                                             \
+                _Pragma("unroll") for (int i = 0; i < CI; ++i) af[(s + 1) & 1][i] = *reinterpret_cast<const f16x8*>(Ab + (2 * (s + 1) * TC + 32 * i) * 16); \
+                _Pragma("unroll") for (int j = 0; j < PI; ++j) bf[(s + 1) & 1][j] = *reinterpret_cast<const f16x8*>(Bb + 2 * (s + 1) * pitch + rowoff[j]); \
+            }                                                                                                                        \
+            _Pragma("unroll") for (int i = 0; i < CI; ++i)                                                                           \
+                _Pragma("unroll") for (int j = 0; j < PI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s & 1][i], bf[s & 1][j], acc[i][j], 0, 0, 0); \
+        }                                                                                                                            \
+        constexpr int NR = CI + PI, NM = CI * PI;     /* fragment reads of pair s + 1 ISSUED before the MFMAs of pair s (as in conv_glds_kernel) */ \
+        __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);                                                                          \
+        _Pragma("unroll") for (int s = 0; s < 3; ++s) { __builtin_amdgcn_sched_group_barrier(0x100, NR, 0); __builtin_amdgcn_sched_group_barrier(0x008, NM, 0); } \
+        __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);                                                                          \
+    }
+    GLDSX_COMPUTE(compute_main, (unsigned)BXG);
+    GLDSX_COMPUTE(compute_left, 16u);
+#undef GLDSX_COMPUTE
+    // Every step issues its pixel images FIRST and its filter pieces LAST: vmcnt retires in order, so "all but the newest NPA
+    // operations" = everything but the filters of the step after next.
+    auto wait_dma = [&](bool filters_in_flight) {
+        if (NBUF == 3 && filters_in_flight) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // not __syncthreads(): its fence would drain the DMA left in flight
+    };
+    const int nblocks = ks * NGB;
+    GLDSX_ISSUE_BLOCK(0);
+    issue_a(0, 0);
+    if (NBUF == 3 && nk > 1) issue_a(1, 1);
+    wait_dma(nk > 1);
+    int cur = 0, nxt = NBUF - 1;
+    int bi = 0, kx = 0;                                                 // main walk: block, tap within the block
+    for (int kt = 0; kt < nmain; ++kt) {
+        // images first: the next block at the first tap of this one; the first left-over image one step early
+        if (kx == 0 && bi + 1 < nblocks) GLDSX_ISSUE_BLOCK(bi + 1);
+        if (walkk.r && kt + 1 == nmain) GLDSX_ISSUE_LEFT(0);
+        if (kt + NBUF - 1 < nk) issue_a(kt + NBUF - 1, nxt);
+        compute_main(cur, Xbuf + (bi & 1) * BX + kx * 16);
+        wait_dma(kt + 2 < nk);
+        cur = cur + 1 == NBUF ? 0 : cur + 1; nxt = nxt + 1 == NBUF ? 0 : nxt + 1;
+        if (++kx == ks) { kx = 0; ++bi; }
+    }
+    for (int kt = nmain; kt < nk; ++kt) {                               // the left-over group: one k-step per filter row
+        const int q = kt - nmain;
+        if (q + 1 < ks) GLDSX_ISSUE_LEFT(q + 1);
+        if (kt + NBUF - 1 < nk) issue_a(kt + NBUF - 1, nxt);
+        compute_left(cur, Lbuf + (q & 1) * BXG);
+        wait_dma(kt + 2 < nk);
+        cur = cur + 1 == NBUF ? 0 : cur + 1; nxt = nxt + 1 == NBUF ? 0 : nxt + 1;
+    }
+
+#undef GLDSX_ISSUE_BLOCK
+#undef GLDSX_ISSUE_LEFT
+
+    // ---- epilogue: acc row = cout (r&3)+8*(r>>2)+4*(lane>>5), col = pixel lane&31
+#pragma unroll
+    for (int j = 0; j < PI; ++j) {
+        const int pix = rem0 + wp * WTP + j * 32 + (lane & 31);
+#pragma unroll
+        for (int i = 0; i < CI; ++i) {
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int c = c0 + wc * WTC + i * 32 + 8 * qd + 4 * (lane >> 5);
+                if (c >= a.Cout) continue;
+                const float4 b = a.bias ? *reinterpret_cast<const float4*>(a.bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 v = make_float4(acc[i][j][4 * qd + 0] + b.x, acc[i][j][4 * qd + 1] + b.y, acc[i][j][4 * qd + 2] + b.z, acc[i][j][4 * qd + 3] + b.w);
+                if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                const f16x4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};   // c8: channels c..c+3 = half of the 16-byte group c/8
+                char* o = reinterpret_cast<char*>(a.out + c4_offset(img, a.Gout_tot, a.gout0 + (c >> 3), HW, pix)) + (c & 4) * 2;
+                *reinterpret_cast<f16x4*>(o) = h;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ weight packing
 __global__ void pack_conv_kernel(const float* __restrict__ w, const float* __restrict__ gamma,
                                  const float* __restrict__ var, float eps, int Cout, int Cout_pad, int Cin, int ks, int rot,
@@ -544,8 +749,23 @@ static int lds_per_block() {                                            // bytes
 }
 static int g_glds_tile = 0;
 extern "C" int cnm_tune_glds_tile(int n) { const int old = g_glds_tile; if (n >= 0 && n <= 5) g_glds_tile = n; return old; }
+static int g_gldsx = 1;                                                 // 1: stride-1 layers that qualify run on conv_gldsx_kernel (row-extended pixel operand); 0: conv_glds_kernel everywhere (A/B)
+extern "C" int cnm_tune_gldsx(int n) { const int old = g_gldsx; if (n == 0 || n == 1) g_gldsx = n; return old; }
+// conv_gldsx_kernel's scope (see the kernel): returns false when the layer stays on conv_glds_kernel
+static bool launch_gldsx(const ConvArgs& a, hipStream_t s) {
+    const F16Walk wk(a.Gin, a.ks);
+    if (!g_gldsx || g_glds_tile || a.stride != 1 || a.Ho != a.H || a.Wo != a.W || a.W % 32 || a.W > 256 || (a.W & (a.W - 1)) || (a.H * a.W) % 256 || wk.NGB < 1 || wk.r > 1) return false;
+    if (lds_per_block() < 160 * 1024) return false;
+    auto wgs = [&](int tc, int tp) { return (long long)(a.Cout_pad / tc) * (a.M / tp); };
+    const bool c128 = a.Cout_pad % 128 == 0, c256 = a.Cout_pad % 256 == 0;
+    if (c256 && (wgs(256, 256) + 255) / 256 * 2.0 / 1.15 < (double)((wgs(128, 256) + 255) / 256)) conv_gldsx_kernel<256, 256, 128, 64><<<(unsigned)wgs(256, 256), 512, 0, s>>>(a);
+    else if (c128) conv_gldsx_kernel<128, 256, 64, 64><<<(unsigned)wgs(128, 256), 512, 0, s>>>(a);
+    else conv_gldsx_kernel<64, 256, 32, 64><<<(unsigned)wgs(64, 256), 512, 0, s>>>(a);
+    return true;
+}
 template <bool UPS = false>
 static void launch_glds(const ConvArgs& a, hipStream_t s) {
+    if (!UPS && launch_gldsx(a, s)) return;
     auto wgs = [&](int tc, int tp) { return (long long)(a.Cout_pad / tc) * cnm_ceil_div(a.M, tp); };
     const bool c128 = a.Cout_pad % 128 == 0, c256 = a.Cout_pad % 256 == 0;
     const long long big = c128 ? wgs(128, 256) : wgs(64, 512);
@@ -617,7 +837,7 @@ static int conv_dispatch(const float* in, int Gin_total, int gin0, int Gin,
     const long long t64x128 = (long long)(a.Cout_pad / 64) * cnm_ceil_div(a.M, 128);
     if (f16) {                                                                 // fp16: every layer on the LDS-DMA kernel (measured faster down to 6x8 images)
         CNM_REQUIRE(!transposed, CNM_ERR_BAD_ARG);
-        a.nk = (ksize * ksize * 8 * Gin + 63) / 64;                            // k-steps of 64 halfs
+        a.nk = F16Walk(Gin, ksize).nk;                                         // k-steps of 64 halfs
         a.w_bytes = (unsigned)((size_t)a.nk * 64 * a.Cout_pad * 2);
         launch_glds(a, s);
     } else if (transposed && tstride == 2) {
@@ -711,21 +931,22 @@ __global__ void pack_conv_f16_kernel(const float* __restrict__ w, const float* _
     // [k-step of 64][8 channel groups][Cout_pad][8 halfs]: the LDS image of conv_glds_kernel, DMA piece by DMA piece
     const int e = (int)(idx % 8);
     const int co = (int)((idx / 8) % Cout_pad);
-    const int kgrp = (int)((idx / 8) / Cout_pad);           // kstep * 8 + group
-    const int k = kgrp * 8 + e;
-    const int Cp = 8 * ((Cin + 7) / 8);
-    const int tap = k / Cp, cp = k - tap * Cp;
+    const int kgrp = (int)((idx / 8) / Cout_pad);           // kstep * 8 + slot
+    const F16Walk walkk((Cin + 7) / 8, ks);
+    int ky, kx, g;
+    const bool ok = walkk.slot(kgrp >> 3, kgrp & 7, ky, kx, g);
+    const int cp = 8 * g + e;
     float v = 0.f;
-    if (tap < ks * ks && cp < Cin && co < Cout) {
+    if (ok && cp < Cin && co < Cout) {
         const int ci = (cp + rot) % Cin;
         double s = 1.0;
         if (gamma) s = (double)gamma[co] / sqrt((double)var[co] + (double)eps);
-        v = (float)((double)w[((size_t)co * Cin + ci) * ks * ks + tap] * s);
+        v = (float)((double)w[((size_t)co * Cin + ci) * ks * ks + ky * ks + kx] * s);
     }
     wp[idx] = (_Float16)v;
 }
 
-static inline int conv_kpad_f16(int Cin, int ks) { return ((ks * ks * 8 * ((Cin + 7) / 8) + 63) / 64) * 64; }
+static inline int conv_kpad_f16(int Cin, int ks) { return F16Walk((Cin + 7) / 8, ks).nk * 64; }
 
 extern "C" size_t cnm_packed_conv_halfs(int Cout, int Cin, int ksize) {
     if (Cout <= 0 || Cin <= 0 || ksize <= 0) return 0;
@@ -791,7 +1012,7 @@ extern "C" int cnm_conv3x3_upsampled_c8_f16(const void* in, int Gin_total, int g
     a.Gin_tot = Gin_total; a.gin0 = gin0; a.Gin = Gin;
     a.Gout_tot = Gout_total; a.gout0 = gout0; a.Cout = 4 * Cout; a.Cout_pad = round64(4 * Cout);
     a.ks = 3; a.stride = 1; a.pad = 1;
-    a.nk = (9 * 8 * Gin + 63) / 64; a.w_bytes = (unsigned)((size_t)a.nk * 64 * a.Cout_pad * 2);
+    a.nk = F16Walk(Gin, 3).nk; a.w_bytes = (unsigned)((size_t)a.nk * 64 * a.Cout_pad * 2);
     a.M = N * H * W; a.relu = relu; a.ring = with_ring;
     launch_glds<true>(a, cnm_stream(stream));
     CNM_LAUNCH_CHECK();

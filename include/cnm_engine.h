@@ -78,6 +78,11 @@ int cnm_tune_upsampled_min_pixels(int n);
  *   workgroup count, stride and reduction depth; 1 .. 5 force 128x256 / 64x512 / 64x128 / 128x512 / 256x256 (falling back
  *   to 64x512 when Cout is not a multiple of 128, to 128x256 when 256x256 does not divide it); any other n only queries. */
 int cnm_tune_glds_tile(int n);
+/* gldsx: 1 (default) = fp16 stride-1 convolutions whose shape qualifies (W a power of two in 32 .. 256, H W a multiple of 256, at
+ *   most one left-over channel group beyond a multiple of 8) run on the row-extended kernel, which stages the pixel operand of a
+ *   filter row once per k x k filter row instead of once per tap; 0 = the tap-by-tap LDS-DMA kernel everywhere (A/B); a forced
+ *   glds_tile also selects the latter.  Returns the previous value. */
+int cnm_tune_gldsx(int n);
 /* wino36_staged: 1 (default) lets the F(4x4,3x3) entry points (plain, concatenated input, fused up_conv) run the
  *   LDS-staged persistent kernel (conv_winograd4s.hip: 128 output channels x 16 tiles per workgroup, input patch by
  *   LDS-DMA) where the output-channel count is a multiple of 128, the image is at least six tiles wide and the units fill
@@ -468,7 +473,9 @@ int cnm_refinenet_forward_multi_f32(const cnm_layer_weights* weights, float idep
  * (pixel, group) exactly like c4, so views are again (base, G_total, g0) with G counted in 8-channel groups.
  * Convolutions run on v_mfma_f32_32x32x16_f16 with fp32 accumulation, fp32 bias/ReLU, fp16 store; the plane
  * sweep computes in fp32 and stores fp16; heads and normals stay fp32.  Tolerance vs the fp32 path is stated in
- * tests/test_gpu_fp16.py.  Weights: [Kpad/32][round64(Cout)][32 halfs], k = (ky*ks+kx)*8*Gin + cpacked. */
+ * tests/test_gpu_fp16.py.  Weights: [k-step of 64 halfs][8 slots][round64(Cout)][8 halfs]; [r5] the k-steps run filter row by
+ * filter row, 8-group block by block, tap by tap within the row -- slot w of step (ky, gb, kx) = channel group 8 gb + w at tap
+ * (ky, kx) -- and the G % 8 left-over groups follow with their taps as slots (cnmnet_amd/csrc/conv_mfma.hip: F16Walk). */
 size_t cnm_packed_conv_halfs(int Cout, int Cin, int ksize);
 int cnm_pack_conv_bn_f16(const float* w_oihw, const float* bn_gamma, const float* bn_beta,
                          const float* bn_mean, const float* bn_var, const float* bias, float eps,

@@ -46,6 +46,43 @@ def test_conv_f16_vs_fp32_torch(dev, cin, cout, k, stride, rot, N, H, W, tile):
         lib.cnm_tune_glds_tile(old_tile)
 
 
+@pytest.mark.parametrize("cin,cout,k,rot,N,H,W", [(67, 128, 7, 3, 2, 16, 256), (128, 256, 5, 0, 1, 32, 128), (65, 64, 3, 0, 2, 16, 64), (257, 128, 3, 0, 1, 32, 32),
+                                                    (64, 64, 3, 0, 1, 8, 32), (513, 256, 3, 0, 1, 16, 64), (128, 512, 3, 0, 3, 8, 32), (72, 64, 5, 0, 1, 8, 64)])
+def test_conv_f16_row_extended_kernel(dev, cin, cout, k, rot, N, H, W):
+    """conv_gldsx_kernel [r5] (stride 1, W a power of two >= 32, H W a multiple of 256: the pixel operand of a filter row staged once and
+    read shifted by the ks taps): every tile instance (Cout 64 / 128 / 256+), tiles of one row / several rows (W = 256 .. 32), filter
+    sizes 3 / 5 / 7, group counts 8 n (no left-over step) and 8 n + 1 (the one-group left-over step: taps as slots), rotation -- against
+    torch on the fp16-rounded operands, and against conv_glds_kernel on the same packed filter (same products, other summation order)."""
+    from cnmnet_amd import _lib, ops
+    lib = _lib.load()
+    assert lib.cnm_tune_gldsx(1) in (0, 1)
+    try:
+        got_x = _conv_f16_case(dev, cin, cout, k, 1, rot, N, H, W)
+        lib.cnm_tune_gldsx(0)
+        got_o = _conv_f16_case(dev, cin, cout, k, 1, rot, N, H, W)
+    finally:
+        lib.cnm_tune_gldsx(1)
+    assert np.abs(got_x - got_o).max() <= 2e-3 * np.abs(got_o).max()
+
+
+def test_conv_f16_row_extended_two_inputs(dev):
+    """The row-extended kernel reading two input views (torch.cat without the copy: 32 + 1 channel groups, the split inside the last block)."""
+    from cnmnet_amd import _lib, ops
+    rng = np.random.default_rng(5)
+    N, H, W, ca, cb, cout = 2, 16, 64, 256, 8, 128
+    xa, xb = T(rng.standard_normal((N, ca, H, W)).astype(np.float32)), T(rng.standard_normal((N, cb, H, W)).astype(np.float32))
+    w = T((rng.standard_normal((cout, ca + cb, 3, 3)) * 0.05).astype(np.float32)); bias = T(rng.normal(0, 0.2, cout).astype(np.float32))
+    want = F.relu(F.conv2d(torch.cat((xa, xb), 1).half().float(), w.half().float(), bias, padding=1)).numpy()
+    wp, bp = ops.pack_conv_f16(w.to(dev), None, bias.to(dev), 0)
+    a8, b8 = ops.nchw_to_c8(xa.to(dev)), ops.nchw_to_c8(xb.to(dev))
+    out = torch.empty(N, cout // 8, H, W, 8, device=dev, dtype=torch.float16)
+    lib = _lib.load()
+    _lib.check(lib.cnm_conv2d_cat2_c8_f16(a8.data_ptr(), ca // 8, 0, ca // 8, b8.data_ptr(), 1, 0, 1, out.data_ptr(), cout // 8, 0, cout,
+                                          wp.data_ptr(), bp.data_ptr(), N, H, W, 3, 1, 1, torch.cuda.current_stream().cuda_stream))
+    got = ops.c8_to_nchw(out, cout).cpu().numpy()
+    assert np.abs(got - want).max() < 1.5e-3 * np.abs(want).max()
+
+
 def _conv_f16_case(dev, cin, cout, k, stride, rot, N, H, W):
     from cnmnet_amd import ops
     rng = np.random.default_rng(cin + k)
@@ -59,6 +96,7 @@ def _conv_f16_case(dev, cin, cout, k, stride, rot, N, H, W):
     got = ops.c8_to_nchw(ops.conv2d_c8(ops.nchw_to_c8(xr.to(dev)), wp, bp, cout, k, stride, True), cout).cpu().numpy()
     scale = np.abs(want).max()
     assert np.abs(got - want).max() < 1.5e-3 * scale, (np.abs(got - want).max(), scale)     # output rounding to fp16: 2^-11 relative
+    return got
 
 
 @pytest.mark.parametrize("cin,cout,N,H,W", [(128, 64, 2, 24, 40), (256, 128, 1, 13, 21), (64, 64, 3, 8, 8)])

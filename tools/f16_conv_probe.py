@@ -40,9 +40,11 @@ for N, Cin, Cout, H, W, k, st in CASES:
         assert os.environ.get("F16_PROBE_NOCHECK") == "1" or float((y - ref).abs().max()) == 0.0, (v, float((y - ref).abs().max()))
         res[v] = bench(fn)
     lib.cnm_tune_glds_tile(0)
+    lib.cnm_tune_gldsx(0); yo = fn().float(); res["old"] = bench(fn); lib.cnm_tune_gldsx(1)      # the automatic choice WITHOUT the row-extended kernel [r5]
+    rowx_diff = float((yo - fn().float()).abs().max())
     gf = 2.0 * Cout * Cin * k * k * (H // st) * (W // st) * N / 1e9
-    best = min((t, v) for v, t in res.items() if v)
-    tot_auto += res[0]; tot_best += best[0]
+    best = min((t, v) for v, t in res.items() if v and v != "old")
+    tot_auto += res[0]; tot_best += best[0]; tot_old = globals().get("tot_old", 0.0) + res["old"]; globals()["tot_old"] = tot_old
     print("N%2d %4d->%4d k%d s%d %3dx%-3d: auto %.3f ms (%4.0f TF) | " % (N, Cin, Cout, k, st, H, W, res[0], gf / res[0]) +
-          "  ".join("%s %.3f" % (NAMES[v], t) for v, t in res.items() if v) + " | best %s" % NAMES[best[1]])
-print("total auto %.2f ms, best-of %.2f ms" % (tot_auto, tot_best))
+          "  ".join("%s %.3f" % (NAMES[v], t) for v, t in res.items() if v and v != "old") + " | best %s | tap-by-tap kernel (gldsx=0) %.3f ms, max |difference| %.1e" % (NAMES[best[1]], res["old"], rowx_diff))
+print("total auto %.2f ms, best-of forced tiles %.2f ms, automatic choice without the row-extended kernel %.2f ms" % (tot_auto, tot_best, tot_old))
