@@ -485,8 +485,22 @@ def glds_tile(cout, m, nk, stride):
     return {1: "128, 256, 64, 64", 2: "64, 512, 64, 64", 3: "64, 128, 32, 32", 4: "128, 512, 64, 128", 5: "256, 256, 128, 64"}[v]
 
 
+def gldsx_tile(cout, cin, k, stride, n_img, h, w):
+    """Mirror of launch_gldsx (cnmnet_amd/csrc/conv_mfma.hip): the instance of the row-extended fp16 kernel that takes a layer, or None
+    when the layer stays on conv_glds_kernel (stride 2, images narrower than 32 or wider than 256 pixels, H W not a multiple of 256,
+    fewer than 8 or more than 8 n + 1 channel groups)."""
+    g = -(-cin // 8)
+    if stride != 1 or w % 32 or w > 256 or (w & (w - 1)) or (h * w) % 256 or g < 8 or g % 8 > 1:
+        return None
+    cp = -(-cout // 64) * 64
+    wgs = lambda tc: (cp // tc) * (n_img * h * w // 256)
+    if cp % 256 == 0 and -(-wgs(256) // 256) * 2.0 / 1.15 < -(-wgs(128) // 256):
+        return "256, 256, 128, 64"
+    return "128, 256, 64, 64" if cp % 128 == 0 else "64, 256, 32, 64"
+
+
 def f16_roofline(dev, frames):
-    """The fp16 engine's convolution layers (conv_glds_kernel, LDS-DMA implicit GEMM on v_mfma_f32_32x32x16_f16) at the shapes
+    """The fp16 engine's convolution layers (conv_gldsx_kernel / conv_glds_kernel, LDS-DMA implicit GEMMs on v_mfma_f32_32x32x16_f16) at the shapes
     of a step, each timed alone with HIP events: executed TFLOP/s of the instance that owns most of the time against the
     2.5 PF dense f16 MFMA peak (compare with conv_glds_kernel rows of profiles/r3_f16_kernel_stats.csv)."""
     from cnmnet_amd import _lib, ops
@@ -510,7 +524,8 @@ def f16_roofline(dev, frames):
                 x = ops.nchw_to_c8(torch.randn(n_img, cin, h, w, device=dev))
                 wp, bp = ops.pack_conv_f16(wt)
                 ms = event_ms(lambda: ops.conv2d_c8(x, wp, bp, L["Cout"], k, st, True), iters=IT, warm=WARM)
-                name = "conv_glds_kernel<%s, false>" % glds_tile(L["Cout"], n_img * ho * wo, (k * k * 8 * g8 + 63) // 64, st)
+                xt = gldsx_tile(L["Cout"], cin, k, st, n_img, h, w)
+                name = ("conv_gldsx_kernel<%s>" % xt) if xt else "conv_glds_kernel<%s, false>" % glds_tile(L["Cout"], n_img * ho * wo, (k * k * 8 * g8 + 63) // 64, st)
             e = per.setdefault(name, [0.0, 0.0, 0])
             e[0] += flop; e[1] += ms; e[2] += 1
     name, (flop, ms, n) = max(per.items(), key=lambda kv: kv[1][1])

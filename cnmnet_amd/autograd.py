@@ -351,6 +351,9 @@ class BatchNormReLUC4(torch.autograd.Function):
         else:
             ctx.save_for_backward(x, y, gamma, mean, invstd)
         ctx.relu, ctx.groups, ctx.recompute = relu, groups, BN_RECOMPUTE_MASK
+        # The recomputed mask is only right for a forward whose outputs came from bn_affine (train_ops.hip: bn_apply_kernel -- the ONE
+        # producer of this Function's y).  A future fused forward must either call bn_affine or clear this tag and keep y.
+        ctx.forward_affine = "bn_affine"
         return y
 
     @staticmethod
@@ -364,6 +367,7 @@ class BatchNormReLUC4(torch.autograd.Function):
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
         with torch.cuda.device(dev):
             if ctx.recompute:                               # `y` holds beta here (see forward)
+                assert getattr(ctx, "forward_affine", None) == "bn_affine", "the mask-recomputing backward needs the forward that rounds like bn_affine"
                 _lib.check(lib.cnm_bn_train_backward_zgb_c4_f32(
                     x.data_ptr(), dy.data_ptr(), gamma.detach().contiguous().data_ptr(), y.detach().contiguous().data_ptr(), mean.data_ptr(), invstd.data_ptr(),
                     int(ctx.relu), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), _bn_workspace(dev, G, ctx.groups).data_ptr(), N, C, H, W, ctx.groups, _s()))
