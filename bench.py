@@ -29,6 +29,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# Kernel arguments in DEVICE memory (HIP runtime switch, read when the runtime initialises): every kernel starts by reading its
+# arguments, and from host-coherent memory that is ~2 us before the first useful instruction -- measured on this step [r5]:
+# 707-708 against 703 frames/s, the plane-sweep launch 54.2 against 56.5 us (same box, alternating runs).  cnmnet_amd sets the same default.
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 import numpy as np   # noqa: E402
 import torch         # noqa: E402

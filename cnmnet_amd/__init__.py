@@ -1,0 +1,8 @@
+"""MI355X-native depth engine for CNMNet's hot path."""
+import os as _os
+
+# Kernel arguments in DEVICE memory: a HIP runtime switch that is read when the runtime initialises (the first HIP call of the
+# process), so it is set here, at import, unless the caller has chosen otherwise.  Every kernel begins by reading its arguments;
+# from host-coherent memory that costs ~2 us before its first useful instruction (bench.py, round 5: +0.6 % frames/s, -2.3 us
+# on the plane-sweep launch).
+_os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")

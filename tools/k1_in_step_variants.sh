@@ -5,6 +5,6 @@ cd "$(dirname "$0")/.."
 L=cnmnet_amd/lib
 for flags in "$@" ""; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize $flags -c cnmnet_amd/csrc/planesweep.hip -o $L/planesweep.o 2>/dev/null || { echo "build failed: $flags"; continue; }
-  hipcc --offload-arch=gfx950 -shared -fPIC -pthread $L/*.o -o $L/libcnm_engine.so
+  hipcc --offload-arch=gfx950 -shared -fPIC -pthread $(ls $L/*.o | grep -v _cblk0) -o $L/libcnm_engine.so
   echo -n "[$flags] "; tools/k1_in_step.sh
 done
