@@ -317,7 +317,7 @@ def conv_kernel(L, m, m4=0, h=0, w=0):
     return conv_tile(L["Cout"], m), 1.0
 
 
-def kernel_rooflines(dev, frames):
+def kernel_rooflines(dev, frames, step=None):
     """Per-kernel HIP-event timing of the dominant kernels at exactly the shapes of the timed
     region: every conv layer of both nets (grouped by kernel instance) and the plane sweep.
     `achieved` counts the flops the kernel EXECUTES on the matrix cores (what the MFMA roofline bounds);
@@ -419,15 +419,17 @@ def kernel_rooflines(dev, frames):
     def burst():
         for _ in range(reps):
             _lib.check(lib.cnm_planesweep_cat_c4_f32(*args))
-    burst_ms = event_ms(burst, iters=2, warm=1) / reps                     # 50 back-to-back launches: the sustained (hot) state
+    under_profiler = "rocprofiler" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
+    burst_ms = None if under_profiler else event_ms(burst, iters=2, warm=1) / reps     # 50 back-to-back launches: the sustained (hot) state
     # As in the step: every plane-sweep launch is followed by its consumer, conv1.0 (2 ms of MFMA work), and timed on
     # its own with a pair of HIP events on the launch stream.  Back-to-back bursts of this VALU-dense kernel pull the
     # clock down within ~1.5 ms (profiles/r2_k1_analysis.md), which no launch of the real pipeline ever sees.
     wt = torch.randn(128, 3 + PLANES, 7, 7, device=dev) * 0.02
     up, (_, bp) = ops.pack_winograd(wt, stride=1), ops.pack_conv(wt)
     n_it = 60
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_it)]
-    for i in range(-5, n_it):
+    n_loop = 0 if (under_profiler and step is not None) else n_it         # (under rocprofv3 only the launches of real steps: its per-kernel average is then the step's)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_loop)]
+    for i in range(-5 if n_loop else 0, n_loop):
         if i >= 0:
             ev[i][0].record()
         _lib.check(lib.cnm_planesweep_cat_c4_f32(*args))
@@ -436,7 +438,27 @@ def kernel_rooflines(dev, frames):
         ops.conv_rows_winograd_c4(out, up, bp, 128, 7, True, stride=1)
     torch.cuda.synchronize()
     per = sorted(a.elapsed_time(b) for a, b in ev)
-    ms = sum(per) / n_it
+    ms_conv_loop = sum(per) / n_loop if n_loop else None
+    # THE measurement [r5]: the launch INSIDE the timed workload -- `step` (the frame pipeline of the timed region) run n_it more times,
+    # its one plane-sweep launch bracketed by a pair of HIP events that the library records on the launch stream right around the
+    # kernel (cnm_debug_sweep_timing_arm / _read; events without the system-scope fence, so the closing one does not wait for the
+    # launch's 210 MB to be written back): the launch between its real neighbours, at the clocks and cache state of the step.
+    in_step = None
+    if step is not None:
+        import ctypes
+        for _ in range(5):
+            step()
+        _lib.check(lib.cnm_debug_sweep_timing_arm(n_it))
+        for _ in range(n_it):
+            step()                                                         # asynchronous: the host runs ahead, the launch finds its predecessors still on the GPU
+        buf = (ctypes.c_float * n_it)()
+        got = lib.cnm_debug_sweep_timing_read(ctypes.cast(buf, ctypes.c_void_p), n_it)
+        lib.cnm_debug_sweep_timing_arm(0)
+        torch.cuda.synchronize()
+        in_step = sorted(buf[i] for i in range(got)) if got == n_it else None
+    per_main = in_step if in_step else per
+    ms = sum(per_main) / len(per_main)
+    n_main = len(per_main)
     # algorithmic bytes per launch (cat-emit variant): per pair read ref 3HW*4 + read src 3HW*4
     # + write (D+3)HW*4; ref counted once per frame because one launch covers both sources of a frame
     pairs = frames * SRC
@@ -446,11 +468,15 @@ def kernel_rooflines(dev, frames):
              "traffic_uncorrected": pmc_traffic("planesweep_kernel<1>", raw=True),
              "target": 0.60, "met": bool(byts / ms / 1e6 / HBM_PEAK_GBS >= 0.60),             # BASELINE.json north_star: >= 60 % of the HBM roofline
              "algorithmic_bytes_per_launch": byts, "avg_launch_ms": ms,
-             "launch_ms": {"median": per[n_it // 2], "p10": per[n_it // 10], "p90": per[9 * n_it // 10], "n": n_it},
-             "burst_avg_launch_ms": burst_ms, "burst_frac": byts / burst_ms / 1e6 / HBM_PEAK_GBS,
-             "note": "one persistent launch per call (no pre-pass).  avg_launch_ms: %d launches, each between its own pair of HIP events on the "
-                     "launch stream and followed by its consumer (conv1.0) as in the step; burst_avg_launch_ms: 50 launches back to back "
-                     "(sustained, clock-throttled state)" % n_it}
+             "launch_ms": {"median": per_main[n_main // 2], "p10": per_main[n_main // 10], "p90": per_main[9 * n_main // 10], "n": n_main},
+             "measured": "inside the step" if in_step else "launch + consumer loop",
+             "avg_launch_ms_before_its_consumer_alone": ms_conv_loop,
+             "burst_avg_launch_ms": burst_ms, "burst_frac": (byts / burst_ms / 1e6 / HBM_PEAK_GBS) if burst_ms else None,
+             "note": "one persistent launch per call (no pre-pass).  avg_launch_ms: %d launches, each INSIDE a step of the timed pipeline, between a pair of HIP "
+                     "events (no system-scope fence) the library records on the launch stream right around the kernel (cnm_debug_sweep_timing_arm); avg_launch_ms_before_its_consumer_alone: "
+                     "%d launches of a synthetic loop (launch, then conv1.0 -- 2 ms of MFMA work -- again and again: every launch starts on a chip that conv1.0 "
+                     "has just driven to its power limit); burst_avg_launch_ms: 50 launches back to back (sustained, clock-throttled state; not run under rocprofv3, "
+                     "whose per-kernel averages should be those of the step)" % (n_main, n_it)}
     v = _by_kernel(_LIVE_VALU, "planesweep_kernel<1>")
     if v is not None and v.get("SQ_INSTS_VALU") and v.get("GRBM_GUI_ACTIVE"):
         # Why 0.60 of the HBM roof is out of this formulation's reach, as numbers.  SQ_ACTIVE_INST_VALU counts
@@ -918,7 +944,7 @@ def main():
         if not a.no_roofline and a.precision == "f32":
             if world == 1 and not a.no_live_traffic:
                 live_pmc()
-            line["roofline"], line["roofline_planesweep"] = kernel_rooflines(dev, B)
+            line["roofline"], line["roofline_planesweep"] = kernel_rooflines(dev, B, step=None if a.graph else (lambda: run(img, cams)))
             src = ("PMC passes of this run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE as child processes, FETCH_SIZE x 2)" if _LIVE_TRAFFIC is not None
                    else "PMC pass committed under profiles/r4_pmc_traffic.json, possibly of an earlier build (live passes: %s)" % _LIVE_TRAFFIC_WHY)
             line["roofline"]["traffic_note"] = line["roofline_planesweep"]["traffic_note"] = "HBM bytes per average launch, " + src

@@ -858,6 +858,34 @@ static int sweep_resident_workgroups() {
     return cached[dev];
 }
 
+// Measurement hook (bench.py): the next n plane-sweep launches of this process are each bracketed by a pair of HIP events recorded
+// on the launch's own stream right around the kernel -- the launch as it runs INSIDE the caller's step, between its real
+// neighbours.  The events are created WITHOUT the system-scope fence of a default hipEventRecord (hipEventDisableSystemFence): with
+// it the closing event first writes the launch's 210 MB of output back to system scope, and the bracket measures that flush.
+#include <vector>
+static std::vector<hipEvent_t> g_sweep_ev;                              // 2 per armed launch
+static int g_sweep_ev_next = 0, g_sweep_ev_armed = 0;
+extern "C" int cnm_debug_sweep_timing_arm(int n) {
+    for (hipEvent_t e : g_sweep_ev) (void)hipEventDestroy(e);
+    g_sweep_ev.clear(); g_sweep_ev_next = 0; g_sweep_ev_armed = 0;
+    if (n <= 0) return CNM_OK;
+    for (int i = 0; i < 2 * n; ++i) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess) { (void)hipGetLastError(); return CNM_ERR_LAUNCH; }
+        g_sweep_ev.push_back(e);
+    }
+    g_sweep_ev_armed = n;
+    return CNM_OK;
+}
+// elapsed milliseconds of the armed launches recorded so far (waits for the last one); returns how many were written to ms[]
+extern "C" int cnm_debug_sweep_timing_read(float* ms, int n) {
+    int k = 0;
+    for (; k < n && k < g_sweep_ev_next; ++k) {
+        if (hipEventSynchronize(g_sweep_ev[2 * k + 1]) != hipSuccess || hipEventElapsedTime(ms + k, g_sweep_ev[2 * k], g_sweep_ev[2 * k + 1]) != hipSuccess) { (void)hipGetLastError(); break; }
+    }
+    return k;
+}
+
 static int sweep_launch(int layout, const float* ref, const float* src, const float* hmkt, float* out,
                         float* ws, size_t ws_floats, int B, int S, int H, int W, int D,
                         double idepth_min, double idepth_max, void* stream) {
@@ -894,9 +922,15 @@ static int sweep_launch(int layout, const float* ref, const float* src, const fl
     a.nh = a.noct >= 2 ? std::min(nt - a.ne - a.nq, g * SWEEP_TAIL_HALVES / 16) : 0;
     a.nfull = nt - a.nh - a.nq - a.ne; a.nunits = a.nfull + 2 * a.nh + 4 * a.nq + 8 * a.ne;
     a.inv_tpp = 1.0f / (float)a.tiles_per_pair; a.inv_ntx = 1.0f / (float)a.ntx;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+#ifndef SWEEP_NO_TIMING_HOOK
+    if (g_sweep_ev_next < g_sweep_ev_armed) { ev0 = g_sweep_ev[2 * g_sweep_ev_next]; ev1 = g_sweep_ev[2 * g_sweep_ev_next + 1]; ++g_sweep_ev_next; }
+#endif
+    if (ev0) (void)hipEventRecord(ev0, cnm_stream(stream));
     if (layout == 0) planesweep_kernel<0><<<grid, SWEEP_NT, 0, cnm_stream(stream)>>>(a);
     else if (layout == 1) planesweep_kernel<1><<<grid, SWEEP_NT, 0, cnm_stream(stream)>>>(a);
     else planesweep_kernel<2><<<grid, SWEEP_NT, 0, cnm_stream(stream)>>>(a);
+    if (ev1) (void)hipEventRecord(ev1, cnm_stream(stream));
     CNM_LAUNCH_CHECK();
     return CNM_OK;
 }

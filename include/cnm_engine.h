@@ -146,6 +146,13 @@ int cnm_idepth_range_host(double idepth_scale, double* idepth_min, double* idept
  *     ws == NULL is allowed: tiles are then dealt to the workgroups with a fixed stride (no scratch, slower
  *     when tiles differ in cost). */
 size_t cnm_planesweep_workspace_floats(int B, int S, int H, int W);
+/* DEBUG / MEASUREMENT: cnm_debug_sweep_timing_arm(n) makes each of the next n plane-sweep launches of the process (any entry point,
+ * including the one inside cnm_depthnet_forward_*) record a HIP event before and after itself on its launch stream (events without
+ * the system-scope fence: the closing one does not wait for the launch's output to be written back); n <= 0 disarms and frees.
+ * cnm_debug_sweep_timing_read(ms, n) waits for the launches recorded so far and writes their elapsed milliseconds; returns the
+ * count.  How bench.py times the launch between its real neighbours of a step.  Not thread-safe. */
+int cnm_debug_sweep_timing_arm(int n);
+int cnm_debug_sweep_timing_read(float* ms, int n);
 int cnm_planesweep_volume_nchw_f32(const float* ref, const float* src, const float* hmkt, float* volume,
                                    float* ws, size_t ws_floats, int B, int S, int H, int W, int D,
                                    double idepth_min, double idepth_max, void* stream);
