@@ -829,8 +829,9 @@ def train_mode(a, dev, dist, pg, backend, rank, world):
                                    "256x192, 64 planes (BASELINE configs[2]: global batch 32 on 8 GPUs)" % B,
                        "global_batch": world * B, "parallelism": "dp%d" % world,
                        "allreduce_backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None,
-                       "launch": ("two HIP graphs (forward + refine backward | depthNet backward) with the refine net's gradient buckets launched in between, "
-                                  "remaining buckets + Adam eager" if world > 1 else "one HIP graph") if a.graph else "eager"}}
+                       "launch": (("three HIP graphs (forward + refine backward | depthNet decoder backward | encoder backward)" if step._graph_c is not None else
+                                   "two HIP graphs (forward + refine backward | depthNet backward)") + " with the gradient buckets of the part "
+                                  "just finished launched in between, remaining buckets + Adam eager" if world > 1 else "one HIP graph") if a.graph else "eager"}}
     if step.reducer is not None:
         r = step.reducer
         exposed = [e0.elapsed_time(e1) for e0, e1 in step.finish_events]

@@ -285,6 +285,13 @@ class depthNet(_EngineNet):
         c1 = _down_train(x0, self.conv1, 3, gr)
         c2 = _down_train(c1, self.conv2, 0, gr); c3 = _down_train(c2, self.conv3, 0, gr)
         c4 = _down_train(c3, self.conv4, 0, gr); c5 = _down_train(c4, self.conv5, 0, gr)
+        # what the ENCODER hands to the decoder goes through identity nodes that only the decoder reads (the encoder itself continues
+        # on the raw tensors, so the nodes are not ancestors of one another): a caller that replays backward in pieces -- the
+        # trainer's segmented HIP-graph step -- can stop the decoder's backward at them and start the encoder's from their gradients
+        c1d, c2d, c3d, c4d, c5d = (t.view_as(t) for t in (c1, c2, c3, c4, c5))
+        if getattr(self, "_enc_cut", None) is not None:                  # a list set by the trainer for the duration of one forward; otherwise nothing is kept
+            self._enc_cut += [c1d, c2d, c3d, c4d, c5d]
+        c1, c2, c3, c4, c5 = c1d, c2d, c3d, c4d, c5d
         i5 = cbr(torch.cat((_up_train(c5, self.upconv5, gr), c4), 1), self.iconv5)
         i4 = cbr(torch.cat((_up_train(i5, self.upconv4, gr), c3), 1), self.iconv4)
         d4 = ag.head(i4, self.disp4[0], s)

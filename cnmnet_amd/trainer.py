@@ -57,6 +57,10 @@ def make_adam(params, lr=1e-4, weight_decay=1e-5, capturable=False):
 SOURCES_IN_ONE_PASS = os.environ.get("CNM_SOURCES_IN_ONE_PASS", "1") != "0"   # depthNet over both sources of a frame in one pass with per-source BatchNorm statistics (depthNet.forward_sources)
 
 
+ENCODER_BLOCKS = ("conv1", "conv2", "conv3", "conv4", "conv5")      # depthNet's contracting half (depthNet_model.py:134-141)
+GRAPH_CUTS = int(os.environ.get("CNM_GRAPH_CUTS", "2"))             # multi-rank graph step: 2 = three graphs (refine | decoder | encoder), 1 = two (refine | depthNet): A/B
+
+
 class BucketedGradAllReduce:
     """Average gradients across ranks with bucketed, backward-overlapped all-reduces.
 
@@ -214,11 +218,12 @@ class TrainStepWoNormal:
         self.optimizer = make_adam(params, lr, weight_decay, capturable=bool(graph))          # utils/misc.py:31-33
         self.reducer = None
         if dist is not None and dist.is_initialized() and dist.get_world_size(group) > 1:
+            # segments of the segmented graph step (see _capture): refine net | depthNet's decoder | depthNet's encoder
             seg = {id(p): 0 for p in refine_net.parameters()}
-            seg.update({id(p): 1 for p in depth_net.parameters()})
+            seg.update({id(p): (2 if n.split(".")[0] in ENCODER_BLOCKS else 1) for n, p in depth_net.named_parameters()})
             self.reducer = BucketedGradAllReduce(params, dist, group=group, hooks=not graph, segment_of=seg if graph else None)
         self.l234 = IdepthLoss_234()
-        self.graph_mode, self._graph, self._graph_b, self._graph_key, self._cut = bool(graph), None, None, None, None
+        self.graph_mode, self._graph, self._graph_b, self._graph_c, self._graph_key, self._cut = bool(graph), None, None, None, None, None
         self.finish_events = None                                        # set to [] to collect (start, end) HIP events around the reducer's finish()
 
     def __call__(self, rgbs, cameras, disparities, depths, warmup_epoch=False):
@@ -260,6 +265,10 @@ class TrainStepWoNormal:
             refine_ids = self._refine_ids
             self.reducer.launch_ready(lambda p: id(p) in refine_ids)
             self._graph_b.replay()
+            if self._graph_c is not None:                  # [r5] third graph: the decoder's buckets leave under the encoder's backward
+                early = self._early_ids
+                self.reducer.launch_ready(lambda p: id(p) in early)
+                self._graph_c.replay()
             self._finish(self.reducer.reduce_all)
             self.optimizer.step()
         return _log_values(self._static_logs)
@@ -280,6 +289,23 @@ class TrainStepWoNormal:
         segmented = self.reducer is not None
         refine_params = [p for p in self.refine_net.parameters() if p.requires_grad]
         self._refine_ids = {id(p) for p in refine_params}
+        three = segmented and GRAPH_CUTS >= 2 and hasattr(self.depth_net, "_forward_train")
+        decoder_params = [p for n, p in self.depth_net.named_parameters() if p.requires_grad and n.split(".")[0] not in ENCODER_BLOCKS]
+        self._early_ids = self._refine_ids | {id(p) for p in decoder_params}
+
+        def backward_decoder(cut, gcut):
+            """Backward from depthNet's outputs down to what its encoder handed the decoder (the identity nodes depthNet records in
+            `_enc_cut`): the decoder's parameter gradients are final after it; returns what the encoder's backward starts from."""
+            enc = [c for c in self.depth_net._enc_cut if c.requires_grad]
+            grads = torch.autograd.grad(cut, decoder_params + enc, grad_outputs=gcut, allow_unused=True)
+            for p, g in zip(decoder_params, grads):
+                p.grad = g
+            ge = grads[len(decoder_params):]
+            return [c for c, g in zip(enc, ge) if g is not None], [g for g in ge if g is not None]
+
+        def forward(*a):
+            self.depth_net._enc_cut = [] if three else None
+            return fn(*a)
 
         def backward_refine(loss):
             """Backward from the loss down to depthNet's outputs (the cut recorded by losses()): the refine net's parameter gradients
@@ -294,10 +320,14 @@ class TrainStepWoNormal:
         with torch.cuda.stream(side):                       # warm-up off the default stream: Adam state and allocator pools exist before capture
             for _ in range(2):
                 with _step_scope():
-                    loss, logs = fn(*self._static_in)
+                    loss, logs = forward(*self._static_in)
                     self.optimizer.zero_grad(set_to_none=True)
                     if segmented:
-                        torch.autograd.backward(*backward_refine(loss))
+                        cut, gcut = backward_refine(loss)
+                        if three:
+                            cut, gcut = backward_decoder(cut, gcut)
+                        torch.autograd.backward(cut, gcut)
+                        del cut, gcut
                     else:
                         loss.backward()
                 if self.reducer is None:
@@ -305,20 +335,28 @@ class TrainStepWoNormal:
                 del loss, logs                              # no autograd graph of the warm-up may outlive it (its AccumulateGrad nodes carry their stream)
         torch.cuda.current_stream().wait_stream(side)
         self.optimizer.zero_grad(set_to_none=True)
-        self._graph, self._graph_b = torch.cuda.CUDAGraph(), None
+        self._graph, self._graph_b, self._graph_c = torch.cuda.CUDAGraph(), None, None
         if segmented:
-            # graph A: forward + backward through the refine net; graph B (same memory pool): depthNet's backward.  Between their
-            # replays the refine net's gradient buckets are handed to the collective.
+            # graph A: forward + backward through the refine net; graph B (same memory pool): depthNet's backward -- [r5] its DECODER's,
+            # with graph C for the encoder's.  Between the replays the gradient buckets of the part just finished are handed to the collective.
             with torch.cuda.graph(self._graph), _step_scope():
-                loss, logs = fn(*self._static_in)
+                loss, logs = forward(*self._static_in)
                 cut, gcut = backward_refine(loss)
             self._graph_b = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph_b, pool=self._graph.pool()), _step_scope():
-                torch.autograd.backward(cut, gcut)
+                if three:
+                    cut, gcut = backward_decoder(cut, gcut)
+                else:
+                    torch.autograd.backward(cut, gcut)
+            if three:
+                self._graph_c = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._graph_c, pool=self._graph.pool()), _step_scope():
+                    torch.autograd.backward(cut, gcut)
             del cut, gcut
+            self.depth_net._enc_cut = None
         else:
             with torch.cuda.graph(self._graph), _step_scope():
-                loss, logs = fn(*self._static_in)
+                loss, logs = forward(*self._static_in)
                 loss.backward()
                 if self.reducer is None:
                     self.optimizer.step()

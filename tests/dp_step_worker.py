@@ -126,10 +126,13 @@ def main():
                 if graph:
                     # the segmented replay: the refine net's buckets (no bucket mixes the two nets) left between the two graphs, the
                     # depthNet buckets after the second one
+                    # [r5] three graphs (refine | depthNet decoder | depthNet encoder): the refine net's AND the decoder's buckets leave early
                     r = st.reducer
                     n_refine = sum(all(id(p) in st._refine_ids for p in b) for b in r.buckets)
-                    assert st._graph_b is not None and n_refine >= 1 and r.hook_launches == n_refine and r.hook_launches + r.late_launches == len(r.buckets), \
-                        (n_refine, r.hook_launches, r.late_launches, len(r.buckets))
+                    n_early = sum(all(id(p) in st._early_ids for p in b) for b in r.buckets)
+                    assert st._graph_b is not None and st._graph_c is not None and n_refine >= 1 and n_early > n_refine, (n_refine, n_early)
+                    assert r.hook_launches == n_early and r.hook_launches + r.late_launches == len(r.buckets), \
+                        (n_refine, n_early, r.hook_launches, r.late_launches, len(r.buckets))
                 pair.append((lg, {k: p.detach().clone() for k, p in named(dg, rg)}))
             (le, pe), (lgr, pg_) = pair
             assert abs(le["loss"] - lgr["loss"]) <= 1e-5 * max(1.0, abs(le["loss"])), (one_pass, le["loss"], lgr["loss"])
