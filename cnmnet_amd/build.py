@@ -22,11 +22,15 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 # order leaves the dominant instance without VGPR spills, and without machine LICM fewer scalars are kept live across the phase loop
 # (67 instead of 71 v_readlane reloads per phase, tools/hotloop_proxy.sh; 5.52 vs 5.57 ms over a step's launches, tools/r4_wino_variants.sh).
 # CNM_NO_FILE_FLAGS=1 builds without them (A/B).
+# the fp16 heads (half_ops.hip) multiply half inputs by fp32 weights: left alone, the SLP vectoriser packs the products into v_pk_fma_f32 (which
+# issues as two FMAs) behind 240 v_cvt_f32_f16 per channel group; without it the compiler selects v_fma_mix_f32 (conversion folded in): 656
+# instead of 896 VALU instructions per group and lane.
 FILE_FLAGS = {"planesweep.hip": ["-fno-slp-vectorize"],
+              "half_ops.hip": ["-fno-slp-vectorize"],
               "conv_winograd4s.hip": ["-mllvm", "-greedy-regclass-priority-trumps-globalness=1", "-mllvm", "-disable-machine-licm"],
               "conv_rows_staged.hip": ["-mllvm", "-greedy-regclass-priority-trumps-globalness=1", "-mllvm", "-disable-machine-licm"]}   # 37 instead of 60 spilled SGPRs
 if os.environ.get("CNM_NO_FILE_FLAGS") == "1":
-    FILE_FLAGS = {"planesweep.hip": ["-fno-slp-vectorize"]}
+    FILE_FLAGS = {"planesweep.hip": ["-fno-slp-vectorize"], "half_ops.hip": ["-fno-slp-vectorize"]}
 
 
 def _stale(target, deps):

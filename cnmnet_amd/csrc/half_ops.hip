@@ -121,6 +121,83 @@ __global__ __launch_bounds__(64 * NS) void head_sigmoid_c8h_kernel(const float* 
     }
 }
 
+// The same head on the high-resolution levels [r5]: a workgroup walks HR output rows of 62 columns (lane = column, lanes 0 / 63 are halo), every
+// (pixel, group) chunk is loaded ONCE -- 10 row loads per 8 output rows, the left / right neighbours come from the adjacent lanes by DPP on the
+// packed halfs -- where the kernel above loads its nine taps separately (41.7 us per launch at the 192 x 256 levels against a 6-13 us HBM floor).
+// Four waves split the channel groups; partial sums meet in LDS in a fixed order.  Same scheme as head_sigmoid_c4_rows_kernel (pointwise.hip).
+typedef unsigned int hd_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned hd_shr1(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, false); }   // wave_shr:1 -> lane l gets lane l - 1
+__device__ __forceinline__ unsigned hd_shl1(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, false); }   // wave_shl:1 -> lane l gets lane l + 1
+template <int HR>
+__global__ __launch_bounds__(256) void head_sigmoid_c8h_rows_kernel(const float* __restrict__ in, int Gin_tot, int gin0, int G,
+                                                                    const float* __restrict__ wh, const float* __restrict__ bias,
+                                                                    float scale, float* __restrict__ disp,
+                                                                    float* __restrict__ up_out, int up_Gtot, int up_g,
+                                                                    int N, int H, int W, int tilesX, int tilesY) {
+    __shared__ float part[4][HR][64];
+    const int HW = H * W;
+    const int lane = threadIdx.x & 63, slice = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int b = blockIdx.x;
+    const int tx = b % tilesX; b /= tilesX;
+    const int ty = b % tilesY, n = b / tilesY;
+    const int x = tx * 62 - 1 + lane, y0 = ty * HR;
+    const bool xin = (unsigned)x < (unsigned)W;
+    const int gper = (G + 3) / 4, gbeg = slice * gper, gend = min(G, gbeg + gper);
+    float acc[HR];
+#pragma unroll
+    for (int r = 0; r < HR; ++r) acc[r] = 0.f;
+    for (int g = gbeg; g < gend; ++g) {
+        const hd_u32x4* base = reinterpret_cast<const hd_u32x4*>(in + c4_offset(n, Gin_tot, gin0 + g, HW, 0));
+        hd_u32x4 row[HR + 2];
+#pragma unroll
+        for (int i = 0; i < HR + 2; ++i) {                               // input rows y0-1 .. y0+HR: all loads first
+            const int iy = y0 + i - 1;
+            row[i] = (xin && (unsigned)iy < (unsigned)H) ? base[iy * W + x] : hd_u32x4{0u, 0u, 0u, 0u};
+        }
+        float wk[9][8];
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wk[k][j] = wh[(size_t)k * (G * 8) + g * 8 + j];   // wave-uniform
+#pragma unroll
+        for (int i = 0; i < HR + 2; ++i) {
+            union U { hd_u32x4 u; f16x8 h; } c, l, r;
+            c.u = row[i];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { l.u[q] = hd_shr1(c.u[q]); r.u[q] = hd_shl1(c.u[q]); }   // columns x-1 / x+1 (lanes 0 / 63 get garbage: halo lanes, no output)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int o = i - ky;                                    // output row of the tile this input row feeds through kernel row ky
+                if (o < 0 || o >= HR) continue;
+                float a = acc[o];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    a = fmaf((float)l.h[j], wk[ky * 3 + 0][j], a);
+                    a = fmaf((float)c.h[j], wk[ky * 3 + 1][j], a);
+                    a = fmaf((float)r.h[j], wk[ky * 3 + 2][j], a);
+                }
+                acc[o] = a;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < HR; ++r) part[slice][r][lane] = acc[r];
+    __syncthreads();
+    for (int r = slice; r < HR; r += 4) {
+        const int y = y0 + r;
+        if (lane == 0 || lane == 63 || !xin || y >= H) continue;
+        const float s = ((part[0][r][lane] + part[1][r][lane]) + (part[2][r][lane] + part[3][r][lane])) + bias[0];
+        const float d = scale / (1.f + expf(-s));
+        disp[(size_t)n * HW + y * W + x] = d;
+        if (up_out) {
+            const int Wo = 2 * W;
+            f16x8 v = {(_Float16)d, 0, 0, 0, 0, 0, 0, 0};
+            const size_t o = c4_offset(n, up_Gtot, up_g, 4 * HW, (2 * y) * Wo + 2 * x);
+            st8(up_out, o, v); st8(up_out, o + 4, v); st8(up_out, o + (size_t)Wo * 4, v); st8(up_out, o + (size_t)Wo * 4 + 4, v);
+        }
+    }
+}
+
 extern "C" int cnm_head_sigmoid_c8_f16(const void* in, int Gin_total, int gin0, int C,
                                        const float* w_head, const float* bias, float scale,
                                        float* disp, void* up_out, int up_Gtotal, int up_g,
@@ -128,6 +205,14 @@ extern "C" int cnm_head_sigmoid_c8_f16(const void* in, int Gin_total, int gin0, 
     CNM_REQUIRE(in && w_head && bias && disp && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, CNM_ERR_BAD_ARG);
     CNM_REQUIRE(gin0 >= 0 && gin0 + C / 8 <= Gin_total && (!up_out || (up_g >= 0 && up_g < up_Gtotal)), CNM_ERR_BAD_ARG);
     const long long total = (long long)N * H * W;
+    if (total >= 8ll * 96 * 128 && W >= 62 && C <= 128) {                  // enough tiles to fill the chip: the row-walking kernel
+        constexpr int HR = 8;
+        const int tilesX = cnm_ceil_div(W, 62), tilesY = cnm_ceil_div(H, HR);
+        head_sigmoid_c8h_rows_kernel<HR><<<(unsigned)(N * tilesX * tilesY), 256, 0, cnm_stream(stream)>>>(
+            static_cast<const float*>(in), Gin_total, gin0, C / 8, w_head, bias, scale, disp, static_cast<float*>(up_out), up_Gtotal, up_g, N, H, W, tilesX, tilesY);
+        CNM_LAUNCH_CHECK();
+        return CNM_OK;
+    }
     if (C >= 256) head_sigmoid_c8h_kernel<16><<<(unsigned)cnm_ceil_div_ll(total, 64), 1024, 0, cnm_stream(stream)>>>(
         static_cast<const float*>(in), Gin_total, gin0, C / 8, w_head, bias, scale, disp, static_cast<float*>(up_out), up_Gtotal, up_g, N, H, W);
     else head_sigmoid_c8h_kernel<4><<<(unsigned)cnm_ceil_div_ll(total, 64), 256, 0, cnm_stream(stream)>>>(

@@ -637,17 +637,18 @@ extern "C" int cnm_conv5x5_wgrad_winograd_c4_f32(const float* x, int Gx_total, i
 // normalisation, unbiased for the running update -- torch.nn.BatchNorm2d defaults).
 // S statistics groups (blockIdx.z): sample n belongs to group n % S -- the S sources of a frame processed as ONE batch keep the
 // batch statistics of S separate forward calls (reference train.py:164-167 calls depthNet once per source).  S = 1: plain BatchNorm.
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int N, int G, int HW, double* __restrict__ stats, int S) {
-    const int g = blockIdx.x, grp = blockIdx.z;
-    const long long total = (long long)((N - grp + S - 1) / S) * HW;
-    stats += (size_t)grp * 8 * G;
-    double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
-    for (long long i = (long long)blockIdx.y * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.y * blockDim.x) {
-        const int n = (int)(i / HW) * S + grp, pix = (int)(i % HW);
-        const float4 v = *reinterpret_cast<const float4*>(x + c4_offset(n, G, g, HW, pix));
-        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
-        q[0] += (double)v.x * v.x; q[1] += (double)v.y * v.y; q[2] += (double)v.z * v.z; q[3] += (double)v.w * v.w;
-    }
+// Grids [r5]: the reducing kernels run (group g, image x pixel-chunk, statistics group), the elementwise ones (pixel-chunk, plane n G + g):
+// a workgroup stays inside ONE c4 plane, its four channels' parameters are workgroup constants and the loops are free of the 64-bit
+// divisions (flat index -> plane, pixel) and per-element fp64 divisions the round-4 kernels paid per float4 -- those, not memory, bound them
+// (45 % of the HBM roof over a training step's 76 layers).
+struct BnGridY { int ypi, ni; };                                          // pixel chunks per image, images side by side in grid.y
+static BnGridY bn_grid_y(int Ng, int HW) {
+    BnGridY r;
+    r.ypi = (HW + 1023) / 1024; r.ypi = r.ypi < 1 ? 1 : (r.ypi > 16 ? 16 : r.ypi);
+    r.ni = 64 / r.ypi; r.ni = r.ni > Ng ? Ng : r.ni; if (r.ni < 1) r.ni = 1;
+    return r;
+}
+__device__ __forceinline__ void bn_block_sums(double (&s)[4], double (&q)[4], double* __restrict__ out, int g) {
     __shared__ double red[8][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -659,9 +660,33 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     __syncthreads();
     if (threadIdx.x < 4) {
         const int j = threadIdx.x;
-        atomicAdd(&stats[(4 * g + j) * 2 + 0], red[0][j] + red[1][j] + red[2][j] + red[3][j]);
-        atomicAdd(&stats[(4 * g + j) * 2 + 1], red[4][j] + red[5][j] + red[6][j] + red[7][j]);
+        atomicAdd(&out[(4 * g + j) * 2 + 0], red[0][j] + red[1][j] + red[2][j] + red[3][j]);
+        atomicAdd(&out[(4 * g + j) * 2 + 1], red[4][j] + red[5][j] + red[6][j] + red[7][j]);
     }
+}
+
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int N, int G, int HW, double* __restrict__ stats, int S, int ypi, int ni) {
+    const int g = blockIdx.x, grp = blockIdx.z;
+    const int i0 = blockIdx.y / ypi, chunk = blockIdx.y - i0 * ypi, step = ypi * 256;
+    stats += (size_t)grp * 8 * G;
+    double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    for (int n = grp + i0 * S; n < N; n += ni * S) {                       // images of this statistics group, ni of them side by side
+        const float4* __restrict__ p = reinterpret_cast<const float4*>(x + c4_offset(n, G, g, HW, 0));
+        int pix = chunk * 256 + threadIdx.x;
+        for (; pix + step < HW; pix += 2 * step) {                         // two loads in flight
+            const float4 v = p[pix], w = p[pix + step];
+            s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+            q[0] += (double)v.x * v.x; q[1] += (double)v.y * v.y; q[2] += (double)v.z * v.z; q[3] += (double)v.w * v.w;
+            s[0] += w.x; s[1] += w.y; s[2] += w.z; s[3] += w.w;
+            q[0] += (double)w.x * w.x; q[1] += (double)w.y * w.y; q[2] += (double)w.z * w.z; q[3] += (double)w.w * w.w;
+        }
+        if (pix < HW) {
+            const float4 v = p[pix];
+            s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+            q[0] += (double)v.x * v.x; q[1] += (double)v.y * v.y; q[2] += (double)v.z * v.z; q[3] += (double)v.w * v.w;
+        }
+    }
+    bn_block_sums(s, q, stats, g);
 }
 
 // rezero: the sums are cleared again once read (the "zero on entry, left zero" workspace of the *_z entry points: no clearing
@@ -707,20 +732,24 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, int C, int relu,
                                                        float* __restrict__ y, int N, int G, int HW, int S) {
-    const long long total = (long long)N * G * HW;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-        const long long ng = idx / HW;
-        const int g = (int)(ng % G), so = S == 1 ? 0 : (int)((ng / G) % S) * C;        // statistics of the sample's group
-        const float4 v = *reinterpret_cast<const float4*>(x + idx * 4);
-        float in[4] = {v.x, v.y, v.z, v.w}, o[4];
+    const int plane = blockIdx.y, n = plane / G, g = plane - n * G, so = S == 1 ? 0 : (n % S) * C;   // statistics of the sample's group
+    float mu[4], is[4], ga[4], be[4]; bool live[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = 4 * g + j; live[j] = c < C;
+        mu[j] = live[j] ? mean[so + c] : 0.f; is[j] = live[j] ? invstd[so + c] : 0.f; ga[j] = live[j] ? gamma[c] : 0.f; be[j] = live[j] ? beta[c] : 0.f;
+    }
+    const float4* __restrict__ p = reinterpret_cast<const float4*>(x) + (size_t)plane * HW;
+    float4* __restrict__ o = reinterpret_cast<float4*>(y) + (size_t)plane * HW;
+    for (int pix = blockIdx.x * 256 + threadIdx.x; pix < HW; pix += gridDim.x * 256) {
+        const float4 v = p[pix];
+        const float in[4] = {v.x, v.y, v.z, v.w}; float r[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int c = 4 * g + j;
-            float r = 0.f;
-            if (c < C) { r = bn_affine(in[j], mean[so + c], invstd[so + c], gamma[c], beta[c]); if (relu) r = fmaxf(r, 0.f); }
-            o[j] = r;
+            r[j] = live[j] ? bn_affine(in[j], mu[j], is[j], ga[j], be[j]) : 0.f;
+            if (relu && live[j]) r[j] = fmaxf(r[j], 0.f);
         }
-        *reinterpret_cast<float4*>(y + idx * 4) = make_float4(o[0], o[1], o[2], o[3]);
+        o[pix] = make_float4(r[0], r[1], r[2], r[3]);
     }
 }
 
@@ -731,9 +760,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ dy, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, int C, int relu,
-                                                            int N, int G, int HW, double* __restrict__ sums, int S) {
+                                                            int N, int G, int HW, double* __restrict__ sums, int S, int ypi, int ni) {
     const int g = blockIdx.x, grp = blockIdx.z;
-    const long long total = (long long)((N - grp + S - 1) / S) * HW;
+    const int i0 = blockIdx.y / ypi, chunk = blockIdx.y - i0 * ypi, step = ypi * 256;
     sums += (size_t)grp * 8 * G;
     double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
     float mu[4], is[4], ga[4], be[4];
@@ -742,35 +771,26 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         const int c = 4 * g + j; mu[j] = c < C ? mean[grp * C + c] : 0.f; is[j] = c < C ? invstd[grp * C + c] : 0.f;
         ga[j] = (RECOMP && c < C) ? gamma[c] : 0.f; be[j] = (RECOMP && c < C) ? beta[c] : 0.f;
     }
-    for (long long i = (long long)blockIdx.y * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.y * blockDim.x) {
-        const int n = (int)(i / HW) * S + grp, pix = (int)(i % HW);
-        const size_t o = c4_offset(n, G, g, HW, pix);
-        const float4 xv = *reinterpret_cast<const float4*>(x + o);
-        float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
-        if (!RECOMP) yv = *reinterpret_cast<const float4*>(y + o);
-        const float4 dv = *reinterpret_cast<const float4*>(dy + o);
-        const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ys[4] = {yv.x, yv.y, yv.z, yv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
+    for (int n = grp + i0 * S; n < N; n += ni * S) {
+        const size_t base = c4_offset(n, G, g, HW, 0);
+        const float4* __restrict__ px = reinterpret_cast<const float4*>(x + base);
+        const float4* __restrict__ py = RECOMP ? nullptr : reinterpret_cast<const float4*>(y + base);
+        const float4* __restrict__ pd = reinterpret_cast<const float4*>(dy + base);
+        for (int pix = chunk * 256 + threadIdx.x; pix < HW; pix += step) {
+            const float4 xv = px[pix];
+            float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (!RECOMP) yv = py[pix];
+            const float4 dv = pd[pix];
+            const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ys[4] = {yv.x, yv.y, yv.z, yv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float pre = RECOMP ? bn_affine(xs[j], mu[j], is[j], ga[j], be[j]) : ys[j];
-            const float d = (relu && !(pre > 0.f)) ? 0.f : ds[j];
-            s[j] += d; q[j] += (double)d * ((xs[j] - mu[j]) * is[j]);
+            for (int j = 0; j < 4; ++j) {
+                const float pre = RECOMP ? bn_affine(xs[j], mu[j], is[j], ga[j], be[j]) : ys[j];
+                const float d = (relu && !(pre > 0.f)) ? 0.f : ds[j];
+                s[j] += d; q[j] += (double)d * ((xs[j] - mu[j]) * is[j]);
+            }
         }
     }
-    __shared__ double red[8][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { s[j] += __shfl_down(s[j], o); q[j] += __shfl_down(q[j], o); }
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) for (int j = 0; j < 4; ++j) { red[wave][j] = s[j]; red[wave + 4][j] = q[j]; }
-    __syncthreads();
-    if (threadIdx.x < 4) {
-        const int j = threadIdx.x;
-        atomicAdd(&sums[(4 * g + j) * 2 + 0], red[0][j] + red[1][j] + red[2][j] + red[3][j]);
-        atomicAdd(&sums[(4 * g + j) * 2 + 1], red[4][j] + red[5][j] + red[6][j] + red[7][j]);
-    }
+    bn_block_sums(s, q, sums, g);
 }
 
 // backward pass 2: dx = gamma*invstd*(dy - sum_dy/m - xhat*sum_dy_xhat/m); dgamma = sum_dy_xhat; dbeta = sum_dy
@@ -781,32 +801,36 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ beta,
                                                            const double* __restrict__ sums, double count, int C, int relu,
                                                            float* __restrict__ dx, int N, int G, int HW, int S) {
-    const long long total = (long long)N * G * HW;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-        const long long ng = idx / HW;
-        const int g = (int)(ng % G), grp = S == 1 ? 0 : (int)((ng / G) % S), so = grp * C;
-        const double* sg = sums + (size_t)grp * 8 * G;
-        const double cnt = S == 1 ? count : (double)((N - grp + S - 1) / S) * HW;
-        const float4 xv = *reinterpret_cast<const float4*>(x + idx * 4);
+    const int plane = blockIdx.y, n = plane / G, g = plane - n * G, grp = S == 1 ? 0 : n % S, so = grp * C;
+    const double* sg = sums + (size_t)grp * 8 * G;
+    const double cnt = S == 1 ? count : (double)((N - grp + S - 1) / S) * HW;
+    float mu[4], is[4], ga[4], be[4], sd[4], sq[4]; bool live[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = 4 * g + j; live[j] = c < C;
+        mu[j] = live[j] ? mean[so + c] : 0.f; is[j] = live[j] ? invstd[so + c] : 0.f; ga[j] = live[j] ? gamma[c] : 0.f; be[j] = (RECOMP && live[j]) ? beta[c] : 0.f;
+        sd[j] = live[j] ? (float)(sg[2 * c] / cnt) : 0.f; sq[j] = live[j] ? (float)(sg[2 * c + 1] / cnt) : 0.f;
+    }
+    const size_t base = (size_t)plane * HW;
+    const float4* __restrict__ px = reinterpret_cast<const float4*>(x) + base;
+    const float4* __restrict__ py = RECOMP ? nullptr : reinterpret_cast<const float4*>(y) + base;
+    const float4* __restrict__ pd = reinterpret_cast<const float4*>(dy) + base;
+    float4* __restrict__ po = reinterpret_cast<float4*>(dx) + base;
+    for (int pix = blockIdx.x * 256 + threadIdx.x; pix < HW; pix += gridDim.x * 256) {
+        const float4 xv = px[pix];
         float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
-        if (!RECOMP) yv = *reinterpret_cast<const float4*>(y + idx * 4);
-        const float4 dv = *reinterpret_cast<const float4*>(dy + idx * 4);
+        if (!RECOMP) yv = py[pix];
+        const float4 dv = pd[pix];
         const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ys[4] = {yv.x, yv.y, yv.z, yv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
         float o[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int c = 4 * g + j;
-            float r = 0.f;
-            if (c < C) {
-                const float pre = RECOMP ? bn_affine(xs[j], mean[so + c], invstd[so + c], gamma[c], beta[c]) : ys[j];
-                const float d = (relu && !(pre > 0.f)) ? 0.f : ds[j];
-                const float xh = (xs[j] - mean[so + c]) * invstd[so + c];
-                const float sd = (float)(sg[2 * c] / cnt), sq = (float)(sg[2 * c + 1] / cnt);
-                r = gamma[c] * invstd[so + c] * (d - sd - xh * sq);
-            }
-            o[j] = r;
+            const float pre = RECOMP ? bn_affine(xs[j], mu[j], is[j], ga[j], be[j]) : ys[j];
+            const float d = (relu && !(pre > 0.f)) ? 0.f : ds[j];
+            const float xh = (xs[j] - mu[j]) * is[j];
+            o[j] = live[j] ? ga[j] * is[j] * (d - sd[j] - xh * sq[j]) : 0.f;
         }
-        *reinterpret_cast<float4*>(dx + idx * 4) = make_float4(o[0], o[1], o[2], o[3]);
+        po[pix] = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
 
@@ -829,7 +853,10 @@ __global__ void bn_zero_kernel(double* __restrict__ p, int n) {
     if (i < n) p[i] = 0.0;
 }
 
-static int bn_grid_y(int N, int HW) { long long t = ((long long)N * HW + 255) / 256; return (int)(t < 64 ? (t < 1 ? 1 : t) : 64); }
+static dim3 bn_plane_grid(int N, int G, int HW) {                         // elementwise kernels: (pixel chunks of 1024, planes)
+    int cx = (HW + 1023) / 1024; cx = cx < 1 ? 1 : (cx > 48 ? 48 : cx);
+    return dim3(cx, N * G);
+}
 
 static int bn_forward(const float* x, const float* gamma, const float* beta,
                       float* running_mean, float* running_var, float momentum, float eps, int relu,
@@ -837,12 +864,13 @@ static int bn_forward(const float* x, const float* gamma, const float* beta,
                       int N, int C, int H, int W, void* stream, int S = 1) {
     CNM_REQUIRE(x && gamma && beta && y && save_mean && save_invstd && stats_ws && N > 0 && C > 0 && H > 0 && W > 0 && S >= 1 && S <= N, CNM_ERR_BAD_ARG);
     const int G = (C + 3) / 4, HW = H * W;
+    CNM_REQUIRE((long long)N * G <= 65535, CNM_ERR_BAD_ARG);                // planes in grid.y
     hipStream_t s = cnm_stream(stream);
     if (!zeroed) bn_zero_kernel<<<cnm_ceil_div(8 * G * S, 256), 256, 0, s>>>(stats_ws, 8 * G * S);
-    bn_stats_kernel<<<dim3(G, bn_grid_y((N + S - 1) / S, HW), S), 256, 0, s>>>(x, N, G, HW, stats_ws, S);
+    const BnGridY gy = bn_grid_y((N + S - 1) / S, HW);
+    bn_stats_kernel<<<dim3(G, gy.ypi * gy.ni, S), 256, 0, s>>>(x, N, G, HW, stats_ws, S, gy.ypi, gy.ni);
     bn_finalize_kernel<<<cnm_ceil_div(4 * G, 256), 256, 0, s>>>(stats_ws, C, (double)N * HW, eps, momentum, save_mean, save_invstd, running_mean, running_var, zeroed, tracked, S, N, HW);
-    const long long total = (long long)N * G * HW;
-    bn_apply_kernel<<<(int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384), 256, 0, s>>>(x, save_mean, save_invstd, gamma, beta, C, relu, y, N, G, HW, S);
+    bn_apply_kernel<<<bn_plane_grid(N, G, HW), 256, 0, s>>>(x, save_mean, save_invstd, gamma, beta, C, relu, y, N, G, HW, S);
     CNM_LAUNCH_CHECK();
     return CNM_OK;
 }
@@ -869,14 +897,15 @@ static int bn_backward(const float* x, const float* y, const float* dy, const fl
                        int N, int C, int H, int W, void* stream, int S = 1, const float* beta = nullptr) {
     CNM_REQUIRE(x && (y || beta || !relu) && dy && gamma && save_mean && save_invstd && dx && dgamma && dbeta && sums_ws && N > 0 && C > 0 && S >= 1 && S <= N, CNM_ERR_BAD_ARG);
     const int G = (C + 3) / 4, HW = H * W;
+    CNM_REQUIRE((long long)N * G <= 65535, CNM_ERR_BAD_ARG);                // planes in grid.y
     hipStream_t s = cnm_stream(stream);
     if (!zeroed) bn_zero_kernel<<<cnm_ceil_div(8 * G * S, 256), 256, 0, s>>>(sums_ws, 8 * G * S);
     const bool recomp = !y && relu;
-    const dim3 rg(G, bn_grid_y((N + S - 1) / S, HW), S);
-    if (recomp) bn_bwd_reduce_kernel<true><<<rg, 256, 0, s>>>(x, nullptr, dy, save_mean, save_invstd, gamma, beta, C, relu, N, G, HW, sums_ws, S);
-    else bn_bwd_reduce_kernel<false><<<rg, 256, 0, s>>>(x, y ? y : x, dy, save_mean, save_invstd, gamma, beta, C, relu, N, G, HW, sums_ws, S);
-    const long long total = (long long)N * G * HW;
-    const int ag = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    const BnGridY gy = bn_grid_y((N + S - 1) / S, HW);
+    const dim3 rg(G, gy.ypi * gy.ni, S);
+    if (recomp) bn_bwd_reduce_kernel<true><<<rg, 256, 0, s>>>(x, nullptr, dy, save_mean, save_invstd, gamma, beta, C, relu, N, G, HW, sums_ws, S, gy.ypi, gy.ni);
+    else bn_bwd_reduce_kernel<false><<<rg, 256, 0, s>>>(x, y ? y : x, dy, save_mean, save_invstd, gamma, beta, C, relu, N, G, HW, sums_ws, S, gy.ypi, gy.ni);
+    const dim3 ag = bn_plane_grid(N, G, HW);
     if (recomp) bn_bwd_apply_kernel<true><<<ag, 256, 0, s>>>(x, nullptr, dy, save_mean, save_invstd, gamma, beta, sums_ws, (double)N * HW, C, relu, dx, N, G, HW, S);
     else bn_bwd_apply_kernel<false><<<ag, 256, 0, s>>>(x, y ? y : x, dy, save_mean, save_invstd, gamma, beta, sums_ws, (double)N * HW, C, relu, dx, N, G, HW, S);
     bn_param_grad_kernel<<<cnm_ceil_div(4 * G, 256), 256, 0, s>>>(sums_ws, C, dgamma, dbeta, zeroed, S);

@@ -131,12 +131,13 @@ def test_upsample2x_c8_vs_torch(dev, N, C, H, W):
     assert got.shape == want.shape and np.abs(got - want).max() < 1e-3 * max(1.0, np.abs(want).max())     # fp16 rounding of the output
 
 
-@pytest.mark.parametrize("N,C,H,W", [(2, 64, 192, 256), (8, 64, 100, 130), (2, 64, 24, 40), (1, 256, 12, 20)])
+@pytest.mark.parametrize("N,C,H,W", [(2, 64, 192, 256), (8, 64, 100, 130), (2, 64, 24, 40), (1, 256, 12, 20), (9, 128, 96, 128), (3, 72, 181, 187)])
 def test_head_sigmoid_c8_vs_torch(dev, N, C, H, W):
     """fp16 disparity head (3x3 conv to one channel + bias + scaled sigmoid) against torch on the fp16-rounded input: the
-    4-slice and the 16-slice kernel, ragged pixel tails; plus the nearest x2 copy into a channel group of a wider tensor.
-    (A port of the fp32 engine's row-walking head was measured on this path: 50 us against 45 us per launch -- half the
-    bytes per texel leave the nine-fold L1 re-read cheaper than the DPP shifts; not kept.)"""
+    row-walking kernel of the high-resolution levels [r5] (tiles of 62 x 8 outputs, ragged in both directions), the 4-slice and the
+    16-slice kernel, ragged pixel tails; plus the nearest x2 copy into a channel group of a wider tensor.
+    (Round 3 measured a port of the fp32 engine's row-walking head at 50 us against 45 us and dropped it; what it lacked was
+    v_fma_mix_f32 -- the half -> float conversions were a third of its instructions, see cnmnet_amd/build.py.)"""
     from cnmnet_amd import ops
     rng = np.random.default_rng(C + H)
     x = T(rng.standard_normal((N, C, H, W)).astype(np.float32)).half().float()

@@ -132,7 +132,7 @@ def test_forward_sources_equals_separate_calls(dev):
     assert rel[len(rel) // 2] < 5e-2 and rel[-1] < 0.5, (rel[len(rel) // 2], rel[-1])
 
 
-@pytest.mark.parametrize("C,N,H,W,S", [(128, 4, 6, 8, 2), (67, 6, 5, 7, 2), (64, 6, 4, 4, 3)])
+@pytest.mark.parametrize("C,N,H,W,S", [(128, 4, 6, 8, 2), (67, 6, 5, 7, 2), (64, 6, 4, 4, 3), (32, 6, 48, 80, 2), (16, 7, 96, 130, 3)])
 def test_batchnorm_groups_equal_separate_calls(dev, C, N, H, W, S):
     """BatchNorm with S statistics groups (sample n -> group n % S) against S separate calls on the interleaved slices: the same
     kernels on the same numbers -- output, input gradient and running statistics bit-equal, parameter gradients to the last bit of
@@ -160,7 +160,8 @@ def test_batchnorm_groups_equal_separate_calls(dev, C, N, H, W, S):
         res.append((y.detach(), xa.grad, ga.grad, ba.grad, rm, rv, int(nb)))
     a, b = res
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[4], b[4]) and torch.equal(a[5], b[5]) and a[6] == b[6] == S
-    assert float((a[2] - b[2]).abs().max()) < 1e-5 and float((a[3] - b[3]).abs().max()) < 1e-5
+    for i in (2, 3):                                                    # parameter gradients: fp32 sums of the groups' fp64 sums -- a couple of ulps of the largest
+        assert float((a[i] - b[i]).abs().max()) <= 1e-5 + 2.5e-7 * float(b[i].abs().max())
 
 
 def test_winograd_wgrad_argument_errors(dev):
@@ -187,7 +188,7 @@ def test_winograd_wgrad_argument_errors(dev):
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("C,N,H,W,relu", [(128, 2, 12, 20, True), (67, 3, 8, 8, False), (512, 2, 6, 8, True)])
+@pytest.mark.parametrize("C,N,H,W,relu", [(128, 2, 12, 20, True), (67, 3, 8, 8, False), (512, 2, 6, 8, True), (32, 5, 72, 100, True), (19, 3, 40, 70, False), (8, 2, 192, 256, True)])
 def test_batchnorm_train_forward_backward(dev, C, N, H, W, relu):
     from cnmnet_amd import ops, autograd as ag
     rng = np.random.default_rng(C)
