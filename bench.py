@@ -22,6 +22,7 @@ Prints ONE JSON line (rank 0).  Extra objects:
                      as a HIP graph, samples/s (secondary as well)
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -160,7 +161,14 @@ def _child_pass(extra, pattern, timeout_s, bench_args=(), env=None):
         cmd = ["rocprofv3", "--kernel-trace"] + list(extra) + ["--output-format", "csv", "-d", d, "--",
                sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline",
                "--no-secondary", "--no-live-traffic"] + list(bench_args)
-        r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, TMPDIR="/tmp", **(env or {})), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+        pin = {}
+        try:
+            from cnmnet_amd import _lib
+            pol = _lib.load().cnm_tune_sweep_store(99, None)             # query: the plane sweep's store policy this process has measured (-1: still sampling)
+            pin = {"CNM_SWEEP_STORE": str(pol)} if pol >= 0 else {}
+        except Exception:                                                # noqa: BLE001  (no library: the child fails by itself)
+            pass
+        r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, TMPDIR="/tmp", **pin, **(env or {})), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
         files = glob.glob(d + "/**/*" + pattern, recursive=True)
         if r.returncode != 0 or not files:
             return "exit code %d, %d file(s)" % (r.returncode, len(files))
@@ -463,9 +471,15 @@ def kernel_rooflines(dev, frames, step=None):
     # + write (D+3)HW*4; ref counted once per frame because one launch covers both sources of a frame
     pairs = frames * SRC
     byts = frames * 3 * H * W * 4 + pairs * 3 * H * W * 4 + pairs * (PLANES + 3) * H * W * 4
-    sweep = {"kernel": "planesweep_kernel<1>", "bound": "hbm", "achieved": byts / ms / 1e6, "peak": HBM_PEAK_GBS,
-             "unit": "GB/s", "frac": byts / ms / 1e6 / HBM_PEAK_GBS, "traffic": pmc_traffic("planesweep_kernel<1>"),
-             "traffic_uncorrected": pmc_traffic("planesweep_kernel<1>", raw=True),
+    med = (ctypes.c_float * 2)()
+    pol = lib.cnm_tune_sweep_store(99, ctypes.cast(med, ctypes.c_void_p))   # query only
+    kname = "planesweep_kernel<1, %d>" % pol if pol >= 0 else "planesweep_kernel<1,"
+    sweep = {"kernel": kname if pol >= 0 else "planesweep_kernel<1, 0 | 2>", "bound": "hbm", "achieved": byts / ms / 1e6, "peak": HBM_PEAK_GBS,
+             "unit": "GB/s", "frac": byts / ms / 1e6 / HBM_PEAK_GBS, "traffic": pmc_traffic(kname),
+             "traffic_uncorrected": pmc_traffic(kname, raw=True),
+             "store_policy": {"in_force": {0: "plain", 2: "nt", -1: "still sampling"}.get(pol, str(pol)), "median_us_plain": round(float(med[0]), 1), "median_us_nt": round(float(med[1]), 1),
+                              "note": "second template argument of the kernel; the first 24 launches of the process alternate between plain and non-temporal output stores inside "
+                                      "the timed steps and the lower median stays (cnm_tune_sweep_store, include/cnm_engine.h): which is faster differs between boxes"},
              "target": 0.60, "met": bool(byts / ms / 1e6 / HBM_PEAK_GBS >= 0.60),             # BASELINE.json north_star: >= 60 % of the HBM roofline
              "algorithmic_bytes_per_launch": byts, "avg_launch_ms": ms,
              "launch_ms": {"median": per_main[n_main // 2], "p10": per_main[n_main // 10], "p90": per_main[9 * n_main // 10], "n": n_main},
@@ -477,7 +491,7 @@ def kernel_rooflines(dev, frames, step=None):
                      "%d launches of a synthetic loop (launch, then conv1.0 -- 2 ms of MFMA work -- again and again: every launch starts on a chip that conv1.0 "
                      "has just driven to its power limit); burst_avg_launch_ms: 50 launches back to back (sustained, clock-throttled state; not run under rocprofv3, "
                      "whose per-kernel averages should be those of the step)" % (n_main, n_it)}
-    v = _by_kernel(_LIVE_VALU, "planesweep_kernel<1>")
+    v = _by_kernel(_LIVE_VALU, kname)
     if v is not None and v.get("SQ_INSTS_VALU") and v.get("GRBM_GUI_ACTIVE"):
         # Why 0.60 of the HBM roof is out of this formulation's reach, as numbers.  SQ_ACTIVE_INST_VALU counts
         # QUAD-cycles in which a wave has a vector instruction in execution, so "cycles per issue" read from it cannot come out below 4;
@@ -737,7 +751,7 @@ def planesweep_alone(dev, B, S, Hh, Ww, D, n_it=12):
     ms = sum(per) / n_it
     pairs = B * S
     byts = B * 3 * Hh * Ww * 4 + pairs * 3 * Hh * Ww * 4 + pairs * (D + 3) * Hh * Ww * 4
-    return {"kernel": "planesweep_kernel<1>", "bound": "hbm", "achieved": byts / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    return {"kernel": "planesweep_kernel<1, %d>" % lib.cnm_tune_sweep_store(99, None), "bound": "hbm", "achieved": byts / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": byts / ms / 1e6 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": byts, "avg_launch_ms": ms,
             "launch_ms": {"median": per[n_it // 2], "min": per[0], "max": per[-1], "n": n_it},
             "note": "ONE launch over the %d pairs of this configuration, timed as roofline_planesweep times the headline's" % pairs}
@@ -897,6 +911,9 @@ def main():
     if a.side_stream >= 0:
         from cnmnet_amd import _lib
         _lib.load().cnm_tune_refine_side_stream(a.side_stream)
+    if os.environ.get("CNM_SWEEP_STORE", "") in ("0", "2"):              # a child pass of this script: the plane sweep's store policy the parent process measured
+        from cnmnet_amd import _lib
+        _lib.load().cnm_tune_sweep_store(int(os.environ["CNM_SWEEP_STORE"]), None)
     pipe = FramePipeline(load_weights(depthNet(3.0, PLANES, precision=a.precision), 1).to(dev),
                          load_weights(DepthRefineNet(32, 3.0, precision=a.precision), 2).to(dev),
                          k_size=KSIZE, normals=True)

@@ -110,6 +110,7 @@ PROTOTYPES = {
     "cnm_conv2d_cat2_c8_f16": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp,
                                      c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "cnm_tune_gldsx": (c_i, [c_i]),
+    "cnm_tune_sweep_store": (c_i, [c_i, c_fp]),
     "cnm_debug_sweep_timing_arm": (c_i, [c_i]),
     "cnm_debug_sweep_timing_read": (c_i, [c_fp, c_i]),
     "cnm_planesweep_cat_c8_f16": (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_sz, c_i, c_i, c_i, c_i, c_i, c_d, c_d, c_fp]),

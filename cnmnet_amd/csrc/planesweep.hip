@@ -129,7 +129,7 @@ extern "C" int cnm_idepth_range_host(double idepth_scale, double* idepth_min, do
 #define SWEEP_ROLL_QUADS 0          // 1: the two quads of an octet as a loop (half the code of the sample loops; not for the fp16 layout, which packs eight planes)
 #endif
 #ifndef SWEEP_STORE_AUX
-#define SWEEP_STORE_AUX 2           // cache policy of the output stores (gfx950: 1 sc0, 2 nt, 16 sc1): nt - the volume is 13 MB per pair written once; in the step 57 us against 60 us with the default policy
+#define SWEEP_STORE_AUX 2           // the non-default cache policy of the output stores (gfx950: 1 sc0, 2 nt, 16 sc1), the kernel's AUX template argument next to 0: see sweep_store_policy()
 #endif
 #define SWEEP_MAX_OCT (CNM_MAX_PLANES / 8)
 #define SWEEP_PASSES ((SWEEP_CAP + SWEEP_NT - 1) / SWEEP_NT)   // staging passes a full box needs
@@ -566,7 +566,7 @@ __device__ __attribute__((noinline)) float4 sweep_quad_global(unsigned src_lo_, 
 // blockIdx.x, then tiles drawn from a ticket counter in the caller's workspace (ws[0]: tickets, ws[1]: exits; both
 // are zero between launches - the last workgroup to leave resets them).  Per tile: footprints (wave 0) ->
 // [stage box -> sweep its planes]*.  The ticket and the camera terms of the NEXT tile are fetched while the current one is swept.
-template <int LAYOUT>   // 0: volume [P,D,H,W] fp32   1: c4 [P,D/4+1,H,W,4] fp32   2: c8 [P,D/8+1,H,W,8] fp16
+template <int LAYOUT, int AUX>   // LAYOUT 0: volume [P,D,H,W] fp32   1: c4 [P,D/4+1,H,W,4] fp32   2: c8 [P,D/8+1,H,W,8] fp16;  AUX: cache policy of the output stores
 __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_MINW, SWEEP_MINW))) void planesweep_kernel(const SweepArgs a) {
     char* const box = SWEEP_LDS_BOX;
     float* const zsh = SWEEP_LDS_Z;
@@ -768,7 +768,7 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
                     if (LAYOUT == 0) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            if (d0 + 4 * q + j < D) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(cost[j]), orsrc, ovoff, osoff, SWEEP_STORE_AUX);
+                            if (d0 + 4 * q + j < D) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(cost[j]), orsrc, ovoff, osoff, AUX);
                             osoff += ostride;
                         }
                     } else if (LAYOUT == 1) {
@@ -778,9 +778,9 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
                         if (d0 + 4 * q < D) {
                             const sw_u32x4 v = {__float_as_uint(cost[0]), __float_as_uint(cost[1]), __float_as_uint(cost[2]), __float_as_uint(cost[3])};
 #ifdef SWEEP_STORE_LOCAL
-                            __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, ovoff, 0, SWEEP_STORE_AUX);   // debug builds: every store lands in the pair's first channel group (cache-resident)
+                            __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, ovoff, 0, AUX);   // debug builds: every store lands in the pair's first channel group (cache-resident)
 #else
-                            __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, ovoff, osoff, SWEEP_STORE_AUX);
+                            __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, ovoff, osoff, AUX);
 #endif
                             // (a 16-byte store with an SGPR offset reads its data registers over several cycles and hipcc pads no hazard
                             // for that form -- conv_winograd4s.hip found the tail of such a store leaving with the NEXT values when the
@@ -799,7 +799,7 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
 #endif
                 if (LAYOUT == 2) {
                     const sw_u32x4 v = {__builtin_bit_cast(unsigned, hh[0]), __builtin_bit_cast(unsigned, hh[1]), __builtin_bit_cast(unsigned, hh[2]), __builtin_bit_cast(unsigned, hh[3])};
-                    __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, ovoff, osoff, SWEEP_STORE_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, ovoff, osoff, AUX);
                     osoff += ostride;
                 }
             }
@@ -807,12 +807,12 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
         // osoff now points at the channel group behind the D planes: the reference image (depthNet_model.py:233)
         if (LAYOUT == 1 && obeg + ocnt == noct) {
             const sw_u32x4 v = {__float_as_uint(-nr), __float_as_uint(-ng), __float_as_uint(-nb), 0u};
-            __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, ovoff, osoff, SWEEP_STORE_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, ovoff, osoff, AUX);
         }
         if (LAYOUT == 2 && obeg + ocnt == noct) {
             const sw_f16x2 h0 = {(_Float16)(-nr), (_Float16)(-ng)}, h1 = {(_Float16)(-nb), (_Float16)0.f};
             const sw_u32x4 v = {__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1), 0u, 0u};
-            __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, ovoff, osoff, SWEEP_STORE_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, ovoff, osoff, AUX);
         }
 #ifdef SWEEP_SPAN
         if (tid == 0 && blockIdx.x < 1024) { sweep_span[blockIdx.x][2] = __builtin_amdgcn_s_memrealtime(); sweep_span[blockIdx.x][3] += 1;
@@ -886,6 +886,71 @@ extern "C" int cnm_debug_sweep_timing_read(float* ms, int n) {
     return k;
 }
 
+// Cache policy of the output stores, chosen per device by measurement [r5].  The volume is written once (13 MB per pair); whether `nt`
+// stores or plain ones are faster INSIDE a step depends on the box: the launch displaces the dirty lines its predecessors left in the
+// memory-side cache (tools/k1_context_probe.py: 55 us into its own still-cached buffer, 63 us after any kernel that wrote 400 MB), and on
+// the pool's boxes that costs nt 55-57 us against 60 us plain on some and 65 against 60 on others (tools/k1_in_step_variants.sh).  So the
+// first SWEEP_TUNE_N large launches of a device alternate between the two policies, each between a pair of fence-free events on its own
+// stream; once they have all completed (queried, never waited for) the policy with the lower median stays.  Both produce the same bytes.
+// cnm_tune_sweep_store(0 / 2) forces a policy, (-1) returns to measuring; launches under stream capture and small launches never sample.
+#include <algorithm>
+#include <mutex>
+#ifndef SWEEP_TUNE_N
+#define SWEEP_TUNE_N 24
+#endif
+struct SweepStoreTune {
+    int forced = -1, chosen = -1, issued = 0;
+    float median_us[2] = {0.f, 0.f};
+    hipEvent_t ev[SWEEP_TUNE_N][2] = {};
+};
+static SweepStoreTune g_sweep_tune[64];
+static std::mutex g_sweep_tune_mu;
+static void sweep_tune_release(SweepStoreTune& t) {
+    for (int i = 0; i < SWEEP_TUNE_N; ++i) for (int j = 0; j < 2; ++j) if (t.ev[i][j]) { (void)hipEventDestroy(t.ev[i][j]); t.ev[i][j] = nullptr; }
+}
+// returns the policy of this launch; *e0 / *e1 = events to record around it (nullptr: not a sampling launch)
+static int sweep_store_policy(hipStream_t s, size_t out_bytes, hipEvent_t* e0, hipEvent_t* e1) {
+    *e0 = *e1 = nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return SWEEP_STORE_AUX; }
+    std::lock_guard<std::mutex> lock(g_sweep_tune_mu);
+    SweepStoreTune& t = g_sweep_tune[dev];
+    if (t.forced >= 0) return t.forced;
+    if (t.chosen >= 0) return t.chosen;
+    if (t.issued == SWEEP_TUNE_N) {                                       // all samples issued: decide as soon as the last one has run
+        if (hipEventQuery(t.ev[SWEEP_TUNE_N - 1][1]) != hipSuccess) { (void)hipGetLastError(); return SWEEP_STORE_AUX; }
+        float v[2][SWEEP_TUNE_N / 2]; int n[2] = {0, 0};
+        for (int i = 0; i < SWEEP_TUNE_N; ++i) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, t.ev[i][0], t.ev[i][1]) == hipSuccess) v[i & 1][n[i & 1]++] = ms * 1e3f; else (void)hipGetLastError();
+        }
+        for (int k = 0; k < 2; ++k) { std::sort(v[k], v[k] + n[k]); t.median_us[k] = n[k] ? v[k][n[k] / 2] : 0.f; }
+        t.chosen = (n[0] && n[1] && t.median_us[0] < t.median_us[1]) ? 0 : SWEEP_STORE_AUX;
+        sweep_tune_release(t);
+        return t.chosen;
+    }
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (out_bytes < (32u << 20) || hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return SWEEP_STORE_AUX; }
+    const int i = t.issued;
+    for (int j = 0; j < 2; ++j)
+        if (!t.ev[i][j] && hipEventCreateWithFlags(&t.ev[i][j], hipEventDisableSystemFence) != hipSuccess) { (void)hipGetLastError(); t.ev[i][j] = nullptr; return SWEEP_STORE_AUX; }
+    *e0 = t.ev[i][0]; *e1 = t.ev[i][1];
+    ++t.issued;
+    return (i & 1) ? SWEEP_STORE_AUX : 0;                                 // even samples plain, odd samples SWEEP_STORE_AUX
+}
+// n = 0 / SWEEP_STORE_AUX: force that policy; n = -1: measure again; anything else only queries.  Returns the policy in force on the current
+// device: 0 or SWEEP_STORE_AUX once chosen or forced, -1 while the samples are being taken.  median_us (may be NULL): [plain, nt] of the last decision.
+extern "C" int cnm_tune_sweep_store(int n, float* median_us) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return -1; }
+    std::lock_guard<std::mutex> lock(g_sweep_tune_mu);
+    SweepStoreTune& t = g_sweep_tune[dev];
+    if (n == 0 || n == SWEEP_STORE_AUX) t.forced = n;
+    else if (n == -1) { t.forced = -1; t.chosen = -1; t.issued = 0; sweep_tune_release(t); }
+    if (median_us) { median_us[0] = t.median_us[0]; median_us[1] = t.median_us[1]; }
+    return t.forced >= 0 ? t.forced : t.chosen;
+}
+
 static int sweep_launch(int layout, const float* ref, const float* src, const float* hmkt, float* out,
                         float* ws, size_t ws_floats, int B, int S, int H, int W, int D,
                         double idepth_min, double idepth_max, void* stream) {
@@ -926,10 +991,21 @@ static int sweep_launch(int layout, const float* ref, const float* src, const fl
 #ifndef SWEEP_NO_TIMING_HOOK
     if (g_sweep_ev_next < g_sweep_ev_armed) { ev0 = g_sweep_ev[2 * g_sweep_ev_next]; ev1 = g_sweep_ev[2 * g_sweep_ev_next + 1]; ++g_sweep_ev_next; }
 #endif
+    hipEvent_t tv0 = nullptr, tv1 = nullptr;
+    const size_t out_bytes = (size_t)B * S * H * W * (layout == 2 ? 2 : 4) * (size_t)(D + (layout == 0 ? 0 : layout == 1 ? 4 : 8));
+    const int aux = sweep_store_policy(cnm_stream(stream), out_bytes, &tv0, &tv1);
     if (ev0) (void)hipEventRecord(ev0, cnm_stream(stream));
-    if (layout == 0) planesweep_kernel<0><<<grid, SWEEP_NT, 0, cnm_stream(stream)>>>(a);
-    else if (layout == 1) planesweep_kernel<1><<<grid, SWEEP_NT, 0, cnm_stream(stream)>>>(a);
-    else planesweep_kernel<2><<<grid, SWEEP_NT, 0, cnm_stream(stream)>>>(a);
+    if (tv0) (void)hipEventRecord(tv0, cnm_stream(stream));
+    if (aux == 0) {
+        if (layout == 0) planesweep_kernel<0, 0><<<grid, SWEEP_NT, 0, cnm_stream(stream)>>>(a);
+        else if (layout == 1) planesweep_kernel<1, 0><<<grid, SWEEP_NT, 0, cnm_stream(stream)>>>(a);
+        else planesweep_kernel<2, 0><<<grid, SWEEP_NT, 0, cnm_stream(stream)>>>(a);
+    } else {
+        if (layout == 0) planesweep_kernel<0, SWEEP_STORE_AUX><<<grid, SWEEP_NT, 0, cnm_stream(stream)>>>(a);
+        else if (layout == 1) planesweep_kernel<1, SWEEP_STORE_AUX><<<grid, SWEEP_NT, 0, cnm_stream(stream)>>>(a);
+        else planesweep_kernel<2, SWEEP_STORE_AUX><<<grid, SWEEP_NT, 0, cnm_stream(stream)>>>(a);
+    }
+    if (tv1) (void)hipEventRecord(tv1, cnm_stream(stream));
     if (ev1) (void)hipEventRecord(ev1, cnm_stream(stream));
     CNM_LAUNCH_CHECK();
     return CNM_OK;

@@ -146,6 +146,13 @@ int cnm_idepth_range_host(double idepth_scale, double* idepth_min, double* idept
  *     ws == NULL is allowed: tiles are then dealt to the workgroups with a fixed stride (no scratch, slower
  *     when tiles differ in cost). */
 size_t cnm_planesweep_workspace_floats(int B, int S, int H, int W);
+/* sweep_store [r5]: cache policy of the plane sweep's output stores (0 plain, 2 non-temporal).  Which one is faster inside a step
+ * depends on the machine (the launch displaces the dirty lines its predecessors left in the memory-side cache), so by default the
+ * first 24 large launches (>= 32 MB of output, not under stream capture) on a device alternate between the two, each between a pair
+ * of fence-free events on its own stream, and the policy with the lower median stays for the process; the two produce identical
+ * bytes.  cnm_tune_sweep_store(0 / 2, .) forces a policy, (-1, .) starts measuring again, any other n only queries.  Returns the
+ * policy in force on the current device (-1 while sampling); median_us (may be NULL) receives [plain, nt] of the last decision. */
+int cnm_tune_sweep_store(int n, float* median_us);
 /* DEBUG / MEASUREMENT: cnm_debug_sweep_timing_arm(n) makes each of the next n plane-sweep launches of the process (any entry point,
  * including the one inside cnm_depthnet_forward_*) record a HIP event before and after itself on its launch stream (events without
  * the system-scope fence: the closing one does not wait for the launch's output to be written back); n <= 0 disarms and frees.

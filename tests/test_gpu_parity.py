@@ -244,6 +244,41 @@ def test_planesweep_full_size_identity_known_answer(dev, ops):
     assert float((vol - want).abs().max()) < 1e-2
 
 
+def test_planesweep_store_policy_is_measured_and_invisible(dev, ops):
+    """cnm_tune_sweep_store [r5]: plain and non-temporal output stores give the same bytes; left alone, the first 24 large launches of a
+    device alternate between them between fence-free events, and once those have run the library settles on one (whichever -- it is a
+    property of the box) and reports both medians; small launches and forced policies never sample."""
+    import ctypes
+    from cnmnet_amd import _lib
+    lib = _lib.load()
+    B, S, H, W, D = 8, 2, 192, 256, 64
+    img, cams = syn.frames(B, S, H, W, seed=9)
+    ref, src = T(img[:, 0]).to(dev), T(img[:, 1:]).to(dev)
+    hmkt = ops.homography_terms(T(cams[:, 0]).to(dev), T(cams[:, 1:]).to(dev))
+    med = (ctypes.c_float * 2)()
+    try:
+        outs = []
+        for pol in (0, 2):
+            assert lib.cnm_tune_sweep_store(pol, None) == pol
+            outs.append(ops.plane_sweep_cat_c4(ref, src, hmkt, 3.0, D).clone())
+        assert torch.equal(outs[0], outs[1])
+        assert lib.cnm_tune_sweep_store(-1, None) == -1                          # measure again
+        small = ops.plane_sweep_cat_c4(ref[:1, :, :32, :32].contiguous(), src[:1, :, :, :32, :32].contiguous(), hmkt[:1], 3.0, D)   # 0.3 MB: not a sample
+        assert small.shape[0] == S and lib.cnm_tune_sweep_store(99, None) == -1
+        for i in range(24):
+            got = ops.plane_sweep_cat_c4(ref, src, hmkt, 3.0, D)
+            assert lib.cnm_tune_sweep_store(99, None) == -1, i                     # still sampling: the decision is taken by a LATER launch
+        torch.cuda.synchronize()
+        assert torch.equal(got, outs[0])
+        got = ops.plane_sweep_cat_c4(ref, src, hmkt, 3.0, D)
+        pol = lib.cnm_tune_sweep_store(99, ctypes.cast(med, ctypes.c_void_p))
+        assert pol in (0, 2) and 20.0 < med[0] < 500.0 and 20.0 < med[1] < 500.0, (pol, med[0], med[1])
+        assert (med[0] < med[1]) == (pol == 0)
+        assert torch.equal(got, outs[0])
+    finally:
+        lib.cnm_tune_sweep_store(-1, None)
+
+
 # ------------------------------------------------------------------ conv stack pieces
 @pytest.mark.parametrize("cin,cout,k,stride,rot,N,H,W", [
     (67, 128, 7, 1, 3, 2, 24, 40), (128, 128, 7, 2, 0, 1, 32, 32), (128, 256, 5, 1, 0, 1, 16, 24),

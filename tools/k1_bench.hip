@@ -59,7 +59,7 @@ int main(int argc, char** argv) {
     hipMemcpy(dref, ref.data(), ref.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dsrc, src.data(), src.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(dh, hmkt.data(), hmkt.size() * 4, hipMemcpyHostToDevice);
     hipMemset(dout, 0xff, outn * 4); hipMemset(dvol, 0xff, voln * 4);
-    int nb = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, planesweep_kernel<1>, SWEEP_NT, 0);
+    int nb = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, planesweep_kernel<1, SWEEP_STORE_AUX>, SWEEP_NT, 0);
     for (int i = 0; i < 5; ++i) {
         const int rc = cnm_planesweep_cat_c4_f32(dref, dsrc, dh, dout, K1_WS, wsn, B, S, H, W, D, 0.1, 3.0, nullptr);
         if (rc != 0) { printf("launch failed: %d\n", rc); return 1; }

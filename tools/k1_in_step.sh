@@ -7,14 +7,14 @@ rm -rf /tmp/k1is; timeout 600 rocprofv3 --kernel-trace --output-format csv -d /t
 python3 - <<'PY'
 import csv, glob
 f = glob.glob("/tmp/k1is/**/*kernel_trace.csv", recursive=True)[0]
-rows = sorted(((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3) for r in csv.DictReader(open(f)) if "planesweep_kernel<1>" in r["Kernel_Name"]))
+rows = sorted(((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3) for r in csv.DictReader(open(f)) if "planesweep_kernel<1," in r["Kernel_Name"]))
 import os
 if os.environ.get("K1_SERIES"): print("in launch order:", " ".join("%.0f" % v for _, v in rows))
 if os.environ.get("K1_NEIGHBOURS"):
     allr = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"][:46]) for r in csv.DictReader(open(f))))
     shown = 0
     for i, (s0, e0, nm) in enumerate(allr):
-        if "planesweep_kernel<1>" in nm and 2 <= i < len(allr) - 2 and shown < 8 and i > len(allr) // 2:
+        if "planesweep_kernel<1," in nm and 2 <= i < len(allr) - 2 and shown < 8 and i > len(allr) // 2:
             shown += 1
             print("  ...", " | ".join("%s %.1f us (gap %.1f)" % (allr[j][2][:28], (allr[j][1] - allr[j][0]) / 1e3, (allr[j][0] - allr[j - 1][1]) / 1e3) for j in range(i - 2, i + 2)))
 d = sorted(v for _, v in rows)

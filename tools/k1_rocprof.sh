@@ -8,7 +8,7 @@ rocprofv3 --kernel-trace --output-format csv -d /tmp/k1prof_out -- /tmp/k1_prof 
 f=$(find /tmp/k1prof_out -name "*kernel_trace.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys, statistics as st
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if 'planesweep_kernel<1>' in r['Kernel_Name'] or 'planesweep_kernelILi1' in r['Kernel_Name']]
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if 'planesweep_kernel<1,' in r['Kernel_Name'] or 'planesweep_kernelILi1' in r['Kernel_Name']]
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 dur = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3 for r in rows]
 gap = [(int(b['Start_Timestamp']) - int(a['End_Timestamp'])) / 1e3 for a, b in zip(rows, rows[1:])]
