@@ -211,7 +211,8 @@ def load():
     # A/B switches without code changes: CNM_TUNE="wino36_staged=2,refine_side_stream=0" calls cnm_tune_<name>(<value>)
     for item in filter(None, os.environ.get("CNM_TUNE", "").split(",")):
         name, _, val = item.partition("=")
-        getattr(lib, "cnm_tune_" + name.strip())(int(val))
+        fn = getattr(lib, "cnm_tune_" + name.strip())
+        fn(int(val), *([None] * (len(fn.argtypes) - 1)))               # knobs with an output pointer (sweep_store) take NULL
     _lib = lib
     return lib
 

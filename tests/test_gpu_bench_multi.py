@@ -15,7 +15,16 @@ def _launch(cmd, env, timeout):
     """Run a multi-rank bench command, ONCE (no retry: a rank lost to a signal fails the test -- with its Python and C++ stacks on
     stderr: faulthandler, TORCH_SHOW_CPP_STACKTRACES)."""
     env = dict(env, PYTHONFAULTHANDLER="1", TORCH_SHOW_CPP_STACKTRACES="1")
-    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    if r.returncode != 0:                                                 # keep EVERYTHING the ranks wrote (the assertion message shows an excerpt): gpurun_out/ comes back from the GPU box
+        try:
+            d = os.path.join(ROOT, "gpurun_out")
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, "multi_rank_failure_%d.txt" % os.getpid()), "a") as f:
+                f.write("==== %s\n---- exit code %d\n---- stdout\n%s\n---- stderr\n%s\n" % (" ".join(cmd), r.returncode, r.stdout, r.stderr))
+        except OSError:
+            pass
+    return r
 
 
 def _check_line(r, world=2, frames=8):
