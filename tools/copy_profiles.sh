@@ -16,5 +16,6 @@ cp $S/train_kernel_stats.csv $D/r5_train_kernel_stats.csv
 [ -f $S/config4_kernel_stats.csv ] && cp $S/config4_kernel_stats.csv $D/r5_config4_kernel_stats.csv
 [ -f $S/wgrad_sweep.txt ] && cp $S/wgrad_sweep.txt $D/r5_wgrad_sweep.txt
 [ -f $S/f16_conv_probe.txt ] && cp $S/f16_conv_probe.txt $D/r5_f16_conv_probe.txt
+[ -s $S/f16_step_layers.txt ] && cp $S/f16_step_layers.txt $D/r5_f16_step_layers.txt
 for f in k1_pmc k1_loop_probe k1_harness k1_trace k1_in_step wino_tile_ablation; do [ -s $S/$f.txt ] && cp $S/$f.txt $D/r5_$f.txt; done
 git status --short $D

@@ -29,6 +29,8 @@ timeout 300 python3 tools/train_bench.py 4 2>/dev/null | tail -1 >> "$O/train_be
 timeout 300 python3 tools/train_bench.py 4 graph 2>/dev/null | tail -1 >> "$O/train_bench.txt" || true
 timeout 600 python3 tools/wgrad_sweep.py > "$O/wgrad_sweep.txt" 2>/dev/null || true
 timeout 600 python3 tools/f16_conv_probe.py > "$O/f16_conv_probe.txt" 2>/dev/null || true
+timeout 300 python3 tools/f16_step_layers.py 2>/dev/null | grep -v amdgpu.ids > "$O/f16_step_layers.txt" || true
+timeout 300 python3 tools/k1_context_probe.py 2>/dev/null | grep -v amdgpu.ids > "$O/k1_context_probe_box.txt" || true
 bash tools/f16_profile.sh > /dev/null 2>&1 || true
 # the plane sweep on its own: wave-cycle split (issuing / waiting / stalled), LDS counters, the sample loop in isolation, one traced launch
 K1_FLAGS="" bash tools/k1_pmc.sh > "$O/k1_pmc.txt" 2>&1 || true
