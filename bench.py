@@ -899,8 +899,7 @@ def main():
         if line is not None:
             line["config"]["host_threads_per_rank"] = host_threads
         if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
+            dist.barrier()                                               # the last collective: no teardown after it (_leave)
         if line is not None:
             print(json.dumps(compact(line)), flush=True)
         return
@@ -985,8 +984,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline()
             line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
     if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        dist.barrier()                                                   # the last collective: no teardown after it (_leave)
     if line is not None:
         print(json.dumps(compact(line)), flush=True)
 
@@ -1021,15 +1019,18 @@ def compact(line):
 
 
 def _leave(code=0):
-    """End of a RANK of a multi-rank run: flush and leave without interpreter finalisation.  The one unexplained failure of
-    the multi-rank dry runs was a rank dying of SIGABRT with no Python error AFTER its work was done (round 4: once in about
-    twenty suite runs; round 5: not once in 60 consecutive un-retried runs, profiles/r5_dryrun_loop.txt) -- the signature of
-    a finalisation-order abort (a runtime or collective-library thread still alive while the interpreter and the HIP runtime
-    are torn down).  The process group has been destroyed behind a barrier and the line is out: nothing is left that needs
-    the destructors."""
+    """End of a RANK of a multi-rank run: flush and leave without ANY teardown -- neither the interpreter's finalisation nor
+    torch.distributed's.  The one unexplained failure of the multi-rank dry runs is a rank dying of SIGABRT with no Python error
+    (round 4: once in about twenty suite runs; round 5: once in seven suite runs, never in 82 consecutive un-retried runs of the same
+    commands outside the suite, profiles/r5_dryrun_loop.txt) -- the signature of a teardown-order abort: a runtime or collective-library
+    thread still alive while the process group, the interpreter and the HIP runtime are taken apart, or a peer's sockets closing under a
+    rank that is still inside its last collective.  So the last thing the ranks do together is a barrier; every rank then waits a
+    moment (the peers that entered the barrier last are still returning from it), and exits with os._exit: nothing is left that needs a
+    destructor, the line is out, the launcher sees exit code 0 from every rank."""
     sys.stdout.flush(); sys.stderr.flush()
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         torch.cuda.synchronize()
+        time.sleep(0.5)
         os._exit(code)
 
 
