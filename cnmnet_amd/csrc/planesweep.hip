@@ -917,6 +917,8 @@ static int sweep_store_policy(hipStream_t s, size_t out_bytes, hipEvent_t* e0, h
     SweepStoreTune& t = g_sweep_tune[dev];
     if (t.forced >= 0) return t.forced;
     if (t.chosen >= 0) return t.chosen;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;               // under capture: no event call of any kind (a query can invalidate a global-mode capture)
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return SWEEP_STORE_AUX; }
     if (t.issued == SWEEP_TUNE_N) {                                       // all samples issued: decide as soon as the last one has run
         if (hipEventQuery(t.ev[SWEEP_TUNE_N - 1][1]) != hipSuccess) { (void)hipGetLastError(); return SWEEP_STORE_AUX; }
         float v[2][SWEEP_TUNE_N / 2]; int n[2] = {0, 0};
@@ -929,8 +931,7 @@ static int sweep_store_policy(hipStream_t s, size_t out_bytes, hipEvent_t* e0, h
         sweep_tune_release(t);
         return t.chosen;
     }
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (out_bytes < (32u << 20) || hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return SWEEP_STORE_AUX; }
+    if (out_bytes < (32u << 20)) return SWEEP_STORE_AUX;
     const int i = t.issued;
     for (int j = 0; j < 2; ++j)
         if (!t.ev[i][j] && hipEventCreateWithFlags(&t.ev[i][j], hipEventDisableSystemFence) != hipSuccess) { (void)hipGetLastError(); t.ev[i][j] = nullptr; return SWEEP_STORE_AUX; }
