@@ -148,10 +148,17 @@ _LIVE_TRACE = None        # kernel name -> (average in-step duration in us, laun
 VALU_COUNTERS = ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE")
 
 
+_CHILD_DEADLINE = None         # wall-clock budget of ALL profiler child passes of a run (live_pmc sets it): a box on which they crawl must not hold the line back
+
+
 def _child_pass(extra, pattern, timeout_s, bench_args=(), env=None):
     """One `rocprofv3 <extra> -- python3 bench.py --steps 2 ...` child run (the interpreter directly behind `--`); returns the rows of
     the CSV matching `pattern`, or a string saying why not."""
     import csv
+    if _CHILD_DEADLINE is not None:
+        timeout_s = min(timeout_s, _CHILD_DEADLINE - time.monotonic())
+        if timeout_s < 20:
+            return "skipped: the run's budget for profiler child passes is spent"
     import glob
     import shutil
     import subprocess
@@ -189,7 +196,8 @@ def live_pmc(timeout_s=240):
     Sets the module tables; any pass that fails leaves its table None (the committed profiles are cited then)."""
     import collections
     import shutil
-    global _LIVE_TRAFFIC, _LIVE_TRAFFIC_WHY, _LIVE_VALU, _LIVE_TRACE, _LIVE_TRAFFIC_F16, _LIVE_FETCH_CBLK0
+    global _LIVE_TRAFFIC, _LIVE_TRAFFIC_WHY, _LIVE_VALU, _LIVE_TRACE, _LIVE_TRAFFIC_F16, _LIVE_FETCH_CBLK0, _CHILD_DEADLINE
+    _CHILD_DEADLINE = time.monotonic() + 300.0                           # eight passes of ~12 s each when all is well
     if shutil.which("rocprofv3") is None:
         _LIVE_TRAFFIC_WHY = "rocprofv3 not on PATH"
         return
