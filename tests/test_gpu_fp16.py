@@ -31,10 +31,12 @@ def _load(module, seed):
 
 
 @pytest.mark.parametrize("cin,cout,k,stride,rot,N,H,W", [(67, 128, 7, 1, 3, 2, 24, 40), (128, 128, 7, 2, 0, 1, 32, 32),
-                                                          (513, 256, 3, 1, 0, 1, 12, 20), (65, 64, 3, 1, 0, 3, 20, 28), (512, 512, 3, 2, 0, 2, 6, 8)])
+                                                          (513, 256, 3, 1, 0, 1, 12, 20), (65, 64, 3, 1, 0, 3, 20, 28), (512, 512, 3, 2, 0, 2, 6, 8),
+                                                          (104, 128, 5, 2, 0, 2, 12, 16), (80, 64, 3, 1, 0, 1, 10, 14), (40, 64, 3, 2, 0, 2, 9, 11), (32, 128, 7, 1, 0, 1, 8, 8)])
 @pytest.mark.parametrize("tile", [0, 1, 3, 4, 5])
 def test_conv_f16_vs_fp32_torch(dev, cin, cout, k, stride, rot, N, H, W, tile):
-    """conv_glds_kernel on small shapes: pixel tail, ragged K (9 / 65 channel groups), stride 2, rotation; tile 0 = the
+    """conv_glds_kernel on small shapes: pixel tail, ragged K (9 / 65 channel groups; 13 / 10 / 5 / 4 groups: left-over steps of five, two, five
+    and four groups, with and without full 8-group blocks before them -- the incremental k-walk), stride 2, rotation; tile 0 = the
     automatic choice, 1 = 128 x 256 (64 x 512 for the 64-cout layer), 3 = 64 x 128, 4 = 128 x 512, 5 = 256 x 256 (falling
     back as the header documents when Cout does not divide)."""
     from cnmnet_amd import _lib, ops
