@@ -266,14 +266,15 @@ def _by_kernel(table, kernel):
 
 def pmc_traffic(kernel, raw=False):
     """HBM bytes per launch of `kernel` (raw=True: without the x2 read correction): from this run's own PMC passes when they ran (live_traffic), else from the
-    committed pass of the last profiled build (profiles/r3_pmc_traffic.json), else None."""
+    committed pass of the last profiled build (profiles/r5_pmc_traffic.json), else None."""
     table = _LIVE_TRAFFIC
     if table is None:
         try:
-            with open(os.path.join(ROOT, "profiles", "r4_pmc_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r4_pmc_traffic.json")) else "r3_pmc_traffic.json")) as f:
+            name = next(n for n in ("r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
+            with open(os.path.join(ROOT, "profiles", name)) as f:
                 table = {k: (v["fetch_bytes_corrected"] + v["write_bytes"], v["fetch_bytes_corrected"] / 2 + v["write_bytes"])
                          for k, v in json.load(f)["kernels"].items()}
-        except (OSError, ValueError, KeyError):
+        except (OSError, ValueError, KeyError, StopIteration):
             return None
     for name, v in table.items():
         if name.replace("void ", "").startswith(kernel):
@@ -971,7 +972,7 @@ def main():
                 live_pmc()
             line["roofline"], line["roofline_planesweep"] = kernel_rooflines(dev, B, step=None if a.graph else (lambda: run(img, cams)))
             src = ("PMC passes of this run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE as child processes, FETCH_SIZE x 2)" if _LIVE_TRAFFIC is not None
-                   else "PMC pass committed under profiles/r4_pmc_traffic.json, possibly of an earlier build (live passes: %s)" % _LIVE_TRAFFIC_WHY)
+                   else "PMC pass committed under profiles/r5_pmc_traffic.json, possibly of an earlier build (live passes: %s)" % _LIVE_TRAFFIC_WHY)
             line["roofline"]["traffic_note"] = line["roofline_planesweep"]["traffic_note"] = "HBM bytes per average launch, " + src
         if world == 1 and not a.no_secondary and a.precision == "f32":
             del pipe, run, out
