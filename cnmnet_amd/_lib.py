@@ -20,7 +20,7 @@ class LayerInfo(C.Structure):
 
 
 class LayerWeights(C.Structure):
-    _fields_ = [("w", c_fp), ("b", c_fp), ("u", c_fp), ("u4", c_fp), ("uu", c_fp), ("bu", c_fp), ("wr", c_fp)]
+    _fields_ = [("w", c_fp), ("b", c_fp), ("u", c_fp), ("u4", c_fp), ("uu", c_fp), ("bu", c_fp), ("wr", c_fp), ("u4q", c_fp)]
 
 
 # name -> (restype, argtypes); mirrors include/cnm_engine.h declaration by declaration
@@ -58,6 +58,12 @@ PROTOTYPES = {
     "cnm_conv3x3_s2_winograd_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp]),
     "cnm_conv3x3_upsampled_winograd4_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "cnm_wino36_sync_floats": (c_sz, []),
+    "cnm_packed_winograd4_quad_floats": (c_sz, [c_i, c_i]),
+    "cnm_repack_winograd4_quad_f32": (c_i, [c_fp, c_i, c_i, c_fp, c_fp]),
+    "cnm_conv3x3_winograd4q_ok": (c_i, [c_i, c_i, c_i]),
+    "cnm_conv3x3_winograd4q_sync_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp,
+                                                 c_i, c_i, c_i, c_i, c_fp, c_sz, c_fp]),
+    "cnm_tune_wino36_quad": (c_i, [c_i]),
     "cnm_conv3x3_winograd4_sync_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp,
                                                 c_i, c_i, c_i, c_i, c_fp, c_sz, c_fp]),
     "cnm_conv5x5_winograd_sync_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp,
@@ -206,8 +212,8 @@ def load():
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch
         fn.restype, fn.argtypes = res, args
-    if lib.cnm_abi_version() != 5:
-        raise EngineError("libcnm_engine.so ABI version %d, expected 5" % lib.cnm_abi_version())
+    if lib.cnm_abi_version() != 6:
+        raise EngineError("libcnm_engine.so ABI version %d, expected 6" % lib.cnm_abi_version())
     # A/B switches without code changes: CNM_TUNE="wino36_staged=2,refine_side_stream=0" calls cnm_tune_<name>(<value>)
     for item in filter(None, os.environ.get("CNM_TUNE", "").split(",")):
         name, _, val = item.partition("=")

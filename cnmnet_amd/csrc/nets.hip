@@ -9,6 +9,7 @@
 #include <string.h>
 #include "cnm_common.h"
 #include "host_ops.h"
+#include "wino4_args.h"
 
 // ------------------------------------------------------------------ layer tables
 static const cnm_layer_info kDepthLayers[] = {
@@ -145,7 +146,16 @@ struct EngF32 {
     // with a sync workspace the staged F(4x4,3x3) kernel spreads ANY number of units evenly over the CUs, so it also takes the
     // small layers (down to 3 x 3 tiles per image) that the gather-fed kernel could not fill the chip with
     static bool wino4_staged_small(int Cout, int H, int W, const float* sync) { return sync && g_wino4_small && Cout % 128 == 0 && (W + 3) / 4 >= 3 && (H + 3) / 4 >= 3; }
+    // [r6] the four-wave F(4x4,3x3) kernel (64 output channels x 32 tiles per workgroup): where the eight-wave kernel cannot go (Cout = 64: the three
+    // iconv1 layers, which ran the gather-fed kernel at 0.42-0.46 of the matrix roof); on the Cout % 128 == 0 layers it was measured 10-25 % slower
+    // than the eight-wave kernel (profiles/r6_wino36q_probe*.txt), so mode 1 leaves those alone
+    static bool wino4_quad(const cnm_layer_weights& w, int Cout, int H, int W) {
+        const int mode = cnm_wino36_quad_mode();
+        return w.u4q && mode && (mode == 2 || Cout % 128 != 0) && cnm_conv3x3_winograd4q_ok(Cout, H, W);
+    }
     static int conv(const float* in, int Gt, int g0, int Gin, float* out, int Gto, int go0, int Cout, const cnm_layer_weights& w, int N, int H, int W, int k, int st, float* sync, void* s) {
+        if (k == 3 && st == 1 && wino4_quad(w, Cout, H, W))
+            return cnm_conv3x3_winograd4q_sync_c4_f32(in, Gt, g0, Gin, nullptr, 0, 0, 0, out, Gto, go0, Cout, w.u4q, w.b, N, H, W, 1, sync, sync ? cnm_wino36_sync_floats() : 0, s);
         if (w.u4 && k == 3 && st == 1 && (wino4_fills_chip(Cout, N, H, W) || wino4_staged_small(Cout, H, W, sync)))
             return cnm_conv3x3_winograd4_sync_c4_f32(in, Gt, g0, Gin, nullptr, 0, 0, 0, out, Gto, go0, Cout, w.u4, w.b, N, H, W, 1, sync, sync ? cnm_wino36_sync_floats() : 0, s);
         if (w.u && k == 3 && st == 2 && (Cout / 64) * (((long long)N * ((H + 1) / 2) * ((W + 1) / 2) + 63) / 64) < 256)   // too few implicit-GEMM tiles
@@ -162,6 +172,8 @@ struct EngF32 {
         if (w.u && (k == 5 || k == 7)) return cnm_conv_rows_winograd_sync_c4_f32(in, Gt, g0, Gin, nullptr, 0, 0, 0, out, Gto, go0, Cout, w.u, w.b, N, H, W, k, st, (k == 5 && st == 1) ? 2 : 4, 1, sync, sync ? cnm_wino36_sync_floats() : 0, s);
         return cnm_conv2d_c4_f32(in, Gt, g0, Gin, out, Gto, go0, Cout, w.w, w.b, N, H, W, k, st, 1, s); }
     static int conv2(const float* a, int Ga, const float* b, int Gb, float* out, int Gto, int Cout, const cnm_layer_weights& w, int N, int H, int W, float* sync, void* s) {
+        if (wino4_quad(w, Cout, H, W))
+            return cnm_conv3x3_winograd4q_sync_c4_f32(a, Ga, 0, Ga, b, Gb, 0, Gb, out, Gto, 0, Cout, w.u4q, w.b, N, H, W, 1, sync, sync ? cnm_wino36_sync_floats() : 0, s);
         if (w.u4 && (wino4_fills_chip(Cout, N, H, W) || wino4_staged_small(Cout, H, W, sync))) return cnm_conv3x3_winograd4_sync_c4_f32(a, Ga, 0, Ga, b, Gb, 0, Gb, out, Gto, 0, Cout, w.u4, w.b, N, H, W, 1, sync, sync ? cnm_wino36_sync_floats() : 0, s);
         if (w.u) return cnm_conv3x3_winograd_c4_f32(a, Ga, 0, Ga, b, Gb, 0, Gb, out, Gto, 0, Cout, w.u, w.b, N, H, W, 1, s);
         return cnm_conv2d_cat2_c4_f32(a, Ga, 0, Ga, b, Gb, 0, Gb, out, Gto, 0, Cout, w.w, w.b, N, H, W, 3, 1, 1, s); }

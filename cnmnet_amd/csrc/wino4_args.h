@@ -19,3 +19,6 @@ struct Wino4Args {
 // s2: the stride-2 form on the four pixel phases of the input (a.H / a.W = output size, a.nchunks = 4 x the input's chunks,
 // filter packed by cnm_pack_winograd4_s2_bn_f32): M = 4 for a 5x5, M = 3 for a 7x7 filter; there is no gather-fed twin.
 int cnm_wino36s_try_launch(const Wino4Args& a, int M, int ups, hipStream_t stream, int s2 = 0);
+// Four-wave variant (conv_winograd4q.hip): a.u = the quad-packed filter, a.nchunks = 8-channel chunks; same return convention.
+int cnm_wino36q_try_launch(const Wino4Args& a, hipStream_t stream);
+int cnm_wino36_quad_mode();                                              // cnm_tune_wino36_quad: 0 never, 1 where measured faster, 2 wherever eligible

@@ -77,6 +77,7 @@ class _EngineNet(nn.Module):
         self._layers = None        # engine layer table (resolved lazily: needs the library)
         self.winograd = os.environ.get("CNM_WINOGRAD", "1") != "0"   # fp32 stride-1 layers in the Winograd domain
         self.winograd4 = os.environ.get("CNM_WINOGRAD4", "1") != "0"  # large 3x3 layers: F(4x4,3x3) instead of F(2x2,3x3)
+        self.quad_all = os.environ.get("CNM_QUAD_ALL", "0") == "1"     # pack the four-wave kernel's filter for EVERY 3x3 stride-1 layer (A/B with cnm_tune_wino36_quad(2))
         self.fused_upsample = os.environ.get("CNM_FUSED_UPSAMPLE", "1") != "0"   # up_conv layers: upsample folded into the conv (composed phase filters)
         self._packed = None        # [(w, b[, u])] device tensors, one per engine layer
         self._packed_key = None
@@ -147,13 +148,18 @@ class _EngineNet(nn.Module):
                         # 3x3 stride 2: a third filter, in the uu slot (bu / wr stay empty: not an up_conv) -- the pixel-phase form for the
                         # shapes that would otherwise run the implicit GEMM (nets.hip)
                         fused = (ops.pack_winograd4_s2(w, bnp, rot=L["rot"], eps=bn.eps), None, None)
-                    packed.append((wp, bp, up, u4) + tuple(fused))
+                    # [r6] 3x3 stride 1: the quad re-ordering of u4 for the four-wave kernel -- by default only where the executor uses it (Cout not a
+                    # multiple of 128: the iconv1 layers); quad_all packs it for every such layer (A/B through cnm_tune_wino36_quad(2))
+                    u4q = (ops.repack_winograd4_quad(u4, L["Cout"], L["Cin"])
+                           if (u4 is not None and L["ksize"] == 3 and L["stride"] == 1 and (L["Cout"] % 128 != 0 or getattr(self, "quad_all", False))) else None)
+                    packed.append((wp, bp, up, u4) + tuple(fused) + (u4q,))
         arr = (_lib.LayerWeights * len(packed))()
         for i, t in enumerate(packed):
             arr[i].w, arr[i].b = t[0].data_ptr(), t[1].data_ptr()
             arr[i].u = t[2].data_ptr() if len(t) > 2 and t[2] is not None else None
             arr[i].u4 = t[3].data_ptr() if len(t) > 3 and t[3] is not None else None
             arr[i].uu, arr[i].bu, arr[i].wr = [t[j].data_ptr() if len(t) > 6 and t[j] is not None else None for j in (4, 5, 6)]
+            arr[i].u4q = t[7].data_ptr() if len(t) > 7 and t[7] is not None else None
         self._packed, self._weights_arr, self._packed_key = packed, arr, key
 
     def _workspace(self, device, nfloats):

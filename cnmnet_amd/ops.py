@@ -413,6 +413,30 @@ def conv3x3_winograd4_c4(x, u_packed, b_packed, Cout, relu=True, x2=None, ksize=
     return out
 
 
+def repack_winograd4_quad(u_packed, Cout, Cin):
+    """The 36-point packed filter of pack_winograd4 (3x3) re-ordered for the four-wave kernel's 8-channel phases (a permutation)."""
+    _dev(u_packed)
+    lib = _lib.load()
+    uq = torch.empty(lib.cnm_packed_winograd4_quad_floats(Cout, Cin), device=u_packed.device, dtype=torch.float32)
+    with torch.cuda.device(u_packed.device):
+        _lib.check(lib.cnm_repack_winograd4_quad_f32(_p(u_packed), Cout, Cin, _p(uq), _stream()))
+    return uq
+
+
+def conv3x3_winograd4q_c4(x, uq_packed, b_packed, Cout, relu=True, x2=None, sync=None):
+    """Four-wave F(4x4,3x3) kernel (cnm_conv3x3_winograd4q_sync_c4_f32): 64 output channels x 32 tiles per workgroup, one wave per SIMD."""
+    _dev(x, uq_packed, b_packed, x2, sync)
+    N, G, H, W, _ = x.shape
+    out = torch.empty(N, Cout // 4, H, W, 4, device=x.device, dtype=torch.float32)
+    G2 = x2.shape[1] if x2 is not None else 0
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        _lib.check(lib.cnm_conv3x3_winograd4q_sync_c4_f32(_p(x), G, 0, G, _p(x2) if x2 is not None else None, G2, 0, G2,
+                                                          _p(out), Cout // 4, 0, Cout, _p(uq_packed), _p(b_packed), N, H, W, int(relu),
+                                                          _p(sync) if sync is not None else None, sync.numel() if sync is not None else 0, _stream()))
+    return out
+
+
 # rows of the bilinear 2x upsampling (align_corners=False) seen by a 3-tap window, as weights on low-resolution rows
 # (i-1, i, i+1): [output parity a][tap k] -- hi-res row 2i+a+k-1
 _UPS_TAPS = (((0.75, 0.25, 0.0), (0.25, 0.75, 0.0), (0.0, 0.75, 0.25)),

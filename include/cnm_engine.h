@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define CNM_ABI_VERSION 5                    /* 5 [r5]: engine status per device; CNM_ERR_LAUNCH is sticky per device after a hand-off time-out; sync-workspace flag
+#define CNM_ABI_VERSION 6                    /* 6 [r6]: cnm_layer_weights gains u4q (the four-wave F(4x4,3x3) kernel's filter); 5 [r5]: engine status per device; CNM_ERR_LAUNCH is sticky per device after a hand-off time-out; sync-workspace flag
                                                words are no longer guaranteed zero after a FAILED call (stale generations, harmless to later launches on the
                                                same queue; callers that acknowledge a failure should zero their sync workspaces, as cnmnet_amd.ops.engine_status
                                                does); _cpu host twins, cnm_engine_status, cnm_tune_sync_spin_limit exported since 4 */
@@ -251,6 +251,26 @@ int cnm_conv3x3_winograd4_sync_c4_f32(const float* in_a, int Ga_total, int ga0, 
                                       const float* u_packed, const float* b_packed,
                                       int N, int H, int W, int relu, float* sync_ws, size_t sync_floats, void* stream);
 
+/* [r6] The four-wave F(4x4,3x3) kernel (csrc/conv_winograd4q.hip): 64 output channels x 32 tiles per workgroup, ONE wave per SIMD with
+ * 288 accumulator registers, so that every weight fragment streamed out of L2 feeds two groups of MFMAs (half the weight stream per
+ * flop of the eight-wave kernel above) and Cout only has to be a multiple of 64 (the three iconv1 layers, depthNet_model.py:110-112,
+ * 278-308).  The filter is the 36-point packed filter of cnm_pack_winograd4_bn_f32 re-ordered for 8-channel phases -- a permutation,
+ * cnm_packed_winograd4_quad_floats(Cout, Cin) floats.  Shapes: cnm_conv3x3_winograd4q_ok (at least 12 x 2 or 6 x 3 tiles per image);
+ * others return CNM_ERR_BAD_ARG.  Same sync-workspace contract as cnm_conv3x3_winograd4_sync_c4_f32 (NULL / 0 allowed: ranges then end
+ * on unit boundaries).  Results are bit-reproducible run to run and differ from the eight-wave kernel's in the last bits (the reduction
+ * over input channels is grouped differently).
+ * cnm_tune_wino36_quad: 0 = the fp32 executors never use it, 1 (default) = on the layers where it was measured faster, 2 = wherever
+ * the shape is eligible and the quad filter was supplied (cnm_layer_weights.u4q); other values query.  Returns the previous value. */
+size_t cnm_packed_winograd4_quad_floats(int Cout, int Cin);
+int cnm_repack_winograd4_quad_f32(const float* u_packed, int Cout, int Cin, float* u_packed_quad, void* stream);
+int cnm_conv3x3_winograd4q_ok(int Cout, int H, int W);
+int cnm_conv3x3_winograd4q_sync_c4_f32(const float* in_a, int Ga_total, int ga0, int Ga,
+                                       const float* in_b, int Gb_total, int gb0, int Gb,
+                                       float* out, int Gout_total, int gout0, int Cout,
+                                       const float* u_packed_quad, const float* b_packed,
+                                       int N, int H, int W, int relu, float* sync_ws, size_t sync_floats, void* stream);
+int cnm_tune_wino36_quad(int mode);
+
 /* Winograd F(2x2,5x5) for the 5x5 stride-1 layer (conv2.0 = nn.Conv2d(128, 256, 5, 1, 2), depthNet_model.py:141-144):
  * the 36-point machine of the F(4x4,3x3) kernel with 2x2 output tiles; 9 instead of 25 multiplies per output (the
  * row-wise kernel: 15).  u_packed from cnm_pack_winograd5x5_bn_f32, size cnm_packed_winograd4_floats(Cout, Cin). */
@@ -452,7 +472,9 @@ int cnm_net_layer(int net, int index, cnm_layer_info* info);   /* D=64 table */
  * output channels (fp32 engine: cnm_pack_winograd4_bn_f32; fp16 engine: cnm_pack_conv_bn_f16, half data), the folded
  * bias four times, and the ring-pass filter (cnm_pack_upsampled_ring_f32, fp32 for both engines); all three or none. */
 typedef struct cnm_layer_weights { const float* w; const float* b; const float* u; const float* u4;
-                                   const float* uu; const float* bu; const float* wr; } cnm_layer_weights;
+                                   const float* uu; const float* bu; const float* wr;
+                                   const float* u4q;   /* [r6, ABI 6] 3x3 stride-1 layers: the quad re-ordering of u4 (cnm_repack_winograd4_quad_f32), or NULL */
+                                 } cnm_layer_weights;
 
 /* depthNet.forward (depthNet_model.py:226-263) for P = B*S (ref,src) pairs.
  * weights[i] = packed tensors of layer i of the CNM_NET_DEPTH table (conv1.0 packed with

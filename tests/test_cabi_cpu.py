@@ -37,7 +37,7 @@ def test_header_symbols_exported_and_bound(lib):
 
 
 def test_host_entry_points(lib):
-    assert lib.cnm_abi_version() == 5
+    assert lib.cnm_abi_version() == 6
     lo, hi = ctypes.c_double(), ctypes.c_double()
     assert lib.cnm_idepth_range_host(3.0, ctypes.byref(lo), ctypes.byref(hi)) == 0 and (lo.value, hi.value) == (0.1, 3.0)
     assert lib.cnm_idepth_range_host(2.0, ctypes.byref(lo), ctypes.byref(hi)) == 0 and (lo.value, hi.value) == (0.02, 2.0)

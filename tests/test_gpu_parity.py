@@ -487,6 +487,43 @@ def test_conv3x3_winograd4_staged(dev, ops, cin, cin2, cout, rot, N, H, W):
     assert torch.equal(outs[2], outs[3]) and ops.sync_workspace_state(sync) == 0
 
 
+@pytest.mark.parametrize("cin,cin2,cout,rot,N,H,W", [
+    (64, 0, 64, 0, 2, 48, 64),         # the iconv1 shape class: Cout = 64, 2 x 16 tile blocks, whole blocks
+    (65, 0, 64, 0, 1, 40, 72),         # 65 channels (17 groups: the last phase has one plane), ragged tile columns (18: second block mostly empty)
+    (67, 0, 128, 3, 2, 24, 64),        # rotated first layer, two channel blocks, 6 tile rows
+    (32, 0, 256, 0, 3, 24, 32),        # 4 x 8 tile blocks (8 tile columns), four channel blocks
+    (128, 129, 128, 0, 2, 32, 64),     # concatenated input: 128 + 129 channels, the second view starts mid-chunk
+    (20, 0, 128, 0, 1, 24, 28),        # seven tile columns (4 x 8 blocks, ragged), ragged channel group, 6 tile rows = 1.5 blocks
+    (16, 0, 64, 0, 40, 16, 64),        # many images, two phases per unit
+    (48, 0, 192, 0, 2, 52, 100),       # three channel blocks, ragged rows and columns
+    (512, 0, 256, 0, 1, 48, 64)])      # 64 phases per unit: long reductions, ranges cut units
+def test_conv3x3_winograd4_quad(dev, ops, cin, cin2, cout, rot, N, H, W):
+    """Four-wave F(4x4,3x3) kernel (conv_winograd4q.hip): against the fp64 torch convolution at the gather-fed kernel's bar (2e-4 of
+    the output scale), bit-reproducible, with unit-aligned ranges and with ranges that cut units (every flag re-armed)."""
+    rng = np.random.default_rng(cin * 17 + H + cout)
+    cp = 4 * ((cin + 3) // 4)
+    x = T(rng.standard_normal((N, cin, H, W)).astype(np.float32))
+    x2 = T(rng.standard_normal((N, cin2, H, W)).astype(np.float32)) if cin2 else None
+    ct = (cp if cin2 else cin) + cin2
+    w = T((rng.standard_normal((cout, ct, 3, 3)) * (2.0 / (ct * 9)) ** 0.5).astype(np.float32))
+    bnp = [T(a.astype(np.float32)) for a in (rng.uniform(0.5, 1.5, cout), rng.normal(0, 0.2, cout), rng.normal(0, 0.2, cout), rng.uniform(0.5, 1.5, cout))]
+    sc = bnp[0].double() / torch.sqrt(bnp[3].double() + 1e-5)
+    xin = x if not cin2 else torch.cat([x, torch.zeros(N, cp - cin, H, W), x2], 1)
+    want = F.relu(F.conv2d(xin.double(), w.double(), padding=1) * sc[None, :, None, None] + (bnp[1].double() - bnp[2].double() * sc)[None, :, None, None]).numpy()
+    bnd = tuple(t.to(dev) for t in bnp)
+    _, bp = ops.pack_conv(w.to(dev), bnd, rot=rot)
+    uq = ops.repack_winograd4_quad(ops.pack_winograd4(w.to(dev), bnd, rot=rot), cout, ct)
+    xr = torch.cat((x[:, rot:], x[:, :rot]), 1) if rot else x
+    xc = ops.nchw_to_c4(xr.to(dev)); x2c = ops.nchw_to_c4(x2.to(dev)) if cin2 else None
+    sync = ops.wino36_sync_workspace(dev)
+    outs = [ops.conv3x3_winograd4q_c4(xc, uq, bp, cout, True, x2=x2c, sync=sy).clone() for sy in (None, None, sync, sync)]
+    scale = max(np.abs(want).max(), 1.0)
+    for o in (outs[0], outs[2]):
+        got = ops.c4_to_nchw(o, cout).cpu().numpy()
+        assert np.abs(got - want).max() < 2e-4 * scale, np.abs(got - want).max()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[2], outs[3]) and ops.sync_workspace_state(sync) == 0
+
+
 def test_sync_generation_differs_from_launch_to_launch(dev):
     """The hand-off generation is the queue's dispatch id (csrc/sync_ws.h): the same for every workgroup of a launch, different for
     every launch -- eager launches and replays of one captured HIP graph alike (a constant would make a stale flag of a failed
