@@ -171,7 +171,7 @@ def _child_pass(extra, pattern, timeout_s, bench_args=(), env=None):
         pin = {}
         try:
             from cnmnet_amd import _lib
-            pol = _lib.load().cnm_tune_sweep_store(99, None)             # query: the plane sweep's store policy this process has measured (-1: still sampling)
+            pol = _lib.load().cnm_tune_sweep_store(99, None)             # query: the plane sweep's store policy this process calibrated (-1: none; the library reads CNM_SWEEP_STORE itself)
             pin = {"CNM_SWEEP_STORE": str(pol)} if pol >= 0 else {}
         except Exception:                                                # noqa: BLE001  (no library: the child fails by itself)
             pass
@@ -462,7 +462,6 @@ def kernel_rooflines(dev, frames, step=None):
     # launch's 210 MB to be written back): the launch between its real neighbours, at the clocks and cache state of the step.
     in_step = None
     if step is not None:
-        import ctypes
         for _ in range(5):
             step()
         _lib.check(lib.cnm_debug_sweep_timing_arm(n_it))
@@ -482,13 +481,14 @@ def kernel_rooflines(dev, frames, step=None):
     byts = frames * 3 * H * W * 4 + pairs * 3 * H * W * 4 + pairs * (PLANES + 3) * H * W * 4
     med = (ctypes.c_float * 2)()
     pol = lib.cnm_tune_sweep_store(99, ctypes.cast(med, ctypes.c_void_p))   # query only
-    kname = "planesweep_kernel<1, %d>" % pol if pol >= 0 else "planesweep_kernel<1,"
-    sweep = {"kernel": kname if pol >= 0 else "planesweep_kernel<1, 0 | 2>", "bound": "hbm", "achieved": byts / ms / 1e6, "peak": HBM_PEAK_GBS,
+    kname = "planesweep_kernel<1, %d>" % (pol if pol >= 0 else 2)
+    sweep = {"kernel": kname, "bound": "hbm", "achieved": byts / ms / 1e6, "peak": HBM_PEAK_GBS,
              "unit": "GB/s", "frac": byts / ms / 1e6 / HBM_PEAK_GBS, "traffic": pmc_traffic(kname),
              "traffic_uncorrected": pmc_traffic(kname, raw=True),
-             "store_policy": {"in_force": {0: "plain", 2: "nt", -1: "still sampling"}.get(pol, str(pol)), "median_us_plain": round(float(med[0]), 1), "median_us_nt": round(float(med[1]), 1),
-                              "note": "second template argument of the kernel; the first 24 launches of the process alternate between plain and non-temporal output stores inside "
-                                      "the timed steps and the lower median stays (cnm_tune_sweep_store, include/cnm_engine.h): which is faster differs between boxes"},
+             "store_policy": {"in_force": {0: "plain", 2: "nt", -1: "default (nt): nothing calibrated"}.get(pol, str(pol)), "median_us_plain": round(float(med[0]), 1), "median_us_nt": round(float(med[1]), 1),
+                              "note": "second template argument of the kernel.  [r6] decided ONCE per device, before any timed step or graph capture, by "
+                                      "cnm_calibrate_sweep_store (24 launches on scratch, each behind a 400 MB fill, run when the depthNet allocates its workspace; medians "
+                                      "above): every launch of the timed region, eager or replayed from a HIP graph, runs this policy -- none samples.  Which is faster differs between boxes"},
              "target": 0.60, "met": bool(byts / ms / 1e6 / HBM_PEAK_GBS >= 0.60),             # BASELINE.json north_star: >= 60 % of the HBM roofline
              "algorithmic_bytes_per_launch": byts, "avg_launch_ms": ms,
              "launch_ms": {"median": per_main[n_main // 2], "p10": per_main[n_main // 10], "p90": per_main[9 * n_main // 10], "n": n_main},
@@ -760,7 +760,7 @@ def planesweep_alone(dev, B, S, Hh, Ww, D, n_it=12):
     ms = sum(per) / n_it
     pairs = B * S
     byts = B * 3 * Hh * Ww * 4 + pairs * 3 * Hh * Ww * 4 + pairs * (D + 3) * Hh * Ww * 4
-    return {"kernel": "planesweep_kernel<1, %d>" % lib.cnm_tune_sweep_store(99, None), "bound": "hbm", "achieved": byts / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    return {"kernel": "planesweep_kernel<1, %d>" % (lambda q: q if q >= 0 else 2)(lib.cnm_tune_sweep_store(99, None)), "bound": "hbm", "achieved": byts / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": byts / ms / 1e6 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": byts, "avg_launch_ms": ms,
             "launch_ms": {"median": per[n_it // 2], "min": per[0], "max": per[-1], "n": n_it},
             "note": "ONE launch over the %d pairs of this configuration, timed as roofline_planesweep times the headline's" % pairs}

@@ -117,6 +117,9 @@ PROTOTYPES = {
                                      c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "cnm_tune_gldsx": (c_i, [c_i]),
     "cnm_tune_sweep_store": (c_i, [c_i, c_fp]),
+    "cnm_calibrate_sweep_store_floats": (c_sz, []),
+    "cnm_calibrate_sweep_store": (c_i, [c_fp, c_sz, c_fp, c_fp]),
+    "cnm_decide_sweep_store": (c_i, [c_i, c_fp]),
     "cnm_debug_sweep_timing_arm": (c_i, [c_i]),
     "cnm_debug_sweep_timing_read": (c_i, [c_fp, c_i]),
     "cnm_planesweep_cat_c8_f16": (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_sz, c_i, c_i, c_i, c_i, c_i, c_d, c_d, c_fp]),
@@ -218,7 +221,7 @@ def load():
     for item in filter(None, os.environ.get("CNM_TUNE", "").split(",")):
         name, _, val = item.partition("=")
         fn = getattr(lib, "cnm_tune_" + name.strip())
-        fn(int(val), *([None] * (len(fn.argtypes) - 1)))               # knobs with an output pointer (sweep_store) take NULL
+        fn(int(val), *([None] * (len(fn.argtypes or (None,)) - 1)))               # knobs with an output pointer (sweep_store) take NULL
     _lib = lib
     return lib
 

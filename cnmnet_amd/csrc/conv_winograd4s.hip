@@ -52,6 +52,13 @@
 #ifndef WINO4S_PRIO
 #define WINO4S_PRIO 0
 #endif
+#ifndef WINO4S_CLUMP
+#define WINO4S_CLUMP 0
+#endif
+#ifndef WINO4S_CLUMP_A
+#define WINO4S_CLUMP_A 4
+#define WINO4S_CLUMP_B 10
+#endif
 #ifndef WINO4S_HI_STEP
 #define WINO4S_HI_STEP 6  // double step at which waves 4-7 start issuing their DMA pieces (waves 0-3: step 0); >= 4
 #endif
@@ -336,13 +343,13 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
             }
             // between the MFMAs: the transform of phase p + 1 -- row T (double steps 0-4), rows P and M (3-11) -- and the
             // DMA of phase p + 2 (waves 0-3: double steps 0.., waves 4-7: double steps 6..)
-            if (xp >= 1 && xp <= 3) { trT_col(2 * xp - 2); trT_col(2 * xp - 1); }
+            if (!WINO4S_CLUMP && xp >= 1 && xp <= 3) { trT_col(2 * xp - 2); trT_col(2 * xp - 1); }
             if (xp <= 2) { trT_read(2 * xp, rT); trT_read(2 * xp + 1, rT); }
-            if (xp == 4) tr_row(rowT, w0 + hi * 5 * 6144);
-            if (xp >= 4 && xp <= 9) trP_col(xp - 4);
+            if (!WINO4S_CLUMP && xp == 4) tr_row(rowT, w0 + hi * 5 * 6144);
+            if (!WINO4S_CLUMP && xp >= 4 && xp <= 9) trP_col(xp - 4);
             if (xp >= 3 && xp <= 8) trP_read(xp - 3, r0);
-            if (xp == 10) tr_row(rowP, w0 + 6144 + hi * 2 * 6144);
-            if (xp == 11) tr_row(rowM, w0 + 2 * 6144 + hi * 2 * 6144);
+            if (!WINO4S_CLUMP && xp == 10) tr_row(rowP, w0 + 6144 + hi * 2 * 6144);
+            if (!WINO4S_CLUMP && xp == 11) tr_row(rowM, w0 + 2 * 6144 + hi * 2 * 6144);
 #if defined(WINO4S_DMA_SPREAD)                                            // one piece every WINO4S_DMA_SPREAD double steps (waves 4-7: half a stride later)
             {
                 constexpr int SP = WINO4S_DMA_SPREAD;
@@ -377,6 +384,21 @@ __global__ __launch_bounds__(512, 2) void conv_winograd36s_f32_kernel(const Wino
             acc[x1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, acc[x1], 0, 0, 0);
             acc[x0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc[x0], 0, 0, 0);
             acc[x1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, acc[x1], 0, 0, 0);
+            // WINO4S_CLUMP [r6]: the transform's VALU work in TWO clumps behind the MFMAs of a double step (24 + 48 operations) instead of groups of
+            // 2-12 between them: an fp32 VALU instruction between two fp32 MFMAs drains and refills the matrix pipe (conv_winograd4q.hip)
+            if (WINO4S_CLUMP && xp == WINO4S_CLUMP_A) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) trT_col(j);
+                tr_row(rowT, w0 + hi * 5 * 6144);
+            }
+            if (WINO4S_CLUMP && xp == WINO4S_CLUMP_B) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) trP_col(j);
+                tr_row(rowP, w0 + 6144 + hi * 2 * 6144);
+                tr_row(rowM, w0 + 2 * 6144 + hi * 2 * 6144);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         // every DMA this wave issued in the phase is older than the WD weight fragments still in flight: vmcnt retires in order

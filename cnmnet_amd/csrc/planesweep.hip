@@ -862,99 +862,122 @@ static int sweep_resident_workgroups() {
 // on the launch's own stream right around the kernel -- the launch as it runs INSIDE the caller's step, between its real
 // neighbours.  The events are created WITHOUT the system-scope fence of a default hipEventRecord (hipEventDisableSystemFence): with
 // it the closing event first writes the launch's 210 MB of output back to system scope, and the bracket measures that flush.
+// [r6] The launch path looks at ONE relaxed atomic (armed launches left); everything else happens under the hook's mutex, and a launch
+// under stream capture is never bracketed.
 #include <vector>
+#include <atomic>
+#include <mutex>
+#include <algorithm>
+#include <stdlib.h>
+#include <string.h>
+static std::mutex g_sweep_ev_mu;
 static std::vector<hipEvent_t> g_sweep_ev;                              // 2 per armed launch
-static int g_sweep_ev_next = 0, g_sweep_ev_armed = 0;
+static int g_sweep_ev_next = 0;
+static std::atomic<int> g_sweep_ev_left{0};
 extern "C" int cnm_debug_sweep_timing_arm(int n) {
+    std::lock_guard<std::mutex> lock(g_sweep_ev_mu);
+    g_sweep_ev_left.store(0, std::memory_order_relaxed);
     for (hipEvent_t e : g_sweep_ev) (void)hipEventDestroy(e);
-    g_sweep_ev.clear(); g_sweep_ev_next = 0; g_sweep_ev_armed = 0;
+    g_sweep_ev.clear(); g_sweep_ev_next = 0;
     if (n <= 0) return CNM_OK;
     for (int i = 0; i < 2 * n; ++i) {
         hipEvent_t e = nullptr;
         if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess) { (void)hipGetLastError(); return CNM_ERR_LAUNCH; }
         g_sweep_ev.push_back(e);
     }
-    g_sweep_ev_armed = n;
+    g_sweep_ev_left.store(n, std::memory_order_relaxed);
     return CNM_OK;
 }
 // elapsed milliseconds of the armed launches recorded so far (waits for the last one); returns how many were written to ms[]
 extern "C" int cnm_debug_sweep_timing_read(float* ms, int n) {
+    std::lock_guard<std::mutex> lock(g_sweep_ev_mu);
     int k = 0;
     for (; k < n && k < g_sweep_ev_next; ++k) {
         if (hipEventSynchronize(g_sweep_ev[2 * k + 1]) != hipSuccess || hipEventElapsedTime(ms + k, g_sweep_ev[2 * k], g_sweep_ev[2 * k + 1]) != hipSuccess) { (void)hipGetLastError(); break; }
     }
     return k;
 }
-
-// Cache policy of the output stores, chosen per device by measurement [r5].  The volume is written once (13 MB per pair); whether `nt`
-// stores or plain ones are faster INSIDE a step depends on the box: the launch displaces the dirty lines its predecessors left in the
-// memory-side cache (tools/k1_context_probe.py: 55 us into its own still-cached buffer, 63 us after any kernel that wrote 400 MB), and on
-// the pool's boxes that costs nt 55-57 us against 60 us plain on some and 65 against 60 on others (tools/k1_in_step_variants.sh).  So the
-// first SWEEP_TUNE_N large launches of a device alternate between the two policies, each between a pair of fence-free events on its own
-// stream; once they have all completed (queried, never waited for) the policy with the lower median stays.  Both produce the same bytes.
-// cnm_tune_sweep_store(0 / 2) forces a policy, (-1) returns to measuring; launches under stream capture and small launches never sample.
-#include <algorithm>
-#include <mutex>
-#ifndef SWEEP_TUNE_N
-#define SWEEP_TUNE_N 24
-#endif
-struct SweepStoreTune {
-    int forced = -1, chosen = -1, issued = 0;
-    float median_us[2] = {0.f, 0.f};
-    hipEvent_t ev[SWEEP_TUNE_N][2] = {};
-};
-static SweepStoreTune g_sweep_tune[64];
-static std::mutex g_sweep_tune_mu;
-static void sweep_tune_release(SweepStoreTune& t) {
-    for (int i = 0; i < SWEEP_TUNE_N; ++i) for (int j = 0; j < 2; ++j) if (t.ev[i][j]) { (void)hipEventDestroy(t.ev[i][j]); t.ev[i][j] = nullptr; }
-}
-// returns the policy of this launch; *e0 / *e1 = events to record around it (nullptr: not a sampling launch)
-static int sweep_store_policy(hipStream_t s, size_t out_bytes, hipEvent_t* e0, hipEvent_t* e1) {
+static void sweep_timing_events(hipStream_t s, hipEvent_t* e0, hipEvent_t* e1) {   // cold: only while a measurement is armed
     *e0 = *e1 = nullptr;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return; }
+    std::lock_guard<std::mutex> lock(g_sweep_ev_mu);
+    if (g_sweep_ev_left.load(std::memory_order_relaxed) <= 0 || 2 * g_sweep_ev_next + 1 >= (int)g_sweep_ev.size()) return;
+    *e0 = g_sweep_ev[2 * g_sweep_ev_next]; *e1 = g_sweep_ev[2 * g_sweep_ev_next + 1]; ++g_sweep_ev_next;
+    g_sweep_ev_left.fetch_sub(1, std::memory_order_relaxed);
+}
+
+// Cache policy of the output stores: a per-device DECISION [r6], not a side effect of launching.  The volume is written once (13 MB per
+// pair); whether `nt` stores or plain ones are faster INSIDE a step depends on the box: the launch displaces the dirty lines its
+// predecessors left in the memory-side cache (tools/k1_context_probe.py: 55 us into its own still-cached buffer, 63 us after any kernel
+// that wrote 400 MB), and on the pool's boxes that costs nt 55-57 us against 60 us plain on some and 65 against 60 on others.  Round 5
+// sampled the first 24 large launches of a process in place -- events and a process-global mutex in the launch path, the timed steps
+// of a benchmark not the steady state, and launches under stream capture pinned to the default.  Now
+//   * a launch reads ONE relaxed atomic per device: forced (cnm_tune_sweep_store, or CNM_SWEEP_STORE = plain | nt | 0 | 2 in the
+//     environment, read once) > calibrated > the default (nt);
+//   * cnm_calibrate_sweep_store(scratch, stream) is the measurement, explicit and blocking: 24 launches of the 16-pair 192 x 256 x 64
+//     shape on caller-provided scratch, alternating policies, each behind a 400 MB fill (the predecessor that matters) and between two
+//     fence-free events; the lower median becomes the device's policy.  The Python modules run it once per device when a depthNet
+//     allocates its workspace (never under capture), i.e. before any graph is captured and before any timed region.
+// Both policies write the same bytes (tests/test_gpu_parity.py).
+struct SweepStoreState { std::atomic<int> forced{-1}, chosen{-1}; float median_us[2] = {0.f, 0.f}; };
+static SweepStoreState g_sweep_store[64];
+static std::mutex g_sweep_store_mu;                                     // calibration and the tuning knob only
+static int sweep_store_env() {                                          // CNM_SWEEP_STORE, read once: -1 = not set
+    static const int v = [] {
+        const char* e = getenv("CNM_SWEEP_STORE");
+        if (!e || !*e) return -1;
+        if (!strcmp(e, "plain") || !strcmp(e, "0")) return 0;
+        if (!strcmp(e, "nt") || !strcmp(e, "2")) return SWEEP_STORE_AUX;
+        return -1;
+    }();
+    return v;
+}
+static int sweep_store_policy() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return SWEEP_STORE_AUX; }
-    std::lock_guard<std::mutex> lock(g_sweep_tune_mu);
-    SweepStoreTune& t = g_sweep_tune[dev];
-    if (t.forced >= 0) return t.forced;
-    if (t.chosen >= 0) return t.chosen;
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;               // under capture: no event call of any kind (a query can invalidate a global-mode capture)
-    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return SWEEP_STORE_AUX; }
-    if (t.issued == SWEEP_TUNE_N) {                                       // all samples issued: decide as soon as the last one has run
-        if (hipEventQuery(t.ev[SWEEP_TUNE_N - 1][1]) != hipSuccess) { (void)hipGetLastError(); return SWEEP_STORE_AUX; }
-        float v[2][SWEEP_TUNE_N / 2]; int n[2] = {0, 0};
-        for (int i = 0; i < SWEEP_TUNE_N; ++i) {
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, t.ev[i][0], t.ev[i][1]) == hipSuccess) v[i & 1][n[i & 1]++] = ms * 1e3f; else (void)hipGetLastError();
-        }
-        for (int k = 0; k < 2; ++k) { std::sort(v[k], v[k] + n[k]); t.median_us[k] = n[k] ? v[k][n[k] / 2] : 0.f; }
-        t.chosen = (n[0] && n[1] && t.median_us[0] < t.median_us[1]) ? 0 : SWEEP_STORE_AUX;
-        sweep_tune_release(t);
-        return t.chosen;
-    }
-    if (out_bytes < (32u << 20)) return SWEEP_STORE_AUX;
-    const int i = t.issued;
-    for (int j = 0; j < 2; ++j)
-        if (!t.ev[i][j] && hipEventCreateWithFlags(&t.ev[i][j], hipEventDisableSystemFence) != hipSuccess) { (void)hipGetLastError(); t.ev[i][j] = nullptr; return SWEEP_STORE_AUX; }
-    *e0 = t.ev[i][0]; *e1 = t.ev[i][1];
-    ++t.issued;
-    return (i & 1) ? SWEEP_STORE_AUX : 0;                                 // even samples plain, odd samples SWEEP_STORE_AUX
+    const int f = g_sweep_store[dev].forced.load(std::memory_order_relaxed);
+    if (f >= 0) return f;
+    const int e = sweep_store_env();
+    if (e >= 0) return e;
+    const int c = g_sweep_store[dev].chosen.load(std::memory_order_relaxed);
+    return c >= 0 ? c : SWEEP_STORE_AUX;
 }
-// n = 0 / SWEEP_STORE_AUX: force that policy; n = -1: measure again; anything else only queries.  Returns the policy in force on the current
-// device: 0 or SWEEP_STORE_AUX once chosen or forced, -1 while the samples are being taken.  median_us (may be NULL): [plain, nt] of the last decision.
+// n = 0 / SWEEP_STORE_AUX: force that policy on the current device; n = -1: drop the forced policy AND the calibration (back to the
+// default until the next cnm_calibrate_sweep_store); anything else only queries.  Returns the policy launches on the current device
+// use now: forced, from the environment, calibrated -- or -1 when none of these has decided (launches then use nt).  median_us (may be
+// NULL): [plain, nt] of the last calibration.
 extern "C" int cnm_tune_sweep_store(int n, float* median_us) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return -1; }
-    std::lock_guard<std::mutex> lock(g_sweep_tune_mu);
-    SweepStoreTune& t = g_sweep_tune[dev];
-    if (n == 0 || n == SWEEP_STORE_AUX) t.forced = n;
-    else if (n == -1) { t.forced = -1; t.chosen = -1; t.issued = 0; sweep_tune_release(t); }
+    std::lock_guard<std::mutex> lock(g_sweep_store_mu);
+    SweepStoreState& t = g_sweep_store[dev];
+    if (n == 0 || n == SWEEP_STORE_AUX) t.forced.store(n, std::memory_order_relaxed);
+    else if (n == -1) { t.forced.store(-1, std::memory_order_relaxed); t.chosen.store(-1, std::memory_order_relaxed); t.median_us[0] = t.median_us[1] = 0.f; }
     if (median_us) { median_us[0] = t.median_us[0]; median_us[1] = t.median_us[1]; }
-    return t.forced >= 0 ? t.forced : t.chosen;
+    const int f = t.forced.load(std::memory_order_relaxed);
+    if (f >= 0) return f;
+    if (sweep_store_env() >= 0) return sweep_store_env();
+    return t.chosen.load(std::memory_order_relaxed);
+}
+
+// A caller that measured the launch inside ITS OWN step (cnmnet_amd/pipeline.py: both policies forced in turn, the launch timed by the
+// hook above between its real neighbours) records the decision here: it replaces the scratch calibration's (more faithful: what the
+// launch's stores meet depends on the kernels around it).  policy = 0 / 2; median_us (may be NULL) = [plain, nt] as measured.
+extern "C" int cnm_decide_sweep_store(int policy, const float* median_us) {
+    CNM_REQUIRE(policy == 0 || policy == SWEEP_STORE_AUX, CNM_ERR_BAD_ARG);
+    int dev = 0;
+    CNM_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64, CNM_ERR_LAUNCH);
+    std::lock_guard<std::mutex> lock(g_sweep_store_mu);
+    SweepStoreState& t = g_sweep_store[dev];
+    t.chosen.store(policy, std::memory_order_relaxed);
+    if (median_us) { t.median_us[0] = median_us[0]; t.median_us[1] = median_us[1]; }
+    return CNM_OK;
 }
 
 static int sweep_launch(int layout, const float* ref, const float* src, const float* hmkt, float* out,
                         float* ws, size_t ws_floats, int B, int S, int H, int W, int D,
-                        double idepth_min, double idepth_max, void* stream) {
+                        double idepth_min, double idepth_max, void* stream, int force_policy = -1) {
     CNM_REQUIRE(ref && src && hmkt && out, CNM_ERR_BAD_ARG);
     CNM_REQUIRE(ws == nullptr || (((uintptr_t)ws & 15) == 0 && ws_floats >= 4), CNM_ERR_WORKSPACE);
     CNM_REQUIRE(B > 0 && S > 0 && H > 0 && W > 0 && D >= 2 && D <= CNM_MAX_PLANES, CNM_ERR_BAD_ARG);
@@ -989,14 +1012,9 @@ static int sweep_launch(int layout, const float* ref, const float* src, const fl
     a.nfull = nt - a.nh - a.nq - a.ne; a.nunits = a.nfull + 2 * a.nh + 4 * a.nq + 8 * a.ne;
     a.inv_tpp = 1.0f / (float)a.tiles_per_pair; a.inv_ntx = 1.0f / (float)a.ntx;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-#ifndef SWEEP_NO_TIMING_HOOK
-    if (g_sweep_ev_next < g_sweep_ev_armed) { ev0 = g_sweep_ev[2 * g_sweep_ev_next]; ev1 = g_sweep_ev[2 * g_sweep_ev_next + 1]; ++g_sweep_ev_next; }
-#endif
-    hipEvent_t tv0 = nullptr, tv1 = nullptr;
-    const size_t out_bytes = (size_t)B * S * H * W * (layout == 2 ? 2 : 4) * (size_t)(D + (layout == 0 ? 0 : layout == 1 ? 4 : 8));
-    const int aux = sweep_store_policy(cnm_stream(stream), out_bytes, &tv0, &tv1);
+    if (g_sweep_ev_left.load(std::memory_order_relaxed) > 0) sweep_timing_events(cnm_stream(stream), &ev0, &ev1);   // bench.py's measurement hook, armed explicitly
+    const int aux = force_policy >= 0 ? force_policy : sweep_store_policy();
     if (ev0) (void)hipEventRecord(ev0, cnm_stream(stream));
-    if (tv0) (void)hipEventRecord(tv0, cnm_stream(stream));
     if (aux == 0) {
         if (layout == 0) planesweep_kernel<0, 0><<<grid, SWEEP_NT, 0, cnm_stream(stream)>>>(a);
         else if (layout == 1) planesweep_kernel<1, 0><<<grid, SWEEP_NT, 0, cnm_stream(stream)>>>(a);
@@ -1006,10 +1024,57 @@ static int sweep_launch(int layout, const float* ref, const float* src, const fl
         else if (layout == 1) planesweep_kernel<1, SWEEP_STORE_AUX><<<grid, SWEEP_NT, 0, cnm_stream(stream)>>>(a);
         else planesweep_kernel<2, SWEEP_STORE_AUX><<<grid, SWEEP_NT, 0, cnm_stream(stream)>>>(a);
     }
-    if (tv1) (void)hipEventRecord(tv1, cnm_stream(stream));
     if (ev1) (void)hipEventRecord(ev1, cnm_stream(stream));
     CNM_LAUNCH_CHECK();
     return CNM_OK;
+}
+
+// The calibration (see above).  scratch: cnm_calibrate_sweep_store_floats() floats of device memory, 16-byte aligned, contents
+// irrelevant.  Blocking (synchronises `stream`), not allowed under stream capture.  Returns the chosen policy (0 / 2) or a negative status.
+static constexpr int kCalB = 8, kCalS = 2, kCalH = 192, kCalW = 256, kCalD = 64, kCalN = 24;
+static constexpr size_t kCalOut = (size_t)kCalB * kCalS * (kCalD / 4 + 1) * kCalH * kCalW * 4, kCalRef = (size_t)kCalB * 3 * kCalH * kCalW,
+                        kCalSrc = kCalRef * kCalS, kCalDirty = (size_t)100 << 20, kCalSmall = 256;   // floats; small = tile queue (4) + 16 pairs x 12 terms
+extern "C" size_t cnm_calibrate_sweep_store_floats(void) { return kCalOut + kCalRef + kCalSrc + kCalDirty + kCalSmall; }
+extern "C" int cnm_calibrate_sweep_store(float* scratch, size_t scratch_floats, void* stream, float* median_us) {
+    CNM_REQUIRE(scratch && ((uintptr_t)scratch & 15) == 0 && scratch_floats >= cnm_calibrate_sweep_store_floats(), CNM_ERR_WORKSPACE);
+    hipStream_t s = cnm_stream(stream);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return CNM_ERR_BAD_ARG; }
+    int dev = 0;
+    CNM_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64, CNM_ERR_LAUNCH);
+    std::lock_guard<std::mutex> lock(g_sweep_store_mu);
+    float* out = scratch; float* ref = out + kCalOut; float* src = ref + kCalRef; float* dirty = src + kCalSrc; float* small = dirty + kCalDirty;
+    float hm[kCalB * kCalS * 12];                                        // identity homography, 0.1 m baseline at f = 288: u' = x + 28.8 / z
+    for (int p = 0; p < kCalB * kCalS; ++p) { const float t[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, (p & 1) ? -28.8f : 28.8f, 0, 0}; memcpy(hm + 12 * p, t, sizeof(t)); }
+    bool ok = hipMemsetAsync(ref, 0, (kCalRef + kCalSrc) * 4, s) == hipSuccess && hipMemsetAsync(small, 0, kCalSmall * 4, s) == hipSuccess &&
+              hipMemcpyAsync(small + 16, hm, sizeof(hm), hipMemcpyHostToDevice, s) == hipSuccess;
+    hipEvent_t ev[kCalN][2] = {};
+    for (int i = 0; ok && i < kCalN; ++i)
+        for (int j = 0; ok && j < 2; ++j) ok = hipEventCreateWithFlags(&ev[i][j], hipEventDisableSystemFence) == hipSuccess;
+    int rc = CNM_OK;
+    for (int i = 0; ok && rc == CNM_OK && i < kCalN + 2; ++i) {         // two untimed launches first
+        const int k = i - 2;
+        ok = hipMemsetAsync(dirty, i & 0xFF, kCalDirty * 4, s) == hipSuccess;   // the predecessor that matters: 400 MB of dirty lines in the memory-side cache
+        if (ok && k >= 0) ok = hipEventRecord(ev[k][0], s) == hipSuccess;
+        if (ok) rc = sweep_launch(1, ref, src, small + 16, out, small, 4, kCalB, kCalS, kCalH, kCalW, kCalD, 0.1, 3.0, stream, (i & 1) ? SWEEP_STORE_AUX : 0);
+        if (ok && rc == CNM_OK && k >= 0) ok = hipEventRecord(ev[k][1], s) == hipSuccess;
+    }
+    ok = ok && hipStreamSynchronize(s) == hipSuccess;
+    int chosen = -1;
+    if (ok && rc == CNM_OK) {
+        float v[2][kCalN / 2]; int n[2] = {0, 0};
+        for (int k = 0; k < kCalN; ++k) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ev[k][0], ev[k][1]) == hipSuccess) v[k & 1][n[k & 1]++] = ms * 1e3f; else (void)hipGetLastError();
+        }
+        SweepStoreState& t = g_sweep_store[dev];
+        for (int k = 0; k < 2; ++k) { std::sort(v[k], v[k] + n[k]); t.median_us[k] = n[k] ? v[k][n[k] / 2] : 0.f; }
+        if (n[0] && n[1]) { chosen = t.median_us[0] < t.median_us[1] ? 0 : SWEEP_STORE_AUX; t.chosen.store(chosen, std::memory_order_relaxed); }
+        if (median_us) { median_us[0] = t.median_us[0]; median_us[1] = t.median_us[1]; }
+    }
+    for (int i = 0; i < kCalN; ++i) for (int j = 0; j < 2; ++j) if (ev[i][j]) (void)hipEventDestroy(ev[i][j]);
+    if (!ok) { (void)hipGetLastError(); return CNM_ERR_LAUNCH; }
+    return rc != CNM_OK ? rc : (chosen >= 0 ? chosen : CNM_ERR_LAUNCH);
 }
 
 extern "C" int cnm_planesweep_volume_nchw_f32(const float* ref, const float* src, const float* hmkt, float* volume,

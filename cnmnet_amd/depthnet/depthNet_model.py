@@ -172,7 +172,9 @@ class _EngineNet(nn.Module):
             ws = self._ws[str(device)]
             if not torch.cuda.is_current_stream_capturing():
                 with torch.cuda.device(device):
-                    ops.engine_status(clear=False)                      # allocates this device's status word before anybody captures a graph over this net
+                    ops.engine_status(clear=False, device=device)       # allocates this device's status word before anybody captures a graph over this net
+                    if self._NET == _lib.NET_DEPTH:
+                        ops.calibrate_sweep_store(device)                # [r6] the plane sweep's store policy: decided here, once per device, never by a launch
         cur = torch.cuda.current_stream(device)
         last = getattr(self, "_ws_stream", None)
         if last is not None and last != cur and not torch.cuda.is_current_stream_capturing():

@@ -9,6 +9,7 @@ infrastructure and never involved.
 """
 import weakref
 
+import os
 import torch
 
 from . import _lib, host
@@ -376,21 +377,102 @@ def sync_workspace_state(sync):
     return int((sync[:1024].view(torch.int32)[:1020] != 0).sum().item())
 
 
-def engine_status(clear=True):
-    """Raise EngineError if a stream-K hand-off has timed out on the current device since the last acknowledgement
-    (cnm_engine_status); with clear=True the failure is acknowledged, so later launches are accepted again, and every registered
-    workspace on that device is zeroed: a timed-out hand-off leaves stale generation words behind, which the queue that wrote
-    them can never mistake for its own, but a workspace may next be used from another stream, i.e. another hardware queue whose
-    dispatch counter runs through the same small numbers.  Synchronise first."""
-    rc = _lib.load().cnm_engine_status(int(bool(clear)))
-    if rc != 0 and clear and torch.cuda.is_available():
-        cur = torch.cuda.current_device()
-        torch.cuda.synchronize()
-        for t in list(_SYNC_OWNERS):
-            if t.is_cuda and t.device.index == cur:
-                t.zero_()
-        torch.cuda.synchronize()
-    _lib.check(rc)
+def engine_status(clear=True, device=None):
+    """Raise EngineError if a stream-K hand-off has timed out since the last acknowledgement (cnm_engine_status; the status word is
+    per device).  device=None asks every device that owns a registered workspace plus the current one (a net may live on a device that
+    is not current: ADVICE r5), a device asks that one.  With clear=True the failure is acknowledged, so later launches are accepted
+    again, and every registered workspace on that device is zeroed: a timed-out hand-off leaves stale generation words behind, which
+    the queue that wrote them can never mistake for its own, but a workspace may next be used from another stream, i.e. another
+    hardware queue whose dispatch counter runs through the same small numbers.  Synchronise first."""
+    lib = _lib.load()
+    if not torch.cuda.is_available():
+        return _lib.check(lib.cnm_engine_status(int(bool(clear))))
+    if device is None:
+        devs = sorted({torch.cuda.current_device()} | {t.device.index for t in list(_SYNC_OWNERS) if t.is_cuda})
+    else:
+        devs = [torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()]
+    first = 0
+    for d in devs:
+        with torch.cuda.device(d):
+            rc = lib.cnm_engine_status(int(bool(clear)))
+            if rc != 0 and clear:
+                torch.cuda.synchronize()
+                for t in list(_SYNC_OWNERS):
+                    if t.is_cuda and t.device.index == d:
+                        t.zero_()
+                torch.cuda.synchronize()
+        first = first or rc
+    _lib.check(first)
+
+
+_SWEEP_STORE_CALIBRATED = set()
+
+
+def calibrate_sweep_store(device=None, force=False):
+    """The plane sweep's output-store policy for `device`, measured once per device and process (cnm_calibrate_sweep_store: 24 launches on
+    ~630 MB of scratch, blocking) unless CNM_SWEEP_STORE or cnm_tune_sweep_store has already decided.  Never call under stream capture; the
+    depthNet modules call it when they first allocate a workspace, i.e. before any graph is captured over them and before any timed region.
+    Returns the policy in force (0 plain, 2 non-temporal)."""
+    lib = _lib.load()
+    dev = torch.device("cuda" if device is None else device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    with torch.cuda.device(idx):
+        pol = lib.cnm_tune_sweep_store(99, None)
+        if (pol >= 0 or idx in _SWEEP_STORE_CALIBRATED) and not force:
+            return pol
+        if torch.cuda.is_current_stream_capturing():
+            return pol
+        _SWEEP_STORE_CALIBRATED.add(idx)
+        scratch = torch.empty(lib.cnm_calibrate_sweep_store_floats(), device="cuda:%d" % idx, dtype=torch.float32)
+        rc = lib.cnm_calibrate_sweep_store(_p(scratch), scratch.numel(), _stream(), None)
+        del scratch
+        if rc < 0:
+            _lib.check(rc)
+        return lib.cnm_tune_sweep_store(99, None)
+
+
+_SWEEP_STORE_IN_STEP = set()
+
+
+def calibrate_sweep_store_in_step(step_fn, device=None, n=6, force=False):
+    """The same decision measured where it matters: `step_fn()` runs ONE real step of the caller (containing one plane-sweep launch); both
+    policies are forced in turn, the launch is timed between its real neighbours by the library's measurement hook, and the policy with
+    the lower median becomes the device's (cnm_decide_sweep_store) -- what the launch's stores meet depends on the kernels around it, and
+    the scratch calibration's margin is ~1 us.  Blocking, once per device and process, never under capture; skipped when CNM_SWEEP_STORE
+    or cnm_tune_sweep_store already forces a policy.  Returns the policy in force."""
+    import ctypes
+    lib = _lib.load()
+    dev = torch.device("cuda" if device is None else device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    with torch.cuda.device(idx):
+        if (idx in _SWEEP_STORE_IN_STEP and not force) or torch.cuda.is_current_stream_capturing() or os.environ.get("CNM_SWEEP_STORE", "") in ("0", "2", "plain", "nt"):
+            return lib.cnm_tune_sweep_store(99, None)
+        before = lib.cnm_tune_sweep_store(99, None)
+        med_prev = (ctypes.c_float * 2)()
+        lib.cnm_tune_sweep_store(99, ctypes.cast(med_prev, ctypes.c_void_p))
+        _SWEEP_STORE_IN_STEP.add(idx)
+        med = (ctypes.c_float * 2)()
+        buf = (ctypes.c_float * n)()
+        try:
+            for k, pol in enumerate((0, 2)):
+                lib.cnm_tune_sweep_store(pol, None)
+                for _ in range(2):
+                    step_fn()
+                _lib.check(lib.cnm_debug_sweep_timing_arm(n))
+                for _ in range(n):
+                    step_fn()
+                got = lib.cnm_debug_sweep_timing_read(ctypes.cast(buf, ctypes.c_void_p), n)
+                lib.cnm_debug_sweep_timing_arm(0)
+                torch.cuda.synchronize()
+                if got != n:                                             # the step launched no (or several differently many) sweeps: leave the decision as it was
+                    return before
+                med[k] = sorted(buf[i] for i in range(n))[n // 2] * 1e3
+        finally:
+            lib.cnm_tune_sweep_store(-1, None)                           # drop the forced policy (this also drops the scratch calibration: restored or replaced below)
+            if before >= 0:
+                lib.cnm_decide_sweep_store(before, ctypes.cast(med_prev, ctypes.c_void_p))
+        _lib.check(lib.cnm_decide_sweep_store(0 if med[0] < med[1] else 2, ctypes.cast(med, ctypes.c_void_p)))
+        return lib.cnm_tune_sweep_store(99, None)
 
 
 def conv3x3_winograd4_c4(x, u_packed, b_packed, Cout, relu=True, x2=None, ksize=3, sync=None):

@@ -18,6 +18,7 @@ import os
 import torch
 
 from .depthnet.losses import IdepthLoss_234, _valid, total, row_totals, mean_all
+from .depthnet.depthNet_model import DepthRefineNet as _EngineRefine
 
 
 class _step_scope:
@@ -393,8 +394,13 @@ class TrainStepWoNormal:
             c4 = getattr(f, "_cnm_c4", None)
             if c4 is None:
                 return node(f)
-            g = f.detach()                                   # the NCHW twin only carries the c4 tensor the refine net reads
-            g._cnm_c4 = node(c4)
+            c = node(c4)
+            if isinstance(self.refine_net, _EngineRefine):
+                g = f.detach()                               # the engine's DepthRefineNet reads the c4 tensor: the NCHW twin only carries it
+            else:
+                from . import autograd as _ag                # any other refine net reads the NCHW tensor: rebuilt from the cut node, so both forms
+                g = _ag.C4ToNCHW.apply(c, f.shape[1])        # carry autograd through the cut (the detached twin silently lost this gradient)
+            g._cnm_c4 = c
             return g
 
         out = ([node(t) for t in p01], feature(f01), [node(t) for t in p02], feature(f02))

@@ -146,18 +146,32 @@ int cnm_idepth_range_host(double idepth_scale, double* idepth_min, double* idept
  *     ws == NULL is allowed: tiles are then dealt to the workgroups with a fixed stride (no scratch, slower
  *     when tiles differ in cost). */
 size_t cnm_planesweep_workspace_floats(int B, int S, int H, int W);
-/* sweep_store [r5]: cache policy of the plane sweep's output stores (0 plain, 2 non-temporal).  Which one is faster inside a step
- * depends on the machine (the launch displaces the dirty lines its predecessors left in the memory-side cache), so by default the
- * first 24 large launches (>= 32 MB of output, not under stream capture) on a device alternate between the two, each between a pair
- * of fence-free events on its own stream, and the policy with the lower median stays for the process; the two produce identical
- * bytes.  cnm_tune_sweep_store(0 / 2, .) forces a policy, (-1, .) starts measuring again, any other n only queries.  Returns the
- * policy in force on the current device (-1 while sampling); median_us (may be NULL) receives [plain, nt] of the last decision. */
+/* sweep_store: cache policy of the plane sweep's output stores (0 plain, 2 non-temporal); the two write identical bytes.  Which one
+ * is faster inside a step depends on the machine (the launch displaces the dirty lines its predecessors left in the memory-side
+ * cache).  [r6] The policy is a per-device DECISION, never a side effect of launching: a launch reads one atomic, in this order --
+ * forced by cnm_tune_sweep_store(0 / 2, .); CNM_SWEEP_STORE = plain | nt | 0 | 2 in the environment (read once); calibrated by
+ * cnm_calibrate_sweep_store; the default, non-temporal.  No launch records events or takes a lock for it, launches under stream capture
+ * use the same policy as all others.
+ * cnm_calibrate_sweep_store(scratch, scratch_floats, stream, median_us) is the measurement: 24 launches of the 16-pair 192 x 256 x 64
+ * shape on the caller's scratch (cnm_calibrate_sweep_store_floats() floats, ~630 MB, contents irrelevant), alternating policies, each
+ * behind a 400 MB fill and between two fence-free events on `stream`; BLOCKING (synchronises the stream), refused under stream capture
+ * (CNM_ERR_BAD_ARG).  Returns the policy chosen for the current device (0 / 2) or a negative status; median_us (may be NULL) receives
+ * [plain, nt] in microseconds.  The Python modules call it once per device and process when a depthNet first allocates its workspace.
+ * cnm_tune_sweep_store(n, median_us): n = 0 / 2 forces; n = -1 drops the forced policy and the calibration; other n only query.
+ * Returns the policy in force on the current device, -1 if nothing has decided yet (launches then use non-temporal stores). */
 int cnm_tune_sweep_store(int n, float* median_us);
+size_t cnm_calibrate_sweep_store_floats(void);
+int cnm_calibrate_sweep_store(float* scratch, size_t scratch_floats, void* stream, float* median_us);
+/* A caller that has measured the launch inside its own step (both policies forced in turn, the launch timed between its real neighbours
+ * with cnm_debug_sweep_timing_arm -- cnmnet_amd/pipeline.py does this on its first call) records the decision for the current device; it
+ * replaces the scratch calibration's.  policy 0 / 2; median_us (may be NULL) = [plain, nt] microseconds as measured. */
+int cnm_decide_sweep_store(int policy, const float* median_us);
 /* DEBUG / MEASUREMENT: cnm_debug_sweep_timing_arm(n) makes each of the next n plane-sweep launches of the process (any entry point,
- * including the one inside cnm_depthnet_forward_*) record a HIP event before and after itself on its launch stream (events without
- * the system-scope fence: the closing one does not wait for the launch's output to be written back); n <= 0 disarms and frees.
- * cnm_debug_sweep_timing_read(ms, n) waits for the launches recorded so far and writes their elapsed milliseconds; returns the
- * count.  How bench.py times the launch between its real neighbours of a step.  Not thread-safe. */
+ * including the one inside cnm_depthnet_forward_*; not those under stream capture) record a HIP event before and after itself on its
+ * launch stream (events without the system-scope fence: the closing one does not wait for the launch's output to be written back);
+ * n <= 0 disarms and frees.  cnm_debug_sweep_timing_read(ms, n) waits for the launches recorded so far and writes their elapsed
+ * milliseconds; returns the count.  How bench.py times the launch between its real neighbours of a step.  [r6] Thread-safe: the launch
+ * path reads one atomic while nothing is armed, everything else is under the hook's own mutex. */
 int cnm_debug_sweep_timing_arm(int n);
 int cnm_debug_sweep_timing_read(float* ms, int n);
 int cnm_planesweep_volume_nchw_f32(const float* ref, const float* src, const float* hmkt, float* volume,

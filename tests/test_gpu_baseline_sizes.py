@@ -173,3 +173,39 @@ def test_forward_pairs_batch_split_matches_unsplit(dev):
     for a, b in zip(whole[0], split[0]):
         assert float((a - b).abs().max()) < 1e-4                          # kernel choice per layer differs with the pair count (fp32 rounding on a [0,3] range)
     assert float((whole[1] - split[1]).abs().max()) < 1e-4 * float(whole[1].abs().max())
+
+
+def test_pipeline_decides_the_sweep_store_policy_in_its_own_step(dev):
+    """[r6] FramePipeline's first call measures the plane sweep's two store policies INSIDE its own step (ops.calibrate_sweep_store_in_step)
+    and records the decision for the device before anything can be captured or timed; later calls and a HIP-graph capture of the
+    pipeline neither sample nor change it, and the outputs do not depend on it."""
+    import ctypes
+    from cnmnet_amd import _lib, ops
+    from cnmnet_amd.pipeline import FramePipeline, GraphedFramePipeline
+    from cnmnet_amd.depthnet import depthNet, DepthRefineNet
+    lib = _lib.load()
+    B, S, H, W, D = 4, 2, 192, 256, 64
+    img, cams = syn.frames(B, S, H, W, seed=5)
+    img, cams = T(img).to(dev), T(cams).to(dev)
+    idx = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
+    lib.cnm_tune_sweep_store(-1, None)
+    ops._SWEEP_STORE_IN_STEP.discard(idx)
+    try:
+        pipe = FramePipeline(_load(depthNet(3.0, D), 3).to(dev).eval(), _load(DepthRefineNet(32, 3.0), 4).to(dev).eval(), k_size=9)
+        out = pipe(img, cams)
+        med = (ctypes.c_float * 2)()
+        pol = lib.cnm_tune_sweep_store(99, ctypes.cast(med, ctypes.c_void_p))
+        assert pol in (0, 2) and 5.0 < med[0] < 500.0 and 5.0 < med[1] < 500.0 and (med[0] < med[1]) == (pol == 0), (pol, med[0], med[1])
+        ref = {k: v.clone() for k, v in out.items() if torch.is_tensor(v)}
+        g = GraphedFramePipeline(pipe, img, cams)
+        got = g()
+        torch.cuda.synchronize()
+        assert lib.cnm_tune_sweep_store(99, None) == pol
+        assert all(torch.equal(got[k], ref[k]) for k in ("disp", "prob"))
+        lib.cnm_tune_sweep_store(2 - pol, None)                              # the other policy: the same bytes
+        other = pipe(img, cams)
+        assert all(torch.equal(other[k], ref[k]) for k in ("disp", "prob"))
+    finally:
+        lib.cnm_tune_sweep_store(-1, None)
+        ops._SWEEP_STORE_IN_STEP.discard(idx)
+        ops._SWEEP_STORE_CALIBRATED.discard(idx)

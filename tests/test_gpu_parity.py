@@ -244,10 +244,11 @@ def test_planesweep_full_size_identity_known_answer(dev, ops):
     assert float((vol - want).abs().max()) < 1e-2
 
 
-def test_planesweep_store_policy_is_measured_and_invisible(dev, ops):
-    """cnm_tune_sweep_store [r5]: plain and non-temporal output stores give the same bytes; left alone, the first 24 large launches of a
-    device alternate between them between fence-free events, and once those have run the library settles on one (whichever -- it is a
-    property of the box) and reports both medians; small launches and forced policies never sample."""
+def test_planesweep_store_policy_is_a_decision(dev, ops):
+    """The plane sweep's output-store policy [r6]: plain and non-temporal stores give the same bytes; a launch never samples -- the policy
+    in force is what cnm_tune_sweep_store forced, else what cnm_calibrate_sweep_store measured (explicit, blocking, on scratch; whichever
+    it picks is a property of the box), else the default; launches captured into a HIP graph use the same policy as eager ones; the
+    calibration refuses to run under stream capture."""
     import ctypes
     from cnmnet_amd import _lib
     lib = _lib.load()
@@ -262,21 +263,34 @@ def test_planesweep_store_policy_is_measured_and_invisible(dev, ops):
             assert lib.cnm_tune_sweep_store(pol, None) == pol
             outs.append(ops.plane_sweep_cat_c4(ref, src, hmkt, 3.0, D).clone())
         assert torch.equal(outs[0], outs[1])
-        assert lib.cnm_tune_sweep_store(-1, None) == -1                          # measure again
-        small = ops.plane_sweep_cat_c4(ref[:1, :, :32, :32].contiguous(), src[:1, :, :, :32, :32].contiguous(), hmkt[:1], 3.0, D)   # 0.3 MB: not a sample
-        assert small.shape[0] == S and lib.cnm_tune_sweep_store(99, None) == -1
-        for i in range(24):
+        assert lib.cnm_tune_sweep_store(-1, None) == -1                          # nothing forced, nothing calibrated
+        for i in range(30):                                                     # launching decides nothing
             got = ops.plane_sweep_cat_c4(ref, src, hmkt, 3.0, D)
-            assert lib.cnm_tune_sweep_store(99, None) == -1, i                     # still sampling: the decision is taken by a LATER launch
         torch.cuda.synchronize()
-        assert torch.equal(got, outs[0])
-        got = ops.plane_sweep_cat_c4(ref, src, hmkt, 3.0, D)
-        pol = lib.cnm_tune_sweep_store(99, ctypes.cast(med, ctypes.c_void_p))
-        assert pol in (0, 2) and 20.0 < med[0] < 500.0 and 20.0 < med[1] < 500.0, (pol, med[0], med[1])
-        assert (med[0] < med[1]) == (pol == 0)
-        assert torch.equal(got, outs[0])
+        assert lib.cnm_tune_sweep_store(99, None) == -1 and torch.equal(got, outs[0])
+        pol = ops.calibrate_sweep_store(dev, force=True)
+        assert pol in (0, 2) and lib.cnm_tune_sweep_store(99, ctypes.cast(med, ctypes.c_void_p)) == pol
+        assert 20.0 < med[0] < 500.0 and 20.0 < med[1] < 500.0 and (med[0] < med[1]) == (pol == 0), (pol, med[0], med[1])
+        assert ops.calibrate_sweep_store(dev) == pol                            # decided: no second measurement
+        # under capture: refused by the library, skipped by the wrapper; a captured launch replays with the device's policy
+        ws = torch.zeros(lib.cnm_planesweep_workspace_floats(B, S, H, W), device=dev)
+        out = torch.empty_like(outs[0])
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ops.plane_sweep_cat_c4(ref, src, hmkt, 3.0, D, ws=ws, out=out)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                scratch = torch.empty(16, device=dev)
+                assert lib.cnm_calibrate_sweep_store(ctypes.c_void_p(scratch.data_ptr()), 1 << 40, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), None) < 0
+                ops.plane_sweep_cat_c4(ref, src, hmkt, 3.0, D, ws=ws, out=out)
+            out.zero_()
+            g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, outs[0])
     finally:
         lib.cnm_tune_sweep_store(-1, None)
+        ops._SWEEP_STORE_CALIBRATED.discard(torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device())
 
 
 # ------------------------------------------------------------------ conv stack pieces

@@ -366,6 +366,35 @@ def test_trainer_steps_and_first_loss_vs_oracle(dev):
     assert torch.isfinite(o[0]).all()
 
 
+def test_cut_keeps_the_feature_gradient_for_a_foreign_refine_net(dev):
+    """the cut between depthNet and what follows hands the engine's DepthRefineNet a DETACHED NCHW feature (it reads the c4
+    twin); any other refine net reads the NCHW tensor, which must then carry autograd through the cut node -- the gradient of a loss
+    on that tensor has to reach depthNet's iconv1 filter."""
+    from cnmnet_amd.depthnet import depthNet, DepthRefineNet
+    from cnmnet_amd.trainer import TrainStepWoNormal, synthetic_training_sample
+
+    class Foreign(torch.nn.Module):                                       # reads the NCHW features like the reference's own module would
+        def __init__(self):
+            super().__init__()
+            self.mix = torch.nn.Conv2d(64, 1, 1)
+
+        def forward(self, idepth01, idepth02, iconv01, iconv02):
+            y = torch.sigmoid(self.mix(iconv01) + self.mix(iconv02))
+            return y, y
+
+    sd = {k: v.to(dev) for k, v in synthetic_training_sample(1, 64, 96, seed=31).items()}
+    for refine, wants_grad in ((Foreign().to(dev), True), (_load(DepthRefineNet(32, 3.0), 72).to(dev), False)):
+        step = TrainStepWoNormal(_load(depthNet(3.0), 71).to(dev), refine, lr=1e-4)
+        step.depth_net.train()
+        (p01, f01), (p02, f02) = step.depth_net.forward_sources(sd["rgbs"][:, 0], sd["rgbs"][:, 1:3], sd["cameras"][:, 0], sd["cameras"][:, 1:3])
+        p01, f01, p02, f02 = step._cut_here(p01, f01, p02, f02)
+        assert f01.requires_grad == wants_grad and getattr(f01, "_cnm_c4").requires_grad
+        if wants_grad:
+            w = dict(step.depth_net.named_parameters())["iconv1.0.weight"]
+            (f01.square().mean() + f02.square().mean()).backward()
+            assert w.grad is not None and float(w.grad.abs().max()) > 0
+
+
 def test_graphed_train_step_equals_eager(dev):
     """TrainStepWoNormal(graph=True): the captured step replayed on three different batches (then re-captured for a new
     shape) against the eager step from the same initial weights -- logged losses, every parameter and the BatchNorm
