@@ -676,6 +676,8 @@ def init_dist(want, dev, world):
     pg, ok = None, 0
     if want == "nccl":
         try:
+            if os.environ.get("CNM_BENCH_FAIL_NCCL") == "1":             # test hook (tests/test_sharding_gloo.py): the failure path as a tested path
+                raise RuntimeError("injected: RCCL refused (CNM_BENCH_FAIL_NCCL=1)")
             pg = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=180))
             t = torch.ones(1, device=dev)
             dist.all_reduce(t, group=pg)

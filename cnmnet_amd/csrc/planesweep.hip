@@ -238,6 +238,9 @@ __device__ unsigned long long sweep_trace[8192][4];
 __device__ unsigned int sweep_trace_n;
 __device__ unsigned long long sweep_trace_first[1024][6];   // first unit of a workgroup: kernel entry, loop top, footprints done (wave 0), barrier passed, first box staged, first octet stored
 #endif
+#ifdef SWEEP_BOXTIME
+__device__ unsigned long long sweep_boxtime[4];   // debug builds (tools/k1_bench.hip -DSWEEP_BOXTIME): 100 MHz ticks summed over workgroups (thread 0's view): footprints + barrier, box staging, sweeps, units
+#endif
 #ifdef SWEEP_STATS
 __device__ unsigned int sweep_stats[4];     // debug builds only: workgroups, staged boxes, octets gathered from global, box texels
 #endif
@@ -486,6 +489,9 @@ __device__ __attribute__((noinline)) void sweep_stage_box(unsigned src_lo_, unsi
     const unsigned src_lo = (unsigned)sweep_sgpr((int)src_lo_), src_hi = (unsigned)sweep_sgpr((int)src_hi_);
     const int rx0 = sweep_sgpr(rx0_), ry0 = sweep_sgpr(ry0_), rw = sweep_sgpr(rw_), rh = sweep_sgpr(rh_), W = sweep_sgpr(W_), H = sweep_sgpr(H_);
     const int barrier_first = sweep_sgpr(barrier_first_);
+#if defined(SWEEP_NOSTAGE) && SWEEP_NOSTAGE == 1                          // debug builds (wrong output): staging free -- no loads, no LDS writes, no barriers
+    return;
+#endif
     const unsigned chan_bytes = (unsigned)(H * W) * 4u;
     const __amdgpu_buffer_rsrc_t rsrc = sweep_rsrc(src_lo, src_hi, 3 * chan_bytes);
     char* const box = SWEEP_LDS_BOX;
@@ -509,8 +515,12 @@ __device__ __attribute__((noinline)) void sweep_stage_box(unsigned src_lo_, unsi
         const unsigned o1 = (xin && (unsigned)(yy + 1) < (unsigned)H) ? o + (unsigned)W * 4u : 0xFFFFFFFFu;
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
+#if defined(SWEEP_NOSTAGE) && SWEEP_NOSTAGE == 3                          // debug builds (wrong output): the staging's barriers and LDS writes without its loads
+            p0[k][ch] = (float)o0; p1[k][ch] = (float)o1;
+#else
             p0[k][ch] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, o0, ch * chan_bytes, 0));
             p1[k][ch] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, o1, ch * chan_bytes, 0));
+#endif
         }
     }
     if (barrier_first) __syncthreads();                                      // every wave is done with the previous box
@@ -675,6 +685,9 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
 #ifdef SWEEP_TRACE
         if (trace_first && tid == 0 && blockIdx.x < 1024) sweep_trace_first[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
 #endif
+#ifdef SWEEP_BOXTIME
+        unsigned long long bt_foot = __builtin_amdgcn_s_memrealtime(), bt_stage = 0, bt_sweep = 0;
+#endif
         if (tid < 64) {
             if (ocnt <= 8) sweep_footprints8(hmkt_pair, tx0, ty0, obeg, ocnt, W, H, D, idmin_f, idstep_f, parity);
             else sweep_footprints16(hmkt_pair, tx0, ty0, obeg, ocnt, W, H, D, idmin_f, idstep_f, parity);
@@ -688,6 +701,9 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
 #endif
 #ifdef SWEEP_TRACE
         const unsigned long long trace_t1 = __builtin_amdgcn_s_memrealtime();
+#endif
+#ifdef SWEEP_BOXTIME
+        bt_foot = __builtin_amdgcn_s_memrealtime() - bt_foot;
 #endif
         const int level = __builtin_amdgcn_readfirstlane(hdr[2 * parity]);
         const int ngroups = (ocnt + (1 << level) - 1) >> level;
@@ -720,7 +736,14 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
                 else atomicAdd(&sweep_stats[2], (unsigned)(min((g + 1) << level, ocnt) - (g << level)));
             }
 #endif
+#ifdef SWEEP_BOXTIME
+            const unsigned long long bt0 = __builtin_amdgcn_s_memrealtime();
+#endif
             if (staged) sweep_stage_box(src_lo, src_hi, bx.rx0, bx.ry0, bx.rw, bx.rh, W, H, g > 0);
+#ifdef SWEEP_BOXTIME
+            const unsigned long long bt1 = __builtin_amdgcn_s_memrealtime();
+            bt_stage += bt1 - bt0;
+#endif
 #ifdef SWEEP_TRACE
             if (trace_first && g == 0 && tid == 0 && blockIdx.x < 1024) sweep_trace_first[blockIdx.x][4] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -803,7 +826,13 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
                     osoff += ostride;
                 }
             }
+#ifdef SWEEP_BOXTIME
+            bt_sweep += __builtin_amdgcn_s_memrealtime() - bt1;
+#endif
         }
+#ifdef SWEEP_BOXTIME
+        if (tid == 0) { atomicAdd(&sweep_boxtime[0], bt_foot); atomicAdd(&sweep_boxtime[1], bt_stage); atomicAdd(&sweep_boxtime[2], bt_sweep); atomicAdd(&sweep_boxtime[3], 1ull); }
+#endif
         // osoff now points at the channel group behind the D planes: the reference image (depthNet_model.py:233)
         if (LAYOUT == 1 && obeg + ocnt == noct) {
             const sw_u32x4 v = {__float_as_uint(-nr), __float_as_uint(-ng), __float_as_uint(-nb), 0u};
@@ -933,13 +962,14 @@ static int sweep_store_env() {                                          // CNM_S
     }();
     return v;
 }
-static int sweep_store_policy() {
+static int sweep_store_policy(bool beyond_cache) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return SWEEP_STORE_AUX; }
     const int f = g_sweep_store[dev].forced.load(std::memory_order_relaxed);
     if (f >= 0) return f;
     const int e = sweep_store_env();
     if (e >= 0) return e;
+    if (beyond_cache) return SWEEP_STORE_AUX;
     const int c = g_sweep_store[dev].chosen.load(std::memory_order_relaxed);
     return c >= 0 ? c : SWEEP_STORE_AUX;
 }
@@ -1013,7 +1043,11 @@ static int sweep_launch(int layout, const float* ref, const float* src, const fl
     a.inv_tpp = 1.0f / (float)a.tiles_per_pair; a.inv_ntx = 1.0f / (float)a.ntx;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (g_sweep_ev_left.load(std::memory_order_relaxed) > 0) sweep_timing_events(cnm_stream(stream), &ev0, &ev1);   // bench.py's measurement hook, armed explicitly
-    const int aux = force_policy >= 0 ? force_policy : sweep_store_policy();
+    // the device's policy decides for outputs that fit the 256 MB memory-side cache (what it was measured on); a larger volume (config 4: 2 GB per
+    // launch) streams to HBM whatever surrounds the launch, and there non-temporal stores win by 10 % on every box seen (503 against 554-566 us,
+    // profiles/r6_k1_store_aux.txt) -- unless a policy is FORCED (cnm_tune_sweep_store / CNM_SWEEP_STORE)
+    const size_t out_bytes = (size_t)B * S * H * W * (layout == 2 ? 2 : 4) * (size_t)(D + (layout == 0 ? 0 : layout == 1 ? 4 : 8));
+    const int aux = force_policy >= 0 ? force_policy : sweep_store_policy(out_bytes > ((size_t)256 << 20));
     if (ev0) (void)hipEventRecord(ev0, cnm_stream(stream));
     if (aux == 0) {
         if (layout == 0) planesweep_kernel<0, 0><<<grid, SWEEP_NT, 0, cnm_stream(stream)>>>(a);

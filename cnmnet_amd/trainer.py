@@ -69,7 +69,14 @@ class BucketedGradAllReduce:
     `train_wo_normal`, reference train.py:555-559) contributes zeros to its bucket -- every rank builds the same
     graph, so the unused set is the same everywhere and the collective shapes match -- and its `.grad` is left
     exactly as it was (None stays None): the optimizer then skips it as it does on one device and under the
-    reference's DataParallel, instead of decaying it towards zero."""
+    reference's DataParallel, instead of decaying it towards zero.
+
+    [r6] Gradients LIVE in the buckets: `views[i][k]` is parameter k's slice of `flat[i]`, shaped like the parameter.  The eager
+    step attaches the views as `.grad` before backward (`attach()`: one fill per bucket instead of one per parameter), autograd
+    accumulates straight into the bucket, and a bucket leaves as it is -- no copy-in; after the exchange one division per bucket
+    averages in place and `.grad` keeps pointing at the view -- no copy-out (rounds 3-5 copied 2 x 179 MB per step through ~480
+    small launches).  The HIP-graph step, whose gradients are tensors of the graph's memory pool, copies them into the views INSIDE
+    the captured graphs (`capture_copy`), so a replay is followed by nothing but the collectives."""
 
     def __init__(self, params, dist, bucket_bytes=25 * 2**20, group=None, hooks=True, segment_of=None):
         """group: the process group of the all-reduces (None = the default group); hooks=False: no backward hooks -- the
@@ -90,6 +97,13 @@ class BucketedGradAllReduce:
             self.buckets.append(cur)
         self.bucket_of = {id(p): i for i, b in enumerate(self.buckets) for p in b}
         self.flat = [torch.zeros(sum(p.numel() for p in b), device=b[0].device, dtype=torch.float32) for b in self.buckets]
+        self.views = []
+        for b, f in zip(self.buckets, self.flat):
+            off, vs = 0, []
+            for p in b:
+                vs.append(f[off:off + p.numel()].view_as(p)); off += p.numel()
+            self.views.append(vs)
+        self.view_of = {id(p): v for b, vs in zip(self.buckets, self.views) for p, v in zip(b, vs)}
         self.pending, self.work = [len(b) for b in self.buckets], [None] * len(self.buckets)
         self.fired = set()                                 # ids of the parameters whose gradient arrived this step
         self.hook_launches = self.late_launches = 0        # buckets launched from backward hooks / from finish(), last step
@@ -105,15 +119,30 @@ class BucketedGradAllReduce:
             self._hook_count += 1
             self._launch(i)
 
+    def attach(self):
+        """Eager step, instead of optimizer.zero_grad(): zero the buckets and make every parameter's `.grad` its bucket view, so that
+        backward accumulates straight into the buckets.  A parameter that then receives no gradient gets `.grad = None` back in finish()."""
+        for f in self.flat:
+            f.zero_()
+        for b, vs in zip(self.buckets, self.views):
+            for p, v in zip(b, vs):
+                p.grad = v
+
+    def capture_copy(self, params):
+        """Inside a stream capture: copy the gradients the captured backward has just produced (tensors of the graph's pool) into their
+        bucket views, so that a replay leaves the buckets ready for the collective."""
+        for p in params:
+            v = self.view_of.get(id(p))
+            if v is not None and p.grad is not None and p.grad.data_ptr() != v.data_ptr():
+                v.copy_(p.grad)
+
     def _launch(self, i):
-        off = 0
-        for p in self.buckets[i]:
-            n = p.numel()
-            if id(p) in self.fired:
-                self.flat[i][off:off + n].copy_(p.grad.reshape(-1))
-            else:
-                self.flat[i][off:off + n].zero_()
-            off += n
+        for p, v in zip(self.buckets[i], self.views[i]):
+            g = p.grad
+            if id(p) in self.fired and g is not None and g.data_ptr() != v.data_ptr():
+                v.copy_(g)                                 # a gradient autograd ASSIGNED instead of accumulating into the view (the step right after a capture; callers that never attach())
+            elif id(p) not in self.fired and (g is None or g.data_ptr() != v.data_ptr()):
+                v.zero_()                                  # no gradient this step and the slice may hold an older one
         self.work[i] = self.dist.all_reduce(self.flat[i], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def launch_ready(self, ready):
@@ -146,12 +175,12 @@ class BucketedGradAllReduce:
                 self._launch(i)
         for i, b in enumerate(self.buckets):
             self.work[i].wait()
-            off = 0
-            for p in b:
-                n = p.numel()
+            self.flat[i].div_(self.world)                  # the average, in place: one launch per bucket
+            for p, v in zip(b, self.views[i]):
                 if id(p) in self.fired:
-                    p.grad.copy_(self.flat[i][off:off + n].view_as(p) / self.world)
-                off += n
+                    p.grad = v                             # the averaged gradient IS the bucket slice: no copy back
+                elif p.grad is not None and p.grad.data_ptr() == v.data_ptr():
+                    p.grad = None                          # attached by attach(), never written: as on one device, the optimizer skips it
             self.work[i], self.pending[i] = None, len(b)
         self.hook_launches, self.late_launches, self._hook_count = self._hook_count, late, 0
         self.fired.clear()
@@ -235,7 +264,10 @@ class TrainStepWoNormal:
                                       lambda *a: self.losses(*a, warmup_epoch))
         with _step_scope():
             loss, logs = self.losses(rgbs, cameras, disparities, depths, warmup_epoch)
-            self.optimizer.zero_grad(set_to_none=self.reducer is None)                       # :562-565 (see _zero_grad_note)
+            if self.reducer is None:
+                self.optimizer.zero_grad(set_to_none=True)                                   # :562-565 (see _zero_grad_note)
+            else:
+                self.reducer.attach()                                                        # gradients accumulate straight into the all-reduce buckets
             loss.backward()
         if self.reducer is not None:
             self._finish(self.reducer.finish)
@@ -340,19 +372,24 @@ class TrainStepWoNormal:
         if segmented:
             # graph A: forward + backward through the refine net; graph B (same memory pool): depthNet's backward -- [r5] its DECODER's,
             # with graph C for the encoder's.  Between the replays the gradient buckets of the part just finished are handed to the collective.
+            depth_params = [p for p in self.depth_net.parameters() if p.requires_grad]
             with torch.cuda.graph(self._graph), _step_scope():
                 loss, logs = forward(*self._static_in)
                 cut, gcut = backward_refine(loss)
+                self.reducer.capture_copy(refine_params)                 # [r6] the gradients land in their all-reduce buckets inside the graph
             self._graph_b = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph_b, pool=self._graph.pool()), _step_scope():
                 if three:
                     cut, gcut = backward_decoder(cut, gcut)
+                    self.reducer.capture_copy(decoder_params)
                 else:
                     torch.autograd.backward(cut, gcut)
+                    self.reducer.capture_copy(depth_params)
             if three:
                 self._graph_c = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self._graph_c, pool=self._graph.pool()), _step_scope():
                     torch.autograd.backward(cut, gcut)
+                    self.reducer.capture_copy([p for p in depth_params if id(p) not in self._early_ids])
             del cut, gcut
             self.depth_net._enc_cut = None
         else:
@@ -504,7 +541,10 @@ class TrainStep(TrainStepWoNormal):
                                       lambda r, c, i, d, n, poses: self.losses(r, c, i, d, n, poses))
         with _step_scope():
             loss, logs = self.losses(rgbs, cameras, disparities, depths, normals)
-            self.optimizer.zero_grad(set_to_none=self.reducer is None)                       # :307-310 (see _zero_grad_note)
+            if self.reducer is None:
+                self.optimizer.zero_grad(set_to_none=True)                                   # :307-310 (see _zero_grad_note)
+            else:
+                self.reducer.attach()
             loss.backward()
         if self.reducer is not None:
             self._finish(self.reducer.finish)

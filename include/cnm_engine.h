@@ -151,7 +151,8 @@ size_t cnm_planesweep_workspace_floats(int B, int S, int H, int W);
  * cache).  [r6] The policy is a per-device DECISION, never a side effect of launching: a launch reads one atomic, in this order --
  * forced by cnm_tune_sweep_store(0 / 2, .); CNM_SWEEP_STORE = plain | nt | 0 | 2 in the environment (read once); calibrated by
  * cnm_calibrate_sweep_store; the default, non-temporal.  No launch records events or takes a lock for it, launches under stream capture
- * use the same policy as all others.
+ * use the same policy as all others.  The calibrated policy applies to launches whose output fits the 256 MB memory-side cache (what it
+ * was measured on); a larger volume (640 x 480 x 96 planes x 16 pairs = 2 GB) is always written with non-temporal stores unless forced.
  * cnm_calibrate_sweep_store(scratch, scratch_floats, stream, median_us) is the measurement: 24 launches of the 16-pair 192 x 256 x 64
  * shape on the caller's scratch (cnm_calibrate_sweep_store_floats() floats, ~630 MB, contents irrelevant), alternating policies, each
  * behind a 400 MB fill and between two fence-free events on `stream`; BLOCKING (synchronises the stream), refused under stream capture

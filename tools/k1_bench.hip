@@ -198,6 +198,11 @@ int main(int argc, char** argv) {
             if (!v.empty()) printf("   first unit, %-30s min %.2f median %.2f max %.2f us\n", nm[st], v.front(), v[v.size() / 2], v.back()); }
     }
 #endif
+#ifdef SWEEP_BOXTIME
+    { unsigned long long bt[4]; hipMemcpyFromSymbol(bt, HIP_SYMBOL(sweep_boxtime), 32); const double nl = 5 + iters + 25 + 1, wg = 512;   // launches so far; ticks of 10 ns, thread 0 of each workgroup
+      printf("   per workgroup and launch (us, thread 0): footprints + barrier %.1f, box staging %.1f, sweeps %.1f | units per launch %.0f\n",
+             bt[0] / nl / wg / 100.0, bt[1] / nl / wg / 100.0, bt[2] / nl / wg / 100.0, bt[3] / nl); }
+#endif
 #ifdef SWEEP_STATS
     { unsigned int st[4]; hipMemcpyFromSymbol(st, HIP_SYMBOL(sweep_stats), 16); const double nl = 5 + iters + 1;   // launches so far
       printf("   per launch: workgroups %.0f, boxes staged %.0f, octets gathered from global %.0f, texels per box %.0f\n", st[0] / nl, st[1] / nl, st[2] / nl, (double)st[3] / (st[1] + 1e-9)); }
