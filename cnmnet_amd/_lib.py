@@ -53,6 +53,7 @@ PROTOTYPES = {
     "cnm_packed_winograd4_floats": (c_sz, [c_i, c_i]),
     "cnm_pack_winograd4_bn_f32": (c_i, [c_fp, c_fp, c_fp, c_f, c_i, c_i, c_i, c_fp, c_fp]),
     "cnm_pack_winograd4_dgrad_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_fp]),
+    "cnm_pack_winograd4_batch_f32": (c_i, [c_fp, c_i, c_i, c_fp]),
     "cnm_conv3x3_winograd4_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp,
                                            c_i, c_i, c_i, c_i, c_fp]),
     "cnm_conv3x3_s2_winograd_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp]),
@@ -152,6 +153,9 @@ PROTOTYPES = {
     "cnm_bn_train_backward_z_c4_f32": (c_i, [c_fp] * 6 + [c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp]),
     "cnm_bn_train_forward_zg_c4_f32": (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_f, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "cnm_bn_train_backward_zg_c4_f32": (c_i, [c_fp] * 6 + [c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    "cnm_bn_train_partials_doubles": (c_sz, [c_i, c_i, c_i, c_i, c_i]),
+    "cnm_bn_train_forward_p_c4_f32": (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_f, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    "cnm_bn_train_backward_p_c4_f32": (c_i, [c_fp] * 7 + [c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "cnm_bn_train_backward_zgb_c4_f32": (c_i, [c_fp] * 6 + [c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "cnm_head_backward_workspace_doubles": (c_sz, [c_i]),
     "cnm_head_backward_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_f, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp]),

@@ -48,7 +48,81 @@ def _bn_workspace(device, G, groups=1):
     return ws
 
 
+_BN_PART = {}   # (device, stream) -> fp64 partial-sum workspace of the two-launch BatchNorm (cnm_bn_train_*_p_c4_f32): contents irrelevant between calls
+BN_PARTIALS = os.environ.get("CNM_BN_PARTIALS", "1") != "0"   # [r6] BatchNorm forward / backward in two launches each (fixed-slot partial sums) instead of three
+
+
+def _bn_partials(device, N, C, H, W, groups):
+    n = _lib.load().cnm_bn_train_partials_doubles(N, C, H, W, groups)
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    ws = _BN_PART.get(key)
+    if ws is None or ws.numel() < n:
+        ws = _BN_PART[key] = torch.empty(max(n, 1 << 20), device=device, dtype=torch.float64)
+    return ws
+
+
 PACK_CACHE = None   # a dict while a trainer step runs (trainer._step_scope): packed filters shared by the two depthNet passes of a step
+PACK_PLAN = None    # the PackPlan of the running step (trainer._step_scope), or None
+
+
+class PackPlan:
+    """[r6] The 36-point 3x3 filter packs of a training step as ONE launch.  Every filter is re-packed every step (the weights change in
+    optimizer.step()), forward form and data-gradient form: 63 launches of ~10 us.  The first step under a plan RECORDS which packs it
+    asked for ("u4": pack_winograd4(weight, None, rot), "u4d": pack_winograd4_dgrad(weight)); every later step runs them all with one
+    cnm_pack_winograd4_batch_f32 launch when the step scope opens and hands the results out through PACK_CACHE.  A pack the plan does not
+    know (another shape, another variant of the step) is computed the old way.  Outputs are persistent tensors: static under graph capture."""
+    BATCH = os.environ.get("CNM_PACK_BATCH", "1") != "0"
+
+    def __init__(self):
+        self.requests, self.seen, self.table, self.outs, self.blocks = [], set(), None, None, 0
+
+    def record(self, kind, weight, rot):
+        key = (kind, id(weight), rot)
+        if self.table is None and key not in self.seen and self.BATCH and kind in ("u4", "u4d") and weight.shape[2] == 3 and weight.is_cuda:
+            self.seen.add(key)
+            self.requests.append((kind, weight, rot))
+
+    def freeze(self):
+        """End of the recording step: allocate the outputs, build the job table on the device."""
+        if self.table is not None or not self.requests:
+            return
+        import numpy as np
+        lib = _lib.load()
+        jobs = np.zeros(len(self.requests), dtype=np.dtype([("w", "<u8"), ("out", "<u8"), ("Cout", "<i4"), ("Cin", "<i4"), ("rot", "<i4"),
+                                                            ("nchunks", "<i4"), ("dgrad", "<i4"), ("first", "<i4")]))
+        assert jobs.dtype.itemsize == 40
+        self.outs, first = [], 0
+        for j, (kind, w, rot) in enumerate(self.requests):
+            co, ci = (w.shape[1], w.shape[0]) if kind == "u4d" else (w.shape[0], w.shape[1])     # as the single-filter call sees them
+            out = torch.empty(lib.cnm_packed_winograd4_floats(co, ci), device=w.device, dtype=torch.float32)
+            nch = (4 * ((ci + 3) // 4) + 15) // 16
+            jobs[j] = (w.data_ptr(), out.data_ptr(), co, ci, rot, nch, int(kind == "u4d"), first)
+            first += nch * (co // 16)
+            self.outs.append(out)
+        self.blocks = first
+        self.table = torch.from_numpy(jobs.view(np.uint8).copy()).to(self.requests[0][1].device)
+
+    def run(self, launch=True):
+        """Step scope opens: one launch for every recorded pack (launch=False: an earlier scope of this step has launched it), results
+        into PACK_CACHE under the keys _packed() will ask for."""
+        if self.table is None:
+            return
+        w0 = self.requests[0][1]
+        if any((not w.is_contiguous()) or w.data_ptr() != int(p) for (_, w, _), p in zip(self.requests, self._ptrs())):
+            self.__init__()                                               # a parameter moved (load_state_dict keeps storage; .to(), re-creation do not): record again
+            return
+        if launch:
+            with torch.cuda.device(w0.device):
+                _lib.check(_lib.load().cnm_pack_winograd4_batch_f32(self.table.data_ptr(), len(self.requests), self.blocks, _s()))
+        for (kind, w, rot), out in zip(self.requests, self.outs):
+            PACK_CACHE[(kind, w.data_ptr(), w._version, tuple(w.shape), 0 if kind == "u4d" else rot, 1)] = (w, out)
+
+    def _ptrs(self):
+        if not hasattr(self, "_ptr_cache") or self._ptr_cache[0] is not self.table:
+            import numpy as np
+            raw = self.table.cpu().numpy().view(np.dtype([("w", "<u8"), ("rest", "V32")]))
+            self._ptr_cache = (self.table, [int(v) for v in raw["w"]])
+        return self._ptr_cache[1]
 
 
 def _packed(kind, weight, rot, stride, fn):
@@ -58,6 +132,8 @@ def _packed(kind, weight, rot, stride, fn):
     c = PACK_CACHE
     if c is None:
         return fn()
+    if PACK_PLAN is not None:
+        PACK_PLAN.record(kind, weight, rot)
     key = (kind, weight.data_ptr(), weight._version, tuple(weight.shape), rot, stride)
     hit = c.get(key)
     # the keyed tensor is held next to the value: a temporary used as a weight (a detached view, a derived filter) may be
@@ -338,11 +414,13 @@ class BatchNormReLUC4(torch.autograd.Function):
         mean = torch.empty(groups * C, device=dev, dtype=torch.float32)
         invstd = torch.empty_like(mean)
         with torch.cuda.device(dev):
-            _lib.check(lib.cnm_bn_train_forward_zg_c4_f32(
+            fwd = lib.cnm_bn_train_forward_p_c4_f32 if BN_PARTIALS else lib.cnm_bn_train_forward_zg_c4_f32
+            ws = _bn_partials(dev, N, C, H, W, groups) if BN_PARTIALS else _bn_workspace(dev, G, groups)
+            _lib.check(fwd(
                 x.data_ptr(), gamma.detach().contiguous().data_ptr(), beta.detach().contiguous().data_ptr(),
                 running_mean.data_ptr() if running_mean is not None else 0,
                 running_var.data_ptr() if running_var is not None else 0, float(momentum), float(eps), int(relu),
-                y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _bn_workspace(dev, G, groups).data_ptr(),
+                y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(),
                 num_batches_tracked.data_ptr() if num_batches_tracked is not None else 0, N, C, H, W, groups, _s()))
         # the backward recomputes the ReLU mask from x (cnm_bn_train_backward_zgb_c4_f32): y is not kept on the tape for BatchNorm's
         # sake, and the backward kernels read 5 tensors instead of 7
@@ -366,8 +444,14 @@ class BatchNormReLUC4(torch.autograd.Function):
         dx = torch.empty_like(x)
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
         with torch.cuda.device(dev):
-            if ctx.recompute:                               # `y` holds beta here (see forward)
+            if ctx.recompute:
                 assert getattr(ctx, "forward_affine", None) == "bn_affine", "the mask-recomputing backward needs the forward that rounds like bn_affine"
+            if BN_PARTIALS:                                 # `y` holds beta when the mask is recomputed (see forward)
+                _lib.check(lib.cnm_bn_train_backward_p_c4_f32(
+                    x.data_ptr(), 0 if ctx.recompute else y.data_ptr(), dy.data_ptr(), gamma.detach().contiguous().data_ptr(),
+                    y.detach().contiguous().data_ptr() if ctx.recompute else 0, mean.data_ptr(), invstd.data_ptr(),
+                    int(ctx.relu), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), _bn_partials(dev, N, C, H, W, ctx.groups).data_ptr(), N, C, H, W, ctx.groups, _s()))
+            elif ctx.recompute:
                 _lib.check(lib.cnm_bn_train_backward_zgb_c4_f32(
                     x.data_ptr(), dy.data_ptr(), gamma.detach().contiguous().data_ptr(), y.detach().contiguous().data_ptr(), mean.data_ptr(), invstd.data_ptr(),
                     int(ctx.relu), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), _bn_workspace(dev, G, ctx.groups).data_ptr(), N, C, H, W, ctx.groups, _s()))

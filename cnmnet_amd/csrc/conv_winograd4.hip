@@ -249,13 +249,13 @@ __global__ __launch_bounds__(256, 2) void conv_winograd36_f32_kernel(const Wino4
 // tap (jy, jx) -> w[2 jy + py - o][2 jx + px - o] (o = 0 for 5x5, 1 for 7x7 and 3x3: the window starts (K - 1) / 2 input pixels
 // = 1 or 2 phase pixels before the output pixel), zero where that leaves the filter (a 3x3 filter fills 1 / 2 / 2 / 4 of the 9 taps).
 template <int R, bool S2 = false>
-__global__ __launch_bounds__(256) void pack_winograd36_kernel(const float* __restrict__ w, const float* __restrict__ gamma, const float* __restrict__ var,
-                                                              float eps, int Cout, int Cin, int rot, int nchunks, float* __restrict__ up, int dgrad) {
+__device__ __forceinline__ void pack_winograd36_body(const float* __restrict__ w, const float* __restrict__ gamma, const float* __restrict__ var,
+                                                     float eps, int Cout, int Cin, int rot, int nchunks, float* __restrict__ up, int dgrad, int block) {
     const int ncb16 = Cout / 16;
-    const int cb = blockIdx.x % ncb16, chunk = blockIdx.x / ncb16;
+    const int cb = block % ncb16, chunk = block / ncb16;
     const int t = threadIdx.x, e = t & 3, lane = t >> 2;
     const int co = cb * 16 + (lane & 15), cp = (S2 ? chunk >> 2 : chunk) * 16 + 4 * (lane >> 4) + e;
-    float* out = up + (size_t)blockIdx.x * 36 * 256 + t;
+    float* out = up + (size_t)block * 36 * 256 + t;
     if (cp >= Cin) {
 #pragma unroll
         for (int xi = 0; xi < 36; ++xi) out[xi * 256] = 0.f;
@@ -297,6 +297,29 @@ __global__ __launch_bounds__(256) void pack_winograd36_kernel(const float* __res
         if (gamma) s *= scale;
         out[xi * 256] = (float)s;
     }
+}
+template <int R, bool S2 = false>
+__global__ __launch_bounds__(256) void pack_winograd36_kernel(const float* __restrict__ w, const float* __restrict__ gamma, const float* __restrict__ var,
+                                                              float eps, int Cout, int Cin, int rot, int nchunks, float* __restrict__ up, int dgrad) {
+    pack_winograd36_body<R, S2>(w, gamma, var, eps, Cout, Cin, rot, nchunks, up, dgrad, (int)blockIdx.x);
+}
+
+// [r6] MANY 3x3 filters in ONE launch (training: every filter is re-packed every step, forward and data-gradient form -- 63 launches of
+// ~10 us each, 2 % of the step).  jobs[j] describes one cnm_pack_winograd4_bn_f32 (no BatchNorm fold) or cnm_pack_winograd4_dgrad_f32
+// call; block b belongs to the job with the largest first_block <= b.  Same arithmetic per output float: bit-identical packed filters.
+struct PackJob { const float* w; float* out; int Cout, Cin, rot, nchunks, dgrad, first_block; };
+static_assert(sizeof(PackJob) == 40, "cnmnet_amd/autograd.py builds this table");
+__global__ __launch_bounds__(256) void pack_winograd36_batch_kernel(const PackJob* __restrict__ jobs, int njobs) {
+    int lo = 0, hi = njobs - 1;                                          // wave-uniform binary search
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (jobs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
+    const PackJob j = jobs[lo];
+    pack_winograd36_body<3, false>(j.w, nullptr, nullptr, 0.f, j.Cout, j.Cin, j.rot, j.nchunks, j.out, j.dgrad, (int)blockIdx.x - j.first_block);
+}
+extern "C" int cnm_pack_winograd4_batch_f32(const void* jobs_dev, int njobs, int total_blocks, void* stream) {
+    CNM_REQUIRE(jobs_dev && njobs > 0 && total_blocks > 0, CNM_ERR_BAD_ARG);
+    pack_winograd36_batch_kernel<<<(unsigned)total_blocks, 256, 0, cnm_stream(stream)>>>(static_cast<const PackJob*>(jobs_dev), njobs);
+    CNM_LAUNCH_CHECK();
+    return CNM_OK;
 }
 
 extern "C" size_t cnm_packed_winograd4_floats(int Cout, int Cin) {

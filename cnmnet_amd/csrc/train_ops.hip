@@ -953,6 +953,264 @@ extern "C" int cnm_bn_train_backward_zgb_c4_f32(const float* x, const float* dy,
     return bn_backward(x, nullptr, dy, gamma, save_mean, save_invstd, relu, dx, dgamma, dbeta, zero_ws, 1, N, C, H, W, stream, groups, beta);
 }
 
+// ------------------------------------------------------------------ BatchNorm without the finalising launches [r6]
+// The *_p entry points: the reductions write one PARTIAL per workgroup into fixed slots ([group][chunk][channel][2] fp64: no atomics, nothing
+// to clear, a fixed summation order), and the elementwise pass that follows sums the <= 64 partials of its own four channels in its prologue
+// (one wave, four loads per lane, a shuffle tree: the same tree in every workgroup, so every workgroup -- and the one that records
+// save_mean / save_invstd / the running statistics / dgamma / dbeta -- holds bit-identical statistics).  Two launches per direction instead
+// of three: 76 launches of ~5 us less per training step; and the sums no longer depend on the order atomics happened to land in.
+// (Round 5 folded the finalisation with last-workgroup TICKETS and lost: a ticket per workgroup is dearer than a launch.  Here nobody
+// waits for anybody.)
+__device__ __forceinline__ void bn_block_partials(double (&s)[4], double (&q)[4], double* __restrict__ slot) {   // slot: [4 channels of this group][2]
+    __shared__ double red[8][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { s[j] += __shfl_down(s[j], o); q[j] += __shfl_down(q[j], o); }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) for (int j = 0; j < 4; ++j) { red[wave][j] = s[j]; red[wave + 4][j] = q[j]; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int j = threadIdx.x;
+        slot[2 * j + 0] = red[0][j] + red[1][j] + red[2][j] + red[3][j];
+        slot[2 * j + 1] = red[4][j] + red[5][j] + red[6][j] + red[7][j];
+    }
+}
+// sum of the Y partials of channel group g, statistics group grp: every lane of wave 0 returns (sum0, sum1) of channel 4 g + (lane & 3)
+__device__ __forceinline__ void bn_sum_partials(const double* __restrict__ part, int Y, int Cp, int grp, int g, double& a, double& b) {
+    const int lane = threadIdx.x & 63, j = lane & 3;
+    a = 0.0; b = 0.0;
+    for (int y = lane >> 2; y < Y; y += 16) {
+        const double* p = part + (((size_t)grp * Y + y) * Cp + 4 * g + j) * 2;
+        a += p[0]; b += p[1];
+    }
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+}
+
+__global__ __launch_bounds__(256) void bn_stats_p_kernel(const float* __restrict__ x, int N, int G, int HW, double* __restrict__ part, int S, int ypi, int ni) {
+    const int g = blockIdx.x, grp = blockIdx.z;
+    const int i0 = blockIdx.y / ypi, chunk = blockIdx.y - i0 * ypi, step = ypi * 256;
+    double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    for (int n = grp + i0 * S; n < N; n += ni * S) {
+        const float4* __restrict__ p = reinterpret_cast<const float4*>(x + c4_offset(n, G, g, HW, 0));
+        int pix = chunk * 256 + threadIdx.x;
+        for (; pix + step < HW; pix += 2 * step) {
+            const float4 v = p[pix], w = p[pix + step];
+            s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+            q[0] += (double)v.x * v.x; q[1] += (double)v.y * v.y; q[2] += (double)v.z * v.z; q[3] += (double)v.w * v.w;
+            s[0] += w.x; s[1] += w.y; s[2] += w.z; s[3] += w.w;
+            q[0] += (double)w.x * w.x; q[1] += (double)w.y * w.y; q[2] += (double)w.z * w.z; q[3] += (double)w.w * w.w;
+        }
+        if (pix < HW) {
+            const float4 v = p[pix];
+            s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+            q[0] += (double)v.x * v.x; q[1] += (double)v.y * v.y; q[2] += (double)v.z * v.z; q[3] += (double)v.w * v.w;
+        }
+    }
+    bn_block_partials(s, q, part + (((size_t)grp * gridDim.y + blockIdx.y) * 4 * G + 4 * g) * 2);
+}
+
+__device__ __forceinline__ void bn_moments(double sum, double sumsq, double cnt, float eps, float& mu_f, float& is_f, double& mu, double& var) {
+    mu = sum / cnt; var = sumsq / cnt - mu * mu;
+    if (var < 0) var = 0;
+    mu_f = (float)mu; is_f = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+__global__ __launch_bounds__(256) void bn_apply_p_kernel(const float* __restrict__ x, const double* __restrict__ part, int Y,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta, int C, int relu,
+                                                         float* __restrict__ y, int N, int G, int HW, int S, float eps, float momentum,
+                                                         float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                         float* __restrict__ running_mean, float* __restrict__ running_var, long long* __restrict__ tracked) {
+    __shared__ float sh[8];
+    const int plane = blockIdx.y, n = plane / G, g = plane - n * G, grp = S == 1 ? 0 : n % S, Cp = 4 * G;
+    if (threadIdx.x < 64) {
+        const int j = threadIdx.x & 3, c = 4 * g + j;
+        double a, b, mu, var; float mf, isf;
+        bn_sum_partials(part, Y, Cp, grp, g, a, b);
+        bn_moments(a, b, (double)((N - grp + S - 1) / S) * HW, eps, mf, isf, mu, var);
+        if (threadIdx.x < 4) { sh[j] = mf; sh[4 + j] = isf; }
+        if (blockIdx.x == 0 && n == grp && threadIdx.x < 4 && c < C) { save_mean[grp * C + c] = mf; save_invstd[grp * C + c] = isf; }
+        if (blockIdx.x == 0 && n == 0) {                                  // the running statistics take the groups' updates one after the other, in source order
+            if (g == 0 && threadIdx.x == 0 && tracked) *tracked += S;
+            float rm = 0.f, rv = 0.f;
+            if (running_mean && c < C) { rm = running_mean[c]; rv = running_var[c]; }
+            for (int k = 0; k < S; ++k) {
+                if (k != grp || S > 1) { bn_sum_partials(part, Y, Cp, k, g, a, b); }
+                const double cnt = (double)((N - k + S - 1) / S) * HW;
+                bn_moments(a, b, cnt, eps, mf, isf, mu, var);
+                const double unbiased = cnt > 1 ? var * cnt / (cnt - 1.0) : var;
+                rm = (float)((1.0 - momentum) * rm + momentum * mu);
+                rv = (float)((1.0 - momentum) * rv + momentum * unbiased);
+            }
+            if (running_mean && threadIdx.x < 4 && c < C) { running_mean[c] = rm; running_var[c] = rv; }
+        }
+    }
+    __syncthreads();
+    float mu[4], is[4], ga[4], be[4]; bool live[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = 4 * g + j; live[j] = c < C;
+        mu[j] = live[j] ? sh[j] : 0.f; is[j] = live[j] ? sh[4 + j] : 0.f; ga[j] = live[j] ? gamma[c] : 0.f; be[j] = live[j] ? beta[c] : 0.f;
+    }
+    const float4* __restrict__ p = reinterpret_cast<const float4*>(x) + (size_t)plane * HW;
+    float4* __restrict__ o = reinterpret_cast<float4*>(y) + (size_t)plane * HW;
+    for (int pix = blockIdx.x * 256 + threadIdx.x; pix < HW; pix += gridDim.x * 256) {
+        const float4 v = p[pix];
+        const float in[4] = {v.x, v.y, v.z, v.w}; float r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            r[j] = live[j] ? bn_affine(in[j], mu[j], is[j], ga[j], be[j]) : 0.f;
+            if (relu && live[j]) r[j] = fmaxf(r[j], 0.f);
+        }
+        o[pix] = make_float4(r[0], r[1], r[2], r[3]);
+    }
+}
+
+template <bool RECOMP>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_p_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                              const float* __restrict__ dy, const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, int C, int relu,
+                                                              int N, int G, int HW, double* __restrict__ part, int S, int ypi, int ni) {
+    const int g = blockIdx.x, grp = blockIdx.z;
+    const int i0 = blockIdx.y / ypi, chunk = blockIdx.y - i0 * ypi, step = ypi * 256;
+    double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    float mu[4], is[4], ga[4], be[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = 4 * g + j; mu[j] = c < C ? mean[grp * C + c] : 0.f; is[j] = c < C ? invstd[grp * C + c] : 0.f;
+        ga[j] = (RECOMP && c < C) ? gamma[c] : 0.f; be[j] = (RECOMP && c < C) ? beta[c] : 0.f;
+    }
+    for (int n = grp + i0 * S; n < N; n += ni * S) {
+        const size_t base = c4_offset(n, G, g, HW, 0);
+        const float4* __restrict__ px = reinterpret_cast<const float4*>(x + base);
+        const float4* __restrict__ py = RECOMP ? nullptr : reinterpret_cast<const float4*>(y + base);
+        const float4* __restrict__ pd = reinterpret_cast<const float4*>(dy + base);
+        for (int pix = chunk * 256 + threadIdx.x; pix < HW; pix += step) {
+            const float4 xv = px[pix];
+            float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (!RECOMP) yv = py[pix];
+            const float4 dv = pd[pix];
+            const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ys[4] = {yv.x, yv.y, yv.z, yv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float pre = RECOMP ? bn_affine(xs[j], mu[j], is[j], ga[j], be[j]) : ys[j];
+                const float d = (relu && !(pre > 0.f)) ? 0.f : ds[j];
+                s[j] += d; q[j] += (double)d * ((xs[j] - mu[j]) * is[j]);
+            }
+        }
+    }
+    bn_block_partials(s, q, part + (((size_t)grp * gridDim.y + blockIdx.y) * 4 * G + 4 * g) * 2);
+}
+
+template <bool RECOMP>
+__global__ __launch_bounds__(256) void bn_bwd_apply_p_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                             const float* __restrict__ dy, const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const double* __restrict__ part, int Y, int C, int relu,
+                                                             float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int G, int HW, int S) {
+    __shared__ float sh[8];
+    const int plane = blockIdx.y, n = plane / G, g = plane - n * G, grp = S == 1 ? 0 : n % S, so = grp * C, Cp = 4 * G;
+    if (threadIdx.x < 64) {
+        const int j = threadIdx.x & 3, c = 4 * g + j;
+        double a, b;
+        bn_sum_partials(part, Y, Cp, grp, g, a, b);
+        const double cnt = (double)((N - grp + S - 1) / S) * HW;
+        if (threadIdx.x < 4) { sh[j] = (float)(a / cnt); sh[4 + j] = (float)(b / cnt); }
+        if (blockIdx.x == 0 && n == 0) {                                  // the groups' parameter gradients add in source order, in fp32, as S backward passes accumulate them
+            float db = 0.f, dg = 0.f;
+            for (int k = 0; k < S; ++k) {
+                if (k != grp || S > 1) bn_sum_partials(part, Y, Cp, k, g, a, b);
+                db += (float)a; dg += (float)b;
+            }
+            if (threadIdx.x < 4 && c < C) { dbeta[c] = db; dgamma[c] = dg; }
+        }
+    }
+    __syncthreads();
+    float mu[4], is[4], ga[4], be[4], sd[4], sq[4]; bool live[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = 4 * g + j; live[j] = c < C;
+        mu[j] = live[j] ? mean[so + c] : 0.f; is[j] = live[j] ? invstd[so + c] : 0.f; ga[j] = live[j] ? gamma[c] : 0.f; be[j] = (RECOMP && live[j]) ? beta[c] : 0.f;
+        sd[j] = live[j] ? sh[j] : 0.f; sq[j] = live[j] ? sh[4 + j] : 0.f;
+    }
+    const size_t base = (size_t)plane * HW;
+    const float4* __restrict__ px = reinterpret_cast<const float4*>(x) + base;
+    const float4* __restrict__ py = RECOMP ? nullptr : reinterpret_cast<const float4*>(y) + base;
+    const float4* __restrict__ pd = reinterpret_cast<const float4*>(dy) + base;
+    float4* __restrict__ po = reinterpret_cast<float4*>(dx) + base;
+    for (int pix = blockIdx.x * 256 + threadIdx.x; pix < HW; pix += gridDim.x * 256) {
+        const float4 xv = px[pix];
+        float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (!RECOMP) yv = py[pix];
+        const float4 dv = pd[pix];
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ys[4] = {yv.x, yv.y, yv.z, yv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float pre = RECOMP ? bn_affine(xs[j], mu[j], is[j], ga[j], be[j]) : ys[j];
+            const float d = (relu && !(pre > 0.f)) ? 0.f : ds[j];
+            const float xh = (xs[j] - mu[j]) * is[j];
+            o[j] = live[j] ? ga[j] * is[j] * (d - sd[j] - xh * sq[j]) : 0.f;
+        }
+        po[pix] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// Partial-sum workspace of the *_p entry points: 2 * 4 * ceil(C / 4) doubles per (statistics group, reducing workgroup); contents irrelevant on
+// entry and exit (every slot a call reads it has written), one per stream.
+extern "C" size_t cnm_bn_train_partials_doubles(int N, int C, int H, int W, int groups) {
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || groups < 1) return 0;
+    const BnGridY gy = bn_grid_y((N + groups - 1) / groups, H * W);
+    return (size_t)groups * gy.ypi * gy.ni * 8 * ((C + 3) / 4);
+}
+// Training-mode BatchNorm + optional ReLU on a c4 tensor, `groups` statistics groups as cnm_bn_train_forward_zg_c4_f32 (same results up to
+// the summation order of the fp64 sums), in TWO launches; num_batches_tracked may be NULL.
+extern "C" int cnm_bn_train_forward_p_c4_f32(const float* x, const float* gamma, const float* beta,
+                                             float* running_mean, float* running_var, float momentum, float eps, int relu,
+                                             float* y, float* save_mean, float* save_invstd, double* partials_ws, long long* num_batches_tracked,
+                                             int N, int C, int H, int W, int groups, void* stream) {
+    const int S = groups;
+    CNM_REQUIRE(x && gamma && beta && y && save_mean && save_invstd && partials_ws && N > 0 && C > 0 && H > 0 && W > 0 && S >= 1 && S <= N, CNM_ERR_BAD_ARG);
+    CNM_REQUIRE(!running_mean == !running_var, CNM_ERR_BAD_ARG);
+    const int G = (C + 3) / 4, HW = H * W;
+    CNM_REQUIRE((long long)N * G <= 65535, CNM_ERR_BAD_ARG);
+    hipStream_t s = cnm_stream(stream);
+    const BnGridY gy = bn_grid_y((N + S - 1) / S, HW);
+    const int Y = gy.ypi * gy.ni;
+    bn_stats_p_kernel<<<dim3(G, Y, S), 256, 0, s>>>(x, N, G, HW, partials_ws, S, gy.ypi, gy.ni);
+    bn_apply_p_kernel<<<bn_plane_grid(N, G, HW), 256, 0, s>>>(x, partials_ws, Y, gamma, beta, C, relu, y, N, G, HW, S, eps, momentum, save_mean, save_invstd,
+                                                             running_mean, running_var, num_batches_tracked);
+    CNM_LAUNCH_CHECK();
+    return CNM_OK;
+}
+// Its backward (y == NULL with relu: the ReLU mask is recomputed from x, gamma, beta and the saved statistics, as cnm_bn_train_backward_zgb_c4_f32).
+extern "C" int cnm_bn_train_backward_p_c4_f32(const float* x, const float* y, const float* dy, const float* gamma, const float* beta,
+                                              const float* save_mean, const float* save_invstd, int relu,
+                                              float* dx, float* dgamma, float* dbeta, double* partials_ws,
+                                              int N, int C, int H, int W, int groups, void* stream) {
+    const int S = groups;
+    CNM_REQUIRE(x && (y || beta || !relu) && dy && gamma && save_mean && save_invstd && dx && dgamma && dbeta && partials_ws && N > 0 && C > 0 && S >= 1 && S <= N, CNM_ERR_BAD_ARG);
+    const int G = (C + 3) / 4, HW = H * W;
+    CNM_REQUIRE((long long)N * G <= 65535, CNM_ERR_BAD_ARG);
+    hipStream_t s = cnm_stream(stream);
+    const bool recomp = !y && relu;
+    const BnGridY gy = bn_grid_y((N + S - 1) / S, HW);
+    const int Y = gy.ypi * gy.ni;
+    const dim3 rg(G, Y, S), ag = bn_plane_grid(N, G, HW);
+    if (recomp) {
+        bn_bwd_reduce_p_kernel<true><<<rg, 256, 0, s>>>(x, nullptr, dy, save_mean, save_invstd, gamma, beta, C, relu, N, G, HW, partials_ws, S, gy.ypi, gy.ni);
+        bn_bwd_apply_p_kernel<true><<<ag, 256, 0, s>>>(x, nullptr, dy, save_mean, save_invstd, gamma, beta, partials_ws, Y, C, relu, dx, dgamma, dbeta, N, G, HW, S);
+    } else {
+        bn_bwd_reduce_p_kernel<false><<<rg, 256, 0, s>>>(x, y ? y : x, dy, save_mean, save_invstd, gamma, beta, C, relu, N, G, HW, partials_ws, S, gy.ypi, gy.ni);
+        bn_bwd_apply_p_kernel<false><<<ag, 256, 0, s>>>(x, y ? y : x, dy, save_mean, save_invstd, gamma, beta, partials_ws, Y, C, relu, dx, dgamma, dbeta, N, G, HW, S);
+    }
+    CNM_LAUNCH_CHECK();
+    return CNM_OK;
+}
+
 // ------------------------------------------------------------------ adjoint of the bilinear x2 upsample
 __global__ __launch_bounds__(256) void upsample2x_bwd_c4_kernel(const float* __restrict__ dy, float* __restrict__ dx,
                                                                 int N, int G, int H, int W) {

@@ -25,14 +25,25 @@ class _step_scope:
     """Forward + backward of ONE optimisation step: packed filters are shared inside it (autograd.PACK_CACHE) and dropped at
     its end -- the weights change right after it, in optimizer.step()."""
 
+    def __init__(self, plan=None, launch=True):
+        """plan: the autograd.PackPlan of this step variant -- its 3x3 filter packs as ONE launch when the scope opens [r6]; launch=False
+        (the later graphs of a segmented capture): the packs were launched by the scope of the step's first graph, only hand them out."""
+        self.plan, self.launch = plan, launch
+
     def __enter__(self):
         from . import autograd
         autograd.PACK_CACHE = {}
+        autograd.PACK_PLAN = self.plan
+        if self.plan is not None:
+            self.plan.run(self.launch)
         return self
 
     def __exit__(self, *exc):
         from . import autograd
         autograd.PACK_CACHE = None
+        autograd.PACK_PLAN = None
+        if self.plan is not None and exc[0] is None:
+            self.plan.freeze()
         return False
 
 
@@ -254,6 +265,7 @@ class TrainStepWoNormal:
             self.reducer = BucketedGradAllReduce(params, dist, group=group, hooks=not graph, segment_of=seg if graph else None)
         self.l234 = IdepthLoss_234()
         self.graph_mode, self._graph, self._graph_b, self._graph_c, self._graph_key, self._cut = bool(graph), None, None, None, None, None
+        self._pack_plans = {}                                            # step variant -> autograd.PackPlan (the step's 3x3 filter packs as one launch)
         self.finish_events = None                                        # set to [] to collect (start, end) HIP events around the reducer's finish()
 
     def __call__(self, rgbs, cameras, disparities, depths, warmup_epoch=False):
@@ -262,7 +274,7 @@ class TrainStepWoNormal:
         if self.graph_mode:
             return self._graphed_step((rgbs, cameras, disparities, depths), bool(warmup_epoch),
                                       lambda *a: self.losses(*a, warmup_epoch))
-        with _step_scope():
+        with _step_scope(self._plan((tuple(rgbs.shape), bool(warmup_epoch)))):
             loss, logs = self.losses(rgbs, cameras, disparities, depths, warmup_epoch)
             if self.reducer is None:
                 self.optimizer.zero_grad(set_to_none=True)                                   # :562-565 (see _zero_grad_note)
@@ -273,6 +285,13 @@ class TrainStepWoNormal:
             self._finish(self.reducer.finish)
         self.optimizer.step()
         return _log_values(logs)
+
+    def _plan(self, key):
+        from . import autograd
+        p = self._pack_plans.get(key)
+        if p is None:
+            p = self._pack_plans[key] = autograd.PackPlan()
+        return p
 
     def _finish(self, fn):
         """The part of the gradient exchange that backward did not hide: buckets still in flight + the write-back."""
@@ -350,9 +369,10 @@ class TrainStepWoNormal:
             gc = grads[len(refine_params):]
             return [c for c, g in zip(cut, gc) if g is not None], [g for g in gc if g is not None]
 
+        plan = self._plan(("graph",) + tuple(key))
         with torch.cuda.stream(side):                       # warm-up off the default stream: Adam state and allocator pools exist before capture
             for _ in range(2):
-                with _step_scope():
+                with _step_scope(plan):
                     loss, logs = forward(*self._static_in)
                     self.optimizer.zero_grad(set_to_none=True)
                     if segmented:
@@ -373,12 +393,12 @@ class TrainStepWoNormal:
             # graph A: forward + backward through the refine net; graph B (same memory pool): depthNet's backward -- [r5] its DECODER's,
             # with graph C for the encoder's.  Between the replays the gradient buckets of the part just finished are handed to the collective.
             depth_params = [p for p in self.depth_net.parameters() if p.requires_grad]
-            with torch.cuda.graph(self._graph), _step_scope():
+            with torch.cuda.graph(self._graph), _step_scope(plan):
                 loss, logs = forward(*self._static_in)
                 cut, gcut = backward_refine(loss)
                 self.reducer.capture_copy(refine_params)                 # [r6] the gradients land in their all-reduce buckets inside the graph
             self._graph_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph_b, pool=self._graph.pool()), _step_scope():
+            with torch.cuda.graph(self._graph_b, pool=self._graph.pool()), _step_scope(plan, launch=False):
                 if three:
                     cut, gcut = backward_decoder(cut, gcut)
                     self.reducer.capture_copy(decoder_params)
@@ -387,13 +407,13 @@ class TrainStepWoNormal:
                     self.reducer.capture_copy(depth_params)
             if three:
                 self._graph_c = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self._graph_c, pool=self._graph.pool()), _step_scope():
+                with torch.cuda.graph(self._graph_c, pool=self._graph.pool()), _step_scope(plan, launch=False):
                     torch.autograd.backward(cut, gcut)
                     self.reducer.capture_copy([p for p in depth_params if id(p) not in self._early_ids])
             del cut, gcut
             self.depth_net._enc_cut = None
         else:
-            with torch.cuda.graph(self._graph), _step_scope():
+            with torch.cuda.graph(self._graph), _step_scope(plan):
                 loss, logs = forward(*self._static_in)
                 loss.backward()
                 if self.reducer is None:
@@ -539,7 +559,7 @@ class TrainStep(TrainStepWoNormal):
         if self.graph_mode:                                  # the relative poses (a 4x4 inverse) are computed outside the captured region
             return self._graphed_step((rgbs, cameras, disparities, depths, normals, self.relative_poses(cameras)), "normals",
                                       lambda r, c, i, d, n, poses: self.losses(r, c, i, d, n, poses))
-        with _step_scope():
+        with _step_scope(self._plan((tuple(rgbs.shape), "normals"))):
             loss, logs = self.losses(rgbs, cameras, disparities, depths, normals)
             if self.reducer is None:
                 self.optimizer.zero_grad(set_to_none=True)                                   # :307-310 (see _zero_grad_note)

@@ -243,6 +243,12 @@ int cnm_pack_winograd4_bn_f32(const float* w_oihw, const float* bn_gamma, const 
  * (training, train.py:307-310 through autograd): w'[ci][co] = w[co][ci] rotated by 180 degrees, i.e. Cw_in output channels
  * (a multiple of 64) and Cw_out input channels, cnm_packed_winograd4_floats(Cw_in, Cw_out) floats; read straight from w. */
 int cnm_pack_winograd4_dgrad_f32(const float* w_oihw, int Cw_out, int Cw_in, int ksize, float* u_packed, void* stream);
+/* [r6] Many 3x3 filters in ONE launch (training re-packs every filter every step, forward and data-gradient form): jobs_dev = device
+ * array of njobs records { const float* w; float* out; int Cout, Cin, rot, nchunks, dgrad, first_block; } (40 bytes each; Cout / Cin as
+ * the single-filter calls see them: the data-gradient form of w [Cw_out][Cw_in][3][3] has Cout = Cw_in, Cin = Cw_out, dgrad = 1, rot = 0;
+ * nchunks = ceil(4 ceil(Cin / 4) / 16); a job owns nchunks * Cout / 16 blocks from first_block on, jobs sorted by first_block);
+ * total_blocks = their sum.  No BatchNorm fold.  Bit-identical to the single-filter calls. */
+int cnm_pack_winograd4_batch_f32(const void* jobs_dev, int njobs, int total_blocks, void* stream);
 int cnm_conv3x3_winograd4_c4_f32(const float* in_a, int Ga_total, int ga0, int Ga,
                                  const float* in_b, int Gb_total, int gb0, int Gb,
                                  float* out, int Gout_total, int gout0, int Cout,
@@ -660,6 +666,22 @@ int cnm_bn_train_backward_zgb_c4_f32(const float* x, const float* dy, const floa
                                      const float* save_mean, const float* save_invstd, int relu,
                                      float* dx, float* dgamma, float* dbeta, double* zero_ws,
                                      int N, int C, int H, int W, int groups, void* stream);
+/* [r6] The same BatchNorm in TWO launches per direction: the reductions leave one partial sum per workgroup in fixed slots of
+ * partials_ws (cnm_bn_train_partials_doubles(N, C, H, W, groups) doubles, contents irrelevant on entry and exit, one per stream: no
+ * atomics, nothing to clear, a fixed summation order), and the elementwise pass sums the <= 64 partials of its own four channels in its
+ * prologue -- every workgroup with the same shuffle tree, so the one that records save_mean / save_invstd / the running statistics /
+ * dgamma / dbeta holds bit-identical values.  Semantics as cnm_bn_train_forward_zg_c4_f32 / cnm_bn_train_backward_zg(b)_c4_f32 (groups,
+ * num_batches_tracked, y == NULL with beta: the ReLU mask recomputed from x); results equal theirs up to the summation order of the
+ * fp64 sums.  76 launches less per training step (train.py:164-310). */
+size_t cnm_bn_train_partials_doubles(int N, int C, int H, int W, int groups);
+int cnm_bn_train_forward_p_c4_f32(const float* x, const float* gamma, const float* beta,
+                                  float* running_mean, float* running_var, float momentum, float eps, int relu,
+                                  float* y, float* save_mean, float* save_invstd, double* partials_ws, long long* num_batches_tracked,
+                                  int N, int C, int H, int W, int groups, void* stream);
+int cnm_bn_train_backward_p_c4_f32(const float* x, const float* y, const float* dy, const float* gamma, const float* beta,
+                                   const float* save_mean, const float* save_invstd, int relu,
+                                   float* dx, float* dgamma, float* dbeta, double* partials_ws,
+                                   int N, int C, int H, int W, int groups, void* stream);
 
 /* Masked mean L1 of the training losses -- IdepthLoss / IdepthwithProbLoss (losses.py:30-73) without the `pred[mask]` gather:
  *   out2[0] = sum_m weight |pred - gt| / count(m),  out2[1] = count(m),  m = gt > 0 && finite(gt) && finite(pred) && pred > 0

@@ -11,19 +11,52 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _launch(cmd, env, timeout):
-    """Run a multi-rank bench command, ONCE (no retry: a rank lost to a signal fails the test -- with its Python and C++ stacks on
-    stderr: faulthandler, TORCH_SHOW_CPP_STACKTRACES)."""
-    env = dict(env, PYTHONFAULTHANDLER="1", TORCH_SHOW_CPP_STACKTRACES="1")
+def _launch(cmd, env, timeout, amd_log=False):
+    """Run a multi-rank bench command, ONCE (no retry: a rank lost to a signal fails the test).  [r6] Every launch is logged UNCONDITIONALLY:
+    per-rank stderr (faulthandler, TORCH_SHOW_CPP_STACKTRACES; AMD_LOG_LEVEL=2 for the eight-rank runs) and per-rank resource lines go to
+    gpurun_out/multi_rank_logs/<launch>/ from the first instruction on, the parent empties its caching allocator first and records what it
+    still holds on the GPU the ranks are about to share.  On success the directory is removed and its resource lines are appended to
+    gpurun_out/multi_rank_resources.txt (the record of the runs that did NOT fail); on failure everything stays."""
+    import shutil
+    import time
+    import torch
+    tag = "%s_%d_%d" % (os.environ.get("PYTEST_CURRENT_TEST", "launch").split("::")[-1].split(" ")[0], os.getpid(), int(time.time() * 1000) % 10**9)
+    d = os.path.join(ROOT, "gpurun_out", "multi_rank_logs", tag)
+    os.makedirs(d, exist_ok=True)
+    parent = "parent pid %d: " % os.getpid()
+    try:
+        if torch.cuda.is_available() and torch.cuda.is_initialized():
+            torch.cuda.synchronize(); torch.cuda.empty_cache()
+            free, total = torch.cuda.mem_get_info()
+            parent += "device free %.2f of %.2f GB after empty_cache (reserved %.2f GB, allocated %.2f GB), " % (
+                free / 2**30, total / 2**30, torch.cuda.memory_reserved() / 2**30, torch.cuda.memory_allocated() / 2**30)
+        parent += "open fds %d" % len(os.listdir("/proc/self/fd"))
+    except Exception as e:                                               # noqa: BLE001
+        parent += "(%s)" % e
+    with open(os.path.join(d, "parent.txt"), "w") as f:
+        f.write(parent + "\n" + " ".join(cmd) + "\n")
+    env = dict(env, PYTHONFAULTHANDLER="1", TORCH_SHOW_CPP_STACKTRACES="1", CNM_RANK_LOG_DIR=d)
+    if amd_log:
+        env["AMD_LOG_LEVEL"] = "2"
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
-    if r.returncode != 0:                                                 # keep EVERYTHING the ranks wrote (the assertion message shows an excerpt): gpurun_out/ comes back from the GPU box
+    with open(os.path.join(d, "launcher.txt"), "w") as f:
+        f.write("---- exit code %d\n---- stdout\n%s\n---- stderr\n%s\n" % (r.returncode, r.stdout, r.stderr))
+    if r.returncode == 0:
         try:
-            d = os.path.join(ROOT, "gpurun_out")
-            os.makedirs(d, exist_ok=True)
-            with open(os.path.join(d, "multi_rank_failure_%d.txt" % os.getpid()), "a") as f:
-                f.write("==== %s\n---- exit code %d\n---- stdout\n%s\n---- stderr\n%s\n" % (" ".join(cmd), r.returncode, r.stdout, r.stderr))
+            with open(os.path.join(ROOT, "gpurun_out", "multi_rank_resources.txt"), "a") as out:
+                out.write("==== %s ok\n%s\n" % (tag, parent))
+                for name in sorted(os.listdir(d)):
+                    if name.startswith("rank") and name.endswith(".txt"):
+                        out.write(open(os.path.join(d, name)).read())
+            shutil.rmtree(d, ignore_errors=True)
         except OSError:
             pass
+    else:                                                                 # what the ranks wrote to their own stderr files, for the assertion message
+        extra = []
+        for name in sorted(os.listdir(d)):
+            if name.endswith(".err"):
+                extra.append("---- %s\n%s" % (name, open(os.path.join(d, name), errors="replace").read()[-4000:]))
+        r.stderr = (r.stderr or "") + "\n" + "\n".join(extra)
     return r
 
 
@@ -96,7 +129,7 @@ def test_eight_rank_dry_run_eval():
     host threads capped per rank), one frame per rank: the line has the N = 8 shape and the whole-job value."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--frames-per-gpu", "1",
            "--no-roofline", "--no-secondary"]
-    r = _launch(cmd, _clean_env(), 1200)
+    r = _launch(cmd, _clean_env(), 1200, amd_log=True)
     _check_line(r, world=8, frames=1)
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert d["config"]["barrier_backend"] == "gloo" and d["config"]["host_threads_per_rank"] >= 1
@@ -106,7 +139,7 @@ def test_eight_rank_dry_run_train():
     """The same for --mode train (BASELINE configs[2]: 8 ranks, data parallel): every bucket of the gradient exchange leaves
     from a backward hook on every step (the overlapped path), the line carries the global batch of 8 x 1."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "train", "--gpus", "8", "--steps", "2", "--warmup", "1", "--samples-per-gpu", "1"]
-    r = _launch(cmd, _clean_env(), 1800)
+    r = _launch(cmd, _clean_env(), 1800, amd_log=True)
     assert r.returncode == 0, _why(r)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]

@@ -250,6 +250,35 @@ def test_batchnorm_backward_recomputed_mask_is_bit_identical(dev, C, N, H, W, S,
     assert torch.equal(y0, y1) and torch.equal(dx0, dx1) and torch.equal(dg0, dg1) and torch.equal(db0, db1)
 
 
+@pytest.mark.parametrize("C,N,H,W,S,relu", [(128, 4, 12, 20, 2, True), (67, 3, 8, 8, 1, False), (256, 2, 24, 32, 1, True), (64, 6, 8, 12, 3, True), (32, 8, 96, 128, 2, True)])
+def test_batchnorm_two_launch_matches_three_launch(dev, C, N, H, W, S, relu):
+    """[r6] cnm_bn_train_{forward,backward}_p_c4_f32 (fixed-slot partial sums, summed in the elementwise pass's prologue: two launches per
+    direction) against the three-launch form (atomics + a finalising launch): outputs, saved and running statistics, num_batches_tracked,
+    dx, dgamma, dbeta -- equal up to the summation order of the fp64 sums; and the two-launch form is bit-reproducible."""
+    from cnmnet_amd import ops, autograd as ag
+    rng = np.random.default_rng(C + N + S)
+    x0 = ops.nchw_to_c4(T((rng.standard_normal((N, C, H, W)) * 1.5 + 0.3).astype(np.float32)).to(dev))
+    gy = ops.nchw_to_c4(T(rng.standard_normal((N, C, H, W)).astype(np.float32)).to(dev))
+    g0 = T(rng.uniform(0.5, 1.5, C).astype(np.float32)).to(dev); b0 = T(rng.normal(0, 0.2, C).astype(np.float32)).to(dev)
+    outs = []
+    old = ag.BN_PARTIALS
+    try:
+        for flag in (False, True, True):
+            ag.BN_PARTIALS = flag
+            x = x0.clone().requires_grad_(True); g = g0.clone().requires_grad_(True); b = b0.clone().requires_grad_(True)
+            rm, rv, nbt = torch.zeros(C, device=dev), torch.ones(C, device=dev), torch.zeros((), dtype=torch.long, device=dev)
+            y = ag.BatchNormReLUC4.apply(x, g, b, rm, rv, 0.1, 1e-5, relu, nbt, S)
+            y.backward(gy)
+            outs.append((y.detach(), rm, rv, x.grad, g.grad, b.grad, int(nbt.item())))
+    finally:
+        ag.BN_PARTIALS = old
+    a, p, q = outs
+    assert a[6] == p[6] == S
+    for u, v in zip(a[:6], p[:6]):
+        assert _rel(v.cpu().numpy(), u.cpu().numpy()) < 1e-6, _rel(v.cpu().numpy(), u.cpu().numpy())
+    assert all(torch.equal(u, v) for u, v in zip(p[:6], q[:6]))
+
+
 def test_batchnorm_workspace_left_zero_and_counter(dev):
     """The *_z BatchNorm entry points: the fp64 sum workspace is zero again after forward and after backward, and
     num_batches_tracked is incremented by the forward kernel."""
