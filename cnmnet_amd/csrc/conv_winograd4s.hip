@@ -664,6 +664,15 @@ int cnm_wino36s_try_launch(const Wino4Args& a, int M, int ups, hipStream_t strea
         return 1;
     }
 #ifdef WINO4S_ABLATE
+    if (g_wino36s_ablate && tsx == 16 && ups && M == 4 && !s2) {          // [r6] the fused up_conv instance: where its 0.57 of the roof goes
+        switch (g_wino36s_ablate) {
+#define WINO4S_UCASE(n) case n: conv_winograd36s_f32_kernel<16, true, n><<<grid, 512, 0, stream>>>(a, SH, SW, tilesC, (int)nunits, flags, slots); break;
+            WINO4S_UCASE(1) WINO4S_UCASE(2) WINO4S_UCASE(4) WINO4S_UCASE(16) WINO4S_UCASE(7)
+            default: return CNM_ERR_BAD_ARG;
+        }
+        CNM_LAUNCH_CHECK();
+        return CNM_OK;
+    }
     if (g_wino36s_ablate && tsx == 16 && !ups && M == 4 && !s2) {
         switch (g_wino36s_ablate) {
 #define WINO4S_CASE(n) case n: conv_winograd36s_f32_kernel<16, false, n><<<grid, 512, 0, stream>>>(a, SH, SW, tilesC, (int)nunits, flags, slots); break;
