@@ -518,6 +518,9 @@ extern "C" int cnm_conv_s2_winograd4_sync_c4_f32(const float* in_a, int Ga_total
 // interpolated from the low-resolution input into LDS once per 16-channel chunk and feed the three taps of the side as
 // shifted B operands of v_mfma_f32_16x16x4_f32; the two extra taps of a corner pixel are added by the row block that
 // owns it.  w_ring: [tap 9][chunk][cout/16][lane][4] in MFMA A-operand order (cnm_pack_upsampled_ring_f32).
+#ifndef RING_NW
+#define RING_NW 4        // waves per workgroup of the ring pass = chunks of the reduction in flight per workgroup.  [r6] eight were measured: SLOWER (23.4 against 20.5 us, 38.1 against 36.1: tools/ring_ab.sh, profiles/r6_ring_ab.txt) -- the pass scales with its work (13 us for 8 images, 21-23 for 16), it is not one latency chain per chunk
+#endif
 struct RingArgs {
     const float* in; float* out; const float* wr; const float* bias;
     int N, H, W, Gin_tot, gin0, Gin, Gout_tot, gout0, Cout, nchunks, relu;
@@ -556,14 +559,14 @@ __device__ __forceinline__ float4 ring_up_sample(const float* __restrict__ in, i
 }
 
 template <bool HALF>                                                     // HALF: fp16 c8 input / output (a.Gin = virtual c4 groups = 2 x the c8 groups)
-__global__ __launch_bounds__(256) void conv_upsampled_ring_kernel(const RingArgs a) {
-    // The reduction is short and latency-bound (a few dozen workgroups, 8-32 chunks each): the four waves split the
-    // chunks (wave w takes chunks w, w+4, ...), each staging its own chunk in a private LDS region (no workgroup
-    // barrier in the loop) for all 64 couts, and the four partial sums meet in LDS at the end.
+__global__ __launch_bounds__(64 * RING_NW) void conv_upsampled_ring_kernel(const RingArgs a) {
+    // The reduction is short and latency-bound (a few hundred workgroups, 8-32 chunks each): the RING_NW waves split the
+    // chunks (wave w takes chunks w, w + RING_NW, ...), each staging its own chunk in a private LDS region (no workgroup
+    // barrier in the loop) for all 64 couts, and the partial sums meet in LDS at the end.
     constexpr int PB = 2, NPX = 16 * PB;                                 // 16-pixel MFMA blocks / pixels per workgroup
     constexpr int LD = 20;                                               // row pitch in floats: conflict-free ds_read_b128
     constexpr int LSZ = (NPX + 2) * LD + 4 * 16;                         // border samples j' = 0..NPX+1 (16 channels) + up to 4 corner samples
-    __shared__ __attribute__((aligned(16))) float smem[4 * LSZ];         // 12 KB (fits next to two 72 KB convolution workgroups): per-wave staging, then the partial sums
+    __shared__ __attribute__((aligned(16))) float smem[RING_NW * LSZ > RING_NW * PB * 64 * 4 ? RING_NW * LSZ : RING_NW * PB * 64 * 4];   // 12 KB at four waves (fits next to two 72 KB convolution workgroups): per-wave staging, then the partial sums
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     float* Ls = smem + wave * LSZ;
     float* Es = Ls + (NPX + 2) * LD;
@@ -592,7 +595,7 @@ __global__ __launch_bounds__(256) void conv_upsampled_ring_kernel(const RingArgs
     const size_t tapstride = (size_t)a.nchunks * ncb16 * 64, chunkstride = (size_t)ncb16 * 64;
     const int col = lane & 15, kg = lane >> 4;
 
-    for (int c = wave; c < a.nchunks; c += 4) {
+    for (int c = wave; c < a.nchunks; c += RING_NW) {
         // all global loads of the chunk first (weights of the three taps, then the four low-resolution texels of each
         // border sample), arithmetic after: the loop is a latency chain, not a throughput problem
         float4 af[3][4];
@@ -698,12 +701,13 @@ __global__ __launch_bounds__(256) void conv_upsampled_ring_kernel(const RingArgs
             for (int blk = 0; blk < PB; ++blk) {
                 sum[blk] = red[blk * 64 + lane];
 #pragma unroll
-                for (int src = 1; src < 4; ++src) sum[blk] += red[(src * PB + blk) * 64 + lane];
+                for (int src = 1; src < RING_NW; ++src) sum[blk] += red[(src * PB + blk) * 64 + lane];
             }
         }
     }
 
     // ---- epilogue: row = cout 4*kg + r of group `wave`, col = pixel blk*16 + col: out = act(pre - correction + bias)
+    if (wave >= 4) return;                                               // waves 0-3 each finish one 16-channel group
     const int co = cblk * 64 + wave * 16 + 4 * kg;
     const float4 bias = a.bias ? *reinterpret_cast<const float4*>(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -775,7 +779,7 @@ extern "C" int cnm_conv3x3_upsampled_ring_c4_f32(const float* in, int Gin_total,
     a.nchunks = (4 * Gin + 15) / 16; a.relu = relu;
     a.nrow = cnm_ceil_div(2 * W, 32); a.ncol = cnm_ceil_div(2 * H - 2, 32);              // 32-pixel blocks (conv_upsampled_ring_kernel NPX)
     const int nblocks = N * (2 * a.nrow + 2 * a.ncol) * (Cout / 64);
-    conv_upsampled_ring_kernel<false><<<nblocks, 256, 0, cnm_stream(stream)>>>(a);
+    conv_upsampled_ring_kernel<false><<<nblocks, 64 * RING_NW, 0, cnm_stream(stream)>>>(a);
     CNM_LAUNCH_CHECK();
     return CNM_OK;
 }
@@ -794,7 +798,7 @@ extern "C" int cnm_conv3x3_upsampled_ring_c8_f16(const void* in, int Gin_total, 
     a.nchunks = (8 * Gin + 15) / 16; a.relu = relu;
     a.nrow = cnm_ceil_div(2 * W, 32); a.ncol = cnm_ceil_div(2 * H - 2, 32);
     const int nblocks = N * (2 * a.nrow + 2 * a.ncol) * (Cout / 64);
-    conv_upsampled_ring_kernel<true><<<nblocks, 256, 0, cnm_stream(stream)>>>(a);
+    conv_upsampled_ring_kernel<true><<<nblocks, 64 * RING_NW, 0, cnm_stream(stream)>>>(a);
     CNM_LAUNCH_CHECK();
     return CNM_OK;
 }

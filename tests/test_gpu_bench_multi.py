@@ -157,3 +157,16 @@ def test_two_rank_f16_line():
     _check_line(r, world=2, frames=8)
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert d["dtype"].startswith("f16") and d["config"]["frames_per_gpu"] == 8
+
+
+def test_bench_graph_mode_with_roofline():
+    """`python bench.py --graph` with the roofline on (the path that died of an UnboundLocalError): one GPU, the step replayed as
+    a HIP graph, the line carries the roofline objects and the store policy the graph was captured with."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--graph", "--steps", "3", "--warmup", "1", "--no-secondary", "--no-cpu-baseline", "--no-live-traffic"]
+    env = _clean_env()
+    env.pop("CNM_BENCH_BACKEND", None); env.pop("CNM_BENCH_DEVICE", None)
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, _why(r)
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["roofline"]["bound"] == "mfma" and d["roofline_planesweep"]["bound"] == "hbm"
+    assert d["roofline_planesweep"]["store_policy"]["in_force"] in ("plain", "nt") and "Graph" in d["config"]["launch"]

@@ -222,6 +222,40 @@ def test_pack_winograd4_dgrad_equals_flipped_pack(dev, cout, cin, k):
     assert a.shape == b.shape and torch.equal(a, b)
 
 
+def test_pack_plan_batches_the_step_s_filter_packs(dev):
+    """[r6] autograd.PackPlan: the 3x3 filter packs a step asks for (forward and data-gradient form), recorded once, then computed by ONE
+    cnm_pack_winograd4_batch_f32 launch when the step scope opens -- bit-identical to the single-filter calls, handed out through the
+    step's pack cache, re-recorded when a parameter's storage moves."""
+    from cnmnet_amd import ops, autograd as ag
+    from cnmnet_amd.trainer import _step_scope
+    rng = np.random.default_rng(11)
+    ws = [torch.nn.Parameter(T((rng.standard_normal(sh) * 0.1).astype(np.float32)).to(dev)) for sh in ((128, 64, 3, 3), (64, 67, 3, 3), (256, 128, 3, 3), (128, 128, 5, 5))]
+    want = lambda: [(ops.pack_winograd4(ws[0], None, 0), ops.pack_winograd4(ws[1], None, 3), ops.pack_winograd4_dgrad(ws[2]), ops.pack_winograd4_dgrad(ws[0]))]
+    ask = lambda: [ag._packed("u4", ws[0], 0, 1, lambda: ops.pack_winograd4(ws[0], None, 0)), ag._packed("u4", ws[1], 3, 1, lambda: ops.pack_winograd4(ws[1], None, 3)),
+                   ag._packed("u4d", ws[2], 0, 1, lambda: ops.pack_winograd4_dgrad(ws[2])), ag._packed("u4d", ws[0], 0, 1, lambda: ops.pack_winograd4_dgrad(ws[0])),
+                   ag._packed("u4", ws[3], 0, 1, lambda: ops.pack_winograd4(ws[3], None, 0))]          # 5x5: not batched, packed the old way
+    plan = ag.PackPlan()
+    with _step_scope(plan):
+        first = ask()
+    assert plan.table is not None and len(plan.requests) == 4
+    for step in range(2):
+        with torch.no_grad():
+            for w in ws:
+                w.add_(0.01)                                              # optimizer.step(): new values, same storage, version bumped
+        with _step_scope(plan):
+            got = ask()
+            assert all(g.data_ptr() == o.data_ptr() for g, o in zip(got[:4], plan.outs))      # served from the batched launch
+        ref = want()[0]
+        assert all(torch.equal(g, r) for g, r in zip(got[:4], ref)) and torch.equal(got[4], ops.pack_winograd4(ws[3], None, 0))
+    ws[1].data = ws[1].data.clone()                                       # the parameter's storage moved: the plan starts over
+    with _step_scope(plan):
+        got = ask()
+    assert plan.table is not None and all(torch.equal(g, r) for g, r in zip(got[:4], want()[0]))
+    with _step_scope(plan):
+        got = ask()
+        assert got[1].data_ptr() == plan.outs[1].data_ptr()
+
+
 @pytest.mark.parametrize("relu", [True, False])
 @pytest.mark.parametrize("C,N,H,W,S", [(128, 4, 12, 20, 2), (67, 3, 8, 8, 1), (256, 2, 24, 32, 1), (64, 6, 8, 12, 3)])
 def test_batchnorm_backward_recomputed_mask_is_bit_identical(dev, C, N, H, W, S, relu):
