@@ -43,6 +43,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_32x32x2_f32)
 WINO4_MIN_WORKGROUPS = 384     # include/cnm_engine.h CNM_WINO4_MIN_WORKGROUPS (executor's F(4x4,3x3) / F(2x2,3x3) switch)
 UPSAMPLED_MIN_PIXELS = 196608   # include/cnm_engine.h CNM_UPSAMPLED_MIN_PIXELS (executor's fused upsample + conv switch for up_conv layers)
+UPSAMPLED_MIN_PIXELS_F16 = 262144   # ... CNM_UPSAMPLED_MIN_PIXELS_F16: the fp16 engine's
 DEPTH_LEVEL = [0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 4, 4, 3, 3, 2, 2, 1, 1, 0, 0]      # input resolution level per conv layer
 REFINE_LEVEL = [0, 0, 1, 1, 2, 2, 2, 2, 1, 1, 0, 0, 2, 2, 1, 1, 0, 0]
 
@@ -579,7 +580,7 @@ def f16_roofline(dev, frames):
             wt = torch.randn(L["Cout"], cin, k, k, device=dev) * 0.02
             flop = 2.0 * L["Cout"] * cin * k * k * ho * wo * n_img
             g8 = (cin + 7) // 8
-            if L["conv_key"].startswith("upconv") and cin <= 256 and n_img * ho * wo >= UPSAMPLED_MIN_PIXELS:
+            if L["conv_key"].startswith("upconv") and cin <= 256 and n_img * ho * wo >= UPSAMPLED_MIN_PIXELS_F16:
                 xl = ops.nchw_to_c8(torch.randn(n_img, cin, h // 2, w // 2, device=dev))
                 wp, bp, wr = ops.pack_upsampled_f16(wt)
                 ms = event_ms(lambda: ops.conv3x3_upsampled_c8(xl, wp, bp, L["Cout"], True, wr), iters=IT, warm=WARM)

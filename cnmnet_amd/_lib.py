@@ -46,6 +46,7 @@ PROTOTYPES = {
     "cnm_tune_wino4_min_workgroups": (c_i, [c_i]),
     "cnm_tune_refine_side_stream": (c_i, [c_i]),
     "cnm_tune_upsampled_min_pixels": (c_i, [c_i]),
+    "cnm_tune_upsampled_min_pixels_f16": (c_i, [c_i]),
     "cnm_tune_glds_tile": (c_i, [c_i]),
     "cnm_tune_wino36_staged": (c_i, [c_i]),
     "cnm_tune_rows_wide": (c_i, [c_i]),

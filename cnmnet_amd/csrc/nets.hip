@@ -126,6 +126,10 @@ static SideStream* side_stream() {
 // up_conv layers: one fused pass over the low-resolution input when the upsampled tensor is big and the ring is cheap
 static int g_upsampled_min_pixels = CNM_UPSAMPLED_MIN_PIXELS;
 extern "C" int cnm_tune_upsampled_min_pixels(int n) { const int old = g_upsampled_min_pixels; if (n > 0) g_upsampled_min_pixels = n; return old; }
+// [r6] the fp16 engine's own threshold: depthNet's upconv2 (256 -> 128 channels, 16 x 96 x 128 output pixels) is faster UNFUSED there (upsample + the
+// row-extended implicit GEMM: 0.166 against 0.199 ms; bench step 1863-1867 against 1843-1855 frames/s, tools/ups_threshold_ab.sh); the fp32 engine is indifferent
+static int g_upsampled_min_pixels_f16 = CNM_UPSAMPLED_MIN_PIXELS_F16;
+extern "C" int cnm_tune_upsampled_min_pixels_f16(int n) { const int old = g_upsampled_min_pixels_f16; if (n > 0) g_upsampled_min_pixels_f16 = n; return old; }
 
 struct EngF32 {
     static constexpr int GD = 4;
@@ -190,7 +194,7 @@ struct EngF16 {
     static constexpr bool HOST = false;
     static int homography(const float* rc, const float* sc, float* hmkt, int B, int S, void* s) { return cnm_homography_terms_f32(rc, sc, hmkt, B, S, s); }
     static int upconv(const float* in, int G, float* up_tmp, float* out, int Gto, int go0, int Cout, const cnm_layer_weights& w, int N, int H, int W, float* sync, void* s) {
-        if (w.uu && w.bu && w.wr && G * 8 <= 256 && (long long)N * 4 * H * W >= g_upsampled_min_pixels) {   // one fused pass over the low-resolution input + ring pass
+        if (w.uu && w.bu && w.wr && G * 8 <= 256 && (long long)N * 4 * H * W >= g_upsampled_min_pixels_f16) {   // one fused pass over the low-resolution input + ring pass
             const int e = cnm_conv3x3_upsampled_c8_f16(in, G, 0, G, out, Gto, go0, Cout, w.uu, w.bu, N, H, W, 1, 1, s);
             return e != CNM_OK ? e : cnm_conv3x3_upsampled_ring_c8_f16(in, G, 0, G, out, Gto, go0, Cout, w.wr, w.b, N, H, W, 1, s);
         }

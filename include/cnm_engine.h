@@ -45,6 +45,7 @@ extern "C" {
                                                does); _cpu host twins, cnm_engine_status, cnm_tune_sync_spin_limit exported since 4 */
 #define CNM_WINO4_MIN_WORKGROUPS 384
 #define CNM_UPSAMPLED_MIN_PIXELS 196608      /* 16 images x 96 x 128 */
+#define CNM_UPSAMPLED_MIN_PIXELS_F16 262144  /* [r6] the fp16 engine fuses from MORE output pixels on: 16 x 96 x 128 runs unfused there */
 /* Engine status.  The persistent stream-K convolution kernels hand partial outputs from one workgroup to another inside a
  * launch; a hand-off that does not complete within its spin bound (it cannot, unless workgroups of one launch are not
  * co-resident for seconds) does not hang and does not pass silently: the kernel records it in a pinned host word, the
@@ -74,6 +75,7 @@ int cnm_tune_refine_side_stream(int on);
  *   pixels over the batch and at most 256 input channels -- below that the ring pass costs more than the upsampled
  *   tensor's round trip; n <= 0 only queries, INT_MAX switches the fused path off. */
 int cnm_tune_upsampled_min_pixels(int n);
+int cnm_tune_upsampled_min_pixels_f16(int n);   /* [r6] the same switch of the fp16 engine (default CNM_UPSAMPLED_MIN_PIXELS_F16) */
 /* glds_tile: tile (couts x pixels) of the LDS-DMA implicit-GEMM kernel: 0 (default) = chosen per layer from its
  *   workgroup count, stride and reduction depth; 1 .. 5 force 128x256 / 64x512 / 64x128 / 128x512 / 256x256 (falling back
  *   to 64x512 when Cout is not a multiple of 128, to 128x256 when 256x256 does not divide it); any other n only queries. */

@@ -204,7 +204,7 @@ def test_f16_fused_upsample_networks_agree(dev):
     lib = _lib.load()
     img, cams = syn.frames(2, 2, 64, 96, seed=31)
     outs = []
-    old = lib.cnm_tune_upsampled_min_pixels(1)
+    old = lib.cnm_tune_upsampled_min_pixels_f16(1)
     try:
         for fused in (True, False):
             net = _load(depthNet(3.0, precision="f16"), 5).to(dev); net.fused_upsample = fused
@@ -215,7 +215,7 @@ def test_f16_fused_upsample_networks_agree(dev):
                 d, p = ref(o1[0], o2[0], f1, f2)
             outs.append([t.float().cpu().numpy() for t in (o1[0], o1[1], d, p)])
     finally:
-        lib.cnm_tune_upsampled_min_pixels(old)
+        lib.cnm_tune_upsampled_min_pixels_f16(old)
     for a, b in zip(*outs):
         assert np.abs(a - b).max() < 4e-2 and np.abs(a - b).mean() < 3e-3, (np.abs(a - b).max(), np.abs(a - b).mean())   # [0, 3] range; two fp16 evaluation orders (measured 2.4e-2 / 1.2e-3)
     assert any(np.abs(a - b).max() > 0 for a, b in zip(*outs))           # the fused path really ran

@@ -33,7 +33,7 @@ def main():
             wt = torch.randn(L["Cout"], cin, k, k, device=dev) * 0.02
             flop = 2.0 * L["Cout"] * cin * k * k * ho * wo * n_img
             g8 = (cin + 7) // 8
-            if L["conv_key"].startswith("upconv") and cin <= 256 and n_img * ho * wo >= bench.UPSAMPLED_MIN_PIXELS:
+            if L["conv_key"].startswith("upconv") and cin <= 256 and n_img * ho * wo >= bench.UPSAMPLED_MIN_PIXELS_F16:
                 xl = ops.nchw_to_c8(torch.randn(n_img, cin, h // 2, w // 2, device=dev))
                 wp, bp, wr = ops.pack_upsampled_f16(wt)
                 ms = bench.event_ms(lambda: ops.conv3x3_upsampled_c8(xl, wp, bp, L["Cout"], True, wr), iters=20, warm=3)
