@@ -42,6 +42,7 @@ PROTOTYPES = {
     "cnm_conv3x3_winograd_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp,
                                           c_i, c_i, c_i, c_i, c_fp]),
     "cnm_engine_status": (c_i, [c_i]),
+    "cnm_debug_sync_generation": (c_i, [c_fp, c_i, c_fp]),
     "cnm_tune_sync_spin_limit": (C.c_uint, [C.c_uint]),
     "cnm_tune_wino4_min_workgroups": (c_i, [c_i]),
     "cnm_tune_refine_side_stream": (c_i, [c_i]),

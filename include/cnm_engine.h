@@ -59,6 +59,10 @@ extern "C" {
  * Replaying a captured hipGraph runs none of these entry points, so nothing refuses there: call cnm_engine_status() after
  * synchronising a replay (cnmnet_amd/trainer.py does at the step's loss read-back, bench.py after its timed region). */
 int cnm_engine_status(int clear);
+/* DEBUG / TEST: writes the hand-off generation the kernels of ONE launch see (the queue's dispatch id, made odd) to out[0 .. nblocks-1],
+ * one value per workgroup of a probe launch on `stream`: the same for every workgroup of a launch, different from launch to launch,
+ * eager or hipGraph replay (tests/test_gpu_parity.py::test_sync_generation_differs_from_launch_to_launch). */
+int cnm_debug_sync_generation(unsigned* out, int nblocks, void* stream);
 /* DEBUG / TEST ONLY: polls before a hand-off gives up (0 = the default, 2^24: about five seconds; looked at every 4096 polls);
  * bit 31 injects the fault the bound exists for (every wait fails at once).  Returns the previous value. */
 unsigned cnm_tune_sync_spin_limit(unsigned polls);
