@@ -423,7 +423,10 @@ def calibrate_sweep_store(device=None, force=False):
         if torch.cuda.is_current_stream_capturing():
             return pol
         _SWEEP_STORE_CALIBRATED.add(idx)
-        scratch = torch.empty(lib.cnm_calibrate_sweep_store_floats(), device="cuda:%d" % idx, dtype=torch.float32)
+        try:
+            scratch = torch.empty(lib.cnm_calibrate_sweep_store_floats(), device="cuda:%d" % idx, dtype=torch.float32)
+        except torch.cuda.OutOfMemoryError:                              # no 630 MB to spare: the default policy (non-temporal) stays, nothing else changes
+            return pol
         rc = lib.cnm_calibrate_sweep_store(_p(scratch), scratch.numel(), _stream(), None)
         del scratch
         if rc < 0:
