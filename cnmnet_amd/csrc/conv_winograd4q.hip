@@ -47,6 +47,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         y0 = (m0) + s1 + s2; y1 = d1 + 2.f * d2; y2 = s1 + 4.f * s2; y3 = d1 + 8.f * d2 + (m5);                 \
     } while (0)
 
+#ifndef WINO4Q_WD
+#define WINO4Q_WD 18          // weight fragments in flight per wave (18: a whole phase ahead)
+#endif
 #ifndef WINO4Q_WRITE_STEP
 #define WINO4Q_WRITE_STEP 12   // double step at which a wave starts moving its six raw pieces (one per step: ds_write_b128, then the re-load two phases ahead)
 #endif
@@ -142,6 +145,34 @@ __global__ __launch_bounds__(256, 1) void conv_winograd36q_f32_kernel(const Wino
         if (ABL & 2) return;
         *reinterpret_cast<u32x4*>(smem + RAW0 + buf * RAWBUF + (m / 3) * PLANE1 + lslot[m % 3]) = rawr[m];
     };
+    // The same inside the phase loop, with everything that is not a memory instruction hoisted to the TOP of the phase [r6]: the first build
+    // worked out the plane's view, descriptor, scalar offset and validity next to every piece -- ~16 SALU + 2 VALU instructions between two
+    // MFMAs, three times the 32-cycle gap, six times per phase: the raw pieces cost 21 % of the launch (tools/wino36q_ablate.sh).  Per phase now:
+    // eight pinned scalars (descriptor base / size and scalar offset of either plane; an invalid plane is a ZERO-SIZE buffer, so its loads
+    // return zeros without a per-lane select) and three LDS write addresses; a piece is s_waitcnt + ds_write_b128 + buffer_load.
+    unsigned in1_lo = (unsigned)reinterpret_cast<unsigned long long>(a.in), in1_hi = (unsigned)(reinterpret_cast<unsigned long long>(a.in) >> 32);
+    unsigned in2_lo = (unsigned)reinterpret_cast<unsigned long long>(a.in2), in2_hi = (unsigned)(reinterpret_cast<unsigned long long>(a.in2) >> 32);
+    unsigned pq_lo[2], pq_hi[2], pq_bytes[2], pq_soff[2], pq_wa[3];
+    auto phase_scalars = [&](int buf) {                                  // of the phase the load cursor points at (lu, lc, lgp); stores go to RAW[buf]
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int g = 2 * lc + q;
+            const bool s1 = g < a.Gsplit, ok = g < a.Gin && lgp < pe;
+            pq_lo[q] = s1 ? in1_lo : in2_lo; pq_hi[q] = s1 ? in1_hi : in2_hi;
+            pq_bytes[q] = ok ? (s1 ? a.in_bytes : a.in2_bytes) : 0u;
+            pq_soff[q] = (s1 ? lbase1 : lbase2) + (unsigned)g * hw16;
+            asm volatile("" : "+s"(pq_lo[q]), "+s"(pq_hi[q]), "+s"(pq_bytes[q]), "+s"(pq_soff[q]));
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { pq_wa[j] = lslot[j] + (unsigned)(RAW0 + buf * RAWBUF); asm volatile("" : "+v"(pq_wa[j])); }
+    };
+    auto move_piece = [&](int m) {                                       // piece m: out of its registers into RAW, and the next phase's into the registers
+        if (ABL & 2) return;
+        const int q = m / 3, j = m % 3;
+        *reinterpret_cast<u32x4*>(smem + pq_wa[j] + q * PLANE1) = rawr[m];
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>((unsigned long long)pq_lo[q] | ((unsigned long long)pq_hi[q] << 32)), 0, pq_bytes[q], 0x00020000);
+        rawr[m] = __builtin_amdgcn_raw_buffer_load_b128(rs, lvoff[j], pq_soff[q], 0);
+    };
 
     // ---- transform role: thread = one window (tile tt, channel 4 s + comp of the chunk)
     const int comp = lane & 3, txl = (lane >> 2) & 3, tsl = (lane >> 4) & 1, sel = (lane >> 5) | (wave << 1);
@@ -177,9 +208,11 @@ __global__ __launch_bounds__(256, 1) void conv_winograd36q_f32_kernel(const Wino
     int mcblk = mu / nstrips;
     int part_c0 = mc;
     unsigned a_cur = abase(mcblk, mc);
-    f32x4 af[NP];
+    constexpr int WD = WINO4Q_WD;                                        // weight fragments in flight per wave: the prefetch distance in double steps (divides 18)
+    static_assert(NP % WD == 0, "ring");
+    f32x4 af[WD];
 #pragma unroll
-    for (int s = 0; s < NP; ++s) af[s] = (ABL & 4) ? f32x4{1.f, 0.5f, 0.25f, 2.f} : ldA(a_cur + s * 1024);
+    for (int s = 0; s < WD; ++s) af[s] = (ABL & 4) ? f32x4{1.f, 0.5f, 0.25f, 2.f} : ldA(a_cur + s * 1024);
     load_unit();
 #pragma unroll
     for (int m = 0; m < 6; ++m) load_piece(m);
@@ -215,6 +248,7 @@ __global__ __launch_bounds__(256, 1) void conv_winograd36q_f32_kernel(const Wino
         ncblk_ = mcblk;
         if (lastc) ncblk_ = (mu + 1) / nstrips;
         const unsigned a_nxt = p + 1 < P ? (lastc ? abase(ncblk_, 0) : a_cur + (unsigned)(ncb16 * NP) * 1024u) : a_cur;
+        phase_scalars(p & 1);
         f32x4 bq[2][2];                                                  // B fragments: [step parity][point of the pair]
         bq[0][0] = *reinterpret_cast<const f32x4*>(smem + vc); bq[0][1] = *reinterpret_cast<const f32x4*>(smem + vc + 1024);
         __builtin_amdgcn_sched_barrier(0);
@@ -263,14 +297,13 @@ __global__ __launch_bounds__(256, 1) void conv_winograd36q_f32_kernel(const Wino
                                                    if constexpr ((so > sw ? so : sw) == g) tr_write(W_); });
             }
             if constexpr (k == 4 && xp >= 12) {
-                store_piece(xp - 12, p & 1);
-                load_piece(xp - 12);
+                move_piece(xp - 12);
                 if constexpr (xp == 17) load_advance();
             }
         };
         auto step = [&](auto XP_) {
             constexpr int xp = decltype(XP_)::value, x0 = 2 * xp, x1 = x0 + 1;
-            const f32x4 av = af[xp], c0 = bq[xp & 1][0], c1 = bq[xp & 1][1];
+            const f32x4 av = af[xp % WD], c0 = bq[xp & 1][0], c1 = bq[xp & 1][1];
 #define WQ_SLOT(K, X, H, A, B) WQ_MFMA(acc, X, H, A, B); fill(std::integral_constant<int, 8 * xp + K>{}); __builtin_amdgcn_sched_barrier(0)
             WQ_SLOT(0, x0, 0, av[0], c0[0]);
             WQ_SLOT(1, x1, 0, av[2], c1[0]);
@@ -281,7 +314,7 @@ __global__ __launch_bounds__(256, 1) void conv_winograd36q_f32_kernel(const Wino
             WQ_SLOT(6, x0, 1, av[1], c0[3]);
             WQ_MFMA(acc, x1, 1, av[3], c1[3]);
             fill(std::integral_constant<int, 8 * xp + 7>{});
-            if constexpr (!(ABL & 4)) af[xp] = ldA(a_nxt + xp * 1024);
+            if constexpr (!(ABL & 4)) af[xp % WD] = xp + WD < NP ? ldA(a_cur + (xp + WD) * 1024) : ldA(a_nxt + (xp + WD - NP) * 1024);
             __builtin_amdgcn_sched_barrier(0);
 #undef WQ_SLOT
         };

@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 L=cnmnet_amd/lib
 if [ "$1" = build ]; then
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DRING_NW=4 -c cnmnet_amd/csrc/conv_winograd4.hip -o $L/conv_winograd4_nw4.o || exit 1
-  objs=$(ls $L/*.o | grep -v "_abl\|_uabl\|_cblk0.o\|conv_winograd4.o\|_qv\|_cl\|_nw4")
+  objs="$L/planesweep.o $L/conv_mfma.o $L/conv_winograd.o $L/conv_winograd4s.o $L/conv_winograd4q.o $L/conv_winograd_rows.o $L/conv_rows_staged.o $L/pointwise.o $L/geometry.o $L/nets.o $L/train_ops.o $L/half_ops.o $L/host_twins.o"
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread $objs $L/conv_winograd4_nw4.o -o $L/libcnm_engine_nw4.so && echo built
   exit
 fi

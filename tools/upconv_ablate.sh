@@ -8,7 +8,7 @@ L=cnmnet_amd/lib
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -mllvm -greedy-regclass-priority-trumps-globalness=1 -mllvm -disable-machine-licm"
 if [ "$1" = build ]; then
   /opt/rocm/bin/hipcc $F -DWINO4S_ABLATE -c cnmnet_amd/csrc/conv_winograd4s.hip -o $L/conv_winograd4s_uabl.o || exit 1
-  objs=$(ls $L/*.o | grep -v "_abl\|_uabl\|_cblk0.o\|conv_winograd4s.o\|_qv\|_cl")
+  objs="$L/planesweep.o $L/conv_mfma.o $L/conv_winograd.o $L/conv_winograd4.o $L/conv_winograd4q.o $L/conv_winograd_rows.o $L/conv_rows_staged.o $L/pointwise.o $L/geometry.o $L/nets.o $L/train_ops.o $L/half_ops.o $L/host_twins.o"
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread $objs $L/conv_winograd4s_uabl.o -o $L/libcnm_engine_uabl.so && echo built
   exit
 fi

@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 L=cnmnet_amd/lib
 if [ "$1" = build ]; then
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DWINO4Q_ABLATE $WQ_FLAGS -c cnmnet_amd/csrc/conv_winograd4q.hip -o $L/conv_winograd4q_abl.o || exit 1
-  objs=$(ls $L/*.o | grep -v "_abl.o\|_cblk0.o\|conv_winograd4q.o")
+  objs="$L/planesweep.o $L/conv_mfma.o $L/conv_winograd.o $L/conv_winograd4.o $L/conv_winograd4s.o $L/conv_winograd_rows.o $L/conv_rows_staged.o $L/pointwise.o $L/geometry.o $L/nets.o $L/train_ops.o $L/half_ops.o $L/host_twins.o"
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread $objs $L/conv_winograd4q_abl.o -o $L/libcnm_engine_qabl.so && echo built $L/libcnm_engine_qabl.so
   exit
 fi

@@ -7,7 +7,7 @@ L=cnmnet_amd/lib
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -mllvm -greedy-regclass-priority-trumps-globalness=1 -mllvm -disable-machine-licm"
 VARIANTS=("-DWINO4S_CLUMP=1" "-DWINO4S_CLUMP=1 -DWINO4S_CLUMP_A=5 -DWINO4S_CLUMP_B=11" "-DWINO4S_CLUMP=1 -DWINO4S_CLUMP_A=3 -DWINO4S_CLUMP_B=9")
 if [ "$1" = build ]; then
-  objs=$(ls $L/*.o | grep -v "_abl\|_cblk0.o\|conv_winograd4s.o\|_qv\|_cl")
+  objs="$L/planesweep.o $L/conv_mfma.o $L/conv_winograd.o $L/conv_winograd4.o $L/conv_winograd4q.o $L/conv_winograd_rows.o $L/conv_rows_staged.o $L/pointwise.o $L/geometry.o $L/nets.o $L/train_ops.o $L/half_ops.o $L/host_twins.o"
   i=0
   for v in "${VARIANTS[@]}"; do
     /opt/rocm/bin/hipcc $F $v -Rpass-analysis=kernel-resource-usage -c cnmnet_amd/csrc/conv_winograd4s.hip -o $L/conv_winograd4s_cl$i.o 2> /tmp/cl$i.log &
