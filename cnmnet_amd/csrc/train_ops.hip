@@ -4,9 +4,11 @@
 //   adjoint of the bilinear x2 upsample.
 // The plane sweep needs no backward: images and cameras carry no gradient.
 #include "cnm_common.h"
+#include "sync_ws.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float4 tr_buffer_load_f4(const float* base, unsigned bytes, unsigned voff) {
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes, 0x00020000);
@@ -25,23 +27,27 @@ struct WgradArgs {
     int ks, stride, pad, Kflat, Kpad128, M, pix_per_split;
     int per_image_splits;           // 0: one reduction over all N*Ho*Wo pixels, split by grid.z.  s > 0: grid.z = problem * s + split -- every group of
                                     // `ipp` images is a problem of its own (the frequency points of the Winograd-domain gradients below), M = ipp*Ho*Wo
+    int N_problems;                 // stream-K form: problems (frequency points) of the launch, 1 for the direct gradient
     int ipp, ksx, padx;             // images per problem; taps / padding along x (ks, pad: along y) -- the direct gradient has ksx = ks, padx = pad
 };
 
 // TCO = couts per workgroup: 128 (waves 2 x 2, 64 x 64 each) or 64 (waves 1 x 4, 64 couts x 32 k each) for the 64-cout
 // layers, where a 128-row tile would spend half of its MFMAs on padding rows.
+template <int TCO> struct WgradTile {
+    static constexpr int LDK = 20, WK = TCO == 128 ? 2 : 4, PJ = 4 / WK;   // waves along k, 32-column blocks per wave
+    static constexpr int SMEM_FLOATS = 2 * (TCO + 128) * LDK;
+};
+
+// The reduction of ONE tile (couts c0 .. c0 + TCO, flat k k0 .. k0 + 128) over the pixels r0 .. r1 of problem `zimg`, added into acc.
+// The workgroup's LDS is free again when this returns (it ends on a barrier).
 template <int TCO>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
-    constexpr int LDK = 20, WK = TCO == 128 ? 2 : 4, PJ = 4 / WK;          // waves along k, 32-column blocks per wave
-    __shared__ __attribute__((aligned(16))) float smem[2 * (TCO + 128) * LDK];
+__device__ __forceinline__ void wgrad_tile_segment(const WgradArgs& a, float* smem, int c0, int k0, int zimg, int r0, int r1,
+                                                   f32x16 (&acc)[2][WgradTile<TCO>::PJ]) {
+    constexpr int LDK = WgradTile<TCO>::LDK, WK = WgradTile<TCO>::WK, PJ = WgradTile<TCO>::PJ;
     float* As = smem;                 // [2][TCO co][LDK pix]
     float* Bs = smem + 2 * TCO * LDK; // [2][128 k ][LDK pix]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wc = wave / WK, wp = wave % WK;
-    const int c0 = blockIdx.x * TCO, k0 = blockIdx.y * 128;
     const int HW = a.H * a.W, HoWo = a.Ho * a.Wo;
-    const int zsplit = a.per_image_splits ? (int)blockIdx.z % a.per_image_splits : (int)blockIdx.z;
-    const int zimg = a.per_image_splits ? (int)blockIdx.z / a.per_image_splits : 0;
-    const int r0 = zsplit * a.pix_per_split, r1 = min(r0 + a.pix_per_split, a.M);
 
     // loader mapping: float4 slot f = t + i*256 (i = 0,1): pixel lane pl = f % 16, quad row q = f / 16 (0..31)
     const int pl = t & 15;
@@ -59,75 +65,85 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     int m = r0 + pl, img = m / HoWo, rem = m - img * HoWo, oy = rem / a.Wo, ox = rem - oy * a.Wo;
     img += zimg * a.ipp;
 
-    f32x16 acc[2][PJ];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < PJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    float4 ra[2], rb[2];
-    auto load = [&]() {
+    // Operand prefetch TWO steps ahead [r6]: the transformed tensors stream from HBM / the memory-side cache (50-110 MB per layer), and one
+    // 16-pixel step is 2048 matrix-pipe cycles = 0.85 us -- less than a loaded HBM round trip.  Two register sets, by step parity: at the end
+    // of step st the set of step st + 1 goes to LDS and is re-loaded with step st + 3.
+    float4 ra[2][2], rb[2][2];
+    auto load = [&](float4 (&qa)[2], float4 (&qb)[2]) {
         const bool mok = m < r1;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const unsigned offa = (mok && aok[i]) ? ((unsigned)((img * a.Gy_tot + a.gy0 + aq[i]) * HoWo + rem)) * 16u : 0xFFFFFFFFu;
-            ra[i] = tr_buffer_load_f4(a.dy, a.dy_bytes, offa);
+            qa[i] = tr_buffer_load_f4(a.dy, a.dy_bytes, offa);
             const int iy = oy * a.stride - a.pad + bky[i], ix = ox * a.stride - a.padx + bkx[i];
             const bool ok = mok && bok[i] && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
             const unsigned offb = ok ? ((unsigned)((img * a.Gx_tot + a.gx0 + bgc[i]) * HW + iy * a.W + ix)) * 16u : 0xFFFFFFFFu;
-            rb[i] = tr_buffer_load_f4(a.x, a.x_bytes, offb);
+            qb[i] = tr_buffer_load_f4(a.x, a.x_bytes, offb);
         }
         m += 16; ox += 16; rem += 16;
         while (ox >= a.Wo) { ox -= a.Wo; ++oy; }
         while (oy >= a.Ho) { oy -= a.Ho; ++img; rem -= HoWo; }
     };
-    auto store = [&](int buf) {
+    auto store = [&](int buf, const float4 (&qa)[2], const float4 (&qb)[2]) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = 4 * ((t >> 4) + 16 * i);
             if (row < TCO) {
                 float* pa = As + ((size_t)buf * TCO + row) * LDK + pl;
-                pa[0] = ra[i].x; pa[LDK] = ra[i].y; pa[2 * LDK] = ra[i].z; pa[3 * LDK] = ra[i].w;
+                pa[0] = qa[i].x; pa[LDK] = qa[i].y; pa[2 * LDK] = qa[i].z; pa[3 * LDK] = qa[i].w;
             }
             float* pb = Bs + ((size_t)buf * 128 + row) * LDK + pl;
-            pb[0] = rb[i].x; pb[LDK] = rb[i].y; pb[2 * LDK] = rb[i].z; pb[3 * LDK] = rb[i].w;
+            pb[0] = qb[i].x; pb[LDK] = qb[i].y; pb[2 * LDK] = qb[i].z; pb[3 * LDK] = qb[i].w;
         }
     };
     const int nsteps = (r1 - r0 + 15) / 16;
     const int frow = lane & 31, fk = (lane >> 5) * 4;
+    auto compute = [&](int buf) {
+        const float* Ab = As + ((size_t)buf * TCO + wc * 64 + frow) * LDK + fk;
+        const float* Bb = Bs + ((size_t)buf * 128 + wp * 32 * PJ + frow) * LDK + fk;
+#pragma unroll
+        for (int kg = 0; kg < 2; ++kg) {
+            float4 af[2], bf[PJ];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDK + kg * 8);
+#pragma unroll
+            for (int j = 0; j < PJ; ++j) bf[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDK + kg * 8);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < PJ; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+    };
     if (nsteps > 0) {
-        load(); store(0);
+        load(ra[0], rb[0]); store(0, ra[0], rb[0]);                      // step 0 -> LDS
+        if (nsteps > 1) load(ra[1], rb[1]);                              // step 1 (odd set)
+        if (nsteps > 2) load(ra[0], rb[0]);                              // step 2 (even set)
         __syncthreads();
-        for (int st = 0; st < nsteps; ++st) {
-            const int buf = st & 1;
-            if (st + 1 < nsteps) load();
-            const float* Ab = As + ((size_t)buf * TCO + wc * 64 + frow) * LDK + fk;
-            const float* Bb = Bs + ((size_t)buf * 128 + wp * 32 * PJ + frow) * LDK + fk;
-#pragma unroll
-            for (int kg = 0; kg < 2; ++kg) {
-                float4 af[2], bf[PJ];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDK + kg * 8);
-#pragma unroll
-                for (int j = 0; j < PJ; ++j) bf[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDK + kg * 8);
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < PJ; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-                    }
-            }
-            if (st + 1 < nsteps) store(buf ^ 1);
+        for (int st = 0; st < nsteps; st += 2) {
+            compute(0);                                                  // step st (even)
+            if (st + 1 < nsteps) store(1, ra[1], rb[1]);
+            if (st + 3 < nsteps) load(ra[1], rb[1]);
             __syncthreads();
+            if (st + 1 < nsteps) {
+                compute(1);                                              // step st + 1 (odd)
+                if (st + 2 < nsteps) store(0, ra[0], rb[0]);
+                if (st + 4 < nsteps) load(ra[0], rb[0]);
+                __syncthreads();
+            }
         }
     }
-    // partial[split][co][k]: acc row = co, col = k
-    float* P = a.partial + (size_t)blockIdx.z * a.Cout_pad * a.Kpad128;
+}
+
+// out[co][k] of one tile: acc row = co, col = k
+template <int TCO>
+__device__ __forceinline__ void wgrad_tile_store(const WgradArgs& a, float* P, int c0, int k0, const f32x16 (&acc)[2][WgradTile<TCO>::PJ]) {
+    constexpr int WK = WgradTile<TCO>::WK, PJ = WgradTile<TCO>::PJ;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wc = wave / WK, wp = wave % WK;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -139,6 +155,106 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
                 P[(size_t)co * a.Kpad128 + k] = acc[i][j][r];
             }
         }
+}
+
+// Split form: grid.z = pixel ranges (x problems); every workgroup writes its partial tile, a second kernel sums the splits.  Kept for A/B
+// (cnm_tune_wgrad_streamk(0)) and for devices whose sync workspace cannot be had.
+template <int TCO>
+__global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const WgradArgs a) {
+    constexpr int PJ = WgradTile<TCO>::PJ;
+    __shared__ __attribute__((aligned(16))) float smem[WgradTile<TCO>::SMEM_FLOATS];
+    const int c0 = blockIdx.x * TCO, k0 = blockIdx.y * 128;
+    const int zsplit = a.per_image_splits ? (int)blockIdx.z % a.per_image_splits : (int)blockIdx.z;
+    const int zimg = a.per_image_splits ? (int)blockIdx.z / a.per_image_splits : 0;
+    const int r0 = zsplit * a.pix_per_split, r1 = min(r0 + a.pix_per_split, a.M);
+    f32x16 acc[2][PJ];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < PJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    wgrad_tile_segment<TCO>(a, smem, c0, k0, zimg, r0, r1, acc);
+    // partial[split][co][k]
+    wgrad_tile_store<TCO>(a, a.partial + (size_t)blockIdx.z * a.Cout_pad * a.Kpad128, c0, k0, acc);
+}
+
+// [r6] Stream-K form: a PERSISTENT grid of G workgroups (three per CU: what the kernel's registers and LDS allow) shares the flattened
+// (tile, 16-pixel step) space in equal contiguous ranges, so a tile's reduction is cut only where a range boundary falls into it -- at
+// most one partial tile per workgroup travels through memory (G x 64 KB) instead of `splits` partial copies of EVERY tile (134 MB written
+// and read back per layer: 8.6 GB per training step), and there is no second kernel.  A workgroup walks its range from the LAST tile to the
+// first: the part that does not reach its tile's end (the head of a tile whose tail belongs to the next workgroup) comes first and is
+// PUBLISHED at once (sc1 stores into this workgroup's slot, then its flag = the launch's generation, sync_ws.h); the part that holds a
+// tile's end comes last and FINISHES the tile: it waits for the lower-numbered workgroups that hold the tile's earlier parts -- they published
+// at the start of their walk, long ago -- adds their slots in descending workgroup order and stores the tile.  Waits point at lower workgroup
+// numbers only (dispatched earlier), so progress does not depend on all G workgroups being resident; the summation order is a function of
+// (shape, G) alone: bit-reproducible on a device.  A time-out is reported as for the convolution kernels (cnm_engine_status).
+template <int TCO>
+__global__ __launch_bounds__(256, 3) void conv_wgrad_sk_kernel(const WgradArgs a, int tilesC, int tilesK, int S, unsigned* __restrict__ flags, float* __restrict__ slots) {
+    constexpr int PJ = WgradTile<TCO>::PJ, SLOT_FLOATS = TCO * 128;
+    __shared__ __attribute__((aligned(16))) float smem[WgradTile<TCO>::SMEM_FLOATS];
+    const int t = threadIdx.x, g = blockIdx.x, G = gridDim.x;
+    const long long Wtot = (long long)a.N_problems * tilesC * tilesK * S;
+    const auto range_begin = [&](int r) { return Wtot * r / G; };
+    const long long fb = range_begin(g);
+    long long fe = range_begin(g + 1);
+    const auto srsrc = __builtin_amdgcn_make_buffer_rsrc(slots, 0, (unsigned)G * (unsigned)(SLOT_FLOATS * 4), 0x00020000);
+    while (fe > fb) {
+        const long long tile = (fe - 1) / S, t0 = tile * S;
+        const int s1 = (int)(fe - t0), s0 = (int)((fb > t0 ? fb : t0) - t0);
+        const int bx = (int)(tile % tilesC), rest = (int)(tile / tilesC), by = rest % tilesK, z = rest / tilesK;
+        const int c0 = bx * TCO, k0 = by * 128;
+        f32x16 acc[2][PJ];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < PJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        wgrad_tile_segment<TCO>(a, smem, c0, k0, z, s0 * 16, min(s1 * 16, a.M), acc);
+        if (s1 < S) {
+            // ---- publish: [workgroup][(i, j, quad)][thread] float4 -- every lane of the finisher re-reads exactly what its twin wrote
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < PJ; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4v v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&v), srsrc,
+                                                               ((unsigned)g * (unsigned)SLOT_FLOATS + (unsigned)(((i * PJ + j) * 4 + q) * 256 + t) * 4u) * 4u, 0, 16);
+                    }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t == 0) sync_publish(flags, g, sync_generation());
+        } else {
+            if (s0 > 0) {
+                // ---- finish a tile whose earlier parts lie in the ranges g - 1, g - 2, ... down to the one that holds the tile's first step
+                int nsrc = 1;
+                while (range_begin(g - nsrc) > t0) ++nsrc;
+                if (t == 0) {
+                    const unsigned gen = sync_generation();
+                    for (int k = 1; k <= nsrc; ++k) sync_wait(flags, g - k, gen);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
+                __syncthreads();
+                for (int k = 1; k <= nsrc; ++k) {                        // fixed order: own part, then the ranges below in descending order; sc1 loads match the sc1 stores
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < PJ; ++j)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const u32x4 pv = __builtin_amdgcn_raw_buffer_load_b128(srsrc, ((unsigned)(g - k) * (unsigned)SLOT_FLOATS + (unsigned)(((i * PJ + j) * 4 + q) * 256 + t) * 4u) * 4u, 0, 16);
+                                const f32x4v f = *reinterpret_cast<const f32x4v*>(&pv);
+                                acc[i][j][4 * q] += f[0]; acc[i][j][4 * q + 1] += f[1]; acc[i][j][4 * q + 2] += f[2]; acc[i][j][4 * q + 3] += f[3];
+                            }
+                }
+            }
+            wgrad_tile_store<TCO>(a, a.partial + (size_t)z * a.Cout_pad * a.Kpad128, c0, k0, acc);
+        }
+        fe = t0 + s0;
+    }
 }
 
 // One thread per (cout, flat k) of the PADDED partial layout, so the `splits` reads of a wave are contiguous rows (the
@@ -163,6 +279,51 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int split
 static inline int wg_round(int v, int m) { return (v + m - 1) / m * m; }
 
 static inline int wgrad_tco(int Cout) { return wg_round(Cout, 64) % 128 ? 64 : 128; }   // couts per workgroup
+
+// ---- stream-K form (conv_wgrad_sk_kernel): host side
+static int g_wgrad_streamk = 1;                                          // 1: persistent stream-K launch, no split partials (default); 0: the split form + reduction kernels (A/B)
+extern "C" int cnm_tune_wgrad_streamk(int n) { const int old = g_wgrad_streamk; if (n == 0 || n == 1) g_wgrad_streamk = n; return old; }
+static int wgrad_cus() {                                                 // compute units of the current device, queried once per device
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 256; }
+    if (!cus[dev]) { int n = 0; cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256; }
+    return cus[dev];
+}
+// Which launches take the stream-K form: those whose tiles are shared by at most `g_wgrad_sk_share` ranges on average -- the range that
+// finishes a tile adds the other ranges' partial tiles one after the other (sc1 loads from the memory side, a round trip each), so a launch
+// of a few dozen tiles cut into 768 ranges ends on 10-20 serial round trips (tools/wgrad_sk_trace.sh).  0 = no limit.
+static int g_wgrad_sk_share = 8;
+extern "C" int cnm_tune_wgrad_streamk_share(int n) { const int old = g_wgrad_sk_share; if (n >= 0) g_wgrad_sk_share = n; return old; }
+static inline int wgrad_sk_max_ranges();
+static bool wgrad_sk_wanted(const WgradArgs& a, int NP) {
+    if (!g_wgrad_streamk) return false;
+    const int tco = a.Cout_pad % 128 ? 64 : 128;
+    const long long tiles = (long long)NP * (a.Cout_pad / tco) * (a.Kpad128 / 128), S = (a.M + 15) / 16;
+    long long G = wgrad_sk_max_ranges();
+    if (G > tiles * S / 16) G = tiles * S / 16 > 0 ? tiles * S / 16 : 1;
+    return g_wgrad_sk_share == 0 || G <= (long long)g_wgrad_sk_share * tiles;
+}
+static inline int wgrad_sk_max_ranges() { const int g = 3 * wgrad_cus(); return g < kSyncMaxRanges ? g : kSyncMaxRanges; }   // three workgroups per CU: 132 registers, 40 KB of LDS
+// floats of the sync area appended to every weight-gradient workspace: flag words + one 64 KB (TCO = 128) partial-tile slot per range
+static inline size_t wgrad_sk_sync_floats() { return kSyncFlagBytes / 4 + (size_t)wgrad_sk_max_ranges() * 128 * 128; }
+// Launch the persistent form over `NP` problems; out = [NP][Cout_pad][Kpad128] (the split form's layout with one split).  `sync` = the
+// workspace's sync area; its flag words must be zero (zero_flags: a memset node here -- the Winograd paths let their transform kernel do it).
+static int wgrad_sk_launch(WgradArgs a, int NP, float* sync, bool zero_flags, hipStream_t s) {
+    const int tco = wgrad_tco(a.Cout), tilesC = a.Cout_pad / tco, tilesK = a.Kpad128 / 128, S = (a.M + 15) / 16;
+    const long long Wtot = (long long)NP * tilesC * tilesK * S;
+    long long G = wgrad_sk_max_ranges();
+    if (G > Wtot / 16) G = Wtot / 16 > 0 ? Wtot / 16 : 1;                // at least 16 steps (256 pixels) per range
+    a.N_problems = NP;
+    sync_ctl_upload(s);
+    if (cnm_sync_failed()) return CNM_ERR_LAUNCH;                        // an earlier hand-off timed out: refuse until cnm_engine_status(1) has acknowledged it
+    unsigned* flags = reinterpret_cast<unsigned*>(sync);
+    float* slots = sync + kSyncFlagBytes / 4;
+    if (zero_flags && hipMemsetAsync(flags, 0, kSyncFlagBytes, s) != hipSuccess) { (void)hipGetLastError(); return CNM_ERR_LAUNCH; }
+    if (tco == 128) conv_wgrad_sk_kernel<128><<<(unsigned)G, 256, 0, s>>>(a, tilesC, tilesK, S, flags, slots);
+    else conv_wgrad_sk_kernel<64><<<(unsigned)G, 256, 0, s>>>(a, tilesC, tilesK, S, flags, slots);
+    return CNM_OK;
+}
 static void wgrad_plan(int Cout, int Cin, int ksize, int M, int* Cout_pad, int* Kpad128, int* splits, int* pps) {
     const int tco = wgrad_tco(Cout);
     *Cout_pad = wg_round(Cout, tco);
@@ -180,7 +341,7 @@ extern "C" size_t cnm_conv2d_wgrad_workspace_floats(int Cout, int Cin, int ksize
     if (Cout <= 0 || Cin <= 0 || ksize <= 0 || N <= 0 || Ho <= 0 || Wo <= 0) return 0;
     int cp, kp, sp, pps;
     wgrad_plan(Cout, Cin, ksize, N * Ho * Wo, &cp, &kp, &sp, &pps);
-    return (size_t)sp * cp * kp;
+    return (size_t)sp * cp * kp + wgrad_sk_sync_floats();
 }
 
 extern "C" int cnm_conv2d_wgrad_c4_f32(const float* x, int Gx_total, int gx0, int Cin,
@@ -197,12 +358,16 @@ extern "C" int cnm_conv2d_wgrad_c4_f32(const float* x, int Gx_total, int gx0, in
     a.Kflat = ksize * ksize * 4 * a.Gin; a.M = N * a.Ho * a.Wo;
     int splits;
     wgrad_plan(Cout, Cin, ksize, a.M, &a.Cout_pad, &a.Kpad128, &splits, &a.pix_per_split);
-    a.per_image_splits = 0; a.ipp = 1; a.ksx = a.ks; a.padx = a.pad;
-    CNM_REQUIRE((size_t)splits * a.Cout_pad * a.Kpad128 <= ws_floats, CNM_ERR_WORKSPACE);
+    a.per_image_splits = 0; a.ipp = 1; a.ksx = a.ks; a.padx = a.pad; a.N_problems = 1;
+    CNM_REQUIRE((size_t)splits * a.Cout_pad * a.Kpad128 + wgrad_sk_sync_floats() <= ws_floats, CNM_ERR_WORKSPACE);
     const unsigned long long xb = (unsigned long long)N * Gx_total * H * W * 16ull, yb = (unsigned long long)N * Gy_total * a.Ho * a.Wo * 16ull;
     CNM_REQUIRE(xb < 0xFFFFFFFFull && yb < 0xFFFFFFFFull, CNM_ERR_BAD_ARG);
     a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)yb;
-    if (wgrad_tco(Cout) == 128) conv_wgrad_kernel<128><<<dim3(a.Cout_pad / 128, a.Kpad128 / 128, splits), 256, 0, cnm_stream(stream)>>>(a);
+    if (wgrad_sk_wanted(a, 1)) {
+        const int rc = wgrad_sk_launch(a, 1, ws + (size_t)splits * a.Cout_pad * a.Kpad128, true, cnm_stream(stream));
+        if (rc != CNM_OK) return rc;
+        splits = 1;
+    } else if (wgrad_tco(Cout) == 128) conv_wgrad_kernel<128><<<dim3(a.Cout_pad / 128, a.Kpad128 / 128, splits), 256, 0, cnm_stream(stream)>>>(a);
     else conv_wgrad_kernel<64><<<dim3(a.Cout_pad / 64, a.Kpad128 / 128, splits), 256, 0, cnm_stream(stream)>>>(a);
     const long long total = (long long)Cout * a.Kflat;
     wgrad_reduce_kernel<<<(unsigned)cnm_ceil_div_ll(total, 256), 256, 0, cnm_stream(stream)>>>(
@@ -281,9 +446,11 @@ __device__ __forceinline__ void wg_a6(const wg_f4 (&v)[M], wg_f4 (&o)[6]) {
 }
 template <int M>
 __global__ __launch_bounds__(256) void wino_wgrad_xform_dy_kernel(const float* __restrict__ dy, int Gy_tot, int gy0, int Gout, int N, int H, int W,
-                                                                  int TH, int TW, float* __restrict__ yh) {
+                                                                  int TH, int TW, float* __restrict__ yh, unsigned* __restrict__ zero_flags) {
     const int T = N * TH * TW;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (zero_flags)                                                      // the flag words of the stream-K GEMM that follows on this stream
+        for (long long i = idx; i < (long long)(kSyncFlagBytes / 4); i += (long long)gridDim.x * blockDim.x) zero_flags[i] = 0u;
     if (idx >= (long long)T * Gout) return;
     const int t = (int)(idx % T), g = (int)(idx / T);
     const int n = t / (TH * TW), r = t - n * TH * TW, ty = r / TW, tx = r - ty * TW;
@@ -399,7 +566,7 @@ static size_t wino_wgrad_ws(int Cout, int Cin, int N, int H, int W, int ks) {
     const int Ceff = ph * 4 * ((Cin + 3) / 4);
     int cp, kp, sp, pps;
     wino_wgrad_plan(Cout, Ceff, (int)T, &cp, &kp, &sp, &pps);
-    return 36 * T * (size_t)Ceff + 36 * T * 4 * (size_t)((Cout + 3) / 4) + (size_t)36 * sp * cp * kp + (size_t)36 * Cout * Ceff;
+    return 36 * T * (size_t)Ceff + 36 * T * 4 * (size_t)((Cout + 3) / 4) + (size_t)36 * sp * cp * kp + (size_t)36 * Cout * Ceff + wgrad_sk_sync_floats();
 }
 
 static int wino_wgrad(const float* x, int Gx_total, int gx0, int Cin, const float* dy, int Gy_total, int gy0, int Cout,
@@ -421,17 +588,25 @@ static int wino_wgrad(const float* x, int Gx_total, int gx0, int Cin, const floa
     if (ks == 3) wino_wgrad_xform_x_kernel<4, false><<<nbx, 256, 0, s>>>(x, Gx_total, gx0, Gin, N, Ho, Wo, TH, TW, xh);
     else if (ks == 5) wino_wgrad_xform_x_kernel<4, true><<<nbx, 256, 0, s>>>(x, Gx_total, gx0, Gin, N, Ho, Wo, TH, TW, xh);
     else wino_wgrad_xform_x_kernel<3, true><<<nbx, 256, 0, s>>>(x, Gx_total, gx0, Gin, N, Ho, Wo, TH, TW, xh);
-    if (M == 4) wino_wgrad_xform_dy_kernel<4><<<nby, 256, 0, s>>>(dy, Gy_total, gy0, Gout, N, Ho, Wo, TH, TW, yh);
-    else wino_wgrad_xform_dy_kernel<3><<<nby, 256, 0, s>>>(dy, Gy_total, gy0, Gout, N, Ho, Wo, TH, TW, yh);
     WgradArgs a;
+    int splits;
+    wino_wgrad_plan(Cout, 4 * Geff, T, &a.Cout_pad, &a.Kpad128, &splits, &a.pix_per_split);
+    float* sync = partial + (size_t)36 * splits * a.Cout_pad * a.Kpad128 + (size_t)36 * Cout * 4 * Geff;   // the sync area of the stream-K form: behind everything else
+    a.Cout = Cout; a.M = T;
+    const bool sk = wgrad_sk_wanted(a, 36);
+    unsigned* zf = sk ? reinterpret_cast<unsigned*>(sync) : nullptr;                                        // its flag words are zeroed by the dY transform
+    if (M == 4) wino_wgrad_xform_dy_kernel<4><<<nby, 256, 0, s>>>(dy, Gy_total, gy0, Gout, N, Ho, Wo, TH, TW, yh, zf);
+    else wino_wgrad_xform_dy_kernel<3><<<nby, 256, 0, s>>>(dy, Gy_total, gy0, Gout, N, Ho, Wo, TH, TW, yh, zf);
     a.x = xh; a.dy = yh; a.partial = partial; a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)yb;
     a.N = 36; a.H = 1; a.W = T; a.Ho = 1; a.Wo = T; a.ks = 1; a.stride = 1; a.pad = 0;
     a.Gx_tot = Geff; a.gx0 = 0; a.Gin = Geff; a.Gy_tot = Gout; a.gy0 = 0; a.Cout = Cout;
     a.Kflat = 4 * Geff; a.M = T;
-    int splits;
-    wino_wgrad_plan(Cout, 4 * Geff, T, &a.Cout_pad, &a.Kpad128, &splits, &a.pix_per_split);
-    a.per_image_splits = splits; a.ipp = 1; a.ksx = 1; a.padx = 0;
-    if (wgrad_tco(Cout) == 128) conv_wgrad_kernel<128><<<dim3(a.Cout_pad / 128, a.Kpad128 / 128, 36 * splits), 256, 0, s>>>(a);
+    a.per_image_splits = splits; a.ipp = 1; a.ksx = 1; a.padx = 0; a.N_problems = 36;
+    if (sk) {
+        const int rc = wgrad_sk_launch(a, 36, sync, false, s);
+        if (rc != CNM_OK) return rc;
+        splits = 1;                                                       // the tiles are whole: the fused finishing kernel reads them as one split
+    } else if (wgrad_tco(Cout) == 128) conv_wgrad_kernel<128><<<dim3(a.Cout_pad / 128, a.Kpad128 / 128, 36 * splits), 256, 0, s>>>(a);
     else conv_wgrad_kernel<64><<<dim3(a.Cout_pad / 64, a.Kpad128 / 128, 36 * splits), 256, 0, s>>>(a);
     const unsigned nfin = (unsigned)cnm_ceil_div_ll((long long)Cout * 4 * Geff, 256);
     const int fks = s2 ? ks : 0;
@@ -580,7 +755,7 @@ static size_t wino_rows_ws(int Cout, int Cin, int R, int N, int H, int W) {
     const size_t TW = (size_t)(W + 3) / 4, P = (size_t)N * H * TW, NP = R + 3;
     int cp, kp, sp, pps;
     wino_rows_plan(Cout, Cin, R, (long long)P, &cp, &kp, &sp, &pps);
-    return NP * P * 4 * (size_t)((Cin + 3) / 4) + NP * P * 4 * (size_t)((Cout + 3) / 4) + NP * sp * (size_t)cp * kp + NP * Cout * (size_t)R * 4 * ((Cin + 3) / 4);
+    return NP * P * 4 * (size_t)((Cin + 3) / 4) + NP * P * 4 * (size_t)((Cout + 3) / 4) + NP * sp * (size_t)cp * kp + NP * Cout * (size_t)R * 4 * ((Cin + 3) / 4) + wgrad_sk_sync_floats();
 }
 
 template <int R>
@@ -605,11 +780,15 @@ static int wino_rows_wgrad(const float* x, int Gx_total, int gx0, int Cin, const
     a.Kflat = R * 4 * Gin; a.M = (int)P;
     int splits;
     wino_rows_plan(Cout, Cin, R, P, &a.Cout_pad, &a.Kpad128, &splits, &a.pix_per_split);
-    a.per_image_splits = splits;
-    if (wgrad_tco(Cout) == 128) conv_wgrad_kernel<128><<<dim3(a.Cout_pad / 128, a.Kpad128 / 128, NP * splits), 256, 0, s>>>(a);
-    else conv_wgrad_kernel<64><<<dim3(a.Cout_pad / 64, a.Kpad128 / 128, NP * splits), 256, 0, s>>>(a);
+    a.per_image_splits = splits; a.N_problems = NP;
     float* u = partial + (size_t)NP * splits * a.Cout_pad * a.Kpad128;
     const int KR = R * 4 * Gin;
+    if (wgrad_sk_wanted(a, NP)) {
+        const int rc = wgrad_sk_launch(a, NP, u + (size_t)NP * Cout * KR, true, s);
+        if (rc != CNM_OK) return rc;
+        splits = 1;                                                       // whole tiles: the reduction kernel below only repacks them
+    } else if (wgrad_tco(Cout) == 128) conv_wgrad_kernel<128><<<dim3(a.Cout_pad / 128, a.Kpad128 / 128, NP * splits), 256, 0, s>>>(a);
+    else conv_wgrad_kernel<64><<<dim3(a.Cout_pad / 64, a.Kpad128 / 128, NP * splits), 256, 0, s>>>(a);
     wino_wgrad_reduce_kernel<<<(unsigned)cnm_ceil_div_ll((long long)NP * Cout * KR, 256), 256, 0, s>>>(partial, splits, Cout, a.Cout_pad, KR, a.Kpad128, u, NP);
     wino_wgrad_rows_finish_kernel<R><<<(unsigned)cnm_ceil_div_ll((long long)Cout * KR, 256), 256, 0, s>>>(u, Cout, Cin, rot, dw_oihw);
     CNM_LAUNCH_CHECK();

@@ -593,6 +593,17 @@ int cnm_conv2d_dgrad_c4_f32(const float* dy, int Gy_total, int gy0, int Cout,
  * the pixels as the reduction dimension, split into partial sums (ws) and reduced in fp64.
  * x [N,.,H,W,4] (forward input view), dy [N,.,Ho,Wo,4] -> dw_oihw [Cout,Cin,k,k] (rotation undone). */
 size_t cnm_conv2d_wgrad_workspace_floats(int Cout, int Cin, int ksize, int N, int Ho, int Wo);
+/* [r6] How the pixel reduction of every weight-gradient GEMM below is shared out.  1 (default): stream-K -- ONE persistent launch of three
+ *   workgroups per CU that share the flattened (tile, 16-pixel step) space in equal contiguous ranges; a tile's sum is cut only where a range
+ *   boundary falls into it and the (at most one per workgroup) partial tiles are handed over inside the launch, in a fixed order (results
+ *   are bit-reproducible on a device; a hand-off that times out is reported through cnm_engine_status, as for the convolution kernels).
+ *   0: the earlier split form -- a grid of ~2048 workgroups, every tile's `splits` partial copies written to ws and summed in fp64 by a
+ *   second kernel (134 MB written and read back per layer).  The workspace sizes cover both.  Returns the previous value. */
+int cnm_tune_wgrad_streamk(int n);
+/* ... and which launches take that form: those whose tiles are shared by at most n ranges on average (default 8; 0 = every launch).  The
+ *   range that finishes a tile adds the other ranges' partial tiles one round trip after the other, so a launch of a few dozen tiles cut
+ *   into 768 ranges would end on 10-20 serial round trips; such launches keep the split form.  Returns the previous value. */
+int cnm_tune_wgrad_streamk_share(int n);
 /* The same gradient for a 3x3 stride-1 pad-1 convolution in the Winograd domain of the forward's F(4x4,3x3):
  * dW = G^T [ sum_tiles (A dY A^T) (.) (B^T X B) ] G -- two transform kernels, ONE launch of 36 GEMMs over the tiles (a quarter of
  * the direct gradient's multiplies), a finishing kernel (fp64 split sums, G^T . G, OIHW scatter).  Same arguments as

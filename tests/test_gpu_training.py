@@ -65,6 +65,46 @@ def test_conv_forward_dgrad_wgrad(dev, cin, cout, k, stride, rot, N, H, W):
     assert _rel(wd.grad.cpu().numpy(), w.grad.numpy()) < 5e-5
 
 
+@pytest.mark.parametrize("cin,cout,k,stride,N,H,W", [
+    (256, 512, 3, 1, 8, 48, 64),          # 36 x 4 x 2 tiles of 96 steps: ranges cut most tiles once or twice
+    (64, 64, 3, 1, 4, 96, 128),           # 36 tiles (64-cout form) of 768 steps each: every tile is shared by a dozen ranges
+    (67, 128, 7, 1, 2, 96, 128),          # row-wise F(4,7): 7 x 1 taps, ten problems
+    (128, 256, 5, 1, 2, 48, 64),          # row-wise F(4,5)
+    (64, 128, 5, 2, 2, 48, 64),           # stride 2 on the pixel phases
+    (512, 512, 3, 2, 2, 12, 16),          # the direct gradient (one problem), few steps per tile
+    (36, 64, 3, 1, 2, 30, 46),            # ragged tiles, ragged channel group
+    (16, 64, 3, 1, 1, 8, 8)])             # a launch with a single range
+def test_wgrad_stream_k_equals_split_form(dev, cin, cout, k, stride, N, H, W):
+    """[r6] The persistent stream-K weight-gradient GEMM (one launch, partial tiles handed over in a fixed order) against the split form
+    (partial copies of every tile summed in fp64 by a second kernel): the same gradient to fp32 round-off, bit-identical from run to run,
+    and no hand-off left pending."""
+    from cnmnet_amd import _lib, ops, autograd as ag
+    lib = _lib.load()
+    rng = np.random.default_rng(cin + 5 * k + stride)
+    xd = ops.nchw_to_c4(T(rng.standard_normal((N, cin, H, W)).astype(np.float32)).to(dev))
+    w0 = T((rng.standard_normal((cout, cin, k, k)) * 0.05).astype(np.float32)).to(dev)
+    gy = None
+    def grad():
+        nonlocal gy
+        x = xd.clone().requires_grad_(True); w = w0.clone().requires_grad_(True)
+        y = ag.ConvC4.apply(x, w, stride, 0)
+        if gy is None:
+            gy = torch.from_numpy(rng.standard_normal(tuple(y.shape)).astype(np.float32)).to(dev)
+        y.backward(gy)
+        torch.cuda.synchronize()
+        return w.grad.clone()
+    old, old_share = lib.cnm_tune_wgrad_streamk(1), lib.cnm_tune_wgrad_streamk_share(0)   # share 0: every launch takes the stream-K form, however many ranges share a tile
+    try:
+        a = grad(); b = grad()
+        lib.cnm_tune_wgrad_streamk(0)
+        c = grad()
+    finally:
+        lib.cnm_tune_wgrad_streamk(old); lib.cnm_tune_wgrad_streamk_share(old_share)
+    assert lib.cnm_engine_status(0) == 0
+    assert torch.equal(a, b)                                             # fixed summation order
+    assert _rel(a.cpu().numpy(), c.cpu().numpy()) < 5e-5                 # two fp32 summation orders of the same products (the reference bar of test_conv_forward_dgrad_wgrad)
+
+
 @pytest.mark.parametrize("cin,cout,k,N,Ho,Wo", [(64, 128, 3, 2, 24, 32), (128, 64, 5, 1, 48, 64), (64, 64, 3, 3, 9, 14), (256, 128, 5, 2, 6, 8),
                                                  (128, 128, 7, 2, 48, 64), (64, 32, 7, 1, 10, 31)])
 def test_stride2_dgrad_phase_scatter(dev, cin, cout, k, N, Ho, Wo):

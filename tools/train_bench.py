@@ -7,6 +7,12 @@ import torch
 from cnmnet_amd.depthnet import depthNet, DepthRefineNet
 from cnmnet_amd.trainer import TrainStep, TrainStepWoNormal, synthetic_training_sample
 dev = torch.device("cuda:0")
+if os.environ.get("CNM_WGRAD_STREAMK"):                   # A/B: 0 = the split form of the weight-gradient GEMMs
+    from cnmnet_amd import _lib
+    _lib.load().cnm_tune_wgrad_streamk(int(os.environ["CNM_WGRAD_STREAMK"]))
+if os.environ.get("CNM_WGRAD_SK_SHARE"):
+    from cnmnet_amd import _lib
+    _lib.load().cnm_tune_wgrad_streamk_share(int(os.environ["CNM_WGRAD_SK_SHARE"]))
 torch.manual_seed(0)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 GRAPH, NORMALS = "graph" in sys.argv[2:], "normals" in sys.argv[2:]
