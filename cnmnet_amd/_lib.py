@@ -69,6 +69,7 @@ PROTOTYPES = {
     "cnm_tune_wino36_quad": (c_i, [c_i]),
     "cnm_tune_wgrad_streamk": (c_i, [c_i]),
     "cnm_tune_wgrad_streamk_share": (c_i, [c_i]),
+    "cnm_tune_wgrad_linear": (c_i, [c_i]),
     "cnm_conv3x3_winograd4_sync_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp,
                                                 c_i, c_i, c_i, c_i, c_fp, c_sz, c_fp]),
     "cnm_conv5x5_winograd_sync_c4_f32": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp,

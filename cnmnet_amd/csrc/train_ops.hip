@@ -40,7 +40,11 @@ template <int TCO> struct WgradTile {
 
 // The reduction of ONE tile (couts c0 .. c0 + TCO, flat k k0 .. k0 + 128) over the pixels r0 .. r1 of problem `zimg`, added into acc.
 // The workgroup's LDS is free again when this returns (it ends on a barrier).
-template <int TCO>
+// LINEAR [r6]: the Winograd-domain GEMMs (1 x 1 taps, one "image" of T tiles per frequency point) -- a thread's four operand addresses advance by
+// 256 bytes per step and nothing else, so they are a per-thread constant plus a scalar offset: no vector ALU in the loop (the general walk's
+// coordinates, range checks and address products are ~ 50 VALU instructions per 32 MFMAs and wave, and on this chip an fp32 VALU instruction
+// takes matrix-pipe time from the fp32 MFMAs of every wave on its SIMD: the counters read 1.65 VALU per MFMA at 62 % matrix-pipe busy).
+template <int TCO, bool LINEAR>
 __device__ __forceinline__ void wgrad_tile_segment(const WgradArgs& a, float* smem, int c0, int k0, int zimg, int r0, int r1,
                                                    f32x16 (&acc)[2][WgradTile<TCO>::PJ]) {
     constexpr int LDK = WgradTile<TCO>::LDK, WK = WgradTile<TCO>::WK, PJ = WgradTile<TCO>::PJ;
@@ -69,7 +73,31 @@ __device__ __forceinline__ void wgrad_tile_segment(const WgradArgs& a, float* sm
     // 16-pixel step is 2048 matrix-pipe cycles = 0.85 us -- less than a loaded HBM round trip.  Two register sets, by step parity: at the end
     // of step st the set of step st + 1 goes to LDS and is re-loaded with step st + 3.
     float4 ra[2][2], rb[2][2];
+    // LINEAR: byte offsets of this thread's pixel lane at step 0 of the segment (all-ones: the row is padding -- out of range whatever the scalar
+    // offset adds: raw buffers check the vector offset alone); `lin_step` counts the steps loaded so far
+    unsigned lva[2], lvb[2]; int lin_step = 0;
+    if constexpr (LINEAR) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            lva[i] = aok[i] ? ((unsigned)((zimg * a.Gy_tot + a.gy0 + aq[i]) * HoWo + r0 + pl)) * 16u : 0xFFFFFFFFu;
+            lvb[i] = bok[i] ? ((unsigned)((zimg * a.Gx_tot + a.gx0 + bgc[i]) * HW + r0 + pl)) * 16u : 0xFFFFFFFFu;
+        }
+    }
+    const auto rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, a.dy_bytes, 0x00020000);
+    const auto rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
     auto load = [&](float4 (&qa)[2], float4 (&qb)[2]) {
+        if constexpr (LINEAR) {
+            const int soff = __builtin_amdgcn_readfirstlane(lin_step * 256);
+            const bool mok = r0 + 16 * lin_step + pl < r1;               // only the problem's last, partial step has lanes beyond the last tile (branch-free on purpose: with a
+            ++lin_step;                                                  // scalar branch around a masked twin hipcc put an s_waitcnt vmcnt(0) between the loads of a step)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const u32x4 va = __builtin_amdgcn_raw_buffer_load_b128(rsa, mok ? lva[i] : 0xFFFFFFFFu, soff, 0), vb = __builtin_amdgcn_raw_buffer_load_b128(rsb, mok ? lvb[i] : 0xFFFFFFFFu, soff, 0);
+                qa[i] = make_float4(__uint_as_float(va.x), __uint_as_float(va.y), __uint_as_float(va.z), __uint_as_float(va.w));
+                qb[i] = make_float4(__uint_as_float(vb.x), __uint_as_float(vb.y), __uint_as_float(vb.z), __uint_as_float(vb.w));
+            }
+            return;
+        }
         const bool mok = m < r1;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -120,19 +148,22 @@ __device__ __forceinline__ void wgrad_tile_segment(const WgradArgs& a, float* sm
         }
     };
     if (nsteps > 0) {
+        // every load below is issued UNCONDITIONALLY (steps beyond the segment have all lanes out of range: zeros, no memory access): with
+        // `if (st + 3 < nsteps) load(...)` the number of loads in flight differed between paths and hipcc's s_waitcnt in front of the LDS stores
+        // assumed the smaller one -- vmcnt(3) .. (0) instead of (7) .. (4), i.e. it also waited for the set loaded one step ago
         load(ra[0], rb[0]); store(0, ra[0], rb[0]);                      // step 0 -> LDS
-        if (nsteps > 1) load(ra[1], rb[1]);                              // step 1 (odd set)
-        if (nsteps > 2) load(ra[0], rb[0]);                              // step 2 (even set)
+        load(ra[1], rb[1]);                                              // step 1 (odd set)
+        load(ra[0], rb[0]);                                              // step 2 (even set)
         __syncthreads();
         for (int st = 0; st < nsteps; st += 2) {
             compute(0);                                                  // step st (even)
-            if (st + 1 < nsteps) store(1, ra[1], rb[1]);
-            if (st + 3 < nsteps) load(ra[1], rb[1]);
+            store(1, ra[1], rb[1]);
+            load(ra[1], rb[1]);                                          // step st + 3
             __syncthreads();
             if (st + 1 < nsteps) {
                 compute(1);                                              // step st + 1 (odd)
-                if (st + 2 < nsteps) store(0, ra[0], rb[0]);
-                if (st + 4 < nsteps) load(ra[0], rb[0]);
+                store(0, ra[0], rb[0]);
+                load(ra[0], rb[0]);                                      // step st + 4
                 __syncthreads();
             }
         }
@@ -159,7 +190,7 @@ __device__ __forceinline__ void wgrad_tile_store(const WgradArgs& a, float* P, i
 
 // Split form: grid.z = pixel ranges (x problems); every workgroup writes its partial tile, a second kernel sums the splits.  Kept for A/B
 // (cnm_tune_wgrad_streamk(0)) and for devices whose sync workspace cannot be had.
-template <int TCO>
+template <int TCO, bool LINEAR>
 __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const WgradArgs a) {
     constexpr int PJ = WgradTile<TCO>::PJ;
     __shared__ __attribute__((aligned(16))) float smem[WgradTile<TCO>::SMEM_FLOATS];
@@ -174,7 +205,7 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const WgradArgs a) {
         for (int j = 0; j < PJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    wgrad_tile_segment<TCO>(a, smem, c0, k0, zimg, r0, r1, acc);
+    wgrad_tile_segment<TCO, LINEAR>(a, smem, c0, k0, zimg, r0, r1, acc);
     // partial[split][co][k]
     wgrad_tile_store<TCO>(a, a.partial + (size_t)blockIdx.z * a.Cout_pad * a.Kpad128, c0, k0, acc);
 }
@@ -189,7 +220,7 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const WgradArgs a) {
 // at the start of their walk, long ago -- adds their slots in descending workgroup order and stores the tile.  Waits point at lower workgroup
 // numbers only (dispatched earlier), so progress does not depend on all G workgroups being resident; the summation order is a function of
 // (shape, G) alone: bit-reproducible on a device.  A time-out is reported as for the convolution kernels (cnm_engine_status).
-template <int TCO>
+template <int TCO, bool LINEAR>
 __global__ __launch_bounds__(256, 3) void conv_wgrad_sk_kernel(const WgradArgs a, int tilesC, int tilesK, int S, unsigned* __restrict__ flags, float* __restrict__ slots) {
     constexpr int PJ = WgradTile<TCO>::PJ, SLOT_FLOATS = TCO * 128;
     __shared__ __attribute__((aligned(16))) float smem[WgradTile<TCO>::SMEM_FLOATS];
@@ -211,7 +242,7 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_sk_kernel(const WgradArgs a
             for (int j = 0; j < PJ; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        wgrad_tile_segment<TCO>(a, smem, c0, k0, z, s0 * 16, min(s1 * 16, a.M), acc);
+        wgrad_tile_segment<TCO, LINEAR>(a, smem, c0, k0, z, s0 * 16, min(s1 * 16, a.M), acc);
         if (s1 < S) {
             // ---- publish: [workgroup][(i, j, quad)][thread] float4 -- every lane of the finisher re-reads exactly what its twin wrote
 #pragma unroll
@@ -281,6 +312,8 @@ static inline int wg_round(int v, int m) { return (v + m - 1) / m * m; }
 static inline int wgrad_tco(int Cout) { return wg_round(Cout, 64) % 128 ? 64 : 128; }   // couts per workgroup
 
 // ---- stream-K form (conv_wgrad_sk_kernel): host side
+static int g_wgrad_linear = 1;                                           // 1: the Winograd-domain GEMMs use the scalar-offset loader (default); 0: the general walk (A/B)
+extern "C" int cnm_tune_wgrad_linear(int n) { const int old = g_wgrad_linear; if (n == 0 || n == 1) g_wgrad_linear = n; return old; }
 static int g_wgrad_streamk = 1;                                          // 1: persistent stream-K launch, no split partials (default); 0: the split form + reduction kernels (A/B)
 extern "C" int cnm_tune_wgrad_streamk(int n) { const int old = g_wgrad_streamk; if (n == 0 || n == 1) g_wgrad_streamk = n; return old; }
 static int wgrad_cus() {                                                 // compute units of the current device, queried once per device
@@ -309,6 +342,13 @@ static inline int wgrad_sk_max_ranges() { const int g = 3 * wgrad_cus(); return 
 static inline size_t wgrad_sk_sync_floats() { return kSyncFlagBytes / 4 + (size_t)wgrad_sk_max_ranges() * 128 * 128; }
 // Launch the persistent form over `NP` problems; out = [NP][Cout_pad][Kpad128] (the split form's layout with one split).  `sync` = the
 // workspace's sync area; its flag words must be zero (zero_flags: a memset node here -- the Winograd paths let their transform kernel do it).
+// the Winograd-domain GEMMs: 1 x 1 taps over one row of T tiles per problem -- the loader's addresses are linear in the step
+static inline bool wgrad_linear(const WgradArgs& a) { return a.ks == 1 && a.ksx == 1 && a.H == 1 && a.Ho == 1 && a.W == a.Wo && a.ipp == 1 && a.stride == 1 && a.pad == 0 && a.padx == 0 && g_wgrad_linear; }
+static void wgrad_split_launch(const WgradArgs& a, int tco, dim3 grid, hipStream_t s) {
+    const bool lin = wgrad_linear(a);
+    if (tco == 128) { if (lin) conv_wgrad_kernel<128, true><<<grid, 256, 0, s>>>(a); else conv_wgrad_kernel<128, false><<<grid, 256, 0, s>>>(a); }
+    else { if (lin) conv_wgrad_kernel<64, true><<<grid, 256, 0, s>>>(a); else conv_wgrad_kernel<64, false><<<grid, 256, 0, s>>>(a); }
+}
 static int wgrad_sk_launch(WgradArgs a, int NP, float* sync, bool zero_flags, hipStream_t s) {
     const int tco = wgrad_tco(a.Cout), tilesC = a.Cout_pad / tco, tilesK = a.Kpad128 / 128, S = (a.M + 15) / 16;
     const long long Wtot = (long long)NP * tilesC * tilesK * S;
@@ -320,8 +360,9 @@ static int wgrad_sk_launch(WgradArgs a, int NP, float* sync, bool zero_flags, hi
     unsigned* flags = reinterpret_cast<unsigned*>(sync);
     float* slots = sync + kSyncFlagBytes / 4;
     if (zero_flags && hipMemsetAsync(flags, 0, kSyncFlagBytes, s) != hipSuccess) { (void)hipGetLastError(); return CNM_ERR_LAUNCH; }
-    if (tco == 128) conv_wgrad_sk_kernel<128><<<(unsigned)G, 256, 0, s>>>(a, tilesC, tilesK, S, flags, slots);
-    else conv_wgrad_sk_kernel<64><<<(unsigned)G, 256, 0, s>>>(a, tilesC, tilesK, S, flags, slots);
+    const bool lin = wgrad_linear(a);
+    if (tco == 128) { if (lin) conv_wgrad_sk_kernel<128, true><<<(unsigned)G, 256, 0, s>>>(a, tilesC, tilesK, S, flags, slots); else conv_wgrad_sk_kernel<128, false><<<(unsigned)G, 256, 0, s>>>(a, tilesC, tilesK, S, flags, slots); }
+    else { if (lin) conv_wgrad_sk_kernel<64, true><<<(unsigned)G, 256, 0, s>>>(a, tilesC, tilesK, S, flags, slots); else conv_wgrad_sk_kernel<64, false><<<(unsigned)G, 256, 0, s>>>(a, tilesC, tilesK, S, flags, slots); }
     return CNM_OK;
 }
 static void wgrad_plan(int Cout, int Cin, int ksize, int M, int* Cout_pad, int* Kpad128, int* splits, int* pps) {
@@ -367,8 +408,7 @@ extern "C" int cnm_conv2d_wgrad_c4_f32(const float* x, int Gx_total, int gx0, in
         const int rc = wgrad_sk_launch(a, 1, ws + (size_t)splits * a.Cout_pad * a.Kpad128, true, cnm_stream(stream));
         if (rc != CNM_OK) return rc;
         splits = 1;
-    } else if (wgrad_tco(Cout) == 128) conv_wgrad_kernel<128><<<dim3(a.Cout_pad / 128, a.Kpad128 / 128, splits), 256, 0, cnm_stream(stream)>>>(a);
-    else conv_wgrad_kernel<64><<<dim3(a.Cout_pad / 64, a.Kpad128 / 128, splits), 256, 0, cnm_stream(stream)>>>(a);
+    } else wgrad_split_launch(a, wgrad_tco(Cout), dim3(a.Cout_pad / wgrad_tco(Cout), a.Kpad128 / 128, splits), cnm_stream(stream));
     const long long total = (long long)Cout * a.Kflat;
     wgrad_reduce_kernel<<<(unsigned)cnm_ceil_div_ll(total, 256), 256, 0, cnm_stream(stream)>>>(
         ws, splits, Cout, a.Cout_pad, Cin, ksize, rot, a.Kpad128, dw_oihw);
@@ -606,8 +646,7 @@ static int wino_wgrad(const float* x, int Gx_total, int gx0, int Cin, const floa
         const int rc = wgrad_sk_launch(a, 36, sync, false, s);
         if (rc != CNM_OK) return rc;
         splits = 1;                                                       // the tiles are whole: the fused finishing kernel reads them as one split
-    } else if (wgrad_tco(Cout) == 128) conv_wgrad_kernel<128><<<dim3(a.Cout_pad / 128, a.Kpad128 / 128, 36 * splits), 256, 0, s>>>(a);
-    else conv_wgrad_kernel<64><<<dim3(a.Cout_pad / 64, a.Kpad128 / 128, 36 * splits), 256, 0, s>>>(a);
+    } else wgrad_split_launch(a, wgrad_tco(Cout), dim3(a.Cout_pad / wgrad_tco(Cout), a.Kpad128 / 128, 36 * splits), s);
     const unsigned nfin = (unsigned)cnm_ceil_div_ll((long long)Cout * 4 * Geff, 256);
     const int fks = s2 ? ks : 0;
     const float* src = partial;
@@ -787,8 +826,7 @@ static int wino_rows_wgrad(const float* x, int Gx_total, int gx0, int Cin, const
         const int rc = wgrad_sk_launch(a, NP, u + (size_t)NP * Cout * KR, true, s);
         if (rc != CNM_OK) return rc;
         splits = 1;                                                       // whole tiles: the reduction kernel below only repacks them
-    } else if (wgrad_tco(Cout) == 128) conv_wgrad_kernel<128><<<dim3(a.Cout_pad / 128, a.Kpad128 / 128, NP * splits), 256, 0, s>>>(a);
-    else conv_wgrad_kernel<64><<<dim3(a.Cout_pad / 64, a.Kpad128 / 128, NP * splits), 256, 0, s>>>(a);
+    } else wgrad_split_launch(a, wgrad_tco(Cout), dim3(a.Cout_pad / wgrad_tco(Cout), a.Kpad128 / 128, NP * splits), s);
     wino_wgrad_reduce_kernel<<<(unsigned)cnm_ceil_div_ll((long long)NP * Cout * KR, 256), 256, 0, s>>>(partial, splits, Cout, a.Cout_pad, KR, a.Kpad128, u, NP);
     wino_wgrad_rows_finish_kernel<R><<<(unsigned)cnm_ceil_div_ll((long long)Cout * KR, 256), 256, 0, s>>>(u, Cout, Cin, rot, dw_oihw);
     CNM_LAUNCH_CHECK();

@@ -604,6 +604,10 @@ int cnm_tune_wgrad_streamk(int n);
  *   range that finishes a tile adds the other ranges' partial tiles one round trip after the other, so a launch of a few dozen tiles cut
  *   into 768 ranges would end on 10-20 serial round trips; such launches keep the split form.  Returns the previous value. */
 int cnm_tune_wgrad_streamk_share(int n);
+/* wgrad_linear [r6]: 1 (default) = the Winograd-domain GEMMs (1 x 1 taps over one row of tiles per frequency point) load their operands at a
+ *   per-thread constant offset plus a scalar step offset -- no vector ALU in the loop; 0 = the general coordinate walk (A/B).  Bit-identical results.
+ *   Returns the previous value. */
+int cnm_tune_wgrad_linear(int n);
 /* The same gradient for a 3x3 stride-1 pad-1 convolution in the Winograd domain of the forward's F(4x4,3x3):
  * dW = G^T [ sum_tiles (A dY A^T) (.) (B^T X B) ] G -- two transform kernels, ONE launch of 36 GEMMs over the tiles (a quarter of
  * the direct gradient's multiplies), a finishing kernel (fp64 split sums, G^T . G, OIHW scatter).  Same arguments as

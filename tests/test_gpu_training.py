@@ -96,10 +96,16 @@ def test_wgrad_stream_k_equals_split_form(dev, cin, cout, k, stride, N, H, W):
     old, old_share = lib.cnm_tune_wgrad_streamk(1), lib.cnm_tune_wgrad_streamk_share(0)   # share 0: every launch takes the stream-K form, however many ranges share a tile
     try:
         a = grad(); b = grad()
+        old_lin = lib.cnm_tune_wgrad_linear(0)                           # the general coordinate walk instead of the scalar-offset loader: the same loads
+        try:
+            d = grad()
+        finally:
+            lib.cnm_tune_wgrad_linear(old_lin)
         lib.cnm_tune_wgrad_streamk(0)
         c = grad()
     finally:
         lib.cnm_tune_wgrad_streamk(old); lib.cnm_tune_wgrad_streamk_share(old_share)
+    assert torch.equal(a, d)
     assert lib.cnm_engine_status(0) == 0
     assert torch.equal(a, b)                                             # fixed summation order
     assert _rel(a.cpu().numpy(), c.cpu().numpy()) < 5e-5                 # two fp32 summation orders of the same products (the reference bar of test_conv_forward_dgrad_wgrad)

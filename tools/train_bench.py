@@ -10,6 +10,9 @@ dev = torch.device("cuda:0")
 if os.environ.get("CNM_WGRAD_STREAMK"):                   # A/B: 0 = the split form of the weight-gradient GEMMs
     from cnmnet_amd import _lib
     _lib.load().cnm_tune_wgrad_streamk(int(os.environ["CNM_WGRAD_STREAMK"]))
+if os.environ.get("CNM_WGRAD_LINEAR"):
+    from cnmnet_amd import _lib
+    _lib.load().cnm_tune_wgrad_linear(int(os.environ["CNM_WGRAD_LINEAR"]))
 if os.environ.get("CNM_WGRAD_SK_SHARE"):
     from cnmnet_amd import _lib
     _lib.load().cnm_tune_wgrad_streamk_share(int(os.environ["CNM_WGRAD_SK_SHARE"]))
