@@ -44,6 +44,10 @@ template <int TCO> struct WgradTile {
 // 256 bytes per step and nothing else, so they are a per-thread constant plus a scalar offset: no vector ALU in the loop (the general walk's
 // coordinates, range checks and address products are ~ 50 VALU instructions per 32 MFMAs and wave, and on this chip an fp32 VALU instruction
 // takes matrix-pipe time from the fp32 MFMAs of every wave on its SIMD: the counters read 1.65 VALU per MFMA at 62 % matrix-pipe busy).
+#ifndef WGRAD_ABL
+#define WGRAD_ABL 0      // timing experiments (wrong results; tools/wgrad_ablate.sh): 1 no global loads, 2 no LDS stores, 4 no barriers, 8 no fragment reads
+#endif
+#define WGRAD_SYNC() do { if constexpr ((WGRAD_ABL & 4) == 0) __syncthreads(); } while (0)
 template <int TCO, bool LINEAR>
 __device__ __forceinline__ void wgrad_tile_segment(const WgradArgs& a, float* smem, int c0, int k0, int zimg, int r0, int r1,
                                                    f32x16 (&acc)[2][WgradTile<TCO>::PJ]) {
@@ -56,6 +60,9 @@ __device__ __forceinline__ void wgrad_tile_segment(const WgradArgs& a, float* sm
     // loader mapping: float4 slot f = t + i*256 (i = 0,1): pixel lane pl = f % 16, quad row q = f / 16 (0..31)
     const int pl = t & 15;
     int aq[2], bgc[2], bky[2], bkx[2]; bool bok[2], aok[2];
+#ifdef WGRAD_SAMEDATA   // timing experiment (wrong results): every tile of every problem reads tile (0, 0) of problem 0 -- the operand stream of a launch fits the L2
+    c0 = 0; k0 = 0; zimg = 0;
+#endif
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int q = (t >> 4) + 16 * i;
@@ -86,6 +93,7 @@ __device__ __forceinline__ void wgrad_tile_segment(const WgradArgs& a, float* sm
     const auto rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, a.dy_bytes, 0x00020000);
     const auto rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
     auto load = [&](float4 (&qa)[2], float4 (&qb)[2]) {
+        if constexpr ((WGRAD_ABL & 1) != 0) { asm volatile("" : "+v"(qa[0].x), "+v"(qa[1].x), "+v"(qb[0].x), "+v"(qb[1].x)); return; }
         if constexpr (LINEAR) {
             const int soff = __builtin_amdgcn_readfirstlane(lin_step * 256);
             const bool mok = r0 + 16 * lin_step + pl < r1;               // only the problem's last, partial step has lanes beyond the last tile (branch-free on purpose: with a
@@ -113,6 +121,7 @@ __device__ __forceinline__ void wgrad_tile_segment(const WgradArgs& a, float* sm
         while (oy >= a.Ho) { oy -= a.Ho; ++img; rem -= HoWo; }
     };
     auto store = [&](int buf, const float4 (&qa)[2], const float4 (&qb)[2]) {
+        if constexpr ((WGRAD_ABL & 2) != 0) { asm volatile("" :: "v"(qa[0].x), "v"(qa[1].w), "v"(qb[0].x), "v"(qb[1].w)); return; }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = 4 * ((t >> 4) + 16 * i);
@@ -132,10 +141,17 @@ __device__ __forceinline__ void wgrad_tile_segment(const WgradArgs& a, float* sm
 #pragma unroll
         for (int kg = 0; kg < 2; ++kg) {
             float4 af[2], bf[PJ];
+            if constexpr ((WGRAD_ABL & 8) != 0) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) { af[i] = make_float4(1.f, 2.f, 3.f, 4.f); asm volatile("" : "+v"(af[i].x), "+v"(af[i].y), "+v"(af[i].z), "+v"(af[i].w)); }
+#pragma unroll
+                for (int j = 0; j < PJ; ++j) { bf[j] = make_float4(1.f, 2.f, 3.f, 4.f); asm volatile("" : "+v"(bf[j].x), "+v"(bf[j].y), "+v"(bf[j].z), "+v"(bf[j].w)); }
+            } else {
 #pragma unroll
             for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDK + kg * 8);
 #pragma unroll
             for (int j = 0; j < PJ; ++j) bf[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDK + kg * 8);
+            }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -154,17 +170,17 @@ __device__ __forceinline__ void wgrad_tile_segment(const WgradArgs& a, float* sm
         load(ra[0], rb[0]); store(0, ra[0], rb[0]);                      // step 0 -> LDS
         load(ra[1], rb[1]);                                              // step 1 (odd set)
         load(ra[0], rb[0]);                                              // step 2 (even set)
-        __syncthreads();
+        WGRAD_SYNC();
         for (int st = 0; st < nsteps; st += 2) {
             compute(0);                                                  // step st (even)
             store(1, ra[1], rb[1]);
             load(ra[1], rb[1]);                                          // step st + 3
-            __syncthreads();
+            WGRAD_SYNC();
             if (st + 1 < nsteps) {
                 compute(1);                                              // step st + 1 (odd)
                 store(0, ra[0], rb[0]);
                 load(ra[0], rb[0]);                                      // step st + 4
-                __syncthreads();
+                WGRAD_SYNC();
             }
         }
     }
