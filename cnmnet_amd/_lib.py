@@ -167,6 +167,9 @@ PROTOTYPES = {
     "cnm_masked_l1_workspace_doubles": (c_sz, []),
     "cnm_masked_l1_f32": (c_i, [c_fp, c_fp, c_fp, c_ll, c_fp, c_fp, c_fp]),
     "cnm_masked_l1_backward_f32": (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_ll, c_fp, c_fp, c_fp]),
+    "cnm_normal_cos_workspace_doubles": (c_sz, [c_i]),
+    "cnm_normal_cos_terms_f32": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
+    "cnm_normal_cos_terms_backward_f32": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_fp, c_fp]),
     "cnm_upsample2x_backward_c4_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp]),
     "cnm_depth2normal_f32": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "cnm_plane_normals_f32": (c_i, [c_fp, c_fp, c_fp, c_i, c_fp, c_i, c_i, c_i, c_i, c_fp]),

@@ -520,6 +520,39 @@ class MaskedL1(torch.autograd.Function):
         return dp, None, dw
 
 
+class NormalCosTerms(torch.autograd.Function):
+    """[r6] Per-sample terms of the surface-normal loss (reference losses.py:76-122 as train.py:226-263 uses it): (sum over kept pixels of
+    1 - cos(pred, gt), kept pixels) with kept = valid & finite(gt) & finite(pred) -- trainer.TrainStep._normal_terms as two launches forward and
+    one backward instead of ~40 torch launches per term (three terms per step)."""
+
+    @staticmethod
+    def forward(ctx, pred, gt, valid):
+        pred, gt = pred.contiguous(), gt.contiguous()
+        B, C, H, W = pred.shape
+        assert C == 3 and gt.shape == pred.shape and valid.numel() == B * H * W and valid.dtype == torch.bool
+        valid = valid.contiguous()
+        lib = _lib.load()
+        ws = torch.empty(lib.cnm_normal_cos_workspace_doubles(B), device=pred.device, dtype=torch.float64)
+        s, c = torch.empty(B, device=pred.device, dtype=torch.float32), torch.empty(B, device=pred.device, dtype=torch.float32)
+        with torch.cuda.device(pred.device):
+            _lib.check(lib.cnm_normal_cos_terms_f32(ops._p(pred), ops._p(gt), ops._p(valid), B, H * W, ops._p(ws), ops._p(s), ops._p(c), _s()))
+        ctx.save_for_backward(pred, gt, valid)
+        ctx.mark_non_differentiable(c)
+        return s, c
+
+    @staticmethod
+    def backward(ctx, gs, _gc):
+        pred, gt, valid = ctx.saved_tensors
+        if not ctx.needs_input_grad[0]:
+            return None, None, None
+        B, _, H, W = pred.shape
+        dp = torch.empty_like(pred)
+        gs = gs.contiguous().float()
+        with torch.cuda.device(pred.device):
+            _lib.check(_lib.load().cnm_normal_cos_terms_backward_f32(ops._p(pred), ops._p(gt), ops._p(valid), ops._p(gs), B, H * W, ops._p(dp), _s()))
+        return dp, None, None
+
+
 class SplitSources(torch.autograd.Function):
     """x [B * S, ...] with sample n belonging to source n % S -> S contiguous tensors [B, ...] (depthNet.forward_sources).
     As strided slices x[s::S] every source would cost autograd a zero fill of the whole tensor, a strided copy and an addition;

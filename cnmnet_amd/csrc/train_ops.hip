@@ -1551,6 +1551,77 @@ extern "C" int cnm_masked_l1_backward_f32(const float* pred, const float* gt, co
     return CNM_OK;
 }
 
+// ------------------------------------------------------------------ surface-normal loss terms (surface_normal_loss, losses.py:76-122) [r6]
+// Per sample b: s[b] = sum_keep (1 - cos(pred, gt)),  c[b] = count(keep),  keep = valid && finite(sum_c gt) && finite(sum_c pred);
+// cos as torch.nn.functional.cosine_similarity(dim = 1, eps = 1e-8) on vectors zeroed outside `keep`: (p . g) / (max(|p|, eps) max(|g|, eps)).
+// Two launches, no atomics: block partials in fp64 to fixed slots ([b][block][2]), then one block per sample adds them in block order.
+// pred, gt: [B, 3, HW] planes; valid: [B, HW] bytes (torch bool).  The torch expression of the same thing is ~40 launches per term both ways.
+constexpr int kNrmBlocks = 64;
+__global__ __launch_bounds__(256) void normal_cos_partials_kernel(const float* __restrict__ pred, const float* __restrict__ gt, const unsigned char* __restrict__ valid,
+                                                                  int HW, double* __restrict__ part) {
+    __shared__ double sh[2][4];
+    const int b = blockIdx.y;
+    const float* p = pred + (size_t)b * 3 * HW; const float* g = gt + (size_t)b * 3 * HW; const unsigned char* v = valid + (size_t)b * HW;
+    double s = 0.0, c = 0.0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+        const float px = p[i], py = p[i + HW], pz = p[i + 2 * HW], gx = g[i], gy = g[i + HW], gz = g[i + 2 * HW];
+        if (v[i] && isfinite(px + py + pz) && isfinite(gx + gy + gz)) {
+            const float np = fmaxf(sqrtf(px * px + py * py + pz * pz), 1e-8f), ng = fmaxf(sqrtf(gx * gx + gy * gy + gz * gz), 1e-8f);
+            s += (double)(1.f - (px * gx + py * gy + pz * gz) / (np * ng)); c += 1.0;
+        }
+    }
+    for (int o = 32; o; o >>= 1) { s += __shfl_down(s, o); c += __shfl_down(c, o); }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[0][wave] = s; sh[1][wave] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[((size_t)b * gridDim.x + blockIdx.x) * 2] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+        part[((size_t)b * gridDim.x + blockIdx.x) * 2 + 1] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+    }
+}
+__global__ __launch_bounds__(64) void normal_cos_finish_kernel(const double* __restrict__ part, int nblk, float* __restrict__ s_out, float* __restrict__ c_out) {
+    const int b = blockIdx.x;
+    double s = 0.0, c = 0.0;
+    if ((int)threadIdx.x < nblk) { s = part[((size_t)b * nblk + threadIdx.x) * 2]; c = part[((size_t)b * nblk + threadIdx.x) * 2 + 1]; }   // nblk <= 64: one partial per lane
+    for (int o = 32; o; o >>= 1) { s += __shfl_down(s, o); c += __shfl_down(c, o); }
+    if (threadIdx.x == 0) { s_out[b] = (float)s; c_out[b] = (float)c; }
+}
+// d s[b] / d pred = -(g / (np ng) - (p . g) p / (np^3 ng)) on `keep` (the |p| > eps branch; below it the clamp is constant: -(g / (eps ng))), 0 elsewhere.
+__global__ __launch_bounds__(256) void normal_cos_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ gt, const unsigned char* __restrict__ valid,
+                                                             const float* __restrict__ go, int HW, float* __restrict__ dpred) {
+    const int b = blockIdx.y;
+    const float* p = pred + (size_t)b * 3 * HW; const float* g = gt + (size_t)b * 3 * HW; const unsigned char* v = valid + (size_t)b * HW;
+    float* d = dpred + (size_t)b * 3 * HW;
+    const float k = go[b];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+        const float px = p[i], py = p[i + HW], pz = p[i + 2 * HW], gx = g[i], gy = g[i + HW], gz = g[i + 2 * HW];
+        float dx = 0.f, dy = 0.f, dz = 0.f;
+        if (v[i] && isfinite(px + py + pz) && isfinite(gx + gy + gz)) {
+            const float n2 = px * px + py * py + pz * pz, nrm = sqrtf(n2), np = fmaxf(nrm, 1e-8f), ng = fmaxf(sqrtf(gx * gx + gy * gy + gz * gz), 1e-8f);
+            const float inv = 1.f / (np * ng), dot = px * gx + py * gy + pz * gz;
+            const float t = nrm > 1e-8f ? dot * inv / n2 : 0.f;           // d(1 / max(|p|, eps)) / dp = -p / |p|^3 above eps, 0 below
+            dx = -k * (gx * inv - t * px); dy = -k * (gy * inv - t * py); dz = -k * (gz * inv - t * pz);
+        }
+        d[i] = dx; d[i + HW] = dy; d[i + 2 * HW] = dz;
+    }
+}
+extern "C" size_t cnm_normal_cos_workspace_doubles(int B) { return B > 0 ? (size_t)B * kNrmBlocks * 2 : 0; }
+extern "C" int cnm_normal_cos_terms_f32(const float* pred, const float* gt, const unsigned char* valid, int B, int HW, double* ws, float* s_out, float* c_out, void* stream) {
+    CNM_REQUIRE(pred && gt && valid && ws && s_out && c_out && B > 0 && HW > 0, CNM_ERR_BAD_ARG);
+    const int nblk = (HW + 1023) / 1024 < kNrmBlocks ? (HW + 1023) / 1024 : kNrmBlocks;
+    normal_cos_partials_kernel<<<dim3(nblk, B), 256, 0, cnm_stream(stream)>>>(pred, gt, valid, HW, ws);
+    normal_cos_finish_kernel<<<B, 64, 0, cnm_stream(stream)>>>(ws, nblk, s_out, c_out);
+    CNM_LAUNCH_CHECK();
+    return CNM_OK;
+}
+extern "C" int cnm_normal_cos_terms_backward_f32(const float* pred, const float* gt, const unsigned char* valid, const float* grad_s, int B, int HW, float* dpred, void* stream) {
+    CNM_REQUIRE(pred && gt && valid && grad_s && dpred && B > 0 && HW > 0, CNM_ERR_BAD_ARG);
+    const int nblk = (HW + 1023) / 1024 < 256 ? (HW + 1023) / 1024 : 256;
+    normal_cos_bwd_kernel<<<dim3(nblk, B), 256, 0, cnm_stream(stream)>>>(pred, gt, valid, grad_s, HW, dpred);
+    CNM_LAUNCH_CHECK();
+    return CNM_OK;
+}
+
 // ------------------------------------------------------------------ backward of the disparity head (depth_layer, depthNet_model.py:82-84)
 // d = scale * sigmoid(s),  s = conv3x3(x; w [1,C,3,3], zero padding) + bias  ->  ds = gd * d * (1 - d / scale),
 //   dx[c](p) = sum_k ds(p - (k - 1)) w[c][k],   dw[c][k] = sum_p ds(p) x[c](p + (k - 1)),   dbias = sum_p ds(p).

@@ -53,6 +53,7 @@ class _step_scope:
 # probability decoder during the warm-up epochs, train.py:555-559) is skipped by Adam either way until its first gradient.  With a
 # gradient reducer the buffers stay allocated (its buckets copy from / to them).
 FUSED_MASKED_L1 = os.environ.get("CNM_FUSED_MASKED_L1", "1") != "0"   # the masked mean-L1 loss terms as one HIP launch each way (autograd.MaskedL1)
+FUSED_NORMAL_TERMS = os.environ.get("CNM_FUSED_NORMAL_TERMS", "1") != "0"   # [r6] the surface-normal loss terms as two HIP launches forward, one backward (autograd.NormalCosTerms)
 FUSED_ADAM = os.environ.get("CNM_FUSED_ADAM", "1") != "0"   # torch's single-kernel Adam on GPU parameters (the multi-tensor form otherwise)
 
 
@@ -580,6 +581,9 @@ class TrainStep(TrainStepWoNormal):
     @staticmethod
     def _normal_terms(pred, gt, valid):
         """Per-sample (sum of 1 - cos over the kept pixels, kept-pixel count) of `surface_normal_loss` (losses.py:76-122)."""
+        if FUSED_NORMAL_TERMS and pred.is_cuda and pred.dtype == torch.float32 and gt.dtype == torch.float32:
+            from .autograd import NormalCosTerms
+            return NormalCosTerms.apply(pred, gt.expand_as(pred), valid.expand(pred.shape[0], 1, pred.shape[2], pred.shape[3]))   # two launches forward, one backward
         finite = torch.isfinite(gt.sum(1, keepdim=True)) & torch.isfinite(pred.sum(1, keepdim=True))
         keep = finite & valid
         zero = torch.zeros((), dtype=pred.dtype, device=pred.device)

@@ -714,6 +714,13 @@ size_t cnm_masked_l1_workspace_doubles(void);
 int cnm_masked_l1_f32(const float* pred, const float* gt, const float* weight, long long n, double* zero_ws, float* out2, void* stream);
 int cnm_masked_l1_backward_f32(const float* pred, const float* gt, const float* weight, const float* grad_out, const float* out2,
                                long long n, float* dpred, float* dweight, void* stream);
+/* [r6] Surface-normal loss terms (reference losses.py:76-122, train.py:226-263) per sample: s[b] = sum over kept pixels of 1 - cos(pred, gt),
+ * c[b] = kept pixels; kept = valid && finite(sum_c gt) && finite(sum_c pred); cos as torch's cosine_similarity(dim = 1, eps = 1e-8).
+ * pred, gt [B,3,H,W] fp32, valid [B,H,W] bytes (torch bool), HW = H * W; ws: cnm_normal_cos_workspace_doubles(B) doubles, contents irrelevant.
+ * Two launches forward (fp64 block partials in fixed slots, summed in block order: bit-reproducible), one backward (grad_s [B] -> dpred). */
+size_t cnm_normal_cos_workspace_doubles(int B);
+int cnm_normal_cos_terms_f32(const float* pred, const float* gt, const unsigned char* valid, int B, int HW, double* ws, float* s_out, float* c_out, void* stream);
+int cnm_normal_cos_terms_backward_f32(const float* pred, const float* gt, const unsigned char* valid, const float* grad_s, int B, int HW, float* dpred, void* stream);
 
 /* Backward of cnm_head_sigmoid_c4_f32 -- depth_layer = Conv2d(C, 1, 3, padding = 1) + Sigmoid, times `scale`
  * (depthNet_model.py:82-84, :246): with ds = grad_disp * disp * (1 - disp / scale),

@@ -567,6 +567,41 @@ def test_graph_replay_reports_a_handoff_timeout(dev):
     assert np.isfinite(step(*args)["loss"]) and lib.cnm_engine_status(0) == 0
 
 
+@pytest.mark.parametrize("B,H,W", [(4, 192, 256), (3, 17, 23), (1, 1, 5), (2, 300, 301)])
+def test_normal_cos_terms_kernel_vs_torch_expression(dev, B, H, W):
+    """[r6] cnm_normal_cos_terms_f32 / _backward_f32 (autograd.NormalCosTerms) against the torch expression of the surface-normal loss terms
+    (TrainStep._normal_terms with FUSED_NORMAL_TERMS off; reference losses.py:76-122): per-sample sums and counts, d/d pred; NaN / inf
+    normals in both inputs, invalid pixels, zero vectors, a sample that keeps nothing; bit-identical from run to run."""
+    from cnmnet_amd import trainer
+    g = torch.Generator().manual_seed(B * H + W)
+    pred = torch.randn(B, 3, H, W, generator=g)
+    gt = torch.nn.functional.normalize(torch.randn(B, 3, H, W, generator=g), dim=1)
+    valid = torch.rand(B, 1, H, W, generator=g) > 0.2
+    pred.flatten()[2::17] = float("nan"); pred.flatten()[5::29] = float("inf"); gt.flatten()[3::31] = float("nan")
+    pred[:, :, 0, 0] = 0.0                                              # a zero vector: |p| below eps
+    if B > 1:
+        valid[B - 1] = False                                             # a sample that keeps nothing
+    wts = torch.arange(1, B + 1, dtype=torch.float32) * 0.37
+    res = {}
+    for fused in (True, True, False):
+        trainer.FUSED_NORMAL_TERMS = fused
+        try:
+            p = pred.to(dev).requires_grad_(True)
+            s_, c_ = trainer.TrainStep._normal_terms(p, gt.to(dev), valid.to(dev))
+            (s_ * wts.to(dev)).sum().backward()
+            res.setdefault(fused, []).append((s_.detach().cpu(), c_.detach().cpu(), p.grad.cpu()))
+        finally:
+            trainer.FUSED_NORMAL_TERMS = True
+    (s1, c1, g1), (s1b, c1b, g1b) = res[True]
+    s0, c0, g0 = res[False][0]
+    assert torch.equal(s1, s1b) and torch.equal(c1, c1b) and torch.equal(g1, g1b)
+    assert torch.equal(c1, c0)
+    assert torch.isfinite(s1).all() and float((s1 - s0).abs().max()) <= 2e-6 * max(1.0, float(s0.abs().max())), (s1, s0)
+    assert torch.isfinite(g1).all() and float((g1 - g0).abs().max()) <= 2e-5 * max(1e-6, float(g0.abs().max())), float((g1 - g0).abs().max())
+    if B > 1:
+        assert float(c1[B - 1]) == 0.0 and float(s1[B - 1]) == 0.0 and float(g1[B - 1].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("shape,weighted", [((4, 1, 192, 256), False), ((4, 1, 192, 256), True), ((3, 1, 17, 23), True), ((1, 1, 1, 5), False)])
 def test_masked_l1_kernel_vs_torch_expression(dev, shape, weighted):
     """cnm_masked_l1_f32 / _backward_f32 (autograd.MaskedL1) against the torch expression of losses.py:30-73 the trainer used before
