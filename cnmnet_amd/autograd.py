@@ -520,6 +520,31 @@ class MaskedL1(torch.autograd.Function):
         return dp, None, dw
 
 
+class MaskedL1Both(torch.autograd.Function):
+    """[r6] sum_m |a - b| / max(count(m), 1) with m = a > 0 & finite(a) & b > 0 & finite(b), gradients to BOTH arguments (the warped-depth loss of
+    trainer.get_warped_depth_loss: the refined depth reaches it directly and through the sampling position of the warp).  MaskedL1's two
+    kernels: its mask is symmetric, d / d b = -d / d a, and an empty mask gives 0 with zero gradients instead of the kernel's NaN."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        assert a.shape == b.shape
+        out = torch.empty(2, device=a.device, dtype=torch.float32)
+        with torch.cuda.device(a.device):
+            _lib.check(_lib.load().cnm_masked_l1_f32(ops._p(a), ops._p(b), None, a.numel(), ops._p(_ml1_workspace(a.device)), ops._p(out), _s()))
+        ctx.save_for_backward(a, b, out)
+        return torch.where(out[1] > 0, out[0], torch.zeros((), device=a.device, dtype=torch.float32))
+
+    @staticmethod
+    def backward(ctx, go):
+        a, b, out = ctx.saved_tensors
+        da = torch.empty_like(a)
+        go = go.contiguous().float()
+        with torch.cuda.device(a.device):                                # an empty mask: every element is outside it and gets an exact zero
+            _lib.check(_lib.load().cnm_masked_l1_backward_f32(ops._p(a), ops._p(b), None, ops._p(go), ops._p(out), a.numel(), ops._p(da), None, _s()))
+        return (da if ctx.needs_input_grad[0] else None), (-da if ctx.needs_input_grad[1] else None)
+
+
 class NormalCosTerms(torch.autograd.Function):
     """[r6] Per-sample terms of the surface-normal loss (reference losses.py:76-122 as train.py:226-263 uses it): (sum over kept pixels of
     1 - cos(pred, gt), kept pixels) with kept = valid & finite(gt) & finite(pred) -- trainer.TrainStep._normal_terms as two launches forward and

@@ -567,6 +567,38 @@ def test_graph_replay_reports_a_handoff_timeout(dev):
     assert np.isfinite(step(*args)["loss"]) and lib.cnm_engine_status(0) == 0
 
 
+def test_warped_depth_loss_fused_vs_torch_expression(dev):
+    """[r6] trainer.get_warped_depth_loss on autograd.MaskedL1Both against its torch expression: value and the gradient with respect to the refined
+    depth (directly and through the warp's sampling position), holes in the source depth, non-positive refined depths, and an empty mask
+    (0, zero gradient)."""
+    from cnmnet_amd import trainer
+    sd = trainer.synthetic_training_sample(2, 96, 128, seed=5)
+    cams = sd["cameras"].to(dev)
+    K = cams[:, 0, 1, :3, :3].contiguous(); k_inv = torch.linalg.inv(K)
+    ref_inv = torch.linalg.inv(cams[:, 0, 0])
+    pose = (cams[:, 1, 0] @ ref_inv)[:, :3, :].contiguous()
+    gt_src = sd["depths"][:, 1, 0].to(dev).clone()                      # holes (zeros) in its corner; a NaN here makes the warp's own backward 0 x NaN in either form
+    base = sd["depths"][:, 0, 0].to(dev).clone() * 1.03
+    base.flatten()[11::59] = -1.0                                        # (a non-finite refined depth makes the warp's own backward 0 x inf in either form: not this test's subject)
+    res = {}
+    for fused in (True, False):
+        trainer.FUSED_MASKED_L1 = fused
+        try:
+            d = base.clone().requires_grad_(True)
+            v = trainer.get_warped_depth_loss(d, gt_src, pose, K, k_inv)
+            (v * 1.3).backward()
+            res[fused] = (float(v), d.grad.cpu())
+        finally:
+            trainer.FUSED_MASKED_L1 = True
+    (v1, g1), (v0, g0) = res[True], res[False]
+    assert np.isfinite(v0) and v0 > 0 and abs(v1 - v0) <= 1e-6 * abs(v0), (v1, v0)
+    assert torch.isfinite(g1).all() and float((g1 - g0).abs().max()) <= 1e-5 * float(g0.abs().max())
+    d = base.clone().requires_grad_(True)
+    v = trainer.get_warped_depth_loss(d, torch.zeros_like(gt_src), pose, K, k_inv)   # nothing to sample: empty mask
+    v.backward()
+    assert float(v) == 0.0 and float(d.grad.abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("B,H,W", [(4, 192, 256), (3, 17, 23), (1, 1, 5), (2, 300, 301)])
 def test_normal_cos_terms_kernel_vs_torch_expression(dev, B, H, W):
     """[r6] cnm_normal_cos_terms_f32 / _backward_f32 (autograd.NormalCosTerms) against the torch expression of the surface-normal loss terms
