@@ -137,6 +137,13 @@ PROTOTYPES = {
     "cnm_depthnet_workspace_floats_f16": (c_sz, [c_i, c_i, c_i, c_i]),
     "cnm_depthnet_forward_f16": (c_i, [C.POINTER(LayerWeights), c_f, c_i, c_fp, c_fp, c_fp, c_fp,
                                        c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_sz, c_i, c_i, c_i, c_i, c_fp]),
+    "cnm_depthnet_forward_strided_f32": (c_i, [C.POINTER(LayerWeights), c_f, c_i, c_fp, c_ll, c_fp, c_ll, c_fp, c_ll, c_fp, c_ll,
+                                               c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_sz, c_i, c_i, c_i, c_i, c_fp]),
+    "cnm_depthnet_forward_strided_f16": (c_i, [C.POINTER(LayerWeights), c_f, c_i, c_fp, c_ll, c_fp, c_ll, c_fp, c_ll, c_fp, c_ll,
+                                               c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_sz, c_i, c_i, c_i, c_i, c_fp]),
+    "cnm_homography_terms_strided_f32": (c_i, [c_fp, c_ll, c_fp, c_ll, c_fp, c_i, c_i, c_fp]),
+    "cnm_planesweep_cat_strided_c4_f32": (c_i, [c_fp, c_ll, c_fp, c_ll, c_fp, c_fp, c_fp, c_sz, c_i, c_i, c_i, c_i, c_i, c_d, c_d, c_fp]),
+    "cnm_planesweep_cat_strided_c8_f16": (c_i, [c_fp, c_ll, c_fp, c_ll, c_fp, c_fp, c_fp, c_sz, c_i, c_i, c_i, c_i, c_i, c_d, c_d, c_fp]),
     "cnm_refinenet_forward_multi_f16": (c_i, [C.POINTER(LayerWeights), c_f, c_fp, c_fp, c_i, c_fp, c_fp, c_fp,
                                               c_fp, c_sz, c_i, c_i, c_i, c_fp]),
     "cnm_packed_dgrad_floats": (c_sz, [c_i, c_i, c_i]),

@@ -131,10 +131,18 @@ extern "C" int cnm_tune_upsampled_min_pixels(int n) { const int old = g_upsample
 static int g_upsampled_min_pixels_f16 = CNM_UPSAMPLED_MIN_PIXELS_F16;
 extern "C" int cnm_tune_upsampled_min_pixels_f16(int n) { const int old = g_upsampled_min_pixels_f16; if (n > 0) g_upsampled_min_pixels_f16 = n; return old; }
 
+// [r6] floats between consecutive frames of the four inputs (0 = dense): ref = frames[:, 0], src = frames[:, 1:] of one tensor are read where they lie
+struct InStrides { long long ref, src, ref_cam, src_cam; };
+extern "C" {
+int cnm_homography_terms_strided_f32(const float*, long long, const float*, long long, float*, int, int, void*);
+int cnm_planesweep_cat_strided_c4_f32(const float*, long long, const float*, long long, const float*, float*, float*, size_t, int, int, int, int, int, double, double, void*);
+int cnm_planesweep_cat_strided_c8_f16(const float*, long long, const float*, long long, const float*, void*, float*, size_t, int, int, int, int, int, double, double, void*);
+}
+
 struct EngF32 {
     static constexpr int GD = 4;
     static constexpr bool HOST = false;
-    static int homography(const float* rc, const float* sc, float* hmkt, int B, int S, void* s) { return cnm_homography_terms_f32(rc, sc, hmkt, B, S, s); }
+    static int homography(const float* rc, const float* sc, float* hmkt, int B, int S, void* s, const InStrides& st) { return cnm_homography_terms_strided_f32(rc, st.ref_cam, sc, st.src_cam, hmkt, B, S, s); }
     static int assemble(const float* a, const float* b, long long st, const float* f1, int G1, int g1, const float* f2, int G2, int g2, float* x, int N, int H, int W, void* s) {
         return cnm_refine_assemble_c4_f32(a, b, st, f1, G1, g1, f2, G2, g2, x, N, 64, H, W, s); }
     // nn.Upsample(2, bilinear) + conv3x3 + BN + ReLU (up_conv_layer, depthNet_model.py:89-112): in [N][G][H][W] -> out at 2H x 2W
@@ -185,14 +193,14 @@ struct EngF32 {
     static int head(const float* in, int G, int C, const cnm_layer_weights& w, float scale, float* disp, float* up, int upG, int upg, int N, int H, int W, void* s) {
         return cnm_head_sigmoid_c4_f32(in, G, 0, C, w.w, w.b, scale, disp, up, upG, upg, N, H, W, s); }
     static int assemble_multi(const float* idp, const float* f, float* x, int B, int S, int H, int W, void* s) { return cnm_refine_assemble_multi_c4_f32(idp, f, x, B, S, 64, H, W, s); }
-    static int sweep(const float* ref, const float* src, const float* hmkt, float* x, float* tex, size_t texn, int B, int S, int H, int W, int D, double lo, double hi, void* s) {
-        return cnm_planesweep_cat_c4_f32(ref, src, hmkt, x, tex, texn, B, S, H, W, D, lo, hi, s); }
+    static int sweep(const float* ref, const float* src, const float* hmkt, float* x, float* tex, size_t texn, int B, int S, int H, int W, int D, double lo, double hi, void* s, const InStrides& st) {
+        return cnm_planesweep_cat_strided_c4_f32(ref, st.ref, src, st.src, hmkt, x, tex, texn, B, S, H, W, D, lo, hi, s); }
 };
 
 struct EngF16 {
     static constexpr int GD = 8;
     static constexpr bool HOST = false;
-    static int homography(const float* rc, const float* sc, float* hmkt, int B, int S, void* s) { return cnm_homography_terms_f32(rc, sc, hmkt, B, S, s); }
+    static int homography(const float* rc, const float* sc, float* hmkt, int B, int S, void* s, const InStrides& st) { return cnm_homography_terms_strided_f32(rc, st.ref_cam, sc, st.src_cam, hmkt, B, S, s); }
     static int upconv(const float* in, int G, float* up_tmp, float* out, int Gto, int go0, int Cout, const cnm_layer_weights& w, int N, int H, int W, float* sync, void* s) {
         if (w.uu && w.bu && w.wr && G * 8 <= 256 && (long long)N * 4 * H * W >= g_upsampled_min_pixels_f16) {   // one fused pass over the low-resolution input + ring pass
             const int e = cnm_conv3x3_upsampled_c8_f16(in, G, 0, G, out, Gto, go0, Cout, w.uu, w.bu, N, H, W, 1, 1, s);
@@ -209,8 +217,8 @@ struct EngF16 {
     static int head(const float* in, int G, int C, const cnm_layer_weights& w, float scale, float* disp, float* up, int upG, int upg, int N, int H, int W, void* s) {
         return cnm_head_sigmoid_c8_f16(in, G, 0, C, w.w, w.b, scale, disp, up, upG, upg, N, H, W, s); }
     static int assemble_multi(const float* idp, const float* f, float* x, int B, int S, int H, int W, void* s) { return cnm_refine_assemble_multi_c8_f16(idp, f, x, B, S, 64, H, W, s); }
-    static int sweep(const float* ref, const float* src, const float* hmkt, float* x, float* tex, size_t texn, int B, int S, int H, int W, int D, double lo, double hi, void* s) {
-        return cnm_planesweep_cat_c8_f16(ref, src, hmkt, x, tex, texn, B, S, H, W, D, lo, hi, s); }
+    static int sweep(const float* ref, const float* src, const float* hmkt, float* x, float* tex, size_t texn, int B, int S, int H, int W, int D, double lo, double hi, void* s, const InStrides& st) {
+        return cnm_planesweep_cat_strided_c8_f16(ref, st.ref, src, st.src, hmkt, x, tex, texn, B, S, H, W, D, lo, hi, s); }
 };
 
 // Host twin of the fp32 engine (host_twins.cpp): the same launch sequences on HOST pointers -- direct convolutions with the
@@ -218,7 +226,7 @@ struct EngF16 {
 struct EngHost {
     static constexpr int GD = 4;
     static constexpr bool HOST = true;
-    static int homography(const float* rc, const float* sc, float* hmkt, int B, int S, void*) { return cnmh::homography(rc, sc, hmkt, B, S); }
+    static int homography(const float* rc, const float* sc, float* hmkt, int B, int S, void*, const InStrides&) { return cnmh::homography(rc, sc, hmkt, B, S); }   // dense inputs only
     static int up(const float* in, int G, float* out, int N, int H, int W, void*) { return cnmh::upsample2x(in, G, 0, out, G, 0, N, G, H, W); }
     static int conv(const float* in, int Gt, int g0, int Gin, float* out, int Gto, int go0, int Cout, const cnm_layer_weights& w, int N, int H, int W, int k, int st, float*, void*) {
         return cnmh::conv(in, Gt, g0, Gin, nullptr, 0, 0, 0, out, Gto, go0, Cout, w.w, w.b, N, H, W, k, st, 1); }
@@ -232,7 +240,7 @@ struct EngHost {
     static int assemble(const float* a, const float* b, long long st, const float* f1, int G1, int g1, const float* f2, int G2, int g2, float* x, int N, int H, int W, void*) {
         return cnmh::assemble(a, b, st, f1, G1, g1, f2, G2, g2, x, N, 64, H, W); }
     static int assemble_multi(const float* idp, const float* f, float* x, int B, int S, int H, int W, void*) { return cnmh::assemble_multi(idp, f, x, B, S, 64, H, W); }
-    static int sweep(const float* ref, const float* src, const float* hmkt, float* x, float*, size_t, int B, int S, int H, int W, int D, double lo, double hi, void*) {
+    static int sweep(const float* ref, const float* src, const float* hmkt, float* x, float*, size_t, int B, int S, int H, int W, int D, double lo, double hi, void*, const InStrides&) {
         return cnmh::sweep(ref, src, hmkt, x, B, S, H, W, D, lo, hi, 0); }
 };
 
@@ -302,7 +310,7 @@ template <class E>
 static int depthnet_forward(const cnm_layer_weights* wt, float idepth_scale, int D,
                             const float* ref, const float* src, const float* ref_cam, const float* src_cam,
                             float* disp1, float* disp2, float* disp3, float* disp4, float* iconv1,
-                            float* ws, size_t ws_floats, int B, int S, int H, int W, void* s) {
+                            float* ws, size_t ws_floats, int B, int S, int H, int W, void* s, const InStrides& strides = InStrides{0, 0, 0, 0}) {
     CNM_REQUIRE(wt && ref && src && ref_cam && src_cam && disp1 && disp2 && disp3 && disp4 && iconv1 && ws, CNM_ERR_BAD_ARG);
     CNM_REQUIRE(B > 0 && S > 0 && D >= E::GD && D % E::GD == 0 && D <= 128, CNM_ERR_BAD_ARG);
     CNM_REQUIRE(H > 0 && W > 0 && H % 32 == 0 && W % 32 == 0, CNM_ERR_BAD_SHAPE);
@@ -318,8 +326,8 @@ static int depthnet_forward(const cnm_layer_weights* wt, float idepth_scale, int
 #define CONV(L, in, Gt, g0, Gin, out, Gto, go0, Cout, HH, WW) \
     CNM_TRY(E::conv(in, Gt, g0, Gin, out, Gto, go0, Cout, wt[L], P, HH, WW, kDepthLayers[L].ksize, kDepthLayers[L].stride, b.SYNC, s))
     // geometry + cost volume                                                   depthNet_model.py:228-233
-    CNM_TRY(E::homography(ref_cam, src_cam, b.hmkt, B, S, s));
-    CNM_TRY(E::sweep(ref, src, b.hmkt, b.X0, b.TEX, 4, B, S, H, W, D, idmin, idmax, s));
+    CNM_TRY(E::homography(ref_cam, src_cam, b.hmkt, B, S, s, strides));
+    CNM_TRY(E::sweep(ref, src, b.hmkt, b.X0, b.TEX, 4, B, S, H, W, D, idmin, idmax, s, strides));
     // encoder                                                                  :235-239
     CONV(D_CONV1_0, b.X0, G0, 0, G0, b.A1, g128, 0, 128, H, W);
     CONV(D_CONV1_3, b.A1, g128, 0, g128, b.CAT2, 2 * g128 + 1, g128, 128, H, W);              // conv1 -> skip slot of iconv2
@@ -355,6 +363,26 @@ extern "C" int cnm_depthnet_forward_f32(const cnm_layer_weights* wt, float idept
                                         float* disp1, float* disp2, float* disp3, float* disp4, float* iconv1_c4,
                                         float* ws, size_t ws_floats, int B, int S, int H, int W, void* stream) {
     return depthnet_forward<EngF32>(wt, idepth_scale, D, ref, src, ref_cam, src_cam, disp1, disp2, disp3, disp4, iconv1_c4, ws, ws_floats, B, S, H, W, stream);
+}
+
+// [r6] The same two forwards with the images and cameras as VIEWS of the caller's frame tensors: *_bstride = floats between consecutive frames
+// (0 = dense).  ref = frames[:, 0] / src = frames[:, 1:] of frames [B][1 + S][3][H][W] and the like for cams [B][1 + S][2][4][4] are read where
+// they lie -- the reference slices them the same way (eval.py:440-447) and lets every consumer make its own contiguous copy.
+extern "C" int cnm_depthnet_forward_strided_f32(const cnm_layer_weights* wt, float idepth_scale, int D,
+                                                const float* ref, long long ref_bstride, const float* src, long long src_bstride,
+                                                const float* ref_cam, long long ref_cam_bstride, const float* src_cam, long long src_cam_bstride,
+                                                float* disp1, float* disp2, float* disp3, float* disp4, float* iconv1_c4,
+                                                float* ws, size_t ws_floats, int B, int S, int H, int W, void* stream) {
+    return depthnet_forward<EngF32>(wt, idepth_scale, D, ref, src, ref_cam, src_cam, disp1, disp2, disp3, disp4, iconv1_c4, ws, ws_floats, B, S, H, W, stream,
+                                    InStrides{ref_bstride, src_bstride, ref_cam_bstride, src_cam_bstride});
+}
+extern "C" int cnm_depthnet_forward_strided_f16(const cnm_layer_weights* wt, float idepth_scale, int D,
+                                                const float* ref, long long ref_bstride, const float* src, long long src_bstride,
+                                                const float* ref_cam, long long ref_cam_bstride, const float* src_cam, long long src_cam_bstride,
+                                                float* disp1, float* disp2, float* disp3, float* disp4, void* iconv1_c8,
+                                                float* ws, size_t ws_floats, int B, int S, int H, int W, void* stream) {
+    return depthnet_forward<EngF16>(wt, idepth_scale, D, ref, src, ref_cam, src_cam, disp1, disp2, disp3, disp4, static_cast<float*>(iconv1_c8), ws, ws_floats, B, S, H, W, stream,
+                                    InStrides{ref_bstride, src_bstride, ref_cam_bstride, src_cam_bstride});
 }
 
 extern "C" int cnm_depthnet_forward_f16(const cnm_layer_weights* wt, float idepth_scale, int D,

@@ -53,11 +53,11 @@ __device__ static bool inv_nxn(double* A, double* Ai, int n) {   // Gauss-Jordan
 }
 
 __global__ void homography_terms_kernel(const float* __restrict__ ref_cam, const float* __restrict__ src_cam,
-                                        float* __restrict__ hmkt, int B, int S) {
+                                        float* __restrict__ hmkt, int B, int S, long long rc_bstride, long long sc_bstride) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= B * S) return;
-    const float* lc = ref_cam + (size_t)(p / S) * 32;
-    const float* rc = src_cam + (size_t)p * 32;
+    const float* lc = ref_cam + (size_t)(p / S) * (size_t)rc_bstride;
+    const float* rc = src_cam + (size_t)(p / S) * (size_t)sc_bstride + (size_t)(p % S) * 32;
     double El[16], Eli[16], Kl[9], Kli[9], rel[16];
     for (int i = 0; i < 16; ++i) El[i] = lc[i];
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Kl[i * 3 + j] = lc[16 + i * 4 + j];
@@ -85,7 +85,15 @@ __global__ void homography_terms_kernel(const float* __restrict__ ref_cam, const
 extern "C" int cnm_homography_terms_f32(const float* ref_cam, const float* src_cam, float* hmkt,
                                         int B, int S, void* stream) {
     CNM_REQUIRE(ref_cam && src_cam && hmkt && B > 0 && S > 0, CNM_ERR_BAD_ARG);
-    homography_terms_kernel<<<cnm_ceil_div(B * S, 64), 64, 0, cnm_stream(stream)>>>(ref_cam, src_cam, hmkt, B, S);
+    homography_terms_kernel<<<cnm_ceil_div(B * S, 64), 64, 0, cnm_stream(stream)>>>(ref_cam, src_cam, hmkt, B, S, 32, 32ll * S);
+    CNM_LAUNCH_CHECK();
+    return CNM_OK;
+}
+// [r6] ... with the cameras as views: floats between consecutive frames of ref_cam [B][2][4][4] / src_cam [B][S][2][4][4] (0 = dense)
+extern "C" int cnm_homography_terms_strided_f32(const float* ref_cam, long long rc_bstride, const float* src_cam, long long sc_bstride, float* hmkt,
+                                                int B, int S, void* stream) {
+    CNM_REQUIRE(ref_cam && src_cam && hmkt && B > 0 && S > 0 && (rc_bstride == 0 || rc_bstride >= 32) && (sc_bstride == 0 || sc_bstride >= 32ll * S), CNM_ERR_BAD_ARG);
+    homography_terms_kernel<<<cnm_ceil_div(B * S, 64), 64, 0, cnm_stream(stream)>>>(ref_cam, src_cam, hmkt, B, S, rc_bstride ? rc_bstride : 32, sc_bstride ? sc_bstride : 32ll * S);
     CNM_LAUNCH_CHECK();
     return CNM_OK;
 }
@@ -136,6 +144,7 @@ extern "C" int cnm_idepth_range_host(double idepth_scale, double* idepth_min, do
 
 struct SweepArgs {
     const float* ref; const float* src; const float* hmkt; float* out;
+    long long ref_bstride, src_bstride;   // [r6] floats between consecutive frames of ref [B][3][H][W] / src [B][S][3][H][W] (dense: 3 H W, S 3 H W) -- views of a frame tensor [B][1 + S][3][H][W] need no copy
     unsigned int* queue;            // [0] tile tickets, [1] workgroups that have left; zero between launches
     int B, S, H, W, D;
     // launch constants worked out on the host (sweep_launch): 512 workgroups x 16 waves need not each derive them
@@ -674,10 +683,10 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
         // the reference pixel, negated (the blend's addend): needed at the first blend only, i.e. after the first staging
         float nr = 0.f, ng = 0.f, nb = 0.f;
         if (pvalid) {
-            const float* refp = a.ref + (size_t)(p / a.S) * 3 * HW + (size_t)y * W + x;
+            const float* refp = a.ref + (size_t)(p / a.S) * (size_t)a.ref_bstride + (size_t)y * W + x;
             nr = -refp[0]; ng = -refp[HW]; nb = -refp[2 * HW];
         }
-        const unsigned long long srcb = reinterpret_cast<unsigned long long>(a.src + (size_t)p * 3 * HW);
+        const unsigned long long srcb = reinterpret_cast<unsigned long long>(a.src + (size_t)(p / a.S) * (size_t)a.src_bstride + (size_t)(p % a.S) * 3 * HW);
         const unsigned src_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)srcb);
         const unsigned src_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(srcb >> 32));
 
@@ -1007,8 +1016,9 @@ extern "C" int cnm_decide_sweep_store(int policy, const float* median_us) {
 
 static int sweep_launch(int layout, const float* ref, const float* src, const float* hmkt, float* out,
                         float* ws, size_t ws_floats, int B, int S, int H, int W, int D,
-                        double idepth_min, double idepth_max, void* stream, int force_policy = -1) {
+                        double idepth_min, double idepth_max, void* stream, int force_policy = -1, long long ref_bstride = 0, long long src_bstride = 0) {
     CNM_REQUIRE(ref && src && hmkt && out, CNM_ERR_BAD_ARG);
+    CNM_REQUIRE((ref_bstride == 0 || ref_bstride >= 3ll * H * W) && (src_bstride == 0 || src_bstride >= 3ll * S * H * W), CNM_ERR_BAD_ARG);
     CNM_REQUIRE(ws == nullptr || (((uintptr_t)ws & 15) == 0 && ws_floats >= 4), CNM_ERR_WORKSPACE);
     CNM_REQUIRE(B > 0 && S > 0 && H > 0 && W > 0 && D >= 2 && D <= CNM_MAX_PLANES, CNM_ERR_BAD_ARG);
     CNM_REQUIRE(layout == 0 || D % 4 == 0, CNM_ERR_BAD_ARG);
@@ -1019,6 +1029,7 @@ static int sweep_launch(int layout, const float* ref, const float* src, const fl
     CNM_REQUIRE(ntiles < (1ll << 20), CNM_ERR_BAD_ARG);                      // the kernel decodes tile ids with fp32 reciprocals
     SweepArgs a;
     a.ref = ref; a.src = src; a.hmkt = hmkt; a.out = out;
+    a.ref_bstride = ref_bstride ? ref_bstride : 3ll * H * W; a.src_bstride = src_bstride ? src_bstride : 3ll * S * H * W;
     a.queue = reinterpret_cast<unsigned int*>(ws);
     a.B = B; a.S = S; a.H = H; a.W = W; a.D = D;
     const double idstep = (idepth_max - idepth_min) / (D - 1.0);             // depthNet_model.py:194
@@ -1127,4 +1138,14 @@ extern "C" int cnm_planesweep_cat_c8_f16(const float* ref, const float* src, con
                                          float* ws, size_t ws_floats, int B, int S, int H, int W, int D,
                                          double idepth_min, double idepth_max, void* stream) {
     return sweep_launch(2, ref, src, hmkt, static_cast<float*>(x), ws, ws_floats, B, S, H, W, D, idepth_min, idepth_max, stream);
+}
+// [r6] the same two with the images as VIEWS: ref_bstride / src_bstride = floats between consecutive frames (0 = dense) -- ref = frames[:, 0] and
+// src = frames[:, 1:] of one [B][1 + S][3][H][W] tensor are read where they lie
+extern "C" int cnm_planesweep_cat_strided_c4_f32(const float* ref, long long ref_bstride, const float* src, long long src_bstride, const float* hmkt, float* x,
+                                                 float* ws, size_t ws_floats, int B, int S, int H, int W, int D, double idepth_min, double idepth_max, void* stream) {
+    return sweep_launch(1, ref, src, hmkt, x, ws, ws_floats, B, S, H, W, D, idepth_min, idepth_max, stream, -1, ref_bstride, src_bstride);
+}
+extern "C" int cnm_planesweep_cat_strided_c8_f16(const float* ref, long long ref_bstride, const float* src, long long src_bstride, const float* hmkt, void* x,
+                                                 float* ws, size_t ws_floats, int B, int S, int H, int W, int D, double idepth_min, double idepth_max, void* stream) {
+    return sweep_launch(2, ref, src, hmkt, static_cast<float*>(x), ws, ws_floats, B, S, H, W, D, idepth_min, idepth_max, stream, -1, ref_bstride, src_bstride);
 }

@@ -208,6 +208,21 @@ def _up_train(x, seq, groups=1):
     return ag.conv_bn_relu(ag.Upsample2xC4.apply(x), seq[1], seq[2], 0, groups)
 
 
+FRAME_VIEWS = os.environ.get("CNM_FRAME_VIEWS", "1") != "0"   # 0: copy sliced inputs as before (A/B)
+
+
+def _frame_view(t):
+    """(tensor, floats between consecutive frames): `t` itself when every frame t[b] is dense and the frames are at least a frame apart
+    (a slice of a larger frame tensor), else a contiguous copy."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    inner = t[0].numel()
+    if FRAME_VIEWS and t[0].is_contiguous() and (t.shape[0] == 1 or t.stride(0) >= inner):
+        return t, (t.stride(0) if t.shape[0] > 1 else inner)
+    t = t.contiguous()
+    return t, inner
+
+
 class depthNet(_EngineNet):
     """Plane-sweep cost volume + hourglass regression (reference depthNet_model.py:124-263).
 
@@ -264,7 +279,10 @@ class depthNet(_EngineNet):
             return [torch.cat([p[0][k] for p in parts], 0) for k in range(4)], torch.cat([p[1] for p in parts], 0)
         self._ensure_packed()
         lib, P, dev = _lib.load(), B * S, ref.device
-        ref, src, ref_cam, src_cam = (t.contiguous() for t in (ref, src, ref_cam, src_cam))
+        # [r6] the four inputs are usually SLICES of the caller's frame tensors (images[:, 0], images[:, 1:], the reference's own eval.py:440-447):
+        # dense inside a frame, a larger stride from frame to frame.  The engine reads them where they lie (cnm_depthnet_forward_strided_*);
+        # anything else is made contiguous first (four copy launches per call: 1 % of an fp16 step).
+        ref, rs = _frame_view(ref); src, ss = _frame_view(src); ref_cam, rcs = _frame_view(ref_cam); src_cam, scs = _frame_view(src_cam)
         disp = [torch.empty(P, 1, H >> i, W >> i, device=dev, dtype=torch.float32) for i in range(4)]
         f16 = self.precision == "f16"
         feat = (torch.empty(P, 8, H, W, 8, device=dev, dtype=torch.float16) if f16
@@ -272,9 +290,9 @@ class depthNet(_EngineNet):
         n = (lib.cnm_depthnet_workspace_floats_f16 if f16 else lib.cnm_depthnet_workspace_floats)(P, H, W, self.planes)
         ws = self._workspace(dev, n)
         with torch.cuda.device(dev):
-            _lib.check((lib.cnm_depthnet_forward_f16 if f16 else lib.cnm_depthnet_forward_f32)(
+            _lib.check((lib.cnm_depthnet_forward_strided_f16 if f16 else lib.cnm_depthnet_forward_strided_f32)(
                 self._weights_arr, float(self.idepth_scale), self.planes,
-                ref.data_ptr(), src.data_ptr(), ref_cam.data_ptr(), src_cam.data_ptr(),
+                ref.data_ptr(), rs, src.data_ptr(), ss, ref_cam.data_ptr(), rcs, src_cam.data_ptr(), scs,
                 disp[0].data_ptr(), disp[1].data_ptr(), disp[2].data_ptr(), disp[3].data_ptr(), feat.data_ptr(),
                 ws.data_ptr(), ws.numel(), B, S, H, W, torch.cuda.current_stream().cuda_stream))
         return disp, feat

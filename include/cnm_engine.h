@@ -187,6 +187,15 @@ int cnm_planesweep_volume_nchw_f32(const float* ref, const float* src, const flo
 int cnm_planesweep_cat_c4_f32(const float* ref, const float* src, const float* hmkt, float* x,
                               float* ws, size_t ws_floats, int B, int S, int H, int W, int D,
                               double idepth_min, double idepth_max, void* stream);
+/* [r6] ... and with the images / cameras as VIEWS of the caller's frame tensors: *_bstride = floats between consecutive frames (0 = dense:
+ * 3 H W, S 3 H W, 32, 32 S).  ref = frames[:, 0] and src = frames[:, 1:] of frames [B][1 + S][3][H][W] (cams [B][1 + S][2][4][4] likewise) are read
+ * where they lie; the reference slices its batches the same way (eval.py:440-447) and every consumer makes a contiguous copy. */
+int cnm_homography_terms_strided_f32(const float* ref_cam, long long ref_cam_bstride, const float* src_cam, long long src_cam_bstride, float* hmkt,
+                                     int B, int S, void* stream);
+int cnm_planesweep_cat_strided_c4_f32(const float* ref, long long ref_bstride, const float* src, long long src_bstride, const float* hmkt, float* x,
+                                      float* ws, size_t ws_floats, int B, int S, int H, int W, int D, double idepth_min, double idepth_max, void* stream);
+int cnm_planesweep_cat_strided_c8_f16(const float* ref, long long ref_bstride, const float* src, long long src_bstride, const float* hmkt, void* x,
+                                      float* ws, size_t ws_floats, int B, int S, int H, int W, int D, double idepth_min, double idepth_max, void* stream);
 
 /* ---------------------------------------------------------------- conv stack (K2-K5)
  * Weight packing.  Folds eval-mode BatchNorm (depthNet_model.py:19-79, eps/affine per
@@ -570,6 +579,18 @@ int cnm_depthnet_forward_f16(const cnm_layer_weights* weights, float idepth_scal
                              const float* ref, const float* src, const float* ref_cam, const float* src_cam,
                              float* disp1, float* disp2, float* disp3, float* disp4, void* iconv1_c8,
                              float* ws, size_t ws_floats, int B, int S, int H, int W, void* stream);
+/* [r6] depthNet forwards with the images and cameras as views of the caller's frame tensors (see cnm_planesweep_cat_strided_c4_f32): *_bstride =
+ * floats between consecutive frames, 0 = dense. */
+int cnm_depthnet_forward_strided_f32(const cnm_layer_weights* weights, float idepth_scale, int D,
+                                     const float* ref, long long ref_bstride, const float* src, long long src_bstride,
+                                     const float* ref_cam, long long ref_cam_bstride, const float* src_cam, long long src_cam_bstride,
+                                     float* disp1, float* disp2, float* disp3, float* disp4, float* iconv1_c4,
+                                     float* ws, size_t ws_floats, int B, int S, int H, int W, void* stream);
+int cnm_depthnet_forward_strided_f16(const cnm_layer_weights* weights, float idepth_scale, int D,
+                                     const float* ref, long long ref_bstride, const float* src, long long src_bstride,
+                                     const float* ref_cam, long long ref_cam_bstride, const float* src_cam, long long src_cam_bstride,
+                                     float* disp1, float* disp2, float* disp3, float* disp4, void* iconv1_c8,
+                                     float* ws, size_t ws_floats, int B, int S, int H, int W, void* stream);
 int cnm_refinenet_forward_multi_f16(const cnm_layer_weights* weights, float idepth_scale,
                                     const float* idepth_pairs, const void* iconv_pairs_c8, int S,
                                     float* disp_refined, float* prob_map, void* iconv1_depth_c8,

@@ -195,6 +195,34 @@ def test_f16_engine_other_sizes_vs_f32_engine(dev, B, S, H, W, D):
     assert bool(torch.isfinite(outs["f16"]["normal"]).all())
 
 
+@pytest.mark.parametrize("prec", ["f32", "f16"])
+def test_forward_pairs_reads_frame_slices_in_place(dev, prec):
+    """[r6] depthNet.forward_pairs on SLICES of the caller's frame tensors (images[:, 0], images[:, 1:], cams likewise -- the reference's own call
+    pattern, eval.py:440-447): the engine reads them where they lie (cnm_depthnet_forward_strided_*), bit-identical to contiguous copies; a
+    view whose frames are not dense (a channel slice) still goes through a copy."""
+    from cnmnet_amd.depthnet import depthNet
+    from cnmnet_amd.depthnet.depthNet_model import _frame_view
+    B, S, H, W = 3, 2, 64, 96
+    img, cams = syn.frames(B, S, H, W, seed=23)
+    img, cams = T(img).to(dev), T(cams).to(dev)
+    net = _load(depthNet(3.0, 32, precision=prec), 4).to(dev)
+    with torch.no_grad():
+        a = net.forward_pairs(img[:, 0], img[:, 1:], cams[:, 0], cams[:, 1:])                                   # strided views
+        b = net.forward_pairs(img[:, 0].contiguous(), img[:, 1:].contiguous(), cams[:, 0].contiguous(), cams[:, 1:].contiguous())
+    for x, y in zip(a[0], b[0]):
+        assert torch.equal(x, y)
+    assert torch.equal(a[1], b[1])
+    v, st = _frame_view(img[:, 0])
+    assert v.data_ptr() == img.data_ptr() and st == (1 + S) * 3 * H * W                                         # no copy was made
+    v, st = _frame_view(img[:, 1:])
+    assert v.data_ptr() == img[:, 1:].data_ptr() and st == (1 + S) * 3 * H * W
+    wide = torch.randn(B, 4, H, W, device=dev)
+    v, st = _frame_view(wide[:, :3])                                                                             # frames dense: stride 4 H W
+    assert v.data_ptr() == wide.data_ptr() and st == 4 * H * W
+    v, st = _frame_view(wide[:, :, :, ::2])                                                                      # not dense inside a frame: copied
+    assert v.is_contiguous() and st == 4 * H * (W // 2)
+
+
 def test_f16_fused_upsample_networks_agree(dev):
     """fp16 nets with every eligible up_conv layer fused (threshold lowered to 1 pixel) against the same nets with the fused
     path off: the two differ only by fp16 roundings (composed filters instead of an upsampled tensor), and the fused path
