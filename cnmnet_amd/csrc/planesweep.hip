@@ -144,7 +144,8 @@ extern "C" int cnm_idepth_range_host(double idepth_scale, double* idepth_min, do
 
 struct SweepArgs {
     const float* ref; const float* src; const float* hmkt; float* out;
-    long long ref_bstride, src_bstride;   // [r6] floats between consecutive frames of ref [B][3][H][W] / src [B][S][3][H][W] (dense: 3 H W, S 3 H W) -- views of a frame tensor [B][1 + S][3][H][W] need no copy
+    int frame_strides;              // [r6] images between consecutive frames of ref [B][3][H][W] (low 16 bits; dense: 1) and of src [B][S][3][H][W] (high 16 bits; dense: S) -- the views
+                                    // frames[:, 0] / frames[:, 1:] of one [B][1 + S][3][H][W] tensor (1 + S each) need no copy.  One packed word: two 64-bit strides cost the launch 0.5 us of argument re-loads
     unsigned int* queue;            // [0] tile tickets, [1] workgroups that have left; zero between launches
     int B, S, H, W, D;
     // launch constants worked out on the host (sweep_launch): 512 workgroups x 16 waves need not each derive them
@@ -683,10 +684,18 @@ __global__ __launch_bounds__(SWEEP_NT) __attribute__((amdgpu_waves_per_eu(SWEEP_
         // the reference pixel, negated (the blend's addend): needed at the first blend only, i.e. after the first staging
         float nr = 0.f, ng = 0.f, nb = 0.f;
         if (pvalid) {
-            const float* refp = a.ref + (size_t)(p / a.S) * (size_t)a.ref_bstride + (size_t)y * W + x;
+#ifdef SWEEP_DENSE   // A/B build: the dense addressing of rounds 1-5 (tools/k1_stride_ab.sh)
+            const float* refp = a.ref + (size_t)(p / a.S) * 3 * HW + (size_t)y * W + x;
+#else
+            const float* refp = a.ref + (size_t)((p / a.S) * (a.frame_strides & 0xFFFF)) * 3 * HW + (size_t)y * W + x;
+#endif
             nr = -refp[0]; ng = -refp[HW]; nb = -refp[2 * HW];
         }
-        const unsigned long long srcb = reinterpret_cast<unsigned long long>(a.src + (size_t)(p / a.S) * (size_t)a.src_bstride + (size_t)(p % a.S) * 3 * HW);
+#ifdef SWEEP_DENSE
+        const unsigned long long srcb = reinterpret_cast<unsigned long long>(a.src + (size_t)p * 3 * HW);
+#else
+        const unsigned long long srcb = reinterpret_cast<unsigned long long>(a.src + (size_t)((p / a.S) * (int)((unsigned)a.frame_strides >> 16) + p % a.S) * 3 * HW);
+#endif
         const unsigned src_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)srcb);
         const unsigned src_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(srcb >> 32));
 
@@ -1018,7 +1027,10 @@ static int sweep_launch(int layout, const float* ref, const float* src, const fl
                         float* ws, size_t ws_floats, int B, int S, int H, int W, int D,
                         double idepth_min, double idepth_max, void* stream, int force_policy = -1, long long ref_bstride = 0, long long src_bstride = 0) {
     CNM_REQUIRE(ref && src && hmkt && out, CNM_ERR_BAD_ARG);
-    CNM_REQUIRE((ref_bstride == 0 || ref_bstride >= 3ll * H * W) && (src_bstride == 0 || src_bstride >= 3ll * S * H * W), CNM_ERR_BAD_ARG);
+    // frame strides: whole images (multiples of 3 H W), at most 65535 images apart
+    const long long img = 3ll * H * W, rfs = ref_bstride ? ref_bstride / img : 1, sfs = src_bstride ? src_bstride / img : S;
+    CNM_REQUIRE(rfs * img == (ref_bstride ? ref_bstride : img) && sfs * img == (src_bstride ? src_bstride : (long long)S * img) && rfs >= 1 && rfs < 65536 && sfs >= S && sfs < 65536, CNM_ERR_BAD_ARG);
+    CNM_REQUIRE((long long)B * (rfs > sfs ? rfs : sfs) < (1ll << 24), CNM_ERR_BAD_ARG);
     CNM_REQUIRE(ws == nullptr || (((uintptr_t)ws & 15) == 0 && ws_floats >= 4), CNM_ERR_WORKSPACE);
     CNM_REQUIRE(B > 0 && S > 0 && H > 0 && W > 0 && D >= 2 && D <= CNM_MAX_PLANES, CNM_ERR_BAD_ARG);
     CNM_REQUIRE(layout == 0 || D % 4 == 0, CNM_ERR_BAD_ARG);
@@ -1029,7 +1041,7 @@ static int sweep_launch(int layout, const float* ref, const float* src, const fl
     CNM_REQUIRE(ntiles < (1ll << 20), CNM_ERR_BAD_ARG);                      // the kernel decodes tile ids with fp32 reciprocals
     SweepArgs a;
     a.ref = ref; a.src = src; a.hmkt = hmkt; a.out = out;
-    a.ref_bstride = ref_bstride ? ref_bstride : 3ll * H * W; a.src_bstride = src_bstride ? src_bstride : 3ll * S * H * W;
+    a.frame_strides = (int)(((unsigned)sfs << 16) | (unsigned)rfs);
     a.queue = reinterpret_cast<unsigned int*>(ws);
     a.B = B; a.S = S; a.H = H; a.W = W; a.D = D;
     const double idstep = (idepth_max - idepth_min) / (D - 1.0);             // depthNet_model.py:194
@@ -1140,7 +1152,7 @@ extern "C" int cnm_planesweep_cat_c8_f16(const float* ref, const float* src, con
     return sweep_launch(2, ref, src, hmkt, static_cast<float*>(x), ws, ws_floats, B, S, H, W, D, idepth_min, idepth_max, stream);
 }
 // [r6] the same two with the images as VIEWS: ref_bstride / src_bstride = floats between consecutive frames (0 = dense) -- ref = frames[:, 0] and
-// src = frames[:, 1:] of one [B][1 + S][3][H][W] tensor are read where they lie
+// src = frames[:, 1:] of one [B][1 + S][3][H][W] tensor are read where they lie.  The strides must be whole images (multiples of 3 H W), < 65536 images
 extern "C" int cnm_planesweep_cat_strided_c4_f32(const float* ref, long long ref_bstride, const float* src, long long src_bstride, const float* hmkt, float* x,
                                                  float* ws, size_t ws_floats, int B, int S, int H, int W, int D, double idepth_min, double idepth_max, void* stream) {
     return sweep_launch(1, ref, src, hmkt, x, ws, ws_floats, B, S, H, W, D, idepth_min, idepth_max, stream, -1, ref_bstride, src_bstride);

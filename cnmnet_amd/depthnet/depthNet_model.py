@@ -211,13 +211,13 @@ def _up_train(x, seq, groups=1):
 FRAME_VIEWS = os.environ.get("CNM_FRAME_VIEWS", "1") != "0"   # 0: copy sliced inputs as before (A/B)
 
 
-def _frame_view(t):
-    """(tensor, floats between consecutive frames): `t` itself when every frame t[b] is dense and the frames are at least a frame apart
-    (a slice of a larger frame tensor), else a contiguous copy."""
+def _frame_view(t, unit=1):
+    """(tensor, floats between consecutive frames): `t` itself when every frame t[b] is dense and the frames are at least a frame apart and a
+    multiple of `unit` floats apart (a slice of a larger frame tensor; the plane sweep wants whole images), else a contiguous copy."""
     if t.dtype != torch.float32:
         t = t.float()
     inner = t[0].numel()
-    if FRAME_VIEWS and t[0].is_contiguous() and (t.shape[0] == 1 or t.stride(0) >= inner):
+    if FRAME_VIEWS and t[0].is_contiguous() and (t.shape[0] == 1 or (t.stride(0) >= inner and t.stride(0) % unit == 0 and t.stride(0) // unit < 65536)):
         return t, (t.stride(0) if t.shape[0] > 1 else inner)
     t = t.contiguous()
     return t, inner
@@ -282,7 +282,7 @@ class depthNet(_EngineNet):
         # [r6] the four inputs are usually SLICES of the caller's frame tensors (images[:, 0], images[:, 1:], the reference's own eval.py:440-447):
         # dense inside a frame, a larger stride from frame to frame.  The engine reads them where they lie (cnm_depthnet_forward_strided_*);
         # anything else is made contiguous first (four copy launches per call: 1 % of an fp16 step).
-        ref, rs = _frame_view(ref); src, ss = _frame_view(src); ref_cam, rcs = _frame_view(ref_cam); src_cam, scs = _frame_view(src_cam)
+        ref, rs = _frame_view(ref, 3 * H * W); src, ss = _frame_view(src, 3 * H * W); ref_cam, rcs = _frame_view(ref_cam); src_cam, scs = _frame_view(src_cam)
         disp = [torch.empty(P, 1, H >> i, W >> i, device=dev, dtype=torch.float32) for i in range(4)]
         f16 = self.precision == "f16"
         feat = (torch.empty(P, 8, H, W, 8, device=dev, dtype=torch.float16) if f16

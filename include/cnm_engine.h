@@ -189,7 +189,8 @@ int cnm_planesweep_cat_c4_f32(const float* ref, const float* src, const float* h
                               double idepth_min, double idepth_max, void* stream);
 /* [r6] ... and with the images / cameras as VIEWS of the caller's frame tensors: *_bstride = floats between consecutive frames (0 = dense:
  * 3 H W, S 3 H W, 32, 32 S).  ref = frames[:, 0] and src = frames[:, 1:] of frames [B][1 + S][3][H][W] (cams [B][1 + S][2][4][4] likewise) are read
- * where they lie; the reference slices its batches the same way (eval.py:440-447) and every consumer makes a contiguous copy. */
+ * where they lie; the reference slices its batches the same way (eval.py:440-447) and every consumer makes a contiguous copy.  The image strides
+ * must be whole images (multiples of 3 H W, less than 65536 images; the sweep carries them as one packed word), the camera strides are free. */
 int cnm_homography_terms_strided_f32(const float* ref_cam, long long ref_cam_bstride, const float* src_cam, long long src_cam_bstride, float* hmkt,
                                      int B, int S, void* stream);
 int cnm_planesweep_cat_strided_c4_f32(const float* ref, long long ref_bstride, const float* src, long long src_bstride, const float* hmkt, float* x,

@@ -219,6 +219,8 @@ def test_forward_pairs_reads_frame_slices_in_place(dev, prec):
     wide = torch.randn(B, 4, H, W, device=dev)
     v, st = _frame_view(wide[:, :3])                                                                             # frames dense: stride 4 H W
     assert v.data_ptr() == wide.data_ptr() and st == 4 * H * W
+    v, st = _frame_view(wide[:, :3], 3 * H * W)                                                                  # ... but not whole images apart: copied for the sweep
+    assert v.is_contiguous() and st == 3 * H * W
     v, st = _frame_view(wide[:, :, :, ::2])                                                                      # not dense inside a frame: copied
     assert v.is_contiguous() and st == 4 * H * (W // 2)
 
