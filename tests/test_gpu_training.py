@@ -111,6 +111,44 @@ def test_wgrad_stream_k_equals_split_form(dev, cin, cout, k, stride, N, H, W):
     assert _rel(a.cpu().numpy(), c.cpu().numpy()) < 5e-5                 # two fp32 summation orders of the same products (the reference bar of test_conv_forward_dgrad_wgrad)
 
 
+def test_wgrad_stream_k_handoff_timeout_is_loud(dev):
+    """[r6] A stream-K weight-gradient launch whose hand-offs do not complete (fault injection as in test_gpu_parity.py::
+    test_stream_k_handoff_timeout_is_loud: every wait gives up at once) returns, reports CNM_ERR_LAUNCH through cnm_engine_status, makes the
+    next weight-gradient call refuse until the failure is acknowledged -- and then gives the bit-identical right gradient again."""
+    from cnmnet_amd import _lib, ops
+    lib = _lib.load()
+    rng = np.random.default_rng(91)
+    cin, cout, N, H, W = 256, 512, 8, 48, 64                              # 288 tiles of 96 steps on 768 ranges: most tiles are cut
+    x = ops.nchw_to_c4(T(rng.standard_normal((N, cin, H, W)).astype(np.float32)).to(dev))
+    dy = ops.nchw_to_c4(T(rng.standard_normal((N, cout, H, W)).astype(np.float32)).to(dev))
+    ws = torch.empty(lib.cnm_conv3x3_wgrad_winograd_workspace_floats(cout, cin, N, H, W), device=dev, dtype=torch.float32)
+    st = lambda: torch.cuda.current_stream().cuda_stream
+    def run():
+        dw = torch.empty(cout, cin, 3, 3, device=dev)
+        _lib.check(lib.cnm_conv3x3_wgrad_winograd_c4_f32(x.data_ptr(), cin // 4, 0, cin, dy.data_ptr(), cout // 4, 0, cout, dw.data_ptr(), ws.data_ptr(), ws.numel(), N, H, W, 0, st()))
+        torch.cuda.synchronize()
+        return dw
+    old_sk, old_share = lib.cnm_tune_wgrad_streamk(1), lib.cnm_tune_wgrad_streamk_share(0)
+    try:
+        good = run()
+        assert lib.cnm_engine_status(0) == 0
+        old = lib.cnm_tune_sync_spin_limit(0x80000000 | 500)
+        try:
+            run()                                                        # hand-offs time out: a wrong gradient, but the call returns
+            assert lib.cnm_engine_status(0) == -4                        # CNM_ERR_LAUNCH, sticky
+            with pytest.raises(_lib.EngineError):
+                run()                                                    # refused, nothing launched
+            with pytest.raises(_lib.EngineError):
+                ops.engine_status(clear=True)                            # reports and acknowledges
+            assert lib.cnm_engine_status(0) == 0
+        finally:
+            lib.cnm_tune_sync_spin_limit(old)
+            lib.cnm_engine_status(1)
+        assert torch.equal(run(), good)                                  # the same workspace, unrepaired
+    finally:
+        lib.cnm_tune_wgrad_streamk(old_sk); lib.cnm_tune_wgrad_streamk_share(old_share)
+
+
 @pytest.mark.parametrize("cin,cout,k,N,Ho,Wo", [(64, 128, 3, 2, 24, 32), (128, 64, 5, 1, 48, 64), (64, 64, 3, 3, 9, 14), (256, 128, 5, 2, 6, 8),
                                                  (128, 128, 7, 2, 48, 64), (64, 32, 7, 1, 10, 31)])
 def test_stride2_dgrad_phase_scatter(dev, cin, cout, k, N, Ho, Wo):
