@@ -90,3 +90,31 @@ def test_product_modules_share_reference_state_dict_and_cpu_behaviour():
         Depth2normal(9)(torch.ones(1, 8, 8, dtype=torch.float64), torch.eye(3, dtype=torch.float64)[None])
     n, p = Depth2normal(9)(torch.ones(1, 8, 8), torch.eye(3)[None])
     assert n.shape == (1, 3, 8, 8) and p.shape == (1, 3, 8, 8)
+
+
+def test_frame_view_recognises_frame_slices():
+    """[r6] depthNet_model._frame_view (host logic, no GPU): slices of a frame tensor whose frames are dense and whole images apart are
+    handed to the engine as (pointer, frame stride); anything else is copied."""
+    import torch
+    from cnmnet_amd.depthnet.depthNet_model import _frame_view
+    B, S, H, W = 3, 2, 8, 12
+    frames = torch.randn(B, 1 + S, 3, H, W)
+    v, st = _frame_view(frames[:, 0], 3 * H * W)
+    assert v.data_ptr() == frames.data_ptr() and st == (1 + S) * 3 * H * W
+    v, st = _frame_view(frames[:, 1:], 3 * H * W)
+    assert v.data_ptr() == frames[:, 1:].data_ptr() and st == (1 + S) * 3 * H * W
+    v, st = _frame_view(frames[:1, 0], 3 * H * W)                         # one frame: any stride will do, the dense one is reported
+    assert v.data_ptr() == frames.data_ptr() and st == 3 * H * W
+    cams = torch.randn(B, 1 + S, 2, 4, 4)
+    v, st = _frame_view(cams[:, 1:])
+    assert v.data_ptr() == cams[:, 1:].data_ptr() and st == (1 + S) * 32
+    wide = torch.randn(B, 4, H, W)
+    v, st = _frame_view(wide[:, :3], 3 * H * W)                          # dense frames, but not whole images apart: copied
+    assert v.is_contiguous() and v.data_ptr() != wide.data_ptr() and st == 3 * H * W and torch.equal(v, wide[:, :3])
+    v, st = _frame_view(frames[:, 0, :, :, ::2], 3 * H * (W // 2))       # not dense inside a frame: copied
+    assert v.is_contiguous() and st == 3 * H * (W // 2)
+    v, st = _frame_view(frames.flip(0)[:, 0], 3 * H * W)                 # (flip materialises a copy; its slice is an ordinary view again)
+    assert st == (1 + S) * 3 * H * W
+    d = torch.randn(B, 3, H, W, dtype=torch.float64)
+    v, st = _frame_view(d, 3 * H * W)                                    # other dtypes are converted
+    assert v.dtype == torch.float32 and st == 3 * H * W

@@ -1397,3 +1397,32 @@ def test_inverse_warp_padding_modes(dev, golden, mode):
         assert float(np.quantile(err, 0.999)) < 1e-4 and float(err.max()) < 2e-3, (mode, float(np.quantile(err, 0.999)), float(err.max()))
     with pytest.raises(ValueError):
         inverse_warp(feat.to(dev), depth.to(dev), far.to(dev), K.to(dev), K_inv.to(dev), padding_mode="circular")
+
+
+@pytest.mark.gpu
+def test_strided_sweep_entry_points_check_their_strides(dev):
+    """[r6] cnm_planesweep_cat_strided_c4_f32 / cnm_homography_terms_strided_f32: frame strides that are not whole images, smaller than a frame or too
+    large are refused (CNM_ERR_BAD_ARG, nothing launched); 0 means dense and equals the dense entry point bit for bit."""
+    from cnmnet_amd import _lib, ops
+    lib = _lib.load()
+    B, S, H, W, D = 2, 2, 32, 64, 8
+    img, cams = syn.frames(B, S, H, W, seed=3)
+    img, cams = T(img).to(dev), T(cams).to(dev)
+    ref, src = img[:, 0].contiguous(), img[:, 1:].contiguous()
+    hm = torch.empty(B * S, 12, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.cnm_homography_terms_strided_f32(cams.data_ptr(), (1 + S) * 32, cams[:, 1:].data_ptr(), (1 + S) * 32, hm.data_ptr(), B, S, st) == 0
+    hm2 = ops.homography_terms(cams[:, 0].contiguous(), cams[:, 1:].contiguous())
+    assert torch.equal(hm, hm2.view_as(hm))
+    assert lib.cnm_homography_terms_strided_f32(cams.data_ptr(), 16, cams.data_ptr(), 0, hm.data_ptr(), B, S, st) == -1          # frames overlap
+    G = D // 4 + 1
+    out = torch.empty(B * S, G, H, W, 4, device=dev); out2 = torch.empty_like(out)
+    ws = torch.zeros(64, device=dev)
+    call = lambda o, rs, ss, r=ref, s_=src: lib.cnm_planesweep_cat_strided_c4_f32(r.data_ptr(), rs, s_.data_ptr(), ss, hm.data_ptr(), o.data_ptr(), ws.data_ptr(), ws.numel(), B, S, H, W, D, 0.1, 3.0, st)
+    assert call(out, 0, 0) == 0
+    assert call(out2, (1 + S) * 3 * H * W, (1 + S) * 3 * H * W, img, img[:, 1:]) == 0                                           # the same images as views of the frame tensor
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)
+    assert call(out2, 3 * H * W + 4, 0) == -1                                                                                    # not whole images
+    assert call(out2, 0, 3 * H * W) == -1                                                                                        # source frames overlap (S = 2)
+    assert call(out2, 70000 * 3 * H * W, 0) == -1                                                                                # beyond the packed 16 bits
