@@ -48,10 +48,11 @@ template <int TCO> struct WgradTile {
 #define WGRAD_ABL 0      // timing experiments (wrong results; tools/wgrad_ablate.sh): 1 no global loads, 2 no LDS stores, 4 no barriers, 8 no fragment reads
 #endif
 #define WGRAD_SYNC() do { if constexpr ((WGRAD_ABL & 4) == 0) __syncthreads(); } while (0)
-template <int TCO, bool LINEAR>
+template <int TCO, int MODE>
 __device__ __forceinline__ void wgrad_tile_segment(const WgradArgs& a, float* smem, int c0, int k0, int zimg, int r0, int r1,
                                                    f32x16 (&acc)[2][WgradTile<TCO>::PJ]) {
     constexpr int LDK = WgradTile<TCO>::LDK, WK = WgradTile<TCO>::WK, PJ = WgradTile<TCO>::PJ;
+    constexpr bool LINEAR = MODE == 1, ROWSTEP = MODE == 2;
     float* As = smem;                 // [2][TCO co][LDK pix]
     float* Bs = smem + 2 * TCO * LDK; // [2][128 k ][LDK pix]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wc = wave / WK, wp = wave % WK;
@@ -90,6 +91,23 @@ __device__ __forceinline__ void wgrad_tile_segment(const WgradArgs& a, float* sm
             lvb[i] = bok[i] ? ((unsigned)((zimg * a.Gx_tot + a.gx0 + bgc[i]) * HW + r0 + pl)) * 16u : 0xFFFFFFFFu;
         }
     }
+    // ROWSTEP [r6]: Wo a multiple of 16 -- the 16 pixels of a step lie in ONE output row, so the walk (image, row, column of the step's first pixel)
+    // is scalar; a thread adds its own constants: the dY address needs no vector ALU at all, an X address one add per load and two compares for
+    // the tap's row / column range (the general walk below: ~ 47 VALU instructions per step and wave)
+    int rs_img = 0, rs_oy = 0, rs_ox = 0;                                 // of pixel r0 + 16 * (steps loaded so far)
+    unsigned rva[2] = {0, 0}; int rvb[2] = {0, 0}, riy[2] = {0, 0}, rix[2] = {0, 0};
+    if constexpr (ROWSTEP) {
+        rs_img = __builtin_amdgcn_readfirstlane(r0 / HoWo);
+        const int rem0 = r0 - rs_img * HoWo;
+        rs_oy = __builtin_amdgcn_readfirstlane(rem0 / a.Wo); rs_ox = __builtin_amdgcn_readfirstlane(rem0 - rs_oy * a.Wo);
+        rs_img += zimg * a.ipp;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            rva[i] = aok[i] ? ((unsigned)((a.gy0 + aq[i]) * HoWo + pl)) * 16u : 0xFFFFFFFFu;   // + scalar (img Gy_tot HoWo + oy Wo + ox) * 16
+            riy[i] = bky[i] - a.pad; rix[i] = pl * a.stride + bkx[i] - a.padx;                  // + scalar oy * stride / ox * stride
+            rvb[i] = ((a.gx0 + bgc[i]) * HW + riy[i] * a.W + rix[i]) * 16;                      // + scalar (img Gx_tot HW + oy stride W + ox stride) * 16; may be negative: added in the VALU
+        }
+    }
     const auto rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, a.dy_bytes, 0x00020000);
     const auto rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
     auto load = [&](float4 (&qa)[2], float4 (&qb)[2]) {
@@ -104,6 +122,24 @@ __device__ __forceinline__ void wgrad_tile_segment(const WgradArgs& a, float* sm
                 qa[i] = make_float4(__uint_as_float(va.x), __uint_as_float(va.y), __uint_as_float(va.z), __uint_as_float(va.w));
                 qb[i] = make_float4(__uint_as_float(vb.x), __uint_as_float(vb.y), __uint_as_float(vb.z), __uint_as_float(vb.w));
             }
+            return;
+        }
+        if constexpr (ROWSTEP) {
+            const int m0 = r0 + 16 * lin_step; ++lin_step;
+            const bool mok = m0 + pl < r1;
+            const unsigned sa = (unsigned)(((rs_img * a.Gy_tot) * HoWo + rs_oy * a.Wo + rs_ox) * 16);
+            const unsigned sb = (unsigned)((rs_img * a.Gx_tot) * HW + rs_oy * a.stride * a.W + rs_ox * a.stride) * 16u;
+            const int sy = rs_oy * a.stride, sx = rs_ox * a.stride;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const u32x4 va = __builtin_amdgcn_raw_buffer_load_b128(rsa, mok ? rva[i] : 0xFFFFFFFFu, sa, 0);
+                const bool ok = mok && bok[i] && (unsigned)(riy[i] + sy) < (unsigned)a.H && (unsigned)(rix[i] + sx) < (unsigned)a.W;
+                const u32x4 vb = __builtin_amdgcn_raw_buffer_load_b128(rsb, ok ? (unsigned)rvb[i] + sb : 0xFFFFFFFFu, 0, 0);
+                qa[i] = make_float4(__uint_as_float(va.x), __uint_as_float(va.y), __uint_as_float(va.z), __uint_as_float(va.w));
+                qb[i] = make_float4(__uint_as_float(vb.x), __uint_as_float(vb.y), __uint_as_float(vb.z), __uint_as_float(vb.w));
+            }
+            rs_ox += 16;                                                 // scalar walk: Wo % 16 == 0, a step never straddles a row
+            if (rs_ox >= a.Wo) { rs_ox = 0; if (++rs_oy >= a.Ho) { rs_oy = 0; ++rs_img; } }
             return;
         }
         const bool mok = m < r1;
@@ -206,7 +242,7 @@ __device__ __forceinline__ void wgrad_tile_store(const WgradArgs& a, float* P, i
 
 // Split form: grid.z = pixel ranges (x problems); every workgroup writes its partial tile, a second kernel sums the splits.  Kept for A/B
 // (cnm_tune_wgrad_streamk(0)) and for devices whose sync workspace cannot be had.
-template <int TCO, bool LINEAR>
+template <int TCO, int MODE>
 __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const WgradArgs a) {
     constexpr int PJ = WgradTile<TCO>::PJ;
     __shared__ __attribute__((aligned(16))) float smem[WgradTile<TCO>::SMEM_FLOATS];
@@ -221,7 +257,7 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const WgradArgs a) {
         for (int j = 0; j < PJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    wgrad_tile_segment<TCO, LINEAR>(a, smem, c0, k0, zimg, r0, r1, acc);
+    wgrad_tile_segment<TCO, MODE>(a, smem, c0, k0, zimg, r0, r1, acc);
     // partial[split][co][k]
     wgrad_tile_store<TCO>(a, a.partial + (size_t)blockIdx.z * a.Cout_pad * a.Kpad128, c0, k0, acc);
 }
@@ -236,7 +272,7 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const WgradArgs a) {
 // at the start of their walk, long ago -- adds their slots in descending workgroup order and stores the tile.  Waits point at lower workgroup
 // numbers only (dispatched earlier), so progress does not depend on all G workgroups being resident; the summation order is a function of
 // (shape, G) alone: bit-reproducible on a device.  A time-out is reported as for the convolution kernels (cnm_engine_status).
-template <int TCO, bool LINEAR>
+template <int TCO, int MODE>
 __global__ __launch_bounds__(256, 3) void conv_wgrad_sk_kernel(const WgradArgs a, int tilesC, int tilesK, int S, unsigned* __restrict__ flags, float* __restrict__ slots) {
     constexpr int PJ = WgradTile<TCO>::PJ, SLOT_FLOATS = TCO * 128;
     __shared__ __attribute__((aligned(16))) float smem[WgradTile<TCO>::SMEM_FLOATS];
@@ -258,7 +294,7 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_sk_kernel(const WgradArgs a
             for (int j = 0; j < PJ; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        wgrad_tile_segment<TCO, LINEAR>(a, smem, c0, k0, z, s0 * 16, min(s1 * 16, a.M), acc);
+        wgrad_tile_segment<TCO, MODE>(a, smem, c0, k0, z, s0 * 16, min(s1 * 16, a.M), acc);
         if (s1 < S) {
             // ---- publish: [workgroup][(i, j, quad)][thread] float4 -- every lane of the finisher re-reads exactly what its twin wrote
 #pragma unroll
@@ -360,10 +396,17 @@ static inline size_t wgrad_sk_sync_floats() { return kSyncFlagBytes / 4 + (size_
 // workspace's sync area; its flag words must be zero (zero_flags: a memset node here -- the Winograd paths let their transform kernel do it).
 // the Winograd-domain GEMMs: 1 x 1 taps over one row of T tiles per problem -- the loader's addresses are linear in the step
 static inline bool wgrad_linear(const WgradArgs& a) { return a.ks == 1 && a.ksx == 1 && a.H == 1 && a.Ho == 1 && a.W == a.Wo && a.ipp == 1 && a.stride == 1 && a.pad == 0 && a.padx == 0 && g_wgrad_linear; }
+// loader of a launch: 1 = linear (above); 2 = row steps (Wo a multiple of 16 and the split boundaries on steps: the walk is scalar); 0 = the general walk
+static inline int wgrad_loader_mode(const WgradArgs& a) {
+    if (wgrad_linear(a)) return 1;
+    return (g_wgrad_linear && a.Wo % 16 == 0 && a.pix_per_split % 16 == 0) ? 2 : 0;
+}
 static void wgrad_split_launch(const WgradArgs& a, int tco, dim3 grid, hipStream_t s) {
-    const bool lin = wgrad_linear(a);
-    if (tco == 128) { if (lin) conv_wgrad_kernel<128, true><<<grid, 256, 0, s>>>(a); else conv_wgrad_kernel<128, false><<<grid, 256, 0, s>>>(a); }
-    else { if (lin) conv_wgrad_kernel<64, true><<<grid, 256, 0, s>>>(a); else conv_wgrad_kernel<64, false><<<grid, 256, 0, s>>>(a); }
+    const int mode = wgrad_loader_mode(a);
+#define WGRAD_SPLIT(T_, M_) conv_wgrad_kernel<T_, M_><<<grid, 256, 0, s>>>(a)
+    if (tco == 128) { if (mode == 1) WGRAD_SPLIT(128, 1); else if (mode == 2) WGRAD_SPLIT(128, 2); else WGRAD_SPLIT(128, 0); }
+    else { if (mode == 1) WGRAD_SPLIT(64, 1); else if (mode == 2) WGRAD_SPLIT(64, 2); else WGRAD_SPLIT(64, 0); }
+#undef WGRAD_SPLIT
 }
 static int wgrad_sk_launch(WgradArgs a, int NP, float* sync, bool zero_flags, hipStream_t s) {
     const int tco = wgrad_tco(a.Cout), tilesC = a.Cout_pad / tco, tilesK = a.Kpad128 / 128, S = (a.M + 15) / 16;
@@ -376,9 +419,11 @@ static int wgrad_sk_launch(WgradArgs a, int NP, float* sync, bool zero_flags, hi
     unsigned* flags = reinterpret_cast<unsigned*>(sync);
     float* slots = sync + kSyncFlagBytes / 4;
     if (zero_flags && hipMemsetAsync(flags, 0, kSyncFlagBytes, s) != hipSuccess) { (void)hipGetLastError(); return CNM_ERR_LAUNCH; }
-    const bool lin = wgrad_linear(a);
-    if (tco == 128) { if (lin) conv_wgrad_sk_kernel<128, true><<<(unsigned)G, 256, 0, s>>>(a, tilesC, tilesK, S, flags, slots); else conv_wgrad_sk_kernel<128, false><<<(unsigned)G, 256, 0, s>>>(a, tilesC, tilesK, S, flags, slots); }
-    else { if (lin) conv_wgrad_sk_kernel<64, true><<<(unsigned)G, 256, 0, s>>>(a, tilesC, tilesK, S, flags, slots); else conv_wgrad_sk_kernel<64, false><<<(unsigned)G, 256, 0, s>>>(a, tilesC, tilesK, S, flags, slots); }
+    const int mode = wgrad_loader_mode(a);
+#define WGRAD_SK(T_, M_) conv_wgrad_sk_kernel<T_, M_><<<(unsigned)G, 256, 0, s>>>(a, tilesC, tilesK, S, flags, slots)
+    if (tco == 128) { if (mode == 1) WGRAD_SK(128, 1); else if (mode == 2) WGRAD_SK(128, 2); else WGRAD_SK(128, 0); }
+    else { if (mode == 1) WGRAD_SK(64, 1); else if (mode == 2) WGRAD_SK(64, 2); else WGRAD_SK(64, 0); }
+#undef WGRAD_SK
     return CNM_OK;
 }
 static void wgrad_plan(int Cout, int Cin, int ksize, int M, int* Cout_pad, int* Kpad128, int* splits, int* pps) {

@@ -627,7 +627,8 @@ int cnm_tune_wgrad_streamk(int n);
  *   into 768 ranges would end on 10-20 serial round trips; such launches keep the split form.  Returns the previous value. */
 int cnm_tune_wgrad_streamk_share(int n);
 /* wgrad_linear [r6]: 1 (default) = the Winograd-domain GEMMs (1 x 1 taps over one row of tiles per frequency point) load their operands at a
- *   per-thread constant offset plus a scalar step offset -- no vector ALU in the loop; 0 = the general coordinate walk (A/B).  Bit-identical results.
+ *   per-thread constant offset plus a scalar step offset -- no vector ALU in the loop -- and every other launch whose output width is a multiple of 16
+ *   walks in row steps (scalar image / row / column, per-thread constants); 0 = the general coordinate walk everywhere (A/B).  Bit-identical results.
  *   Returns the previous value. */
 int cnm_tune_wgrad_linear(int n);
 /* The same gradient for a 3x3 stride-1 pad-1 convolution in the Winograd domain of the forward's F(4x4,3x3):

@@ -96,7 +96,7 @@ def test_wgrad_stream_k_equals_split_form(dev, cin, cout, k, stride, N, H, W):
     old, old_share = lib.cnm_tune_wgrad_streamk(1), lib.cnm_tune_wgrad_streamk_share(0)   # share 0: every launch takes the stream-K form, however many ranges share a tile
     try:
         a = grad(); b = grad()
-        old_lin = lib.cnm_tune_wgrad_linear(0)                           # the general coordinate walk instead of the scalar-offset loader: the same loads
+        old_lin = lib.cnm_tune_wgrad_linear(0)                           # the general coordinate walk instead of the scalar-offset / row-step loaders: the same loads
         try:
             d = grad()
         finally:
