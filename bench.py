@@ -817,7 +817,7 @@ def secondary(dev, precision, B, S, Hh, Ww, D, steps=10, warmup=3):
             "workload": "%d frames, 1 ref + %d src, %dx%d, %d planes" % (B, S, Ww, Hh, D)}
 
 
-def train_secondary(dev, B=4, steps=10):
+def train_secondary(dev, B=4, steps=20):
     """BASELINE configs[2] per-GPU shard: one `train` optimisation step (train.py:164-310: forward of both nets, Depth2normal
     k = 9 normal losses, warped-depth losses, backward, Adam) on B samples of 192x256 with 64 planes, replayed as a HIP
     graph; samples/s between synchronisations."""
@@ -826,8 +826,8 @@ def train_secondary(dev, B=4, steps=10):
     step = TrainStep(*training_nets(dev), k_size=KSIZE, graph=True)
     s = {k: v.to(dev) for k, v in synthetic_training_sample(B, H, W, seed=7).items()}
     a = (s["rgbs"], s["cameras"], s["disparities"], s["depths"], s["normals"])
-    for _ in range(3):                                   # the first call captures (its warm-up iterations are undone)
-        log = step(*a)
+    for _ in range(8):                                   # the first call captures (its warm-up iterations are undone); the replays after it settle the clocks
+        log = step(*a)                                   # (with three warm-up calls and ten timed steps one full run in five read 30.4 instead of 28.4 ms)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
